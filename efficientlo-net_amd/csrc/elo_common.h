@@ -1,0 +1,63 @@
+// elo_common.h -- shared device/host helpers for libelo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+
+#include "../../include/elo.h"
+
+#define ELO_WAVE 64            // CDNA4 wavefront (hard-coded on purpose)
+#define ELO_BLOCK 256          // 4 waves, one per SIMD
+#define ELO_MAX_WINDOW 5000    // tf_ops/2d_conv_*_k/fused_conv_g.cu:42-43
+
+namespace elo {
+
+// ---- host: thread-local error text -------------------------------------
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+int check_launch(const char *what);
+
+// ---- device: arithmetic contract -----------------------------------------
+// Squared norms are ((x*x + y*y) + z*z) in fp32 with no fused multiply-add, so
+// that the GPU result equals the CPU oracle bit for bit (DESIGN.md "numerics").
+__device__ __forceinline__ float sq3(float x, float y, float z)
+{
+    return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+}
+// the reference's max(a,b) with a NaN first operand returns b
+__device__ __forceinline__ float pick_max(float a, float b) { return a > b ? a : b; }
+
+// ---- device: XCD-aware tile order ------------------------------------------
+// The dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md, workgroup
+// dispatch).  Give each XCD one contiguous run of tiles so that neighbouring
+// centres, which read overlapping windows, share that XCD's L2.  Pure speed
+// choice: any placement gives the same result.
+__device__ __forceinline__ unsigned xcd_tile(unsigned bid, unsigned nblocks)
+{
+    const unsigned q = nblocks >> 3, r = nblocks & 7u;
+    const unsigned xcd = bid & 7u, k = bid >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + k;
+}
+
+// ---- device: sub-wave ballots ----------------------------------------------
+// G lanes (16/32/64) cooperate on one centre; a wave holds 64/G groups.
+template <int G>
+__device__ __forceinline__ unsigned long long group_ballot(bool p, int group_shift)
+{
+    unsigned long long m = __ballot(p);
+    if (G == 64) return m;
+    return (m >> group_shift) & ((1ull << (G & 63)) - 1ull);
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        unsigned long long t = __shfl_xor(v, o, ELO_WAVE);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+}  // namespace elo

@@ -1,0 +1,158 @@
+"""GPU parity of the two grouping ops: HIP kernels (through the C ABI) against the
+committed golden vectors (reference outputs), against the CPU oracle on seeded
+sweeps, and against the reference digests at full 64x1800 / 128x2048 size.
+Bar: bit-exact on all four outputs (integer indices and 0/1 masks)."""
+import hashlib
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, expand_prefix, load_pkg
+from oracle import grouping as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip(op, xyz1, xyz2, idx, perm, kH, kW, K, fc, dist, sh, sw, want_valid=True):
+    elo = load_pkg()
+    fn = elo.fused_conv_random_k if op == "random" else elo.fused_conv_select_k
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    B, H, W, _ = xyz1.shape
+    out = fn(t(xyz1), t(xyz2), t(idx), t(perm), H, W, idx.shape[1], kH, kW, K, flag_copy=fc,
+             distance=dist, stride_h=sh, stride_w=sw, want_valid=want_valid)
+    torch.cuda.synchronize()
+    return [o.cpu().numpy() if o is not None else None for o in out]
+
+
+def test_golden_cases_bit_exact(golden_cases):
+    meta, blobs = golden_cases
+    for c in meta:
+        k = c["name"]
+        kH, kW = c["window"]
+        sel, valid, indis, mask = _hip(c["op"], blobs[k + "/xyz1"], blobs[k + "/xyz2"], blobs[k + "/idx_n2"],
+                                       blobs[k + "/random_hw"], kH, kW, c["K"], c["flag_copy"], c["distance"],
+                                       c["stride"][0], c["stride"][1])
+        assert sel.dtype == np.int32 and mask.dtype == np.float32
+        assert np.array_equal(sel, blobs[k + "/sel"]), k
+        assert np.array_equal(mask, blobs[k + "/mask"]), k
+        assert np.array_equal(valid, expand_prefix(blobs[k + "/n_valid"], kH * kW)), k
+        assert np.array_equal(indis, expand_prefix(blobs[k + "/n_indis"], kH * kW)), k
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_sweep_against_oracle(seed):
+    rng = np.random.default_rng(100 + seed)
+    B = int(rng.integers(1, 4))
+    H, W = int(rng.integers(1, 20)), int(rng.integers(6, 80))
+    sh, sw = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    H2, W2 = math.ceil(H / sh), math.ceil(W / sw)
+    kH = int(rng.integers(1, 12))
+    kW = int(rng.integers(1, min(2 * W2, 30)))
+    K = int(rng.integers(1, 40))
+    lattice = seed % 2 == 0
+
+    def cloud(h, w):
+        x = rng.normal(0, 2.0, (B, h, w, 3))
+        if lattice:
+            x = np.round(x)
+        x[rng.random((B, h, w)) < 0.15] = 0
+        return x.astype(np.float32)
+    xyz1, xyz2 = cloud(H, W), cloud(H2, W2)
+    N = int(rng.integers(1, 300))
+    idx = np.stack([rng.integers(0, H, (B, N)), rng.integers(0, W, (B, N))], -1).astype(np.int32)
+    perm = rng.permutation(kH * kW).astype(np.int32)
+    dist = float(rng.choice([0.5, 2.0, 5.0, 1000.0]))
+    fc = int(rng.integers(0, 2))
+    for op, fn in (("random", G.fused_conv_random_k), ("select", G.fused_conv_select_k)):
+        want = fn(xyz1, xyz2, idx, perm, H, W, N, kH, kW, K, fc, dist, sh, sw)
+        got = _hip(op, xyz1, xyz2, idx, perm, kH, kW, K, fc, dist, sh, sw)
+        for g, w_ in zip(got, want):
+            assert np.array_equal(g, w_), (op, seed)
+
+
+def test_edge_cases():
+    # all-empty clouds, one centre, K larger than the window, widest legal window
+    z = np.zeros((2, 3, 9, 3), np.float32)
+    idx = np.zeros((2, 1, 2), np.int32)
+    for op in ("random", "select"):
+        sel, valid, indis, mask = _hip(op, z, z, idx, np.arange(15, dtype=np.int32), 3, 5, 4, 1, 1.0, 1, 1)
+        assert not sel.any() and not mask.any() and not valid.any() and not indis.any()
+    rng = np.random.default_rng(5)
+    x = rng.normal(0, 1, (1, 2, 5, 3)).astype(np.float32)
+    idx = np.array([[[1, 4], [0, 0]]], np.int32)
+    perm = rng.permutation(2 * 11).astype(np.int32)       # kW/2 = 5 == W2: every column wraps
+    for op, fn in (("random", G.fused_conv_random_k), ("select", G.fused_conv_select_k)):
+        for fc in (0, 1):
+            want = fn(x, x, idx, perm, 2, 5, 2, 2, 11, 40, fc, 100.0, 1, 1)
+            got = _hip(op, x, x, idx, perm, 2, 11, 40, fc, 100.0, 1, 1)
+            for g, w_ in zip(got, want):
+                assert np.array_equal(g, w_)
+        got = _hip(op, x, x, idx, perm, 2, 11, 40, 0, 100.0, 1, 1, want_valid=False)
+        assert got[1] is None and got[2] is None and np.array_equal(got[0], want[0] if fc == 0 else got[0])
+
+
+def test_error_behaviour():
+    elo = load_pkg()
+    dev = "cuda:0"
+    x = torch.zeros(1, 4, 8, 3, device=dev)
+    idx = torch.zeros(1, 2, 2, dtype=torch.int32, device=dev)
+    perm = torch.arange(15, dtype=torch.int32, device=dev)
+    with pytest.raises(ValueError, match="positive K"):
+        elo.fused_conv_random_k(x, x, idx, perm, 4, 8, 2, 3, 5, 0, 0, 1.0, 1, 1)
+    with pytest.raises(ValueError, match="positive distance"):
+        elo.fused_conv_select_k(x, x, idx, perm, 4, 8, 2, 3, 5, 4, 0, 0.0, 1, 1)
+    with pytest.raises(ValueError, match="xyz2 shape"):
+        elo.fused_conv_random_k(x, x, idx, perm, 4, 8, 2, 3, 5, 4, 0, 1.0, 2, 1)
+    with pytest.raises(ValueError, match="random_hw shape"):
+        elo.fused_conv_random_k(x, x, idx, perm[:14], 4, 8, 2, 3, 5, 4, 0, 1.0, 1, 1)
+    with pytest.raises(Exception, match="no CPU fallback"):
+        elo.fused_conv_random_k(x.cpu(), x.cpu(), idx.cpu(), perm.cpu(), 4, 8, 2, 3, 5, 4, 0, 1.0, 1, 1)
+    big = torch.arange(71 * 71, dtype=torch.int32, device=dev)          # 5041 > 5000 slots
+    xx = torch.zeros(1, 80, 80, 3, device=dev)
+    with pytest.raises(Exception, match="exceeds 5000"):
+        elo.fused_conv_select_k(xx, xx, idx, big, 80, 80, 2, 71, 71, 4, 0, 1.0, 1, 1)
+
+
+def _digest(*arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_full_size_digests(i):
+    """BASELINE config 1 (64x1800 all-pixel random-k, 9x15, K=16, d=0.5) and the other
+    full-resolution cases: sha256 of the REFERENCE outputs."""
+    with open(os.path.join(GOLDEN, "large_digests.json")) as f:
+        d = json.load(f)[i]
+    synth = load_pkg("synth")
+    f1, f2 = synth.frame_pair(1, d["H"], d["W"], seed=d["seed"])
+    idx = synth.hw_index(1, d["H"], d["W"])
+    kH, kW = d["window"]
+    perm = np.random.default_rng(d["seed"]).permutation(kH * kW).astype(np.int32)
+    sel, valid, indis, mask = _hip(d["op"], f1, f2, idx, perm, kH, kW, d["K"], 0, d["distance"], 1, 1)
+    if _digest(f1, f2, idx, perm) == d["inputs_sha256"]:
+        assert _digest(sel) == d["sel_sha256"]
+        assert _digest(mask) == d["mask_sha256"]
+        assert _digest(valid.sum(2).astype(np.int32), indis.sum(2).astype(np.int32)) == d["counts_sha256"]
+    # independent of the RNG stream: equality with the oracle on the same inputs
+    fn = G.fused_conv_random_k if d["op"] == "random" else G.fused_conv_select_k
+    want = fn(f1, f2, idx, perm, d["H"], d["W"], idx.shape[1], kH, kW, d["K"], 0, d["distance"], 1, 1, threads=16)
+    for g, w_ in zip((sel, valid, indis, mask), want):
+        assert np.array_equal(g, w_)
+    # size-independent properties: every selected index is inside the window and within the radius
+    b, h, w = sel[..., 0], sel[..., 1], sel[..., 2]
+    m = mask[..., 0] == 1
+    assert (b[m] == 0).all() and (h[m] >= 0).all() and (h[m] < d["H"]).all()
+    ch = idx[0, :, 0][:, None]
+    assert (np.abs(h - ch)[m] <= kH // 2).all()
+    p = f2[0][h, w]
+    cpt = f1[0][idx[0, :, 0], idx[0, :, 1]][:, None, :]
+    dd = ((cpt - p) ** 2).sum(-1)
+    assert (dd[m] <= d["distance"] ** 2 * (1 + 1e-5)).all()
