@@ -23,12 +23,46 @@ class GroupArgs(ctypes.Structure):
                 ("selected_mask", _vp)]
 
 
+def _struct(name, fields):
+    return type(name, (ctypes.Structure,), {"_fields_": fields, "__doc__": "struct %s (include/elo.h)." % name})
+
+
+_i, _f = ctypes.c_int, ctypes.c_float
+GroupConcatArgs = _struct("elo_group_concat_args", [
+    ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
+    ("centre_xyz", _vp), ("src_xyz", _vp), ("src_feat", _vp), ("idx", _vp), ("mask", _vp), ("out", _vp)])
+MaskedMaxpoolArgs = _struct("elo_masked_maxpool_args", [
+    ("batch", _i), ("npoints", _i), ("K", _i), ("C", _i), ("x", _vp), ("mask", _vp), ("out", _vp)])
+CvEncode1Args = _struct("elo_cv_encode1_args", [
+    ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
+    ("xyz1", _vp), ("feat1", _vp), ("xyz2", _vp), ("feat2", _vp), ("idx", _vp), ("mask", _vp), ("out", _vp)])
+CvEncode2Args = _struct("elo_cv_encode2_args", [
+    ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("C", _i), ("Cc", _i),
+    ("xyz1", _vp), ("feat1", _vp), ("cost", _vp), ("idx", _vp), ("mask", _vp), ("xyz_cat", _vp), ("rest", _vp)])
+SoftmaxPoolArgs = _struct("elo_softmax_pool_args", [
+    ("batch", _i), ("npoints", _i), ("K", _i), ("C", _i), ("logits", _vp), ("values", _vp),
+    ("values_stride", _i), ("mask", _vp), ("out", _vp)])
+SoftmaxValidArgs = _struct("elo_softmax_valid_args", [
+    ("batch", _i), ("npoints", _i), ("C", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp), ("out", _vp)])
+WarpProjectArgs = _struct("elo_warp_project_args", [
+    ("batch", _i), ("npoints", _i), ("C", _i), ("H", _i), ("W", _i),
+    ("az_res", _f), ("vert_res", _f), ("vert_off", _f),
+    ("xyz", _vp), ("feat", _vp), ("q", _vp), ("t", _vp), ("warped", _vp), ("out_xyz", _vp), ("out_feat", _vp),
+    ("scratch", _vp)])
+
 # every symbol include/elo.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("elo_abi_version", ctypes.c_int, []),
     ("elo_last_error", ctypes.c_char_p, []),
     ("elo_fused_conv_random_k", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
     ("elo_fused_conv_select_k", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
+    ("elo_group_concat", ctypes.c_int, [ctypes.POINTER(GroupConcatArgs), _vp]),
+    ("elo_masked_maxpool", ctypes.c_int, [ctypes.POINTER(MaskedMaxpoolArgs), _vp]),
+    ("elo_cv_encode1", ctypes.c_int, [ctypes.POINTER(CvEncode1Args), _vp]),
+    ("elo_cv_encode2", ctypes.c_int, [ctypes.POINTER(CvEncode2Args), _vp]),
+    ("elo_masked_softmax_pool", ctypes.c_int, [ctypes.POINTER(SoftmaxPoolArgs), _vp]),
+    ("elo_softmax_valid", ctypes.c_int, [ctypes.POINTER(SoftmaxValidArgs), _vp]),
+    ("elo_warp_project", ctypes.c_int, [ctypes.POINTER(WarpProjectArgs), _vp]),
 ]
 
 _lib = None
@@ -56,6 +90,12 @@ def lib():
 def check(rc):
     if rc != 0:
         raise EloError("libelo_hip: %s (status %d)" % (lib().elo_last_error().decode(), rc))
+
+
+def call(entry, args, like):
+    """Launch `entry(args, current stream)` on like.device; raise on a non-zero status."""
+    with torch.cuda.device(like.device):
+        check(getattr(lib(), entry)(ctypes.byref(args), stream_ptr(like)))
 
 
 def stream_ptr(t):

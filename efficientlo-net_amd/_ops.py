@@ -1,0 +1,132 @@
+"""Thin torch-tensor front-ends of the fused feature kernels (include/elo.h,
+csrc/elo_features.hip).  Forward only at this layer; shapes are validated in C
+as well.  No CPU fallback: CPU tensors raise."""
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def _f32(*ts):
+    out = []
+    for t in ts:
+        if t.dtype != torch.float32:
+            raise TypeError("feature-path tensors are float32 (got %s)" % t.dtype)
+        out.append(t.contiguous())
+    return out
+
+
+def group_concat(centre_xyz, src_xyz, src_feat, idx, mask):
+    """[src_xyz[idx]*m - centre, src_feat[idx]*m] -> (B,N,K,3+C).  pointnet_util.py:203-213, :277-284."""
+    L.require_gpu(centre_xyz, src_xyz, src_feat, idx, mask)
+    centre_xyz, src_xyz, src_feat, mask = _f32(centre_xyz, src_xyz, src_feat, mask)
+    idx = idx.contiguous()
+    B, N, K, _ = idx.shape
+    _, H2, W2, C = src_feat.shape
+    out = torch.empty((B, N, K, 3 + C), dtype=torch.float32, device=idx.device)
+    a = L.GroupConcatArgs(B, N, K, H2, W2, C, centre_xyz.data_ptr(), src_xyz.data_ptr(), src_feat.data_ptr(),
+                          idx.data_ptr(), mask.data_ptr(), out.data_ptr())
+    L.call("elo_group_concat", a, out)
+    return out
+
+
+def masked_maxpool(x, mask):
+    """max_k x*mask -> (B,N,C).  pointnet_util.py:224-230, :295-298."""
+    L.require_gpu(x, mask)
+    x, mask = _f32(x, mask)
+    B, N, K, C = x.shape
+    out = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
+    L.call("elo_masked_maxpool", L.MaskedMaxpoolArgs(B, N, K, C, x.data_ptr(), mask.data_ptr(), out.data_ptr()), out)
+    return out
+
+
+def cv_encode1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask):
+    """(B,N,K,10+2C) = [p, q, q-p, |q-p|, feat1, feat2[idx]*m].  pointnet_util.py:54-66."""
+    L.require_gpu(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask)
+    xyz1, feat1, xyz2_proj, feat2_proj, mask = _f32(xyz1, feat1, xyz2_proj, feat2_proj, mask)
+    idx = idx.contiguous()
+    B, N, K, _ = idx.shape
+    _, H2, W2, C = feat2_proj.shape
+    out = torch.empty((B, N, K, 10 + 2 * C), dtype=torch.float32, device=idx.device)
+    a = L.CvEncode1Args(B, N, K, H2, W2, C, xyz1.data_ptr(), feat1.data_ptr(), xyz2_proj.data_ptr(),
+                        feat2_proj.data_ptr(), idx.data_ptr(), mask.data_ptr(), out.data_ptr())
+    L.call("elo_cv_encode1", a, out)
+    return out
+
+
+def cv_encode2(xyz1_proj, feat1_proj, cost_proj, idx, mask):
+    """xyz_cat (B,N,K,10) and rest (B,N,K,C+Cc) = [feat1, cost[idx]*m].  pointnet_util.py:110-129."""
+    L.require_gpu(xyz1_proj, feat1_proj, cost_proj, idx, mask)
+    xyz1_proj, feat1_proj, cost_proj, mask = _f32(xyz1_proj, feat1_proj, cost_proj, mask)
+    idx = idx.contiguous()
+    B, N, K, _ = idx.shape
+    _, H, W, C = feat1_proj.shape
+    Cc = cost_proj.shape[-1]
+    xyz_cat = torch.empty((B, N, K, 10), dtype=torch.float32, device=idx.device)
+    rest = torch.empty((B, N, K, C + Cc), dtype=torch.float32, device=idx.device)
+    a = L.CvEncode2Args(B, N, K, H, W, C, Cc, xyz1_proj.data_ptr(), feat1_proj.data_ptr(), cost_proj.data_ptr(),
+                        idx.data_ptr(), mask.data_ptr(), xyz_cat.data_ptr(), rest.data_ptr())
+    L.call("elo_cv_encode2", a, rest)
+    return xyz_cat, rest
+
+
+def masked_softmax_pool(logits, values, mask):
+    """sum_k softmax_k(where(mask==1, logits, -1e10)) * values -> (B,N,C).  pointnet_util.py:92-98, :137-146.
+    `values` may be a last-dim slice of a wider contiguous tensor (no copy)."""
+    L.require_gpu(logits, values, mask)
+    logits, mask = _f32(logits, mask)
+    B, N, K, C = logits.shape
+    if values.dtype != torch.float32 or values.shape != logits.shape:
+        raise ValueError("values must be float32 with the shape of logits")
+    if values.stride(-1) != 1 or values.stride(1) != K * values.stride(2) or values.stride(0) != N * values.stride(1):
+        values = values.contiguous()
+    out = torch.empty((B, N, C), dtype=torch.float32, device=logits.device)
+    a = L.SoftmaxPoolArgs(B, N, K, C, logits.data_ptr(), values.data_ptr(), values.stride(2), mask.data_ptr(),
+                          out.data_ptr())
+    L.call("elo_masked_softmax_pool", a, out)
+    return out
+
+
+def softmax_valid(feature_bnc, weight_bnc, xyz_bn3):
+    """model_util.py:319-343 with mask_valid = any(xyz != 0) -> (B,1,C)."""
+    L.require_gpu(feature_bnc, weight_bnc, xyz_bn3)
+    feature_bnc, weight_bnc, xyz_bn3 = _f32(feature_bnc, weight_bnc, xyz_bn3)
+    B, N, C = feature_bnc.shape
+    out = torch.empty((B, 1, C), dtype=torch.float32, device=feature_bnc.device)
+    a = L.SoftmaxValidArgs(B, N, C, feature_bnc.data_ptr(), weight_bnc.data_ptr(), xyz_bn3.data_ptr(), out.data_ptr())
+    L.call("elo_softmax_valid", a, out)
+    return out
+
+
+def projection_constants(H_input, W_input):
+    """model_util.py:189-200: python doubles (cast to float32 by the ctypes struct)."""
+    d2r = math.pi / 180
+    az = (360.0 / W_input) * d2r
+    down, up = -24.8 * d2r, 2.0 * d2r
+    vres = (up - down) / (H_input - 1)
+    return az, vres, -down / vres
+
+
+def warp_project(xyz, feat, q, t, H, W):
+    """Optional quaternion warp (q,t: (B,4),(B,3) or None) + ProjectPC2SphericalRing.
+    Returns (warped (B,N,3) or None, xyz_proj (B,H,W,3), feat_proj (B,H,W,C) or None)."""
+    L.require_gpu(xyz, feat, q, t)
+    (xyz,) = _f32(xyz)
+    B, N, _ = xyz.shape
+    C = 0 if feat is None else feat.shape[-1]
+    if feat is not None:
+        (feat,) = _f32(feat)
+    if q is not None:
+        q, t = _f32(q.reshape(B, 4), t.reshape(B, 3))
+    dev = xyz.device
+    warped = torch.empty((B, N, 3), dtype=torch.float32, device=dev) if q is not None else None
+    out_xyz = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+    out_feat = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if C else None
+    scratch = torch.empty((B * H * W + 2 * B * N,), dtype=torch.int32, device=dev)
+    az, vres, voff = projection_constants(H, W)
+    ptr = lambda x: x.data_ptr() if x is not None else None
+    a = L.WarpProjectArgs(B, N, C, H, W, az, vres, voff, xyz.data_ptr(), ptr(feat), ptr(q), ptr(t), ptr(warped),
+                          out_xyz.data_ptr(), ptr(out_feat), scratch.data_ptr())
+    L.call("elo_warp_project", a, out_xyz)
+    return warped, out_xyz, out_feat

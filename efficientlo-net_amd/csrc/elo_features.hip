@@ -1,0 +1,351 @@
+// elo_features.hip -- fused gather / encode / pool kernels of the feature path
+// (set-conv, attentive cost volume, set-upconv, softmax_valid, warp+re-projection)
+// for MI355X (gfx950, wave64).  Interfaces and the reference lines each kernel
+// covers: include/elo.h.
+//
+// All of these are HBM/L2-bound gathers and reductions (< 1 flop per byte): the
+// design goal is one pass over the operator-boundary tensors with coalesced
+// channel-contiguous accesses -- a wavefront walks one (b,n[,k]) row, lanes run
+// along the channel axis, so every gathered feature row is read as one
+// contiguous segment and every output row is written as one.  The dense 1x1
+// convolutions between them are GEMMs and stay with hipBLASLt.
+#include "elo_common.h"
+
+namespace elo {
+namespace {
+
+constexpr int ROWS_PER_BLOCK = ELO_BLOCK / ELO_WAVE;   // one wave per row
+
+__device__ __forceinline__ long row_of_wave(long total_rows)
+{
+    const long r = (long)xcd_tile(blockIdx.x, gridDim.x) * ROWS_PER_BLOCK + threadIdx.x / ELO_WAVE;
+    return r < total_rows ? r : -1;
+}
+
+inline unsigned grid_for_rows(long rows) { return (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
+
+// ------------------------------------------------------------ group_concat
+__global__ __launch_bounds__(ELO_BLOCK) void group_concat_kernel(const elo_group_concat_args a, const long rows)
+{
+    const long r = row_of_wave(rows);                  // r = (b*N + n)*K + k
+    if (r < 0) return;
+    const int lane = threadIdx.x % ELO_WAVE;
+    const long bn = r / a.K;
+    const int *id = a.idx + r * 3;
+    const long cell = ((long)id[0] * a.H2 + id[1]) * a.W2 + id[2];
+    const float m = a.mask[r];
+    const float *cen = a.centre_xyz + bn * 3;
+    const float *sx = a.src_xyz + cell * 3;
+    const float *sf = a.src_feat + cell * a.C;
+    float *o = a.out + r * (3 + a.C);
+    for (int ch = lane; ch < 3 + a.C; ch += ELO_WAVE)
+        o[ch] = ch < 3 ? sx[ch] * m - cen[ch] : sf[ch - 3] * m;
+}
+
+// ------------------------------------------------------------ masked max-pool
+__global__ __launch_bounds__(ELO_BLOCK) void masked_maxpool_kernel(const elo_masked_maxpool_args a, const long rows)
+{
+    const long r = row_of_wave(rows);                  // r = b*N + n
+    if (r < 0) return;
+    const int lane = threadIdx.x % ELO_WAVE;
+    const float *x = a.x + r * a.K * a.C;
+    const float *m = a.mask + r * a.K;
+    for (int c = lane; c < a.C; c += ELO_WAVE) {
+        float best = x[c] * m[0];
+        for (int k = 1; k < a.K; ++k) best = fmaxf(best, x[(long)k * a.C + c] * m[k]);
+        a.out[r * a.C + c] = best;
+    }
+}
+
+// ------------------------------------------------------------ cost volume: encode
+struct Geo { float p[3], g[3], d[3], euc; };
+
+__device__ __forceinline__ Geo geometry(const float *p, const float *g, float m)
+{
+    Geo s;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { s.p[i] = p[i]; s.g[i] = g[i] * m; s.d[i] = s.g[i] - s.p[i]; }
+    s.euc = sqrtf(s.d[0] * s.d[0] + s.d[1] * s.d[1] + s.d[2] * s.d[2] + 1e-20f);
+    return s;
+}
+
+__device__ __forceinline__ float geo_channel(const Geo &s, int ch)
+{
+    return ch < 3 ? s.p[ch] : ch < 6 ? s.g[ch - 3] : ch < 9 ? s.d[ch - 6] : s.euc;
+}
+
+__global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_kernel(const elo_cv_encode1_args a, const long rows)
+{
+    const long r = row_of_wave(rows);
+    if (r < 0) return;
+    const int lane = threadIdx.x % ELO_WAVE;
+    const long bn = r / a.K;
+    const int *id = a.idx + r * 3;
+    const long cell = ((long)id[0] * a.H2 + id[1]) * a.W2 + id[2];
+    const float m = a.mask[r];
+    const Geo s = geometry(a.xyz1 + bn * 3, a.xyz2 + cell * 3, m);
+    const float *f1 = a.feat1 + bn * a.C;
+    const float *f2 = a.feat2 + cell * a.C;
+    const int C = a.C, CT = 10 + 2 * C;
+    float *o = a.out + r * CT;
+    for (int ch = lane; ch < CT; ch += ELO_WAVE)
+        o[ch] = ch < 10 ? geo_channel(s, ch) : ch < 10 + C ? f1[ch - 10] : f2[ch - 10 - C] * m;
+}
+
+__global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_kernel(const elo_cv_encode2_args a, const long rows)
+{
+    const long r = row_of_wave(rows);
+    if (r < 0) return;
+    const int lane = threadIdx.x % ELO_WAVE;
+    const long bn = r / a.K;
+    const int *id = a.idx + r * 3;
+    const long cell = ((long)id[0] * a.H + id[1]) * a.W + id[2];
+    const float m = a.mask[r];
+    const Geo s = geometry(a.xyz1 + bn * 3, a.xyz1 + cell * 3, m);
+    if (lane < 10) a.xyz_cat[r * 10 + lane] = geo_channel(s, lane);
+    const float *f1 = a.feat1 + bn * a.C;
+    const float *cv = a.cost + cell * a.Cc;
+    const int CT = a.C + a.Cc;
+    float *o = a.rest + r * CT;
+    for (int ch = lane; ch < CT; ch += ELO_WAVE)
+        o[ch] = ch < a.C ? f1[ch] : cv[ch - a.C] * m;
+}
+
+// ------------------------------------------------------------ masked softmax-pool over K
+__global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_kernel(const elo_softmax_pool_args a, const long rows)
+{
+    const long r = row_of_wave(rows);                  // r = b*N + n
+    if (r < 0) return;
+    const int lane = threadIdx.x % ELO_WAVE;
+    const float *lg = a.logits + r * a.K * a.C;
+    const float *vl = a.values + r * a.K * (long)a.values_stride;
+    const float *m = a.mask + r * a.K;
+    for (int c = lane; c < a.C; c += ELO_WAVE) {
+        float mx = -INFINITY;
+        for (int k = 0; k < a.K; ++k) {
+            const float l = m[k] == 1.0f ? lg[(long)k * a.C + c] : -1e10f;
+            mx = fmaxf(mx, l);
+        }
+        float den = 0.0f, acc = 0.0f;
+        for (int k = 0; k < a.K; ++k) {
+            const float l = m[k] == 1.0f ? lg[(long)k * a.C + c] : -1e10f;
+            const float e = expf(l - mx);
+            den += e;
+            acc += e * vl[(long)k * a.values_stride + c];
+        }
+        a.out[r * a.C + c] = acc / den;
+    }
+}
+
+// ------------------------------------------------------------ softmax_valid over the point axis
+// grid (batch, ceil(C/64)); 4 waves stride over the points, lanes over channels.
+__global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_kernel(const elo_softmax_valid_args a)
+{
+    __shared__ float part[3][ROWS_PER_BLOCK][ELO_WAVE];
+    const int b = blockIdx.x, lane = threadIdx.x % ELO_WAVE, wave = threadIdx.x / ELO_WAVE;
+    const int c = blockIdx.y * ELO_WAVE + lane;
+    const bool live = c < a.C;
+    const float *f = a.feature + (long)b * a.npoints * a.C;
+    const float *w = a.weight + (long)b * a.npoints * a.C;
+    const float *p = a.xyz + (long)b * a.npoints * 3;
+    float mx = -INFINITY, den = 0.0f, acc = 0.0f;      // online softmax
+    for (int n = wave; n < a.npoints; n += ROWS_PER_BLOCK) {
+        const bool valid = !(p[n * 3 + 0] == 0.0f && p[n * 3 + 1] == 0.0f && p[n * 3 + 2] == 0.0f);
+        if (!valid || !live) continue;
+        const float l = w[(long)n * a.C + c], v = f[(long)n * a.C + c];
+        if (l > mx) {
+            const float sc = expf(mx - l);            // exp(-inf) = 0 on the first valid point
+            den = den * sc + 1.0f;
+            acc = acc * sc + v;
+            mx = l;
+        } else {
+            const float e = expf(l - mx);
+            den += e;
+            acc += e * v;
+        }
+    }
+    part[0][wave][lane] = mx; part[1][wave][lane] = den; part[2][wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && live) {
+        float M = -INFINITY;
+        for (int i = 0; i < ROWS_PER_BLOCK; ++i) M = fmaxf(M, part[0][i][lane]);
+        float D = 0.0f, A = 0.0f;
+        for (int i = 0; i < ROWS_PER_BLOCK; ++i) {
+            if (part[1][i][lane] == 0.0f) continue;   // that wave saw no valid point
+            const float sc = expf(part[0][i][lane] - M);
+            D += part[1][i][lane] * sc;
+            A += part[2][i][lane] * sc;
+        }
+        a.out[(long)b * a.C + c] = D > 0.0f ? A / D : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------ warp + spherical re-projection
+// pass A: one thread per point -> warped xyz, range bits, cell id, atomicMin of the cell's range.
+__global__ __launch_bounds__(ELO_BLOCK) void warp_cell_kernel(const elo_warp_project_args a, unsigned *minr,
+                                                              int *cell_of, unsigned *rbits)
+{
+    const long total = (long)a.batch * a.npoints;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / a.npoints);
+        float x = a.xyz[i * 3 + 0], y = a.xyz[i * 3 + 1], z = a.xyz[i * 3 + 2];
+        if (a.q) {
+            const bool keep = !(x == 0.0f && y == 0.0f && z == 0.0f);          // pwclo_model.py:219-221
+            const float *q = a.q + b * 4, *t = a.t + b * 3;
+            const float q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            // mul_q_point(q, [0,p])      model_util.py:17-36
+            const float v0 = q0 * 0.0f - q1 * x - q2 * y - q3 * z;
+            const float v1 = q0 * x + q1 * 0.0f + q2 * z - q3 * y;
+            const float v2 = q0 * y - q1 * z + q2 * 0.0f + q3 * x;
+            const float v3 = q0 * z + q1 * y - q2 * x + q3 * 0.0f;
+            // inv_q                      model_util.py:61-69
+            const float n2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3 + 1e-10f;
+            const float i0 = q0 / n2, i1 = -q1 / n2, i2 = -q2 / n2, i3 = -q3 / n2;
+            // mul_point_q(v, q^-1)[1:]   model_util.py:39-58
+            const float w1 = v0 * i1 + v1 * i0 + v2 * i3 - v3 * i2;
+            const float w2 = v0 * i2 - v1 * i3 + v2 * i0 + v3 * i1;
+            const float w3 = v0 * i3 + v1 * i2 - v2 * i1 + v3 * i0;
+            const float k = keep ? 1.0f : 0.0f;
+            x = (w1 + t[0]) * k; y = (w2 + t[1]) * k; z = (w3 + t[2]) * k;
+            a.warped[i * 3 + 0] = x; a.warped[i * 3 + 1] = y; a.warped[i * 3 + 2] = z;
+        }
+        const float r = sqrtf(x * x + y * y + z * z);
+        const float PI_F = 3.14159265358979323846f;
+        int col = (int)((PI_F - atan2f(y, x)) / a.az_res);                       // model_util.py:234-235
+        const float beta = asinf(z / r);
+        int row = a.H - (int)(beta / a.vert_res + a.vert_off);                   // NaN -> 0, :237-242
+        row = row < 0 ? 0 : row > a.H - 1 ? a.H - 1 : row;
+        col = col < 0 ? 0 : col > a.W - 1 ? a.W - 1 : col;
+        const int cell = row * a.W + col;
+        const unsigned rb = __float_as_uint(r);        // r >= 0: bit order == float order; NaN sorts last
+        cell_of[i] = cell;
+        rbits[i] = rb;
+        atomicMin(minr + (long)b * a.H * a.W + cell, rb);
+    }
+}
+
+// pass B: the point(s) holding the cell minimum are summed into the cell (tf.scatter_nd adds duplicates).
+__global__ __launch_bounds__(ELO_BLOCK) void scatter_min_kernel(const elo_warp_project_args a, const unsigned *minr,
+                                                                const int *cell_of, const unsigned *rbits)
+{
+    const int CT = 3 + a.C;
+    const long total = (long)a.batch * a.npoints * CT;
+    const float *pts = a.q ? a.warped : a.xyz;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long i = e / CT;
+        const int ch = (int)(e - i * CT);
+        const int b = (int)(i / a.npoints);
+        const long cell = (long)b * a.H * a.W + cell_of[i];
+        if (rbits[i] != minr[cell]) continue;
+        if (ch < 3) atomicAdd(a.out_xyz + cell * 3 + ch, pts[i * 3 + ch]);
+        else atomicAdd(a.out_feat + cell * a.C + (ch - 3), a.feat[i * a.C + (ch - 3)]);
+    }
+}
+
+#define ELO_REQUIRE(cond, who, what) \
+    do { if (!(cond)) return fail(ELO_ERR_ARG, "%s: %s", who, what); } while (0)
+
+}  // namespace
+}  // namespace elo
+
+using namespace elo;
+
+extern "C" int elo_group_concat(const elo_group_concat_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_group_concat";
+    ELO_REQUIRE(a, who, "null argument block");
+    ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->K > 0 && a->H2 > 0 && a->W2 > 0 && a->C >= 0, who, "bad sizes");
+    ELO_REQUIRE(a->centre_xyz && a->src_xyz && (a->src_feat || a->C == 0) && a->idx && a->mask && a->out, who, "null tensor pointer");
+    const long rows = (long)a->batch * a->npoints * a->K;
+    if (rows == 0) return ELO_OK;
+    hipLaunchKernelGGL(group_concat_kernel, dim3(grid_for_rows(rows)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
+    return check_launch(who);
+}
+
+extern "C" int elo_masked_maxpool(const elo_masked_maxpool_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_masked_maxpool";
+    ELO_REQUIRE(a, who, "null argument block");
+    ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->K > 0 && a->C > 0, who, "bad sizes");
+    ELO_REQUIRE(a->x && a->mask && a->out, who, "null tensor pointer");
+    const long rows = (long)a->batch * a->npoints;
+    if (rows == 0) return ELO_OK;
+    hipLaunchKernelGGL(masked_maxpool_kernel, dim3(grid_for_rows(rows)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
+    return check_launch(who);
+}
+
+extern "C" int elo_cv_encode1(const elo_cv_encode1_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_cv_encode1";
+    ELO_REQUIRE(a, who, "null argument block");
+    ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->K > 0 && a->H2 > 0 && a->W2 > 0 && a->C > 0, who, "bad sizes");
+    ELO_REQUIRE(a->xyz1 && a->feat1 && a->xyz2 && a->feat2 && a->idx && a->mask && a->out, who, "null tensor pointer");
+    const long rows = (long)a->batch * a->npoints * a->K;
+    if (rows == 0) return ELO_OK;
+    hipLaunchKernelGGL(cv_encode1_kernel, dim3(grid_for_rows(rows)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
+    return check_launch(who);
+}
+
+extern "C" int elo_cv_encode2(const elo_cv_encode2_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_cv_encode2";
+    ELO_REQUIRE(a, who, "null argument block");
+    ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->K > 0 && a->H > 0 && a->W > 0 && a->C > 0 && a->Cc > 0, who, "bad sizes");
+    ELO_REQUIRE(a->npoints == a->H * a->W, who, "npoints must equal H*W (every pixel is a centre)");
+    ELO_REQUIRE(a->xyz1 && a->feat1 && a->cost && a->idx && a->mask && a->xyz_cat && a->rest, who, "null tensor pointer");
+    const long rows = (long)a->batch * a->npoints * a->K;
+    if (rows == 0) return ELO_OK;
+    hipLaunchKernelGGL(cv_encode2_kernel, dim3(grid_for_rows(rows)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
+    return check_launch(who);
+}
+
+extern "C" int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_masked_softmax_pool";
+    ELO_REQUIRE(a, who, "null argument block");
+    ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->K > 0 && a->C > 0 && a->values_stride >= a->C, who, "bad sizes");
+    ELO_REQUIRE(a->logits && a->values && a->mask && a->out, who, "null tensor pointer");
+    const long rows = (long)a->batch * a->npoints;
+    if (rows == 0) return ELO_OK;
+    hipLaunchKernelGGL(softmax_pool_kernel, dim3(grid_for_rows(rows)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
+    return check_launch(who);
+}
+
+extern "C" int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_softmax_valid";
+    ELO_REQUIRE(a, who, "null argument block");
+    ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->C > 0, who, "bad sizes");
+    ELO_REQUIRE(a->feature && a->weight && a->xyz && a->out, who, "null tensor pointer");
+    if (a->batch == 0) return ELO_OK;
+    hipLaunchKernelGGL(softmax_valid_kernel, dim3(a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE), dim3(ELO_BLOCK), 0,
+                       (hipStream_t)stream, *a);
+    return check_launch(who);
+}
+
+extern "C" int elo_warp_project(const elo_warp_project_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_warp_project";
+    ELO_REQUIRE(a, who, "null argument block");
+    ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->C >= 0 && a->H > 0 && a->W > 0, who, "bad sizes");
+    ELO_REQUIRE(a->xyz && a->out_xyz && a->scratch, who, "null tensor pointer");
+    ELO_REQUIRE(a->C == 0 || (a->feat && a->out_feat), who, "features requested without buffers");
+    ELO_REQUIRE(!a->q || (a->t && a->warped), who, "warp requested without t / warped");
+    if (a->batch == 0) return ELO_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t cells = (size_t)a->batch * a->H * a->W, pts = (size_t)a->batch * a->npoints;
+    unsigned *minr = a->scratch;
+    int *cell_of = (int *)(a->scratch + cells);
+    unsigned *rbits = a->scratch + cells + pts;
+    // 0x7f7f7f7f = 3.39e38f: above every finite range, below NaN bit patterns
+    if (hipMemsetAsync(minr, 0x7f, cells * sizeof(unsigned), s) != hipSuccess ||
+        hipMemsetAsync(a->out_xyz, 0, cells * 3 * sizeof(float), s) != hipSuccess ||
+        (a->C && hipMemsetAsync(a->out_feat, 0, cells * a->C * sizeof(float), s) != hipSuccess))
+        return fail(ELO_ERR_LAUNCH, "%s: hipMemsetAsync failed", who);
+    const unsigned ga = (unsigned)((pts + ELO_BLOCK - 1) / ELO_BLOCK);
+    hipLaunchKernelGGL(warp_cell_kernel, dim3(ga > 4096 ? 4096 : ga), dim3(ELO_BLOCK), 0, s, *a, minr, cell_of, rbits);
+    const size_t elems = pts * (3 + a->C);
+    const unsigned gb = (unsigned)((elems + ELO_BLOCK - 1) / ELO_BLOCK);
+    hipLaunchKernelGGL(scatter_min_kernel, dim3(gb > 4096 ? 4096 : gb), dim3(ELO_BLOCK), 0, s, *a, minr, cell_of, rbits);
+    return check_launch(who);
+}

@@ -1,0 +1,73 @@
+"""PWCLONet: the object a user holds -- variables + visiting orders + (optionally)
+a captured HIP graph of the whole forward pass.
+
+The reference builds a TF graph once (main.py:141-179) and calls sess.run per
+batch.  The MI355X-native equivalent of "build once, run many" is a hipGraph:
+one frame pair's forward is ~600 small kernels, so at batch 1 the GPU is
+launch-bound unless the launches are replayed from a graph.  `capture()`
+records get_model_from_projection on static input buffers; `__call__` copies the
+new range images in and replays.
+"""
+import torch
+
+from . import perm, pwclo_model, tf_util
+
+
+class PWCLONet:
+    def __init__(self, device="cuda:0", seed=0, perm_source=None):
+        self.device = torch.device(device)
+        self.store = tf_util.VariableStore(self.device, seed=seed)
+        self.perms = perm_source if perm_source is not None else perm.PermSource(seed=seed)
+        self._graph = None
+        self._static_in = None
+        self._static_out = None
+
+    # -- eager ---------------------------------------------------------------
+    def forward(self, xyz_f1_proj, xyz_f2_proj, is_training=False, bn_decay=None):
+        """get_model_from_projection under this net's variables and permutations."""
+        with tf_util.default_store(self.store), perm.default_perm_source(self.perms):
+            if is_training:
+                return pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, True, bn_decay)
+            with torch.no_grad():
+                return pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, False, bn_decay)
+
+    def forward_points(self, point_cloud, H_input, W_input, T_gt, T_trans, T_trans_inv, is_training=False,
+                       bn_decay=None, aug_frame=None):
+        """get_model with the reference's full signature (raw clouds in)."""
+        with tf_util.default_store(self.store), perm.default_perm_source(self.perms):
+            ctx = torch.enable_grad() if is_training else torch.no_grad()
+            with ctx:
+                return pwclo_model.get_model(point_cloud, H_input, W_input, T_gt, T_trans, T_trans_inv, is_training,
+                                             bn_decay, aug_frame)
+
+    # -- HIP graph -----------------------------------------------------------
+    def capture(self, batch_size, H_input, W_input, warmup=3):
+        """Record one inference forward into a hipGraph (torch.cuda.CUDAGraph on ROCm)."""
+        dev = self.device
+        self._static_in = (torch.zeros((batch_size, H_input, W_input, 3), device=dev),
+                           torch.zeros((batch_size, H_input, W_input, 3), device=dev))
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                 # creates variables, folded weights, caches, hipBLASLt plans
+                self.forward(*self._static_in)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_out = self.forward(*self._static_in)
+        return self
+
+    def load_inputs(self, xyz_f1_proj, xyz_f2_proj):
+        self._static_in[0].copy_(xyz_f1_proj, non_blocking=True)
+        self._static_in[1].copy_(xyz_f2_proj, non_blocking=True)
+
+    def replay(self):
+        self._graph.replay()
+        return self._static_out
+
+    def __call__(self, xyz_f1_proj, xyz_f2_proj):
+        if self._graph is None:
+            return self.forward(xyz_f1_proj, xyz_f2_proj)
+        self.load_inputs(xyz_f1_proj, xyz_f2_proj)
+        return self.replay()

@@ -1,0 +1,191 @@
+"""Operator library with the reference's names and argument lists
+(utils/pointnet_util.py): warping_layers (:18-20), get_hw_idx (:23-30),
+cost_volume (:33-149), flow_predictor (:153-175), down_conv (:179-250),
+up_conv (:254-316).
+
+Same call signatures, so the pyramid schedule (pwclo_model.py) calls them the
+way the reference does.  Inside, every chain of stock TF ops between two 1x1
+convolutions is ONE hand-written HIP kernel (csrc/elo_features.hip), the two
+custom ops are the HIP grouping kernels (csrc/elo_grouping.hip), and the 1x1
+convolutions are hipBLASLt GEMMs (tf_util.conv2d).  Concatenations feeding a
+convolution are never materialised when they only join already-existing
+tensors: conv(concat[a, b]) is computed as a @ W[:Ca] + b @ W[Ca:] (two
+accumulating GEMMs on row-slices of the same weight variable).
+
+`tf.random_shuffle(tf.range(KT))` becomes `random_shuffle(scope, tag, KT)` from
+the active PermSource (see perm.py): the caller owns the randomness.
+"""
+import torch
+
+from . import _ops, tf_util
+from .fused_conv import fused_conv_random_k, fused_conv_select_k
+from .perm import random_shuffle
+
+
+def warping_layers(xyz1, upsampled_flow):
+    """utils/pointnet_util.py:18-20."""
+    return xyz1 + upsampled_flow
+
+
+_hw_cache = {}
+
+
+def get_hw_idx(B, H, W, device="cuda"):
+    """utils/pointnet_util.py:23-30 -> (B, H*W, 2) int32, row-major (h, w) of every pixel."""
+    key = (B, H, W, str(device))
+    if key not in _hw_cache:
+        hh = torch.arange(H, dtype=torch.int32, device=device).view(1, H, 1, 1).expand(B, H, W, 1)
+        ww = torch.arange(W, dtype=torch.int32, device=device).view(1, 1, W, 1).expand(B, H, W, 1)
+        _hw_cache[key] = torch.cat([hh, ww], -1).reshape(B, H * W, 2).contiguous()
+    return _hw_cache[key]
+
+
+def _split_conv(parts, num_output_channels, scope, is_training, bn_decay, bn=True):
+    """tf_util.conv2d(tf.concat(parts, -1), ...) without building the concat.
+
+    In inference the folded weight rows are sliced per part and the GEMMs accumulate into one output;
+    when gradients are needed it falls back to the literal concat + conv."""
+    if is_training or torch.is_grad_enabled():
+        return tf_util.conv2d(torch.cat(parts, -1), num_output_channels, [1, 1], padding='VALID', stride=[1, 1],
+                              bn=bn, is_training=is_training, scope=scope, bn_decay=bn_decay)
+    cin = sum(p.shape[-1] for p in parts)
+    lead = parts[0].shape[:-1]
+    W, b = tf_util.folded_variables(scope, cin, num_output_channels, (1, 1), bn)
+    y, row = None, 0
+    for p in parts:
+        c = p.shape[-1]
+        x2 = p.reshape(-1, c)
+        y = torch.addmm(b, x2, W[row:row + c]) if y is None else y.addmm_(x2, W[row:row + c])
+        row += c
+    return y.relu_().reshape(lead + (num_output_channels,))
+
+
+def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_size1, kernel_size2, nsample,
+                nsample_q, distance, mlp1, mlp2, is_training, bn_decay, scope, bn=True, pooling='max', knn=True,
+                corr_func='elementwise_product'):
+    """Attentive cost volume, utils/pointnet_util.py:33-149.  Returns (B, H*W, mlp2[-1])."""
+    with tf_util.variable_scope(scope):
+        B, H, W, _ = warped_xyz1_proj.shape
+        N = H * W
+        warped_xyz1 = warped_xyz1_proj.reshape(B, N, 3)
+        points1 = points1_proj.reshape(B, N, -1)
+        dev = warped_xyz1_proj.device
+
+        # ---- stage 1: point -> patch in frame 2 (:47-100)
+        random_HW_q = random_shuffle(tf_util.scope_name(), "random_HW_q", kernel_size2[0] * kernel_size2[1], dev)
+        idx_hw = get_hw_idx(B, H, W, dev)
+        qi_idx, _, _, valid_mask = fused_conv_select_k(
+            warped_xyz1_proj, xyz2_proj, idx_hw, random_HW_q, H, W, N, kernel_size2[0], kernel_size2[1], nsample_q,
+            flag_copy=0, distance=1000, stride_h=1, stride_w=1, want_valid=False)            # :49-51 (1000 is literal)
+        mask = valid_mask.reshape(B, N, nsample_q)
+        feat_cat = _ops.cv_encode1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask)   # :54-66
+        xyz_cat = feat_cat.reshape(-1, feat_cat.shape[-1])[:, :10]      # :62 -- 2-D strided view, no copy (lda = 10+2C)
+        x = feat_cat
+        for j, num_out_channel in enumerate(mlp1):
+            x = tf_util.conv2d(x, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                               is_training=is_training, scope='CV_%d' % j, bn_decay=bn_decay)     # :72-76
+        enc = tf_util.conv2d(xyz_cat, mlp1[-1], [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                             is_training=is_training, scope='CV_xyz', bn_decay=bn_decay)          # :79-82
+        enc = enc.reshape(B, N, nsample_q, -1)
+        cat = None
+        for j, num_out_channel in enumerate(mlp2):                                                # :84-90
+            if j == 0:
+                cat = _split_conv([enc, x], num_out_channel, 'sum_CV_0', is_training, bn_decay)
+            else:
+                cat = tf_util.conv2d(cat, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                                     is_training=is_training, scope='sum_CV_%d' % j, bn_decay=bn_decay)
+        pi_feat1_new = _ops.masked_softmax_pool(cat, x, mask).reshape(B, H, W, -1)                # :92-100
+
+        # ---- stage 2: patch -> patch inside frame 1 (:104-146)
+        random_HW_p = random_shuffle(tf_util.scope_name(), "random_HW_p", kernel_size1[0] * kernel_size1[1], dev)
+        pc_idx, _, _, valid_mask2 = fused_conv_random_k(
+            warped_xyz1_proj, warped_xyz1_proj, idx_hw, random_HW_p, H, W, N, kernel_size1[0], kernel_size1[1],
+            nsample, flag_copy=0, distance=distance, stride_h=1, stride_w=1, want_valid=False)    # :106-108
+        mask2 = valid_mask2.reshape(B, N, nsample)
+        pc_xyz_cat, rest = _ops.cv_encode2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2)  # :110-120
+        pc_enc = tf_util.conv2d(pc_xyz_cat, mlp1[-1], [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                                is_training=is_training, scope='sum_xyz_encoding', bn_decay=bn_decay)    # :123-126
+        pc_cat = None
+        for j, num_out_channel in enumerate(mlp2):                                                # :129-135
+            if j == 0:
+                pc_cat = _split_conv([pc_enc, rest], num_out_channel, 'sum_cost_volume_0', is_training, bn_decay)
+            else:
+                pc_cat = tf_util.conv2d(pc_cat, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                                        is_training=is_training, scope='sum_cost_volume_%d' % j, bn_decay=bn_decay)
+        pc_points_grouped = rest[..., points1.shape[-1]:]            # cost[idx]*mask, a channel slice of `rest`
+        return _ops.masked_softmax_pool(pc_cat, pc_points_grouped, mask2)                         # :137-146
+
+
+def flow_predictor(points_f1, upsampled_feat, cost_volume, mlp, is_training, bn_decay, scope, bn=True):
+    """utils/pointnet_util.py:153-175: MLP over concat[points_f1, upsampled_feat?, cost_volume?] -> (B,N,mlp[-1])."""
+    with tf_util.variable_scope(scope):
+        parts = [points_f1]
+        if upsampled_feat is not None:
+            parts.append(upsampled_feat)
+        if cost_volume is not None:
+            parts.append(cost_volume)
+        parts = [p.unsqueeze(2) for p in parts]                                                   # :166
+        x = None
+        for i, num_out_channel in enumerate(mlp):
+            if i == 0:
+                x = _split_conv(parts, num_out_channel, 'conv_predictor0', is_training, bn_decay, bn=bn)
+            else:
+                x = tf_util.conv2d(x, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
+                                   is_training=is_training, scope='conv_predictor%d' % i, bn_decay=bn_decay)
+        return x.squeeze(2)
+
+
+def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distance, mlp, mlp2, flag_add, is_training,
+              bn_decay, scope, bn=True, pooling='max', knn=False, use_xyz=True, use_nchw=False):
+    """Set-conv, utils/pointnet_util.py:179-250.  Returns ((B, n, mlp[-1]), new_xyz_proj (B,H',W',3))."""
+    if use_nchw or pooling != 'max' or mlp2 is not None:
+        raise NotImplementedError("the model uses NHWC, max pooling and mlp2=None (pwclo_model.py:126-177)")
+    with tf_util.variable_scope(scope):
+        B, H, W, _ = xyz_proj.shape
+        idx_n2 = selected_idx.reshape(B, -1, 3)
+        n_sampled = idx_n2.shape[1]
+        dev = xyz_proj.device
+        random_HW = random_shuffle(tf_util.scope_name(), "random_HW", kernel_size[0] * kernel_size[1], dev)
+        sel, _, _, valid_mask = fused_conv_random_k(
+            xyz_proj, xyz_proj, idx_n2[:, :, 1:].contiguous(), random_HW, H, W, n_sampled, kernel_size[0],
+            kernel_size[1], K_sample, flag_copy=0, distance=distance, stride_h=1, stride_w=1, want_valid=False)  # :197-199
+        mask = valid_mask.reshape(B, n_sampled, K_sample)
+        li = selected_idx.reshape(-1, 3).long()
+        new_xyz_proj = xyz_proj[li[:, 0], li[:, 1], li[:, 2]].reshape(selected_idx.shape[:-1] + (3,))  # :206
+        new_xyz = new_xyz_proj.reshape(B, -1, 3)
+        x = _ops.group_concat(new_xyz, xyz_proj, points_proj, sel, mask)                          # :203-213
+        for i, num_out_channel in enumerate(mlp):
+            x = tf_util.conv2d(x, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
+                               is_training=is_training, scope='conv%d' % i, bn_decay=bn_decay)    # :217-222
+        return _ops.masked_maxpool(x, mask), new_xyz_proj                                         # :224-230
+
+
+def up_conv(xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kernel_size, stride_h, stride_w, nsample, distance, mlp,
+            mlp2, is_training, scope, bn_decay=None, bn=True, pooling='max', radius=None, knn=True):
+    """Set-upconv (embedding and embedding-mask up-convolution), utils/pointnet_util.py:254-316."""
+    with tf_util.variable_scope(scope):
+        B, H, W, _ = xyz1_proj.shape
+        N = H * W
+        dev = xyz1_proj.device
+        xyz1 = xyz1_proj.reshape(B, N, 3)
+        points1 = feat1_proj.reshape(B, N, -1)
+        idx_hw = get_hw_idx(B, H, W, dev)
+        random_HW = random_shuffle(tf_util.scope_name(), "random_HW", kernel_size[0] * kernel_size[1], dev)
+        sel, _, _, valid_mask = fused_conv_random_k(
+            xyz1_proj, xyz2_proj, idx_hw, random_HW, H, W, N, kernel_size[0], kernel_size[1], nsample,
+            flag_copy=0, distance=distance, stride_h=stride_h, stride_w=stride_w, want_valid=False)      # :272-274
+        mask = valid_mask.reshape(B, N, nsample)
+        x = _ops.group_concat(xyz1, xyz2_proj, feat2_proj, sel, mask)                             # :277-284
+        for j, num_out_channel in enumerate(mlp):
+            x = tf_util.conv2d(x, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                               is_training=is_training, scope='up_1_%d' % j, bn_decay=bn_decay)   # :289-293
+        up_feat = _ops.masked_maxpool(x, mask)                                                    # :295-298
+        y = None
+        for i, num_out_channel in enumerate(mlp2):                                                # :303-311
+            if i == 0:
+                y = _split_conv([up_feat.unsqueeze(2), points1.unsqueeze(2)], num_out_channel, 'up_2_0',
+                                is_training, bn_decay)
+            else:
+                y = tf_util.conv2d(y, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                                   is_training=is_training, scope='up_2_%d' % i, bn_decay=bn_decay)
+        return y.squeeze(2)

@@ -1,0 +1,208 @@
+"""The pyramid schedule, get_model / get_loss of pwclo_model.py (:30-433, :437-481),
+calling the operator library with the reference's own call shapes.
+
+Differences from the reference, all documented in DESIGN.md:
+  * TF graph-building -> eager PyTorch under a VariableStore (tf_util.py) and a
+    PermSource (perm.py); capture with model.PWCLONet for HIP-graph replay.
+  * the re-projection sizes (4,57), (8,113), (16,225) that the reference
+    hard-codes (:232,:306,:380) come from out_h_list/out_w_list so other
+    resolutions (128x2048) work.
+  * `get_model_from_projection` starts at the two (B,H,W,3) range images;
+    `get_model` keeps the reference signature and does PreProcess + input
+    projection first (:54-67).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import tf_util
+from .model_util import (PreProcess, ProjectPC2SphericalRing, get_selected_idx, inv_q, mul_point_q, mul_q_point,
+                         softmax_valid, warp_and_project)
+from .pointnet_util import cost_volume, down_conv, flow_predictor, up_conv
+
+Down_conv_dis = [0.5, 3.0, 6.0, 12.0]       # pwclo_model.py:38
+Up_conv_dis = [3.0, 6.0, 9.0]               # :39
+Cost_volume_dis = [1.0, 2.0, 4.0]           # :40
+stride_h_list = [1, 1, 4, 2, 2, 1]          # :42
+stride_w_list = [1, 1, 8, 2, 2, 2]          # :43
+
+
+def pyramid_sizes(H_input, W_input):
+    """pwclo_model.py:45-50."""
+    out_h = [math.ceil(H_input / stride_h_list[0])]
+    out_w = [math.ceil(W_input / stride_w_list[0])]
+    for i in range(1, 6):
+        out_h.append(math.ceil(out_h[i - 1] / stride_h_list[i]))
+        out_w.append(math.ceil(out_w[i - 1] / stride_w_list[i]))
+    return out_h, out_w
+
+
+def placeholder_inputs(batch_size, NUM_POINTS, device="cuda"):
+    """pwclo_model.py:19-27: zero tensors of the feed shapes."""
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
+    return z(batch_size, NUM_POINTS * 2, 6), z(batch_size, 4, 4), z(batch_size, 4, 4), z(batch_size, 4, 4)
+
+
+def _normalise_q(q):
+    return q / (torch.sqrt((q * q).sum(-1, keepdim=True) + 1e-10) + 1e-10)
+
+
+def _pose_head(feat_b1c, level, coarse, is_training, dropout_gen=None):
+    """pwclo_model.py:197-208 (l3) and :264-273 / :340-349 / :408-417 (refinement levels)."""
+    big = tf_util.conv1d(feat_b1c, 256, 1, padding='VALID', activation_fn=None, scope='l%d_big' % level)
+    if is_training:
+        big = torch.nn.functional.dropout(big, p=0.5, training=True)                                # :199
+    qn, tn = ('l%d_q_coarse', 'l%d_t_coarse') if coarse else ('l%d_q_det', 'l%d_t_det')
+    q = _normalise_q(tf_util.conv1d(big, 4, 1, padding='VALID', activation_fn=None, scope=qn % level))
+    t = tf_util.conv1d(big, 3, 1, padding='VALID', activation_fn=None, scope=tn % level)
+    return q, t
+
+
+def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training, bn_decay=None):
+    """pwclo_model.py:69-433 from the projected inputs on.
+    Returns (l0_q_norm, l0_t, l1_q_norm, l1_t, l2_q_norm, l2_t, l3_q_norm, l3_t, l0_xyz_f1)."""
+    batch_size, H_input, W_input, _ = xyz_f1_input_proj.shape
+    dev = xyz_f1_input_proj.device
+    out_h_list, out_w_list = pyramid_sizes(H_input, W_input)
+
+    points_f1_input_proj = torch.zeros((batch_size, H_input, W_input, 3), dtype=torch.float32, device=dev)  # :69-70
+    points_f2_input_proj = points_f1_input_proj
+
+    # strided centre grids (:88-114).  Only the index tensors matter: down_conv re-gathers the xyz itself.
+    pre2 = xyz_f1_input_proj
+    l0_selected_idx = get_selected_idx(pre2, stride_h_list[2], stride_w_list[2], out_h_list[2], out_w_list[2])
+    l1_selected_idx = get_selected_idx(pre2, stride_h_list[3], stride_w_list[3], out_h_list[3], out_w_list[3])
+    l2_selected_idx = get_selected_idx(pre2, stride_h_list[4], stride_w_list[4], out_h_list[4], out_w_list[4])
+    l3_selected_idx = get_selected_idx(pre2, stride_h_list[5], stride_w_list[5], out_h_list[5], out_w_list[5])
+
+    def feature_pyramid(xyz_in, points_in):                                                         # :126-139 / :151-164
+        l0_points, l0_xyz_proj = down_conv(xyz_in, points_in, l0_selected_idx, K_sample=32, kernel_size=[9, 15],
+                                           distance=Down_conv_dis[0], mlp=[8, 8, 16], mlp2=None, flag_add=False,
+                                           is_training=is_training, bn_decay=bn_decay, scope='layer0')
+        l0_points_proj = l0_points.reshape(batch_size, out_h_list[2], out_w_list[2], -1)
+        l1_points, l1_xyz_proj = down_conv(l0_xyz_proj, l0_points_proj, l1_selected_idx, K_sample=32,
+                                           kernel_size=[7, 11], distance=Down_conv_dis[1], mlp=[16, 16, 32], mlp2=None,
+                                           flag_add=False, is_training=is_training, bn_decay=bn_decay, scope='layer1')
+        l1_points_proj = l1_points.reshape(batch_size, out_h_list[3], out_w_list[3], -1)
+        l2_points, l2_xyz_proj = down_conv(l1_xyz_proj, l1_points_proj, l2_selected_idx, K_sample=16,
+                                           kernel_size=[5, 9], distance=Down_conv_dis[2], mlp=[32, 32, 64], mlp2=None,
+                                           flag_add=False, is_training=is_training, bn_decay=bn_decay, scope='layer2')
+        l2_points_proj = l2_points.reshape(batch_size, out_h_list[4], out_w_list[4], -1)
+        l3_points, l3_xyz_proj = down_conv(l2_xyz_proj, l2_points_proj, l3_selected_idx, K_sample=16,
+                                           kernel_size=[5, 9], distance=Down_conv_dis[3], mlp=[64, 64, 128], mlp2=None,
+                                           flag_add=False, is_training=is_training, bn_decay=bn_decay, scope='layer3')
+        return ([l0_points, l1_points, l2_points, l3_points],
+                [l0_points_proj, l1_points_proj, l2_points_proj, None],
+                [l0_xyz_proj, l1_xyz_proj, l2_xyz_proj, l3_xyz_proj])
+
+    with tf_util.variable_scope('sa1') as scope:                                                    # :117
+        pts_f1, pts_proj_f1, xyz_proj_f1 = feature_pyramid(xyz_f1_input_proj, points_f1_input_proj)
+        scope.reuse_variables()                                                                     # :143
+        pts_f2, pts_proj_f2, xyz_proj_f2 = feature_pyramid(xyz_f2_input_proj, points_f2_input_proj)
+
+    # initial cost volume at l2 and the extra set-conv on it (:170-177)
+    l2_points_f1_new = cost_volume(xyz_proj_f1[2], xyz_proj_f2[2], pts_proj_f1[2], pts_proj_f2[2],
+                                   kernel_size1=[3, 5], kernel_size2=[5, 35], nsample=4, nsample_q=32,
+                                   distance=Cost_volume_dis[2], mlp1=[128, 64, 64], mlp2=[128, 64],
+                                   is_training=is_training, bn_decay=bn_decay, scope='flow_embedding_l2_origin',
+                                   bn=True, pooling='max', knn=True, corr_func='concat')
+    l2_points_new_proj_f1 = l2_points_f1_new.reshape(batch_size, out_h_list[4], out_w_list[4], -1)
+    l3_points_f1_cost_volume, _ = down_conv(xyz_proj_f1[2], l2_points_new_proj_f1, l3_selected_idx, K_sample=16,
+                                            kernel_size=[5, 9], distance=Down_conv_dis[3], mlp=[128, 64, 64], mlp2=None,
+                                            flag_add=False, is_training=is_training, bn_decay=bn_decay,
+                                            scope='new_layer3')
+
+    # coarse pose at l3 (:183-208)
+    l3_points_predict = l3_points_f1_cost_volume
+    l3_points_predict_proj = l3_points_predict.reshape(batch_size, out_h_list[5], out_w_list[5], -1)
+    l3_cost_volume_w = flow_predictor(pts_f1[3], None, l3_points_predict, mlp=[128, 64], is_training=is_training,
+                                      bn_decay=bn_decay, scope='l3_costvolume_predict_ww')
+    l3_cost_volume_w_proj = l3_cost_volume_w.reshape(batch_size, out_h_list[5], out_w_list[5], -1)
+    l3_xyz_f1 = xyz_proj_f1[3].reshape(batch_size, -1, 3)
+    l3_points_f1_new = softmax_valid(feature_bnc=l3_points_predict, weight_bnc=l3_cost_volume_w, mask_valid=l3_xyz_f1)
+    l3_q_coarse, l3_t_coarse = _pose_head(l3_points_f1_new, 3, True, is_training)
+    l3_q, l3_t = l3_q_coarse.squeeze(1), l3_t_coarse.squeeze(1)
+
+    # three warp-refinement levels (:211-425); one loop instead of three pasted blocks
+    cv_kernel2 = {2: [5, 15], 1: [7, 25], 0: [11, 41]}                                              # :243,:317,:391
+    poses = {3: (l3_q, l3_t)}
+    q_prev, t_prev = l3_q, l3_t
+    coarse_w_proj, coarse_predict_proj, coarse_xyz_proj = l3_cost_volume_w_proj, l3_points_predict_proj, xyz_proj_f1[3]
+    for level, g in ((2, 4), (1, 3), (0, 2)):
+        q_coarse = q_prev.reshape(batch_size, 1, -1)                                                # :211-212
+        t_coarse = t_prev.reshape(batch_size, 1, -1)
+        xyz_f1 = xyz_proj_f1[level].reshape(batch_size, -1, 3)
+        # warp by the coarse pose, zero invalid points, re-project with the level's features (:217-236)
+        _warped, xyz_warp_proj_f1, points_warp_proj_f1 = warp_and_project(
+            xyz_f1, pts_f1[level], q_coarse, t_coarse, out_h_list[g], out_w_list[g])
+        xyz_warp_f1 = xyz_warp_proj_f1.reshape(batch_size, -1, 3)
+        points_warp_f1 = points_warp_proj_f1.reshape(batch_size, out_h_list[g] * out_w_list[g], -1)
+
+        cost = cost_volume(xyz_warp_proj_f1, xyz_proj_f2[level], points_warp_proj_f1, pts_proj_f2[level],
+                           kernel_size1=[3, 5], kernel_size2=cv_kernel2[level], nsample=4, nsample_q=6,
+                           distance=Cost_volume_dis[level], mlp1=[128, 64, 64], mlp2=[128, 64],
+                           is_training=is_training, bn_decay=bn_decay, scope='flow_embedding_l%d' % level,
+                           bn=True, pooling='max', knn=True, corr_func='concat')                    # :242
+        w_up_sample = up_conv(xyz_warp_proj_f1, coarse_xyz_proj, points_warp_proj_f1, coarse_w_proj,
+                              kernel_size=[7, 15], stride_h=stride_h_list[g + 1], stride_w=stride_w_list[g + 1],
+                              nsample=8, distance=Up_conv_dis[level], mlp=[128, 64], mlp2=[128, 64],
+                              scope='up_sa_layer_layer_l%dw' % level, is_training=is_training, bn_decay=bn_decay,
+                              knn=True)                                                             # :247
+        cost_up_sample = up_conv(xyz_warp_proj_f1, coarse_xyz_proj, points_warp_proj_f1, coarse_predict_proj,
+                                 kernel_size=[7, 15], stride_h=stride_h_list[g + 1], stride_w=stride_w_list[g + 1],
+                                 nsample=8, distance=Up_conv_dis[level], mlp=[128, 64], mlp2=[128, 64],
+                                 scope='up_sa_layer_layer_l%dcostvolume' % level, is_training=is_training,
+                                 bn_decay=bn_decay, knn=True)                                       # :250
+        predict = flow_predictor(points_warp_f1, cost_up_sample, cost, mlp=[128, 64], is_training=is_training,
+                                 bn_decay=bn_decay, scope='l%d_costvolume_predict' % level)         # :253
+        weight = flow_predictor(points_warp_f1, w_up_sample, cost, mlp=[128, 64], is_training=is_training,
+                                bn_decay=bn_decay, scope='l%d_w_predict' % level)                   # :254
+        summed = softmax_valid(feature_bnc=predict, weight_bnc=weight, mask_valid=xyz_warp_f1)      # :262
+        q_det, t_det = _pose_head(summed, level, False, is_training)                                # :264-273
+
+        t_coarse_trans = torch.cat([torch.zeros((batch_size, 1, 1), dtype=torch.float32, device=dev), t_coarse], -1)
+        t_coarse_trans = mul_q_point(q_det, t_coarse_trans, batch_size)
+        t_coarse_trans = mul_point_q(t_coarse_trans, inv_q(q_det, batch_size), batch_size)[:, :, 1:]   # :275-277
+        q_prev = mul_point_q(q_det, q_coarse, batch_size).squeeze(1)                                # :279
+        t_prev = (t_coarse_trans + t_det).squeeze(1)                                                # :280
+        poses[level] = (q_prev, t_prev)
+
+        coarse_w_proj = weight.reshape(batch_size, out_h_list[g], out_w_list[g], -1)                # :256-257
+        coarse_predict_proj = predict.reshape(batch_size, out_h_list[g], out_w_list[g], -1)
+        coarse_xyz_proj = xyz_warp_proj_f1
+
+    l0_xyz_f1 = xyz_proj_f1[0].reshape(batch_size, -1, 3)
+    return (_normalise_q(poses[0][0]), poses[0][1], _normalise_q(poses[1][0]), poses[1][1],
+            _normalise_q(poses[2][0]), poses[2][1], _normalise_q(poses[3][0]), poses[3][1], l0_xyz_f1)   # :427-433
+
+
+def get_model(point_cloud, H_input, W_input, T_gt, T_trans, T_trans_inv, is_training, bn_decay=None, aug_frame=None):
+    """pwclo_model.py:30-433 with the reference's signature: point_cloud (B, 2*N, >=3), three (B,4,4).
+    Returns the reference's 11-tuple."""
+    batch_size = point_cloud.shape[0]
+    num_points = point_cloud.shape[1] // 2
+    xyz_f1_input = point_cloud[:, :num_points, 0:3]
+    xyz_f2_input = point_cloud[:, num_points:, 0:3]
+    if aug_frame is None:
+        aug_frame = np.random.choice([1, 2], size=batch_size, replace=True)                         # :59
+    with torch.no_grad():                                                                           # tf.stop_gradient, :66-67
+        xyz_f1_aug, xyz_f2_aug, q_gt, t_gt = PreProcess(xyz_f1_input, xyz_f2_input, T_gt, T_trans, T_trans_inv,
+                                                        aug_frame)
+        xyz_f1_proj, _ = ProjectPC2SphericalRing(xyz_f1_aug, None, H_input, W_input)
+        xyz_f2_proj, _ = ProjectPC2SphericalRing(xyz_f2_aug, None, H_input, W_input)
+    out = get_model_from_projection(xyz_f1_proj, xyz_f2_proj, is_training, bn_decay)
+    return out + (q_gt, t_gt)
+
+
+def get_loss(l0_q, l0_t, l1_q, l1_t, l2_q, l2_t, l3_q, l3_t, q_gt, t_gt, w_x, w_q):
+    """pwclo_model.py:437-481."""
+    t_gt = t_gt.squeeze(-1)
+
+    def level(q, t):
+        q_norm = _normalise_q(q)
+        loss_q = torch.sqrt(((q_gt - q_norm) * (q_gt - q_norm)).sum(-1, keepdim=True) + 1e-10).mean()
+        loss_x = torch.sqrt((t - t_gt) * (t - t_gt) + 1e-10).mean()
+        return loss_x * torch.exp(-w_x) + w_x + loss_q * torch.exp(-w_q) + w_q
+
+    return 1.6 * level(l3_q, l3_t) + 0.8 * level(l2_q, l2_t) + 0.4 * level(l1_q, l1_t) + 0.2 * level(l0_q, l0_t)

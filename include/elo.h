@@ -85,6 +85,124 @@ typedef struct elo_group_args {
 int elo_fused_conv_random_k(const elo_group_args *a, elo_stream_t stream);
 int elo_fused_conv_select_k(const elo_group_args *a, elo_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * Feature path: fused gather / encode / pool kernels.  These replace chains of
+ * stock TF ops (tf.gather_nd, tf.tile, tf.concat, tf.where, tf.nn.softmax,
+ * tf.reduce_max/sum, tf.scatter_nd, ...) in utils/pointnet_util.py and
+ * model_util.py; each comment names the lines it covers.  "idx" is always the
+ * (batch,npoints,K,3) int32 (b,h,w) tensor produced by the grouping ops and
+ * "mask" its (batch,npoints,K) float 0/1 mask.  Features are fp32, row-major,
+ * channels last.  A masked slot gathers idx (0,0,0) and is multiplied by 0,
+ * exactly like `tf.gather_nd(...) * mask` (Appendix A.4 of SURVEY.md).
+ * ------------------------------------------------------------------------- */
+
+/* set-conv / set-upconv input:  out[b,n,k,:] = [ src_xyz[idx]*m - centre_xyz[b,n] , src_feat[idx]*m ]
+ * utils/pointnet_util.py:203-213 (down_conv) and :277-284 (up_conv). */
+typedef struct elo_group_concat_args {
+    int batch, npoints, K;
+    int H2, W2, C;                /* source grid and its feature channels */
+    const float *centre_xyz;      /* (batch,npoints,3) */
+    const float *src_xyz;         /* (batch,H2,W2,3)   */
+    const float *src_feat;        /* (batch,H2,W2,C)   */
+    const int *idx;
+    const float *mask;
+    float *out;                   /* (batch,npoints,K,3+C) */
+} elo_group_concat_args;
+int elo_group_concat(const elo_group_concat_args *a, elo_stream_t stream);
+
+/* out[b,n,c] = max_k x[b,n,k,c] * mask[b,n,k]     utils/pointnet_util.py:224-230, :295-298 */
+typedef struct elo_masked_maxpool_args {
+    int batch, npoints, K, C;
+    const float *x;               /* (batch,npoints,K,C) */
+    const float *mask;
+    float *out;                   /* (batch,npoints,C)   */
+} elo_masked_maxpool_args;
+int elo_masked_maxpool(const elo_masked_maxpool_args *a, elo_stream_t stream);
+
+/* Cost volume, stage 1 (point -> patch of frame 2), utils/pointnet_util.py:54-66:
+ *   q = xyz2[idx]*m, diff = q - p, euc = sqrt(sum(diff^2) + 1e-20)
+ *   out[b,n,k,:] = [ p(3), q(3), diff(3), euc(1), feat1[b,n](C), feat2[idx]*m (C) ]      (10+2C channels) */
+typedef struct elo_cv_encode1_args {
+    int batch, npoints, K;
+    int H2, W2, C;
+    const float *xyz1;            /* (batch,npoints,3)  warped frame-1 points      */
+    const float *feat1;           /* (batch,npoints,C)                             */
+    const float *xyz2;            /* (batch,H2,W2,3)                               */
+    const float *feat2;           /* (batch,H2,W2,C)                               */
+    const int *idx;
+    const float *mask;
+    float *out;                   /* (batch,npoints,K,10+2C) */
+} elo_cv_encode1_args;
+int elo_cv_encode1(const elo_cv_encode1_args *a, elo_stream_t stream);
+
+/* Cost volume, stage 2 (patch -> patch inside frame 1), utils/pointnet_util.py:110-129:
+ *   g = xyz1_grid[idx]*m, diff = g - p, euc as above
+ *   xyz_cat[b,n,k,:] = [ p, g, diff, euc ]                       (10 channels)
+ *   rest[b,n,k,:]    = [ feat1[b,n] (C), cost[idx]*m (Cc) ]      (C+Cc channels)
+ * (the reference concatenates conv(xyz_cat) in front of `rest`; the caller
+ *  does that product as a split GEMM, see pointnet_util.cost_volume) */
+typedef struct elo_cv_encode2_args {
+    int batch, npoints, K;
+    int H, W, C, Cc;              /* xyz1 grid (npoints == H*W), feat1 and cost channels */
+    const float *xyz1;            /* (batch,H,W,3)  */
+    const float *feat1;           /* (batch,H,W,C)  */
+    const float *cost;            /* (batch,H,W,Cc) stage-1 output */
+    const int *idx;
+    const float *mask;
+    float *xyz_cat;               /* (batch,npoints,K,10)   */
+    float *rest;                  /* (batch,npoints,K,C+Cc) */
+} elo_cv_encode2_args;
+int elo_cv_encode2(const elo_cv_encode2_args *a, elo_stream_t stream);
+
+/* out[b,n,c] = sum_k softmax_k( mask==1 ? logits : -1e10 )[k,c] * values[b,n,k,c]
+ * utils/pointnet_util.py:92-98 and :137-146.  `values` rows may be a channel
+ * slice of a wider tensor: element (row,c) is values[row*values_stride + c]. */
+typedef struct elo_softmax_pool_args {
+    int batch, npoints, K, C;
+    const float *logits;          /* (batch,npoints,K,C) */
+    const float *values;
+    int values_stride;            /* floats between consecutive (b,n,k) rows, >= C */
+    const float *mask;
+    float *out;                   /* (batch,npoints,C) */
+} elo_softmax_pool_args;
+int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_stream_t stream);
+
+/* model_util.py:319-343 softmax_valid: per batch element, softmax over the
+ * VALID points (xyz != (0,0,0)) per channel, out[b,0,c] = sum_n softmax*feature. */
+typedef struct elo_softmax_valid_args {
+    int batch, npoints, C;
+    const float *feature;         /* (batch,npoints,C) */
+    const float *weight;          /* (batch,npoints,C) */
+    const float *xyz;             /* (batch,npoints,3): a point is valid unless all three are exactly 0 */
+    float *out;                   /* (batch,1,C); all-invalid batch element -> 0 */
+} elo_softmax_valid_args;
+int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t stream);
+
+/* Pose warp + spherical re-projection.
+ *   warp : p' = ((q (x) [0,p]) (x) q^-1)[1:] + t, zeroed where p == (0,0,0)
+ *          (pwclo_model.py:213-227; model_util.py:17-69), skipped when q == NULL
+ *   project : model_util.py:181-292 ProjectPC2SphericalRing -- per point
+ *          r = |p'|, col = int((pi - atan2(y,x)) / az_res), row = H - int(asin(z/r)/vert_res + vert_off)
+ *          (NaN -> 0, the GPU float->int convention), both clipped; the point(s)
+ *          with the minimum r of a cell are SUMMED into it (tf.scatter_nd adds).
+ * az_res / vert_res / vert_off are computed by the caller exactly as
+ * model_util.py:189-200 does (python double -> float32).
+ * scratch: (batch*H*W) + 2*(batch*npoints) 32-bit device words. */
+typedef struct elo_warp_project_args {
+    int batch, npoints, C;        /* C may be 0 (no features) */
+    int H, W;
+    float az_res, vert_res, vert_off;
+    const float *xyz;             /* (batch,npoints,3) */
+    const float *feat;            /* (batch,npoints,C) or NULL */
+    const float *q;               /* (batch,4) or NULL = no warp */
+    const float *t;               /* (batch,3) */
+    float *warped;                /* (batch,npoints,3) OUT (nullable when q == NULL) */
+    float *out_xyz;               /* (batch,H,W,3) OUT */
+    float *out_feat;              /* (batch,H,W,C) OUT or NULL */
+    unsigned *scratch;
+} elo_warp_project_args;
+int elo_warp_project(const elo_warp_project_args *a, elo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

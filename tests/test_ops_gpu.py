@@ -1,0 +1,201 @@
+"""GPU parity of the operator library (set-conv, cost volume, set-upconv, flow predictor,
+softmax_valid, quaternion warp + re-projection) against the numpy restatement in oracle/ops_np.py.
+Tolerance (north_star): 1e-4 for fp32 features; neighbour indices are compared bit-exact elsewhere."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg
+from oracle import ops_np as O
+from util_params import close, export, randomise, shuffle_fn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ctx():
+    tf_util, perm = load_pkg("tf_util"), load_pkg("perm")
+    store = tf_util.VariableStore(DEV, seed=1)
+    return tf_util, perm, store, perm.PermSource(fn=shuffle_fn)
+
+
+def _run(fn, store, perms):
+    """Run once to create variables, randomise them, run again for the checked result."""
+    tf_util, perm = load_pkg("tf_util"), load_pkg("perm")
+    with tf_util.default_store(store), perm.default_perm_source(perms), torch.no_grad():
+        fn()
+        randomise(store, seed=3)
+        out = fn()
+    torch.cuda.synchronize()
+    return out
+
+
+def _scene(B, H, W, seed, C=None):
+    synth = load_pkg("synth")
+    f1, f2 = synth.frame_pair(B, H, W, seed=seed)
+    rng = np.random.default_rng(seed)
+    feats = None
+    if C:
+        feats = [rng.normal(0, 1, (B, H, W, C)).astype(np.float32) for _ in range(2)]
+    return f1, f2, feats
+
+
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("B,H,W,C,K,ks,dist,mlp", [(1, 16, 225, 16, 32, [7, 11], 3.0, [16, 16, 32]),
+                                                   (2, 8, 113, 32, 16, [5, 9], 6.0, [32, 32, 64]),
+                                                   (1, 64, 450, 3, 32, [9, 15], 0.5, [8, 8, 16])])
+def test_down_conv(B, H, W, C, K, ks, dist, mlp):
+    pu, mu = load_pkg("pointnet_util"), load_pkg("model_util")
+    _, _, store, perms = _ctx()
+    f1, _, feats = _scene(B, H, W, 11, C)
+    oh, ow = (H + 1) // 2, (W + 1) // 2
+    sel_np = O.get_selected_idx(B, 2, 2, oh, ow)
+    xyz, pts = t(f1), t(feats[0])
+    sel = mu.get_selected_idx(xyz, 2, 2, oh, ow)
+    assert np.array_equal(sel.cpu().numpy(), sel_np)
+    got = _run(lambda: pu.down_conv(xyz, pts, sel, K_sample=K, kernel_size=ks, distance=dist, mlp=mlp, mlp2=None,
+                                    flag_add=False, is_training=False, bn_decay=None, scope='layerX'), store, perms)
+    want = O.down_conv(export(store), shuffle_fn, f1, feats[0], sel_np, K, ks, dist, mlp, "layerX")
+    close(got[0], want[0])
+    close(got[1], want[1], atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("B,H,W,C,Kq,ks2,dist", [(1, 4, 57, 64, 32, [5, 35], 4.0), (2, 8, 113, 32, 6, [7, 25], 2.0),
+                                                 (1, 16, 225, 16, 6, [11, 41], 1.0)])
+def test_cost_volume(B, H, W, C, Kq, ks2, dist):
+    pu = load_pkg("pointnet_util")
+    _, _, store, perms = _ctx()
+    f1, f2, feats = _scene(B, H, W, 21, C)
+    a = [t(x) for x in (f1, f2, feats[0], feats[1])]
+    got = _run(lambda: pu.cost_volume(a[0], a[1], a[2], a[3], kernel_size1=[3, 5], kernel_size2=ks2, nsample=4,
+                                      nsample_q=Kq, distance=dist, mlp1=[128, 64, 64], mlp2=[128, 64],
+                                      is_training=False, bn_decay=None, scope='flow_embedding_t', bn=True,
+                                      pooling='max', knn=True, corr_func='concat'), store, perms)
+    want = O.cost_volume(export(store), shuffle_fn, f1, f2, feats[0], feats[1], [3, 5], ks2, 4, Kq, dist,
+                         [128, 64, 64], [128, 64], "flow_embedding_t")
+    close(got, want)
+
+
+def test_cost_volume_all_masked_is_uniform_softmax():
+    """Every neighbour masked (frame 2 empty): softmax over K of identical -1e10 logits is uniform 1/K
+     -- must not produce NaN."""
+    pu = load_pkg("pointnet_util")
+    _, _, store, perms = _ctx()
+    f1, _, feats = _scene(1, 4, 57, 5, 8)
+    f2 = np.zeros_like(f1)
+    a = [t(x) for x in (f1, f2, feats[0], feats[1])]
+    got = _run(lambda: pu.cost_volume(a[0], a[1], a[2], a[3], kernel_size1=[3, 5], kernel_size2=[5, 15], nsample=4,
+                                      nsample_q=6, distance=4.0, mlp1=[128, 64, 64], mlp2=[128, 64],
+                                      is_training=False, bn_decay=None, scope='cv_empty'), store, perms)
+    want = O.cost_volume(export(store), shuffle_fn, f1, f2, feats[0], feats[1], [3, 5], [5, 15], 4, 6, 4.0,
+                         [128, 64, 64], [128, 64], "cv_empty")
+    assert torch.isfinite(got).all()
+    close(got, want)
+
+
+@pytest.mark.parametrize("B,H,W,sh,sw,C1,dist", [(1, 4, 57, 1, 2, 64, 9.0), (2, 8, 113, 2, 2, 32, 6.0),
+                                                 (1, 16, 225, 2, 2, 16, 3.0)])
+def test_up_conv(B, H, W, sh, sw, C1, dist):
+    pu = load_pkg("pointnet_util")
+    _, _, store, perms = _ctx()
+    f1, _, feats = _scene(B, H, W, 31, C1)
+    H2, W2 = -(-H // sh), -(-W // sw)
+    sparse_xyz = np.ascontiguousarray(f1[:, ::sh, ::sw][:, :H2, :W2])
+    sparse_feat = np.random.default_rng(2).normal(0, 1, (B, H2, W2, 64)).astype(np.float32)
+    a = [t(x) for x in (f1, sparse_xyz, feats[0], sparse_feat)]
+    got = _run(lambda: pu.up_conv(a[0], a[1], a[2], a[3], kernel_size=[7, 15], stride_h=sh, stride_w=sw, nsample=8,
+                                  distance=dist, mlp=[128, 64], mlp2=[128, 64], scope='up_t', is_training=False,
+                                  bn_decay=None, knn=True), store, perms)
+    want = O.up_conv(export(store), shuffle_fn, f1, sparse_xyz, feats[0], sparse_feat, [7, 15], sh, sw, 8, dist,
+                     [128, 64], [128, 64], "up_t")
+    close(got, want)
+
+
+def test_flow_predictor_none_combinations():
+    pu = load_pkg("pointnet_util")
+    rng = np.random.default_rng(0)
+    a, b, c = (rng.normal(0, 1, (2, 116, n)).astype(np.float32) for n in (128, 64, 64))
+    for name, args in (("fp_ac", (a, None, c)), ("fp_ab", (a, b, None)), ("fp_abc", (a, b, c))):
+        _, _, store, perms = _ctx()
+        ta = [None if x is None else t(x) for x in args]
+        got = _run(lambda: pu.flow_predictor(ta[0], ta[1], ta[2], mlp=[128, 64], is_training=False, bn_decay=None,
+                                             scope=name), store, perms)
+        want = O.flow_predictor(export(store), args[0], args[1], args[2], [128, 64], name)
+        close(got, want)
+
+
+def test_softmax_valid():
+    mu = load_pkg("model_util")
+    rng = np.random.default_rng(4)
+    B, N, C = 3, 904, 64
+    f = rng.normal(0, 1, (B, N, C)).astype(np.float32)
+    w = rng.normal(0, 3, (B, N, C)).astype(np.float32)
+    xyz = rng.normal(0, 5, (B, N, 3)).astype(np.float32)
+    xyz[rng.random((B, N)) < 0.3] = 0
+    xyz[2] = 0                                            # a batch element without any valid point -> zeros
+    valid = ~np.all(xyz == 0, -1)
+    want = O.softmax_valid(f, w, valid)
+    close(mu.softmax_valid(t(f), t(w), t(xyz)), want, atol=1e-5)
+    close(mu.softmax_valid(t(f), t(w), torch.from_numpy(valid).to(DEV)), want, atol=1e-5)
+
+
+def test_quaternion_ops_and_pose_composition():
+    mu = load_pkg("model_util")
+    rng = np.random.default_rng(6)
+    B, N = 2, 50
+    q = rng.normal(0, 1, (B, 1, 4)).astype(np.float32)
+    p = rng.normal(0, 1, (B, N, 4)).astype(np.float32)
+    close(mu.mul_q_point(t(q), t(p), B), O.mul_q_point(q, p, B), atol=1e-6)
+    close(mu.mul_point_q(t(p), t(q), B), O.mul_point_q(p, q, B), atol=1e-6)
+    close(mu.inv_q(t(q), B), O.inv_q(q, B), atol=1e-6)
+
+
+def _boundary_safe_points(rng, B, N, H, W):
+    """Points whose (row, col) sit well inside their cell, so 1-ulp differences between libm
+    implementations of atan2/asin cannot move them to a neighbouring cell."""
+    az_res, vres, voff = (float(x) for x in O.projection_constants(H, W))
+    col = rng.integers(0, W, (B, N)) + rng.uniform(0.2, 0.8, (B, N))
+    rowf = rng.integers(1, H, (B, N)) + rng.uniform(0.2, 0.8, (B, N))       # tmp_int in [1, H): row = H - int(.)
+    az = np.pi - col * az_res
+    beta = (rowf - voff) * vres
+    r = rng.uniform(3, 30, (B, N))
+    return np.stack([r * np.cos(beta) * np.cos(az), r * np.cos(beta) * np.sin(az), r * np.sin(beta)], -1).astype(np.float32)
+
+
+@pytest.mark.parametrize("H,W,N,C", [(4, 57, 228, 64), (16, 225, 3600, 16), (64, 1800, 150000, 0)])
+def test_project_spherical_ring(H, W, N, C):
+    mu = load_pkg("model_util")
+    rng = np.random.default_rng(8)
+    B = 2
+    pc = _boundary_safe_points(rng, B, N, H, W)
+    pc[rng.random((B, N)) < 0.1] = 0                       # empty points all land in one cell and blank it
+    feat = rng.normal(0, 1, (B, N, C)).astype(np.float32) if C else None
+    got = mu.ProjectPC2SphericalRing(t(pc), t(feat) if C else None, H, W)
+    want = O.ProjectPC2SphericalRing(pc, feat, H, W)
+    close(got[0], want[0], atol=1e-5)
+    if C:
+        close(got[1], want[1], atol=1e-5)
+
+
+def test_warp_and_project():
+    mu = load_pkg("model_util")
+    rng = np.random.default_rng(9)
+    B, H, W, C = 2, 8, 113, 32
+    N = H * W
+    # warp with a small rotation; then nudge points off cell borders by testing only cells that agree
+    pc = _boundary_safe_points(rng, B, N, H, W)
+    pc[rng.random((B, N)) < 0.1] = 0
+    feat = rng.normal(0, 1, (B, N, C)).astype(np.float32)
+    q = np.array([[[1.0, 0.002, -0.001, 0.004]], [[0.999, -0.003, 0.002, 0.01]]], np.float32)
+    tt = np.array([[[0.5, 0.05, -0.02]], [[-0.3, 0.1, 0.01]]], np.float32)
+    warped, xyz_proj, feat_proj = mu.warp_and_project(t(pc), t(feat), t(q), t(tt), H, W)
+    want_warped = O.warp(pc, q, tt)
+    close(warped, want_warped, atol=1e-5)
+    # project the GPU's own warped points with the oracle: isolates the projection from 1-ulp warp noise
+    w_xyz, w_feat = O.ProjectPC2SphericalRing(warped.cpu().numpy(), feat, H, W)
+    got_xyz, got_feat = xyz_proj.cpu().numpy(), feat_proj.cpu().numpy()
+    same = np.isclose(got_xyz, w_xyz, atol=1e-5).all(-1)
+    assert same.mean() > 0.995, same.mean()                # cell flips only for points on a cell border
+    assert np.isclose(got_feat[same], w_feat[same], atol=1e-5).all()
