@@ -181,6 +181,17 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_kernel(const elo_soft
 }
 
 // ------------------------------------------------------------ warp + spherical re-projection
+__global__ __launch_bounds__(ELO_BLOCK) void project_init_kernel(unsigned *minr, float *out_xyz, float *out_feat,
+                                                                 size_t cells, int C)
+{
+    const size_t n_xyz = cells * 3, n_feat = cells * (size_t)C, total = cells + n_xyz + n_feat;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < cells) minr[i] = 0x7f7f7f7fu;
+        else if (i < cells + n_xyz) out_xyz[i - cells] = 0.0f;
+        else out_feat[i - cells - n_xyz] = 0.0f;
+    }
+}
+
 // pass A: one thread per point -> warped xyz, range bits, cell id, atomicMin of the cell's range.
 __global__ __launch_bounds__(ELO_BLOCK) void warp_cell_kernel(const elo_warp_project_args a, unsigned *minr,
                                                               int *cell_of, unsigned *rbits)
@@ -337,11 +348,14 @@ extern "C" int elo_warp_project(const elo_warp_project_args *a, elo_stream_t str
     unsigned *minr = a->scratch;
     int *cell_of = (int *)(a->scratch + cells);
     unsigned *rbits = a->scratch + cells + pts;
-    // 0x7f7f7f7f = 3.39e38f: above every finite range, below NaN bit patterns
-    if (hipMemsetAsync(minr, 0x7f, cells * sizeof(unsigned), s) != hipSuccess ||
-        hipMemsetAsync(a->out_xyz, 0, cells * 3 * sizeof(float), s) != hipSuccess ||
-        (a->C && hipMemsetAsync(a->out_feat, 0, cells * a->C * sizeof(float), s) != hipSuccess))
-        return fail(ELO_ERR_LAUNCH, "%s: hipMemsetAsync failed", who);
+    // one init launch instead of three memsets (memset nodes inside a captured hipGraph proved unreliable):
+    // minr <- 0x7f7f7f7f (3.39e38f: above every finite range, below NaN bit patterns), outputs <- 0
+    {
+        const size_t words = cells * (1 + 3 + (size_t)a->C);
+        const unsigned gi = (unsigned)((words + ELO_BLOCK - 1) / ELO_BLOCK);
+        hipLaunchKernelGGL(project_init_kernel, dim3(gi > 4096 ? 4096 : gi), dim3(ELO_BLOCK), 0, s, minr, a->out_xyz,
+                           a->out_feat, cells, a->C);
+    }
     const unsigned ga = (unsigned)((pts + ELO_BLOCK - 1) / ELO_BLOCK);
     hipLaunchKernelGGL(warp_cell_kernel, dim3(ga > 4096 ? 4096 : ga), dim3(ELO_BLOCK), 0, s, *a, minr, cell_of, rbits);
     const size_t elems = pts * (3 + a->C);

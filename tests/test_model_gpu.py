@@ -1,0 +1,62 @@
+"""GPU parity of the whole pyramid (pwclo_model.get_model_from_projection) against the numpy
+restatement, eager and through the captured HIP graph.  Tolerance: 1e-4 on the normalised
+quaternions and translations (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg
+from oracle import ops_np as O
+from util_params import close, export, randomise, shuffle_fn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _net():
+    model, perm = load_pkg("model"), load_pkg("perm")
+    return model.PWCLONet(DEV, seed=5, perm_source=perm.PermSource(fn=shuffle_fn))
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 64, 1800), (2, 64, 900)])
+def test_full_pyramid_matches_oracle(B, H, W):
+    synth = load_pkg("synth")
+    f1, f2 = synth.frame_pair(B, H, W, seed=40)
+    net = _net()
+    a, b = torch.from_numpy(f1).to(DEV), torch.from_numpy(f2).to(DEV)
+    net.forward(a, b)                       # creates the variables
+    randomise(net.store, seed=7)
+    got = net.forward(a, b)
+    torch.cuda.synchronize()
+    want = O.get_model_from_projection(export(net.store), shuffle_fn, f1, f2)
+    names = ["l0_q", "l0_t", "l1_q", "l1_t", "l2_q", "l2_t", "l3_q", "l3_t", "l0_xyz_f1"]
+    for n, g, w_ in zip(names, got, want):
+        assert torch.isfinite(g).all(), n
+        close(g, w_, atol=1e-4, rtol=1e-4)
+    # variable names/shapes are those of the shipped checkpoint index
+    shapes = net.store.tf_shapes
+    assert shapes["sa1/layer0/conv0/weights"] == (1, 1, 6, 8)
+    assert shapes["flow_embedding_l0/CV_0/weights"] == (1, 1, 42, 128)
+    assert shapes["flow_embedding_l1/sum_cost_volume_0/weights"] == (1, 1, 160, 128)
+    assert shapes["l0_big/weights"] == (1, 64, 256) and shapes["l3_q_coarse/weights"] == (1, 256, 4)
+    assert shapes["up_sa_layer_layer_l0w/up_2_0/weights"] == (1, 1, 80, 128)
+    n_train = sum(int(np.prod(p.shape)) for p in net.store.params.values())
+    assert len(net.store.params) == 380 and n_train == 899132      # 382 / 899134 with the loss scalars w_x, w_q
+
+
+def test_graph_replay_equals_eager():
+    synth = load_pkg("synth")
+    net = _net()
+    f1, f2 = synth.frame_pair(1, 64, 1800, seed=41)
+    a, b = torch.from_numpy(f1).to(DEV), torch.from_numpy(f2).to(DEV)
+    eager = [x.clone() for x in net.forward(a, b)]
+    net.capture(1, 64, 1800)
+    for rep in range(2):
+        out = net(a, b)
+        torch.cuda.synchronize()
+        for e, o in zip(eager, out):
+            assert torch.equal(e, o)
+    g1, g2 = synth.frame_pair(1, 64, 1800, seed=43)
+    out2 = [x.clone() for x in net(torch.from_numpy(g1).to(DEV), torch.from_numpy(g2).to(DEV))]
+    torch.cuda.synchronize()
+    assert not torch.equal(out2[1], eager[1])
