@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py -- frame-pairs/s of the EfficientLO-Net hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W] [--batch B --height H --width W]
+
+Workload (BASELINE.json configs[1]): the full 4-level PWC pyramid -- Siamese set-conv
+pyramid, initial attentive cost volume, coarse pose, three warp-refinement levels
+(warp + re-projection + cost volume + 2x set-upconv + pose head) -- on synthetic
+KITTI-shaped 64x1800 range-image pairs, batch 1, fp32, random-init weights.
+A "step" is one forward pass over one batch of pairs already resident in HBM
+(a pool of pre-generated pairs; each step copies the next pair into the captured
+graph's input buffers, device-to-device, inside the timed region).
+
+One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE); frame pairs are
+independent, so ranks shard the stream with no data-path collective; the poses of a
+step are all-gathered (7 floats per pair) once per step so rank 0 can chain them
+(main.py:557-572), which is the only exchange the path has.  scaling = weak.
+
+Besides the contract line this prints, on rank 0 at N=1:
+  roofline     -- the dominant hand-written cost-volume kernel timed live with HIP events
+  cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on a bounded sample
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def pkg(sub=None):
+    return importlib.import_module("efficientlo-net_amd" + ("." + sub if sub else ""))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="frame pairs per step per GPU (configs[1]: 1)")
+    ap.add_argument("--height", type=int, default=64)
+    ap.add_argument("--width", type=int, default=1800)
+    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic pairs kept in HBM")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs in the CPU-oracle sample")
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------- roofline leg
+def cost_volume_bytes(N, C, Kq, Kp, s=4):
+    """algorithmic bytes of the four cost-volume kernels per batch element."""
+    A1 = 2 * N * 12 + 2 * N * C * s + N * Kq * 16 + N * Kq * (10 + 2 * C) * s
+    P1 = 2 * N * Kq * 64 * s + N * Kq * 4 + N * 64 * s
+    A2 = N * 12 + N * C * s + N * 64 * s + N * Kp * 16 + N * Kp * (10 + C + 64) * s
+    P2 = 2 * N * Kp * 64 * s + N * Kp * 4 + N * 64 * s
+    return dict(A1=A1, P1=P1, A2=A2, P2=P2)
+
+
+def roofline_leg(args, dev, reps=200):
+    """Time the dominant cost-volume kernel (the stage-1 masked-softmax pool at l0: the largest
+    algorithmic-byte term, P1) with HIP events on the stream it is launched on."""
+    ops = pkg("_ops")
+    pm = pkg("pwclo_model")
+    oh, ow = pm.pyramid_sizes(args.height, args.width)
+    B, N, Kq, C = args.batch, oh[2] * ow[2], 6, 64
+    g = torch.Generator(device="cpu").manual_seed(0)
+    logits = torch.randn((B, N, Kq, C), generator=g).to(dev)
+    values = torch.randn((B, N, Kq, C), generator=g).to(dev)
+    mask = (torch.rand((B, N, Kq), generator=g) > 0.1).float().to(dev)
+    for _ in range(10):
+        ops.masked_softmax_pool(logits, values, mask)
+    torch.cuda.synchronize(dev)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()                      # torch's current stream == the stream _lib.stream_ptr() hands to the C ABI
+    for _ in range(reps):
+        ops.masked_softmax_pool(logits, values, mask)
+    stop.record()
+    torch.cuda.synchronize(dev)
+    sec = start.elapsed_time(stop) / 1e3 / reps
+    nbytes = cost_volume_bytes(N, 16, Kq, 4)["P1"] * B
+    gbs = nbytes / sec / 1e9
+    return {"bound": "hbm", "kernel": "softmax_pool_kernel (cost volume stage 1, l0)", "achieved": round(gbs, 2),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+            "bytes_per_launch": int(nbytes), "us_per_launch": round(sec * 1e6, 3)}
+
+
+# ----------------------------------------------------------------------------- CPU baseline leg
+def cpu_baseline_leg(args, net, pairs):
+    """The numpy/C restatement of the SAME forward (oracle/, kind 'port'), one core, on `pairs` pairs."""
+    from threadpoolctl import threadpool_limits
+
+    from oracle import ops_np as O
+    synth = pkg("synth")
+    params = {k: v.detach().cpu().numpy() for k, v in net.store.state_dict().items()}
+    rng_perm = {}
+
+    def shuffle(scope, tag, KT):
+        key = (scope, tag, KT)
+        if key not in rng_perm:
+            rng_perm[key] = np.random.default_rng(len(rng_perm)).permutation(KT).astype(np.int32)
+        return rng_perm[key]
+
+    f1, f2 = synth.frame_pair(1, args.height, args.width, seed=900)
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        for _ in range(pairs):
+            O.get_model_from_projection(params, shuffle, f1, f2)
+        sec = time.perf_counter() - t0
+    return {"value": round(pairs / sec, 4), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": "%d x one %dx%d pair through oracle/ops_np.get_model_from_projection (numpy fp32 + C "
+                      "grouping oracle), single thread, %.1f s" % (pairs, args.height, args.width, sec)}
+
+
+# ----------------------------------------------------------------------------- main
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)     # nccl == RCCL on ROCm
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    model, synth = pkg("model"), pkg("synth")
+    net = model.PWCLONet(dev, seed=0)
+    B, H, W = args.batch, args.height, args.width
+    pool = []
+    for i in range(args.pool):                       # inputs resident in HBM before the timed region
+        f1, f2 = synth.frame_pair(B, H, W, seed=1000 * rank + 10 * i)
+        pool.append((torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev)))
+    if args.no_graph:
+        net.forward(*pool[0])
+    else:
+        net.capture(B, H, W)
+    gathered = [torch.empty((B, 7), device=dev) for _ in range(world)] if world > 1 else None
+
+    def step(i):
+        a, b = pool[i % len(pool)]
+        out = net(a, b)
+        if world > 1:                                # poses of this step to every rank (7 floats per pair)
+            dist.all_gather(gathered, torch.cat([out[0], out[1]], -1))
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    line = {
+        "metric": "frame-pairs/sec (KITTI 64x1800 range image)" if (H, W) == (64, 1800)
+                  else "frame-pairs/sec (%dx%d range image)" % (H, W),
+        "value": round(world * B * args.steps / elapsed, 3),
+        "unit": "frame-pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "full 4-level PWC pyramid (set-conv + attentive cost volume + warp-refinement + "
+                               "set-upconv), %dx%d range-image pairs, batch %d per GPU, fp32, random-init weights, "
+                               "%s" % (H, W, B, "eager launches" if args.no_graph else "hipGraph replay"),
+                   "global_batch": B * world, "parallelism": "dp%d" % world},
+    }
+    if rank == 0 and world == 1:
+        line["roofline"] = roofline_leg(args, dev)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_leg(args, net, args.cpu_pairs)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,55 @@ def pyramid_sizes(H_input, W_input):
     return out_h, out_w
 
 
+def variable_specs():
+    """Every conv layer of the model as (scope, Cin, Cout, tf_kernel_dims, has_bn), in creation order.
+    Matches the shipped checkpoint index name for name (tests/golden/ckpt_index_shapes.json,
+    SURVEY.md Appendix B); lets a VariableStore be populated without running a forward pass."""
+    specs = []
+
+    def chain(prefix, names, cin, couts, bn=True, dims=(1, 1)):
+        for n, cout in zip(names, couts):
+            specs.append((prefix + n, cin, cout, dims, bn))
+            cin = cout
+
+    conv3 = ['conv0', 'conv1', 'conv2']
+    chain('sa1/layer0/', conv3, 3 + 3, [8, 8, 16])                  # pwclo_model.py:126
+    chain('sa1/layer1/', conv3, 3 + 16, [16, 16, 32])               # :130
+    chain('sa1/layer2/', conv3, 3 + 32, [32, 32, 64])               # :134
+    chain('sa1/layer3/', conv3, 3 + 64, [64, 64, 128])              # :138
+    for scope, C in (('flow_embedding_l2_origin', 64), ('flow_embedding_l2', 64), ('flow_embedding_l1', 32),
+                     ('flow_embedding_l0', 16)):                    # :170,:242,:316,:390
+        chain(scope + '/', ['CV_0', 'CV_1', 'CV_2'], 10 + 2 * C, [128, 64, 64])
+        chain(scope + '/', ['CV_xyz'], 10, [64])
+        chain(scope + '/', ['sum_CV_0', 'sum_CV_1'], 128, [128, 64])
+        chain(scope + '/', ['sum_xyz_encoding'], 10, [64])
+        chain(scope + '/', ['sum_cost_volume_0', 'sum_cost_volume_1'], 64 + C + 64, [128, 64])
+    chain('new_layer3/', conv3, 3 + 64, [128, 64, 64])              # :177
+    pred = ['conv_predictor0', 'conv_predictor1']
+    chain('l3_costvolume_predict_ww/', pred, 128 + 64, [128, 64])   # :187
+    for level, C in ((2, 64), (1, 32), (0, 16)):
+        for kind in ('w', 'costvolume'):                            # :247,:250
+            chain('up_sa_layer_layer_l%d%s/' % (level, kind), ['up_1_0', 'up_1_1'], 3 + 64, [128, 64])
+            chain('up_sa_layer_layer_l%d%s/' % (level, kind), ['up_2_0', 'up_2_1'], 64 + C, [128, 64])
+        chain('l%d_costvolume_predict/' % level, pred, C + 64 + 64, [128, 64])      # :253
+        chain('l%d_w_predict/' % level, pred, C + 64 + 64, [128, 64])               # :254
+    for level in (3, 2, 1, 0):                                      # :197-208, :264-273
+        heads = ('q_coarse', 't_coarse') if level == 3 else ('q_det', 't_det')
+        specs.append(('l%d_big' % level, 64, 256, (1,), False))
+        specs.append(('l%d_%s' % (level, heads[0]), 256, 4, (1,), False))
+        specs.append(('l%d_%s' % (level, heads[1]), 256, 3, (1,), False))
+    return specs
+
+
+def create_variables(store=None):
+    """Populate the active (or given) VariableStore with every variable of the model."""
+    store = store if store is not None else tf_util.get_store()
+    with tf_util.default_store(store):
+        for scope, cin, cout, dims, bn in variable_specs():
+            tf_util.dense_variables(scope, cin, cout, dims, bn)
+    return store
+
+
 def placeholder_inputs(batch_size, NUM_POINTS, device="cuda"):
     """pwclo_model.py:19-27: zero tensors of the feed shapes."""
     z = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)

@@ -1,0 +1,113 @@
+"""CPU: host-side logic that needs no GPU -- variable table vs the shipped checkpoint index,
+pyramid sizes, the C-ABI library exporting every declared symbol, loud failure on CPU tensors,
+the synthetic generator, the visiting-order source."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, load_pkg
+
+
+def test_variable_table_matches_checkpoint_index():
+    """382 trainable tensors / 899 134 values incl. the two loss scalars."""
+    with open(os.path.join(GOLDEN, "ckpt_index_shapes.json")) as f:
+        ckpt = json.load(f)
+    pm, tf_util = load_pkg("pwclo_model"), load_pkg("tf_util")
+    store = pm.create_variables(tf_util.VariableStore("cpu", seed=0))
+    mine = dict(store.tf_shapes)
+    theirs = {k: tuple(v) for k, v in ckpt.items() if k not in ("Variable", "w_x", "w_q")}
+    assert set(mine) == set(theirs), (sorted(set(mine) ^ set(theirs))[:8])
+    for k in mine:
+        assert tuple(mine[k]) == theirs[k], k
+    n_train = sum(int(np.prod(p.shape)) for p in store.params.values())
+    assert len(store.params) + 2 == 382 and n_train + 2 == 899134
+    assert sum(int(np.prod(b.shape)) for b in store.buffers.values()) == 14912
+
+
+def test_pyramid_sizes():
+    pm = load_pkg("pwclo_model")
+    assert pm.pyramid_sizes(64, 1800) == ([64, 64, 16, 8, 4, 4], [1800, 1800, 225, 113, 57, 29])
+    assert pm.pyramid_sizes(128, 2048) == ([128, 128, 32, 16, 8, 8], [2048, 2048, 256, 128, 64, 32])
+
+
+def test_library_exports_every_declared_symbol():
+    """Every `int elo_*(` / `const char *elo_*(` prototype in include/elo.h resolves in libelo_hip.so,
+    and the ctypes table binds exactly that set (no compute calls: there is no GPU here)."""
+    L = load_pkg("_lib")
+    header = open(os.path.join(ROOT, "include", "elo.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*(elo_\w+)\s*\(", header, flags=re.M))
+    assert declared == {name for name, _, _ in L.SYMBOLS}
+    lib = L.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.elo_abi_version() == 1
+    assert lib.elo_last_error() == b"" or isinstance(lib.elo_last_error(), bytes)
+
+
+def test_argument_validation_without_a_gpu():
+    """The C entry points validate before launching: bad arguments come back as ELO_ERR_ARG/-LIMIT
+    with the reference op's wording, without touching a device."""
+    L = load_pkg("_lib")
+    lib = L.lib()
+    a = L.GroupArgs(1, 4, 8, 4, 8, 0, 3, 5, 4, 0, 1.0, 1, 1, None, None, None, None, None, None, None, None)
+    assert lib.elo_fused_conv_random_k(ctypes.byref(a), None) == -1
+    assert b"positive npoints" in lib.elo_last_error()
+    a.npoints, a.kernel_h, a.kernel_w = 2, 71, 71
+    assert lib.elo_fused_conv_select_k(ctypes.byref(a), None) == -2
+    assert b"exceeds 5000" in lib.elo_last_error()
+    a.kernel_h, a.kernel_w = 3, 19                     # kernel_w/2 = 9 > W2 = 8
+    assert lib.elo_fused_conv_select_k(ctypes.byref(a), None) == -2
+    a.kernel_w = 5
+    assert lib.elo_fused_conv_select_k(ctypes.byref(a), None) == -1 and b"null tensor" in lib.elo_last_error()
+
+
+def test_hot_path_fails_loudly_on_cpu_tensors():
+    elo, ops = load_pkg(), load_pkg("_ops")
+    x = torch.zeros(1, 4, 8, 3)
+    idx = torch.zeros(1, 2, 2, dtype=torch.int32)
+    perm = torch.arange(15, dtype=torch.int32)
+    with pytest.raises(Exception, match="no CPU fallback"):
+        elo.fused_conv_select_k(x, x, idx, perm, 4, 8, 2, 3, 5, 4, 0, 1.0, 1, 1)
+    with pytest.raises(Exception, match="no CPU fallback"):
+        ops.masked_maxpool(torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "efficientlo-net_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "libelo_oracle" not in text, fn
+
+
+def test_synthetic_scene_properties():
+    synth = load_pkg("synth")
+    f1, f2 = synth.frame_pair(2, 64, 1800, seed=3)
+    assert f1.shape == f2.shape == (2, 64, 1800, 3) and f1.dtype == np.float32
+    empty = (f1 == 0).all(-1)
+    assert 0.03 < empty.mean() < 0.6
+    assert (np.hypot(f1[..., 0], f1[..., 1]) <= 35.0 + 1e-3).all()          # 35 m crop, model_util.py:380-383
+    g1, _ = synth.frame_pair(2, 64, 1800, seed=3)
+    assert np.array_equal(f1, g1)                                           # seeded
+    idx = synth.hw_index(2, 4, 5)
+    assert idx.shape == (2, 20, 2) and idx[0, 7].tolist() == [1, 2]
+    assert synth.strided_index(1, 2, 3, 4, 8)[0].tolist() == [[0, 0], [0, 8], [0, 16], [4, 0], [4, 8], [4, 16]]
+
+
+def test_perm_source_fixed_and_reshuffle():
+    perm = load_pkg("perm")
+    src = perm.PermSource(seed=1)
+    a = src.get("s", "t", 45, "cpu")
+    assert sorted(a.tolist()) == list(range(45)) and a.dtype == torch.int32
+    assert src.get("s", "t", 45, "cpu") is a                                # fixed: same buffer
+    before, ptr = a.clone(), a.data_ptr()
+    src.reshuffle()
+    assert a.data_ptr() == ptr and sorted(a.tolist()) == list(range(45)) and not torch.equal(a, before)
+    hooked = perm.PermSource(fn=lambda scope, tag, KT: np.arange(KT)[::-1])
+    assert hooked.get("x", "y", 5, "cpu").tolist() == [4, 3, 2, 1, 0]
