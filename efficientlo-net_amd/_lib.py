@@ -43,7 +43,13 @@ SoftmaxPoolArgs = _struct("elo_softmax_pool_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("C", _i), ("logits", _vp), ("values", _vp),
     ("values_stride", _i), ("mask", _vp), ("out", _vp)])
 SoftmaxValidArgs = _struct("elo_softmax_valid_args", [
-    ("batch", _i), ("npoints", _i), ("C", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp), ("out", _vp)])
+    ("batch", _i), ("npoints", _i), ("C", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp), ("out", _vp),
+    ("scratch", _vp)])
+SV_MAX_PARTS = 64      # ELO_SV_MAX_PARTS
+PoseHeadArgs = _struct("elo_pose_head_args", [
+    ("batch", _i), ("npoints", _i), ("C", _i), ("hidden", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp),
+    ("W_big", _vp), ("b_big", _vp), ("W_q", _vp), ("b_q", _vp), ("W_t", _vp), ("b_t", _vp),
+    ("q_coarse", _vp), ("t_coarse", _vp), ("q", _vp), ("t", _vp), ("q_norm", _vp), ("scratch", _vp)])
 WarpProjectArgs = _struct("elo_warp_project_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("H", _i), ("W", _i),
     ("az_res", _f), ("vert_res", _f), ("vert_off", _f),
@@ -62,6 +68,7 @@ SYMBOLS = [
     ("elo_cv_encode2", ctypes.c_int, [ctypes.POINTER(CvEncode2Args), _vp]),
     ("elo_masked_softmax_pool", ctypes.c_int, [ctypes.POINTER(SoftmaxPoolArgs), _vp]),
     ("elo_softmax_valid", ctypes.c_int, [ctypes.POINTER(SoftmaxValidArgs), _vp]),
+    ("elo_pose_head", ctypes.c_int, [ctypes.POINTER(PoseHeadArgs), _vp]),
     ("elo_warp_project", ctypes.c_int, [ctypes.POINTER(WarpProjectArgs), _vp]),
 ]
 

@@ -94,9 +94,34 @@ def softmax_valid(feature_bnc, weight_bnc, xyz_bn3):
     feature_bnc, weight_bnc, xyz_bn3 = _f32(feature_bnc, weight_bnc, xyz_bn3)
     B, N, C = feature_bnc.shape
     out = torch.empty((B, 1, C), dtype=torch.float32, device=feature_bnc.device)
-    a = L.SoftmaxValidArgs(B, N, C, feature_bnc.data_ptr(), weight_bnc.data_ptr(), xyz_bn3.data_ptr(), out.data_ptr())
+    scratch = torch.empty((3 * B * L.SV_MAX_PARTS * C,), dtype=torch.float32, device=feature_bnc.device)
+    a = L.SoftmaxValidArgs(B, N, C, feature_bnc.data_ptr(), weight_bnc.data_ptr(), xyz_bn3.data_ptr(), out.data_ptr(),
+                           scratch.data_ptr())
     L.call("elo_softmax_valid", a, out)
     return out
+
+
+def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse=None, t_coarse=None):
+    """softmax_valid -> conv1d(256) -> q,t heads -> normalise -> compose with the coarse pose, two launches.
+    pwclo_model.py:194-208 / :262-280.  Returns (q (B,4), t (B,3), q_norm (B,4))."""
+    L.require_gpu(feature_bnc, weight_bnc, xyz_bn3, W_big, W_q, W_t, q_coarse, t_coarse)
+    feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t = _f32(
+        feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t)
+    B, N, C = feature_bnc.shape
+    hidden = W_big.shape[1]
+    dev = feature_bnc.device
+    if q_coarse is not None:
+        q_coarse, t_coarse = _f32(q_coarse.reshape(B, 4), t_coarse.reshape(B, 3))
+    q = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    t = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    q_norm = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    scratch = torch.empty((3 * B * L.SV_MAX_PARTS * C,), dtype=torch.float32, device=dev)
+    ptr = lambda x: x.data_ptr() if x is not None else None
+    a = L.PoseHeadArgs(B, N, C, hidden, feature_bnc.data_ptr(), weight_bnc.data_ptr(), xyz_bn3.data_ptr(),
+                       W_big.data_ptr(), b_big.data_ptr(), W_q.data_ptr(), b_q.data_ptr(), W_t.data_ptr(), b_t.data_ptr(),
+                       ptr(q_coarse), ptr(t_coarse), q.data_ptr(), t.data_ptr(), q_norm.data_ptr(), scratch.data_ptr())
+    L.call("elo_pose_head", a, q)
+    return q, t, q_norm
 
 
 def projection_constants(H_input, W_input):

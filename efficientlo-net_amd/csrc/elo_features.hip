@@ -138,21 +138,38 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_kernel(const elo_softm
 }
 
 // ------------------------------------------------------------ softmax_valid over the point axis
-// grid (batch, ceil(C/64)); 4 waves stride over the points, lanes over channels.
-__global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_kernel(const elo_softmax_valid_args a)
+// Stage 1, grid (parts, batch, ceil(C/64)): each block reduces a slice of the points with an online
+// softmax (4 waves stride over the slice, lanes over channels) and writes one (max, den, acc) triple
+// per channel.  Stage 2 merges the `parts` triples (softmax_valid_merge / pose_head_kernel).
+struct SvPartials {
+    float *mx, *den, *acc;        // each (batch, parts, C)
+};
+
+__device__ __forceinline__ SvPartials sv_partials(float *scratch, int batch, int C)
+{
+    const size_t n = (size_t)batch * ELO_SV_MAX_PARTS * C;
+    return SvPartials{scratch, scratch + n, scratch + 2 * n};
+}
+
+__global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_partial_kernel(const float *__restrict__ feature,
+                                                                          const float *__restrict__ weight,
+                                                                          const float *__restrict__ xyz, int npoints,
+                                                                          int C, int parts, float *scratch)
 {
     __shared__ float part[3][ROWS_PER_BLOCK][ELO_WAVE];
-    const int b = blockIdx.x, lane = threadIdx.x % ELO_WAVE, wave = threadIdx.x / ELO_WAVE;
-    const int c = blockIdx.y * ELO_WAVE + lane;
-    const bool live = c < a.C;
-    const float *f = a.feature + (long)b * a.npoints * a.C;
-    const float *w = a.weight + (long)b * a.npoints * a.C;
-    const float *p = a.xyz + (long)b * a.npoints * 3;
-    float mx = -INFINITY, den = 0.0f, acc = 0.0f;      // online softmax
-    for (int n = wave; n < a.npoints; n += ROWS_PER_BLOCK) {
+    const int slice = blockIdx.x, b = blockIdx.y, lane = threadIdx.x % ELO_WAVE, wave = threadIdx.x / ELO_WAVE;
+    const int c = blockIdx.z * ELO_WAVE + lane;
+    const bool live = c < C;
+    const float *f = feature + (long)b * npoints * C;
+    const float *w = weight + (long)b * npoints * C;
+    const float *p = xyz + (long)b * npoints * 3;
+    const int per = (npoints + parts - 1) / parts;
+    const int lo = slice * per, hi = min(npoints, lo + per);
+    float mx = -INFINITY, den = 0.0f, acc = 0.0f;
+    for (int n = lo + wave; n < hi; n += ROWS_PER_BLOCK) {
         const bool valid = !(p[n * 3 + 0] == 0.0f && p[n * 3 + 1] == 0.0f && p[n * 3 + 2] == 0.0f);
         if (!valid || !live) continue;
-        const float l = w[(long)n * a.C + c], v = f[(long)n * a.C + c];
+        const float l = w[(long)n * C + c], v = f[(long)n * C + c];
         if (l > mx) {
             const float sc = expf(mx - l);            // exp(-inf) = 0 on the first valid point
             den = den * sc + 1.0f;
@@ -176,7 +193,94 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_kernel(const elo_soft
             D += part[1][i][lane] * sc;
             A += part[2][i][lane] * sc;
         }
-        a.out[(long)b * a.C + c] = D > 0.0f ? A / D : 0.0f;
+        const SvPartials o = sv_partials(scratch, gridDim.y, C);
+        const size_t at = ((size_t)b * ELO_SV_MAX_PARTS + slice) * C + c;
+        o.mx[at] = M; o.den[at] = D; o.acc[at] = A;
+    }
+}
+
+// merged softmax-pooled feature of channel c of batch element b (0 when no point is valid)
+__device__ __forceinline__ float sv_merge(const SvPartials &s, int b, int c, int C, int parts)
+{
+    float M = -INFINITY;
+    for (int i = 0; i < parts; ++i) M = fmaxf(M, s.mx[((size_t)b * ELO_SV_MAX_PARTS + i) * C + c]);
+    float D = 0.0f, A = 0.0f;
+    for (int i = 0; i < parts; ++i) {
+        const size_t at = ((size_t)b * ELO_SV_MAX_PARTS + i) * C + c;
+        if (s.den[at] == 0.0f) continue;
+        const float sc = expf(s.mx[at] - M);
+        D += s.den[at] * sc;
+        A += s.acc[at] * sc;
+    }
+    return D > 0.0f ? A / D : 0.0f;
+}
+
+__global__ void softmax_valid_merge_kernel(float *scratch, int batch, int C, int parts, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * C) return;
+    out[i] = sv_merge(sv_partials(scratch, batch, C), i / C, i % C, C, parts);
+}
+
+// ------------------------------------------------------------ pose head (one block per batch element)
+__device__ __forceinline__ void hamilton(const float *a, const float *b, float *r)
+{   // model_util.py:21-34
+    r[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    r[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    r[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    r[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+
+__device__ __forceinline__ void normalise_q(const float *q, float *o)
+{   // pwclo_model.py:203
+    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + 1e-10f) + 1e-10f;
+    for (int i = 0; i < 4; ++i) o[i] = q[i] / n;
+}
+
+__global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_head_args a, const int parts)
+{
+    extern __shared__ float sm[];                      // [C] pooled feature, [hidden] big, [8] heads
+    float *feat = sm, *big = sm + a.C, *head = big + a.hidden;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const SvPartials s = sv_partials(a.scratch, gridDim.x, a.C);
+    for (int c = tid; c < a.C; c += blockDim.x) feat[c] = sv_merge(s, b, c, a.C, parts);
+    __syncthreads();
+    for (int j = tid; j < a.hidden; j += blockDim.x) {     // conv1d C -> hidden, no activation (:197)
+        float v = a.b_big[j];
+        for (int c = 0; c < a.C; ++c) v += feat[c] * a.W_big[(size_t)c * a.hidden + j];
+        big[j] = v;
+    }
+    __syncthreads();
+    if (tid < 7) {                                          // conv1d hidden -> 4 (q) and hidden -> 3 (t)
+        const bool isq = tid < 4;
+        const int o = isq ? tid : tid - 4, n = isq ? 4 : 3;
+        const float *W = isq ? a.W_q : a.W_t;
+        float v = isq ? a.b_q[o] : a.b_t[o];
+        for (int j = 0; j < a.hidden; ++j) v += big[j] * W[(size_t)j * n + o];
+        head[tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float q_det[4], q[4], t[3], qn[4];
+        normalise_q(head, q_det);
+        const float *t_det = head + 4;
+        if (a.q_coarse) {
+            const float *qc = a.q_coarse + b * 4, *tc = a.t_coarse + b * 3;
+            const float tq[4] = {0.0f, tc[0], tc[1], tc[2]};
+            float v[4], w[4], inv[4];
+            hamilton(q_det, tq, v);                                                   // :275-276
+            const float n2 = q_det[0] * q_det[0] + q_det[1] * q_det[1] + q_det[2] * q_det[2] + q_det[3] * q_det[3] + 1e-10f;
+            inv[0] = q_det[0] / n2; inv[1] = -q_det[1] / n2; inv[2] = -q_det[2] / n2; inv[3] = -q_det[3] / n2;
+            hamilton(v, inv, w);                                                      // :277
+            hamilton(q_det, qc, q);                                                   // :279
+            for (int i = 0; i < 3; ++i) t[i] = w[i + 1] + t_det[i];                   // :280
+        } else {
+            for (int i = 0; i < 4; ++i) q[i] = q_det[i];
+            for (int i = 0; i < 3; ++i) t[i] = t_det[i];
+        }
+        normalise_q(q, qn);
+        for (int i = 0; i < 4; ++i) { a.q[b * 4 + i] = q[i]; a.q_norm[b * 4 + i] = qn[i]; }
+        for (int i = 0; i < 3; ++i) a.t[b * 3 + i] = t[i];
     }
 }
 
@@ -322,15 +426,43 @@ extern "C" int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_strea
     return check_launch(who);
 }
 
+static int sv_parts(int npoints)
+{
+    int parts = (npoints + 63) / 64;                 // >= 64 points (16 per wave) per block
+    return parts < 1 ? 1 : parts > ELO_SV_MAX_PARTS ? ELO_SV_MAX_PARTS : parts;
+}
+
 extern "C" int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t stream)
 {
     const char *who = "elo_softmax_valid";
     ELO_REQUIRE(a, who, "null argument block");
     ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->C > 0, who, "bad sizes");
-    ELO_REQUIRE(a->feature && a->weight && a->xyz && a->out, who, "null tensor pointer");
+    ELO_REQUIRE(a->feature && a->weight && a->xyz && a->out && a->scratch, who, "null tensor pointer");
     if (a->batch == 0) return ELO_OK;
-    hipLaunchKernelGGL(softmax_valid_kernel, dim3(a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE), dim3(ELO_BLOCK), 0,
-                       (hipStream_t)stream, *a);
+    const int parts = sv_parts(a->npoints);
+    hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
+                       dim3(ELO_BLOCK), 0, (hipStream_t)stream, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
+                       a->scratch);
+    hipLaunchKernelGGL(softmax_valid_merge_kernel, dim3((a->batch * a->C + ELO_BLOCK - 1) / ELO_BLOCK), dim3(ELO_BLOCK),
+                       0, (hipStream_t)stream, a->scratch, a->batch, a->C, parts, a->out);
+    return check_launch(who);
+}
+
+extern "C" int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_pose_head";
+    ELO_REQUIRE(a, who, "null argument block");
+    ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->C > 0 && a->hidden > 0, who, "bad sizes");
+    ELO_REQUIRE(a->feature && a->weight && a->xyz && a->W_big && a->b_big && a->W_q && a->b_q && a->W_t && a->b_t &&
+                a->q && a->t && a->q_norm && a->scratch, who, "null tensor pointer");
+    ELO_REQUIRE((a->q_coarse == nullptr) == (a->t_coarse == nullptr), who, "q_coarse and t_coarse go together");
+    if (a->batch == 0) return ELO_OK;
+    const int parts = sv_parts(a->npoints);
+    hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
+                       dim3(ELO_BLOCK), 0, (hipStream_t)stream, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
+                       a->scratch);
+    const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8);
+    hipLaunchKernelGGL(pose_head_kernel, dim3(a->batch), dim3(ELO_BLOCK), lds, (hipStream_t)stream, *a, parts);
     return check_launch(who);
 }
 

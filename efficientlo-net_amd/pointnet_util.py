@@ -52,12 +52,17 @@ def _split_conv(parts, num_output_channels, scope, is_training, bn_decay, bn=Tru
     lead = parts[0].shape[:-1]
     W, b = tf_util.folded_variables(scope, cin, num_output_channels, (1, 1), bn)
     y, row = None, 0
-    for p in parts:
+    for i, p in enumerate(parts):
         c = p.shape[-1]
         x2 = p.reshape(-1, c)
-        y = torch.addmm(b, x2, W[row:row + c]) if y is None else y.addmm_(x2, W[row:row + c])
+        if y is None:
+            y = torch.addmm(b, x2, W[row:row + c])
+        elif i + 1 < len(parts):
+            y = y.addmm_(x2, W[row:row + c])
+        else:
+            y = torch._addmm_activation(y, x2, W[row:row + c])      # relu(y + x @ W)
         row += c
-    return y.relu_().reshape(lead + (num_output_channels,))
+    return y.reshape(lead + (num_output_channels,))
 
 
 def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_size1, kernel_size2, nsample,

@@ -16,7 +16,7 @@ import math
 import numpy as np
 import torch
 
-from . import tf_util
+from . import _ops, tf_util
 from .model_util import (PreProcess, ProjectPC2SphericalRing, get_selected_idx, inv_q, mul_point_q, mul_q_point,
                          softmax_valid, warp_and_project)
 from .pointnet_util import cost_volume, down_conv, flow_predictor, up_conv
@@ -97,7 +97,7 @@ def _normalise_q(q):
     return q / (torch.sqrt((q * q).sum(-1, keepdim=True) + 1e-10) + 1e-10)
 
 
-def _pose_head(feat_b1c, level, coarse, is_training, dropout_gen=None):
+def _pose_head(feat_b1c, level, coarse, is_training):
     """pwclo_model.py:197-208 (l3) and :264-273 / :340-349 / :408-417 (refinement levels)."""
     big = tf_util.conv1d(feat_b1c, 256, 1, padding='VALID', activation_fn=None, scope='l%d_big' % level)
     if is_training:
@@ -106,6 +106,32 @@ def _pose_head(feat_b1c, level, coarse, is_training, dropout_gen=None):
     q = _normalise_q(tf_util.conv1d(big, 4, 1, padding='VALID', activation_fn=None, scope=qn % level))
     t = tf_util.conv1d(big, 3, 1, padding='VALID', activation_fn=None, scope=tn % level)
     return q, t
+
+
+def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training):
+    """softmax_valid + pose head + composition with the coarse pose (q_coarse None at l3).
+    Returns (q (B,4), t (B,3), q_norm (B,4)): the level's pose and its final normalisation (:427-430).
+    Inference: two fused HIP launches (_ops.pose_head).  Training: the literal operator chain."""
+    batch_size = predict.shape[0]
+    coarse = q_coarse is None
+    if not (is_training or torch.is_grad_enabled()):
+        qn, tn = ('l%d_q_coarse', 'l%d_t_coarse') if coarse else ('l%d_q_det', 'l%d_t_det')
+        W_big, b_big = tf_util.folded_variables('l%d_big' % level, predict.shape[-1], 256, (1,), bn=False)
+        W_q, b_q = tf_util.folded_variables(qn % level, 256, 4, (1,), bn=False)
+        W_t, b_t = tf_util.folded_variables(tn % level, 256, 3, (1,), bn=False)
+        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse)
+    summed = softmax_valid(feature_bnc=predict, weight_bnc=weight, mask_valid=xyz)                  # :194 / :262
+    q_det, t_det = _pose_head(summed, level, coarse, is_training)                                   # :197-208 / :264-273
+    if coarse:
+        q = q_det.squeeze(1)
+        return q, t_det.squeeze(1), _normalise_q(q)
+    dev = predict.device
+    t_coarse_trans = torch.cat([torch.zeros((batch_size, 1, 1), dtype=torch.float32, device=dev), t_coarse], -1)
+    t_coarse_trans = mul_q_point(q_det, t_coarse_trans, batch_size)
+    t_coarse_trans = mul_point_q(t_coarse_trans, inv_q(q_det, batch_size), batch_size)[:, :, 1:]    # :275-277
+    q = mul_point_q(q_det, q_coarse, batch_size).squeeze(1)                                         # :279
+    t = (t_coarse_trans + t_det).squeeze(1)                                                         # :280
+    return q, t, _normalise_q(q)
 
 
 def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training, bn_decay=None):
@@ -169,13 +195,12 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                                       bn_decay=bn_decay, scope='l3_costvolume_predict_ww')
     l3_cost_volume_w_proj = l3_cost_volume_w.reshape(batch_size, out_h_list[5], out_w_list[5], -1)
     l3_xyz_f1 = xyz_proj_f1[3].reshape(batch_size, -1, 3)
-    l3_points_f1_new = softmax_valid(feature_bnc=l3_points_predict, weight_bnc=l3_cost_volume_w, mask_valid=l3_xyz_f1)
-    l3_q_coarse, l3_t_coarse = _pose_head(l3_points_f1_new, 3, True, is_training)
-    l3_q, l3_t = l3_q_coarse.squeeze(1), l3_t_coarse.squeeze(1)
+    l3_q, l3_t, l3_q_norm = _estimate_pose(l3_points_predict, l3_cost_volume_w, l3_xyz_f1, 3, None, None,
+                                           is_training)                                            # :194-208
 
     # three warp-refinement levels (:211-425); one loop instead of three pasted blocks
     cv_kernel2 = {2: [5, 15], 1: [7, 25], 0: [11, 41]}                                              # :243,:317,:391
-    poses = {3: (l3_q, l3_t)}
+    poses = {3: (l3_q_norm, l3_t)}
     q_prev, t_prev = l3_q, l3_t
     coarse_w_proj, coarse_predict_proj, coarse_xyz_proj = l3_cost_volume_w_proj, l3_points_predict_proj, xyz_proj_f1[3]
     for level, g in ((2, 4), (1, 3), (0, 2)):
@@ -207,23 +232,17 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                                  bn_decay=bn_decay, scope='l%d_costvolume_predict' % level)         # :253
         weight = flow_predictor(points_warp_f1, w_up_sample, cost, mlp=[128, 64], is_training=is_training,
                                 bn_decay=bn_decay, scope='l%d_w_predict' % level)                   # :254
-        summed = softmax_valid(feature_bnc=predict, weight_bnc=weight, mask_valid=xyz_warp_f1)      # :262
-        q_det, t_det = _pose_head(summed, level, False, is_training)                                # :264-273
-
-        t_coarse_trans = torch.cat([torch.zeros((batch_size, 1, 1), dtype=torch.float32, device=dev), t_coarse], -1)
-        t_coarse_trans = mul_q_point(q_det, t_coarse_trans, batch_size)
-        t_coarse_trans = mul_point_q(t_coarse_trans, inv_q(q_det, batch_size), batch_size)[:, :, 1:]   # :275-277
-        q_prev = mul_point_q(q_det, q_coarse, batch_size).squeeze(1)                                # :279
-        t_prev = (t_coarse_trans + t_det).squeeze(1)                                                # :280
-        poses[level] = (q_prev, t_prev)
+        q_prev, t_prev, q_norm = _estimate_pose(predict, weight, xyz_warp_f1, level, q_coarse, t_coarse,
+                                                is_training)                                       # :262-280
+        poses[level] = (q_norm, t_prev)
 
         coarse_w_proj = weight.reshape(batch_size, out_h_list[g], out_w_list[g], -1)                # :256-257
         coarse_predict_proj = predict.reshape(batch_size, out_h_list[g], out_w_list[g], -1)
         coarse_xyz_proj = xyz_warp_proj_f1
 
     l0_xyz_f1 = xyz_proj_f1[0].reshape(batch_size, -1, 3)
-    return (_normalise_q(poses[0][0]), poses[0][1], _normalise_q(poses[1][0]), poses[1][1],
-            _normalise_q(poses[2][0]), poses[2][1], _normalise_q(poses[3][0]), poses[3][1], l0_xyz_f1)   # :427-433
+    return (poses[0][0], poses[0][1], poses[1][0], poses[1][1], poses[2][0], poses[2][1], poses[3][0], poses[3][1],
+            l0_xyz_f1)                                                                              # :427-433
 
 
 def get_model(point_cloud, H_input, W_input, T_gt, T_trans, T_trans_inv, is_training, bn_decay=None, aug_frame=None):

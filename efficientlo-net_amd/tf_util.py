@@ -17,7 +17,7 @@ the shipped checkpoint index, so the Siamese sharing
 falls out and a TF checkpoint can be imported by name.
 
 Inference (is_training False) folds BN's moving statistics and the bias into
-the GEMM: y = relu(x @ W' + b'), one addmm + one in-place relu.  Folded weights
+the GEMM: y = relu(x @ W' + b') is ONE hipBLASLt launch (bias + ReLU epilogue).  Folded weights
 are cached per scope until VariableStore.invalidate().
 """
 import contextlib
@@ -192,11 +192,12 @@ def _dense(inputs, num_output_channels, scope, tf_kernel_dims, activation_fn, bn
             y = activation_fn(y)
     else:                                        # inference: BN + bias folded into the GEMM
         Wf, bf = get_store().folded(name, W, b, bn_vars)
-        y = torch.addmm(bf, x2, Wf)
         if activation_fn is relu:
-            y.relu_()
-        elif activation_fn is not None:
-            y = activation_fn(y)
+            y = torch._addmm_activation(bf, x2, Wf)      # bias + ReLU in the hipBLASLt epilogue: one kernel
+        else:
+            y = torch.addmm(bf, x2, Wf)
+            if activation_fn is not None:
+                y = activation_fn(y)
     return y.reshape(inputs.shape[:-1] + (num_output_channels,))
 
 

@@ -168,15 +168,44 @@ typedef struct elo_softmax_pool_args {
 int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_stream_t stream);
 
 /* model_util.py:319-343 softmax_valid: per batch element, softmax over the
- * VALID points (xyz != (0,0,0)) per channel, out[b,0,c] = sum_n softmax*feature. */
+ * VALID points (xyz != (0,0,0)) per channel, out[b,0,c] = sum_n softmax*feature.
+ * Two launches: `parts` blocks per batch element reduce slices of the point axis
+ * with an online softmax, a second kernel merges the partials.
+ * scratch: 3 * batch * ELO_SV_MAX_PARTS * C floats. */
+#define ELO_SV_MAX_PARTS 64
 typedef struct elo_softmax_valid_args {
     int batch, npoints, C;
     const float *feature;         /* (batch,npoints,C) */
     const float *weight;          /* (batch,npoints,C) */
     const float *xyz;             /* (batch,npoints,3): a point is valid unless all three are exactly 0 */
     float *out;                   /* (batch,1,C); all-invalid batch element -> 0 */
+    float *scratch;
 } elo_softmax_valid_args;
 int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t stream);
+
+/* Pose head of one pyramid level, inference form (pwclo_model.py:194-208 at l3,
+ * :262-280 / :338-356 / :406-425 at the refinement levels), fused:
+ *   f      = softmax_valid(feature, weight, xyz)                       (B,C)
+ *   big    = f @ W_big + b_big                                         (B,hidden)   conv1d, no activation
+ *   q_det  = normalise(big @ W_q + b_q),  t_det = big @ W_t + b_t      normalise: q / (sqrt(sum q^2 + 1e-10) + 1e-10)
+ *   coarse == NULL :  q = q_det, t = t_det                             (l3)
+ *   else           :  q = q_det (x) q_coarse,
+ *                     t = (q_det (x) [0,t_coarse] (x) q_det^-1)[1:] + t_det
+ *   q_norm = normalise(q)                                              (:427-430)
+ * Weights are row-major (in,out).  Dropout (training only) is not part of this kernel.
+ * scratch: as elo_softmax_valid. */
+typedef struct elo_pose_head_args {
+    int batch, npoints, C, hidden;
+    const float *feature, *weight, *xyz;
+    const float *W_big, *b_big;   /* (C,hidden), (hidden) */
+    const float *W_q, *b_q;       /* (hidden,4), (4)      */
+    const float *W_t, *b_t;       /* (hidden,3), (3)      */
+    const float *q_coarse;        /* (batch,4) or NULL    */
+    const float *t_coarse;        /* (batch,3) or NULL    */
+    float *q, *t, *q_norm;        /* (batch,4), (batch,3), (batch,4) OUT */
+    float *scratch;
+} elo_pose_head_args;
+int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream);
 
 /* Pose warp + spherical re-projection.
  *   warp : p' = ((q (x) [0,p]) (x) q^-1)[1:] + t, zeroed where p == (0,0,0)
