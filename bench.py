@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--width", type=int, default=1800)
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic pairs kept in HBM")
+    ap.add_argument("--lanes", type=int, default=4, help="independent forwards in flight (streams x hipGraphs)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs in the CPU-oracle sample")
@@ -143,21 +144,27 @@ def main():
     for i in range(args.pool):                       # inputs resident in HBM before the timed region
         f1, f2 = synth.frame_pair(B, H, W, seed=1000 * rank + 10 * i)
         pool.append((torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev)))
+    lanes = 1 if args.no_graph else max(1, args.lanes)
     if args.no_graph:
         net.forward(*pool[0])
     else:
-        net.capture(B, H, W)
+        net.capture(B, H, W, lanes=lanes)
     gathered = [torch.empty((B, 7), device=dev) for _ in range(world)] if world > 1 else None
 
     def step(i):
         a, b = pool[i % len(pool)]
-        out = net(a, b)
+        if args.no_graph:
+            out, stream = net.forward(a, b), torch.cuda.current_stream(dev)
+        else:                                        # step i rides lane i % lanes; lanes overlap on the GPU
+            out, stream = net.submit(i % lanes, a, b), net.lane_stream(i % lanes)
         if world > 1:                                # poses of this step to every rank (7 floats per pair)
-            dist.all_gather(gathered, torch.cat([out[0], out[1]], -1))
+            with torch.cuda.stream(stream):
+                dist.all_gather(gathered, torch.cat([out[0], out[1]], -1))
         return out
 
     for i in range(args.warmup):
         step(i)
+    torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -185,7 +192,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "full 4-level PWC pyramid (set-conv + attentive cost volume + warp-refinement + "
                                "set-upconv), %dx%d range-image pairs, batch %d per GPU, fp32, random-init weights, "
-                               "%s" % (H, W, B, "eager launches" if args.no_graph else "hipGraph replay"),
+                               "%s" % (H, W, B, "eager launches" if args.no_graph else
+                                      "hipGraph replay, %d forwards in flight" % lanes),
                    "global_batch": B * world, "parallelism": "dp%d" % world},
     }
     if rank == 0 and world == 1:

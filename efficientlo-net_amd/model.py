@@ -21,6 +21,7 @@ class PWCLONet:
         self._graph = None
         self._static_in = None
         self._static_out = None
+        self._lanes = []
 
     # -- eager ---------------------------------------------------------------
     def forward(self, xyz_f1_proj, xyz_f2_proj, is_training=False, bn_decay=None):
@@ -41,21 +42,31 @@ class PWCLONet:
                                              bn_decay, aug_frame)
 
     # -- HIP graph -----------------------------------------------------------
-    def capture(self, batch_size, H_input, W_input, warmup=3):
-        """Record one inference forward into a hipGraph (torch.cuda.CUDAGraph on ROCm)."""
+    def capture(self, batch_size, H_input, W_input, warmup=3, lanes=1):
+        """Record the inference forward into `lanes` independent hipGraphs (torch.cuda.CUDAGraph on ROCm).
+
+        One frame pair keeps only a few of the 256 CUs busy per kernel, and frame pairs are independent,
+        so several forwards can be in flight: lane i owns a stream, a graph and its static input / output
+        buffers; the weights are shared.  `lanes=1` is the plain single-stream replay."""
         dev = self.device
-        self._static_in = (torch.zeros((batch_size, H_input, W_input, 3), device=dev),
-                           torch.zeros((batch_size, H_input, W_input, 3), device=dev))
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        zeros = lambda: torch.zeros((batch_size, H_input, W_input, 3), device=dev)
         with torch.cuda.stream(side):
+            probe = (zeros(), zeros())
             for _ in range(warmup):                 # creates variables, folded weights, caches, hipBLASLt plans
-                self.forward(*self._static_in)
+                self.forward(*probe)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._static_out = self.forward(*self._static_in)
+        self._lanes = []
+        for _ in range(lanes):
+            lane = {"stream": torch.cuda.Stream(device=dev), "in": (zeros(), zeros()), "graph": torch.cuda.CUDAGraph()}
+            with torch.cuda.graph(lane["graph"]):
+                lane["out"] = self.forward(*lane["in"])
+            self._lanes.append(lane)
+        torch.cuda.synchronize(dev)
+        self._graph, self._static_in, self._static_out = (self._lanes[0]["graph"], self._lanes[0]["in"],
+                                                          self._lanes[0]["out"])
         return self
 
     def load_inputs(self, xyz_f1_proj, xyz_f2_proj):
@@ -65,6 +76,19 @@ class PWCLONet:
     def replay(self):
         self._graph.replay()
         return self._static_out
+
+    def submit(self, lane_index, xyz_f1_proj, xyz_f2_proj):
+        """Enqueue one forward on lane `lane_index` (its own stream); returns the lane's static outputs,
+        valid once that stream has been synchronised (or waited on)."""
+        lane = self._lanes[lane_index]
+        with torch.cuda.stream(lane["stream"]):
+            lane["in"][0].copy_(xyz_f1_proj, non_blocking=True)
+            lane["in"][1].copy_(xyz_f2_proj, non_blocking=True)
+            lane["graph"].replay()
+        return lane["out"]
+
+    def lane_stream(self, lane_index):
+        return self._lanes[lane_index]["stream"]
 
     def __call__(self, xyz_f1_proj, xyz_f2_proj):
         if self._graph is None:
