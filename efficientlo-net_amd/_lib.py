@@ -56,6 +56,25 @@ WarpProjectArgs = _struct("elo_warp_project_args", [
     ("xyz", _vp), ("feat", _vp), ("q", _vp), ("t", _vp), ("warped", _vp), ("out_xyz", _vp), ("out_feat", _vp),
     ("scratch", _vp)])
 
+Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i)])
+_l = ctypes.c_long
+SetconvArgs = _struct("elo_setconv_args", [
+    ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("H2", _i), ("W2", _i), ("C", _i),
+    ("xyz1_grid", _vp), ("centre_hw", _vp), ("centre_xyz", _vp), ("src_xyz", _vp), ("src_feat", _vp),
+    ("idx", _vp), ("mask", _vp), ("n_layers", _i), ("layers", Dense * 3), ("out", _vp), ("new_xyz", _vp)])
+MlpArgs = _struct("elo_mlp_args", [
+    ("rows", _l), ("n_sources", _i), ("src", _vp * 3), ("src_width", _i * 3), ("n_layers", _i),
+    ("layers", Dense * 3), ("out", _vp)])
+Cv1Args = _struct("elo_cv1_args", [
+    ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
+    ("xyz1", _vp), ("feat1", _vp), ("xyz2", _vp), ("feat2", _vp), ("idx", _vp), ("mask", _vp),
+    ("cv0", Dense), ("cv1", Dense), ("cv2", Dense), ("cv_xyz", Dense), ("sum_cv0", Dense), ("sum_cv1", Dense),
+    ("out", _vp)])
+Cv2Args = _struct("elo_cv2_args", [
+    ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("C", _i),
+    ("xyz1", _vp), ("feat1", _vp), ("cost", _vp), ("idx", _vp), ("mask", _vp),
+    ("xyz_enc", Dense), ("sum_cost0", Dense), ("sum_cost1", Dense), ("out", _vp)])
+
 # every symbol include/elo.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("elo_abi_version", ctypes.c_int, []),
@@ -70,6 +89,10 @@ SYMBOLS = [
     ("elo_softmax_valid", ctypes.c_int, [ctypes.POINTER(SoftmaxValidArgs), _vp]),
     ("elo_pose_head", ctypes.c_int, [ctypes.POINTER(PoseHeadArgs), _vp]),
     ("elo_warp_project", ctypes.c_int, [ctypes.POINTER(WarpProjectArgs), _vp]),
+    ("elo_setconv_fused", ctypes.c_int, [ctypes.POINTER(SetconvArgs), _vp]),
+    ("elo_mlp_fused", ctypes.c_int, [ctypes.POINTER(MlpArgs), _vp]),
+    ("elo_cv_stage1_fused", ctypes.c_int, [ctypes.POINTER(Cv1Args), _vp]),
+    ("elo_cv_stage2_fused", ctypes.c_int, [ctypes.POINTER(Cv2Args), _vp]),
 ]
 
 _lib = None

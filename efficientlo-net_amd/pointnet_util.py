@@ -15,11 +15,27 @@ accumulating GEMMs on row-slices of the same weight variable).
 `tf.random_shuffle(tf.range(KT))` becomes `random_shuffle(scope, tag, KT)` from
 the active PermSource (see perm.py): the caller owns the randomness.
 """
+import os
+
 import torch
 
-from . import _ops, tf_util
+from . import _ops, fused, tf_util
 from .fused_conv import fused_conv_random_k, fused_conv_select_k
 from .perm import random_shuffle
+
+
+# Inference uses the fused "gather -> conv chain -> pool" kernels (csrc/elo_fused.hip); ELO_FUSED=0 or
+# use_fused(False) selects the per-operator kernels + hipBLASLt GEMMs instead (same results to ~1e-6).
+_FUSED = os.environ.get("ELO_FUSED", "1") != "0"
+
+
+def use_fused(flag):
+    global _FUSED
+    _FUSED = bool(flag)
+
+
+def _fused_path(is_training):
+    return _FUSED and not is_training and not torch.is_grad_enabled()
 
 
 def warping_layers(xyz1, upsampled_flow):
@@ -83,23 +99,19 @@ def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_
             warped_xyz1_proj, xyz2_proj, idx_hw, random_HW_q, H, W, N, kernel_size2[0], kernel_size2[1], nsample_q,
             flag_copy=0, distance=1000, stride_h=1, stride_w=1, want_valid=False)            # :49-51 (1000 is literal)
         mask = valid_mask.reshape(B, N, nsample_q)
-        feat_cat = _ops.cv_encode1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask)   # :54-66
-        xyz_cat = feat_cat.reshape(-1, feat_cat.shape[-1])[:, :10]      # :62 -- 2-D strided view, no copy (lda = 10+2C)
-        x = feat_cat
-        for j, num_out_channel in enumerate(mlp1):
-            x = tf_util.conv2d(x, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
-                               is_training=is_training, scope='CV_%d' % j, bn_decay=bn_decay)     # :72-76
-        enc = tf_util.conv2d(xyz_cat, mlp1[-1], [1, 1], padding='VALID', stride=[1, 1], bn=True,
-                             is_training=is_training, scope='CV_xyz', bn_decay=bn_decay)          # :79-82
-        enc = enc.reshape(B, N, nsample_q, -1)
-        cat = None
-        for j, num_out_channel in enumerate(mlp2):                                                # :84-90
-            if j == 0:
-                cat = _split_conv([enc, x], num_out_channel, 'sum_CV_0', is_training, bn_decay)
-            else:
-                cat = tf_util.conv2d(cat, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
-                                     is_training=is_training, scope='sum_CV_%d' % j, bn_decay=bn_decay)
-        pi_feat1_new = _ops.masked_softmax_pool(cat, x, mask).reshape(B, H, W, -1)                # :92-100
+        C = points1.shape[-1]
+        if _fused_path(is_training):
+            if list(mlp1) != [128, 64, 64] or list(mlp2) != [128, 64]:
+                raise NotImplementedError("the fused cost volume is built for mlp1=[128,64,64], mlp2=[128,64]")
+            P = fused.packed_layer
+            pi_feat1_new = fused.cv_stage1(
+                warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask,
+                P('CV_0', 10 + 2 * C, 128), P('CV_1', 128, 64), P('CV_2', 64, 64), P('CV_xyz', 10, 64),
+                P('sum_CV_0', 128, 128, row_order=list(range(64, 128)) + list(range(64))),      # kernel order [x | enc]
+                P('sum_CV_1', 128, 64)).reshape(B, H, W, -1)                                     # :54-100
+        else:
+            pi_feat1_new = _cost_volume_stage1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask, mlp1, mlp2,
+                                               is_training, bn_decay).reshape(B, H, W, -1)
 
         # ---- stage 2: patch -> patch inside frame 1 (:104-146)
         random_HW_p = random_shuffle(tf_util.scope_name(), "random_HW_p", kernel_size1[0] * kernel_size1[1], dev)
@@ -107,18 +119,53 @@ def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_
             warped_xyz1_proj, warped_xyz1_proj, idx_hw, random_HW_p, H, W, N, kernel_size1[0], kernel_size1[1],
             nsample, flag_copy=0, distance=distance, stride_h=1, stride_w=1, want_valid=False)    # :106-108
         mask2 = valid_mask2.reshape(B, N, nsample)
-        pc_xyz_cat, rest = _ops.cv_encode2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2)  # :110-120
-        pc_enc = tf_util.conv2d(pc_xyz_cat, mlp1[-1], [1, 1], padding='VALID', stride=[1, 1], bn=True,
-                                is_training=is_training, scope='sum_xyz_encoding', bn_decay=bn_decay)    # :123-126
-        pc_cat = None
-        for j, num_out_channel in enumerate(mlp2):                                                # :129-135
-            if j == 0:
-                pc_cat = _split_conv([pc_enc, rest], num_out_channel, 'sum_cost_volume_0', is_training, bn_decay)
-            else:
-                pc_cat = tf_util.conv2d(pc_cat, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
-                                        is_training=is_training, scope='sum_cost_volume_%d' % j, bn_decay=bn_decay)
-        pc_points_grouped = rest[..., points1.shape[-1]:]            # cost[idx]*mask, a channel slice of `rest`
-        return _ops.masked_softmax_pool(pc_cat, pc_points_grouped, mask2)                         # :137-146
+        if _fused_path(is_training):
+            P = fused.packed_layer
+            order = list(range(64 + C, 128 + C)) + list(range(64)) + list(range(64, 64 + C))   # [grouped | enc | feat1]
+            return fused.cv_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2,
+                                   P('sum_xyz_encoding', 10, 64), P('sum_cost_volume_0', 128 + C, 128, row_order=order),
+                                   P('sum_cost_volume_1', 128, 64))                              # :110-146
+        return _cost_volume_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2, mlp1, mlp2, is_training,
+                                   bn_decay)
+
+
+def _cost_volume_stage1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask, mlp1, mlp2, is_training, bn_decay):
+    """utils/pointnet_util.py:54-100 as per-operator kernels + GEMMs (caller holds the variable scope)."""
+    B, N, nsample_q = mask.shape
+    feat_cat = _ops.cv_encode1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask)       # :54-66
+    xyz_cat = feat_cat.reshape(-1, feat_cat.shape[-1])[:, :10]      # :62 -- 2-D strided view, no copy (lda = 10+2C)
+    x = feat_cat
+    for j, num_out_channel in enumerate(mlp1):
+        x = tf_util.conv2d(x, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                           is_training=is_training, scope='CV_%d' % j, bn_decay=bn_decay)         # :72-76
+    enc = tf_util.conv2d(xyz_cat, mlp1[-1], [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                         is_training=is_training, scope='CV_xyz', bn_decay=bn_decay)              # :79-82
+    enc = enc.reshape(B, N, nsample_q, -1)
+    cat = None
+    for j, num_out_channel in enumerate(mlp2):                                                    # :84-90
+        if j == 0:
+            cat = _split_conv([enc, x], num_out_channel, 'sum_CV_0', is_training, bn_decay)
+        else:
+            cat = tf_util.conv2d(cat, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                                 is_training=is_training, scope='sum_CV_%d' % j, bn_decay=bn_decay)
+    return _ops.masked_softmax_pool(cat, x, mask)                                                 # :92-98
+
+
+def _cost_volume_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2, mlp1, mlp2, is_training, bn_decay):
+    """utils/pointnet_util.py:110-146 as per-operator kernels + GEMMs (caller holds the variable scope)."""
+    C = points1_proj.shape[-1]
+    pc_xyz_cat, rest = _ops.cv_encode2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2)  # :110-120
+    pc_enc = tf_util.conv2d(pc_xyz_cat, mlp1[-1], [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                            is_training=is_training, scope='sum_xyz_encoding', bn_decay=bn_decay)    # :123-126
+    pc_cat = None
+    for j, num_out_channel in enumerate(mlp2):                                                    # :129-135
+        if j == 0:
+            pc_cat = _split_conv([pc_enc, rest], num_out_channel, 'sum_cost_volume_0', is_training, bn_decay)
+        else:
+            pc_cat = tf_util.conv2d(pc_cat, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                                    is_training=is_training, scope='sum_cost_volume_%d' % j, bn_decay=bn_decay)
+    pc_points_grouped = rest[..., C:]                              # cost[idx]*mask, a channel slice of `rest`
+    return _ops.masked_softmax_pool(pc_cat, pc_points_grouped, mask2)                             # :137-146
 
 
 def flow_predictor(points_f1, upsampled_feat, cost_volume, mlp, is_training, bn_decay, scope, bn=True):
@@ -129,6 +176,11 @@ def flow_predictor(points_f1, upsampled_feat, cost_volume, mlp, is_training, bn_
             parts.append(upsampled_feat)
         if cost_volume is not None:
             parts.append(cost_volume)
+        if _fused_path(is_training) and len(mlp) <= 3:
+            widths = [sum(p.shape[-1] for p in parts)] + list(mlp)
+            layers = [fused.packed_layer('conv_predictor%d' % i, widths[i], widths[i + 1], bn=bn)
+                      for i in range(len(mlp))]
+            return fused.mlp(parts, layers)                                                       # one launch
         parts = [p.unsqueeze(2) for p in parts]                                                   # :166
         x = None
         for i, num_out_channel in enumerate(mlp):
@@ -155,6 +207,14 @@ def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distan
             xyz_proj, xyz_proj, idx_n2[:, :, 1:].contiguous(), random_HW, H, W, n_sampled, kernel_size[0],
             kernel_size[1], K_sample, flag_copy=0, distance=distance, stride_h=1, stride_w=1, want_valid=False)  # :197-199
         mask = valid_mask.reshape(B, n_sampled, K_sample)
+        if _fused_path(is_training) and len(mlp) <= 3 and K_sample <= 32:
+            # centre = xyz_proj[b, h, w] read in-kernel (selected_idx's batch column is the batch index, as
+            # get_selected_idx builds it); gather + MLP + masked max-pool in one launch                  :203-230
+            widths = [3 + points_proj.shape[-1]] + list(mlp)
+            layers = [fused.packed_layer('conv%d' % i, widths[i], widths[i + 1], bn=bn) for i in range(len(mlp))]
+            out, new_xyz = fused.setconv(xyz_proj, points_proj, sel, mask, layers, xyz1_grid=xyz_proj,
+                                         centre_hw=idx_n2[:, :, 1:].contiguous())
+            return out, new_xyz.reshape(selected_idx.shape[:-1] + (3,))
         li = selected_idx.reshape(-1, 3).long()
         new_xyz_proj = xyz_proj[li[:, 0], li[:, 1], li[:, 2]].reshape(selected_idx.shape[:-1] + (3,))  # :206
         new_xyz = new_xyz_proj.reshape(B, -1, 3)
@@ -180,6 +240,14 @@ def up_conv(xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kernel_size, stride_h,
             xyz1_proj, xyz2_proj, idx_hw, random_HW, H, W, N, kernel_size[0], kernel_size[1], nsample,
             flag_copy=0, distance=distance, stride_h=stride_h, stride_w=stride_w, want_valid=False)      # :272-274
         mask = valid_mask.reshape(B, N, nsample)
+        if _fused_path(is_training) and len(mlp) <= 3 and len(mlp2) <= 3 and nsample <= 32:
+            P = fused.packed_layer
+            w1 = [3 + feat2_proj.shape[-1]] + list(mlp)
+            up_feat, _ = fused.setconv(xyz2_proj, feat2_proj, sel, mask,
+                                       [P('up_1_%d' % j, w1[j], w1[j + 1]) for j in range(len(mlp))],
+                                       centre_xyz=xyz1)                                           # :277-298
+            w2 = [mlp[-1] + points1.shape[-1]] + list(mlp2)
+            return fused.mlp([up_feat, points1], [P('up_2_%d' % i, w2[i], w2[i + 1]) for i in range(len(mlp2))])  # :303-311
         x = _ops.group_concat(xyz1, xyz2_proj, feat2_proj, sel, mask)                             # :277-284
         for j, num_out_channel in enumerate(mlp):
             x = tf_util.conv2d(x, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,

@@ -232,6 +232,97 @@ typedef struct elo_warp_project_args {
 } elo_warp_project_args;
 int elo_warp_project(const elo_warp_project_args *a, elo_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * Fused inference kernels: gather/encode -> chain of 1x1 convolutions (BN and
+ * bias folded, ReLU) -> pooling, in ONE launch with the activations of a
+ * 32-row tile resident in LDS and the contractions on the fp32 matrix cores
+ * (v_mfma_f32_32x32x2_f32: exact fp32, bit-equal to an fmaf chain).  They
+ * compute what the unfused kernels above + the hipBLASLt GEMMs compute, for
+ * the launch-bound small-batch regime.
+ *
+ * A layer is  y = act(x[K] @ W[K,N] + b[N]).  `w_packed` is W zero-padded to
+ * (Kp = ceil8(K), Np = ceil32(N)) and stored in MFMA B-fragment order
+ *     w_packed[((nb*(Kp/8) + ks)*64 + lane)*4 + i] = W[ks*8 + 4*(lane>>5) + i][nb*32 + (lane&31)]
+ * so that one wave-wide 16-byte load is a contiguous 1 KiB; `bias` has Np
+ * entries (zero padded).  Packing is done once per parameter update by the
+ * host (efficientlo-net_amd/fused.py).
+ * ------------------------------------------------------------------------- */
+typedef struct elo_dense {
+    const float *w_packed;
+    const float *bias;
+    int K, N;
+    int relu;
+} elo_dense;
+
+#define ELO_MAX_CHAIN 3
+
+/* set-conv / set-upconv stage 1:  group_concat -> chain -> masked max over K.
+ * utils/pointnet_util.py:197-230 (down_conv) and :272-298 (up_conv). K <= 32.
+ * centre_hw != NULL: centre = xyz1_grid[b, centre_hw[b,n,0], centre_hw[b,n,1]] and is also
+ * written to new_xyz (the `new_xyz_proj` output of down_conv, :206); else centre = centre_xyz[b,n]. */
+typedef struct elo_setconv_args {
+    int batch, npoints, K;
+    int H, W;                     /* xyz1 grid (only with centre_hw)        */
+    int H2, W2, C;                /* gathered grid and its feature channels */
+    const float *xyz1_grid;       /* (batch,H,W,3) or NULL                  */
+    const int *centre_hw;         /* (batch,npoints,2) or NULL              */
+    const float *centre_xyz;      /* (batch,npoints,3) or NULL              */
+    const float *src_xyz;         /* (batch,H2,W2,3)                        */
+    const float *src_feat;        /* (batch,H2,W2,C)                        */
+    const int *idx;
+    const float *mask;
+    int n_layers;
+    elo_dense layers[ELO_MAX_CHAIN];
+    float *out;                   /* (batch,npoints,layers[last].N)         */
+    float *new_xyz;               /* (batch,npoints,3) or NULL              */
+} elo_setconv_args;
+int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream);
+
+/* Row-wise MLP over the concatenation of up to three row-aligned sources:
+ * flow_predictor (utils/pointnet_util.py:153-175) and set-upconv stage 2 (:303-311). */
+typedef struct elo_mlp_args {
+    long rows;
+    int n_sources;
+    const float *src[3];
+    int src_width[3];
+    int n_layers;
+    elo_dense layers[ELO_MAX_CHAIN];
+    float *out;                   /* (rows, layers[last].N) */
+} elo_mlp_args;
+int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream);
+
+/* Attentive cost volume, stage 1 (utils/pointnet_util.py:54-100) in one launch:
+ * encode -> CV_0..2 -> CV_xyz -> sum_CV_0..1 -> masked softmax over K -> weighted sum.
+ * sum_cv0 expects its input rows ordered [x (64), xyz-encoding (64)] (the reference
+ * concatenates [encoding, x], :84: the host permutes the weight rows when packing). K <= 32. */
+typedef struct elo_cv1_args {
+    int batch, npoints, K;
+    int H2, W2, C;
+    const float *xyz1, *feat1;    /* (batch,npoints,3), (batch,npoints,C)  */
+    const float *xyz2, *feat2;    /* (batch,H2,W2,3),  (batch,H2,W2,C)     */
+    const int *idx;
+    const float *mask;
+    elo_dense cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1;     /* N: 128,64,64,64,128,64 */
+    float *out;                   /* (batch,npoints,64) */
+} elo_cv1_args;
+int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream);
+
+/* Attentive cost volume, stage 2 (utils/pointnet_util.py:104-146) in one launch.
+ * sum_cost0 expects input rows ordered [cost[idx]*m (64), xyz-encoding (64), feat1 (C)]
+ * (reference order [encoding, feat1, grouped], :129). K <= 32, npoints == H*W. */
+typedef struct elo_cv2_args {
+    int batch, npoints, K;
+    int H, W, C;
+    const float *xyz1;            /* (batch,H,W,3)  */
+    const float *feat1;           /* (batch,H,W,C)  */
+    const float *cost;            /* (batch,H,W,64) */
+    const int *idx;
+    const float *mask;
+    elo_dense xyz_enc, sum_cost0, sum_cost1;               /* N: 64,128,64 */
+    float *out;                   /* (batch,npoints,64) */
+} elo_cv2_args;
+int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

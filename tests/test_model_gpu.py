@@ -13,6 +13,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True, params=["fused", "per-operator"])
+def kernel_path(request):
+    """Every parity test runs on both inference paths: the fused MFMA kernels (csrc/elo_fused.hip) and the
+    per-operator kernels + hipBLASLt GEMMs (csrc/elo_features.hip)."""
+    pu = load_pkg("pointnet_util")
+    pu.use_fused(request.param == "fused")
+    yield request.param
+    pu.use_fused(True)
+
+
 def _net():
     model, perm = load_pkg("model"), load_pkg("perm")
     return model.PWCLONet(DEV, seed=5, perm_source=perm.PermSource(fn=shuffle_fn))
