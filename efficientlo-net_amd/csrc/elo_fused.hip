@@ -22,23 +22,16 @@
 namespace elo {
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TILE = 32;           // rows per wave
-constexpr int FUSED_BLOCK = 64;    // one wave per workgroup: tiles are wave-private
+constexpr int FUSED_BLOCK = 256;   // 4 waves cooperate on one tile of rows
+constexpr int FUSED_WAVES = 4;
 
 __device__ __forceinline__ int ceil8(int x) { return (x + 7) & ~7; }
+__device__ __forceinline__ int ceil16(int x) { return (x + 15) & ~15; }
 
-// Phases of a tile hand data from lane to lane through the wave-private LDS image.  A wavefront's LDS
-// operations execute in program order, so no s_barrier is needed; this only stops the COMPILER from
-// moving LDS accesses across the hand-over.
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// LDS row stride (floats) for `cols` columns: a multiple of 4 with (S/4) odd.
+// LDS row stride (floats) for `cols` columns: a multiple of 4 with (S/4) odd, so that the 16 rows a
+// ds_read_b128 A-fragment touches fall into 16 different 16-byte bank slots.
 __host__ __device__ __forceinline__ int row_stride(int cols)
 {
     int s = (cols + 3) & ~3;
@@ -46,95 +39,120 @@ __host__ __device__ __forceinline__ int row_stride(int cols)
     return s;
 }
 
-// ---- one dense layer on the wave's tile ------------------------------------------------------
-template <int NB>
-__device__ __forceinline__ void dense_nb(float *act, int S, int in_off, int out_off, const elo_dense &L)
+// ---- one dense layer on the block's tile ---------------------------------------------------
+// D[TILE x Np] = relu?(A[TILE x Kp] * W + bias) on v_mfma_f32_16x16x4_f32 (exact fp32).  The tile is cut
+// into 16x16 output sub-tiles; wave w owns row block (w % RB) and every (4/RB)-th column block, keeps
+// its <= 4 accumulators in registers over the whole K loop, and streams its columns of W from L2 in
+// packed B-fragment order (one contiguous 1 KiB load per wave-instruction, prefetched one step ahead):
+//     w_packed[((cb*KS + ks)*64 + lane)*4 + s] = W[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)]
+// A comes from LDS, 16 bytes per lane per 16 k's.  Layers run IN PLACE on the tile: barrier after the
+// K loop (every wave has finished reading A), write D, barrier.
+template <int TILE, int MAXT>
+__device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_off, const elo_dense &L)
 {
-    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
-    const int KS = ceil8(L.K) >> 3;
-    f32x16 acc[NB];
+    constexpr int RB = TILE / 16;                 // row blocks: 1 or 2
+    constexpr int CSTEP = FUSED_WAVES / RB;       // column-block stride between a wave's sub-tiles
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int rb = wave % RB, cb0 = wave / RB;
+    const int KS = ceil16(L.K) >> 4, CB = ceil16(L.N) >> 4;
+    f32x4 acc[MAXT];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const float bv = L.bias[nb * 32 + col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = bv;
+    for (int t = 0; t < MAXT; ++t) {
+        const int cb = cb0 + t * CSTEP;
+        const float bv = cb < CB ? L.bias[cb * 16 + i16] : 0.0f;
+        acc[t] = f32x4{bv, bv, bv, bv};
     }
-    const float *arow = act + col * S + in_off + 4 * half;
+    const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
     const float4 *w = reinterpret_cast<const float4 *>(L.w_packed) + lane;
-    float4 bnext[NB];
+    float4 bnext[MAXT];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bnext[nb] = w[(size_t)(nb * KS) * 64];
+    for (int t = 0; t < MAXT; ++t) {
+        const int cb = cb0 + t * CSTEP;
+        bnext[t] = cb < CB ? w[(size_t)(cb * KS) * 64] : float4{0, 0, 0, 0};
+    }
     for (int ks = 0; ks < KS; ++ks) {
-        const float4 a = *reinterpret_cast<const float4 *>(arow + ks * 8);
-        float4 b[NB];
+        const float4 a = *reinterpret_cast<const float4 *>(arow + ks * 16);
+        float4 b[MAXT];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) b[nb] = bnext[nb];
+        for (int t = 0; t < MAXT; ++t) b[t] = bnext[t];
         if (ks + 1 < KS) {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bnext[nb] = w[(size_t)(nb * KS + ks + 1) * 64];
+            for (int t = 0; t < MAXT; ++t) {
+                const int cb = cb0 + t * CSTEP;
+                if (cb < CB) bnext[t] = w[(size_t)(cb * KS + ks + 1) * 64];
+            }
         }
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[nb].x, acc[nb], 0, 0, 0);
+        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[nb].y, acc[nb], 0, 0, 0);
+        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[nb].z, acc[nb], 0, 0, 0);
+        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[nb].w, acc[nb], 0, 0, 0);
+        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
     }
-    // C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    __syncthreads();                               // all A reads done: the tile may be overwritten
+    // C/D layout of a 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + r
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
+    for (int t = 0; t < MAXT; ++t) {
+        const int cb = cb0 + t * CSTEP;
+        if (cb < CB) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = acc[nb][r];
-            if (L.relu) v = fmaxf(v, 0.0f);
-            act[row * S + out_off + nb * 32 + col] = v;
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[t][r];
+                if (L.relu) v = fmaxf(v, 0.0f);
+                act[(rb * 16 + kq * 4 + r) * S + out_off + cb * 16 + i16] = v;
+            }
         }
     }
-    wave_sync();
+    __syncthreads();
 }
 
+template <int TILE>
 __device__ __forceinline__ void dense(float *act, int S, int in_off, int out_off, const elo_dense &L)
 {
-    switch ((L.N + 31) >> 5) {
-    case 1: dense_nb<1>(act, S, in_off, out_off, L); break;
-    case 2: dense_nb<2>(act, S, in_off, out_off, L); break;
-    case 3: dense_nb<3>(act, S, in_off, out_off, L); break;
-    default: dense_nb<4>(act, S, in_off, out_off, L); break;
-    }
+    constexpr int CSTEP = FUSED_WAVES / (TILE / 16);
+    const int per_wave = ((ceil16(L.N) >> 4) + CSTEP - 1) / CSTEP;      // sub-tiles per wave, <= 4 for N <= 128
+    if (per_wave <= 1) dense_t<TILE, 1>(act, S, in_off, out_off, L);
+    else if (per_wave <= 2) dense_t<TILE, 2>(act, S, in_off, out_off, L);
+    else dense_t<TILE, 4>(act, S, in_off, out_off, L);
 }
 
 // ---- per-row gather metadata of a tile -------------------------------------------------------
 struct TileMeta {
-    int *cell;      // [TILE] flat (b*H2 + h)*W2 + w of the gathered pixel, -1 = row not in use
-    float *mask;    // [TILE]
+    int *cell;      // [32] flat (b*H2 + h)*W2 + w of the gathered pixel, -1 = row not in use
+    float *mask;    // [32]
+    float *cxyz;    // [96] centre xyz of the tile's points
 };
 
-// rows of a tile = P points x K slots; lane r < TILE fetches its row's idx/mask once.
+__device__ __forceinline__ TileMeta tile_meta(float *lds, int rows, int S)
+{
+    float *base = lds + rows * S;
+    return TileMeta{reinterpret_cast<int *>(base), base + 32, base + 64};
+}
+
+// rows of a tile = P points x K slots; thread r < TILE fetches its row's idx/mask once.
+template <int TILE>
 __device__ __forceinline__ void load_meta(const TileMeta &m, long first_point, long total_points, int P, int K,
                                           const int *__restrict__ idx, const float *__restrict__ mask, int H2, int W2)
 {
-    const int lane = threadIdx.x & 63;
-    if (lane < TILE) {
-        const int pi = lane / K;
+    const int r = threadIdx.x;
+    if (r < TILE) {
+        const int pi = r / K;
         const long pt = first_point + pi;
         int cell = -1;
         float mk = 0.0f;
         if (pi < P && pt < total_points) {
-            const long gr = pt * K + (lane - pi * K);
+            const long gr = pt * K + (r - pi * K);
             const int *id = idx + gr * 3;
             cell = (id[0] * H2 + id[1]) * W2 + id[2];
             mk = mask[gr];
         }
-        m.cell[lane] = cell;
-        m.mask[lane] = mk;
+        m.cell[r] = cell;
+        m.mask[r] = mk;
     }
-    wave_sync();
 }
-
-struct Geo { float p[3], g[3], d[3], euc; };
 
 __device__ __forceinline__ float geo_channel(const float *p, const float *g, float m, int ch)
 {   // [p, g*m, g*m - p, sqrt(sum((g*m-p)^2) + 1e-20)]   utils/pointnet_util.py:54-62
@@ -147,64 +165,60 @@ __device__ __forceinline__ float geo_channel(const float *p, const float *g, flo
     return sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + 1e-20f);
 }
 
-// ---- poolings over the K rows of each point of the tile --------------------------------------
+// ---- poolings over the K rows of each point of the tile (one (point, channel) per thread) ------
 __device__ __forceinline__ void pool_masked_max(const float *act, int S, int off, int C, const TileMeta &m, int P, int K,
                                                 long first_point, long total_points, float *__restrict__ out)
 {
-    const int lane = threadIdx.x & 63;
-    for (int pi = 0; pi < P; ++pi) {
+    for (int q = threadIdx.x; q < P * C; q += FUSED_BLOCK) {
+        const int pi = q / C, c = q - pi * C;
         const long pt = first_point + pi;
-        if (pt >= total_points) break;
-        for (int c = lane; c < C; c += 64) {
-            float best = act[(pi * K) * S + off + c] * m.mask[pi * K];
-            for (int k = 1; k < K; ++k) best = fmaxf(best, act[(pi * K + k) * S + off + c] * m.mask[pi * K + k]);
-            out[pt * C + c] = best;
-        }
+        if (pt >= total_points) continue;
+        float best = act[(pi * K) * S + off + c] * m.mask[pi * K];
+        for (int k = 1; k < K; ++k) best = fmaxf(best, act[(pi * K + k) * S + off + c] * m.mask[pi * K + k]);
+        out[pt * C + c] = best;
     }
 }
 
-// out = sum_k softmax_k(mask == 1 ? logit : -1e10) * value      (64 channels, one per lane)
+// out = sum_k softmax_k(mask == 1 ? logit : -1e10) * value      (64 channels)
 __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int logit_off, int value_off,
                                                     const TileMeta &m, int P, int K, long first_point,
                                                     long total_points, float *__restrict__ out)
 {
-    const int lane = threadIdx.x & 63;
-    for (int pi = 0; pi < P; ++pi) {
+    for (int q = threadIdx.x; q < P * 64; q += FUSED_BLOCK) {
+        const int pi = q >> 6, c = q & 63;
         const long pt = first_point + pi;
-        if (pt >= total_points) break;
+        if (pt >= total_points) continue;
         float mx = -INFINITY;
         for (int k = 0; k < K; ++k) {
-            const float l = m.mask[pi * K + k] == 1.0f ? act[(pi * K + k) * S + logit_off + lane] : -1e10f;
+            const float l = m.mask[pi * K + k] == 1.0f ? act[(pi * K + k) * S + logit_off + c] : -1e10f;
             mx = fmaxf(mx, l);
         }
         float den = 0.0f, acc = 0.0f;
         for (int k = 0; k < K; ++k) {
-            const float l = m.mask[pi * K + k] == 1.0f ? act[(pi * K + k) * S + logit_off + lane] : -1e10f;
+            const float l = m.mask[pi * K + k] == 1.0f ? act[(pi * K + k) * S + logit_off + c] : -1e10f;
             const float e = expf(l - mx);
             den += e;
-            acc += e * act[(pi * K + k) * S + value_off + lane];
+            acc += e * act[(pi * K + k) * S + value_off + c];
         }
-        out[pt * 64 + lane] = acc / den;
+        out[pt * 64 + c] = acc / den;
     }
 }
 
 // ================================================================ set-conv / set-upconv stage 1
+template <int TILE>
 __global__ __launch_bounds__(FUSED_BLOCK) void setconv_kernel(const elo_setconv_args a, const int S)
 {
     extern __shared__ float lds[];
     float *act = lds;
-    TileMeta meta{reinterpret_cast<int *>(lds + TILE * S), lds + TILE * S + TILE};
-    const int lane = threadIdx.x & 63;
+    const TileMeta meta = tile_meta(lds, TILE, S);
+    const int tid = threadIdx.x;
     const int K = a.K, P = TILE / K;
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     if (first_point >= total_points) return;
-    load_meta(meta, first_point, total_points, P, K, a.idx, a.mask, a.H2, a.W2);
-
-    // centres of the tile's points: cxyz[pi*3 + c] kept in LDS next to the metadata
-    float *cxyz = meta.mask + TILE;
-    if (lane < P * 3) {
-        const int pi = lane / 3, c = lane - pi * 3;
+    load_meta<TILE>(meta, first_point, total_points, P, K, a.idx, a.mask, a.H2, a.W2);
+    if (tid >= 64 && tid < 64 + P * 3) {              // centres of the tile's points (second wave)
+        const int q = tid - 64, pi = q / 3, c = q - pi * 3;
         const long pt = first_point + pi;
         float v = 0.0f;
         if (pt < total_points) {
@@ -217,38 +231,39 @@ __global__ __launch_bounds__(FUSED_BLOCK) void setconv_kernel(const elo_setconv_
                 v = a.centre_xyz[pt * 3 + c];
             }
         }
-        cxyz[lane] = v;
+        meta.cxyz[q] = v;
     }
-    wave_sync();
+    __syncthreads();
     // gather + centre-subtract + concat into act[row][0 .. CTp)                   :203-213 / :277-284
-    const int CT = 3 + a.C, CTp = ceil8(CT);
-    for (int e = lane; e < TILE * CTp; e += 64) {
+    const int CT = 3 + a.C, CTp = ceil16(CT);
+    for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {
         const int row = e / CTp, ch = e - row * CTp;
         const int cell = meta.cell[row];
         float v = 0.0f;
         if (cell >= 0 && ch < CT) {
             const float m = meta.mask[row];
-            v = ch < 3 ? a.src_xyz[(long)cell * 3 + ch] * m - cxyz[(row / K) * 3 + ch]
+            v = ch < 3 ? a.src_xyz[(long)cell * 3 + ch] * m - meta.cxyz[(row / K) * 3 + ch]
                        : a.src_feat[(long)cell * a.C + (ch - 3)] * m;
         }
         act[row * S + ch] = v;
     }
-    wave_sync();
-    for (int l = 0; l < a.n_layers; ++l) dense(act, S, 0, 0, a.layers[l]);          // in place, :217-222
+    __syncthreads();
+    for (int l = 0; l < a.n_layers; ++l) dense<TILE>(act, S, 0, 0, a.layers[l]);    // in place, :217-222
     pool_masked_max(act, S, 0, a.layers[a.n_layers - 1].N, meta, P, K, first_point, total_points, a.out);   // :224-230
 }
 
 // ================================================================ row-wise MLP over concatenated sources
+template <int TILE>
 __global__ __launch_bounds__(FUSED_BLOCK) void mlp_kernel(const elo_mlp_args a, const int S)
 {
     extern __shared__ float lds[];
     float *act = lds;
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x;
     const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * TILE;
     if (first >= a.rows) return;
     const int w0 = a.src_width[0], w1 = a.n_sources > 1 ? a.src_width[1] : 0, w2 = a.n_sources > 2 ? a.src_width[2] : 0;
-    const int CT = w0 + w1 + w2, CTp = ceil8(CT);
-    for (int e = lane; e < TILE * CTp; e += 64) {
+    const int CT = w0 + w1 + w2, CTp = ceil16(CT);
+    for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {
         const int row = e / CTp, ch = e - row * CTp;
         const long gr = first + row;
         float v = 0.0f;
@@ -259,10 +274,10 @@ __global__ __launch_bounds__(FUSED_BLOCK) void mlp_kernel(const elo_mlp_args a, 
         }
         act[row * S + ch] = v;
     }
-    wave_sync();
-    for (int l = 0; l < a.n_layers; ++l) dense(act, S, 0, 0, a.layers[l]);
+    __syncthreads();
+    for (int l = 0; l < a.n_layers; ++l) dense<TILE>(act, S, 0, 0, a.layers[l]);
     const int N = a.layers[a.n_layers - 1].N;
-    for (int e = lane; e < TILE * N; e += 64) {
+    for (int e = tid; e < TILE * N; e += FUSED_BLOCK) {
         const int row = e / N, c = e - row * N;
         const long gr = first + row;
         if (gr < a.rows) a.out[gr * N + c] = act[row * S + c];
@@ -271,19 +286,21 @@ __global__ __launch_bounds__(FUSED_BLOCK) void mlp_kernel(const elo_mlp_args a, 
 
 // ================================================================ cost volume, stage 1
 // LDS columns: [0,128) = X (CV chain, later [x3 | enc]),  [128, 128 + max(CTp,128)) = F (feat_cat, later sum_CV)
+template <int TILE>
 __global__ __launch_bounds__(FUSED_BLOCK) void cv1_kernel(const elo_cv1_args a, const int S)
 {
     extern __shared__ float lds[];
     float *act = lds;
-    TileMeta meta{reinterpret_cast<int *>(lds + TILE * S), lds + TILE * S + TILE};
-    const int lane = threadIdx.x & 63;
+    const TileMeta meta = tile_meta(lds, TILE, S);
+    const int tid = threadIdx.x;
     const int K = a.K, P = TILE / K, C = a.C;
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     if (first_point >= total_points) return;
-    load_meta(meta, first_point, total_points, P, K, a.idx, a.mask, a.H2, a.W2);
-    const int F = 128, CT = 10 + 2 * C, CTp = ceil8(CT);
-    for (int e = lane; e < TILE * CTp; e += 64) {                                     // :54-66
+    load_meta<TILE>(meta, first_point, total_points, P, K, a.idx, a.mask, a.H2, a.W2);
+    __syncthreads();
+    const int F = 128, CT = 10 + 2 * C, CTp = ceil16(CT);
+    for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {                             // :54-66
         const int row = e / CTp, ch = e - row * CTp;
         const int cell = meta.cell[row];
         float v = 0.0f;
@@ -296,54 +313,60 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv1_kernel(const elo_cv1_args a, 
         }
         act[row * S + F + ch] = v;
     }
-    wave_sync();
-    dense(act, S, F, 0, a.cv0);           // feat_cat -> 128                           :72-76
-    dense(act, S, 0, 0, a.cv1);           // -> 64 (in place)
-    dense(act, S, 0, 0, a.cv2);           // -> 64 = x                                  (values of the pooling)
-    dense(act, S, F, 64, a.cv_xyz);       // xyz_cat (first 10 columns of F) -> enc at [64,128)      :79-82
-    dense(act, S, 0, F, a.sum_cv0);       // [x | enc] -> 128 into F                    :84-90
-    dense(act, S, F, F, a.sum_cv1);       // -> 64 logits (in place)
+    __syncthreads();
+    dense<TILE>(act, S, F, 0, a.cv0);           // feat_cat -> 128                     :72-76
+    dense<TILE>(act, S, 0, 0, a.cv1);           // -> 64 (in place)
+    dense<TILE>(act, S, 0, 0, a.cv2);           // -> 64 = x                            (values of the pooling)
+    dense<TILE>(act, S, F, 64, a.cv_xyz);       // xyz_cat (first 10 columns of F) -> enc at [64,128)   :79-82
+    dense<TILE>(act, S, 0, F, a.sum_cv0);       // [x | enc] -> 128 into F              :84-90
+    dense<TILE>(act, S, F, F, a.sum_cv1);       // -> 64 logits (in place)
     pool_masked_softmax(act, S, F, 0, meta, P, K, first_point, total_points, a.out);    // :92-98
 }
 
 // ================================================================ cost volume, stage 2
 // LDS columns: [0,64) grouped cost, [64,128) xyz-encoding, [128,128+C) feat1, [192,208) xyz_cat;
 // sum_cost0 reads [0,128+C) and writes [64,192); sum_cost1 maps [64,192) -> [64,128).
+template <int TILE>
 __global__ __launch_bounds__(FUSED_BLOCK) void cv2_kernel(const elo_cv2_args a, const int S)
 {
     extern __shared__ float lds[];
     float *act = lds;
-    TileMeta meta{reinterpret_cast<int *>(lds + TILE * S), lds + TILE * S + TILE};
-    const int lane = threadIdx.x & 63;
+    const TileMeta meta = tile_meta(lds, TILE, S);
+    const int tid = threadIdx.x;
     const int K = a.K, P = TILE / K, C = a.C;
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     if (first_point >= total_points) return;
-    load_meta(meta, first_point, total_points, P, K, a.idx, a.mask, a.H, a.W);
-    const int Cp = ceil8(C), XYZ = 192;
-    for (int e = lane; e < TILE * 64; e += 64) {                                      // grouped cost * mask  :110
+    load_meta<TILE>(meta, first_point, total_points, P, K, a.idx, a.mask, a.H, a.W);
+    __syncthreads();
+    const int Cp = ceil16(C), XYZ = 192;
+    for (int e = tid; e < TILE * 64; e += FUSED_BLOCK) {                              // grouped cost * mask  :110
         const int row = e >> 6, ch = e & 63;
         const int cell = meta.cell[row];
         act[row * S + ch] = cell >= 0 ? a.cost[(long)cell * 64 + ch] * meta.mask[row] : 0.0f;
     }
-    for (int e = lane; e < TILE * Cp; e += 64) {                                      // centre features      :115
+    for (int e = tid; e < TILE * Cp; e += FUSED_BLOCK) {                              // centre features      :115
         const int row = e / Cp, ch = e - row * Cp;
         const long pt = first_point + row / K;
         act[row * S + 128 + ch] = (meta.cell[row] >= 0 && ch < C) ? a.feat1[pt * C + ch] : 0.0f;
     }
-    for (int e = lane; e < TILE * 16; e += 64) {                                      // 10-channel geometry  :111-120
+    for (int e = tid; e < TILE * 16; e += FUSED_BLOCK) {                              // 10-channel geometry  :111-120
         const int row = e >> 4, ch = e & 15;
         const int cell = meta.cell[row];
         const long pt = first_point + row / K;
         act[row * S + XYZ + ch] = (cell >= 0 && ch < 10)
             ? geo_channel(a.xyz1 + pt * 3, a.xyz1 + (long)cell * 3, meta.mask[row], ch) : 0.0f;
     }
-    wave_sync();
-    dense(act, S, XYZ, 64, a.xyz_enc);     // -> enc at [64,128)                        :123-126
-    dense(act, S, 0, 64, a.sum_cost0);     // [grouped | enc | feat1] -> 128 at [64,192) :129-135
-    dense(act, S, 64, 64, a.sum_cost1);    // -> 64 logits at [64,128)
+    __syncthreads();
+    dense<TILE>(act, S, XYZ, 64, a.xyz_enc);     // -> enc at [64,128)                  :123-126
+    dense<TILE>(act, S, 0, 64, a.sum_cost0);     // [grouped | enc | feat1] -> 128 at [64,192)   :129-135
+    dense<TILE>(act, S, 64, 64, a.sum_cost1);    // -> 64 logits at [64,128)
     pool_masked_softmax(act, S, 64, 0, meta, P, K, first_point, total_points, a.out);   // :137-146
 }
+
+// A 16-row tile halves the serial work per workgroup and doubles their number: take it whenever the
+// K rows of a point fit and 32-row tiles would leave most of the 256 CUs without a workgroup.
+inline bool small_tile(long units_at_32, int K) { return K <= 16 && units_at_32 < 1024; }
 
 int check_dense(const elo_dense &L, int K, int N, const char *who, const char *name)
 {
@@ -354,7 +377,7 @@ int check_dense(const elo_dense &L, int K, int N, const char *who, const char *n
     return ELO_OK;
 }
 
-size_t tile_lds_bytes(int S) { return sizeof(float) * ((size_t)TILE * S + 2 * TILE + 3 * TILE); }
+size_t tile_lds_bytes(int rows, int S) { return sizeof(float) * ((size_t)rows * S + 64 + 96); }
 
 #define ELO_REQUIRE(cond, who, what) \
     do { if (!(cond)) return fail(ELO_ERR_ARG, "%s: %s", who, what); } while (0)
@@ -364,27 +387,48 @@ size_t tile_lds_bytes(int S) { return sizeof(float) * ((size_t)TILE * S + 2 * TI
 
 using namespace elo;
 
+static inline int pad16(int x) { return (x + 15) & ~15; }
+
+template <typename Args, typename K32, typename K16>
+static int launch_tile(const char *who, bool tile16, long units16, long units32, int S, hipStream_t s, const Args &a,
+                       K32 k32, K16 k16)
+{
+    if (tile16)
+        hipLaunchKernelGGL(k16, dim3((unsigned)units16), dim3(FUSED_BLOCK), tile_lds_bytes(16, S), s, a, S);
+    else
+        hipLaunchKernelGGL(k32, dim3((unsigned)units32), dim3(FUSED_BLOCK), tile_lds_bytes(32, S), s, a, S);
+    return check_launch(who);
+}
+
+// column budget of an in-place chain starting from `width` input columns
+static int chain_cols(const elo_dense *layers, int n_layers, int width)
+{
+    int cols = pad16(width);
+    for (int l = 0; l < n_layers; ++l) cols = cols > pad16(layers[l].N) ? cols : pad16(layers[l].N);
+    return cols;
+}
+
 extern "C" int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream)
 {
     const char *who = "elo_setconv_fused";
     ELO_REQUIRE(a, who, "null argument block");
     ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->K > 0 && a->H2 > 0 && a->W2 > 0 && a->C >= 0, who, "bad sizes");
-    if (a->K > TILE) return fail(ELO_ERR_LIMIT, "%s: K = %d exceeds the %d-row tile", who, a->K, TILE);
+    if (a->K > 32) return fail(ELO_ERR_LIMIT, "%s: K = %d exceeds the 32-row tile", who, a->K);
     ELO_REQUIRE(a->n_layers >= 1 && a->n_layers <= ELO_MAX_CHAIN, who, "1..3 layers");
     ELO_REQUIRE(a->src_xyz && (a->src_feat || a->C == 0) && a->idx && a->mask && a->out, who, "null tensor pointer");
     ELO_REQUIRE((a->centre_hw && a->xyz1_grid && a->H > 0 && a->W > 0) || a->centre_xyz, who, "no centre source");
-    int width = 3 + a->C, cols = (width + 7) & ~7;
+    int width = 3 + a->C;
     for (int l = 0; l < a->n_layers; ++l) {
         if (int rc = check_dense(a->layers[l], width, 0, who, "mlp")) return rc;
         width = a->layers[l].N;
-        cols = cols > ((width + 31) & ~31) ? cols : ((width + 31) & ~31);
     }
     const long points = (long)a->batch * a->npoints;
     if (points == 0) return ELO_OK;
-    const int P = TILE / a->K, S = row_stride(cols);
-    const unsigned grid = (unsigned)((points + P - 1) / P);
-    hipLaunchKernelGGL(setconv_kernel, dim3(grid), dim3(FUSED_BLOCK), tile_lds_bytes(S), (hipStream_t)stream, *a, S);
-    return check_launch(who);
+    const int S = row_stride(chain_cols(a->layers, a->n_layers, 3 + a->C));
+    const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
+    const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
+    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, setconv_kernel<32>,
+                       setconv_kernel<16>);
 }
 
 extern "C" int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream)
@@ -398,17 +442,15 @@ extern "C" int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream)
         ELO_REQUIRE(a->src[s] && a->src_width[s] > 0, who, "null / empty source");
         width += a->src_width[s];
     }
-    int cols = (width + 7) & ~7;
+    const int in_width = width;
     for (int l = 0; l < a->n_layers; ++l) {
         if (int rc = check_dense(a->layers[l], width, 0, who, "mlp")) return rc;
         width = a->layers[l].N;
-        cols = cols > ((width + 31) & ~31) ? cols : ((width + 31) & ~31);
     }
     if (a->rows == 0) return ELO_OK;
-    const int S = row_stride(cols);
-    const unsigned grid = (unsigned)((a->rows + TILE - 1) / TILE);
-    hipLaunchKernelGGL(mlp_kernel, dim3(grid), dim3(FUSED_BLOCK), tile_lds_bytes(S), (hipStream_t)stream, *a, S);
-    return check_launch(who);
+    const int S = row_stride(chain_cols(a->layers, a->n_layers, in_width));
+    const long u32 = (a->rows + 31) / 32, u16 = (a->rows + 15) / 16;
+    return launch_tile(who, small_tile(u32, 1), u16, u32, S, (hipStream_t)stream, *a, mlp_kernel<32>, mlp_kernel<16>);
 }
 
 extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
@@ -416,7 +458,7 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
     const char *who = "elo_cv_stage1_fused";
     ELO_REQUIRE(a, who, "null argument block");
     ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->K > 0 && a->H2 > 0 && a->W2 > 0 && a->C > 0, who, "bad sizes");
-    if (a->K > TILE) return fail(ELO_ERR_LIMIT, "%s: K = %d exceeds the %d-row tile", who, a->K, TILE);
+    if (a->K > 32) return fail(ELO_ERR_LIMIT, "%s: K = %d exceeds the 32-row tile", who, a->K);
     ELO_REQUIRE(a->xyz1 && a->feat1 && a->xyz2 && a->feat2 && a->idx && a->mask && a->out, who, "null tensor pointer");
     const int CT = 10 + 2 * a->C;
     if (int rc = check_dense(a->cv0, CT, 128, who, "CV_0")) return rc;
@@ -427,11 +469,11 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
     if (int rc = check_dense(a->sum_cv1, 128, 64, who, "sum_CV_1")) return rc;
     const long points = (long)a->batch * a->npoints;
     if (points == 0) return ELO_OK;
-    const int CTp = (CT + 7) & ~7, P = TILE / a->K;
+    const int CTp = pad16(CT);
     const int S = row_stride(128 + (CTp > 128 ? CTp : 128));
-    const unsigned grid = (unsigned)((points + P - 1) / P);
-    hipLaunchKernelGGL(cv1_kernel, dim3(grid), dim3(FUSED_BLOCK), tile_lds_bytes(S), (hipStream_t)stream, *a, S);
-    return check_launch(who);
+    const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
+    const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
+    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv1_kernel<32>, cv1_kernel<16>);
 }
 
 extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
@@ -440,7 +482,7 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
     ELO_REQUIRE(a, who, "null argument block");
     ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->K > 0 && a->H > 0 && a->W > 0 && a->C > 0, who, "bad sizes");
     ELO_REQUIRE(a->npoints == a->H * a->W, who, "npoints must equal H*W (every pixel is a centre)");
-    if (a->K > TILE) return fail(ELO_ERR_LIMIT, "%s: K = %d exceeds the %d-row tile", who, a->K, TILE);
+    if (a->K > 32) return fail(ELO_ERR_LIMIT, "%s: K = %d exceeds the 32-row tile", who, a->K);
     if (a->C > 64) return fail(ELO_ERR_LIMIT, "%s: C = %d exceeds 64", who, a->C);
     ELO_REQUIRE(a->xyz1 && a->feat1 && a->cost && a->idx && a->mask && a->out, who, "null tensor pointer");
     if (int rc = check_dense(a->xyz_enc, 10, 64, who, "sum_xyz_encoding")) return rc;
@@ -448,8 +490,8 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
     if (int rc = check_dense(a->sum_cost1, 128, 64, who, "sum_cost_volume_1")) return rc;
     const long points = (long)a->batch * a->npoints;
     if (points == 0) return ELO_OK;
-    const int P = TILE / a->K, S = row_stride(208);
-    const unsigned grid = (unsigned)((points + P - 1) / P);
-    hipLaunchKernelGGL(cv2_kernel, dim3(grid), dim3(FUSED_BLOCK), tile_lds_bytes(S), (hipStream_t)stream, *a, S);
-    return check_launch(who);
+    const int S = row_stride(208);
+    const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
+    const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
+    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv2_kernel<32>, cv2_kernel<16>);
 }

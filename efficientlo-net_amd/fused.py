@@ -10,17 +10,17 @@ from . import tf_util
 
 
 class PackedDense:
-    """One inference layer y = act(x @ W + b) with BN folded, packed for v_mfma_f32_32x32x2_f32."""
+    """One inference layer y = act(x @ W + b) with BN folded, packed for v_mfma_f32_16x16x4_f32."""
 
     def __init__(self, W, b, relu=True, row_order=None):
         if row_order is not None:                         # the kernel's LDS column order differs from the concat order
             W = W[row_order]
         K, N = W.shape
-        Kp, Np = (K + 7) // 8 * 8, (N + 31) // 32 * 32
+        Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
         Wp = torch.zeros((Kp, Np), dtype=torch.float32, device=W.device)
         Wp[:K, :N] = W
-        # packed[((nb*KS + ks)*64 + lane)*4 + i] = Wp[ks*8 + 4*(lane>>5) + i][nb*32 + (lane&31)]
-        self.w = Wp.reshape(Kp // 8, 2, 4, Np // 32, 32).permute(3, 0, 1, 4, 2).contiguous()
+        # packed[((cb*KS + ks)*64 + lane)*4 + s] = Wp[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)]
+        self.w = Wp.reshape(Kp // 16, 4, 4, Np // 16, 16).permute(3, 0, 1, 4, 2).contiguous()
         self.b = torch.zeros((Np,), dtype=torch.float32, device=W.device)
         self.b[:N] = b
         self.K, self.N, self.relu = K, N, relu

@@ -235,14 +235,14 @@ int elo_warp_project(const elo_warp_project_args *a, elo_stream_t stream);
 /* ------------------------------------------------------------------------- *
  * Fused inference kernels: gather/encode -> chain of 1x1 convolutions (BN and
  * bias folded, ReLU) -> pooling, in ONE launch with the activations of a
- * 32-row tile resident in LDS and the contractions on the fp32 matrix cores
- * (v_mfma_f32_32x32x2_f32: exact fp32, bit-equal to an fmaf chain).  They
+ * 16/32-row tile resident in LDS and the contractions on the fp32 matrix cores
+ * (v_mfma_f32_16x16x4_f32: exact fp32, bit-equal to an fmaf chain).  They
  * compute what the unfused kernels above + the hipBLASLt GEMMs compute, for
  * the launch-bound small-batch regime.
  *
  * A layer is  y = act(x[K] @ W[K,N] + b[N]).  `w_packed` is W zero-padded to
- * (Kp = ceil8(K), Np = ceil32(N)) and stored in MFMA B-fragment order
- *     w_packed[((nb*(Kp/8) + ks)*64 + lane)*4 + i] = W[ks*8 + 4*(lane>>5) + i][nb*32 + (lane&31)]
+ * (Kp = ceil16(K), Np = ceil16(N)) and stored in v_mfma_f32_16x16x4_f32 B-fragment order
+ *     w_packed[((cb*(Kp/16) + ks)*64 + lane)*4 + s] = W[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)]
  * so that one wave-wide 16-byte load is a contiguous 1 KiB; `bias` has Np
  * entries (zero padded).  Packing is done once per parameter update by the
  * host (efficientlo-net_amd/fused.py).
