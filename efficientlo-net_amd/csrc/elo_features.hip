@@ -251,13 +251,27 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
         big[j] = v;
     }
     __syncthreads();
-    if (tid < 7) {                                          // conv1d hidden -> 4 (q) and hidden -> 3 (t)
-        const bool isq = tid < 4;
-        const int o = isq ? tid : tid - 4, n = isq ? 4 : 3;
-        const float *W = isq ? a.W_q : a.W_t;
-        float v = isq ? a.b_q[o] : a.b_t[o];
-        for (int j = 0; j < a.hidden; ++j) v += big[j] * W[(size_t)j * n + o];
-        head[tid] = v;
+    {   // conv1d hidden -> 4 (q) and hidden -> 3 (t): 7 dot products over `hidden`, reduced wave-wide then across waves
+        float part[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int j = tid; j < a.hidden; j += blockDim.x) {
+            const float bj = big[j];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) part[o] += bj * a.W_q[(size_t)j * 4 + o];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) part[4 + o] += bj * a.W_t[(size_t)j * 3 + o];
+        }
+#pragma unroll
+        for (int o = 0; o < 7; ++o)
+            for (int d = 32; d >= 1; d >>= 1) part[o] += __shfl_xor(part[o], d, ELO_WAVE);
+        float *wsum = head + 8;                       // [waves][8]
+        if ((tid & 63) == 0)
+            for (int o = 0; o < 7; ++o) wsum[(tid >> 6) * 8 + o] = part[o];
+        __syncthreads();
+        if (tid < 7) {
+            float v = tid < 4 ? a.b_q[tid] : a.b_t[tid - 4];
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += wsum[w * 8 + tid];
+            head[tid] = v;
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -461,7 +475,7 @@ extern "C" int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream)
     hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
                        dim3(ELO_BLOCK), 0, (hipStream_t)stream, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
                        a->scratch);
-    const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8);
+    const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (ELO_BLOCK / ELO_WAVE));
     hipLaunchKernelGGL(pose_head_kernel, dim3(a->batch), dim3(ELO_BLOCK), lds, (hipStream_t)stream, *a, parts);
     return check_launch(who);
 }

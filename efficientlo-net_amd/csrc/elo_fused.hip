@@ -52,10 +52,12 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
 {
     constexpr int RB = TILE / 16;                 // row blocks: 1 or 2
     constexpr int CSTEP = FUSED_WAVES / RB;       // column-block stride between a wave's sub-tiles
+    constexpr int GS = MAXT >= 4 ? 2 : 4;         // K steps per prefetch group (register budget: 2*GS*MAXT float4)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
     const int rb = wave % RB, cb0 = wave / RB;
     const int KS = ceil16(L.K) >> 4, CB = ceil16(L.N) >> 4;
+    const int NG = (KS + GS - 1) / GS;
     f32x4 acc[MAXT];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
@@ -65,32 +67,48 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
     }
     const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
     const float4 *w = reinterpret_cast<const float4 *>(L.w_packed) + lane;
-    float4 bnext[MAXT];
+
+    // W is streamed from L2 with a load-to-use distance of one whole group of K steps (two register sets).
+    auto fetch = [&](int g, float4 (&buf)[GS][MAXT]) {
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        const int cb = cb0 + t * CSTEP;
-        bnext[t] = cb < CB ? w[(size_t)(cb * KS) * 64] : float4{0, 0, 0, 0};
-    }
-    for (int ks = 0; ks < KS; ++ks) {
-        const float4 a = *reinterpret_cast<const float4 *>(arow + ks * 16);
-        float4 b[MAXT];
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) b[t] = bnext[t];
-        if (ks + 1 < KS) {
+        for (int s = 0; s < GS; ++s) {
+            const int ks = g * GS + s;
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 const int cb = cb0 + t * CSTEP;
-                if (cb < CB) bnext[t] = w[(size_t)(cb * KS + ks + 1) * 64];
+                buf[s][t] = (ks < KS && cb < CB) ? w[(size_t)(cb * KS + ks) * 64] : float4{0, 0, 0, 0};
             }
         }
+    };
+    auto compute = [&](int g, const float4 (&buf)[GS][MAXT]) {
+        float4 a[GS];
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
+        for (int s = 0; s < GS; ++s) {
+            const int ks = g * GS + s;
+            a[s] = ks < KS ? *reinterpret_cast<const float4 *>(arow + ks * 16) : float4{0, 0, 0, 0};
+        }
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
+        for (int s = 0; s < GS; ++s) {
+            if (g * GS + s >= KS) break;
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
+            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].x, buf[s][t].x, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
+            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].y, buf[s][t].y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].z, buf[s][t].z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].w, buf[s][t].w, acc[t], 0, 0, 0);
+        }
+    };
+    float4 b0[GS][MAXT], b1[GS][MAXT];
+    fetch(0, b0);
+    for (int g = 0; g < NG; g += 2) {
+        if (g + 1 < NG) fetch(g + 1, b1);
+        compute(g, b0);
+        if (g + 1 < NG) {
+            if (g + 2 < NG) fetch(g + 2, b0);
+            compute(g + 1, b1);
+        }
     }
     __syncthreads();                               // all A reads done: the tile may be overwritten
     // C/D layout of a 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + r

@@ -44,6 +44,21 @@ def warping_layers(xyz1, upsampled_flow):
 
 
 _hw_cache = {}
+_centre_hw_cache = {}
+
+
+def _centre_hw(selected_idx):
+    """(B,n,2) contiguous (h,w) columns of a (B,H',W',3) (b,h,w) index grid; cached for the cached grids
+    model_util.get_selected_idx hands out (keyed by storage address + shape)."""
+    key = (selected_idx.data_ptr(), tuple(selected_idx.shape), str(selected_idx.device))
+    hit = _centre_hw_cache.get(key)
+    if hit is None or hit[0] is not selected_idx:
+        B = selected_idx.shape[0]
+        hit = (selected_idx, selected_idx.reshape(B, -1, 3)[:, :, 1:].contiguous())
+        if len(_centre_hw_cache) > 64:
+            _centre_hw_cache.clear()
+        _centre_hw_cache[key] = hit
+    return hit[1]
 
 
 def get_hw_idx(B, H, W, device="cuda"):
@@ -203,8 +218,9 @@ def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distan
         n_sampled = idx_n2.shape[1]
         dev = xyz_proj.device
         random_HW = random_shuffle(tf_util.scope_name(), "random_HW", kernel_size[0] * kernel_size[1], dev)
+        centre_hw = _centre_hw(selected_idx)
         sel, _, _, valid_mask = fused_conv_random_k(
-            xyz_proj, xyz_proj, idx_n2[:, :, 1:].contiguous(), random_HW, H, W, n_sampled, kernel_size[0],
+            xyz_proj, xyz_proj, centre_hw, random_HW, H, W, n_sampled, kernel_size[0],
             kernel_size[1], K_sample, flag_copy=0, distance=distance, stride_h=1, stride_w=1, want_valid=False)  # :197-199
         mask = valid_mask.reshape(B, n_sampled, K_sample)
         if _fused_path(is_training) and len(mlp) <= 3 and K_sample <= 32:
@@ -213,7 +229,7 @@ def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distan
             widths = [3 + points_proj.shape[-1]] + list(mlp)
             layers = [fused.packed_layer('conv%d' % i, widths[i], widths[i + 1], bn=bn) for i in range(len(mlp))]
             out, new_xyz = fused.setconv(xyz_proj, points_proj, sel, mask, layers, xyz1_grid=xyz_proj,
-                                         centre_hw=idx_n2[:, :, 1:].contiguous())
+                                         centre_hw=centre_hw)
             return out, new_xyz.reshape(selected_idx.shape[:-1] + (3,))
         li = selected_idx.reshape(-1, 3).long()
         new_xyz_proj = xyz_proj[li[:, 0], li[:, 1], li[:, 2]].reshape(selected_idx.shape[:-1] + (3,))  # :206
