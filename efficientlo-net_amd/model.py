@@ -51,16 +51,18 @@ class PWCLONet:
         dev = self.device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        zeros = lambda: torch.zeros((batch_size, H_input, W_input, 3), device=dev)
+        def zeros():          # both frames in one allocation: the Siamese pyramid then runs as one 2B batch
+            both = torch.zeros((2 * batch_size, H_input, W_input, 3), device=dev)
+            return both[:batch_size], both[batch_size:]
         with torch.cuda.stream(side):
-            probe = (zeros(), zeros())
+            probe = zeros()
             for _ in range(warmup):                 # creates variables, folded weights, caches, hipBLASLt plans
                 self.forward(*probe)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self._lanes = []
         for _ in range(lanes):
-            lane = {"stream": torch.cuda.Stream(device=dev), "in": (zeros(), zeros()), "graph": torch.cuda.CUDAGraph()}
+            lane = {"stream": torch.cuda.Stream(device=dev), "in": zeros(), "graph": torch.cuda.CUDAGraph()}
             with torch.cuda.graph(lane["graph"]):
                 lane["out"] = self.forward(*lane["in"])
             self._lanes.append(lane)

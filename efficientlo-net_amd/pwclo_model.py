@@ -93,6 +93,16 @@ def placeholder_inputs(batch_size, NUM_POINTS, device="cuda"):
     return z(batch_size, NUM_POINTS * 2, 6), z(batch_size, 4, 4), z(batch_size, 4, 4), z(batch_size, 4, 4)
 
 
+def _adjacent_frames(a, b):
+    """If b starts exactly where a ends in the same allocation (PWCLONet keeps both range images in one
+    (2B,H,W,3) buffer), return that (2B,H,W,3) tensor as a view -- no copy; else None."""
+    if (a.shape == b.shape and a.dtype == b.dtype and a.device == b.device and a.is_contiguous() and b.is_contiguous()
+            and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size()
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()):
+        return torch.as_strided(a, (2 * a.shape[0],) + tuple(a.shape[1:]), a.stride())
+    return None
+
+
 def _normalise_q(q):
     return q / (torch.sqrt((q * q).sum(-1, keepdim=True) + 1e-10) + 1e-10)
 
@@ -141,8 +151,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
     dev = xyz_f1_input_proj.device
     out_h_list, out_w_list = pyramid_sizes(H_input, W_input)
 
-    points_f1_input_proj = torch.zeros((batch_size, H_input, W_input, 3), dtype=torch.float32, device=dev)  # :69-70
-    points_f2_input_proj = points_f1_input_proj
+    zero_features = lambda like: torch.zeros_like(like)                                             # :69-70
 
     # strided centre grids (:88-114).  Only the index tensors matter: down_conv re-gathers the xyz itself.
     pre2 = xyz_f1_input_proj
@@ -151,7 +160,9 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
     l2_selected_idx = get_selected_idx(pre2, stride_h_list[4], stride_w_list[4], out_h_list[4], out_w_list[4])
     l3_selected_idx = get_selected_idx(pre2, stride_h_list[5], stride_w_list[5], out_h_list[5], out_w_list[5])
 
-    def feature_pyramid(xyz_in, points_in):                                                         # :126-139 / :151-164
+    def feature_pyramid(xyz_in, points_in, sel):                                                    # :126-139 / :151-164
+        l0_selected_idx, l1_selected_idx, l2_selected_idx, l3_selected_idx = sel
+        batch_size = xyz_in.shape[0]
         l0_points, l0_xyz_proj = down_conv(xyz_in, points_in, l0_selected_idx, K_sample=32, kernel_size=[9, 15],
                                            distance=Down_conv_dis[0], mlp=[8, 8, 16], mlp2=None, flag_add=False,
                                            is_training=is_training, bn_decay=bn_decay, scope='layer0')
@@ -172,9 +183,24 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                 [l0_xyz_proj, l1_xyz_proj, l2_xyz_proj, l3_xyz_proj])
 
     with tf_util.variable_scope('sa1') as scope:                                                    # :117
-        pts_f1, pts_proj_f1, xyz_proj_f1 = feature_pyramid(xyz_f1_input_proj, points_f1_input_proj)
-        scope.reuse_variables()                                                                     # :143
-        pts_f2, pts_proj_f2, xyz_proj_f2 = feature_pyramid(xyz_f2_input_proj, points_f2_input_proj)
+        both = _adjacent_frames(xyz_f1_input_proj, xyz_f2_input_proj) if not is_training else None
+        if both is not None and not torch.is_grad_enabled():
+            # Siamese pyramid in ONE pass: the two frames share every weight (:143), and inference BN uses moving
+            # statistics, so frame 2 is just batch elements B..2B-1 -- half the launches, identical numbers.
+            sel2 = [get_selected_idx(both, stride_h_list[i], stride_w_list[i], out_h_list[i], out_w_list[i])
+                    for i in (2, 3, 4, 5)]
+            pts, pts_proj, xyz_proj = feature_pyramid(both, zero_features(both), sel2)
+            B = batch_size
+            pts_f1, pts_f2 = [p[:B] for p in pts], [p[B:] for p in pts]
+            pts_proj_f1 = [None if p is None else p[:B] for p in pts_proj]
+            pts_proj_f2 = [None if p is None else p[B:] for p in pts_proj]
+            xyz_proj_f1, xyz_proj_f2 = [x[:B] for x in xyz_proj], [x[B:] for x in xyz_proj]
+        else:
+            sel1 = [l0_selected_idx, l1_selected_idx, l2_selected_idx, l3_selected_idx]
+            points_input_proj = zero_features(xyz_f1_input_proj)
+            pts_f1, pts_proj_f1, xyz_proj_f1 = feature_pyramid(xyz_f1_input_proj, points_input_proj, sel1)
+            scope.reuse_variables()                                                                 # :143
+            pts_f2, pts_proj_f2, xyz_proj_f2 = feature_pyramid(xyz_f2_input_proj, points_input_proj, sel1)
 
     # initial cost volume at l2 and the extra set-conv on it (:170-177)
     l2_points_f1_new = cost_volume(xyz_proj_f1[2], xyz_proj_f2[2], pts_proj_f1[2], pts_proj_f2[2],

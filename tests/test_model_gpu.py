@@ -33,7 +33,11 @@ def test_full_pyramid_matches_oracle(B, H, W):
     synth = load_pkg("synth")
     f1, f2 = synth.frame_pair(B, H, W, seed=40)
     net = _net()
-    a, b = torch.from_numpy(f1).to(DEV), torch.from_numpy(f2).to(DEV)
+    if B == 1:      # both frames in one allocation: the Siamese pyramid runs as one 2B batch (pwclo_model._adjacent_frames)
+        both = torch.from_numpy(np.concatenate([f1, f2], 0)).to(DEV)
+        a, b = both[:B], both[B:]
+    else:
+        a, b = torch.from_numpy(f1).to(DEV), torch.from_numpy(f2).to(DEV)
     net.forward(a, b)                       # creates the variables
     randomise(net.store, seed=7)
     got = net.forward(a, b)
@@ -58,7 +62,8 @@ def test_graph_replay_equals_eager():
     synth = load_pkg("synth")
     net = _net()
     f1, f2 = synth.frame_pair(1, 64, 1800, seed=41)
-    a, b = torch.from_numpy(f1).to(DEV), torch.from_numpy(f2).to(DEV)
+    both = torch.from_numpy(np.concatenate([f1, f2], 0)).to(DEV)      # same memory layout as the graph's buffers
+    a, b = both[:1], both[1:]
     eager = [x.clone() for x in net.forward(a, b)]
     net.capture(1, 64, 1800)
     for rep in range(2):
