@@ -58,10 +58,13 @@ WarpProjectArgs = _struct("elo_warp_project_args", [
 
 Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i)])
 _l = ctypes.c_long
+GroupSpec = _struct("elo_group_spec", [
+    ("random_hw", _vp), ("kernel_h", _i), ("kernel_w", _i), ("distance", _f), ("stride_h", _i), ("stride_w", _i),
+    ("idx_out", _vp), ("mask_out", _vp)])
 SetconvArgs = _struct("elo_setconv_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1_grid", _vp), ("centre_hw", _vp), ("centre_xyz", _vp), ("src_xyz", _vp), ("src_feat", _vp),
-    ("idx", _vp), ("mask", _vp), ("n_layers", _i), ("layers", Dense * 3), ("out", _vp), ("new_xyz", _vp)])
+    ("idx", _vp), ("mask", _vp), ("n_layers", _i), ("layers", Dense * 3), ("out", _vp), ("new_xyz", _vp), ("group", GroupSpec)])
 MlpArgs = _struct("elo_mlp_args", [
     ("rows", _l), ("n_sources", _i), ("src", _vp * 3), ("src_width", _i * 3), ("n_layers", _i),
     ("layers", Dense * 3), ("out", _vp)])
@@ -69,11 +72,11 @@ Cv1Args = _struct("elo_cv1_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("xyz2", _vp), ("feat2", _vp), ("idx", _vp), ("mask", _vp),
     ("cv0", Dense), ("cv1", Dense), ("cv2", Dense), ("cv_xyz", Dense), ("sum_cv0", Dense), ("sum_cv1", Dense),
-    ("out", _vp)])
+    ("out", _vp), ("group", GroupSpec)])
 Cv2Args = _struct("elo_cv2_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("cost", _vp), ("idx", _vp), ("mask", _vp),
-    ("xyz_enc", Dense), ("sum_cost0", Dense), ("sum_cost1", Dense), ("out", _vp)])
+    ("xyz_enc", Dense), ("sum_cost0", Dense), ("sum_cost1", Dense), ("out", _vp), ("group", GroupSpec)])
 
 # every symbol include/elo.h declares: (name, restype, argtypes)
 SYMBOLS = [

@@ -17,7 +17,7 @@
 // final activations column-wise from LDS and write (b,n,C) rows coalesced.
 //
 // Interfaces and the reference lines covered: include/elo.h ("Fused inference kernels").
-#include "elo_common.h"
+#include "elo_group_device.h"
 
 namespace elo {
 namespace {
@@ -172,6 +172,60 @@ __device__ __forceinline__ void load_meta(const TileMeta &m, long first_point, l
     }
 }
 
+// In-kernel grouping of a tile's P points (one wave per point): fills meta.cell / meta.mask (and the
+// centres in meta.cxyz) exactly as load_meta would from the stand-alone grouping op's outputs.
+// lds_off: [KT] decoded visiting order; scratch: FUSED_WAVES x 2*KT words (select-k only).
+template <int TILE, bool SELECT>
+__device__ __forceinline__ void group_tile(const TileMeta &m, int *lds_off, unsigned *scratch, const elo_group_spec &g,
+                                           long first_point, long total_points, int npoints, int P, int K,
+                                           const float *__restrict__ centre_grid, int H1, int W1,
+                                           const int *__restrict__ centre_hw, const float *__restrict__ grid2,
+                                           int H2, int W2, float *__restrict__ new_xyz)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KT = g.kernel_h * g.kernel_w;
+    if (tid < TILE) { m.cell[tid] = -1; m.mask[tid] = 0.0f; }
+    stage_offsets(lds_off, g.random_hw, g.kernel_h, g.kernel_w);              // ends with __syncthreads()
+    const float r2 = g.distance * g.distance;
+    for (int pi = wave; pi < P; pi += FUSED_WAVES) {
+        const long pt = first_point + pi;
+        if (pt >= total_points) continue;
+        const int b = (int)(pt / npoints), n = (int)(pt - (long)b * npoints);
+        const int hc = centre_hw ? centre_hw[pt * 2 + 0] : n / W1, wc = centre_hw ? centre_hw[pt * 2 + 1] : n - (n / W1) * W1;
+        const float *c = centre_grid + (((long)b * H1 + hc) * W1 + wc) * 3;
+        const float cx = c[0], cy = c[1], cz = c[2];
+        if (lane < 3) {
+            const float v = lane == 0 ? cx : lane == 1 ? cy : cz;
+            m.cxyz[pi * 3 + lane] = v;
+            if (new_xyz) new_xyz[pt * 3 + lane] = v;
+        }
+        int *o_idx = g.idx_out ? g.idx_out + pt * K * 3 : nullptr;
+        float *o_mask = g.mask_out ? g.mask_out + pt * K : nullptr;
+        auto emit = [&](int slot, int hw) {
+            m.cell[pi * K + slot] = (b * H2 + (hw >> 16)) * W2 + (hw & 0xffff);
+            m.mask[pi * K + slot] = 1.0f;
+            if (o_idx) { o_idx[slot * 3 + 0] = b; o_idx[slot * 3 + 1] = hw >> 16; o_idx[slot * 3 + 2] = hw & 0xffff; }
+            if (o_mask) o_mask[slot] = 1.0f;
+        };
+        int count = 0;
+        if (!(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS)) {                // valid centre (:62-70)
+            const float *gb = grid2 + (size_t)b * H2 * W2 * 3;
+            if (SELECT)
+                count = wave_select_k(gb, H2, W2, KT, K, lds_off, hc / g.stride_h, wc / g.stride_w, cx, cy, cz, r2,
+                                      scratch + (size_t)wave * 2 * KT, reinterpret_cast<int *>(scratch) + (size_t)wave * 2 * KT + KT, emit);
+            else
+                count = wave_random_k(gb, H2, W2, KT, K, lds_off, hc / g.stride_h, wc / g.stride_w, cx, cy, cz, r2, emit);
+        }
+        for (int k = count + lane; k < K; k += 64) {                           // zero-filled slots: index (0,0,0), mask 0
+            m.cell[pi * K + k] = 0;
+            m.mask[pi * K + k] = 0.0f;
+            if (o_idx) { o_idx[k * 3 + 0] = 0; o_idx[k * 3 + 1] = 0; o_idx[k * 3 + 2] = 0; }
+            if (o_mask) o_mask[k] = 0.0f;
+        }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ float geo_channel(const float *p, const float *g, float m, int ch)
 {   // [p, g*m, g*m - p, sqrt(sum((g*m-p)^2) + 1e-20)]   utils/pointnet_util.py:54-62
     float gm[3], d[3];
@@ -234,24 +288,30 @@ __global__ __launch_bounds__(FUSED_BLOCK) void setconv_kernel(const elo_setconv_
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     if (first_point >= total_points) return;
-    load_meta<TILE>(meta, first_point, total_points, P, K, a.idx, a.mask, a.H2, a.W2);
-    if (tid >= 64 && tid < 64 + P * 3) {              // centres of the tile's points (second wave)
-        const int q = tid - 64, pi = q / 3, c = q - pi * 3;
-        const long pt = first_point + pi;
-        float v = 0.0f;
-        if (pt < total_points) {
-            if (a.centre_hw) {
-                const int b = (int)(pt / a.npoints);
-                const int h = a.centre_hw[pt * 2 + 0], w = a.centre_hw[pt * 2 + 1];
-                v = a.xyz1_grid[(((long)b * a.H + h) * a.W + w) * 3 + c];
-                if (a.new_xyz) a.new_xyz[pt * 3 + c] = v;                       // :206
-            } else {
-                v = a.centre_xyz[pt * 3 + c];
+    if (a.group.random_hw) {
+        int *lds_off = reinterpret_cast<int *>(meta.cxyz + 96);
+        group_tile<TILE, false>(meta, lds_off, nullptr, a.group, first_point, total_points, a.npoints, P, K, a.xyz1_grid,
+                                a.H, a.W, a.centre_hw, a.src_xyz, a.H2, a.W2, a.new_xyz);
+    } else {
+        load_meta<TILE>(meta, first_point, total_points, P, K, a.idx, a.mask, a.H2, a.W2);
+        if (tid >= 64 && tid < 64 + P * 3) {              // centres of the tile's points (second wave)
+            const int q = tid - 64, pi = q / 3, c = q - pi * 3;
+            const long pt = first_point + pi;
+            float v = 0.0f;
+            if (pt < total_points) {
+                if (a.centre_hw) {
+                    const int b = (int)(pt / a.npoints);
+                    const int h = a.centre_hw[pt * 2 + 0], w = a.centre_hw[pt * 2 + 1];
+                    v = a.xyz1_grid[(((long)b * a.H + h) * a.W + w) * 3 + c];
+                    if (a.new_xyz) a.new_xyz[pt * 3 + c] = v;                   // :206
+                } else {
+                    v = a.centre_xyz[pt * 3 + c];
+                }
             }
+            meta.cxyz[q] = v;
         }
-        meta.cxyz[q] = v;
+        __syncthreads();
     }
-    __syncthreads();
     // gather + centre-subtract + concat into act[row][0 .. CTp)                   :203-213 / :277-284
     const int CT = 3 + a.C, CTp = ceil16(CT);
     for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {
@@ -315,8 +375,15 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv1_kernel(const elo_cv1_args a, 
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     if (first_point >= total_points) return;
-    load_meta<TILE>(meta, first_point, total_points, P, K, a.idx, a.mask, a.H2, a.W2);
-    __syncthreads();
+    if (a.group.random_hw) {                          // select-k of frame 2 around every warped frame-1 pixel (:49-51)
+        int *lds_off = reinterpret_cast<int *>(meta.cxyz + 96);
+        unsigned *scratch = reinterpret_cast<unsigned *>(lds_off + a.group.kernel_h * a.group.kernel_w);
+        group_tile<TILE, true>(meta, lds_off, scratch, a.group, first_point, total_points, a.npoints, P, K, a.xyz1, a.H2,
+                               a.W2, nullptr, a.xyz2, a.H2, a.W2, nullptr);
+    } else {
+        load_meta<TILE>(meta, first_point, total_points, P, K, a.idx, a.mask, a.H2, a.W2);
+        __syncthreads();
+    }
     const int F = 128, CT = 10 + 2 * C, CTp = ceil16(CT);
     for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {                             // :54-66
         const int row = e / CTp, ch = e - row * CTp;
@@ -355,8 +422,14 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv2_kernel(const elo_cv2_args a, 
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     if (first_point >= total_points) return;
-    load_meta<TILE>(meta, first_point, total_points, P, K, a.idx, a.mask, a.H, a.W);
-    __syncthreads();
+    if (a.group.random_hw) {                          // random-k of the warped cloud on itself (:106-108)
+        int *lds_off = reinterpret_cast<int *>(meta.cxyz + 96);
+        group_tile<TILE, false>(meta, lds_off, nullptr, a.group, first_point, total_points, a.npoints, P, K, a.xyz1, a.H,
+                                a.W, nullptr, a.xyz1, a.H, a.W, nullptr);
+    } else {
+        load_meta<TILE>(meta, first_point, total_points, P, K, a.idx, a.mask, a.H, a.W);
+        __syncthreads();
+    }
     const int Cp = ceil16(C), XYZ = 192;
     for (int e = tid; e < TILE * 64; e += FUSED_BLOCK) {                              // grouped cost * mask  :110
         const int row = e >> 6, ch = e & 63;
@@ -395,7 +468,24 @@ int check_dense(const elo_dense &L, int K, int N, const char *who, const char *n
     return ELO_OK;
 }
 
-size_t tile_lds_bytes(int rows, int S) { return sizeof(float) * ((size_t)rows * S + 64 + 96); }
+size_t tile_lds_bytes(int rows, int S, int KT = 0, bool select = false)
+{
+    return sizeof(float) * ((size_t)rows * S + 64 + 96 + KT + (select ? (size_t)FUSED_WAVES * 2 * KT : 0));
+}
+
+// in-kernel grouping: validate the spec the way elo_fused_conv_*_k validates its attributes
+int check_group(const elo_group_spec &g, int H2, int W2, size_t lds_bytes, const char *who)
+{
+    if (!g.random_hw) return ELO_OK;
+    if (g.kernel_h <= 0 || g.kernel_w <= 0 || !(g.distance > 0.0f) || g.stride_h <= 0 || g.stride_w <= 0)
+        return fail(ELO_ERR_ARG, "%s: bad grouping attributes", who);
+    if (g.kernel_w / 2 > W2)
+        return fail(ELO_ERR_LIMIT, "%s: kernel_size_W/2 = %d exceeds the queried width %d (single wrap)", who, g.kernel_w / 2, W2);
+    if (H2 >= 32768 || W2 >= 65536) return fail(ELO_ERR_LIMIT, "%s: queried grid larger than 32767 x 65535", who);
+    if (lds_bytes > 64 * 1024)
+        return fail(ELO_ERR_LIMIT, "%s: window %dx%d needs %zu bytes of LDS for in-kernel grouping", who, g.kernel_h, g.kernel_w, lds_bytes);
+    return ELO_OK;
+}
 
 #define ELO_REQUIRE(cond, who, what) \
     do { if (!(cond)) return fail(ELO_ERR_ARG, "%s: %s", who, what); } while (0)
@@ -409,12 +499,15 @@ static inline int pad16(int x) { return (x + 15) & ~15; }
 
 template <typename Args, typename K32, typename K16>
 static int launch_tile(const char *who, bool tile16, long units16, long units32, int S, hipStream_t s, const Args &a,
-                       K32 k32, K16 k16)
+                       K32 k32, K16 k16, const elo_group_spec *g = nullptr, int H2 = 0, int W2 = 0, bool select = false)
 {
+    const int KT = (g && g->random_hw) ? g->kernel_h * g->kernel_w : 0;
+    const size_t lds = tile_lds_bytes(tile16 ? 16 : 32, S, KT, select);
+    if (g) if (int rc = check_group(*g, H2, W2, lds, who)) return rc;
     if (tile16)
-        hipLaunchKernelGGL(k16, dim3((unsigned)units16), dim3(FUSED_BLOCK), tile_lds_bytes(16, S), s, a, S);
+        hipLaunchKernelGGL(k16, dim3((unsigned)units16), dim3(FUSED_BLOCK), lds, s, a, S);
     else
-        hipLaunchKernelGGL(k32, dim3((unsigned)units32), dim3(FUSED_BLOCK), tile_lds_bytes(32, S), s, a, S);
+        hipLaunchKernelGGL(k32, dim3((unsigned)units32), dim3(FUSED_BLOCK), lds, s, a, S);
     return check_launch(who);
 }
 
@@ -433,8 +526,10 @@ extern "C" int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream)
     ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->K > 0 && a->H2 > 0 && a->W2 > 0 && a->C >= 0, who, "bad sizes");
     if (a->K > 32) return fail(ELO_ERR_LIMIT, "%s: K = %d exceeds the 32-row tile", who, a->K);
     ELO_REQUIRE(a->n_layers >= 1 && a->n_layers <= ELO_MAX_CHAIN, who, "1..3 layers");
-    ELO_REQUIRE(a->src_xyz && (a->src_feat || a->C == 0) && a->idx && a->mask && a->out, who, "null tensor pointer");
-    ELO_REQUIRE((a->centre_hw && a->xyz1_grid && a->H > 0 && a->W > 0) || a->centre_xyz, who, "no centre source");
+    ELO_REQUIRE(a->src_xyz && (a->src_feat || a->C == 0) && a->out, who, "null tensor pointer");
+    ELO_REQUIRE(a->group.random_hw || (a->idx && a->mask), who, "neither idx/mask nor a grouping spec");
+    ELO_REQUIRE((a->xyz1_grid && a->H > 0 && a->W > 0 && (a->centre_hw || a->group.random_hw)) || a->centre_xyz, who, "no centre source");
+    ELO_REQUIRE(!a->group.random_hw || (a->xyz1_grid && a->H > 0 && a->W > 0), who, "in-kernel grouping needs xyz1_grid");
     int width = 3 + a->C;
     for (int l = 0; l < a->n_layers; ++l) {
         if (int rc = check_dense(a->layers[l], width, 0, who, "mlp")) return rc;
@@ -446,7 +541,7 @@ extern "C" int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream)
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
     return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, setconv_kernel<32>,
-                       setconv_kernel<16>);
+                       setconv_kernel<16>, &a->group, a->H2, a->W2, false);
 }
 
 extern "C" int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream)
@@ -477,7 +572,9 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
     ELO_REQUIRE(a, who, "null argument block");
     ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->K > 0 && a->H2 > 0 && a->W2 > 0 && a->C > 0, who, "bad sizes");
     if (a->K > 32) return fail(ELO_ERR_LIMIT, "%s: K = %d exceeds the 32-row tile", who, a->K);
-    ELO_REQUIRE(a->xyz1 && a->feat1 && a->xyz2 && a->feat2 && a->idx && a->mask && a->out, who, "null tensor pointer");
+    ELO_REQUIRE(a->xyz1 && a->feat1 && a->xyz2 && a->feat2 && a->out, who, "null tensor pointer");
+    ELO_REQUIRE(a->group.random_hw || (a->idx && a->mask), who, "neither idx/mask nor a grouping spec");
+    ELO_REQUIRE(!a->group.random_hw || a->npoints == a->H2 * a->W2, who, "in-kernel grouping needs npoints == H2*W2");
     const int CT = 10 + 2 * a->C;
     if (int rc = check_dense(a->cv0, CT, 128, who, "CV_0")) return rc;
     if (int rc = check_dense(a->cv1, 128, 64, who, "CV_1")) return rc;
@@ -491,7 +588,8 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
     const int S = row_stride(128 + (CTp > 128 ? CTp : 128));
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
-    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv1_kernel<32>, cv1_kernel<16>);
+    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv1_kernel<32>, cv1_kernel<16>,
+                       &a->group, a->H2, a->W2, true);
 }
 
 extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
@@ -502,7 +600,8 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
     ELO_REQUIRE(a->npoints == a->H * a->W, who, "npoints must equal H*W (every pixel is a centre)");
     if (a->K > 32) return fail(ELO_ERR_LIMIT, "%s: K = %d exceeds the 32-row tile", who, a->K);
     if (a->C > 64) return fail(ELO_ERR_LIMIT, "%s: C = %d exceeds 64", who, a->C);
-    ELO_REQUIRE(a->xyz1 && a->feat1 && a->cost && a->idx && a->mask && a->out, who, "null tensor pointer");
+    ELO_REQUIRE(a->xyz1 && a->feat1 && a->cost && a->out, who, "null tensor pointer");
+    ELO_REQUIRE(a->group.random_hw || (a->idx && a->mask), who, "neither idx/mask nor a grouping spec");
     if (int rc = check_dense(a->xyz_enc, 10, 64, who, "sum_xyz_encoding")) return rc;
     if (int rc = check_dense(a->sum_cost0, 128 + a->C, 128, who, "sum_cost_volume_0")) return rc;
     if (int rc = check_dense(a->sum_cost1, 128, 64, who, "sum_cost_volume_1")) return rc;
@@ -511,5 +610,6 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
     const int S = row_stride(208);
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
-    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv2_kernel<32>, cv2_kernel<16>);
+    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv2_kernel<32>, cv2_kernel<16>,
+                       &a->group, a->H, a->W, false);
 }

@@ -19,52 +19,10 @@
 //   * every output element is written exactly once (zero-fill fused; the op
 //     glue's four cudaMemset calls, fused_conv.cpp:154-166, disappear).
 // Both are memory-latency bound gathers out of an L2-resident grid: no MFMA.
-#include "elo_common.h"
+#include "elo_group_device.h"
 
 namespace elo {
 namespace {
-
-#define ELO_EPS 1e-10f
-#define ELO_FAR 1e10f
-
-struct Probe {
-    bool valid;   // in-grid, non-empty pixel
-    bool hit;     // valid and within the radius
-    float d;      // clamped squared distance (hit or not)
-    int hw;       // (h << 16) | w of the probed pixel
-};
-
-// One window slot of one centre. fused_conv_g.cu:80-123.
-__device__ __forceinline__ Probe probe_slot(const float *__restrict__ grid2, int H2, int W2, int off,
-                                            int base_h, int base_w, float cx, float cy, float cz, float r2)
-{
-    Probe p{false, false, ELO_FAR, 0};
-    int h = base_h + (off >> 16);
-    int w = base_w + (int)(short)(off & 0xffff);
-    if (h < 0 || h >= H2) return p;
-    if (w < 0) w += W2;
-    if (w >= W2) w -= W2;
-    const float *q = grid2 + ((size_t)h * W2 + w) * 3;
-    const float qx = q[0], qy = q[1], qz = q[2];
-    if (sq3(qx, qy, qz) <= ELO_EPS) return p;
-    p.valid = true;
-    p.d = pick_max(sq3(__fsub_rn(cx, qx), __fsub_rn(cy, qy), __fsub_rn(cz, qz)), ELO_EPS);
-    p.hit = !(p.d > r2);
-    p.hw = (h << 16) | w;
-    return p;
-}
-
-// Decode the visiting order once per block: LDS[i] = (dh << 16) | (dw & 0xffff).
-__device__ __forceinline__ void stage_offsets(int *lds_off, const int *__restrict__ perm, int kH, int kW)
-{
-    const int KT = kH * kW, hh = kH / 2, hw = kW / 2;
-    for (int i = threadIdx.x; i < KT; i += blockDim.x) {
-        const int p = perm[i];
-        const int dh = p / kW - hh, dw = p % kW - hw;
-        lds_off[i] = (dh << 16) | (dw & 0xffff);
-    }
-    __syncthreads();
-}
 
 struct Centre {
     bool ok;

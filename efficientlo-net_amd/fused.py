@@ -56,28 +56,60 @@ def _chain(layers):
     return arr
 
 
-def setconv(src_xyz, src_feat, idx, mask, layers, centre_xyz=None, xyz1_grid=None, centre_hw=None):
-    """group_concat -> MLP chain -> masked max over K in one launch.
+class Grouping:
+    """In-kernel grouping spec (include/elo.h elo_group_spec): the fused kernel runs random-k / select-k itself.
+    want_indices=True also returns the (B,N,K,3) indices and (B,N,K) mask the stand-alone op would produce."""
+
+    def __init__(self, random_hw, kernel_size, distance, stride_h=1, stride_w=1, want_indices=False):
+        self.random_hw = random_hw.contiguous()
+        self.kernel_h, self.kernel_w = int(kernel_size[0]), int(kernel_size[1])
+        self.distance, self.stride_h, self.stride_w = float(distance), int(stride_h), int(stride_w)
+        self.want_indices = want_indices
+        self.idx = self.mask = None
+
+    def struct(self, B, N, K, device):
+        if self.random_hw.dtype != torch.int32 or self.random_hw.numel() != self.kernel_h * self.kernel_w:
+            raise ValueError("FusedConv expects (kernel_size_h * kernel_size_w) random_hw shape.")
+        if self.want_indices:
+            self.idx = torch.empty((B, N, K, 3), dtype=torch.int32, device=device)
+            self.mask = torch.empty((B, N, K), dtype=torch.float32, device=device)
+        return L.GroupSpec(self.random_hw.data_ptr(), self.kernel_h, self.kernel_w, self.distance, self.stride_h,
+                           self.stride_w, self.idx.data_ptr() if self.want_indices else None,
+                           self.mask.data_ptr() if self.want_indices else None)
+
+
+_NO_GROUP = L.GroupSpec(None, 0, 0, 0.0, 0, 0, None, None)
+
+
+def setconv(src_xyz, src_feat, idx, mask, layers, centre_xyz=None, xyz1_grid=None, centre_hw=None, group=None, K=None):
+    """group_concat -> MLP chain -> masked max over K in one launch.  Either (idx, mask) from a grouping op, or
+    group=Grouping(...) + K to group in-kernel (needs xyz1_grid; centre_hw None = every pixel of xyz1_grid).
     Returns (out (B,n,Cout), new_xyz (B,n,3) or None)."""
     L.require_gpu(src_xyz, src_feat, idx, mask, centre_xyz, xyz1_grid, centre_hw)
-    src_xyz, src_feat, mask = _f32c(src_xyz), _f32c(src_feat), _f32c(mask)
-    idx = idx.contiguous()
-    B, n, K, _ = idx.shape
+    src_xyz, src_feat = _f32c(src_xyz), _f32c(src_feat)
     _, H2, W2, C = src_feat.shape
-    dev = idx.device
-    out = torch.empty((B, n, layers[-1].N), dtype=torch.float32, device=dev)
+    dev = src_xyz.device
     ptr = lambda x: x.data_ptr() if x is not None else None
-    if centre_hw is not None:
-        xyz1_grid, centre_hw = _f32c(xyz1_grid), centre_hw.contiguous()
+    H = W = 0
+    if xyz1_grid is not None:
+        xyz1_grid = _f32c(xyz1_grid)
         H, W = xyz1_grid.shape[1:3]
-        new_xyz = torch.empty((B, n, 3), dtype=torch.float32, device=dev)
+    if group is None:
+        idx, mask = idx.contiguous(), _f32c(mask)
+        B, n, K, _ = idx.shape
     else:
+        B = src_xyz.shape[0]
+        n = centre_hw.shape[1] if centre_hw is not None else H * W
+    new_xyz = None
+    if centre_hw is not None:
+        centre_hw = centre_hw.contiguous()
+        new_xyz = torch.empty((B, n, 3), dtype=torch.float32, device=dev)
+    elif centre_xyz is not None:
         centre_xyz = _f32c(centre_xyz)
-        H = W = 0
-        new_xyz = None
+    out = torch.empty((B, n, layers[-1].N), dtype=torch.float32, device=dev)
     a = L.SetconvArgs(B, n, K, H, W, H2, W2, C, ptr(xyz1_grid), ptr(centre_hw), ptr(centre_xyz), src_xyz.data_ptr(),
-                      src_feat.data_ptr(), idx.data_ptr(), mask.data_ptr(), len(layers), _chain(layers),
-                      out.data_ptr(), ptr(new_xyz))
+                      src_feat.data_ptr(), ptr(idx), ptr(mask), len(layers), _chain(layers), out.data_ptr(), ptr(new_xyz),
+                      group.struct(B, n, K, dev) if group is not None else _NO_GROUP)
     L.call("elo_setconv_fused", a, out)
     return out, new_xyz
 
@@ -97,28 +129,36 @@ def mlp(sources, layers):
     return out.reshape(lead + (layers[-1].N,))
 
 
-def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1):
+def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1, group=None, K=None):
     L.require_gpu(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask)
-    xyz1, feat1, xyz2_proj, feat2_proj, mask = (_f32c(t) for t in (xyz1, feat1, xyz2_proj, feat2_proj, mask))
-    idx = idx.contiguous()
-    B, N, K, _ = idx.shape
+    xyz1, feat1, xyz2_proj, feat2_proj = (_f32c(t) for t in (xyz1, feat1, xyz2_proj, feat2_proj))
     _, H2, W2, C = feat2_proj.shape
-    out = torch.empty((B, N, 64), dtype=torch.float32, device=idx.device)
+    B, N = xyz1.shape[0], xyz1.shape[1]
+    ptr = lambda x: x.data_ptr() if x is not None else None
+    if group is None:
+        idx, mask = idx.contiguous(), _f32c(mask)
+        K = idx.shape[2]
+    out = torch.empty((B, N, 64), dtype=torch.float32, device=xyz1.device)
     a = L.Cv1Args(B, N, K, H2, W2, C, xyz1.data_ptr(), feat1.data_ptr(), xyz2_proj.data_ptr(), feat2_proj.data_ptr(),
-                  idx.data_ptr(), mask.data_ptr(), cv0.struct(), cv1.struct(), cv2.struct(), cv_xyz.struct(),
-                  sum_cv0.struct(), sum_cv1.struct(), out.data_ptr())
+                  ptr(idx), ptr(mask), cv0.struct(), cv1.struct(), cv2.struct(), cv_xyz.struct(),
+                  sum_cv0.struct(), sum_cv1.struct(), out.data_ptr(),
+                  group.struct(B, N, K, xyz1.device) if group is not None else _NO_GROUP)
     L.call("elo_cv_stage1_fused", a, out)
     return out
 
 
-def cv_stage2(xyz1_proj, feat1_proj, cost_proj, idx, mask, xyz_enc, sum_cost0, sum_cost1):
+def cv_stage2(xyz1_proj, feat1_proj, cost_proj, idx, mask, xyz_enc, sum_cost0, sum_cost1, group=None, K=None):
     L.require_gpu(xyz1_proj, feat1_proj, cost_proj, idx, mask)
-    xyz1_proj, feat1_proj, cost_proj, mask = (_f32c(t) for t in (xyz1_proj, feat1_proj, cost_proj, mask))
-    idx = idx.contiguous()
-    B, N, K, _ = idx.shape
-    _, H, W, C = feat1_proj.shape
-    out = torch.empty((B, N, 64), dtype=torch.float32, device=idx.device)
-    a = L.Cv2Args(B, N, K, H, W, C, xyz1_proj.data_ptr(), feat1_proj.data_ptr(), cost_proj.data_ptr(), idx.data_ptr(),
-                  mask.data_ptr(), xyz_enc.struct(), sum_cost0.struct(), sum_cost1.struct(), out.data_ptr())
+    xyz1_proj, feat1_proj, cost_proj = (_f32c(t) for t in (xyz1_proj, feat1_proj, cost_proj))
+    B, H, W, C = feat1_proj.shape
+    N = H * W
+    ptr = lambda x: x.data_ptr() if x is not None else None
+    if group is None:
+        idx, mask = idx.contiguous(), _f32c(mask)
+        K = idx.shape[2]
+    out = torch.empty((B, N, 64), dtype=torch.float32, device=xyz1_proj.device)
+    a = L.Cv2Args(B, N, K, H, W, C, xyz1_proj.data_ptr(), feat1_proj.data_ptr(), cost_proj.data_ptr(), ptr(idx),
+                  ptr(mask), xyz_enc.struct(), sum_cost0.struct(), sum_cost1.struct(), out.data_ptr(),
+                  group.struct(B, N, K, xyz1_proj.device) if group is not None else _NO_GROUP)
     L.call("elo_cv_stage2_fused", a, out)
     return out

@@ -107,39 +107,41 @@ def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_
         points1 = points1_proj.reshape(B, N, -1)
         dev = warped_xyz1_proj.device
 
-        # ---- stage 1: point -> patch in frame 2 (:47-100)
+        C = points1.shape[-1]
         random_HW_q = random_shuffle(tf_util.scope_name(), "random_HW_q", kernel_size2[0] * kernel_size2[1], dev)
+        random_HW_p = random_shuffle(tf_util.scope_name(), "random_HW_p", kernel_size1[0] * kernel_size1[1], dev)
+        if _fused_path(is_training) and nsample_q <= 32 and nsample <= 32:
+            # two launches for the whole operator: each fused kernel does its own grouping (select-k / random-k),
+            # gather + encoding, the conv chain on the matrix cores and the masked softmax pooling
+            if list(mlp1) != [128, 64, 64] or list(mlp2) != [128, 64]:
+                raise NotImplementedError("the fused cost volume is built for mlp1=[128,64,64], mlp2=[128,64]")
+            P = fused.packed_layer
+            pi_feat1_new = fused.cv_stage1(
+                warped_xyz1, points1, xyz2_proj, points2_proj, None, None,
+                P('CV_0', 10 + 2 * C, 128), P('CV_1', 128, 64), P('CV_2', 64, 64), P('CV_xyz', 10, 64),
+                P('sum_CV_0', 128, 128, row_order=list(range(64, 128)) + list(range(64))),      # kernel order [x | enc]
+                P('sum_CV_1', 128, 64),
+                group=fused.Grouping(random_HW_q, kernel_size2, 1000), K=nsample_q).reshape(B, H, W, -1)   # :49-100
+            order = list(range(64 + C, 128 + C)) + list(range(64)) + list(range(64, 64 + C))   # [grouped | enc | feat1]
+            return fused.cv_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, None, None,
+                                   P('sum_xyz_encoding', 10, 64), P('sum_cost_volume_0', 128 + C, 128, row_order=order),
+                                   P('sum_cost_volume_1', 128, 64),
+                                   group=fused.Grouping(random_HW_p, kernel_size1, distance), K=nsample)   # :104-146
+
+        # ---- stage 1: point -> patch in frame 2 (:47-100)
         idx_hw = get_hw_idx(B, H, W, dev)
         qi_idx, _, _, valid_mask = fused_conv_select_k(
             warped_xyz1_proj, xyz2_proj, idx_hw, random_HW_q, H, W, N, kernel_size2[0], kernel_size2[1], nsample_q,
             flag_copy=0, distance=1000, stride_h=1, stride_w=1, want_valid=False)            # :49-51 (1000 is literal)
         mask = valid_mask.reshape(B, N, nsample_q)
-        C = points1.shape[-1]
-        if _fused_path(is_training):
-            if list(mlp1) != [128, 64, 64] or list(mlp2) != [128, 64]:
-                raise NotImplementedError("the fused cost volume is built for mlp1=[128,64,64], mlp2=[128,64]")
-            P = fused.packed_layer
-            pi_feat1_new = fused.cv_stage1(
-                warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask,
-                P('CV_0', 10 + 2 * C, 128), P('CV_1', 128, 64), P('CV_2', 64, 64), P('CV_xyz', 10, 64),
-                P('sum_CV_0', 128, 128, row_order=list(range(64, 128)) + list(range(64))),      # kernel order [x | enc]
-                P('sum_CV_1', 128, 64)).reshape(B, H, W, -1)                                     # :54-100
-        else:
-            pi_feat1_new = _cost_volume_stage1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask, mlp1, mlp2,
-                                               is_training, bn_decay).reshape(B, H, W, -1)
+        pi_feat1_new = _cost_volume_stage1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask, mlp1, mlp2,
+                                           is_training, bn_decay).reshape(B, H, W, -1)
 
         # ---- stage 2: patch -> patch inside frame 1 (:104-146)
-        random_HW_p = random_shuffle(tf_util.scope_name(), "random_HW_p", kernel_size1[0] * kernel_size1[1], dev)
         pc_idx, _, _, valid_mask2 = fused_conv_random_k(
             warped_xyz1_proj, warped_xyz1_proj, idx_hw, random_HW_p, H, W, N, kernel_size1[0], kernel_size1[1],
             nsample, flag_copy=0, distance=distance, stride_h=1, stride_w=1, want_valid=False)    # :106-108
         mask2 = valid_mask2.reshape(B, N, nsample)
-        if _fused_path(is_training):
-            P = fused.packed_layer
-            order = list(range(64 + C, 128 + C)) + list(range(64)) + list(range(64, 64 + C))   # [grouped | enc | feat1]
-            return fused.cv_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2,
-                                   P('sum_xyz_encoding', 10, 64), P('sum_cost_volume_0', 128 + C, 128, row_order=order),
-                                   P('sum_cost_volume_1', 128, 64))                              # :110-146
         return _cost_volume_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2, mlp1, mlp2, is_training,
                                    bn_decay)
 
@@ -219,18 +221,20 @@ def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distan
         dev = xyz_proj.device
         random_HW = random_shuffle(tf_util.scope_name(), "random_HW", kernel_size[0] * kernel_size[1], dev)
         centre_hw = _centre_hw(selected_idx)
+        if _fused_path(is_training) and len(mlp) <= 3 and K_sample <= 32:
+            # ONE launch: random-k grouping, gather, centre-subtract, MLP on the matrix cores, masked max-pool.
+            # The centre is xyz_proj[b, h, w] (selected_idx's batch column is the batch index, as
+            # get_selected_idx builds it)                                                           :197-230
+            widths = [3 + points_proj.shape[-1]] + list(mlp)
+            layers = [fused.packed_layer('conv%d' % i, widths[i], widths[i + 1], bn=bn) for i in range(len(mlp))]
+            out, new_xyz = fused.setconv(xyz_proj, points_proj, None, None, layers, xyz1_grid=xyz_proj,
+                                         centre_hw=centre_hw, K=K_sample,
+                                         group=fused.Grouping(random_HW, kernel_size, distance))
+            return out, new_xyz.reshape(selected_idx.shape[:-1] + (3,))
         sel, _, _, valid_mask = fused_conv_random_k(
             xyz_proj, xyz_proj, centre_hw, random_HW, H, W, n_sampled, kernel_size[0],
             kernel_size[1], K_sample, flag_copy=0, distance=distance, stride_h=1, stride_w=1, want_valid=False)  # :197-199
         mask = valid_mask.reshape(B, n_sampled, K_sample)
-        if _fused_path(is_training) and len(mlp) <= 3 and K_sample <= 32:
-            # centre = xyz_proj[b, h, w] read in-kernel (selected_idx's batch column is the batch index, as
-            # get_selected_idx builds it); gather + MLP + masked max-pool in one launch                  :203-230
-            widths = [3 + points_proj.shape[-1]] + list(mlp)
-            layers = [fused.packed_layer('conv%d' % i, widths[i], widths[i + 1], bn=bn) for i in range(len(mlp))]
-            out, new_xyz = fused.setconv(xyz_proj, points_proj, sel, mask, layers, xyz1_grid=xyz_proj,
-                                         centre_hw=centre_hw)
-            return out, new_xyz.reshape(selected_idx.shape[:-1] + (3,))
         li = selected_idx.reshape(-1, 3).long()
         new_xyz_proj = xyz_proj[li[:, 0], li[:, 1], li[:, 2]].reshape(selected_idx.shape[:-1] + (3,))  # :206
         new_xyz = new_xyz_proj.reshape(B, -1, 3)
@@ -250,20 +254,21 @@ def up_conv(xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kernel_size, stride_h,
         dev = xyz1_proj.device
         xyz1 = xyz1_proj.reshape(B, N, 3)
         points1 = feat1_proj.reshape(B, N, -1)
-        idx_hw = get_hw_idx(B, H, W, dev)
         random_HW = random_shuffle(tf_util.scope_name(), "random_HW", kernel_size[0] * kernel_size[1], dev)
+        if _fused_path(is_training) and len(mlp) <= 3 and len(mlp2) <= 3 and nsample <= 32:
+            P = fused.packed_layer
+            w1 = [3 + feat2_proj.shape[-1]] + list(mlp)
+            up_feat, _ = fused.setconv(xyz2_proj, feat2_proj, None, None,
+                                       [P('up_1_%d' % j, w1[j], w1[j + 1]) for j in range(len(mlp))],
+                                       xyz1_grid=xyz1_proj, K=nsample,
+                                       group=fused.Grouping(random_HW, kernel_size, distance, stride_h, stride_w))  # :272-298
+            w2 = [mlp[-1] + points1.shape[-1]] + list(mlp2)
+            return fused.mlp([up_feat, points1], [P('up_2_%d' % i, w2[i], w2[i + 1]) for i in range(len(mlp2))])  # :303-311
+        idx_hw = get_hw_idx(B, H, W, dev)
         sel, _, _, valid_mask = fused_conv_random_k(
             xyz1_proj, xyz2_proj, idx_hw, random_HW, H, W, N, kernel_size[0], kernel_size[1], nsample,
             flag_copy=0, distance=distance, stride_h=stride_h, stride_w=stride_w, want_valid=False)      # :272-274
         mask = valid_mask.reshape(B, N, nsample)
-        if _fused_path(is_training) and len(mlp) <= 3 and len(mlp2) <= 3 and nsample <= 32:
-            P = fused.packed_layer
-            w1 = [3 + feat2_proj.shape[-1]] + list(mlp)
-            up_feat, _ = fused.setconv(xyz2_proj, feat2_proj, sel, mask,
-                                       [P('up_1_%d' % j, w1[j], w1[j + 1]) for j in range(len(mlp))],
-                                       centre_xyz=xyz1)                                           # :277-298
-            w2 = [mlp[-1] + points1.shape[-1]] + list(mlp2)
-            return fused.mlp([up_feat, points1], [P('up_2_%d' % i, w2[i], w2[i + 1]) for i in range(len(mlp2))])  # :303-311
         x = _ops.group_concat(xyz1, xyz2_proj, feat2_proj, sel, mask)                             # :277-284
         for j, num_out_channel in enumerate(mlp):
             x = tf_util.conv2d(x, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,

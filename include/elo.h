@@ -256,6 +256,20 @@ typedef struct elo_dense {
 
 #define ELO_MAX_CHAIN 3
 
+/* Optional in-kernel neighbour grouping for the fused kernels: with random_hw != NULL the kernel
+ * runs the grouping itself (same semantics as elo_fused_conv_random_k / _select_k with flag_copy = 0,
+ * one wave per centre) and the idx / mask INPUTS of the argument block are ignored (may be NULL).
+ * idx_out / mask_out, when given, receive the (batch,npoints,K,3) indices and (batch,npoints,K) mask
+ * exactly as the stand-alone ops would write them (used by the parity tests). */
+typedef struct elo_group_spec {
+    const int *random_hw;         /* (kernel_h*kernel_w) visiting order, or NULL = use idx/mask inputs */
+    int kernel_h, kernel_w;
+    float distance;
+    int stride_h, stride_w;
+    int *idx_out;                 /* nullable */
+    float *mask_out;              /* nullable */
+} elo_group_spec;
+
 /* set-conv / set-upconv stage 1:  group_concat -> chain -> masked max over K.
  * utils/pointnet_util.py:197-230 (down_conv) and :272-298 (up_conv). K <= 32.
  * centre_hw != NULL: centre = xyz1_grid[b, centre_hw[b,n,0], centre_hw[b,n,1]] and is also
@@ -275,6 +289,7 @@ typedef struct elo_setconv_args {
     elo_dense layers[ELO_MAX_CHAIN];
     float *out;                   /* (batch,npoints,layers[last].N)         */
     float *new_xyz;               /* (batch,npoints,3) or NULL              */
+    elo_group_spec group;         /* random-k; needs xyz1_grid; centre_hw == NULL: centre n is pixel (n / W, n % W) */
 } elo_setconv_args;
 int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream);
 
@@ -304,6 +319,7 @@ typedef struct elo_cv1_args {
     const float *mask;
     elo_dense cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1;     /* N: 128,64,64,64,128,64 */
     float *out;                   /* (batch,npoints,64) */
+    elo_group_spec group;         /* select-k of xyz2 around every pixel of xyz1 (npoints == H2*W2, stride 1) */
 } elo_cv1_args;
 int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream);
 
@@ -320,6 +336,7 @@ typedef struct elo_cv2_args {
     const float *mask;
     elo_dense xyz_enc, sum_cost0, sum_cost1;               /* N: 64,128,64 */
     float *out;                   /* (batch,npoints,64) */
+    elo_group_spec group;         /* random-k of xyz1 around every pixel of xyz1 (stride 1) */
 } elo_cv2_args;
 int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream);
 

@@ -156,3 +156,53 @@ def test_full_size_digests(i):
     cpt = f1[0][idx[0, :, 0], idx[0, :, 1]][:, None, :]
     dd = ((cpt - p) ** 2).sum(-1)
     assert (dd[m] <= d["distance"] ** 2 * (1 + 1e-5)).all()
+
+
+def test_in_kernel_grouping_of_fused_kernels_is_bit_exact():
+    """The fused kernels group in-kernel (elo_group_spec): their idx_out / mask_out must equal the oracle's
+    random-k / select-k outputs bit for bit, for strided centres, all-pixel centres with a stride, and select-k."""
+    fused, tf_util = load_pkg("fused"), load_pkg("tf_util")
+    synth = load_pkg("synth")
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f1, f2 = synth.frame_pair(2, 16, 225, seed=77)
+    rng = np.random.default_rng(3)
+    store = tf_util.VariableStore(dev, seed=0)
+    with tf_util.default_store(store), torch.no_grad():
+        # (a) set-conv: strided centres, 7x11 window, K=32
+        C = 16
+        feat = rng.normal(0, 1, (2, 16, 225, C)).astype(np.float32)
+        hw = synth.strided_index(2, 8, 113, 2, 2)
+        perm = rng.permutation(77).astype(np.int32)
+        g = fused.Grouping(t(perm), [7, 11], 3.0, want_indices=True)
+        fused.setconv(t(f1), t(feat), None, None, [fused.packed_layer("a0", 3 + C, 32)], xyz1_grid=t(f1),
+                      centre_hw=t(hw), K=32, group=g)
+        want = G.fused_conv_random_k(f1, f1, hw, perm, 16, 225, hw.shape[1], 7, 11, 32, 0, 3.0, 1, 1)
+        assert np.array_equal(g.idx.cpu().numpy(), want[0]) and np.array_equal(g.mask.cpu().numpy()[..., None], want[3])
+        # (b) set-upconv: every pixel of the dense grid, sparse grid at stride (2,2), K=8
+        sparse = np.ascontiguousarray(f2[:, ::2, ::2])
+        sfeat = rng.normal(0, 1, sparse.shape[:3] + (64,)).astype(np.float32)
+        perm = rng.permutation(105).astype(np.int32)
+        g = fused.Grouping(t(perm), [7, 15], 3.0, 2, 2, want_indices=True)
+        fused.setconv(t(sparse), t(sfeat), None, None, [fused.packed_layer("b0", 67, 64)], xyz1_grid=t(f1), K=8, group=g)
+        hw_all = synth.hw_index(2, 16, 225)
+        want = G.fused_conv_random_k(f1, sparse, hw_all, perm, 16, 225, 3600, 7, 15, 8, 0, 3.0, 2, 2)
+        assert np.array_equal(g.idx.cpu().numpy(), want[0]) and np.array_equal(g.mask.cpu().numpy()[..., None], want[3])
+        # (c) cost volume stage 1 (select-k, 11x41, K=6) and stage 2 (random-k on itself, 3x5, K=4)
+        C = 16
+        fa, fb = (rng.normal(0, 1, (2, 16, 225, C)).astype(np.float32) for _ in range(2))
+        perm = rng.permutation(451).astype(np.int32)
+        P = fused.packed_layer
+        g = fused.Grouping(t(perm), [11, 41], 1000, want_indices=True)
+        cost = fused.cv_stage1(t(f1).reshape(2, 3600, 3), t(fa).reshape(2, 3600, C), t(f2), t(fb), None, None,
+                               P("c0", 10 + 2 * C, 128), P("c1", 128, 64), P("c2", 64, 64), P("cx", 10, 64),
+                               P("s0", 128, 128), P("s1", 128, 64), group=g, K=6)
+        want = G.fused_conv_select_k(f1, f2, hw_all, perm, 16, 225, 3600, 11, 41, 6, 0, 1000.0, 1, 1)
+        assert np.array_equal(g.idx.cpu().numpy(), want[0]) and np.array_equal(g.mask.cpu().numpy()[..., None], want[3])
+        perm = rng.permutation(15).astype(np.int32)
+        g = fused.Grouping(t(perm), [3, 5], 1.0, want_indices=True)
+        fused.cv_stage2(t(f1), t(fa), cost.reshape(2, 16, 225, 64), None, None, P("e0", 10, 64), P("e1", 128 + C, 128),
+                        P("e2", 128, 64), group=g, K=4)
+        want = G.fused_conv_random_k(f1, f1, hw_all, perm, 16, 225, 3600, 3, 5, 4, 0, 1.0, 1, 1)
+        assert np.array_equal(g.idx.cpu().numpy(), want[0]) and np.array_equal(g.mask.cpu().numpy()[..., None], want[3])
+    torch.cuda.synchronize()
