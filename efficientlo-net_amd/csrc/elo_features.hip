@@ -442,8 +442,11 @@ extern "C" int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_strea
 
 static int sv_parts(int npoints)
 {
-    int parts = (npoints + 63) / 64;                 // >= 64 points (16 per wave) per block
-    return parts < 1 ? 1 : parts > ELO_SV_MAX_PARTS ? ELO_SV_MAX_PARTS : parts;
+    // Few, fat slices: the merge in the head kernel walks the partials serially per channel, so 16 slices of
+    // ~N/16 points (>= 64 points per block) beat many thin ones.
+    int parts = (npoints + 63) / 64;
+    const int cap = 16 < ELO_SV_MAX_PARTS ? 16 : ELO_SV_MAX_PARTS;
+    return parts < 1 ? 1 : parts > cap ? cap : parts;
 }
 
 extern "C" int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t stream)
