@@ -93,6 +93,41 @@ def placeholder_inputs(batch_size, NUM_POINTS, device="cuda"):
     return z(batch_size, NUM_POINTS * 2, 6), z(batch_size, 4, 4), z(batch_size, 4, 4), z(batch_size, 4, 4)
 
 
+_side_streams = {}
+_CONCURRENT = False      # measured: forked branches inside the hipGraph cost 8% at 1 lane and 35% at 8 lanes
+
+
+def set_concurrent_branches(flag):
+    """Run independent operator branches of a refinement level on forked HIP streams (default off)."""
+    global _CONCURRENT
+    _CONCURRENT = bool(flag)
+
+
+def _parallel(branches):
+    """Run independent closures on forked streams and join; results in order.  Sequential when gradients are
+    enabled, on CPU tensors, or when switched off."""
+    if not _CONCURRENT or torch.is_grad_enabled() or len(branches) < 2 or not torch.cuda.is_available():
+        return [b() for b in branches]
+    dev = torch.cuda.current_device()
+    cur = torch.cuda.current_stream(dev)
+    key = (dev, cur.cuda_stream)
+    pool = _side_streams.setdefault(key, [])
+    while len(pool) < len(branches) - 1:
+        pool.append(torch.cuda.Stream(device=dev))
+    results = [None] * len(branches)
+    for i, b in enumerate(branches[1:]):
+        pool[i].wait_stream(cur)
+        with torch.cuda.stream(pool[i]):
+            results[i + 1] = b()
+    results[0] = branches[0]()
+    for i in range(len(branches) - 1):
+        cur.wait_stream(pool[i])
+        for t in (results[i + 1] if isinstance(results[i + 1], (tuple, list)) else [results[i + 1]]):
+            if torch.is_tensor(t):
+                t.record_stream(cur)
+    return results
+
+
 def _adjacent_frames(a, b):
     """If b starts exactly where a ends in the same allocation (PWCLONet keeps both range images in one
     (2B,H,W,3) buffer), return that (2B,H,W,3) tensor as a view -- no copy; else None."""
@@ -239,25 +274,29 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
         xyz_warp_f1 = xyz_warp_proj_f1.reshape(batch_size, -1, 3)
         points_warp_f1 = points_warp_proj_f1.reshape(batch_size, out_h_list[g] * out_w_list[g], -1)
 
-        cost = cost_volume(xyz_warp_proj_f1, xyz_proj_f2[level], points_warp_proj_f1, pts_proj_f2[level],
-                           kernel_size1=[3, 5], kernel_size2=cv_kernel2[level], nsample=4, nsample_q=6,
-                           distance=Cost_volume_dis[level], mlp1=[128, 64, 64], mlp2=[128, 64],
-                           is_training=is_training, bn_decay=bn_decay, scope='flow_embedding_l%d' % level,
-                           bn=True, pooling='max', knn=True, corr_func='concat')                    # :242
-        w_up_sample = up_conv(xyz_warp_proj_f1, coarse_xyz_proj, points_warp_proj_f1, coarse_w_proj,
-                              kernel_size=[7, 15], stride_h=stride_h_list[g + 1], stride_w=stride_w_list[g + 1],
-                              nsample=8, distance=Up_conv_dis[level], mlp=[128, 64], mlp2=[128, 64],
-                              scope='up_sa_layer_layer_l%dw' % level, is_training=is_training, bn_decay=bn_decay,
-                              knn=True)                                                             # :247
-        cost_up_sample = up_conv(xyz_warp_proj_f1, coarse_xyz_proj, points_warp_proj_f1, coarse_predict_proj,
-                                 kernel_size=[7, 15], stride_h=stride_h_list[g + 1], stride_w=stride_w_list[g + 1],
-                                 nsample=8, distance=Up_conv_dis[level], mlp=[128, 64], mlp2=[128, 64],
-                                 scope='up_sa_layer_layer_l%dcostvolume' % level, is_training=is_training,
-                                 bn_decay=bn_decay, knn=True)                                       # :250
-        predict = flow_predictor(points_warp_f1, cost_up_sample, cost, mlp=[128, 64], is_training=is_training,
-                                 bn_decay=bn_decay, scope='l%d_costvolume_predict' % level)         # :253
-        weight = flow_predictor(points_warp_f1, w_up_sample, cost, mlp=[128, 64], is_training=is_training,
-                                bn_decay=bn_decay, scope='l%d_w_predict' % level)                   # :254
+        def branch_cost():
+            return cost_volume(xyz_warp_proj_f1, xyz_proj_f2[level], points_warp_proj_f1, pts_proj_f2[level],
+                               kernel_size1=[3, 5], kernel_size2=cv_kernel2[level], nsample=4, nsample_q=6,
+                               distance=Cost_volume_dis[level], mlp1=[128, 64, 64], mlp2=[128, 64],
+                               is_training=is_training, bn_decay=bn_decay, scope='flow_embedding_l%d' % level,
+                               bn=True, pooling='max', knn=True, corr_func='concat')                # :242
+
+        def branch_up(kind, coarse_feat_proj):
+            return up_conv(xyz_warp_proj_f1, coarse_xyz_proj, points_warp_proj_f1, coarse_feat_proj,
+                           kernel_size=[7, 15], stride_h=stride_h_list[g + 1], stride_w=stride_w_list[g + 1],
+                           nsample=8, distance=Up_conv_dis[level], mlp=[128, 64], mlp2=[128, 64],
+                           scope='up_sa_layer_layer_l%d%s' % (level, kind), is_training=is_training,
+                           bn_decay=bn_decay, knn=True)                                             # :247, :250
+
+        # the cost volume and the two set-upconvs only share inputs: three concurrent branches (forked HIP
+        # streams, which a hipGraph capture records as parallel graph branches), joined before the predictors
+        cost, w_up_sample, cost_up_sample = _parallel([branch_cost, lambda: branch_up('w', coarse_w_proj),
+                                                       lambda: branch_up('costvolume', coarse_predict_proj)])
+        predict, weight = _parallel([
+            lambda: flow_predictor(points_warp_f1, cost_up_sample, cost, mlp=[128, 64], is_training=is_training,
+                                   bn_decay=bn_decay, scope='l%d_costvolume_predict' % level),     # :253
+            lambda: flow_predictor(points_warp_f1, w_up_sample, cost, mlp=[128, 64], is_training=is_training,
+                                   bn_decay=bn_decay, scope='l%d_w_predict' % level)])             # :254
         q_prev, t_prev, q_norm = _estimate_pose(predict, weight, xyz_warp_f1, level, q_coarse, t_coarse,
                                                 is_training)                                       # :262-280
         poses[level] = (q_norm, t_prev)
