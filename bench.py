@@ -16,8 +16,11 @@ independent, so ranks shard the stream with no data-path collective; the poses o
 step are all-gathered (7 floats per pair) once per step so rank 0 can chain them
 (main.py:557-572), which is the only exchange the path has.  scaling = weak.
 
+Throughput design: the whole forward is one hipGraph; `--lanes` graphs (default 8), each with its own
+stream and static buffers, keep that many independent forwards in flight (step i rides lane i % lanes).
+
 Besides the contract line this prints, on rank 0 at N=1:
-  roofline     -- the dominant hand-written cost-volume kernel timed live with HIP events
+  roofline     -- the dominant cost-volume kernel (fused stage 1 at l0) timed live with HIP events
   cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on a bounded sample
 """
 import argparse
@@ -51,16 +54,19 @@ def parse():
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--width", type=int, default=1800)
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic pairs kept in HBM")
-    ap.add_argument("--lanes", type=int, default=4, help="independent forwards in flight (streams x hipGraphs)")
+    ap.add_argument("--lanes", type=int, default=8, help="independent forwards in flight (streams x hipGraphs)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs in the CPU-oracle sample")
+    ap.add_argument("--cpu-pairs", type=int, default=60, help="pairs in the CPU-oracle sample")
     return ap.parse_args()
 
 
 # ----------------------------------------------------------------------------- roofline leg
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak (= the fp32 vector peak)
+
+
 def cost_volume_bytes(N, C, Kq, Kp, s=4):
-    """algorithmic bytes of the four cost-volume kernels per batch element."""
+    """algorithmic (operator-boundary) bytes of the cost volume per batch element."""
     A1 = 2 * N * 12 + 2 * N * C * s + N * Kq * 16 + N * Kq * (10 + 2 * C) * s
     P1 = 2 * N * Kq * 64 * s + N * Kq * 4 + N * 64 * s
     A2 = N * 12 + N * C * s + N * 64 * s + N * Kp * 16 + N * Kp * (10 + C + 64) * s
@@ -68,32 +74,67 @@ def cost_volume_bytes(N, C, Kq, Kp, s=4):
     return dict(A1=A1, P1=P1, A2=A2, P2=P2)
 
 
-def roofline_leg(args, dev, reps=200):
-    """Time the dominant cost-volume kernel (the stage-1 masked-softmax pool at l0: the largest
-    algorithmic-byte term, P1) with HIP events on the stream it is launched on."""
-    ops = pkg("_ops")
-    pm = pkg("pwclo_model")
-    oh, ow = pm.pyramid_sizes(args.height, args.width)
-    B, N, Kq, C = args.batch, oh[2] * ow[2], 6, 64
-    g = torch.Generator(device="cpu").manual_seed(0)
-    logits = torch.randn((B, N, Kq, C), generator=g).to(dev)
-    values = torch.randn((B, N, Kq, C), generator=g).to(dev)
-    mask = (torch.rand((B, N, Kq), generator=g) > 0.1).float().to(dev)
+def cv1_flops(N, C, Kq):
+    """Multiply-adds x2 of the six 1x1 convolutions of cost-volume stage 1 (pointnet_util.py:72-90)."""
+    per_row = (10 + 2 * C) * 128 + 128 * 64 + 64 * 64 + 10 * 64 + 128 * 128 + 128 * 64
+    return 2 * N * Kq * per_row
+
+
+def _time_launches(fn, dev, reps):
     for _ in range(10):
-        ops.masked_softmax_pool(logits, values, mask)
+        fn()
     torch.cuda.synchronize(dev)
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()                      # torch's current stream == the stream _lib.stream_ptr() hands to the C ABI
     for _ in range(reps):
-        ops.masked_softmax_pool(logits, values, mask)
+        fn()
     stop.record()
     torch.cuda.synchronize(dev)
-    sec = start.elapsed_time(stop) / 1e3 / reps
-    nbytes = cost_volume_bytes(N, 16, Kq, 4)["P1"] * B
-    gbs = nbytes / sec / 1e9
-    return {"bound": "hbm", "kernel": "softmax_pool_kernel (cost volume stage 1, l0)", "achieved": round(gbs, 2),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
-            "bytes_per_launch": int(nbytes), "us_per_launch": round(sec * 1e6, 3)}
+    return start.elapsed_time(stop) / 1e3 / reps
+
+
+def roofline_leg(args, dev, net, reps=200):
+    """The dominant cost-volume kernel of the timed path, timed live with HIP events on the stream it is launched
+    on: the fused stage-1 kernel at l0 (select-k grouping + encode + six 1x1 convs on the fp32 matrix cores +
+    masked softmax pooling in one launch).  It never materialises the operator-boundary tensors, so it is bound
+    by the fp32 MFMA rate, not by HBM; `hbm_equivalent_GBps` is SURVEY 8(d)'s algorithmic bytes (A1+P1) over the
+    same duration for comparison with the per-operator kernels (`per_operator`, the P1 softmax-pool kernel)."""
+    ops, fused, tf_util, perm, pm = pkg("_ops"), pkg("fused"), pkg("tf_util"), pkg("perm"), pkg("pwclo_model")
+    oh, ow = pm.pyramid_sizes(args.height, args.width)
+    B, H, W, C, Kq = args.batch, oh[2], ow[2], 16, 6
+    N = H * W
+    g = torch.Generator(device="cpu").manual_seed(0)
+    synth = pkg("synth")
+    f1, f2 = synth.frame_pair(B, H, W, seed=5)
+    xyz1, xyz2 = torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev)
+    feat1 = torch.randn((B, H, W, C), generator=g).to(dev)
+    feat2 = torch.randn((B, H, W, C), generator=g).to(dev)
+    order = torch.randperm(11 * 41, generator=g).to(torch.int32).to(dev)
+    with tf_util.default_store(net.store), torch.no_grad(), tf_util.variable_scope('flow_embedding_l0'):
+        P = fused.packed_layer
+        layers = (P('CV_0', 10 + 2 * C, 128), P('CV_1', 128, 64), P('CV_2', 64, 64), P('CV_xyz', 10, 64),
+                  P('sum_CV_0', 128, 128, row_order=list(range(64, 128)) + list(range(64))), P('sum_CV_1', 128, 64))
+    grouping = fused.Grouping(order, [11, 41], 1000)
+    run = lambda: fused.cv_stage1(xyz1.reshape(B, N, 3), feat1.reshape(B, N, C), xyz2, feat2, None, None, *layers,
+                                  group=grouping, K=Kq)
+    sec = _time_launches(run, dev, reps)
+    flops = cv1_flops(N, C, Kq) * B
+    cvb = cost_volume_bytes(N, C, Kq, 4)
+    tfs = flops / sec / 1e12
+    logits = torch.randn((B, N, Kq, 64), generator=g).to(dev)
+    values = torch.randn((B, N, Kq, 64), generator=g).to(dev)
+    mask = (torch.rand((B, N, Kq), generator=g) > 0.1).float().to(dev)
+    sec_p1 = _time_launches(lambda: ops.masked_softmax_pool(logits, values, mask), dev, reps)
+    return {"bound": "mfma", "kernel": "cv1_kernel (fused cost volume stage 1, l0: %dx%d, K=%d, batch %d)" % (H, W, Kq, B),
+            "achieved": round(tfs, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tfs / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
+            "flops_per_launch": int(flops), "us_per_launch": round(sec * 1e6, 3),
+            "algorithmic_bytes_per_launch": int((cvb["A1"] + cvb["P1"]) * B),
+            "hbm_equivalent_GBps": round((cvb["A1"] + cvb["P1"]) * B / sec / 1e9, 2),
+            "per_operator": {"kernel": "softmax_pool_kernel (P1 term, ELO_FUSED=0 path)", "bound": "hbm",
+                             "achieved": round(cvb["P1"] * B / sec_p1 / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(cvb["P1"] * B / sec_p1 / 1e9 / HBM_PEAK_GBS, 5),
+                             "us_per_launch": round(sec_p1 * 1e6, 3)}}
 
 
 # ----------------------------------------------------------------------------- CPU baseline leg
@@ -197,7 +238,7 @@ def main():
                    "global_batch": B * world, "parallelism": "dp%d" % world},
     }
     if rank == 0 and world == 1:
-        line["roofline"] = roofline_leg(args, dev)
+        line["roofline"] = roofline_leg(args, dev, net)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_leg(args, net, args.cpu_pairs)
     if rank == 0:
