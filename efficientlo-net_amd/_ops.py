@@ -8,6 +8,16 @@ import torch
 from . import _lib as L
 
 
+def active():
+    """The op set for the current mode: hand-written HIP kernels for inference, their differentiable
+    torch twins (_ops_torch.py) when autograd is recording (training)."""
+    if torch.is_grad_enabled():
+        from . import _ops_torch
+        return _ops_torch
+    import sys
+    return sys.modules[__name__]
+
+
 def _f32(*ts):
     out = []
     for t in ts:

@@ -1,0 +1,116 @@
+"""Differentiable twins of the feature kernels in _ops.py, written with PyTorch-ROCm ops (gather by
+advanced indexing, index_add, scatter_reduce ...) so that autograd provides the backward pass for
+TRAINING.  They run on the GPU like everything else -- this is not a CPU fallback and not the oracle;
+inference never takes this path (it uses the hand-written HIP kernels).  Neighbour indices and masks
+always come from the HIP grouping kernels (they carry no gradient: utils/pointnet_util.py:54-55 wraps
+the mask in stop_gradient and indices are integers).
+
+Gradient semantics follow the reference's TF graph: gather_nd -> scatter-add of the incoming
+gradient, reduce_max -> arg-max routing, and the re-projection passes gradients to the scattered
+VALUES (model_util.py:264-273), never to the cell indices.
+"""
+import math
+
+import torch
+
+
+def _cell(idx, H, W):
+    return (idx[..., 0].long() * H + idx[..., 1].long()) * W + idx[..., 2].long()
+
+
+def _gather(grid, idx):
+    """tf.gather_nd(grid (B,H,W,C), idx (...,3)) -> (..., C)."""
+    B, H, W, C = grid.shape
+    return grid.reshape(B * H * W, C)[_cell(idx, H, W)]
+
+
+def group_concat(centre_xyz, src_xyz, src_feat, idx, mask):
+    m = mask.unsqueeze(-1)
+    return torch.cat([_gather(src_xyz, idx) * m - centre_xyz.unsqueeze(2), _gather(src_feat, idx) * m], -1)
+
+
+def masked_maxpool(x, mask):
+    return (x * mask.unsqueeze(-1)).max(dim=2).values
+
+
+def _geometry(p, g):
+    diff = g - p
+    euc = torch.sqrt((diff * diff).sum(-1, keepdim=True) + 1e-20)
+    return torch.cat([p.expand_as(g), g, diff, euc], -1)
+
+
+def cv_encode1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask):
+    m = mask.unsqueeze(-1)
+    K = idx.shape[2]
+    q = _gather(xyz2_proj, idx) * m
+    f2 = _gather(feat2_proj, idx) * m
+    return torch.cat([_geometry(xyz1.unsqueeze(2), q), feat1.unsqueeze(2).expand(-1, -1, K, -1), f2], -1)
+
+
+def cv_encode2(xyz1_proj, feat1_proj, cost_proj, idx, mask):
+    B, H, W, C = feat1_proj.shape
+    m = mask.unsqueeze(-1)
+    K = idx.shape[2]
+    p = xyz1_proj.reshape(B, H * W, 1, 3)
+    g = _gather(xyz1_proj, idx) * m
+    rest = torch.cat([feat1_proj.reshape(B, H * W, 1, C).expand(-1, -1, K, -1), _gather(cost_proj, idx) * m], -1)
+    return _geometry(p, g), rest
+
+
+def masked_softmax_pool(logits, values, mask):
+    l = torch.where(mask.unsqueeze(-1) == 1.0, logits, torch.full_like(logits, -1e10))
+    return (torch.softmax(l, dim=2) * values).sum(2)
+
+
+def softmax_valid(feature_bnc, weight_bnc, xyz_bn3):
+    valid = (xyz_bn3 != 0).any(-1, keepdim=True)
+    l = weight_bnc.masked_fill(~valid, float("-inf"))
+    w = torch.nan_to_num(torch.softmax(l, dim=1), nan=0.0)          # a batch element without valid points -> 0
+    return (feature_bnc * w).sum(1, keepdim=True)
+
+
+def projection_constants(H_input, W_input):
+    d2r = math.pi / 180
+    az = (360.0 / W_input) * d2r
+    down, up = -24.8 * d2r, 2.0 * d2r
+    vres = (up - down) / (H_input - 1)
+    return az, vres, -down / vres
+
+
+def _hamilton(a, b):
+    a0, a1, a2, a3 = a.unbind(-1)
+    b0, b1, b2, b3 = b.unbind(-1)
+    return torch.stack([a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3, a0 * b1 + a1 * b0 + a2 * b3 - a3 * b2,
+                        a0 * b2 - a1 * b3 + a2 * b0 + a3 * b1, a0 * b3 + a1 * b2 - a2 * b1 + a3 * b0], -1)
+
+
+def warp_project(xyz, feat, q, t, H, W):
+    """Optional quaternion warp + ProjectPC2SphericalRing; same returns as _ops.warp_project."""
+    B, N, _ = xyz.shape
+    warped = None
+    pts = xyz
+    if q is not None:
+        q = q.reshape(B, 1, 4)
+        t = t.reshape(B, 1, 3)
+        keep = (xyz != 0).any(-1, keepdim=True).to(xyz.dtype)
+        q_inv = torch.cat([q[..., :1], -q[..., 1:]], -1) / ((q * q).sum(-1, keepdim=True) + 1e-10)
+        v = _hamilton(q, torch.cat([torch.zeros_like(xyz[..., :1]), xyz], -1))
+        pts = warped = (_hamilton(v, q_inv)[..., 1:] + t) * keep
+    az, vres, voff = projection_constants(H, W)
+    with torch.no_grad():                                    # cell indices carry no gradient
+        x, y, z = pts.detach().unbind(-1)
+        r = torch.sqrt(x * x + y * y + z * z)
+        col = torch.nan_to_num((math.pi - torch.atan2(y, x)) / az, nan=0.0).trunc().long().clamp(0, W - 1)
+        row = (H - torch.nan_to_num(torch.asin(z / r) / vres + voff, nan=0.0).trunc().long()).clamp(0, H - 1)
+        cell = (torch.arange(B, device=xyz.device).view(B, 1) * H + row) * W + col
+        flat_cell, flat_r = cell.reshape(-1), r.reshape(-1)
+        min_r = torch.full((B * H * W,), float("inf"), device=xyz.device).scatter_reduce(0, flat_cell, flat_r, "amin")
+        same = (flat_r == min_r[flat_cell]).to(xyz.dtype).unsqueeze(-1)
+    out_xyz = torch.zeros((B * H * W, 3), dtype=xyz.dtype, device=xyz.device).index_add(
+        0, flat_cell, pts.reshape(-1, 3) * same).reshape(B, H, W, 3)
+    out_feat = None
+    if feat is not None:
+        C = feat.shape[-1]
+        out_feat = torch.zeros((B * H * W, C), dtype=feat.dtype, device=feat.device).index_add(
+            0, flat_cell, feat.reshape(-1, C) * same).reshape(B, H, W, C)
+    return warped, out_xyz, out_feat

@@ -149,7 +149,7 @@ def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_
 def _cost_volume_stage1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask, mlp1, mlp2, is_training, bn_decay):
     """utils/pointnet_util.py:54-100 as per-operator kernels + GEMMs (caller holds the variable scope)."""
     B, N, nsample_q = mask.shape
-    feat_cat = _ops.cv_encode1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask)       # :54-66
+    feat_cat = _ops.active().cv_encode1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask)       # :54-66
     xyz_cat = feat_cat.reshape(-1, feat_cat.shape[-1])[:, :10]      # :62 -- 2-D strided view, no copy (lda = 10+2C)
     x = feat_cat
     for j, num_out_channel in enumerate(mlp1):
@@ -165,13 +165,13 @@ def _cost_volume_stage1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, m
         else:
             cat = tf_util.conv2d(cat, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
                                  is_training=is_training, scope='sum_CV_%d' % j, bn_decay=bn_decay)
-    return _ops.masked_softmax_pool(cat, x, mask)                                                 # :92-98
+    return _ops.active().masked_softmax_pool(cat, x, mask)                                                 # :92-98
 
 
 def _cost_volume_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2, mlp1, mlp2, is_training, bn_decay):
     """utils/pointnet_util.py:110-146 as per-operator kernels + GEMMs (caller holds the variable scope)."""
     C = points1_proj.shape[-1]
-    pc_xyz_cat, rest = _ops.cv_encode2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2)  # :110-120
+    pc_xyz_cat, rest = _ops.active().cv_encode2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2)  # :110-120
     pc_enc = tf_util.conv2d(pc_xyz_cat, mlp1[-1], [1, 1], padding='VALID', stride=[1, 1], bn=True,
                             is_training=is_training, scope='sum_xyz_encoding', bn_decay=bn_decay)    # :123-126
     pc_cat = None
@@ -182,7 +182,7 @@ def _cost_volume_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, ma
             pc_cat = tf_util.conv2d(pc_cat, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
                                     is_training=is_training, scope='sum_cost_volume_%d' % j, bn_decay=bn_decay)
     pc_points_grouped = rest[..., C:]                              # cost[idx]*mask, a channel slice of `rest`
-    return _ops.masked_softmax_pool(pc_cat, pc_points_grouped, mask2)                             # :137-146
+    return _ops.active().masked_softmax_pool(pc_cat, pc_points_grouped, mask2)                             # :137-146
 
 
 def flow_predictor(points_f1, upsampled_feat, cost_volume, mlp, is_training, bn_decay, scope, bn=True):
@@ -238,11 +238,11 @@ def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distan
         li = selected_idx.reshape(-1, 3).long()
         new_xyz_proj = xyz_proj[li[:, 0], li[:, 1], li[:, 2]].reshape(selected_idx.shape[:-1] + (3,))  # :206
         new_xyz = new_xyz_proj.reshape(B, -1, 3)
-        x = _ops.group_concat(new_xyz, xyz_proj, points_proj, sel, mask)                          # :203-213
+        x = _ops.active().group_concat(new_xyz, xyz_proj, points_proj, sel, mask)                          # :203-213
         for i, num_out_channel in enumerate(mlp):
             x = tf_util.conv2d(x, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
                                is_training=is_training, scope='conv%d' % i, bn_decay=bn_decay)    # :217-222
-        return _ops.masked_maxpool(x, mask), new_xyz_proj                                         # :224-230
+        return _ops.active().masked_maxpool(x, mask), new_xyz_proj                                         # :224-230
 
 
 def up_conv(xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kernel_size, stride_h, stride_w, nsample, distance, mlp,
@@ -269,11 +269,11 @@ def up_conv(xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kernel_size, stride_h,
             xyz1_proj, xyz2_proj, idx_hw, random_HW, H, W, N, kernel_size[0], kernel_size[1], nsample,
             flag_copy=0, distance=distance, stride_h=stride_h, stride_w=stride_w, want_valid=False)      # :272-274
         mask = valid_mask.reshape(B, N, nsample)
-        x = _ops.group_concat(xyz1, xyz2_proj, feat2_proj, sel, mask)                             # :277-284
+        x = _ops.active().group_concat(xyz1, xyz2_proj, feat2_proj, sel, mask)                             # :277-284
         for j, num_out_channel in enumerate(mlp):
             x = tf_util.conv2d(x, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
                                is_training=is_training, scope='up_1_%d' % j, bn_decay=bn_decay)   # :289-293
-        up_feat = _ops.masked_maxpool(x, mask)                                                    # :295-298
+        up_feat = _ops.active().masked_maxpool(x, mask)                                                    # :295-298
         y = None
         for i, num_out_channel in enumerate(mlp2):                                                # :303-311
             if i == 0:

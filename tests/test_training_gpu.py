@@ -1,0 +1,148 @@
+"""GPU: the training path -- differentiable torch twins equal the HIP kernels in the forward direction,
+gradients reach every layer, get_loss / PreProcess / the full get_model signature match the oracle, and a
+few optimisation steps reduce the loss."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg
+from oracle import ops_np as O
+from util_params import close, export, randomise, shuffle_fn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_torch_twins_equal_hip_kernels():
+    ops, twin, elo, synth = load_pkg("_ops"), load_pkg("_ops_torch"), load_pkg(), load_pkg("synth")
+    rng = np.random.default_rng(0)
+    B, H, W, C, K = 2, 8, 113, 32, 6
+    f1, f2 = synth.frame_pair(B, H, W, seed=9)
+    x1, x2 = t(f1), t(f2)
+    fa, fb = t(rng.normal(0, 1, (B, H, W, C)).astype(np.float32)), t(rng.normal(0, 1, (B, H, W, C)).astype(np.float32))
+    hw = t(synth.hw_index(B, H, W))
+    perm = t(rng.permutation(35).astype(np.int32))
+    idx, _, _, m = elo.fused_conv_select_k(x1, x2, hw, perm, H, W, H * W, 5, 7, K, 0, 1000.0, 1, 1, want_valid=False)
+    m = m.reshape(B, H * W, K)
+    p1, ff1 = x1.reshape(B, -1, 3), fa.reshape(B, -1, C)
+    with torch.no_grad():
+        for name, args in (("group_concat", (p1, x2, fb, idx, m)), ("cv_encode1", (p1, ff1, x2, fb, idx, m))):
+            close(getattr(twin, name)(*args), getattr(ops, name)(*args).cpu().numpy(), atol=1e-6)
+        big = t(rng.normal(0, 1, (B, H * W, K, 64)).astype(np.float32))
+        val = t(rng.normal(0, 1, (B, H * W, K, 64)).astype(np.float32))
+        close(twin.masked_maxpool(big, m), ops.masked_maxpool(big, m).cpu().numpy(), atol=1e-6)
+        close(twin.masked_softmax_pool(big, val, m), ops.masked_softmax_pool(big, val, m).cpu().numpy(), atol=1e-5)
+        cost = t(rng.normal(0, 1, (B, H, W, 64)).astype(np.float32))
+        for a_, b_ in zip(twin.cv_encode2(x1, fa, cost, idx, m), ops.cv_encode2(x1, fa, cost, idx, m)):
+            close(a_, b_.cpu().numpy(), atol=1e-6)
+        close(twin.softmax_valid(ff1, ff1 * 2, p1), ops.softmax_valid(ff1, ff1 * 2, p1).cpu().numpy(), atol=1e-5)
+        q = t(np.array([[1.0, 0.002, -0.001, 0.004], [0.999, -0.003, 0.002, 0.01]], np.float32))
+        tt = t(np.array([[0.5, 0.05, -0.02], [-0.3, 0.1, 0.01]], np.float32))
+        a_, b_ = twin.warp_project(p1, ff1, q, tt, H, W), ops.warp_project(p1, ff1, q, tt, H, W)
+        close(a_[0], b_[0].cpu().numpy(), atol=1e-5)
+        same = torch.isclose(a_[1], b_[1], atol=1e-5).all(-1)
+        assert same.float().mean() > 0.995                                  # cell flips only on cell borders
+        assert torch.isclose(a_[2][same], b_[2][same], atol=1e-5).all()
+
+
+def test_get_loss_and_preprocess_match_oracle():
+    pm, mu = load_pkg("pwclo_model"), load_pkg("model_util")
+    rng = np.random.default_rng(1)
+    B = 3
+    qs = [rng.normal(0, 1, (B, 4)).astype(np.float32) for _ in range(4)]
+    ts = [rng.normal(0, 1, (B, 3)).astype(np.float32) for _ in range(4)]
+    q_gt, t_gt = rng.normal(0, 1, (B, 4)).astype(np.float32), rng.normal(0, 1, (B, 3, 1)).astype(np.float32)
+    args = [x for pair in zip(qs, ts) for x in pair]
+    want = O.get_loss(*args, q_gt, t_gt, 0.0, -2.5)
+    got = pm.get_loss(*[t(a) for a in args], t(q_gt), t(t_gt), torch.tensor(0.0, device=DEV), torch.tensor(-2.5, device=DEV))
+    assert abs(float(got) - want) < 1e-4 * max(1.0, abs(want))
+    # PreProcess: crop, per-sample augmentation of frame 1 / frame 2, q_gt / t_gt
+    N = 5000
+    pc1 = rng.normal(0, 15, (B, N, 3)).astype(np.float32); pc1[:, :200] = 0
+    pc2 = rng.normal(0, 15, (B, N, 3)).astype(np.float32); pc2[:, -100:] = 0
+
+    def rigid(seed):
+        r = np.random.default_rng(seed)
+        a = r.normal(0, 0.05, 3)
+        Rz = np.array([[np.cos(a[0]), -np.sin(a[0]), 0], [np.sin(a[0]), np.cos(a[0]), 0], [0, 0, 1]])
+        Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
+        T = np.eye(4); T[:3, :3] = Rz @ Ry; T[:3, 3] = r.normal(0, 0.5, 3)
+        return T.astype(np.float32)
+    T_gt = np.stack([rigid(i) for i in range(B)])
+    T_tr = np.stack([rigid(10 + i) for i in range(B)])
+    T_inv = np.linalg.inv(T_tr).astype(np.float32)
+    aug = np.array([1, 2, 1])
+    want = O.PreProcess(pc1, pc2, T_gt, T_tr, T_inv, aug)
+    got = mu.PreProcess(t(pc1), t(pc2), t(T_gt), t(T_tr), t(T_inv), aug)
+    for g, w_ in zip(got, want):
+        close(g, w_, atol=2e-4)
+
+
+def test_forward_points_matches_oracle_composition():
+    """get_model with the reference's full signature: PreProcess + input projection + pyramid."""
+    model, perm_mod, synth = load_pkg("model"), load_pkg("perm"), load_pkg("synth")
+    H, W, B = 64, 900, 1
+    f1, f2 = synth.frame_pair(B, H, W, seed=12)
+    # a raw "cloud" = the range-image points (plus padding zeros), so that re-projecting reproduces a range image
+    pad = np.zeros((B, 1000, 3), np.float32)
+    cloud = np.concatenate([np.concatenate([f1.reshape(B, -1, 3), pad], 1), np.concatenate([f2.reshape(B, -1, 3), pad], 1)], 1)
+    cloud6 = np.concatenate([cloud, np.zeros_like(cloud)], -1)
+    eye = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    net = model.PWCLONet(DEV, seed=2, perm_source=perm_mod.PermSource(fn=shuffle_fn))
+    out = net.forward_points(t(cloud6), H, W, t(eye), t(eye), t(eye), aug_frame=np.array([1]))
+    randomise(net.store, seed=4)
+    out = net.forward_points(t(cloud6), H, W, t(eye), t(eye), t(eye), aug_frame=np.array([1]))
+    n = cloud.shape[1] // 2
+    p1, p2, q_gt, t_gt = O.PreProcess(cloud[:, :n], cloud[:, n:], eye, eye, eye, np.array([1]))
+    # project with the product's own kernel (cell flips at borders are the projection test's business) ...
+    mu = load_pkg("model_util")
+    with torch.no_grad():                 # inference = the HIP projection kernel (autograd on would pick the torch twin;
+        x1 = mu.ProjectPC2SphericalRing(t(p1), None, H, W)[0].cpu().numpy()      # these synthetic points sit exactly on
+        x2 = mu.ProjectPC2SphericalRing(t(p2), None, H, W)[0].cpu().numpy()      # row borders, where 1 ulp of asin flips cells)
+    # ... so the composition is checked exactly: get_model == pyramid(project(PreProcess(cloud))), with PreProcess
+    # and q_gt/t_gt against the oracle (the pyramid itself is checked against the oracle in test_model_gpu.py)
+    direct = net.forward(t(x1), t(x2))
+    for g, w_ in zip(out[:9], direct):
+        assert torch.equal(g, w_)
+    close(out[9], q_gt, atol=1e-5)
+    close(out[10], t_gt, atol=1e-5)
+
+
+def test_training_steps_reduce_the_loss_and_reach_every_layer():
+    model, training, synth = load_pkg("model"), load_pkg("training"), load_pkg("synth")
+    net = model.PWCLONet(DEV, seed=3)
+    tr = training.Trainer(net)
+    assert len(tr.params) == 382 and tr.bucket.flat.numel() == 899134
+    f1, f2 = synth.frame_pair(2, 64, 900, seed=20)
+    a, b = t(f1), t(f2)
+    q_gt = t(np.array([[0.99995, 0.0, 0.0, 0.01]] * 2, np.float32))
+    t_gt = t(np.array([[[0.8], [0.0], [0.0]]] * 2, np.float32))
+    losses = [float(tr.step(a, b, q_gt, t_gt)) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    tr.bucket.zero()
+    with torch.enable_grad():
+        tf_util, perm = load_pkg("tf_util"), load_pkg("perm")
+        pm = load_pkg("pwclo_model")
+        with tf_util.default_store(net.store), perm.default_perm_source(net.perms):
+            out = pm.get_model_from_projection(a, b, True, 0.5)
+        pm.get_loss(*out[:8], q_gt, t_gt, tr.w_x, tr.w_q).backward()
+    dead = [n for n, p in net.store.params.items() if float(p.grad.abs().sum()) == 0.0]
+    assert torch.isfinite(tr.bucket.flat).all()
+    assert len(dead) <= 4, dead                    # every conv of the pyramid receives gradient
+    # inference after training: folded / packed weights were invalidated and rebuilt
+    out = net.forward(a, b)
+    assert all(torch.isfinite(o).all() for o in out)
+
+
+def test_runs_at_128x2048():
+    """BASELINE config 5 resolution: the re-projection sizes come from the pyramid, not from literals."""
+    model, synth, perm_mod = load_pkg("model"), load_pkg("synth"), load_pkg("perm")
+    f1, f2 = synth.frame_pair(1, 128, 2048, seed=30)
+    net = model.PWCLONet(DEV, seed=6, perm_source=perm_mod.PermSource(fn=shuffle_fn))
+    net.forward(t(f1), t(f2))
+    randomise(net.store, seed=8)
+    got = net.forward(t(f1), t(f2))
+    want = O.get_model_from_projection(export(net.store), shuffle_fn, f1, f2)
+    for g, w_ in zip(got, want):
+        close(g, w_, atol=1e-4, rtol=1e-4)
