@@ -1,0 +1,52 @@
+"""Launch one cost-volume kernel repeatedly (for rocprofv3 --kernel-trace / --pmc captures).
+
+    python tools/roofline_micro.py --kernel cv1|pool|encode1 --batch B [--reps N]
+cv1     = fused stage 1 at l0 (16x225, K=6, C=16)          -> cv1_kernel
+pool    = per-operator masked softmax pool (P1 term)       -> softmax_pool_kernel
+encode1 = per-operator gather + geometry encode (A1 term)  -> cv_encode1_kernel
+Prints the algorithmic bytes / flops per launch it used.
+"""
+import argparse, importlib, json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = lambda sub=None: importlib.import_module("efficientlo-net_amd" + ("." + sub if sub else ""))
+import bench
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--kernel", default="cv1"); ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--reps", type=int, default=20)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+ops, fused, tf_util, synth, elo = pkg("_ops"), pkg("fused"), pkg("tf_util"), pkg("synth"), pkg()
+B, H, W, C, Kq = a.batch, 16, 225, 16, 6
+N = H * W
+g = torch.Generator(device="cpu").manual_seed(0)
+f1, f2 = synth.frame_pair(B, H, W, seed=5)
+xyz1, xyz2 = torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev)
+feat1 = torch.randn((B, H, W, C), generator=g).to(dev); feat2 = torch.randn((B, H, W, C), generator=g).to(dev)
+order = torch.randperm(11 * 41, generator=g).to(torch.int32).to(dev)
+cvb = bench.cost_volume_bytes(N, C, Kq, 4)
+if a.kernel == "cv1":
+    store = tf_util.VariableStore(dev, seed=0)
+    with tf_util.default_store(store), torch.no_grad():
+        P = fused.packed_layer
+        layers = (P('CV_0', 10 + 2 * C, 128), P('CV_1', 128, 64), P('CV_2', 64, 64), P('CV_xyz', 10, 64),
+                  P('sum_CV_0', 128, 128), P('sum_CV_1', 128, 64))
+    grp = fused.Grouping(order, [11, 41], 1000)
+    run = lambda: fused.cv_stage1(xyz1.reshape(B, N, 3), feat1.reshape(B, N, C), xyz2, feat2, None, None, *layers, group=grp, K=Kq)
+    info = {"flops": bench.cv1_flops(N, C, Kq) * B, "algorithmic_bytes": (cvb["A1"] + cvb["P1"]) * B}
+elif a.kernel == "pool":
+    logits = torch.randn((B, N, Kq, 64), generator=g).to(dev); values = torch.randn((B, N, Kq, 64), generator=g).to(dev)
+    mask = (torch.rand((B, N, Kq), generator=g) > 0.1).float().to(dev)
+    run = lambda: ops.masked_softmax_pool(logits, values, mask)
+    info = {"algorithmic_bytes": cvb["P1"] * B}
+else:
+    hw = torch.from_numpy(synth.hw_index(B, H, W)).to(dev)
+    idx, _, _, m = elo.fused_conv_select_k(xyz1, xyz2, hw, order, H, W, N, 11, 41, Kq, 0, 1000.0, 1, 1, want_valid=False)
+    m = m.reshape(B, N, Kq)
+    run = lambda: ops.cv_encode1(xyz1.reshape(B, N, 3), feat1.reshape(B, N, C), xyz2, feat2, idx, m)
+    info = {"algorithmic_bytes": cvb["A1"] * B}
+for _ in range(a.reps):
+    run()
+torch.cuda.synchronize()
+print(json.dumps({"kernel": a.kernel, "batch": B, **info}))
