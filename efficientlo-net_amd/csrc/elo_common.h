@@ -50,14 +50,33 @@ __device__ __forceinline__ unsigned long long group_ballot(bool p, int group_shi
     return (m >> group_shift) & ((1ull << (G & 63)) - 1ull);
 }
 
+// Wave-wide minimum of a u32 on the DPP data path (no LDS crossbar traffic, unlike __shfl_xor/ds_bpermute):
+// quad swaps, row_shr:4/8, row_bcast:15/31 leave the result in lane 63; readlane broadcasts it.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_min_step(unsigned v)
+{
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, CTRL, 0xf, 0xf, false);
+    return o < v ? o : v;
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = dpp_min_step<0xb1>(v);     // quad_perm:[1,0,3,2]
+    v = dpp_min_step<0x4e>(v);     // quad_perm:[2,3,0,1]
+    v = dpp_min_step<0x114>(v);    // row_shr:4
+    v = dpp_min_step<0x118>(v);    // row_shr:8
+    v = dpp_min_step<0x142>(v);    // row_bcast:15
+    v = dpp_min_step<0x143>(v);    // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// lexicographic (hi, lo) minimum over the wave, as one u64 key
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        unsigned long long t = __shfl_xor(v, o, ELO_WAVE);
-        v = t < v ? t : v;
-    }
-    return v;
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned mhi = wave_min_u32(hi);
+    const unsigned mlo = wave_min_u32(hi == mhi ? lo : 0xffffffffu);
+    return ((unsigned long long)mhi << 32) | mlo;
 }
 
 }  // namespace elo
