@@ -470,7 +470,8 @@ int check_dense(const elo_dense &L, int K, int N, const char *who, const char *n
 
 size_t tile_lds_bytes(int rows, int S, int KT = 0, bool select = false)
 {
-    return sizeof(float) * ((size_t)rows * S + 64 + 96 + KT + (select ? (size_t)FUSED_WAVES * 2 * KT : 0));
+    // select-k keeps windows of <= 512 slots in registers (elo_group_device.h): LDS scratch only beyond that
+    return sizeof(float) * ((size_t)rows * S + 64 + 96 + KT + (select && KT > 512 ? (size_t)FUSED_WAVES * 2 * KT : 0));
 }
 
 // in-kernel grouping: validate the spec the way elo_fused_conv_*_k validates its attributes

@@ -75,7 +75,39 @@ __device__ __forceinline__ int wave_random_k(const float *__restrict__ grid2, in
     return taken;
 }
 
-// K nearest in-range neighbours, reference tie order (selection sort with swaps). dist/pay: [KT] wave-private LDS.
+// Raw fetch of one window slot with an UNCONDITIONAL load (out-of-grid rows are clamped and flagged), so that
+// several probes can have their loads in flight together; judge() then applies fused_conv_g.cu:83-123.
+struct RawSlot { float x, y, z; int hw; bool in_grid; };
+
+__device__ __forceinline__ RawSlot fetch_slot(const float *__restrict__ grid2, int H2, int W2, int off, int base_h,
+                                              int base_w, bool active)
+{
+    int h = base_h + (off >> 16);
+    int w = base_w + (int)(short)(off & 0xffff);
+    const bool in_grid = active && h >= 0 && h < H2;
+    h = h < 0 ? 0 : h >= H2 ? H2 - 1 : h;
+    if (w < 0) w += W2;
+    if (w >= W2) w -= W2;
+    w = w < 0 ? 0 : w >= W2 ? W2 - 1 : w;               // only reachable for inactive lanes
+    const float *q = grid2 + ((size_t)h * W2 + w) * 3;
+    return RawSlot{q[0], q[1], q[2], (h << 16) | w, in_grid};
+}
+
+__device__ __forceinline__ Probe judge(const RawSlot &r, float cx, float cy, float cz, float r2)
+{
+    Probe p{false, false, ELO_FAR, 0};
+    if (!r.in_grid || sq3(r.x, r.y, r.z) <= ELO_EPS) return p;
+    p.valid = true;
+    p.d = pick_max(sq3(__fsub_rn(cx, r.x), __fsub_rn(cy, r.y), __fsub_rn(cz, r.z)), ELO_EPS);
+    p.hit = !(p.d > r2);
+    p.hw = r.hw;
+    return p;
+}
+
+// K nearest in-range neighbours, reference tie order (selection sort with swaps).
+// Windows up to 512 slots (every call of the model) keep the whole (distance, hw) array in REGISTERS --
+// position j*64 + lane lives in register j of that lane -- and run the K rounds with DPP reductions and three
+// lane broadcasts per round; larger windows use the LDS arrays dist/pay ([KT] wave-private each).
 template <class Emit>
 __device__ __forceinline__ int wave_select_k(const float *__restrict__ grid2, int H2, int W2, int KT, int K,
                                              const int *lds_off, int base_h, int base_w, float cx, float cy, float cz,
@@ -83,6 +115,57 @@ __device__ __forceinline__ int wave_select_k(const float *__restrict__ grid2, in
 {
     const int lane = threadIdx.x & 63;
     const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
+    const int rounds = K < KT ? K : KT;
+    if (KT <= 512 && K <= 64) {
+        constexpr int J = 8;
+        unsigned d[J];
+        int pw[J];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {             // two batches of four probes: 4 loads in flight per lane
+            RawSlot raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = (half * 4 + u) * 64 + lane;
+                raw[u] = fetch_slot(grid2, H2, W2, lds_off[i < KT ? i : 0], base_h, base_w, i < KT);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const Probe p = judge(raw[u], cx, cy, cz, r2);
+                d[half * 4 + u] = p.hit ? __float_as_uint(p.d) : FAR_BITS;    // d > 0: bit order == float order
+                pw[half * 4 + u] = p.hit ? p.hw : 0;
+            }
+            if (KT <= 256 && half == 0) {                   // the second batch would be all padding
+#pragma unroll
+                for (int u = 4; u < J; ++u) { d[u] = FAR_BITS; pw[u] = 0; }
+                break;
+            }
+        }
+        for (int s = 0; s < rounds; ++s) {
+            unsigned best = 0xffffffffu;
+            int where = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const bool open = j > 0 || lane >= s;        // positions < s are already placed
+                if (open && d[j] < best) { best = d[j]; where = j * 64 + lane; }
+            }
+            const unsigned long long key = wave_min_u64(((unsigned long long)best << 32) | (unsigned)where);
+            if ((unsigned)(key >> 32) >= FAR_BITS) return s;                 // sorted: everything left is empty
+            const int m = (int)(key & 0xffffffffu), mj = m >> 6, ml = m & 63;
+            int sel_pw = pw[0];
+#pragma unroll
+            for (int j = 1; j < J; ++j) sel_pw = mj == j ? pw[j] : sel_pw;
+            const int pm = __shfl(sel_pw, ml, ELO_WAVE);
+            const unsigned ds = (unsigned)__shfl((int)d[0], s, ELO_WAVE);       // element at position s (lane s, register 0)
+            const int ps = __shfl(pw[0], s, ELO_WAVE);
+            if (m != s && lane == ml) {                                      // the reference's swap: s moves to m
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    if (mj == j) { d[j] = ds; pw[j] = ps; }
+            }
+            if (lane == 0) emit(s, pm);
+        }
+        return rounds;
+    }
     for (int base = 0; base < KT; base += ELO_WAVE) {
         const int i = base + lane;
         if (i < KT) {
@@ -91,7 +174,6 @@ __device__ __forceinline__ int wave_select_k(const float *__restrict__ grid2, in
             pay[i] = p.hit ? p.hw : 0;
         }
     }
-    const int rounds = K < KT ? K : KT;
     for (int s = 0; s < rounds; ++s) {
         unsigned best = 0xffffffffu;
         int where = 0x7fffffff;

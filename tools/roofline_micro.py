@@ -14,7 +14,7 @@ import bench
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--kernel", default="cv1"); ap.add_argument("--batch", type=int, default=1)
-ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--reps", type=int, default=20); ap.add_argument("--pregrouped", action="store_true"); ap.add_argument("--time", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ops, fused, tf_util, synth, elo = pkg("_ops"), pkg("fused"), pkg("tf_util"), pkg("synth"), pkg()
@@ -33,7 +33,13 @@ if a.kernel == "cv1":
         layers = (P('CV_0', 10 + 2 * C, 128), P('CV_1', 128, 64), P('CV_2', 64, 64), P('CV_xyz', 10, 64),
                   P('sum_CV_0', 128, 128), P('sum_CV_1', 128, 64))
     grp = fused.Grouping(order, [11, 41], 1000)
-    run = lambda: fused.cv_stage1(xyz1.reshape(B, N, 3), feat1.reshape(B, N, C), xyz2, feat2, None, None, *layers, group=grp, K=Kq)
+    if a.pregrouped:
+        hw = torch.from_numpy(synth.hw_index(B, H, W)).to(dev)
+        idx, _, _, m = elo.fused_conv_select_k(xyz1, xyz2, hw, order, H, W, N, 11, 41, Kq, 0, 1000.0, 1, 1, want_valid=False)
+        m = m.reshape(B, N, Kq)
+        run = lambda: fused.cv_stage1(xyz1.reshape(B, N, 3), feat1.reshape(B, N, C), xyz2, feat2, idx, m, *layers)
+    else:
+        run = lambda: fused.cv_stage1(xyz1.reshape(B, N, 3), feat1.reshape(B, N, C), xyz2, feat2, None, None, *layers, group=grp, K=Kq)
     info = {"flops": bench.cv1_flops(N, C, Kq) * B, "algorithmic_bytes": (cvb["A1"] + cvb["P1"]) * B}
 elif a.kernel == "pool":
     logits = torch.randn((B, N, Kq, 64), generator=g).to(dev); values = torch.randn((B, N, Kq, 64), generator=g).to(dev)
@@ -49,4 +55,6 @@ else:
 for _ in range(a.reps):
     run()
 torch.cuda.synchronize()
+if a.time:
+    info["us"] = round(bench._time_launches(run, dev, 200) * 1e6, 2)
 print(json.dumps({"kernel": a.kernel, "batch": B, **info}))
