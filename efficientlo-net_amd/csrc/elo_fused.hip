@@ -330,6 +330,130 @@ __global__ __launch_bounds__(FUSED_BLOCK) void setconv_kernel(const elo_setconv_
     pool_masked_max(act, S, 0, a.layers[a.n_layers - 1].N, meta, P, K, first_point, total_points, a.out);   // :224-230
 }
 
+
+// ================================================================ set-conv with a narrow MLP (widths <= 32, K == 32)
+// The first two set-conv layers (6->8->8->16 and 19->16->16->32 on 7200 / 1808 centres) are far too small for
+// matrix-core tiles: a 4-wave tile spends its time in barriers and dependent loads.  Here HALF A WAVE owns a
+// centre: its 32 lanes are the K = 32 neighbour rows.  Grouping (32 probes per step, ballot + popcount), the
+// gather of the row, the whole MLP (registers, weights broadcast from LDS) and the max over the 32 lanes (DPP)
+// happen without a single barrier after the weights are staged; 8 centres per workgroup.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_step(float v)
+{
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(v), CTRL,
+                                                               ROW_MASK, 0xf, false));
+    return fmaxf(o, v);
+}
+
+// max over each 32-lane half; valid in lane 31 / 63
+__device__ __forceinline__ float half_wave_max(float v)
+{
+    v = dpp_max_step<0xb1, 0xf>(v);      // quad_perm:[1,0,3,2]
+    v = dpp_max_step<0x4e, 0xf>(v);      // quad_perm:[2,3,0,1]
+    v = dpp_max_step<0x114, 0xf>(v);     // row_shr:4
+    v = dpp_max_step<0x118, 0xf>(v);     // row_shr:8
+    v = dpp_max_step<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3 only: halves stay separate
+    return v;
+}
+
+template <int KIN, int NOUT>
+__device__ __forceinline__ void small_layer(const float (&x)[32], float (&y)[32], const float *w, const float *b, bool relu)
+{
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) y[n] = b[n];
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) {
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) y[n] = fmaf(x[k], w[k * NOUT + n], y[n]);
+    }
+    if (relu) {
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) y[n] = fmaxf(y[n], 0.0f);
+    }
+}
+
+template <int CIN, int N1, int N2, int N3>
+__global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setconv_args a)
+{
+    constexpr int G = 32, PER_BLOCK = ELO_BLOCK / G, C = CIN - 3;
+    constexpr int W1 = 0, B1 = W1 + CIN * N1, W2 = B1 + N1, B2 = W2 + N1 * N2, W3 = B2 + N2, B3 = W3 + N2 * N3,
+                  WEND = B3 + N3;
+    __shared__ float wsm[WEND];
+    __shared__ int slot_hw[PER_BLOCK][G];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < WEND; i += ELO_BLOCK) {
+        float v;
+        if (i < B1) v = a.layers[0].w_plain[i - W1];
+        else if (i < W2) v = a.layers[0].bias[i - B1];
+        else if (i < B2) v = a.layers[1].w_plain[i - W2];
+        else if (i < W3) v = a.layers[1].bias[i - B2];
+        else if (i < B3) v = a.layers[2].w_plain[i - W3];
+        else v = a.layers[2].bias[i - B3];
+        wsm[i] = v;
+    }
+    const int g = tid / G, lane = tid % G, shift = (tid & 63) / G * G;
+    const long total = (long)a.batch * a.npoints;
+    const long pt = (long)xcd_tile(blockIdx.x, gridDim.x) * PER_BLOCK + g;
+    const bool live = pt < total;
+    const long ptc = live ? pt : total - 1;                 // dead groups shadow the last point and store nothing
+    const int b = (int)(ptc / a.npoints), n = (int)(ptc - (long)b * a.npoints);
+    const int hc = a.centre_hw ? a.centre_hw[ptc * 2 + 0] : n / a.W, wc = a.centre_hw ? a.centre_hw[ptc * 2 + 1] : n - (n / a.W) * a.W;
+    const float *cp = a.xyz1_grid + (((long)b * a.H + hc) * a.W + wc) * 3;
+    const float cx = cp[0], cy = cp[1], cz = cp[2];
+    if (live && lane < 3 && a.new_xyz) a.new_xyz[pt * 3 + lane] = lane == 0 ? cx : lane == 1 ? cy : cz;
+
+    // ---- random-k, 32 window slots per step (fused_conv_g.cu:74-152)
+    const elo_group_spec &gs = a.group;
+    const int KT = gs.kernel_h * gs.kernel_w, kW = gs.kernel_w, hh = gs.kernel_h / 2, hw2 = gs.kernel_w / 2;
+    const float r2 = gs.distance * gs.distance;
+    const float *grid2 = a.src_xyz + (size_t)b * a.H2 * a.W2 * 3;
+    const int base_h = hc / gs.stride_h, base_w = wc / gs.stride_w;
+    slot_hw[g][lane] = -1;
+    int taken = 0;
+    if (!(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS)) {
+        for (int base = 0; base < KT && taken < G; base += G) {
+            const int i = base + lane;
+            const int p = gs.random_hw[i < KT ? i : 0];
+            const int off = ((p / kW - hh) << 16) | ((p % kW - hw2) & 0xffff);
+            const Probe pr = judge(fetch_slot(grid2, a.H2, a.W2, off, base_h, base_w, i < KT), cx, cy, cz, r2);
+            const unsigned long long mh = group_ballot<G>(pr.hit, shift);
+            const int slot = taken + __popcll(mh & ((1ull << lane) - 1ull));
+            if (pr.hit && slot < G) slot_hw[g][slot] = pr.hw;
+            taken += __popcll(mh);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int hw = slot_hw[g][lane];                         // this lane's neighbour (row `lane` of the centre)
+    const float m = hw >= 0 ? 1.0f : 0.0f;
+    const long cell = hw >= 0 ? ((long)b * a.H2 + (hw >> 16)) * a.W2 + (hw & 0xffff) : 0;   // empty slot: index (0,0,0)
+    if (live && gs.idx_out) {
+        int *o = gs.idx_out + (pt * G + lane) * 3;
+        o[0] = hw >= 0 ? b : 0; o[1] = hw >= 0 ? hw >> 16 : 0; o[2] = hw >= 0 ? hw & 0xffff : 0;
+    }
+    if (live && gs.mask_out) gs.mask_out[pt * G + lane] = m;
+
+    // ---- gather + centre-subtract + concat, then the MLP in registers (:203-222)
+    float x[32], y[32];
+    const float *sx = a.src_xyz + cell * 3;
+    x[0] = sx[0] * m - cx; x[1] = sx[1] * m - cy; x[2] = sx[2] * m - cz;
+    const float *sf = a.src_feat + cell * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) x[3 + c] = sf[c] * m;
+    __syncthreads();                                          // weights staged (issued first, needed only now)
+    small_layer<CIN, N1>(x, y, wsm + W1, wsm + B1, a.layers[0].relu);
+    small_layer<N1, N2>(y, x, wsm + W2, wsm + B2, a.layers[1].relu);
+    small_layer<N2, N3>(x, y, wsm + W3, wsm + B3, a.layers[2].relu);
+    // ---- masked max over the 32 rows (:224-230); lane 31 of the half-wave holds it
+#pragma unroll
+    for (int c = 0; c < N3; ++c) y[c] = half_wave_max(y[c] * m);
+    if (live && lane == G - 1) {
+        float4 *o = reinterpret_cast<float4 *>(a.out + pt * N3);
+#pragma unroll
+        for (int c = 0; c < N3; c += 4) o[c / 4] = float4{y[c], y[c + 1], y[c + 2], y[c + 3]};
+    }
+}
+
 // ================================================================ row-wise MLP over concatenated sources
 template <int TILE>
 __global__ __launch_bounds__(FUSED_BLOCK) void mlp_kernel(const elo_mlp_args a, const int S)
@@ -538,6 +662,20 @@ extern "C" int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream)
     }
     const long points = (long)a->batch * a->npoints;
     if (points == 0) return ELO_OK;
+    if (a->group.random_hw && a->K == 32 && a->n_layers == 3 && a->layers[0].w_plain && a->layers[1].w_plain &&
+        a->layers[2].w_plain) {                     // narrow chains: wave-per-point VALU kernel
+        const int cin = 3 + a->C, n1 = a->layers[0].N, n2 = a->layers[1].N, n3 = a->layers[2].N;
+        const unsigned grid = (unsigned)((points + 7) / 8);
+        if (int rc = check_group(a->group, a->H2, a->W2, 0, who)) return rc;
+        if (cin == 6 && n1 == 8 && n2 == 8 && n3 == 16) {
+            hipLaunchKernelGGL((setconv_small_kernel<6, 8, 8, 16>), dim3(grid), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a);
+            return check_launch(who);
+        }
+        if (cin == 19 && n1 == 16 && n2 == 16 && n3 == 32) {
+            hipLaunchKernelGGL((setconv_small_kernel<19, 16, 16, 32>), dim3(grid), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a);
+            return check_launch(who);
+        }
+    }
     const int S = row_stride(chain_cols(a->layers, a->n_layers, 3 + a->C));
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;

@@ -24,9 +24,11 @@ class PackedDense:
         self.b = torch.zeros((Np,), dtype=torch.float32, device=W.device)
         self.b[:N] = b
         self.K, self.N, self.relu = K, N, relu
+        self.plain = W.contiguous() if max(K, N) <= 32 else None      # narrow layers: also kept row-major (K,N)
 
     def struct(self):
-        return L.Dense(self.w.data_ptr(), self.b.data_ptr(), self.K, self.N, 1 if self.relu else 0)
+        return L.Dense(self.w.data_ptr(), self.b.data_ptr(), self.K, self.N, 1 if self.relu else 0,
+                       self.plain.data_ptr() if self.plain is not None else None)
 
 
 def packed_layer(scope, cin, cout, bn=True, relu=True, row_order=None, tf_kernel_dims=(1, 1)):

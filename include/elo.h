@@ -252,6 +252,8 @@ typedef struct elo_dense {
     const float *bias;
     int K, N;
     int relu;
+    const float *w_plain;         /* optional: the same folded W as plain row-major (K,N); lets narrow chains
+                                     (all widths <= 32) run on the wave-per-point VALU kernel */
 } elo_dense;
 
 #define ELO_MAX_CHAIN 3
