@@ -94,6 +94,8 @@ SYMBOLS = [
     ("elo_warp_project", ctypes.c_int, [ctypes.POINTER(WarpProjectArgs), _vp]),
     ("elo_setconv_fused", ctypes.c_int, [ctypes.POINTER(SetconvArgs), _vp]),
     ("elo_mlp_fused", ctypes.c_int, [ctypes.POINTER(MlpArgs), _vp]),
+    ("elo_setconv_fused2", ctypes.c_int, [ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
+    ("elo_mlp_fused2", ctypes.c_int, [ctypes.POINTER(MlpArgs), ctypes.POINTER(MlpArgs), _vp]),
     ("elo_cv_stage1_fused", ctypes.c_int, [ctypes.POINTER(Cv1Args), _vp]),
     ("elo_cv_stage2_fused", ctypes.c_int, [ctypes.POINTER(Cv2Args), _vp]),
 ]
@@ -129,6 +131,12 @@ def call(entry, args, like):
     """Launch `entry(args, current stream)` on like.device; raise on a non-zero status."""
     with torch.cuda.device(like.device):
         check(getattr(lib(), entry)(ctypes.byref(args), stream_ptr(like)))
+
+
+def call2(entry, args_a, args_b, like):
+    """Paired launch: `entry(a, b, current stream)`."""
+    with torch.cuda.device(like.device):
+        check(getattr(lib(), entry)(ctypes.byref(args_a), ctypes.byref(args_b), stream_ptr(like)))
 
 
 def stream_ptr(t):

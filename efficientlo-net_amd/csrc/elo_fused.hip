@@ -277,9 +277,15 @@ __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int
 }
 
 // ================================================================ set-conv / set-upconv stage 1
+// blockIdx.y selects one of two independent jobs of identical shape (e.g. the embedding and the embedding-mask
+// set-upconv of a refinement level): one launch instead of two.
+template <typename Args>
+struct JobPair { Args job[2]; };                  // one kernarg block: job[blockIdx.y] is a uniform (scalar) access
+
 template <int TILE>
-__global__ __launch_bounds__(FUSED_BLOCK) void setconv_kernel(const elo_setconv_args a, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
 {
+    const elo_setconv_args &a = jobs.job[blockIdx.y];
     extern __shared__ float lds[];
     float *act = lds;
     const TileMeta meta = tile_meta(lds, TILE, S);
@@ -456,8 +462,9 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
 
 // ================================================================ row-wise MLP over concatenated sources
 template <int TILE>
-__global__ __launch_bounds__(FUSED_BLOCK) void mlp_kernel(const elo_mlp_args a, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
 {
+    const elo_mlp_args &a = jobs.job[blockIdx.y];
     extern __shared__ float lds[];
     float *act = lds;
     const int tid = threadIdx.x;
@@ -636,6 +643,25 @@ static int launch_tile(const char *who, bool tile16, long units16, long units32,
     return check_launch(who);
 }
 
+// two jobs of identical shape in one launch (grid.y = 2); b == nullptr: one job
+template <typename Args, typename K32, typename K16>
+static int launch_tile2(const char *who, bool tile16, long units16, long units32, int S, hipStream_t s, const Args &a,
+                        const Args *b, K32 k32, K16 k16, const elo_group_spec *g = nullptr, int H2 = 0, int W2 = 0)
+{
+    const int KT = (g && g->random_hw) ? g->kernel_h * g->kernel_w : 0;
+    const size_t lds = tile_lds_bytes(tile16 ? 16 : 32, S, KT, false);
+    if (g) if (int rc = check_group(*g, H2, W2, lds, who)) return rc;
+    const unsigned jobs = b ? 2 : 1;
+    JobPair<Args> pair;
+    pair.job[0] = a;
+    pair.job[1] = b ? *b : a;
+    if (tile16)
+        hipLaunchKernelGGL(k16, dim3((unsigned)units16, jobs), dim3(FUSED_BLOCK), lds, s, pair, S);
+    else
+        hipLaunchKernelGGL(k32, dim3((unsigned)units32, jobs), dim3(FUSED_BLOCK), lds, s, pair, S);
+    return check_launch(who);
+}
+
 // column budget of an in-place chain starting from `width` input columns
 static int chain_cols(const elo_dense *layers, int n_layers, int width)
 {
@@ -644,9 +670,8 @@ static int chain_cols(const elo_dense *layers, int n_layers, int width)
     return cols;
 }
 
-extern "C" int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream)
+static int check_setconv(const elo_setconv_args *a, const char *who)
 {
-    const char *who = "elo_setconv_fused";
     ELO_REQUIRE(a, who, "null argument block");
     ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->K > 0 && a->H2 > 0 && a->W2 > 0 && a->C >= 0, who, "bad sizes");
     if (a->K > 32) return fail(ELO_ERR_LIMIT, "%s: K = %d exceeds the 32-row tile", who, a->K);
@@ -660,9 +685,31 @@ extern "C" int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream)
         if (int rc = check_dense(a->layers[l], width, 0, who, "mlp")) return rc;
         width = a->layers[l].N;
     }
+    return ELO_OK;
+}
+
+static bool same_shape(const elo_setconv_args *a, const elo_setconv_args *b)
+{
+    if (a->batch != b->batch || a->npoints != b->npoints || a->K != b->K || a->C != b->C || a->n_layers != b->n_layers ||
+        a->H2 != b->H2 || a->W2 != b->W2 || a->group.kernel_h != b->group.kernel_h || a->group.kernel_w != b->group.kernel_w ||
+        (a->group.random_hw == nullptr) != (b->group.random_hw == nullptr))
+        return false;
+    for (int l = 0; l < a->n_layers; ++l)
+        if (a->layers[l].K != b->layers[l].K || a->layers[l].N != b->layers[l].N) return false;
+    return true;
+}
+
+extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_args *b, elo_stream_t stream)
+{
+    const char *who = "elo_setconv_fused";
+    if (int rc = check_setconv(a, who)) return rc;
+    if (b) {
+        if (int rc = check_setconv(b, who)) return rc;
+        if (!same_shape(a, b)) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must have the same shape", who);
+    }
     const long points = (long)a->batch * a->npoints;
     if (points == 0) return ELO_OK;
-    if (a->group.random_hw && a->K == 32 && a->n_layers == 3 && a->layers[0].w_plain && a->layers[1].w_plain &&
+    if (!b && a->group.random_hw && a->K == 32 && a->n_layers == 3 && a->layers[0].w_plain && a->layers[1].w_plain &&
         a->layers[2].w_plain) {                     // narrow chains: wave-per-point VALU kernel
         const int cin = 3 + a->C, n1 = a->layers[0].N, n2 = a->layers[1].N, n3 = a->layers[2].N;
         const unsigned grid = (unsigned)((points + 7) / 8);
@@ -679,13 +726,17 @@ extern "C" int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream)
     const int S = row_stride(chain_cols(a->layers, a->n_layers, 3 + a->C));
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
-    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, setconv_kernel<32>,
-                       setconv_kernel<16>, &a->group, a->H2, a->W2, false);
+    return launch_tile2(who, small_tile(u32 * (b ? 2 : 1), a->K), u16, u32, S, (hipStream_t)stream, *a, b, setconv_kernel<32>,
+                        setconv_kernel<16>, &a->group, a->H2, a->W2);
 }
 
-extern "C" int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream)
+extern "C" int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream)
 {
-    const char *who = "elo_mlp_fused";
+    return elo_setconv_fused2(a, nullptr, stream);
+}
+
+static int check_mlp(const elo_mlp_args *a, const char *who, int *in_width)
+{
     ELO_REQUIRE(a, who, "null argument block");
     ELO_REQUIRE(a->rows >= 0 && a->n_sources >= 1 && a->n_sources <= 3, who, "bad sizes");
     ELO_REQUIRE(a->n_layers >= 1 && a->n_layers <= ELO_MAX_CHAIN && a->out, who, "1..3 layers and an output");
@@ -694,16 +745,33 @@ extern "C" int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream)
         ELO_REQUIRE(a->src[s] && a->src_width[s] > 0, who, "null / empty source");
         width += a->src_width[s];
     }
-    const int in_width = width;
+    *in_width = width;
     for (int l = 0; l < a->n_layers; ++l) {
         if (int rc = check_dense(a->layers[l], width, 0, who, "mlp")) return rc;
         width = a->layers[l].N;
     }
+    return ELO_OK;
+}
+
+extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_stream_t stream)
+{
+    const char *who = "elo_mlp_fused";
+    int in_width = 0, in_width_b = 0;
+    if (int rc = check_mlp(a, who, &in_width)) return rc;
+    if (b) {
+        if (int rc = check_mlp(b, who, &in_width_b)) return rc;
+        bool same = a->rows == b->rows && in_width == in_width_b && a->n_layers == b->n_layers;
+        for (int l = 0; same && l < a->n_layers; ++l) same = a->layers[l].N == b->layers[l].N;
+        if (!same) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must have the same shape", who);
+    }
     if (a->rows == 0) return ELO_OK;
     const int S = row_stride(chain_cols(a->layers, a->n_layers, in_width));
     const long u32 = (a->rows + 31) / 32, u16 = (a->rows + 15) / 16;
-    return launch_tile(who, small_tile(u32, 1), u16, u32, S, (hipStream_t)stream, *a, mlp_kernel<32>, mlp_kernel<16>);
+    return launch_tile2(who, small_tile(u32 * (b ? 2 : 1), 1), u16, u32, S, (hipStream_t)stream, *a, b, mlp_kernel<32>,
+                        mlp_kernel<16>);
 }
+
+extern "C" int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream) { return elo_mlp_fused2(a, nullptr, stream); }
 
 extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
 {

@@ -83,10 +83,8 @@ class Grouping:
 _NO_GROUP = L.GroupSpec(None, 0, 0, 0.0, 0, 0, None, None)
 
 
-def setconv(src_xyz, src_feat, idx, mask, layers, centre_xyz=None, xyz1_grid=None, centre_hw=None, group=None, K=None):
-    """group_concat -> MLP chain -> masked max over K in one launch.  Either (idx, mask) from a grouping op, or
-    group=Grouping(...) + K to group in-kernel (needs xyz1_grid; centre_hw None = every pixel of xyz1_grid).
-    Returns (out (B,n,Cout), new_xyz (B,n,3) or None)."""
+def _setconv_args(src_xyz, src_feat, idx, mask, layers, centre_xyz=None, xyz1_grid=None, centre_hw=None, group=None,
+                  K=None):
     L.require_gpu(src_xyz, src_feat, idx, mask, centre_xyz, xyz1_grid, centre_hw)
     src_xyz, src_feat = _f32c(src_xyz), _f32c(src_feat)
     _, H2, W2, C = src_feat.shape
@@ -112,14 +110,29 @@ def setconv(src_xyz, src_feat, idx, mask, layers, centre_xyz=None, xyz1_grid=Non
     a = L.SetconvArgs(B, n, K, H, W, H2, W2, C, ptr(xyz1_grid), ptr(centre_hw), ptr(centre_xyz), src_xyz.data_ptr(),
                       src_feat.data_ptr(), ptr(idx), ptr(mask), len(layers), _chain(layers), out.data_ptr(), ptr(new_xyz),
                       group.struct(B, n, K, dev) if group is not None else _NO_GROUP)
+    keep = (src_xyz, src_feat, idx, mask, centre_xyz, xyz1_grid, centre_hw, layers, group)   # alive until the launch
+    return a, out, new_xyz, keep
+
+
+def setconv(src_xyz, src_feat, idx, mask, layers, centre_xyz=None, xyz1_grid=None, centre_hw=None, group=None, K=None):
+    """group_concat -> MLP chain -> masked max over K in one launch.  Either (idx, mask) from a grouping op, or
+    group=Grouping(...) + K to group in-kernel (needs xyz1_grid; centre_hw None = every pixel of xyz1_grid).
+    Returns (out (B,n,Cout), new_xyz (B,n,3) or None)."""
+    a, out, new_xyz, _keep = _setconv_args(src_xyz, src_feat, idx, mask, layers, centre_xyz, xyz1_grid, centre_hw, group, K)
     L.call("elo_setconv_fused", a, out)
     return out, new_xyz
 
 
-def mlp(sources, layers):
-    """Row-wise MLP over concat(sources, -1) without building the concat.  sources: (..., C_i) tensors."""
+def setconv_pair(job_a, job_b):
+    """Two set-conv jobs of identical shape (dicts of setconv() keyword arguments) in ONE launch."""
+    a, out_a, new_a, _ka = _setconv_args(**job_a)
+    b, out_b, new_b, _kb = _setconv_args(**job_b)
+    L.call2("elo_setconv_fused2", a, b, out_a)
+    return (out_a, new_a), (out_b, new_b)
+
+
+def _mlp_args(sources, layers):
     L.require_gpu(*sources)
-    lead = sources[0].shape[:-1]
     srcs = [_f32c(s).reshape(-1, s.shape[-1]) for s in sources]
     rows = srcs[0].shape[0]
     out = torch.empty((rows, layers[-1].N), dtype=torch.float32, device=srcs[0].device)
@@ -127,8 +140,23 @@ def mlp(sources, layers):
     a.rows, a.n_sources, a.n_layers, a.layers, a.out = rows, len(srcs), len(layers), _chain(layers), out.data_ptr()
     for i, s in enumerate(srcs):
         a.src[i], a.src_width[i] = s.data_ptr(), s.shape[1]
+    return a, out, (srcs, layers)
+
+
+def mlp(sources, layers):
+    """Row-wise MLP over concat(sources, -1) without building the concat.  sources: (..., C_i) tensors."""
+    a, out, _keep = _mlp_args(sources, layers)
     L.call("elo_mlp_fused", a, out)
-    return out.reshape(lead + (layers[-1].N,))
+    return out.reshape(sources[0].shape[:-1] + (layers[-1].N,))
+
+
+def mlp_pair(sources_a, layers_a, sources_b, layers_b):
+    """Two row-wise MLPs of identical shape in ONE launch."""
+    a, out_a, _ka = _mlp_args(sources_a, layers_a)
+    b, out_b, _kb = _mlp_args(sources_b, layers_b)
+    L.call2("elo_mlp_fused2", a, b, out_a)
+    lead = sources_a[0].shape[:-1]
+    return out_a.reshape(lead + (layers_a[-1].N,)), out_b.reshape(lead + (layers_b[-1].N,))
 
 
 def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1, group=None, K=None):

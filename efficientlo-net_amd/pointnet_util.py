@@ -209,6 +209,48 @@ def flow_predictor(points_f1, upsampled_feat, cost_volume, mlp, is_training, bn_
         return x.squeeze(2)
 
 
+def fused_pairs_available(is_training):
+    """True when the paired-launch forms below can be used (fused inference path)."""
+    return _fused_path(is_training)
+
+
+def flow_predictor_pair(call_a, call_b):
+    """Two flow_predictor calls with identical shapes (dicts of flow_predictor keyword arguments) in ONE launch
+    (pwclo_model.py:253-254: the embedding and the embedding-mask predictors of a refinement level)."""
+    specs = []
+    for c in (call_a, call_b):
+        with tf_util.variable_scope(c["scope"]):
+            parts = [p for p in (c["points_f1"], c["upsampled_feat"], c["cost_volume"]) if p is not None]
+            widths = [sum(p.shape[-1] for p in parts)] + list(c["mlp"])
+            layers = [fused.packed_layer('conv_predictor%d' % i, widths[i], widths[i + 1], bn=c.get("bn", True))
+                      for i in range(len(c["mlp"]))]
+        specs.append((parts, layers))
+    return fused.mlp_pair(specs[0][0], specs[0][1], specs[1][0], specs[1][1])
+
+
+def up_conv_pair(call_a, call_b):
+    """Two up_conv calls that differ only in scope and feat2_proj (pwclo_model.py:247,250) in TWO launches
+    instead of four: paired set-conv stage (grouping + gather + MLP + max-pool) and paired stage-2 MLP."""
+    jobs, stage2 = [], []
+    for c in (call_a, call_b):
+        with tf_util.variable_scope(c["scope"]):
+            xyz1_proj, feat1_proj, feat2_proj = c["xyz1_proj"], c["feat1_proj"], c["feat2_proj"]
+            B, H, W, _ = xyz1_proj.shape
+            ks, mlp, mlp2 = c["kernel_size"], c["mlp"], c["mlp2"]
+            random_HW = random_shuffle(tf_util.scope_name(), "random_HW", ks[0] * ks[1], xyz1_proj.device)
+            P = fused.packed_layer
+            w1 = [3 + feat2_proj.shape[-1]] + list(mlp)
+            jobs.append(dict(src_xyz=c["xyz2_proj"], src_feat=feat2_proj, idx=None, mask=None,
+                             layers=[P('up_1_%d' % j, w1[j], w1[j + 1]) for j in range(len(mlp))],
+                             xyz1_grid=xyz1_proj, K=c["nsample"],
+                             group=fused.Grouping(random_HW, ks, c["distance"], c["stride_h"], c["stride_w"])))
+            points1 = feat1_proj.reshape(B, H * W, -1)
+            w2 = [mlp[-1] + points1.shape[-1]] + list(mlp2)
+            stage2.append((points1, [P('up_2_%d' % i, w2[i], w2[i + 1]) for i in range(len(mlp2))]))
+    (up_a, _), (up_b, _) = fused.setconv_pair(jobs[0], jobs[1])
+    return fused.mlp_pair([up_a, stage2[0][0]], stage2[0][1], [up_b, stage2[1][0]], stage2[1][1])
+
+
 def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distance, mlp, mlp2, flag_add, is_training,
               bn_decay, scope, bn=True, pooling='max', knn=False, use_xyz=True, use_nchw=False):
     """Set-conv, utils/pointnet_util.py:179-250.  Returns ((B, n, mlp[-1]), new_xyz_proj (B,H',W',3))."""

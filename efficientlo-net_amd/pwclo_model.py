@@ -19,7 +19,8 @@ import torch
 from . import _ops, tf_util
 from .model_util import (PreProcess, ProjectPC2SphericalRing, get_selected_idx, inv_q, mul_point_q, mul_q_point,
                          softmax_valid, warp_and_project)
-from .pointnet_util import cost_volume, down_conv, flow_predictor, up_conv
+from .pointnet_util import (cost_volume, down_conv, flow_predictor, flow_predictor_pair, fused_pairs_available, up_conv,
+                            up_conv_pair)
 
 Down_conv_dis = [0.5, 3.0, 6.0, 12.0]       # pwclo_model.py:38
 Up_conv_dis = [3.0, 6.0, 9.0]               # :39
@@ -288,15 +289,29 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                            scope='up_sa_layer_layer_l%d%s' % (level, kind), is_training=is_training,
                            bn_decay=bn_decay, knn=True)                                             # :247, :250
 
-        # the cost volume and the two set-upconvs only share inputs: three concurrent branches (forked HIP
-        # streams, which a hipGraph capture records as parallel graph branches), joined before the predictors
-        cost, w_up_sample, cost_up_sample = _parallel([branch_cost, lambda: branch_up('w', coarse_w_proj),
-                                                       lambda: branch_up('costvolume', coarse_predict_proj)])
-        predict, weight = _parallel([
-            lambda: flow_predictor(points_warp_f1, cost_up_sample, cost, mlp=[128, 64], is_training=is_training,
-                                   bn_decay=bn_decay, scope='l%d_costvolume_predict' % level),     # :253
-            lambda: flow_predictor(points_warp_f1, w_up_sample, cost, mlp=[128, 64], is_training=is_training,
-                                   bn_decay=bn_decay, scope='l%d_w_predict' % level)])             # :254
+        if fused_pairs_available(is_training):
+            # inference: the embedding / embedding-mask twins of a level run as PAIRED launches (same shapes,
+            # different weights): 2 + 1 launches instead of 4 + 2
+            cost = branch_cost()
+            up = dict(xyz1_proj=xyz_warp_proj_f1, xyz2_proj=coarse_xyz_proj, feat1_proj=points_warp_proj_f1,
+                      kernel_size=[7, 15], stride_h=stride_h_list[g + 1], stride_w=stride_w_list[g + 1], nsample=8,
+                      distance=Up_conv_dis[level], mlp=[128, 64], mlp2=[128, 64])
+            w_up_sample, cost_up_sample = up_conv_pair(
+                dict(up, feat2_proj=coarse_w_proj, scope='up_sa_layer_layer_l%dw' % level),
+                dict(up, feat2_proj=coarse_predict_proj, scope='up_sa_layer_layer_l%dcostvolume' % level))
+            fp = dict(points_f1=points_warp_f1, cost_volume=cost, mlp=[128, 64])
+            predict, weight = flow_predictor_pair(
+                dict(fp, upsampled_feat=cost_up_sample, scope='l%d_costvolume_predict' % level),
+                dict(fp, upsampled_feat=w_up_sample, scope='l%d_w_predict' % level))
+        else:
+            # the cost volume and the two set-upconvs only share inputs: optional concurrent branches
+            cost, w_up_sample, cost_up_sample = _parallel([branch_cost, lambda: branch_up('w', coarse_w_proj),
+                                                           lambda: branch_up('costvolume', coarse_predict_proj)])
+            predict, weight = _parallel([
+                lambda: flow_predictor(points_warp_f1, cost_up_sample, cost, mlp=[128, 64], is_training=is_training,
+                                       bn_decay=bn_decay, scope='l%d_costvolume_predict' % level),     # :253
+                lambda: flow_predictor(points_warp_f1, w_up_sample, cost, mlp=[128, 64], is_training=is_training,
+                                       bn_decay=bn_decay, scope='l%d_w_predict' % level)])             # :254
         q_prev, t_prev, q_norm = _estimate_pose(predict, weight, xyz_warp_f1, level, q_coarse, t_coarse,
                                                 is_training)                                       # :262-280
         poses[level] = (q_norm, t_prev)

@@ -294,6 +294,9 @@ typedef struct elo_setconv_args {
     elo_group_spec group;         /* random-k; needs xyz1_grid; centre_hw == NULL: centre n is pixel (n / W, n % W) */
 } elo_setconv_args;
 int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream);
+/* two independent jobs of identical shape in ONE launch (b may be NULL): the embedding and the embedding-mask
+ * set-upconv of a refinement level (pwclo_model.py:247,250) share everything but weights and one input */
+int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_args *b, elo_stream_t stream);
 
 /* Row-wise MLP over the concatenation of up to three row-aligned sources:
  * flow_predictor (utils/pointnet_util.py:153-175) and set-upconv stage 2 (:303-311). */
@@ -307,6 +310,7 @@ typedef struct elo_mlp_args {
     float *out;                   /* (rows, layers[last].N) */
 } elo_mlp_args;
 int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream);
+int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_stream_t stream);   /* paired launch, as above */
 
 /* Attentive cost volume, stage 1 (utils/pointnet_util.py:54-100) in one launch:
  * encode -> CV_0..2 -> CV_xyz -> sum_CV_0..1 -> masked softmax over K -> weighted sum.
