@@ -166,19 +166,30 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_partial_kernel(const 
     const int per = (npoints + parts - 1) / parts;
     const int lo = slice * per, hi = min(npoints, lo + per);
     float mx = -INFINITY, den = 0.0f, acc = 0.0f;
-    for (int n = lo + wave; n < hi; n += ROWS_PER_BLOCK) {
-        const bool valid = !(p[n * 3 + 0] == 0.0f && p[n * 3 + 1] == 0.0f && p[n * 3 + 2] == 0.0f);
-        if (!valid || !live) continue;
-        const float l = w[(long)n * C + c], v = f[(long)n * C + c];
-        if (l > mx) {
-            const float sc = expf(mx - l);            // exp(-inf) = 0 on the first valid point
-            den = den * sc + 1.0f;
-            acc = acc * sc + v;
-            mx = l;
-        } else {
-            const float e = expf(l - mx);
-            den += e;
-            acc += e * v;
+    for (int n0 = lo + wave; n0 < hi; n0 += 4 * ROWS_PER_BLOCK) {
+        float l[4], v[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                 // four rows in flight per wave: the loop is latency-bound
+            const int n = n0 + u * ROWS_PER_BLOCK;
+            const int nn = n < hi ? n : hi - 1;
+            ok[u] = n < hi && live && !(p[nn * 3 + 0] == 0.0f && p[nn * 3 + 1] == 0.0f && p[nn * 3 + 2] == 0.0f);
+            l[u] = live ? w[(long)nn * C + c] : 0.0f;
+            v[u] = live ? f[(long)nn * C + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            if (l[u] > mx) {
+                const float sc = expf(mx - l[u]);      // exp(-inf) = 0 on the first valid point
+                den = den * sc + 1.0f;
+                acc = acc * sc + v[u];
+                mx = l[u];
+            } else {
+                const float e = expf(l[u] - mx);
+                den += e;
+                acc += e * v[u];
+            }
         }
     }
     part[0][wave][lane] = mx; part[1][wave][lane] = den; part[2][wave][lane] = acc;
