@@ -254,7 +254,34 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
     float *feat = sm, *big = sm + a.C, *head = big + a.hidden;
     const int b = blockIdx.x, tid = threadIdx.x;
     const SvPartials s = sv_partials(a.scratch, gridDim.x, a.C);
-    for (int c = tid; c < a.C; c += blockDim.x) feat[c] = sv_merge(s, b, c, a.C, parts);
+    {   // merge the slices: 4 threads per channel (C <= 64), each over every 4th slice, then a 4-way combine
+        float *mpart = head + 8 + 8 * (ELO_BLOCK / ELO_WAVE);          // [3][4][64]
+        const int c = tid & 63, q = tid >> 6;
+        float M = -INFINITY, D = 0.0f, A = 0.0f;
+        if (c < a.C) {
+            for (int i = q; i < parts; i += 4) {
+                const size_t at = ((size_t)b * ELO_SV_MAX_PARTS + i) * a.C + c;
+                if (s.den[at] == 0.0f) continue;
+                const float m2 = s.mx[at];
+                if (m2 > M) { const float sc = expf(M - m2); D = D * sc + s.den[at]; A = A * sc + s.acc[at]; M = m2; }
+                else { const float sc = expf(m2 - M); D += s.den[at] * sc; A += s.acc[at] * sc; }
+            }
+        }
+        mpart[(0 * 4 + q) * 64 + c] = M; mpart[(1 * 4 + q) * 64 + c] = D; mpart[(2 * 4 + q) * 64 + c] = A;
+        __syncthreads();
+        if (tid < 64) {
+            float MM = -INFINITY;
+            for (int i = 0; i < 4; ++i) MM = fmaxf(MM, mpart[(0 * 4 + i) * 64 + tid]);
+            float DD = 0.0f, AA = 0.0f;
+            for (int i = 0; i < 4; ++i) {
+                if (mpart[(1 * 4 + i) * 64 + tid] == 0.0f) continue;
+                const float sc = expf(mpart[(0 * 4 + i) * 64 + tid] - MM);
+                DD += mpart[(1 * 4 + i) * 64 + tid] * sc; AA += mpart[(2 * 4 + i) * 64 + tid] * sc;
+            }
+            if (tid < a.C) feat[tid] = DD > 0.0f ? AA / DD : 0.0f;
+        }
+        for (int c2 = 64 + tid; c2 < a.C; c2 += blockDim.x) feat[c2] = sv_merge(s, b, c2, a.C, parts);   // C > 64 (not the model)
+    }
     __syncthreads();
     for (int j = tid; j < a.hidden; j += blockDim.x) {     // conv1d C -> hidden, no activation (:197)
         float v = a.b_big[j];
@@ -453,11 +480,8 @@ extern "C" int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_strea
 
 static int sv_parts(int npoints)
 {
-    // Few, fat slices: the merge in the head kernel walks the partials serially per channel, so 16 slices of
-    // ~N/16 points (>= 64 points per block) beat many thin ones.
-    int parts = (npoints + 63) / 64;
-    const int cap = 16 < ELO_SV_MAX_PARTS ? 16 : ELO_SV_MAX_PARTS;
-    return parts < 1 ? 1 : parts > cap ? cap : parts;
+    int parts = (npoints + 63) / 64;                 // >= 64 points (16 per wave) per block
+    return parts < 1 ? 1 : parts > ELO_SV_MAX_PARTS ? ELO_SV_MAX_PARTS : parts;
 }
 
 extern "C" int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t stream)
@@ -489,7 +513,7 @@ extern "C" int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream)
     hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
                        dim3(ELO_BLOCK), 0, (hipStream_t)stream, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
                        a->scratch);
-    const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (ELO_BLOCK / ELO_WAVE));
+    const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (ELO_BLOCK / ELO_WAVE) + 3 * 4 * 64);
     hipLaunchKernelGGL(pose_head_kernel, dim3(a->batch), dim3(ELO_BLOCK), lds, (hipStream_t)stream, *a, parts);
     return check_launch(who);
 }
