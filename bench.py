@@ -16,7 +16,7 @@ independent, so ranks shard the stream with no data-path collective; the poses o
 step are all-gathered (7 floats per pair) once per step so rank 0 can chain them
 (main.py:557-572), which is the only exchange the path has.  scaling = weak.
 
-Throughput design: the whole forward is one hipGraph; `--lanes` graphs (default 8), each with its own
+Throughput design: the whole forward is one hipGraph; `--lanes` graphs (default 12), each with its own
 stream and static buffers, keep that many independent forwards in flight (step i rides lane i % lanes).
 
 Besides the contract line this prints, on rank 0 at N=1:
@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--width", type=int, default=1800)
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic pairs kept in HBM")
-    ap.add_argument("--lanes", type=int, default=8, help="independent forwards in flight (streams x hipGraphs)")
+    ap.add_argument("--lanes", type=int, default=12, help="independent forwards in flight (streams x hipGraphs)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=60, help="pairs in the CPU-oracle sample")

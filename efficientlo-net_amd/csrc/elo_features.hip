@@ -24,22 +24,70 @@ __device__ __forceinline__ long row_of_wave(long total_rows)
 
 inline unsigned grid_for_rows(long rows) { return (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
 
+// ------------------------------------------------------------ staged row writers
+// The gather/encode kernels emit rows of 3+C / 10+2C / 10 / C+Cc floats (19 ... 138): written row by row as 4-byte
+// lane stores these are partial, unaligned cache-line writes (measured: 10x WRITE_SIZE amplification, 463 GB/s,
+// profiles/r01_pmc).  So a workgroup builds 64 rows in LDS (wave per row, lanes along channels: gathered feature
+// rows are still read as contiguous segments) and then streams the tile out linearly with 16-byte stores:
+// 64 rows x CT floats is always a multiple of 256 bytes, so every tile starts on a 256-byte boundary.
+constexpr int STAGE_ROWS = 64;
+
+__device__ __forceinline__ void stream_out(const float *tile, float *__restrict__ dst, long first_row, long rows, int CT)
+{
+    const long valid = (rows - first_row < STAGE_ROWS ? rows - first_row : STAGE_ROWS) * CT;   // floats in this tile
+    float *o = dst + first_row * CT;
+    const long vec = valid >> 2;
+    for (long i = threadIdx.x; i < vec; i += ELO_BLOCK)
+        reinterpret_cast<float4 *>(o)[i] = reinterpret_cast<const float4 *>(tile)[i];
+    for (long i = (vec << 2) + threadIdx.x; i < valid; i += ELO_BLOCK) o[i] = tile[i];
+}
+
+inline unsigned grid_for_stage(long rows) { return (unsigned)((rows + STAGE_ROWS - 1) / STAGE_ROWS); }
+
+// per-row gather metadata of a 64-row tile, fetched once by the first 64 threads
+struct StageMeta { long *cell; float *mask; };
+
+__device__ __forceinline__ StageMeta stage_meta(float *after_tile, long first, long rows, const int *__restrict__ idx,
+                                                const float *__restrict__ mask, int H2, int W2)
+{
+    StageMeta m{reinterpret_cast<long *>(after_tile), after_tile + 2 * STAGE_ROWS};
+    const int t = threadIdx.x;
+    if (t < STAGE_ROWS) {
+        const long r = first + t;
+        long cell = -1;
+        float mk = 0.0f;
+        if (r < rows) {
+            const int *id = idx + r * 3;
+            cell = ((long)id[0] * H2 + id[1]) * W2 + id[2];
+            mk = mask[r];
+        }
+        m.cell[t] = cell;
+        m.mask[t] = mk;
+    }
+    __syncthreads();
+    return m;
+}
+
+constexpr size_t STAGE_META_BYTES = sizeof(float) * 3 * STAGE_ROWS;
+
 // ------------------------------------------------------------ group_concat
 __global__ __launch_bounds__(ELO_BLOCK) void group_concat_kernel(const elo_group_concat_args a, const long rows)
 {
-    const long r = row_of_wave(rows);                  // r = (b*N + n)*K + k
-    if (r < 0) return;
-    const int lane = threadIdx.x % ELO_WAVE;
-    const long bn = r / a.K;
-    const int *id = a.idx + r * 3;
-    const long cell = ((long)id[0] * a.H2 + id[1]) * a.W2 + id[2];
-    const float m = a.mask[r];
-    const float *cen = a.centre_xyz + bn * 3;
-    const float *sx = a.src_xyz + cell * 3;
-    const float *sf = a.src_feat + cell * a.C;
-    float *o = a.out + r * (3 + a.C);
-    for (int ch = lane; ch < 3 + a.C; ch += ELO_WAVE)
-        o[ch] = ch < 3 ? sx[ch] * m - cen[ch] : sf[ch - 3] * m;
+    extern __shared__ float tile[];
+    const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * STAGE_ROWS;
+    if (first >= rows) return;
+    const int CT = 3 + a.C;
+    const StageMeta m = stage_meta(tile + STAGE_ROWS * CT + (STAGE_ROWS * CT & 1), first, rows, a.idx, a.mask, a.H2, a.W2);
+    for (int e = threadIdx.x; e < STAGE_ROWS * CT; e += ELO_BLOCK) {     // independent iterations: loads overlap
+        const int lr = e / CT, ch = e - lr * CT;
+        const long cell = m.cell[lr];
+        if (cell < 0) continue;
+        const float mk = m.mask[lr];
+        const long bn = (first + lr) / a.K;
+        tile[e] = ch < 3 ? a.src_xyz[cell * 3 + ch] * mk - a.centre_xyz[bn * 3 + ch] : a.src_feat[cell * a.C + (ch - 3)] * mk;
+    }
+    __syncthreads();
+    stream_out(tile, a.out, first, rows, CT);
 }
 
 // ------------------------------------------------------------ masked max-pool
@@ -74,44 +122,110 @@ __device__ __forceinline__ float geo_channel(const Geo &s, int ch)
     return ch < 3 ? s.p[ch] : ch < 6 ? s.g[ch - 3] : ch < 9 ? s.d[ch - 6] : s.euc;
 }
 
+__device__ __forceinline__ float geo_value(const float *p, const float *g, float m, int ch)
+{   // [p, g*m, g*m - p, sqrt(sum((g*m-p)^2) + 1e-20)]   utils/pointnet_util.py:54-62
+    float gm[3], d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gm[i] = g[i] * m; d[i] = gm[i] - p[i]; }
+    if (ch < 3) return p[ch];
+    if (ch < 6) return gm[ch - 3];
+    if (ch < 9) return d[ch - 6];
+    return sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + 1e-20f);
+}
+
 __global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_kernel(const elo_cv_encode1_args a, const long rows)
 {
-    const long r = row_of_wave(rows);
-    if (r < 0) return;
-    const int lane = threadIdx.x % ELO_WAVE;
-    const long bn = r / a.K;
-    const int *id = a.idx + r * 3;
-    const long cell = ((long)id[0] * a.H2 + id[1]) * a.W2 + id[2];
-    const float m = a.mask[r];
-    const Geo s = geometry(a.xyz1 + bn * 3, a.xyz2 + cell * 3, m);
-    const float *f1 = a.feat1 + bn * a.C;
-    const float *f2 = a.feat2 + cell * a.C;
+    extern __shared__ float tile[];
+    const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * STAGE_ROWS;
+    if (first >= rows) return;
     const int C = a.C, CT = 10 + 2 * C;
-    float *o = a.out + r * CT;
-    for (int ch = lane; ch < CT; ch += ELO_WAVE)
-        o[ch] = ch < 10 ? geo_channel(s, ch) : ch < 10 + C ? f1[ch - 10] : f2[ch - 10 - C] * m;
+    const StageMeta m = stage_meta(tile + STAGE_ROWS * CT + (STAGE_ROWS * CT & 1), first, rows, a.idx, a.mask, a.H2, a.W2);
+    for (int e = threadIdx.x; e < STAGE_ROWS * CT; e += ELO_BLOCK) {
+        const int lr = e / CT, ch = e - lr * CT;
+        const long cell = m.cell[lr];
+        if (cell < 0) continue;
+        const float mk = m.mask[lr];
+        const long bn = (first + lr) / a.K;
+        tile[e] = ch < 10 ? geo_value(a.xyz1 + bn * 3, a.xyz2 + cell * 3, mk, ch)
+                : ch < 10 + C ? a.feat1[bn * C + (ch - 10)] : a.feat2[cell * C + (ch - 10 - C)] * mk;
+    }
+    __syncthreads();
+    stream_out(tile, a.out, first, rows, CT);
 }
 
 __global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_kernel(const elo_cv_encode2_args a, const long rows)
 {
-    const long r = row_of_wave(rows);
-    if (r < 0) return;
-    const int lane = threadIdx.x % ELO_WAVE;
-    const long bn = r / a.K;
-    const int *id = a.idx + r * 3;
-    const long cell = ((long)id[0] * a.H + id[1]) * a.W + id[2];
-    const float m = a.mask[r];
-    const Geo s = geometry(a.xyz1 + bn * 3, a.xyz1 + cell * 3, m);
-    if (lane < 10) a.xyz_cat[r * 10 + lane] = geo_channel(s, lane);
-    const float *f1 = a.feat1 + bn * a.C;
-    const float *cv = a.cost + cell * a.Cc;
-    const int CT = a.C + a.Cc;
-    float *o = a.rest + r * CT;
-    for (int ch = lane; ch < CT; ch += ELO_WAVE)
-        o[ch] = ch < a.C ? f1[ch] : cv[ch - a.C] * m;
+    extern __shared__ float tile[];                     // [64][10] geometry, then [64][C+Cc]
+    const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * STAGE_ROWS;
+    if (first >= rows) return;
+    const int CT = a.C + a.Cc, ALL = 10 + CT;
+    float *geo = tile, *rest = tile + STAGE_ROWS * 10;
+    const StageMeta m = stage_meta(tile + STAGE_ROWS * ALL + (STAGE_ROWS * ALL & 1), first, rows, a.idx, a.mask, a.H, a.W);
+    for (int e = threadIdx.x; e < STAGE_ROWS * ALL; e += ELO_BLOCK) {
+        const int lr = e / ALL, ch = e - lr * ALL;
+        const long cell = m.cell[lr];
+        if (cell < 0) continue;
+        const float mk = m.mask[lr];
+        const long bn = (first + lr) / a.K;
+        if (ch < 10) geo[lr * 10 + ch] = geo_value(a.xyz1 + bn * 3, a.xyz1 + cell * 3, mk, ch);
+        else if (ch < 10 + a.C) rest[lr * CT + (ch - 10)] = a.feat1[bn * a.C + (ch - 10)];
+        else rest[lr * CT + (ch - 10)] = a.cost[cell * a.Cc + (ch - 10 - a.C)] * mk;
+    }
+    __syncthreads();
+    stream_out(geo, a.xyz_cat, first, rows, 10);
+    stream_out(rest, a.rest, first, rows, CT);
 }
 
 // ------------------------------------------------------------ masked softmax-pool over K
+// Vectorised form (C % 4 == 0, 16-byte aligned rows): a quarter-wave (16 lanes x float4 = 64 channels) owns one
+// (b,n) point, so a wave streams 4 points' K x C logits and values with 16-byte loads -- every load instruction
+// of the wave covers four full 256-byte rows -- in ONE pass (online softmax), and writes 16 bytes per lane.
+__global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_vec_kernel(const elo_softmax_pool_args a, const long rows)
+{
+    const int lanes_per_row = a.C >> 2;                              // 16 for C = 64
+    const int rows_per_block = ELO_BLOCK / lanes_per_row;
+    const int sub = threadIdx.x % lanes_per_row;
+    const long r = (long)xcd_tile(blockIdx.x, gridDim.x) * rows_per_block + threadIdx.x / lanes_per_row;
+    if (r >= rows) return;
+    const float4 *lg = reinterpret_cast<const float4 *>(a.logits + r * a.K * a.C) + sub;
+    const float4 *vl = reinterpret_cast<const float4 *>(a.values + r * a.K * (long)a.values_stride) + sub;
+    const int lstep = a.C >> 2, vstep = a.values_stride >> 2;
+    const float *m = a.mask + r * a.K;
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, den[4] = {0, 0, 0, 0}, acc[4] = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < a.K; k0 += 4) {
+        float4 l4[4], v4[4];
+        float mk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                                // four neighbour rows in flight
+            const int k = k0 + u < a.K ? k0 + u : a.K - 1;
+            l4[u] = lg[(long)k * lstep];
+            v4[u] = vl[(long)k * vstep];
+            mk[u] = m[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + u >= a.K) break;
+            const float lv[4] = {l4[u].x, l4[u].y, l4[u].z, l4[u].w}, vv[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float l = mk[u] == 1.0f ? lv[c] : -1e10f;
+                if (l > mx[c]) {
+                    const float sc = expf(mx[c] - l);
+                    den[c] = den[c] * sc + 1.0f;
+                    acc[c] = acc[c] * sc + vv[c];
+                    mx[c] = l;
+                } else {
+                    const float e = expf(l - mx[c]);
+                    den[c] += e;
+                    acc[c] += e * vv[c];
+                }
+            }
+        }
+    }
+    reinterpret_cast<float4 *>(a.out + r * a.C)[sub] = float4{acc[0] / den[0], acc[1] / den[1], acc[2] / den[2], acc[3] / den[3]};
+}
+
+// scalar form for any C / alignment
 __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_kernel(const elo_softmax_pool_args a, const long rows)
 {
     const long r = row_of_wave(rows);                  // r = b*N + n
@@ -425,7 +539,8 @@ extern "C" int elo_group_concat(const elo_group_concat_args *a, elo_stream_t str
     ELO_REQUIRE(a->centre_xyz && a->src_xyz && (a->src_feat || a->C == 0) && a->idx && a->mask && a->out, who, "null tensor pointer");
     const long rows = (long)a->batch * a->npoints * a->K;
     if (rows == 0) return ELO_OK;
-    hipLaunchKernelGGL(group_concat_kernel, dim3(grid_for_rows(rows)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
+    hipLaunchKernelGGL(group_concat_kernel, dim3(grid_for_stage(rows)), dim3(ELO_BLOCK), sizeof(float) * (STAGE_ROWS * (3 + a->C) + 1) + STAGE_META_BYTES,
+                       (hipStream_t)stream, *a, rows);
     return check_launch(who);
 }
 
@@ -449,7 +564,8 @@ extern "C" int elo_cv_encode1(const elo_cv_encode1_args *a, elo_stream_t stream)
     ELO_REQUIRE(a->xyz1 && a->feat1 && a->xyz2 && a->feat2 && a->idx && a->mask && a->out, who, "null tensor pointer");
     const long rows = (long)a->batch * a->npoints * a->K;
     if (rows == 0) return ELO_OK;
-    hipLaunchKernelGGL(cv_encode1_kernel, dim3(grid_for_rows(rows)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
+    hipLaunchKernelGGL(cv_encode1_kernel, dim3(grid_for_stage(rows)), dim3(ELO_BLOCK), sizeof(float) * (STAGE_ROWS * (10 + 2 * a->C) + 1) + STAGE_META_BYTES,
+                       (hipStream_t)stream, *a, rows);
     return check_launch(who);
 }
 
@@ -462,7 +578,8 @@ extern "C" int elo_cv_encode2(const elo_cv_encode2_args *a, elo_stream_t stream)
     ELO_REQUIRE(a->xyz1 && a->feat1 && a->cost && a->idx && a->mask && a->xyz_cat && a->rest, who, "null tensor pointer");
     const long rows = (long)a->batch * a->npoints * a->K;
     if (rows == 0) return ELO_OK;
-    hipLaunchKernelGGL(cv_encode2_kernel, dim3(grid_for_rows(rows)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
+    hipLaunchKernelGGL(cv_encode2_kernel, dim3(grid_for_stage(rows)), dim3(ELO_BLOCK), sizeof(float) * (STAGE_ROWS * (10 + a->C + a->Cc) + 1) + STAGE_META_BYTES,
+                       (hipStream_t)stream, *a, rows);
     return check_launch(who);
 }
 
@@ -474,6 +591,14 @@ extern "C" int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_strea
     ELO_REQUIRE(a->logits && a->values && a->mask && a->out, who, "null tensor pointer");
     const long rows = (long)a->batch * a->npoints;
     if (rows == 0) return ELO_OK;
+    const bool vec = a->C % 4 == 0 && a->C <= 1024 && ELO_BLOCK % (a->C / 4) == 0 && a->values_stride % 4 == 0 &&
+                     ((uintptr_t)a->logits | (uintptr_t)a->values | (uintptr_t)a->out) % 16 == 0;
+    if (vec) {
+        const int rows_per_block = ELO_BLOCK / (a->C / 4);
+        hipLaunchKernelGGL(softmax_pool_vec_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(ELO_BLOCK),
+                           0, (hipStream_t)stream, *a, rows);
+        return check_launch(who);
+    }
     hipLaunchKernelGGL(softmax_pool_kernel, dim3(grid_for_rows(rows)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
     return check_launch(who);
 }
