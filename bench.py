@@ -63,6 +63,10 @@ def parse():
 
 # ----------------------------------------------------------------------------- roofline leg
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak (= the fp32 vector peak)
+# HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_v2/summary.json: FETCH_SIZE x2 +
+# WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); counters cannot be read from inside bench.py.
+# Only for the exact shapes captured (l0 = 16x225, i.e. 64x1800 inputs); otherwise null.
+PMC_TRAFFIC = {("cv1", 1): 3.72e6, ("cv1", 8): 13.87e6, ("pool", 8): 96.94e6, ("pool", 64): 773.96e6}
 
 
 def cost_volume_bytes(N, C, Kq, Kp, s=4):
@@ -103,6 +107,8 @@ def roofline_leg(args, dev, net, reps=200):
     oh, ow = pm.pyramid_sizes(args.height, args.width)
     B, H, W, C, Kq = args.batch, oh[2], ow[2], 16, 6
     N = H * W
+    if (args.height, args.width) != (64, 1800):
+        PMC_TRAFFIC.clear()
     g = torch.Generator(device="cpu").manual_seed(0)
     synth = pkg("synth")
     f1, f2 = synth.frame_pair(B, H, W, seed=5)
@@ -121,20 +127,24 @@ def roofline_leg(args, dev, net, reps=200):
     flops = cv1_flops(N, C, Kq) * B
     cvb = cost_volume_bytes(N, C, Kq, 4)
     tfs = flops / sec / 1e12
-    logits = torch.randn((B, N, Kq, 64), generator=g).to(dev)
-    values = torch.randn((B, N, Kq, 64), generator=g).to(dev)
-    mask = (torch.rand((B, N, Kq), generator=g) > 0.1).float().to(dev)
-    sec_p1 = _time_launches(lambda: ops.masked_softmax_pool(logits, values, mask), dev, reps)
+    def pool_leg(batch):
+        logits = torch.randn((batch, N, Kq, 64), generator=g).to(dev)
+        values = torch.randn((batch, N, Kq, 64), generator=g).to(dev)
+        mask = (torch.rand((batch, N, Kq), generator=g) > 0.1).float().to(dev)
+        sec_p1 = _time_launches(lambda: ops.masked_softmax_pool(logits, values, mask), dev, reps)
+        gbs = cvb["P1"] * batch / sec_p1 / 1e9
+        return {"kernel": "softmax_pool_vec_kernel (P1 term of the ELO_FUSED=0 path)", "batch": batch, "bound": "hbm",
+                "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                "bytes_per_launch": int(cvb["P1"] * batch), "us_per_launch": round(sec_p1 * 1e6, 3),
+                "traffic": PMC_TRAFFIC.get(("pool", batch))}
+
     return {"bound": "mfma", "kernel": "cv1_kernel (fused cost volume stage 1, l0: %dx%d, K=%d, batch %d)" % (H, W, Kq, B),
             "achieved": round(tfs, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tfs / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
+            "frac": round(tfs / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": PMC_TRAFFIC.get(("cv1", B)),
             "flops_per_launch": int(flops), "us_per_launch": round(sec * 1e6, 3),
             "algorithmic_bytes_per_launch": int((cvb["A1"] + cvb["P1"]) * B),
             "hbm_equivalent_GBps": round((cvb["A1"] + cvb["P1"]) * B / sec / 1e9, 2),
-            "per_operator": {"kernel": "softmax_pool_kernel (P1 term, ELO_FUSED=0 path)", "bound": "hbm",
-                             "achieved": round(cvb["P1"] * B / sec_p1 / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(cvb["P1"] * B / sec_p1 / 1e9 / HBM_PEAK_GBS, 5),
-                             "us_per_launch": round(sec_p1 * 1e6, 3)}}
+            "per_operator": pool_leg(B), "per_operator_b8": pool_leg(8)}
 
 
 # ----------------------------------------------------------------------------- CPU baseline leg
