@@ -12,9 +12,9 @@ A "step" is one forward pass over one batch of pairs already resident in HBM
 graph's input buffers, device-to-device, inside the timed region).
 
 One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE); frame pairs are
-independent, so ranks shard the stream with no data-path collective; the poses of a
-step are all-gathered (7 floats per pair) once per step so rank 0 can chain them
-(main.py:557-572), which is the only exchange the path has.  scaling = weak.
+independent, so ranks shard the stream with no data-path collective; every step's pose is
+logged on the device and the logs are all-gathered (7 floats per pair) once, inside the timed
+region, so rank 0 can chain them (main.py:557-572): the only exchange the path has.  scaling = weak.
 
 Throughput design: the whole forward is one hipGraph; `--lanes` graphs (default 12), each with its own
 stream and static buffers, keep that many independent forwards in flight (step i rides lane i % lanes).
@@ -180,13 +180,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)     # nccl == RCCL on ROCm
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # nccl == RCCL on ROCm
 
     model, synth = pkg("model"), pkg("synth")
     net = model.PWCLONet(dev, seed=0)
@@ -200,7 +200,11 @@ def main():
         net.forward(*pool[0])
     else:
         net.capture(B, H, W, lanes=lanes)
-    gathered = [torch.empty((B, 7), device=dev) for _ in range(world)] if world > 1 else None
+    # every step's l0 pose [q | t] is kept (a lane's static outputs are overwritten `lanes` steps later): one (B,7)
+    # row block per step in HBM; with N > 1 ranks the blocks are all-gathered ONCE, inside the timed region
+    # (7 floats per pair: the only exchange of the inference path, main.py:557-572)
+    pose_log = torch.empty((max(args.steps, args.warmup), B, 7), device=dev)
+    gathered = [torch.empty_like(pose_log[:args.steps]) for _ in range(world)] if world > 1 else None
 
     def step(i):
         a, b = pool[i % len(pool)]
@@ -208,9 +212,9 @@ def main():
             out, stream = net.forward(a, b), torch.cuda.current_stream(dev)
         else:                                        # step i rides lane i % lanes; lanes overlap on the GPU
             out, stream = net.submit(i % lanes, a, b), net.lane_stream(i % lanes)
-        if world > 1:                                # poses of this step to every rank (7 floats per pair)
-            with torch.cuda.stream(stream):
-                dist.all_gather(gathered, torch.cat([out[0], out[1]], -1))
+        with torch.cuda.stream(stream):
+            pose_log[i, :, :4].copy_(out[0], non_blocking=True)
+            pose_log[i, :, 4:].copy_(out[1], non_blocking=True)
         return out
 
     for i in range(args.warmup):
@@ -224,9 +228,11 @@ def main():
         out = step(i)
     torch.cuda.synchronize(dev)
     if world > 1:
+        dist.all_gather(gathered, pose_log[:args.steps].contiguous())
+        torch.cuda.synchronize(dev)
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all()
+    assert torch.isfinite(pose_log[:args.steps]).all()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
