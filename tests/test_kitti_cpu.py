@@ -1,0 +1,70 @@
+"""CPU: KITTI I/O + metrics against the reference's own data
+(tests/golden/kitti_seq04_gt.npz = ground_truth_pose/04.txt and kitti_T_diff/04_diff.npy) and closed-form cases."""
+import os
+
+import numpy as np
+
+from conftest import GOLDEN, load_pkg
+
+
+def _seq04():
+    d = np.load(os.path.join(GOLDEN, "kitti_seq04_gt.npz"))
+    return d["poses"], d["diff"]
+
+
+def test_relative_transforms_match_the_reference_files():
+    K, D = load_pkg("kitti"), load_pkg("distributed")
+    poses, diff = _seq04()
+    mine = K.relative_from_absolute(poses)
+    assert mine.shape == diff.shape == (271, 12)
+    assert np.allclose(mine, diff, atol=2e-5)                 # the .txt holds 7 significant digits
+    # chaining the relative transforms (as main.py:557-572 chains network outputs) reproduces the trajectory
+    T = np.eye(4)
+    for i in range(1, 271):
+        T = T @ K.to_4x4(diff[i])
+        assert np.allclose(T[:3].reshape(12), poses[i], atol=5e-3)
+
+
+def test_metrics_closed_form_cases():
+    K = load_pkg("kitti")
+    poses, _ = _seq04()
+    t_rel, r_rel = K.overall(K.sequence_errors(poses, poses))
+    assert abs(t_rel) < 1e-9 and abs(r_rel) < 1e-4            # identical trajectories
+    # a 2 % scale error on every translation -> t_rel = 2 %, no rotation error
+    scaled = poses.copy()
+    scaled[:, [3, 7, 11]] *= 1.02
+    t_rel, r_rel = K.overall(K.sequence_errors(poses, scaled))
+    assert abs(t_rel - 2.0) < 0.05 and r_rel < 1e-3
+    # straight 1 m/frame drive; prediction yaws an extra 0.001 rad per frame -> r_rel = 0.1 rad / 100 m
+    n = 900
+    gt = np.tile(np.eye(4)[:3].reshape(12), (n, 1))
+    gt[:, 11] = np.arange(n)
+    pred = gt.copy()
+    for i in range(n):
+        a = 0.001 * i
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        pred[i, [0, 1, 2, 4, 5, 6, 8, 9, 10]] = R.reshape(9)
+    _, r_rel = K.overall(K.sequence_errors(gt, pred))
+    # a segment of length L (first frame strictly beyond L metres -> L+1 frames) accumulates 0.001*(L+1) rad
+    expect = np.mean([(L + 1) * 0.001 / L for L in K.SEGMENT_LENGTHS]) / np.pi * 180 * 100
+    assert abs(r_rel - expect) / expect < 0.02
+
+
+def test_io_round_trip(tmp_path):
+    K = load_pkg("kitti")
+    seq = tmp_path / "04"
+    (seq / "velodyne").mkdir(parents=True)
+    (seq / "calib.txt").write_text("P0: 1 0 0 0 0 1 0 0 0 0 1 0\nTr: 0 -1 0 0.1 0 0 -1 0.2 1 0 0 0.3\n")
+    rng = np.random.default_rng(0)
+    for i in range(2):
+        rng.normal(0, 10, (1000 + i, 4)).astype(np.float32).tofile(seq / "velodyne" / ("%06d.bin" % i))
+    _, diff = _seq04()
+    pos2, pos1, n2, n1, T_gt = K.load_pair(str(tmp_path), "04", 1, diff, num_points=1500)
+    assert pos1.shape == pos2.shape == (1500, 3) and (n1, n2) == (1000, 1001)
+    assert not pos1[1000:].any() and pos1[:1000].any()
+    Tr = K.to_4x4(K.read_calib(str(seq / "calib.txt"))["Tr"])
+    assert np.allclose(T_gt, np.linalg.inv(Tr) @ K.to_4x4(diff[1]) @ Tr)
+    _, same1, _, _, _ = K.load_pair(str(tmp_path), "04", 0, diff, num_points=1500)      # frame 0 pairs with itself
+    out = tmp_path / "04_pred.txt"
+    K.write_pred_txt(str(out), diff[:5])
+    assert np.allclose(np.loadtxt(out), diff[:5], atol=1e-8)
