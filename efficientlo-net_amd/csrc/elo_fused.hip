@@ -18,6 +18,7 @@
 //
 // Interfaces and the reference lines covered: include/elo.h ("Fused inference kernels").
 #include "elo_group_device.h"
+#include <cstdlib>
 
 namespace elo {
 namespace {
@@ -588,7 +589,12 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv2_kernel(const elo_cv2_args a, 
 
 // A 16-row tile halves the serial work per workgroup and doubles their number: take it whenever the
 // K rows of a point fit and 32-row tiles would leave most of the 256 CUs without a workgroup.
-inline bool small_tile(long units_at_32, int K) { return K <= 16 && units_at_32 < 1024; }
+inline long small_tile_threshold()
+{
+    static const long t = [] { const char *e = getenv("ELO_SMALL_TILE_UNITS"); return e ? atol(e) : 512L; }();
+    return t;
+}
+inline bool small_tile(long units_at_32, int K) { return K <= 16 && units_at_32 < small_tile_threshold(); }
 
 int check_dense(const elo_dense &L, int K, int N, const char *who, const char *name)
 {
