@@ -138,6 +138,120 @@ __device__ __forceinline__ void dense(float *act, int S, int in_off, int out_off
     else dense_t<TILE, 4>(act, S, in_off, out_off, L);
 }
 
+// ---- the same layer with compile-time widths and a cross-layer prefetch (cost-volume kernels) -------------
+// The cost-volume chains have fixed widths (128/64), so the number of sub-tiles per wave is a compile-time
+// constant and the FIRST weight group + bias of the next layer can be fetched into registers while this layer's
+// epilogue (two barriers + the D write) runs: a layer no longer starts with an exposed L2 round trip.
+template <int TILE, int N>
+struct Sub {                                          // sub-tiles per wave, K steps per prefetch group
+    static constexpr int CSTEP = FUSED_WAVES / (TILE / 16);
+    static constexpr int MAXT = ((N + 15) / 16 + CSTEP - 1) / CSTEP;
+    static constexpr int GS = MAXT >= 4 ? 2 : 4;
+};
+
+template <int TILE, int N>
+struct Pre {
+    float4 w[Sub<TILE, N>::GS][Sub<TILE, N>::MAXT];
+    float b[Sub<TILE, N>::MAXT];
+};
+
+template <int TILE, int N>
+__device__ __forceinline__ void prefetch(const elo_dense &L, Pre<TILE, N> &pre)
+{
+    constexpr int RB = TILE / 16, CSTEP = Sub<TILE, N>::CSTEP, MAXT = Sub<TILE, N>::MAXT, GS = Sub<TILE, N>::GS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, cb0 = wave / RB;
+    const int KS = ceil16(L.K) >> 4;
+    constexpr int CB = (N + 15) / 16;
+    const float4 *w = reinterpret_cast<const float4 *>(L.w_packed) + lane;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int cb = cb0 + t * CSTEP;
+        pre.b[t] = cb < CB ? L.bias[cb * 16 + i16] : 0.0f;
+#pragma unroll
+        for (int s = 0; s < GS; ++s)
+            pre.w[s][t] = (s < KS && cb < CB) ? w[(size_t)(cb * KS + s) * 64] : float4{0, 0, 0, 0};
+    }
+}
+
+// layer with width N; NEXT = width of the following layer (0 = none)
+template <int TILE, int N, int NEXT>
+__device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_off, const elo_dense &L,
+                                         const Pre<TILE, N> &pre, const elo_dense *next, Pre<TILE, NEXT ? NEXT : 16> *next_pre)
+{
+    constexpr int RB = TILE / 16, CSTEP = Sub<TILE, N>::CSTEP, MAXT = Sub<TILE, N>::MAXT, GS = Sub<TILE, N>::GS;
+    constexpr int CB = (N + 15) / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int rb = wave % RB, cb0 = wave / RB;
+    const int KS = ceil16(L.K) >> 4;
+    const int NG = (KS + GS - 1) / GS;
+    f32x4 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = f32x4{pre.b[t], pre.b[t], pre.b[t], pre.b[t]};
+    const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
+    const float4 *w = reinterpret_cast<const float4 *>(L.w_packed) + lane;
+    auto fetch = [&](int g, float4 (&buf)[GS][MAXT]) {
+#pragma unroll
+        for (int s = 0; s < GS; ++s) {
+            const int ks = g * GS + s;
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const int cb = cb0 + t * CSTEP;
+                buf[s][t] = (ks < KS && cb < CB) ? w[(size_t)(cb * KS + ks) * 64] : float4{0, 0, 0, 0};
+            }
+        }
+    };
+    auto compute = [&](int g, const float4 (&buf)[GS][MAXT]) {
+        float4 a[GS];
+#pragma unroll
+        for (int s = 0; s < GS; ++s) {
+            const int ks = g * GS + s;
+            a[s] = ks < KS ? *reinterpret_cast<const float4 *>(arow + ks * 16) : float4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int s = 0; s < GS; ++s) {
+            if (g * GS + s >= KS) break;
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].x, buf[s][t].x, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].y, buf[s][t].y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].z, buf[s][t].z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].w, buf[s][t].w, acc[t], 0, 0, 0);
+        }
+    };
+    float4 b0[GS][MAXT], b1[GS][MAXT];
+#pragma unroll
+    for (int s = 0; s < GS; ++s)
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) b0[s][t] = pre.w[s][t];                // group 0 arrived ahead of time
+    for (int g = 0; g < NG; g += 2) {
+        if (g + 1 < NG) fetch(g + 1, b1);
+        compute(g, b0);
+        if (g + 1 < NG) {
+            if (g + 2 < NG) fetch(g + 2, b0);
+            compute(g + 1, b1);
+        }
+    }
+    if (NEXT) prefetch<TILE, NEXT ? NEXT : 16>(*next, *next_pre);              // rides behind the two barriers
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int cb = cb0 + t * CSTEP;
+        if (cb < CB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[t][r];
+                if (L.relu) v = fmaxf(v, 0.0f);
+                act[(rb * 16 + kq * 4 + r) * S + out_off + cb * 16 + i16] = v;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // ---- per-row gather metadata of a tile -------------------------------------------------------
 struct TileMeta {
     int *cell;      // [32] flat (b*H2 + h)*W2 + w of the gathered pixel, -1 = row not in use
@@ -530,13 +644,16 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv1_kernel(const elo_cv1_args a, 
         }
         act[row * S + F + ch] = v;
     }
+    Pre<TILE, 128> p128;
+    Pre<TILE, 64> p64;
+    prefetch<TILE, 128>(a.cv0, p128);           // in flight while the barrier drains the gather
     __syncthreads();
-    dense<TILE>(act, S, F, 0, a.cv0);           // feat_cat -> 128                     :72-76
-    dense<TILE>(act, S, 0, 0, a.cv1);           // -> 64 (in place)
-    dense<TILE>(act, S, 0, 0, a.cv2);           // -> 64 = x                            (values of the pooling)
-    dense<TILE>(act, S, F, 64, a.cv_xyz);       // xyz_cat (first 10 columns of F) -> enc at [64,128)   :79-82
-    dense<TILE>(act, S, 0, F, a.sum_cv0);       // [x | enc] -> 128 into F              :84-90
-    dense<TILE>(act, S, F, F, a.sum_cv1);       // -> 64 logits (in place)
+    dense_pf<TILE, 128, 64>(act, S, F, 0, a.cv0, p128, &a.cv1, &p64);          // feat_cat -> 128          :72-76
+    dense_pf<TILE, 64, 64>(act, S, 0, 0, a.cv1, p64, &a.cv2, &p64);            // -> 64 (in place)
+    dense_pf<TILE, 64, 64>(act, S, 0, 0, a.cv2, p64, &a.cv_xyz, &p64);         // -> 64 = x   (values of the pooling)
+    dense_pf<TILE, 64, 128>(act, S, F, 64, a.cv_xyz, p64, &a.sum_cv0, &p128);  // xyz_cat -> enc at [64,128)   :79-82
+    dense_pf<TILE, 128, 64>(act, S, 0, F, a.sum_cv0, p128, &a.sum_cv1, &p64);  // [x | enc] -> 128 into F      :84-90
+    dense_pf<TILE, 64, 0>(act, S, F, F, a.sum_cv1, p64, nullptr, nullptr);     // -> 64 logits (in place)
     pool_masked_softmax(act, S, F, 0, meta, P, K, first_point, total_points, a.out);    // :92-98
 }
 
@@ -580,10 +697,13 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv2_kernel(const elo_cv2_args a, 
         act[row * S + XYZ + ch] = (cell >= 0 && ch < 10)
             ? geo_channel(a.xyz1 + pt * 3, a.xyz1 + (long)cell * 3, meta.mask[row], ch) : 0.0f;
     }
+    Pre<TILE, 128> p128;
+    Pre<TILE, 64> p64;
+    prefetch<TILE, 64>(a.xyz_enc, p64);
     __syncthreads();
-    dense<TILE>(act, S, XYZ, 64, a.xyz_enc);     // -> enc at [64,128)                  :123-126
-    dense<TILE>(act, S, 0, 64, a.sum_cost0);     // [grouped | enc | feat1] -> 128 at [64,192)   :129-135
-    dense<TILE>(act, S, 64, 64, a.sum_cost1);    // -> 64 logits at [64,128)
+    dense_pf<TILE, 64, 128>(act, S, XYZ, 64, a.xyz_enc, p64, &a.sum_cost0, &p128);   // -> enc at [64,128)       :123-126
+    dense_pf<TILE, 128, 64>(act, S, 0, 64, a.sum_cost0, p128, &a.sum_cost1, &p64);   // [grouped | enc | feat1] -> [64,192)   :129-135
+    dense_pf<TILE, 64, 0>(act, S, 64, 64, a.sum_cost1, p64, nullptr, nullptr);       // -> 64 logits at [64,128)
     pool_masked_softmax(act, S, 64, 0, meta, P, K, first_point, total_points, a.out);   // :137-146
 }
 
