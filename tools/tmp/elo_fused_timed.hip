@@ -17,11 +17,13 @@
 // final activations column-wise from LDS and write (b,n,C) rows coalesced.
 //
 // Interfaces and the reference lines covered: include/elo.h ("Fused inference kernels").
-#include "elo_group_device.h"
+#include "../../efficientlo-net_amd/csrc/elo_group_device.h"
 #include <cstdlib>
 
 namespace elo {
+__device__ long long g_phase[16 * 64];
 namespace {
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 64) g_phase[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -622,6 +624,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv1_kernel(const elo_cv1_args a, 
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     if (first_point >= total_points) return;
+    STAMP(0);
     if (a.group.random_hw) {                          // select-k of frame 2 around every warped frame-1 pixel (:49-51)
         int *lds_off = reinterpret_cast<int *>(meta.cxyz + 96);
         unsigned *scratch = reinterpret_cast<unsigned *>(lds_off + a.group.kernel_h * a.group.kernel_w);
@@ -631,6 +634,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv1_kernel(const elo_cv1_args a, 
         load_meta<TILE>(meta, first_point, total_points, P, K, a.idx, a.mask, a.H2, a.W2);
         __syncthreads();
     }
+    STAMP(1);
     const int F = 128, CT = 10 + 2 * C, CTp = ceil16(CT);
     for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {                             // :54-66
         const int row = e / CTp, ch = e - row * CTp;
@@ -649,13 +653,21 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv1_kernel(const elo_cv1_args a, 
     Pre<TILE, 64> p64;
     prefetch<TILE, 128>(a.cv0, p128);           // in flight while the barrier drains the gather
     __syncthreads();
+    STAMP(2);
     dense_pf<TILE, 128, 64>(act, S, F, 0, a.cv0, p128, &a.cv1, &p64);          // feat_cat -> 128          :72-76
+    STAMP(3);
     dense_pf<TILE, 64, 64>(act, S, 0, 0, a.cv1, p64, &a.cv2, &p64);            // -> 64 (in place)
+    STAMP(4);
     dense_pf<TILE, 64, 64>(act, S, 0, 0, a.cv2, p64, &a.cv_xyz, &p64);         // -> 64 = x   (values of the pooling)
+    STAMP(5);
     dense_pf<TILE, 64, 128>(act, S, F, 64, a.cv_xyz, p64, &a.sum_cv0, &p128);  // xyz_cat -> enc at [64,128)   :79-82
+    STAMP(6);
     dense_pf<TILE, 128, 64>(act, S, 0, F, a.sum_cv0, p128, &a.sum_cv1, &p64);  // [x | enc] -> 128 into F      :84-90
+    STAMP(7);
     dense_pf<TILE, 64, 0>(act, S, F, F, a.sum_cv1, p64, nullptr, nullptr);     // -> 64 logits (in place)
+    STAMP(8);
     pool_masked_softmax(act, S, F, 0, meta, P, K, first_point, total_points, a.out);    // :92-98
+    STAMP(9);
 }
 
 // ================================================================ cost volume, stage 2
@@ -946,4 +958,9 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
     return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv2_kernel<32>, cv2_kernel<16>,
                        &a->group, a->H, a->W, false);
+}
+
+extern "C" int elo_debug_phases(long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(elo::g_phase), sizeof(long long) * 16 * 64) == hipSuccess ? 0 : -1;
 }
