@@ -354,6 +354,8 @@ __device__ __forceinline__ float geo_channel(const float *p, const float *g, flo
 }
 
 // ---- poolings over the K rows of each point of the tile (one (point, channel) per thread) ------
+// The K rows of a point are fetched in chunks of 8 INDEPENDENT LDS reads (a serial "read mask -> branch -> read
+// value" chain cost ~0.3 us per neighbour, 7 us per cost-volume tile).
 __device__ __forceinline__ void pool_masked_max(const float *act, int S, int off, int C, const TileMeta &m, int P, int K,
                                                 long first_point, long total_points, float *__restrict__ out)
 {
@@ -361,13 +363,25 @@ __device__ __forceinline__ void pool_masked_max(const float *act, int S, int off
         const int pi = q / C, c = q - pi * C;
         const long pt = first_point + pi;
         if (pt >= total_points) continue;
-        float best = act[(pi * K) * S + off + c] * m.mask[pi * K];
-        for (int k = 1; k < K; ++k) best = fmaxf(best, act[(pi * K + k) * S + off + c] * m.mask[pi * K + k]);
+        const float *col = act + (pi * K) * S + off + c;
+        const float *mk = m.mask + pi * K;
+        float best = -INFINITY;
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            float v[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = min(k0 + u, K - 1);          // clamped duplicates do not change a maximum
+                v[u] = col[k * S];
+                w[u] = mk[k];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) best = fmaxf(best, v[u] * w[u]);
+        }
         out[pt * C + c] = best;
     }
 }
 
-// out = sum_k softmax_k(mask == 1 ? logit : -1e10) * value      (64 channels)
+// out = sum_k softmax_k(mask == 1 ? logit : -1e10) * value      (64 channels), one pass (online softmax)
 __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int logit_off, int value_off,
                                                     const TileMeta &m, int P, int K, long first_point,
                                                     long total_points, float *__restrict__ out)
@@ -376,17 +390,33 @@ __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int
         const int pi = q >> 6, c = q & 63;
         const long pt = first_point + pi;
         if (pt >= total_points) continue;
-        float mx = -INFINITY;
-        for (int k = 0; k < K; ++k) {
-            const float l = m.mask[pi * K + k] == 1.0f ? act[(pi * K + k) * S + logit_off + c] : -1e10f;
-            mx = fmaxf(mx, l);
-        }
-        float den = 0.0f, acc = 0.0f;
-        for (int k = 0; k < K; ++k) {
-            const float l = m.mask[pi * K + k] == 1.0f ? act[(pi * K + k) * S + logit_off + c] : -1e10f;
-            const float e = expf(l - mx);
-            den += e;
-            acc += e * act[(pi * K + k) * S + value_off + c];
+        const float *lcol = act + (pi * K) * S + logit_off + c, *vcol = act + (pi * K) * S + value_off + c;
+        const float *mk = m.mask + pi * K;
+        float mx = -INFINITY, den = 0.0f, acc = 0.0f;
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            float l[8], v[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = min(k0 + u, K - 1);
+                l[u] = lcol[k * S];
+                v[u] = vcol[k * S];
+                w[u] = mk[k];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k0 + u >= K) break;
+                const float x = w[u] == 1.0f ? l[u] : -1e10f;
+                if (x > mx) {
+                    const float sc = expf(mx - x);
+                    den = den * sc + 1.0f;
+                    acc = acc * sc + v[u];
+                    mx = x;
+                } else {
+                    const float e = expf(x - mx);
+                    den += e;
+                    acc += e * v[u];
+                }
+            }
         }
         out[pt * 64 + c] = acc / den;
     }

@@ -383,6 +383,7 @@ __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int
             const float l = m.mask[pi * K + k] == 1.0f ? act[(pi * K + k) * S + logit_off + c] : -1e10f;
             mx = fmaxf(mx, l);
         }
+        if (q == 0) STAMP(10);
         float den = 0.0f, acc = 0.0f;
         for (int k = 0; k < K; ++k) {
             const float l = m.mask[pi * K + k] == 1.0f ? act[(pi * K + k) * S + logit_off + c] : -1e10f;
@@ -390,7 +391,9 @@ __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int
             den += e;
             acc += e * act[(pi * K + k) * S + value_off + c];
         }
+        if (q == 0) STAMP(11);
         out[pt * 64 + c] = acc / den;
+        if (q == 0) STAMP(12);
     }
 }
 

@@ -18,3 +18,5 @@ print("median phase durations over 64 blocks (us):")
 for i, n in enumerate(names[:9]):
     print("  %-8s -> %-8s %6.2f" % (n, names[i + 1] if i + 1 < len(names) else "", np.median(d[:, i]) / 100.0))
 print("  total %.2f" % (np.median(t[:, 9] - t[:, 0]) / 100.0))
+T = np.array(buf).reshape(64, 16)
+print("pool detail: start->max %.2f, max->exp %.2f, exp->store %.2f, store->end %.2f" % tuple(np.median(x)/100.0 for x in (T[:,10]-T[:,8], T[:,11]-T[:,10], T[:,12]-T[:,11], T[:,9]-T[:,12])))
