@@ -756,10 +756,11 @@ int check_dense(const elo_dense &L, int K, int N, const char *who, const char *n
     return ELO_OK;
 }
 
-size_t tile_lds_bytes(int rows, int S, int KT = 0, bool select = false)
+size_t tile_lds_bytes(int rows, int S, int KT = 0, bool select = false, int K = 0)
 {
-    // select-k keeps windows of <= 512 slots in registers (elo_group_device.h): LDS scratch only beyond that
-    return sizeof(float) * ((size_t)rows * S + 64 + 96 + KT + (select && KT > 512 ? (size_t)FUSED_WAVES * 2 * KT : 0));
+    // select-k keeps small-K windows in registers (elo_group_device.h): LDS scratch only for the LDS form
+    const bool scratch = select && !select_in_registers(KT, K);
+    return sizeof(float) * ((size_t)rows * S + 64 + 96 + KT + (scratch ? (size_t)FUSED_WAVES * 2 * KT : 0));
 }
 
 // in-kernel grouping: validate the spec the way elo_fused_conv_*_k validates its attributes
@@ -788,10 +789,11 @@ static inline int pad16(int x) { return (x + 15) & ~15; }
 
 template <typename Args, typename K32, typename K16>
 static int launch_tile(const char *who, bool tile16, long units16, long units32, int S, hipStream_t s, const Args &a,
-                       K32 k32, K16 k16, const elo_group_spec *g = nullptr, int H2 = 0, int W2 = 0, bool select = false)
+                       K32 k32, K16 k16, const elo_group_spec *g = nullptr, int H2 = 0, int W2 = 0, bool select = false,
+                       int K = 0)
 {
     const int KT = (g && g->random_hw) ? g->kernel_h * g->kernel_w : 0;
-    const size_t lds = tile_lds_bytes(tile16 ? 16 : 32, S, KT, select);
+    const size_t lds = tile_lds_bytes(tile16 ? 16 : 32, S, KT, select, K);
     if (g) if (int rc = check_group(*g, H2, W2, lds, who)) return rc;
     if (tile16)
         hipLaunchKernelGGL(k16, dim3((unsigned)units16), dim3(FUSED_BLOCK), lds, s, a, S);
@@ -953,7 +955,7 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
     return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv1_kernel<32>, cv1_kernel<16>,
-                       &a->group, a->H2, a->W2, true);
+                       &a->group, a->H2, a->W2, true, a->K);
 }
 
 extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)

@@ -104,8 +104,12 @@ __device__ __forceinline__ Probe judge(const RawSlot &r, float cx, float cy, flo
     return p;
 }
 
+// Measured at 64x1800 (tools/grouping_micro.py): with K = 6 the register form wins (11x41: 158 vs ~190 us); with
+// K = 32 every round pays 8 register compares + 3 lane broadcasts and the LDS form wins (5x35: 379 vs 439 us).
+__host__ __device__ __forceinline__ bool select_in_registers(int KT, int K) { return KT <= 512 && K <= 8; }
+
 // K nearest in-range neighbours, reference tie order (selection sort with swaps).
-// Windows up to 512 slots (every call of the model) keep the whole (distance, hw) array in REGISTERS --
+// Windows up to 512 slots with K <= 8 (the three refinement cost volumes) keep the whole (distance, hw) array in REGISTERS --
 // position j*64 + lane lives in register j of that lane -- and run the K rounds with DPP reductions and three
 // lane broadcasts per round; larger windows use the LDS arrays dist/pay ([KT] wave-private each).
 template <class Emit>
@@ -116,7 +120,7 @@ __device__ __forceinline__ int wave_select_k(const float *__restrict__ grid2, in
     const int lane = threadIdx.x & 63;
     const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
     const int rounds = K < KT ? K : KT;
-    if (KT <= 512 && K <= 64) {
+    if (select_in_registers(KT, K)) {
         constexpr int J = 8;
         unsigned d[J];
         int pw[J];

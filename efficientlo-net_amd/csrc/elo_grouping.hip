@@ -136,6 +136,20 @@ __global__ __launch_bounds__(ELO_BLOCK) void group_select_k(const elo_group_args
     float *o_mask = a.selected_mask + u * K;
     const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
 
+    if (c.ok && a.flag_copy == 0 && !a.valid_idx && !a.valid_in_dis_idx && select_in_registers(KT, K)) {
+        // the model's call shape (flag_copy 0, prefix masks not requested): the register-resident wave form shared with
+        // the fused kernels (elo_group_device.h) -- no LDS scans, probes batched four-deep
+        const int count = wave_select_k(grid2, a.H2, a.W2, KT, K, lds_off, c.base_h, c.base_w, c.x, c.y, c.z, r2, dist, pay,
+                                        [&](int slot, int hw) {
+                                            o_sel[slot * 3 + 0] = c.b; o_sel[slot * 3 + 1] = hw >> 16; o_sel[slot * 3 + 2] = hw & 0xffff;
+                                            o_mask[slot] = 1.0f;
+                                        });
+        for (int k = count + lane; k < K; k += ELO_WAVE) {
+            o_sel[k * 3 + 0] = 0; o_sel[k * 3 + 1] = 0; o_sel[k * 3 + 2] = 0;
+            o_mask[k] = 0.0f;
+        }
+        return;
+    }
     int taken = 0, seen = 0;
     if (c.ok) {
         // pass 1: slot position == visiting order (:84,:110,:123,:138)
