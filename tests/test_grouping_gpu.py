@@ -96,6 +96,20 @@ def test_edge_cases():
         assert got[1] is None and got[2] is None and np.array_equal(got[0], want[0] if fc == 0 else got[0])
 
 
+def test_torch_ops_dispatch_to_the_hip_kernels():
+    load_pkg("torch_ops")
+    rng = np.random.default_rng(2)
+    x = rng.normal(0, 2, (1, 6, 20, 3)).astype(np.float32)
+    idx = np.stack([rng.integers(0, 6, (1, 9)), rng.integers(0, 20, (1, 9))], -1).astype(np.int32)
+    perm = rng.permutation(15).astype(np.int32)
+    t = lambda a: torch.from_numpy(a).to("cuda:0")
+    for name, ofn in (("fused_conv_random_k", G.fused_conv_random_k), ("fused_conv_select_k", G.fused_conv_select_k)):
+        got = getattr(torch.ops.elo, name)(t(x), t(x), t(idx), t(perm), 6, 20, 9, 3, 5, 4, 0, 2.0, 1, 1)
+        want = ofn(x, x, idx, perm, 6, 20, 9, 3, 5, 4, 0, 2.0, 1, 1)
+        for g, w_ in zip(got, want):
+            assert np.array_equal(g.cpu().numpy(), w_)
+
+
 def test_error_behaviour():
     elo = load_pkg()
     dev = "cuda:0"

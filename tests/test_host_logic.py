@@ -111,3 +111,24 @@ def test_perm_source_fixed_and_reshuffle():
     assert a.data_ptr() == ptr and sorted(a.tolist()) == list(range(45)) and not torch.equal(a, before)
     hooked = perm.PermSource(fn=lambda scope, tag, KT: np.arange(KT)[::-1])
     assert hooked.get("x", "y", 5, "cpu").tolist() == [4, 3, 2, 1, 0]
+
+
+def test_torch_library_registration_schema_and_shape_function():
+    """torch.ops.elo.fused_conv_{random,select}_k: same attributes/inputs/outputs as the TF REGISTER_OP
+    (fused_conv.cpp:15-63); GPU-only like REGISTER_KERNEL_BUILDER(DEVICE_GPU) (:176)."""
+    load_pkg("torch_ops")
+    for name in ("fused_conv_random_k", "fused_conv_select_k"):
+        op = getattr(torch.ops.elo, name)
+        schema = str(op.default._schema)
+        for arg in ("xyz1", "xyz2", "idx_n2", "random_hw", "int H", "int W", "int npoints", "int kernel_size_H",
+                    "int kernel_size_W", "int K", "int flag_copy", "float distance", "int stride_h", "int stride_w"):
+            assert arg in schema, (name, arg)
+        x = torch.zeros(2, 4, 8, 3, device="meta")
+        idx = torch.zeros(2, 5, 2, dtype=torch.int32, device="meta")
+        perm = torch.zeros(15, dtype=torch.int32, device="meta")
+        out = op(x, x, idx, perm, 4, 8, 5, 3, 5, 6, 0, 1.0, 1, 1)
+        assert [tuple(t.shape) for t in out] == [(2, 5, 6, 3), (2, 5, 15, 1), (2, 5, 15, 1), (2, 5, 6, 1)]
+        assert out[0].dtype == torch.int32 and out[3].dtype == torch.float32
+        with pytest.raises(NotImplementedError):
+            op(torch.zeros(1, 4, 8, 3), torch.zeros(1, 4, 8, 3), torch.zeros(1, 2, 2, dtype=torch.int32),
+               torch.zeros(15, dtype=torch.int32), 4, 8, 2, 3, 5, 4, 0, 1.0, 1, 1)
