@@ -16,8 +16,9 @@ independent, so ranks shard the stream with no data-path collective; every step'
 logged on the device and the logs are all-gathered (7 floats per pair) once, inside the timed
 region, so rank 0 can chain them (main.py:557-572): the only exchange the path has.  scaling = weak.
 
-Throughput design: the whole forward is one hipGraph; `--lanes` graphs (default 12), each with its own
-stream and static buffers, keep that many independent forwards in flight (step i rides lane i % lanes).
+Throughput design: the whole forward is one hipGraph; `--lanes` graphs (default 8), each with its own static
+buffers, dealt over one stream per hardware queue (model.distinct_queue_streams), keep independent forwards
+in flight (step i rides lane i % lanes).
 
 Besides the contract line this prints, on rank 0 at N=1:
   roofline     -- the dominant cost-volume kernel (fused stage 1 at l0) timed live with HIP events
@@ -54,7 +55,8 @@ def parse():
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--width", type=int, default=1800)
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic pairs kept in HBM")
-    ap.add_argument("--lanes", type=int, default=12, help="independent forwards in flight (streams x hipGraphs)")
+    ap.add_argument("--lanes", type=int, default=8,
+                    help="independent forwards in flight (hipGraphs, spread over the hardware queues)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=60, help="pairs in the CPU-oracle sample")
@@ -194,10 +196,10 @@ def main():
     pool = []
     for i in range(args.pool):                       # inputs resident in HBM before the timed region
         f1, f2 = synth.frame_pair(B, H, W, seed=1000 * rank + 10 * i)
-        pool.append((torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev)))
+        pool.append(torch.cat([torch.from_numpy(f1), torch.from_numpy(f2)], 0).to(dev))   # (2B,H,W,3) = [f1 | f2]
     lanes = 1 if args.no_graph else max(1, args.lanes)
     if args.no_graph:
-        net.forward(*pool[0])
+        net.forward(pool[0][:B], pool[0][B:])
     else:
         net.capture(B, H, W, lanes=lanes)
     # every step's l0 pose [q | t] is kept (a lane's static outputs are overwritten `lanes` steps later): one (B,7)
@@ -207,14 +209,13 @@ def main():
     gathered = [torch.empty_like(pose_log[:args.steps]) for _ in range(world)] if world > 1 else None
 
     def step(i):
-        a, b = pool[i % len(pool)]
-        if args.no_graph:
-            out, stream = net.forward(a, b), torch.cuda.current_stream(dev)
-        else:                                        # step i rides lane i % lanes; lanes overlap on the GPU
-            out, stream = net.submit(i % lanes, a, b), net.lane_stream(i % lanes)
-        with torch.cuda.stream(stream):
-            pose_log[i, :, :4].copy_(out[0], non_blocking=True)
-            pose_log[i, :, 4:].copy_(out[1], non_blocking=True)
+        pair = pool[i % len(pool)]
+        if args.no_graph:                            # the l0 pose-head kernel writes the log row itself
+            return net.forward(pair[:B], pair[B:], pose_out=pose_log[i])
+        lane = i % lanes                             # step i rides lane i % lanes; lanes overlap on the GPU
+        out = net.submit(lane, pair)                 # one copy in (the stacked pair), graph replay ...
+        with torch.cuda.stream(net.lane_stream(lane)):
+            pose_log[i].copy_(net.lane_pose(lane), non_blocking=True)      # ... one copy out (B,7)
         return out
 
     for i in range(args.warmup):

@@ -111,9 +111,9 @@ def softmax_valid(feature_bnc, weight_bnc, xyz_bn3):
     return out
 
 
-def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse=None, t_coarse=None):
+def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse=None, t_coarse=None, pose7=None):
     """softmax_valid -> conv1d(256) -> q,t heads -> normalise -> compose with the coarse pose, two launches.
-    pwclo_model.py:194-208 / :262-280.  Returns (q (B,4), t (B,3), q_norm (B,4))."""
+    pwclo_model.py:194-208 / :262-280.  Returns (q (B,4), t (B,3), q_norm (B,4)); `pose7` (B,7), if given, also receives [q_norm | t]."""
     L.require_gpu(feature_bnc, weight_bnc, xyz_bn3, W_big, W_q, W_t, q_coarse, t_coarse)
     feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t = _f32(
         feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t)
@@ -129,7 +129,8 @@ def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t
     ptr = lambda x: x.data_ptr() if x is not None else None
     a = L.PoseHeadArgs(B, N, C, hidden, feature_bnc.data_ptr(), weight_bnc.data_ptr(), xyz_bn3.data_ptr(),
                        W_big.data_ptr(), b_big.data_ptr(), W_q.data_ptr(), b_q.data_ptr(), W_t.data_ptr(), b_t.data_ptr(),
-                       ptr(q_coarse), ptr(t_coarse), q.data_ptr(), t.data_ptr(), q_norm.data_ptr(), scratch.data_ptr())
+                       ptr(q_coarse), ptr(t_coarse), q.data_ptr(), t.data_ptr(), q_norm.data_ptr(), scratch.data_ptr(),
+                       ptr(pose7))
     L.call("elo_pose_head", a, q)
     return q, t, q_norm
 

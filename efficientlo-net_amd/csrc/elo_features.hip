@@ -447,6 +447,10 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
         normalise_q(q, qn);
         for (int i = 0; i < 4; ++i) { a.q[b * 4 + i] = q[i]; a.q_norm[b * 4 + i] = qn[i]; }
         for (int i = 0; i < 3; ++i) a.t[b * 3 + i] = t[i];
+        if (a.pose7) {
+            for (int i = 0; i < 4; ++i) a.pose7[b * 7 + i] = qn[i];
+            for (int i = 0; i < 3; ++i) a.pose7[b * 7 + 4 + i] = t[i];
+        }
     }
 }
 

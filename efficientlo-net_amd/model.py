@@ -8,9 +8,48 @@ launch-bound unless the launches are replayed from a graph.  `capture()`
 records get_model_from_projection on static input buffers; `__call__` copies the
 new range images in and replays.
 """
+import time
+
 import torch
 
 from . import perm, pwclo_model, tf_util
+
+
+def distinct_queue_streams(device, want, candidates=16, cycles=500_000):
+    """Up to `want` torch streams that sit on DIFFERENT hardware queues.
+
+    HIP multiplexes its streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, assigned at stream
+    creation; two streams on one queue never overlap, so lanes must be spread over the queues by
+    measurement, not by counting streams (measured on MI355X, 64x1800, B=1: 12 lanes on whatever streams the
+    pool hands out 3990 pairs/s, 4 lanes on 4 distinct queues 4730; 5 queues and more are slower again).
+    The probe runs pairs of ~0.2 ms single-thread spin kernels: a pair on one queue takes twice as long."""
+    dev = torch.device(device)
+    spin = getattr(torch.cuda, "_sleep", None)
+    pool = [torch.cuda.Stream(device=dev) for _ in range(max(candidates, want))]
+    if spin is None or want <= 1:
+        return pool[:want]
+
+    def timed(streams):
+        best = float("inf")
+        for _ in range(2):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for s in streams:
+                with torch.cuda.stream(s):
+                    spin(cycles)
+            torch.cuda.synchronize(dev)
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    timed(pool)                                     # first use of a stream creates its queue binding
+    single = timed(pool[:1])
+    chosen = []
+    for s in pool:
+        if all(timed([rep, s]) < 1.5 * single for rep in chosen):
+            chosen.append(s)
+            if len(chosen) == want:
+                break
+    return chosen
 
 
 class PWCLONet:
@@ -24,13 +63,13 @@ class PWCLONet:
         self._lanes = []
 
     # -- eager ---------------------------------------------------------------
-    def forward(self, xyz_f1_proj, xyz_f2_proj, is_training=False, bn_decay=None):
+    def forward(self, xyz_f1_proj, xyz_f2_proj, is_training=False, bn_decay=None, pose_out=None):
         """get_model_from_projection under this net's variables and permutations."""
         with tf_util.default_store(self.store), perm.default_perm_source(self.perms):
             if is_training:
-                return pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, True, bn_decay)
+                return pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, True, bn_decay, pose_out)
             with torch.no_grad():
-                return pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, False, bn_decay)
+                return pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, False, bn_decay, pose_out)
 
     def forward_points(self, point_cloud, H_input, W_input, T_gt, T_trans, T_trans_inv, is_training=False,
                        bn_decay=None, aug_frame=None):
@@ -46,25 +85,29 @@ class PWCLONet:
         """Record the inference forward into `lanes` independent hipGraphs (torch.cuda.CUDAGraph on ROCm).
 
         One frame pair keeps only a few of the 256 CUs busy per kernel, and frame pairs are independent,
-        so several forwards can be in flight: lane i owns a stream, a graph and its static input / output
-        buffers; the weights are shared.  `lanes=1` is the plain single-stream replay."""
+        so several forwards can be in flight: lane i owns a graph and its static input / output buffers and
+        replays on one of the streams `distinct_queue_streams` found (one per hardware queue; lanes beyond
+        the number of queues share streams round-robin); the weights are shared.  `lanes=1` is the plain
+        single-stream replay."""
         dev = self.device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         def zeros():          # both frames in one allocation: the Siamese pyramid then runs as one 2B batch
-            both = torch.zeros((2 * batch_size, H_input, W_input, 3), device=dev)
-            return both[:batch_size], both[batch_size:]
+            return torch.zeros((2 * batch_size, H_input, W_input, 3), device=dev)
         with torch.cuda.stream(side):
             probe = zeros()
             for _ in range(warmup):                 # creates variables, folded weights, caches, hipBLASLt plans
-                self.forward(*probe)
+                self.forward(probe[:batch_size], probe[batch_size:])
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self._lanes = []
-        for _ in range(lanes):
-            lane = {"stream": torch.cuda.Stream(device=dev), "in": zeros(), "graph": torch.cuda.CUDAGraph()}
+        streams = distinct_queue_streams(dev, lanes)
+        for i in range(lanes):
+            both = zeros()
+            lane = {"stream": streams[i % len(streams)], "pair": both, "in": (both[:batch_size], both[batch_size:]),
+                    "graph": torch.cuda.CUDAGraph(), "pose": torch.zeros((batch_size, 7), device=dev)}
             with torch.cuda.graph(lane["graph"]):
-                lane["out"] = self.forward(*lane["in"])
+                lane["out"] = self.forward(*lane["in"], pose_out=lane["pose"])
             self._lanes.append(lane)
         torch.cuda.synchronize(dev)
         self._graph, self._static_in, self._static_out = (self._lanes[0]["graph"], self._lanes[0]["in"],
@@ -79,15 +122,23 @@ class PWCLONet:
         self._graph.replay()
         return self._static_out
 
-    def submit(self, lane_index, xyz_f1_proj, xyz_f2_proj):
+    def submit(self, lane_index, xyz_f1_proj, xyz_f2_proj=None):
         """Enqueue one forward on lane `lane_index` (its own stream); returns the lane's static outputs,
-        valid once that stream has been synchronised (or waited on)."""
+        valid once that stream has been synchronised (or waited on).  With `xyz_f2_proj` None the first
+        argument is the stacked pair (2B,H,W,3) = [frame 1 | frame 2]: one copy instead of two."""
         lane = self._lanes[lane_index]
         with torch.cuda.stream(lane["stream"]):
-            lane["in"][0].copy_(xyz_f1_proj, non_blocking=True)
-            lane["in"][1].copy_(xyz_f2_proj, non_blocking=True)
+            if xyz_f2_proj is None:
+                lane["pair"].copy_(xyz_f1_proj, non_blocking=True)
+            else:
+                lane["in"][0].copy_(xyz_f1_proj, non_blocking=True)
+                lane["in"][1].copy_(xyz_f2_proj, non_blocking=True)
             lane["graph"].replay()
         return lane["out"]
+
+    def lane_pose(self, lane_index):
+        """The lane's (B,7) [l0_q_norm | l0_t] block, written by the l0 pose-head kernel of its last replay."""
+        return self._lanes[lane_index]["pose"]
 
     def lane_stream(self, lane_index):
         return self._lanes[lane_index]["stream"]

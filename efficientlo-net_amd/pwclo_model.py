@@ -139,6 +139,20 @@ def _adjacent_frames(a, b):
     return None
 
 
+_ZEROS = {}
+
+
+def _zero_features(like):
+    """The all-zero input features (pwclo_model.py:69-70).  Read-only, so inference shares one tensor per shape
+    instead of a fill launch per forward."""
+    if torch.is_grad_enabled() or (like.is_cuda and torch.cuda.is_current_stream_capturing()):
+        return torch.zeros_like(like)
+    key = (tuple(like.shape), like.device)
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros_like(like)
+    return _ZEROS[key]
+
+
 def _normalise_q(q):
     return q / (torch.sqrt((q * q).sum(-1, keepdim=True) + 1e-10) + 1e-10)
 
@@ -154,7 +168,7 @@ def _pose_head(feat_b1c, level, coarse, is_training):
     return q, t
 
 
-def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training):
+def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training, pose7=None):
     """softmax_valid + pose head + composition with the coarse pose (q_coarse None at l3).
     Returns (q (B,4), t (B,3), q_norm (B,4)): the level's pose and its final normalisation (:427-430).
     Inference: two fused HIP launches (_ops.pose_head).  Training: the literal operator chain."""
@@ -165,7 +179,7 @@ def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training)
         W_big, b_big = tf_util.folded_variables('l%d_big' % level, predict.shape[-1], 256, (1,), bn=False)
         W_q, b_q = tf_util.folded_variables(qn % level, 256, 4, (1,), bn=False)
         W_t, b_t = tf_util.folded_variables(tn % level, 256, 3, (1,), bn=False)
-        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse)
+        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7)
     summed = softmax_valid(feature_bnc=predict, weight_bnc=weight, mask_valid=xyz)                  # :194 / :262
     q_det, t_det = _pose_head(summed, level, coarse, is_training)                                   # :197-208 / :264-273
     if coarse:
@@ -177,17 +191,22 @@ def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training)
     t_coarse_trans = mul_point_q(t_coarse_trans, inv_q(q_det, batch_size), batch_size)[:, :, 1:]    # :275-277
     q = mul_point_q(q_det, q_coarse, batch_size).squeeze(1)                                         # :279
     t = (t_coarse_trans + t_det).squeeze(1)                                                         # :280
-    return q, t, _normalise_q(q)
+    q_norm = _normalise_q(q)
+    if pose7 is not None:
+        pose7.copy_(torch.cat([q_norm, t], -1).detach())
+    return q, t, q_norm
 
 
-def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training, bn_decay=None):
+def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training, bn_decay=None, pose_out=None):
     """pwclo_model.py:69-433 from the projected inputs on.
-    Returns (l0_q_norm, l0_t, l1_q_norm, l1_t, l2_q_norm, l2_t, l3_q_norm, l3_t, l0_xyz_f1)."""
+    Returns (l0_q_norm, l0_t, l1_q_norm, l1_t, l2_q_norm, l2_t, l3_q_norm, l3_t, l0_xyz_f1).
+    `pose_out` (B,7), if given, also receives [l0_q_norm | l0_t] (written by the l0 pose-head kernel: the row a
+    caller logs per frame pair, main.py:557-572)."""
     batch_size, H_input, W_input, _ = xyz_f1_input_proj.shape
     dev = xyz_f1_input_proj.device
     out_h_list, out_w_list = pyramid_sizes(H_input, W_input)
 
-    zero_features = lambda like: torch.zeros_like(like)                                             # :69-70
+    zero_features = _zero_features                                                                  # :69-70
 
     # strided centre grids (:88-114).  Only the index tensors matter: down_conv re-gathers the xyz itself.
     pre2 = xyz_f1_input_proj
@@ -313,7 +332,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                 lambda: flow_predictor(points_warp_f1, w_up_sample, cost, mlp=[128, 64], is_training=is_training,
                                        bn_decay=bn_decay, scope='l%d_w_predict' % level)])             # :254
         q_prev, t_prev, q_norm = _estimate_pose(predict, weight, xyz_warp_f1, level, q_coarse, t_coarse,
-                                                is_training)                                       # :262-280
+                                                is_training, pose_out if level == 0 else None)  # :262-280
         poses[level] = (q_norm, t_prev)
 
         coarse_w_proj = weight.reshape(batch_size, out_h_list[g], out_w_list[g], -1)                # :256-257

@@ -204,6 +204,7 @@ typedef struct elo_pose_head_args {
     const float *t_coarse;        /* (batch,3) or NULL    */
     float *q, *t, *q_norm;        /* (batch,4), (batch,3), (batch,4) OUT */
     float *scratch;
+    float *pose7;                 /* (batch,7) [q_norm | t] OUT, or NULL: the pose as one row a caller can log */
 } elo_pose_head_args;
 int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream);
 

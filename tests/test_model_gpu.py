@@ -75,3 +75,23 @@ def test_graph_replay_equals_eager():
     out2 = [x.clone() for x in net(torch.from_numpy(g1).to(DEV), torch.from_numpy(g2).to(DEV))]
     torch.cuda.synchronize()
     assert not torch.equal(out2[1], eager[1])
+
+
+def test_lanes_take_a_stacked_pair_and_log_the_pose_row():
+    """submit(lane, stacked pair) == forward(f1, f2); lane_pose == [l0_q_norm | l0_t] written by the pose-head
+    kernel (elo_pose_head_args.pose7); eager forward(pose_out=) writes the same row."""
+    synth = load_pkg("synth")
+    net = _net()
+    B = 2
+    f1, f2 = synth.frame_pair(B, 64, 900, seed=77)
+    pair = torch.from_numpy(np.concatenate([f1, f2], 0)).to(DEV)
+    row = torch.full((B, 7), float("nan"), device=DEV)
+    eager = [x.clone() for x in net.forward(pair[:B], pair[B:], pose_out=row)]
+    assert torch.equal(row, torch.cat([eager[0], eager[1]], -1))
+    net.capture(B, 64, 900, lanes=2)
+    for lane in (0, 1):
+        out = net.submit(lane, pair)
+        net.lane_stream(lane).synchronize()
+        for e, o in zip(eager, out):
+            assert torch.equal(e, o)
+        assert torch.equal(net.lane_pose(lane), row)
