@@ -65,10 +65,11 @@ def parse():
 
 # ----------------------------------------------------------------------------- roofline leg
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak (= the fp32 vector peak)
-# HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_v2/summary.json: FETCH_SIZE x2 +
-# WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); counters cannot be read from inside bench.py.
-# Only for the exact shapes captured (l0 = 16x225, i.e. 64x1800 inputs); otherwise null.
-PMC_TRAFFIC = {("cv1", 1): 3.72e6, ("cv1", 8): 13.87e6, ("pool", 8): 96.94e6, ("pool", 64): 773.96e6}
+# HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_v3/summary.json, collected by
+# tools/pmc_collect.sh: FETCH_SIZE x2 + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); counters cannot
+# be read from inside bench.py.  Only for the exact shapes captured (l0 = 16x225, i.e. 64x1800 inputs); otherwise null.
+PMC_TRAFFIC = {("cv1", 1): 3.60e6, ("cv1", 8): 13.58e6, ("A1", 8): 36.19e6, ("P1", 8): 96.95e6, ("A2", 8): 52.57e6,
+               ("P2", 8): 66.92e6, ("A1", 64): 289.58e6, ("P1", 64): 773.96e6, ("A2", 64): 425.74e6, ("P2", 64): 534.63e6}
 
 
 def cost_volume_bytes(N, C, Kq, Kp, s=4):
@@ -87,24 +88,35 @@ def cv1_flops(N, C, Kq):
 
 
 def _time_launches(fn, dev, reps):
-    for _ in range(10):
+    """Average duration of one launch of `fn`: `reps` back-to-back launches captured in a hipGraph (so the host's
+    per-call cost, ~12 us from Python, is not in the number), replayed between two HIP events on torch's current
+    stream == the stream _lib.stream_ptr() hands to the C ABI."""
+    for _ in range(3):
         fn()
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            fn()
+    graph.replay()
     torch.cuda.synchronize(dev)
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()                      # torch's current stream == the stream _lib.stream_ptr() hands to the C ABI
-    for _ in range(reps):
-        fn()
+    start.record()
+    graph.replay()
     stop.record()
     torch.cuda.synchronize(dev)
-    return start.elapsed_time(stop) / 1e3 / reps
+    sec = start.elapsed_time(stop) / 1e3 / reps
+    del graph
+    return sec
 
 
-def roofline_leg(args, dev, net, reps=200):
+def roofline_leg(args, dev, net, reps=50):
     """The dominant cost-volume kernel of the timed path, timed live with HIP events on the stream it is launched
     on: the fused stage-1 kernel at l0 (select-k grouping + encode + six 1x1 convs on the fp32 matrix cores +
     masked softmax pooling in one launch).  It never materialises the operator-boundary tensors, so it is bound
     by the fp32 MFMA rate, not by HBM; `hbm_equivalent_GBps` is SURVEY 8(d)'s algorithmic bytes (A1+P1) over the
-    same duration for comparison with the per-operator kernels (`per_operator`, the P1 softmax-pool kernel)."""
+    same duration for comparison with the per-operator kernels (`per_operator`: the four HBM-bound kernels of the
+    ELO_FUSED=0 cost volume, each against its own algorithmic bytes)."""
     ops, fused, tf_util, perm, pm = pkg("_ops"), pkg("fused"), pkg("tf_util"), pkg("perm"), pkg("pwclo_model")
     oh, ow = pm.pyramid_sizes(args.height, args.width)
     B, H, W, C, Kq = args.batch, oh[2], ow[2], 16, 6
@@ -129,16 +141,43 @@ def roofline_leg(args, dev, net, reps=200):
     flops = cv1_flops(N, C, Kq) * B
     cvb = cost_volume_bytes(N, C, Kq, 4)
     tfs = flops / sec / 1e12
-    def pool_leg(batch):
-        logits = torch.randn((batch, N, Kq, 64), generator=g).to(dev)
-        values = torch.randn((batch, N, Kq, 64), generator=g).to(dev)
-        mask = (torch.rand((batch, N, Kq), generator=g) > 0.1).float().to(dev)
-        sec_p1 = _time_launches(lambda: ops.masked_softmax_pool(logits, values, mask), dev, reps)
-        gbs = cvb["P1"] * batch / sec_p1 / 1e9
-        return {"kernel": "softmax_pool_vec_kernel (P1 term of the ELO_FUSED=0 path)", "batch": batch, "bound": "hbm",
-                "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
-                "bytes_per_launch": int(cvb["P1"] * batch), "us_per_launch": round(sec_p1 * 1e6, 3),
-                "traffic": PMC_TRAFFIC.get(("pool", batch))}
+    def per_operator_leg(batch):
+        """The four cost-volume kernels of the ELO_FUSED=0 path at l0 (SURVEY 8(d) terms A1, P1, A2, P2), each
+        against its own algorithmic bytes, and the four together."""
+        elo = pkg()
+        Kp = 4
+        fb1, fb2 = synth.frame_pair(batch, H, W, seed=6)
+        x1, x2 = torch.from_numpy(fb1).to(dev), torch.from_numpy(fb2).to(dev)
+        ft1 = torch.randn((batch, H, W, C), generator=g).to(dev)
+        ft2 = torch.randn((batch, H, W, C), generator=g).to(dev)
+        hw = torch.from_numpy(synth.hw_index(batch, H, W)).to(dev)
+        idx_q, _, _, m_q = elo.fused_conv_select_k(x1, x2, hw, order, H, W, N, 11, 41, Kq, 0, 1000.0, 1, 1,
+                                                  want_valid=False)
+        order_p = torch.randperm(3 * 5, generator=g).to(torch.int32).to(dev)
+        idx_p, _, _, m_p = elo.fused_conv_random_k(x1, x1, hw, order_p, H, W, N, 3, 5, Kp, 0, 1000.0, 1, 1,
+                                                  want_valid=False)
+        m_q, m_p = m_q.reshape(batch, N, Kq), m_p.reshape(batch, N, Kp)
+        cost = torch.randn((batch, H, W, 64), generator=g).to(dev)
+        lq, vq = (torch.randn((batch, N, Kq, 64), generator=g).to(dev) for _ in range(2))
+        lp, vp = (torch.randn((batch, N, Kp, 64), generator=g).to(dev) for _ in range(2))
+        legs = {"A1": ("cv_encode1_vec_kernel", lambda: ops.cv_encode1(x1.reshape(batch, N, 3), ft1.reshape(batch, N, C),
+                                                                        x2, ft2, idx_q, m_q)),
+                "P1": ("softmax_pool_vec_kernel", lambda: ops.masked_softmax_pool(lq, vq, m_q)),
+                "A2": ("cv_encode2_vec_kernel", lambda: ops.cv_encode2(x1, ft1, cost, idx_p, m_p)),
+                "P2": ("softmax_pool_vec_kernel", lambda: ops.masked_softmax_pool(lp, vp, m_p))}
+        terms, tot_b, tot_s = {}, 0, 0.0
+        for term, (name, fn) in legs.items():
+            s = _time_launches(fn, dev, 20)
+            nbytes = cvb[term] * batch
+            terms[term] = {"kernel": name, "bytes": int(nbytes), "us": round(s * 1e6, 3),
+                           "GBps": round(nbytes / s / 1e9, 1), "frac": round(nbytes / s / 1e9 / HBM_PEAK_GBS, 4),
+                           "traffic": PMC_TRAFFIC.get((term, batch))}
+            tot_b, tot_s = tot_b + nbytes, tot_s + s
+        gbs = tot_b / tot_s / 1e9
+        return {"kernel": "cost volume at l0, ELO_FUSED=0 path: encode1 + pool + encode2 + pool (A1+P1+A2+P2)",
+                "batch": batch, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes_per_launch": int(tot_b), "us_per_launch": round(tot_s * 1e6, 3),
+                "terms": terms}
 
     return {"bound": "mfma", "kernel": "cv1_kernel (fused cost volume stage 1, l0: %dx%d, K=%d, batch %d)" % (H, W, Kq, B),
             "achieved": round(tfs, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -146,7 +185,7 @@ def roofline_leg(args, dev, net, reps=200):
             "flops_per_launch": int(flops), "us_per_launch": round(sec * 1e6, 3),
             "algorithmic_bytes_per_launch": int((cvb["A1"] + cvb["P1"]) * B),
             "hbm_equivalent_GBps": round((cvb["A1"] + cvb["P1"]) * B / sec / 1e9, 2),
-            "per_operator": pool_leg(B), "per_operator_b8": pool_leg(8)}
+            "per_operator": per_operator_leg(B), "per_operator_b8": per_operator_leg(8)}
 
 
 # ----------------------------------------------------------------------------- CPU baseline leg

@@ -5,7 +5,7 @@ FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-reports wide coalesced reads
 (MI355X_MICROARCH.md, HBM section), so both the raw and the fetch-doubled totals are kept."""
 import csv, glob, json, os, sys
 
-KNAME = {"cv1": "cv1_kernel", "pool": "softmax_pool", "encode1": "cv_encode1_kernel"}
+KNAME = {"cv1": "cv1_kernel", "pool": "softmax_pool", "pool2": "softmax_pool", "encode1": "cv_encode1", "encode2": "cv_encode2"}
 
 
 def main(src, dst):

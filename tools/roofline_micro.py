@@ -1,9 +1,11 @@
 """Launch one cost-volume kernel repeatedly (for rocprofv3 --kernel-trace / --pmc captures).
 
-    python tools/roofline_micro.py --kernel cv1|pool|encode1 --batch B [--reps N]
+    python tools/roofline_micro.py --kernel cv1|pool|pool2|encode1|encode2 --batch B [--reps N]
 cv1     = fused stage 1 at l0 (16x225, K=6, C=16)          -> cv1_kernel
-pool    = per-operator masked softmax pool (P1 term)       -> softmax_pool_kernel
-encode1 = per-operator gather + geometry encode (A1 term)  -> cv_encode1_kernel
+pool    = per-operator masked softmax pool, K=6 (P1 term)  -> softmax_pool_vec_kernel
+pool2   = the same with K=4 (P2 term)
+encode1 = per-operator gather + geometry encode (A1 term)  -> cv_encode1_vec_kernel
+encode2 = per-operator stage-2 gather + encode (A2 term)    -> cv_encode2_vec_kernel
 Prints the algorithmic bytes / flops per launch it used.
 """
 import argparse, importlib, json, os, sys
@@ -41,11 +43,21 @@ if a.kernel == "cv1":
     else:
         run = lambda: fused.cv_stage1(xyz1.reshape(B, N, 3), feat1.reshape(B, N, C), xyz2, feat2, None, None, *layers, group=grp, K=Kq)
     info = {"flops": bench.cv1_flops(N, C, Kq) * B, "algorithmic_bytes": (cvb["A1"] + cvb["P1"]) * B}
-elif a.kernel == "pool":
-    logits = torch.randn((B, N, Kq, 64), generator=g).to(dev); values = torch.randn((B, N, Kq, 64), generator=g).to(dev)
-    mask = (torch.rand((B, N, Kq), generator=g) > 0.1).float().to(dev)
+elif a.kernel in ("pool", "pool2"):
+    K = Kq if a.kernel == "pool" else 4
+    logits = torch.randn((B, N, K, 64), generator=g).to(dev); values = torch.randn((B, N, K, 64), generator=g).to(dev)
+    mask = (torch.rand((B, N, K), generator=g) > 0.1).float().to(dev)
     run = lambda: ops.masked_softmax_pool(logits, values, mask)
-    info = {"algorithmic_bytes": cvb["P1"] * B}
+    info = {"algorithmic_bytes": cvb["P1" if a.kernel == "pool" else "P2"] * B}
+elif a.kernel == "encode2":
+    Kp = 4
+    order2 = torch.randperm(3 * 5, generator=g).to(torch.int32).to(dev)
+    hw = torch.from_numpy(synth.hw_index(B, H, W)).to(dev)
+    idx, _, _, m = elo.fused_conv_random_k(xyz1, xyz1, hw, order2, H, W, N, 3, 5, Kp, 0, 1000.0, 1, 1, want_valid=False)
+    m = m.reshape(B, N, Kp)
+    cost = torch.randn((B, H, W, 64), generator=g).to(dev)
+    run = lambda: ops.cv_encode2(xyz1, feat1, cost, idx, m)
+    info = {"algorithmic_bytes": cvb["A2"] * B}
 else:
     hw = torch.from_numpy(synth.hw_index(B, H, W)).to(dev)
     idx, _, _, m = elo.fused_conv_select_k(xyz1, xyz2, hw, order, H, W, N, 11, 41, Kq, 0, 1000.0, 1, 1, want_valid=False)
