@@ -1,11 +1,17 @@
 """Training step for the hot path: forward (batch-statistics BN, dropout, fresh visiting orders) ->
 get_loss -> backward -> ONE flat-bucket all-reduce over RCCL -> Adam.  Mirrors main.py:120-176,344-397
 (the reference's single-GPU loop) with the data-parallel exchange of SURVEY.md section 5 added.
-The full training driver (epochs, evaluation, checkpoint policy) is out of scope.
+Also here: the reference's training-time input augmentation (main.py:259-297) and checkpoint save / restore
+(variables + Adam state as .npz, or the variables as a TensorFlow bundle, tf_checkpoint.py).  The epoch driver
+(evaluation cadence, best-model directory policy, main.py:185-249) is out of scope.
 """
+import math
+import os
+
+import numpy as np
 import torch
 
-from . import perm, pwclo_model, tf_util
+from . import perm, pwclo_model, tf_checkpoint, tf_util
 from .distributed import FlatGradBucket
 
 BASE_LEARNING_RATE, DECAY_STEP, DECAY_RATE = 0.001, 200000, 0.7          # main.py:46-51
@@ -21,6 +27,27 @@ def bn_decay(step, batch_size):
     """main.py:130-138."""
     momentum = BN_INIT_DECAY * BN_DECAY_DECAY_RATE ** ((step * batch_size) // DECAY_STEP)
     return min(BN_DECAY_CLIP, 1 - momentum)
+
+
+def data_augmentation(rng=None):
+    """main.py:259-297 DataAugmentation: a random near-identity rigid transform T_trans (4,4) applied to frame 2 in
+    training -- rotations about x, y (sigma 0.01, clipped to +-0.02) and z (sigma 0.05, clipped to +-0.1), each times
+    pi/4, composed Rx.Ry.Rz; translation sigma (0.5, 0.1, 0.05) clipped to (1.0, 0.2, 0.15).  The reference's scale
+    matrix is uniform(1,1) = identity.  `rng`: a numpy Generator (the reference uses the global numpy state)."""
+    rng = np.random.default_rng() if rng is None else rng
+    draw = lambda sigma, bound: float(np.clip(sigma * rng.standard_normal(), -bound, bound))
+    ax, ay, az = (draw(0.01, 0.02) * math.pi / 4, draw(0.01, 0.02) * math.pi / 4, draw(0.05, 0.1) * math.pi / 4)
+
+    def rot(i, j, angle):                              # rotation in the (i, j) coordinate plane
+        R = np.eye(3)
+        R[i, i] = R[j, j] = math.cos(angle)
+        R[i, j], R[j, i] = -math.sin(angle), math.sin(angle)
+        return R
+
+    T = np.eye(4)
+    T[:3, :3] = rot(1, 2, ax) @ rot(2, 0, ay) @ rot(0, 1, az)
+    T[:3, 3] = (draw(0.5, 1.0), draw(0.1, 0.2), draw(0.05, 0.15))
+    return T
 
 
 class Trainer:
@@ -53,3 +80,50 @@ class Trainer:
         self.net.store.invalidate()                                      # folded / packed inference weights are stale
         self.step_count += 1
         return loss.detach()
+
+    # -- checkpoints -----------------------------------------------------------
+    def save(self, path, tf_bundle=False):
+        """Variables (+ moving statistics), loss weights, step count and Adam moments -> `path` (.npz); with
+        `tf_bundle` the variables, w_x and w_q are written as a TensorFlow bundle <path>.index/.data instead
+        (what main.py:233 `saver.save` produces, minus the optimiser slots)."""
+        state = {k: v.detach().cpu().numpy() for k, v in self.net.store.state_dict().items()}
+        state["w_x"], state["w_q"] = self.w_x.detach().cpu().numpy(), self.w_q.detach().cpu().numpy()
+        if tf_bundle:
+            return tf_checkpoint.save_checkpoint(path, state)
+        opt = self.opt.state_dict()["state"]
+        for i, p in enumerate(self.params):
+            if i in opt:
+                state["adam_m/%d" % i] = opt[i]["exp_avg"].cpu().numpy()
+                state["adam_v/%d" % i] = opt[i]["exp_avg_sq"].cpu().numpy()
+                state["adam_t/%d" % i] = np.asarray(float(opt[i]["step"]))
+        state["step_count"] = np.asarray(self.step_count)
+        np.savez(path, **state)
+        return sorted(state)
+
+    def load(self, path):
+        """Inverse of save(): `path` is the .npz file, or the prefix of a TensorFlow bundle (variables only)."""
+        if os.path.exists(path + ".index"):
+            tf_checkpoint.load_into(self.net.store, path)
+            extra = tf_checkpoint.load_checkpoint(path, [k for k in ("w_x", "w_q")
+                                                         if k in tf_checkpoint.read_index(path)[1]])
+            state = {}
+        else:
+            state = dict(np.load(path if path.endswith(".npz") else path + ".npz"))
+            extra = {k: state.pop(k) for k in ("w_x", "w_q") if k in state}
+            adam = {k: state.pop(k) for k in list(state) if k.startswith("adam_")}
+            self.step_count = int(state.pop("step_count", 0))
+            self.net.store.load_state_dict(state)
+            dev = self.net.device
+            opt_state = self.opt.state_dict()
+            for i, p in enumerate(self.params):
+                if "adam_m/%d" % i in adam:
+                    opt_state["state"][i] = {"step": torch.tensor(float(adam["adam_t/%d" % i])),
+                                             "exp_avg": torch.from_numpy(adam["adam_m/%d" % i]).to(dev),
+                                             "exp_avg_sq": torch.from_numpy(adam["adam_v/%d" % i]).to(dev)}
+            self.opt.load_state_dict(opt_state)
+        with torch.no_grad():
+            if "w_x" in extra:
+                self.w_x.copy_(torch.as_tensor(extra["w_x"]).reshape(()))
+            if "w_q" in extra:
+                self.w_q.copy_(torch.as_tensor(extra["w_q"]).reshape(()))
+        return self

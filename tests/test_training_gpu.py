@@ -1,6 +1,8 @@
 """GPU: the training path -- differentiable torch twins equal the HIP kernels in the forward direction,
 gradients reach every layer, get_loss / PreProcess / the full get_model signature match the oracle, and a
 few optimisation steps reduce the loss."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -134,6 +136,43 @@ def test_training_steps_reduce_the_loss_and_reach_every_layer():
     # inference after training: folded / packed weights were invalidated and rebuilt
     out = net.forward(a, b)
     assert all(torch.isfinite(o).all() for o in out)
+
+
+def test_trainer_checkpoints_resume_bit_exactly(tmp_path):
+    """save -> load into a fresh trainer -> the next step equals the original's next step (variables, moving
+    statistics, loss weights, Adam moments, step count); the TensorFlow-bundle form restores the variables."""
+    model, training, synth = load_pkg("model"), load_pkg("training"), load_pkg("synth")
+    f1, f2 = synth.frame_pair(1, 64, 900, seed=21)
+    a, b = t(f1), t(f2)
+    q_gt, t_gt = t(np.array([[0.99995, 0.0, 0.0, 0.01]], np.float32)), t(np.array([[[0.8], [0.0], [0.0]]], np.float32))
+
+    def fresh(seed):
+        return training.Trainer(model.PWCLONet(DEV, seed=seed))
+    tr = fresh(3)
+    torch.manual_seed(0)
+    for _ in range(2):
+        tr.step(a, b, q_gt, t_gt)
+    tr.save(str(tmp_path / "ck.npz"))
+    tr.save(str(tmp_path / "ck_tf"), tf_bundle=True)
+    perm_state = copy.deepcopy(tr.net.perms)              # the visiting-order stream is not part of a checkpoint
+    torch.manual_seed(5)
+    want = float(tr.step(a, b, q_gt, t_gt))
+    want_vars = {k: v.clone() for k, v in tr.net.store.state_dict().items()}
+
+    tr2 = fresh(9).load(str(tmp_path / "ck.npz"))
+    assert tr2.step_count == 2
+    tr2.net.perms = perm_state
+    torch.manual_seed(5)
+    got = float(tr2.step(a, b, q_gt, t_gt))
+    assert got == want
+    for k, v in tr2.net.store.state_dict().items():
+        assert torch.equal(v, want_vars[k]), k
+
+    tr3 = fresh(11).load(str(tmp_path / "ck_tf"))
+    saved = dict(np.load(str(tmp_path / "ck.npz")))
+    for k, v in tr3.net.store.state_dict().items():
+        assert np.array_equal(v.cpu().numpy(), saved[k]), k
+    assert float(tr3.w_q.detach()) == float(saved["w_q"])
 
 
 def test_runs_at_128x2048():
