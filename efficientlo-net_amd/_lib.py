@@ -49,12 +49,13 @@ SV_MAX_PARTS = 64      # ELO_SV_MAX_PARTS
 PoseHeadArgs = _struct("elo_pose_head_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("hidden", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp),
     ("W_big", _vp), ("b_big", _vp), ("W_q", _vp), ("b_q", _vp), ("W_t", _vp), ("b_t", _vp),
-    ("q_coarse", _vp), ("t_coarse", _vp), ("q", _vp), ("t", _vp), ("q_norm", _vp), ("scratch", _vp), ("pose7", _vp)])
+    ("q_coarse", _vp), ("t_coarse", _vp), ("q", _vp), ("t", _vp), ("q_norm", _vp), ("scratch", _vp), ("pose7", _vp),
+    ("clear_scratch", _vp), ("clear_xyz", _vp), ("clear_feat", _vp), ("clear_cells", ctypes.c_long), ("clear_C", _i)])
 WarpProjectArgs = _struct("elo_warp_project_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("H", _i), ("W", _i),
     ("az_res", _f), ("vert_res", _f), ("vert_off", _f),
     ("xyz", _vp), ("feat", _vp), ("q", _vp), ("t", _vp), ("warped", _vp), ("out_xyz", _vp), ("out_feat", _vp),
-    ("scratch", _vp)])
+    ("scratch", _vp), ("prepared", _i)])
 
 Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i), ("w_plain", _vp)])
 _l = ctypes.c_long

@@ -111,7 +111,20 @@ def softmax_valid(feature_bnc, weight_bnc, xyz_bn3):
     return out
 
 
-def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse=None, t_coarse=None, pose7=None):
+class ProjectionBuffers:
+    """Outputs + scratch of one warp_project call, allocated ahead of it so that the pose head that produces its
+    (q, t) can clear them on the side (`pose_head(clear=...)`): the warp call then skips its init launch."""
+
+    def __init__(self, B, N, H, W, C, device):
+        self.shape = (B, N, H, W, C)
+        self.out_xyz = torch.empty((B, H, W, 3), dtype=torch.float32, device=device)
+        self.out_feat = torch.empty((B, H, W, C), dtype=torch.float32, device=device) if C else None
+        self.scratch = torch.empty((B * H * W + 2 * B * N,), dtype=torch.int32, device=device)
+        self.cleared = False
+
+
+def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse=None, t_coarse=None, pose7=None,
+              clear=None):
     """softmax_valid -> conv1d(256) -> q,t heads -> normalise -> compose with the coarse pose, two launches.
     pwclo_model.py:194-208 / :262-280.  Returns (q (B,4), t (B,3), q_norm (B,4)); `pose7` (B,7), if given, also receives [q_norm | t]."""
     L.require_gpu(feature_bnc, weight_bnc, xyz_bn3, W_big, W_q, W_t, q_coarse, t_coarse)
@@ -130,8 +143,12 @@ def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t
     a = L.PoseHeadArgs(B, N, C, hidden, feature_bnc.data_ptr(), weight_bnc.data_ptr(), xyz_bn3.data_ptr(),
                        W_big.data_ptr(), b_big.data_ptr(), W_q.data_ptr(), b_q.data_ptr(), W_t.data_ptr(), b_t.data_ptr(),
                        ptr(q_coarse), ptr(t_coarse), q.data_ptr(), t.data_ptr(), q_norm.data_ptr(), scratch.data_ptr(),
-                       ptr(pose7))
+                       ptr(pose7), *((clear.scratch.data_ptr(), clear.out_xyz.data_ptr(), ptr(clear.out_feat),
+                                      clear.shape[0] * clear.shape[2] * clear.shape[3], clear.shape[4])
+                                     if clear is not None else (None, None, None, 0, 0)))
     L.call("elo_pose_head", a, q)
+    if clear is not None:
+        clear.cleared = True
     return q, t, q_norm
 
 
@@ -144,9 +161,10 @@ def projection_constants(H_input, W_input):
     return az, vres, -down / vres
 
 
-def warp_project(xyz, feat, q, t, H, W):
+def warp_project(xyz, feat, q, t, H, W, buffers=None):
     """Optional quaternion warp (q,t: (B,4),(B,3) or None) + ProjectPC2SphericalRing.
-    Returns (warped (B,N,3) or None, xyz_proj (B,H,W,3), feat_proj (B,H,W,C) or None)."""
+    Returns (warped (B,N,3) or None, xyz_proj (B,H,W,3), feat_proj (B,H,W,C) or None).
+    `buffers`: a ProjectionBuffers of this call's shape, used (and, if a pose head cleared it, not re-initialised)."""
     L.require_gpu(xyz, feat, q, t)
     (xyz,) = _f32(xyz)
     B, N, _ = xyz.shape
@@ -157,12 +175,15 @@ def warp_project(xyz, feat, q, t, H, W):
         q, t = _f32(q.reshape(B, 4), t.reshape(B, 3))
     dev = xyz.device
     warped = torch.empty((B, N, 3), dtype=torch.float32, device=dev) if q is not None else None
-    out_xyz = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
-    out_feat = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if C else None
-    scratch = torch.empty((B * H * W + 2 * B * N,), dtype=torch.int32, device=dev)
+    if buffers is not None and buffers.shape != (B, N, H, W, C):
+        raise ValueError("ProjectionBuffers of shape %s given to a %s projection" % (buffers.shape, (B, N, H, W, C)))
+    if buffers is None:
+        buffers = ProjectionBuffers(B, N, H, W, C, dev)
+    out_xyz, out_feat, scratch = buffers.out_xyz, buffers.out_feat, buffers.scratch
     az, vres, voff = projection_constants(H, W)
     ptr = lambda x: x.data_ptr() if x is not None else None
     a = L.WarpProjectArgs(B, N, C, H, W, az, vres, voff, xyz.data_ptr(), ptr(feat), ptr(q), ptr(t), ptr(warped),
-                          out_xyz.data_ptr(), ptr(out_feat), scratch.data_ptr())
+                          out_xyz.data_ptr(), ptr(out_feat), scratch.data_ptr(), 1 if buffers.cleared else 0)
+    buffers.cleared = False                               # single use: the outputs now hold this call's result
     L.call("elo_warp_project", a, out_xyz)
     return warped, out_xyz, out_feat

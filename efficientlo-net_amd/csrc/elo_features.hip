@@ -392,12 +392,31 @@ __device__ __forceinline__ SvPartials sv_partials(float *scratch, int batch, int
     return SvPartials{scratch, scratch + n, scratch + 2 * n};
 }
 
+// Side job of the partial kernel (elo_pose_head_args.clear_*): its workgroups also clear the buffers of the
+// projection that follows the pose head, which saves that call's init launch (three per forward).
+struct ProjectionClear { unsigned *minr; float *xyz, *feat; long cells; int C; };
+
+__device__ __forceinline__ void clear_projection(const ProjectionClear &c)
+{
+    if (!c.minr) return;
+    const long n_xyz = c.cells * 3, total = c.cells + n_xyz + c.cells * c.C;
+    const long nthreads = (long)gridDim.x * gridDim.y * gridDim.z * blockDim.x;
+    const long me = (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    for (long i = me; i < total; i += nthreads) {
+        if (i < c.cells) c.minr[i] = 0x7f7f7f7fu;
+        else if (i < c.cells + n_xyz) c.xyz[i - c.cells] = 0.0f;
+        else c.feat[i - c.cells - n_xyz] = 0.0f;
+    }
+}
+
 __global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_partial_kernel(const float *__restrict__ feature,
                                                                           const float *__restrict__ weight,
                                                                           const float *__restrict__ xyz, int npoints,
-                                                                          int C, int parts, float *scratch)
+                                                                          int C, int parts, float *scratch,
+                                                                          const ProjectionClear clear)
 {
     __shared__ float part[3][ROWS_PER_BLOCK][ELO_WAVE];
+    clear_projection(clear);
     const int slice = blockIdx.x, b = blockIdx.y, lane = threadIdx.x % ELO_WAVE, wave = threadIdx.x / ELO_WAVE;
     const int c = blockIdx.z * ELO_WAVE + lane;
     const bool live = c < C;
@@ -763,7 +782,7 @@ extern "C" int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t s
     const int parts = sv_parts(a->npoints);
     hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
                        dim3(ELO_BLOCK), 0, (hipStream_t)stream, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
-                       a->scratch);
+                       a->scratch, ProjectionClear{nullptr, nullptr, nullptr, 0, 0});
     hipLaunchKernelGGL(softmax_valid_merge_kernel, dim3((a->batch * a->C + ELO_BLOCK - 1) / ELO_BLOCK), dim3(ELO_BLOCK),
                        0, (hipStream_t)stream, a->scratch, a->batch, a->C, parts, a->out);
     return check_launch(who);
@@ -778,10 +797,12 @@ extern "C" int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream)
                 a->q && a->t && a->q_norm && a->scratch, who, "null tensor pointer");
     ELO_REQUIRE((a->q_coarse == nullptr) == (a->t_coarse == nullptr), who, "q_coarse and t_coarse go together");
     if (a->batch == 0) return ELO_OK;
+    ELO_REQUIRE(!a->clear_scratch || (a->clear_xyz && a->clear_cells > 0 && a->clear_C >= 0 && (a->clear_feat || a->clear_C == 0)),
+                who, "incomplete clear_* side job");
     const int parts = sv_parts(a->npoints);
     hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
                        dim3(ELO_BLOCK), 0, (hipStream_t)stream, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
-                       a->scratch);
+                       a->scratch, ProjectionClear{a->clear_scratch, a->clear_xyz, a->clear_feat, a->clear_cells, a->clear_C});
     const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (ELO_BLOCK / ELO_WAVE) + 3 * 4 * 64);
     hipLaunchKernelGGL(pose_head_kernel, dim3(a->batch), dim3(ELO_BLOCK), lds, (hipStream_t)stream, *a, parts);
     return check_launch(who);
@@ -803,7 +824,7 @@ extern "C" int elo_warp_project(const elo_warp_project_args *a, elo_stream_t str
     unsigned *rbits = a->scratch + cells + pts;
     // one init launch instead of three memsets (memset nodes inside a captured hipGraph proved unreliable):
     // minr <- 0x7f7f7f7f (3.39e38f: above every finite range, below NaN bit patterns), outputs <- 0
-    {
+    if (!a->prepared) {
         const size_t words = cells * (1 + 3 + (size_t)a->C);
         const unsigned gi = (unsigned)((words + ELO_BLOCK - 1) / ELO_BLOCK);
         hipLaunchKernelGGL(project_init_kernel, dim3(gi > 4096 ? 4096 : gi), dim3(ELO_BLOCK), 0, s, minr, a->out_xyz,

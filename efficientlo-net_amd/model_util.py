@@ -83,9 +83,12 @@ def ProjectPC2SphericalRing(PC, Feature, H_input, W_input):
     return (xyz_proj, feat_proj) if Feature is not None else (xyz_proj, xyz_proj)
 
 
-def warp_and_project(xyz, feature, q_coarse, t_coarse, H_input, W_input):
+def warp_and_project(xyz, feature, q_coarse, t_coarse, H_input, W_input, buffers=None):
     """pwclo_model.py:213-232 fused: p' = (q (x) [0,p] (x) q^-1)[1:] + t, zeroed where p == 0, then
-    ProjectPC2SphericalRing(p', feature).  Returns (warped (B,N,3), xyz_proj, feat_proj)."""
+    ProjectPC2SphericalRing(p', feature).  Returns (warped (B,N,3), xyz_proj, feat_proj).
+    `buffers` (inference only): _ops.ProjectionBuffers already cleared by the pose head that produced q, t."""
+    if buffers is not None:
+        return _ops.warp_project(xyz, feature, q_coarse, t_coarse, H_input, W_input, buffers)
     return _ops.active().warp_project(xyz, feature, q_coarse, t_coarse, H_input, W_input)
 
 

@@ -145,10 +145,12 @@ _ZEROS = {}
 def _zero_features(like):
     """The all-zero input features (pwclo_model.py:69-70).  Read-only, so inference shares one tensor per shape
     instead of a fill launch per forward."""
-    if torch.is_grad_enabled() or (like.is_cuda and torch.cuda.is_current_stream_capturing()):
+    if torch.is_grad_enabled():
         return torch.zeros_like(like)
     key = (tuple(like.shape), like.device)
     if key not in _ZEROS:
+        if like.is_cuda and torch.cuda.is_current_stream_capturing():
+            return torch.zeros_like(like)           # never cache a tensor that lives in a graph's private pool
         _ZEROS[key] = torch.zeros_like(like)
     return _ZEROS[key]
 
@@ -168,7 +170,7 @@ def _pose_head(feat_b1c, level, coarse, is_training):
     return q, t
 
 
-def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training, pose7=None):
+def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training, pose7=None, clear=None):
     """softmax_valid + pose head + composition with the coarse pose (q_coarse None at l3).
     Returns (q (B,4), t (B,3), q_norm (B,4)): the level's pose and its final normalisation (:427-430).
     Inference: two fused HIP launches (_ops.pose_head).  Training: the literal operator chain."""
@@ -179,7 +181,7 @@ def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training,
         W_big, b_big = tf_util.folded_variables('l%d_big' % level, predict.shape[-1], 256, (1,), bn=False)
         W_q, b_q = tf_util.folded_variables(qn % level, 256, 4, (1,), bn=False)
         W_t, b_t = tf_util.folded_variables(tn % level, 256, 3, (1,), bn=False)
-        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7)
+        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7, clear)
     summed = softmax_valid(feature_bnc=predict, weight_bnc=weight, mask_valid=xyz)                  # :194 / :262
     q_det, t_det = _pose_head(summed, level, coarse, is_training)                                   # :197-208 / :264-273
     if coarse:
@@ -276,8 +278,17 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                                       bn_decay=bn_decay, scope='l3_costvolume_predict_ww')
     l3_cost_volume_w_proj = l3_cost_volume_w.reshape(batch_size, out_h_list[5], out_w_list[5], -1)
     l3_xyz_f1 = xyz_proj_f1[3].reshape(batch_size, -1, 3)
+    # inference: the pose head of level L+1 also clears the projection buffers of level L's warp (one launch less)
+    inference = not (is_training or torch.is_grad_enabled())
+
+    def projection_buffers(level, g):
+        if not inference:
+            return None
+        return _ops.ProjectionBuffers(batch_size, xyz_proj_f1[level].shape[1] * xyz_proj_f1[level].shape[2],
+                                      out_h_list[g], out_w_list[g], pts_f1[level].shape[-1], dev)
+    next_buffers = projection_buffers(2, 4)
     l3_q, l3_t, l3_q_norm = _estimate_pose(l3_points_predict, l3_cost_volume_w, l3_xyz_f1, 3, None, None,
-                                           is_training)                                            # :194-208
+                                           is_training, clear=next_buffers)                        # :194-208
 
     # three warp-refinement levels (:211-425); one loop instead of three pasted blocks
     cv_kernel2 = {2: [5, 15], 1: [7, 25], 0: [11, 41]}                                              # :243,:317,:391
@@ -290,7 +301,8 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
         xyz_f1 = xyz_proj_f1[level].reshape(batch_size, -1, 3)
         # warp by the coarse pose, zero invalid points, re-project with the level's features (:217-236)
         _warped, xyz_warp_proj_f1, points_warp_proj_f1 = warp_and_project(
-            xyz_f1, pts_f1[level], q_coarse, t_coarse, out_h_list[g], out_w_list[g])
+            xyz_f1, pts_f1[level], q_coarse, t_coarse, out_h_list[g], out_w_list[g], next_buffers)
+        next_buffers = projection_buffers(level - 1, g - 1) if level > 0 else None
         xyz_warp_f1 = xyz_warp_proj_f1.reshape(batch_size, -1, 3)
         points_warp_f1 = points_warp_proj_f1.reshape(batch_size, out_h_list[g] * out_w_list[g], -1)
 
@@ -332,7 +344,8 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                 lambda: flow_predictor(points_warp_f1, w_up_sample, cost, mlp=[128, 64], is_training=is_training,
                                        bn_decay=bn_decay, scope='l%d_w_predict' % level)])             # :254
         q_prev, t_prev, q_norm = _estimate_pose(predict, weight, xyz_warp_f1, level, q_coarse, t_coarse,
-                                                is_training, pose_out if level == 0 else None)  # :262-280
+                                                is_training, pose_out if level == 0 else None,
+                                                clear=next_buffers)                                # :262-280
         poses[level] = (q_norm, t_prev)
 
         coarse_w_proj = weight.reshape(batch_size, out_h_list[g], out_w_list[g], -1)                # :256-257

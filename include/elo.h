@@ -205,6 +205,14 @@ typedef struct elo_pose_head_args {
     float *q, *t, *q_norm;        /* (batch,4), (batch,3), (batch,4) OUT */
     float *scratch;
     float *pose7;                 /* (batch,7) [q_norm | t] OUT, or NULL: the pose as one row a caller can log */
+    /* Optional side job for the workgroups of the first launch: clear the buffers of the elo_warp_project call
+     * that will consume this pose (its scratch min-range words and its two outputs), so that call can set
+     * `prepared` and skip its own init launch.  clear_scratch == NULL: no side job. */
+    unsigned *clear_scratch;      /* the warp call's `scratch`: the first clear_cells words are set to 0x7f7f7f7f */
+    float *clear_xyz;             /* its out_xyz  (clear_cells*3 floats  <- 0) */
+    float *clear_feat;            /* its out_feat (clear_cells*clear_C floats <- 0), NULL when clear_C == 0 */
+    long clear_cells;             /* batch*H*W of that call */
+    int clear_C;
 } elo_pose_head_args;
 int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream);
 
@@ -230,6 +238,7 @@ typedef struct elo_warp_project_args {
     float *out_xyz;               /* (batch,H,W,3) OUT */
     float *out_feat;              /* (batch,H,W,C) OUT or NULL */
     unsigned *scratch;
+    int prepared;                 /* 1: scratch / out_xyz / out_feat were cleared by elo_pose_head (clear_*): no init launch */
 } elo_warp_project_args;
 int elo_warp_project(const elo_warp_project_args *a, elo_stream_t stream);
 

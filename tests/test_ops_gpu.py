@@ -209,3 +209,33 @@ def test_warp_and_project():
     same = np.isclose(got_xyz, w_xyz, atol=1e-5).all(-1)
     assert same.mean() > 0.995, same.mean()                # cell flips only for points on a cell border
     assert np.isclose(got_feat[same], w_feat[same], atol=1e-5).all()
+
+
+def test_pose_head_clears_the_next_projection():
+    """elo_pose_head_args.clear_* / elo_warp_project_args.prepared: buffers cleared on the side by the pose head's
+    partial kernel give the same projection as the self-initialising call, even when they held garbage."""
+    ops = load_pkg("_ops")
+    rng = np.random.default_rng(12)
+    B, H, W, C = 2, 8, 113, 32
+    N = H * W
+    pc = _boundary_safe_points(rng, B, N, H, W)
+    pc[rng.random((B, N)) < 0.1] = 0
+    feat = t(rng.normal(0, 1, (B, N, C)).astype(np.float32))
+    f, w = (t(rng.normal(0, 1, (B, 116, 64)).astype(np.float32)) for _ in range(2))
+    xyz_small = t(rng.normal(0, 5, (B, 116, 3)).astype(np.float32))
+    Wb, bb = t(rng.normal(0, .1, (64, 256)).astype(np.float32)), t(rng.normal(0, .1, (256,)).astype(np.float32))
+    Wq, bq = t(rng.normal(0, .1, (256, 4)).astype(np.float32)), t(np.array([1, 0, 0, 0], np.float32))
+    Wt, bt = t(rng.normal(0, .1, (256, 3)).astype(np.float32)), t(np.zeros(3, np.float32))
+    plain = ops.pose_head(f, w, xyz_small, Wb, bb, Wq, bq, Wt, bt)
+    want = ops.warp_project(t(pc), feat, plain[0], plain[1], H, W)
+    buf = ops.ProjectionBuffers(B, N, H, W, C, DEV)
+    buf.out_xyz.fill_(float("nan")); buf.out_feat.fill_(7.0); buf.scratch.fill_(-1)
+    q, tt, qn = ops.pose_head(f, w, xyz_small, Wb, bb, Wq, bq, Wt, bt, clear=buf)
+    assert buf.cleared and all(torch.equal(a, b) for a, b in zip((q, tt, qn), plain))
+    got = ops.warp_project(t(pc), feat, q, tt, H, W, buffers=buf)
+    assert not buf.cleared
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # the zero points all tie at range 0 in one cell and are SUMMED there (scatter_nd adds duplicates): atomic order
+    assert torch.allclose(got[2], want[2], atol=1e-4)
+    with pytest.raises(ValueError, match="ProjectionBuffers"):
+        ops.warp_project(t(pc), feat, q, tt, H, W + 1, buffers=buf)
