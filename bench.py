@@ -261,6 +261,7 @@ def main():
         step(i)
     torch.cuda.synchronize(dev)
     if world > 1:
+        dist.all_gather(gathered, pose_log[:args.steps].contiguous())     # untimed: RCCL sets its channels up on first use
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
