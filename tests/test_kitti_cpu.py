@@ -68,3 +68,22 @@ def test_io_round_trip(tmp_path):
     out = tmp_path / "04_pred.txt"
     K.write_pred_txt(str(out), diff[:5])
     assert np.allclose(np.loadtxt(out), diff[:5], atol=1e-8)
+
+
+def test_pose_rows_on_known_motion():
+    """evaluate.pose_rows (main.py:537-572): constant forward motion in the LiDAR frame becomes constant motion along
+    the camera's image of LiDAR x; one row per sample, the first row is the first sample's own transform."""
+    ev, kitti = load_pkg("evaluate"), load_pkg("kitti")
+    TR = np.array([4.276802385584e-04, -9.999672484946e-01, -8.084491683471e-03, -1.198459927713e-02,
+                   -7.210626507497e-03, 8.081198471645e-03, -9.999413164504e-01, -5.403984729748e-02,
+                   9.999738645903e-01, 4.859485810390e-04, -7.206933692422e-03, -2.921968648686e-01])
+    n = 6
+    q = np.tile([1.0, 0, 0, 0], (n, 1))
+    t = np.tile([0.8, 0, 0], (n, 1))
+    rows = ev.pose_rows(q, t, TR)
+    Tr = kitti.to_4x4(TR)
+    step = (Tr @ np.array([0.8, 0, 0, 0.0]))[:3]           # direction of LiDAR x in the camera frame
+    for i in range(n):
+        assert np.allclose(rows[i].reshape(3, 4)[:, :3], np.eye(3), atol=1e-9)
+        assert np.allclose(rows[i].reshape(3, 4)[:, 3], (i + 1) * step, atol=1e-9)
+    assert ev.pose_rows(np.zeros((0, 4)), np.zeros((0, 3)), TR).shape == (0, 12)
