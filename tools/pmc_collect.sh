@@ -5,7 +5,8 @@
 set -u
 OUT=$(realpath -m "${1:-gpurun_out/pmc3}"); REPO=$(pwd)
 mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
-for spec in cv1:1 cv1:8 encode1:8 pool:8 encode2:8 pool2:8 encode1:64 pool:64 encode2:64 pool2:64; do
+SPECS=${ELO_PMC_SPECS:-"cv1:1 cv1:8 encode1:8 pool:8 encode2:8 pool2:8 encode1:64 pool:64 encode2:64 pool2:64 select32:1 select32:8 select32_l2:8 random16:1 random16:8"}
+for spec in $SPECS; do
     k=${spec%%:*}; b=${spec##*:}; tag=${k}_b${b}
     cmd="python $REPO/tools/roofline_micro.py --kernel $k --batch $b --reps 25"
     $cmd > "$OUT/$tag.info" 2>/dev/null

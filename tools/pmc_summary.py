@@ -5,7 +5,8 @@ FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-reports wide coalesced reads
 (MI355X_MICROARCH.md, HBM section), so both the raw and the fetch-doubled totals are kept."""
 import csv, glob, json, os, sys
 
-KNAME = {"cv1": "cv1_kernel", "pool": "softmax_pool", "pool2": "softmax_pool", "encode1": "cv_encode1", "encode2": "cv_encode2"}
+KNAME = {"cv1": "cv1_kernel", "pool": "softmax_pool", "pool2": "softmax_pool", "encode1": "cv_encode1", "encode2": "cv_encode2",
+         "select32": "group_select_k", "select32_l2": "group_select_k", "random16": "group_random_k"}
 
 
 def main(src, dst):

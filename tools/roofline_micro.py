@@ -1,6 +1,6 @@
 """Launch one cost-volume kernel repeatedly (for rocprofv3 --kernel-trace / --pmc captures).
 
-    python tools/roofline_micro.py --kernel cv1|pool|pool2|encode1|encode2 --batch B [--reps N]
+    python tools/roofline_micro.py --kernel cv1|pool|pool2|encode1|encode2|select32|select32_l2|random16 --batch B [--reps N]
 cv1     = fused stage 1 at l0 (16x225, K=6, C=16)          -> cv1_kernel
 pool    = per-operator masked softmax pool, K=6 (P1 term)  -> softmax_pool_vec_kernel
 pool2   = the same with K=4 (P2 term)
@@ -49,6 +49,20 @@ elif a.kernel in ("pool", "pool2"):
     mask = (torch.rand((B, N, K), generator=g) > 0.1).float().to(dev)
     run = lambda: ops.masked_softmax_pool(logits, values, mask)
     info = {"algorithmic_bytes": cvb["P1" if a.kernel == "pool" else "P2"] * B}
+elif a.kernel in ("select32", "select32_l2", "random16"):
+    # the stand-alone grouping ops (no valid_* outputs).  select32: every pixel of a 64x1800 grid, 5x35 window, K=32
+    # (the window / K of the l2_origin cost volume on BASELINE config 1's grid); select32_l2: that call at its real
+    # size (4x57); random16: BASELINE configs[0] (9x15, K=16, d=0.5)
+    gh, gw, win, K, dist, op = {"select32": (64, 1800, (5, 35), 32, 1000.0, elo.fused_conv_select_k),
+                                "select32_l2": (4, 57, (5, 35), 32, 1000.0, elo.fused_conv_select_k),
+                                "random16": (64, 1800, (9, 15), 16, 0.5, elo.fused_conv_random_k)}[a.kernel]
+    g1, g2 = synth.frame_pair(B, gh, gw, seed=5)
+    gx1, gx2 = torch.from_numpy(g1).to(dev), torch.from_numpy(g2).to(dev)
+    hw = torch.from_numpy(synth.hw_index(B, gh, gw)).to(dev)
+    KT, n = win[0] * win[1], gh * gw
+    order_g = torch.randperm(KT, generator=g).to(torch.int32).to(dev)
+    run = lambda: op(gx1, gx2, hw, order_g, gh, gw, n, win[0], win[1], K, 0, dist, 1, 1, want_valid=False)
+    info = {"algorithmic_bytes": (n * 12 + n * 8 + n * 12 + KT * 4 + n * K * 16) * B}
 elif a.kernel == "encode2":
     Kp = 4
     order2 = torch.randperm(3 * 5, generator=g).to(torch.int32).to(dev)
