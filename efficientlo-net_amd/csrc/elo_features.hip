@@ -420,25 +420,30 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_partial_kernel(const 
     const int slice = blockIdx.x, b = blockIdx.y, lane = threadIdx.x % ELO_WAVE, wave = threadIdx.x / ELO_WAVE;
     const int c = blockIdx.z * ELO_WAVE + lane;
     const bool live = c < C;
+    const int cc = live ? c : C - 1;                  // clamped: dead lanes load a real channel and drop it
     const float *f = feature + (long)b * npoints * C;
     const float *w = weight + (long)b * npoints * C;
     const float *p = xyz + (long)b * npoints * 3;
     const int per = (npoints + parts - 1) / parts;
     const int lo = slice * per, hi = min(npoints, lo + per);
     float mx = -INFINITY, den = 0.0f, acc = 0.0f;
-    for (int n0 = lo + wave; n0 < hi; n0 += 4 * ROWS_PER_BLOCK) {
-        float l[4], v[4];
-        bool ok[4];
+    constexpr int SV_ROWS = 16;                       // rows in flight per wave: a slice of <= 64 rows is ONE round trip
+    for (int n0 = lo + wave; n0 < hi; n0 += SV_ROWS * ROWS_PER_BLOCK) {
+        float l[SV_ROWS], v[SV_ROWS];
+        bool ok[SV_ROWS];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                 // four rows in flight per wave: the loop is latency-bound
+        for (int u = 0; u < SV_ROWS; ++u) {           // the loop is latency-bound: all loads first
             const int n = n0 + u * ROWS_PER_BLOCK;
             const int nn = n < hi ? n : hi - 1;
-            ok[u] = n < hi && live && !(p[nn * 3 + 0] == 0.0f && p[nn * 3 + 1] == 0.0f && p[nn * 3 + 2] == 0.0f);
-            l[u] = live ? w[(long)nn * C + c] : 0.0f;
-            v[u] = live ? f[(long)nn * C + c] : 0.0f;
+            // plain loads, no short-circuit: a conditional load costs a full s_waitcnt vmcnt(0) each (measured: the
+            // `a && b && c` form of the zero test serialised three round trips per row)
+            const float px = p[nn * 3 + 0], py = p[nn * 3 + 1], pz = p[nn * 3 + 2];
+            l[u] = w[(long)nn * C + cc];
+            v[u] = f[(long)nn * C + cc];
+            ok[u] = (n < hi) & live & !((px == 0.0f) & (py == 0.0f) & (pz == 0.0f));
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SV_ROWS; ++u) {
             if (!ok[u]) continue;
             if (l[u] > mx) {
                 const float sc = expf(mx - l[u]);      // exp(-inf) = 0 on the first valid point
@@ -519,12 +524,20 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
         const int c = tid & 63, q = tid >> 6;
         float M = -INFINITY, D = 0.0f, A = 0.0f;
         if (c < a.C) {
-            for (int i = q; i < parts; i += 4) {
-                const size_t at = ((size_t)b * ELO_SV_MAX_PARTS + i) * a.C + c;
-                if (s.den[at] == 0.0f) continue;
-                const float m2 = s.mx[at];
-                if (m2 > M) { const float sc = expf(M - m2); D = D * sc + s.den[at]; A = A * sc + s.acc[at]; M = m2; }
-                else { const float sc = expf(m2 - M); D += s.den[at] * sc; A += s.acc[at] * sc; }
+            constexpr int MINE = ELO_SV_MAX_PARTS / 4;    // slices per thread: all their loads go out together
+            float m_[MINE], d_[MINE], a_[MINE];
+#pragma unroll
+            for (int u = 0; u < MINE; ++u) {
+                const int i = q + 4 * u;
+                const size_t at = ((size_t)b * ELO_SV_MAX_PARTS + (i < parts ? i : 0)) * a.C + c;
+                m_[u] = s.mx[at]; a_[u] = s.acc[at];
+                d_[u] = i < parts ? s.den[at] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < MINE; ++u) {
+                if (d_[u] == 0.0f) continue;
+                if (m_[u] > M) { const float sc = expf(M - m_[u]); D = D * sc + d_[u]; A = A * sc + a_[u]; M = m_[u]; }
+                else { const float sc = expf(m_[u] - M); D += d_[u] * sc; A += a_[u] * sc; }
             }
         }
         mpart[(0 * 4 + q) * 64 + c] = M; mpart[(1 * 4 + q) * 64 + c] = D; mpart[(2 * 4 + q) * 64 + c] = A;
@@ -545,6 +558,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
     __syncthreads();
     for (int j = tid; j < a.hidden; j += blockDim.x) {     // conv1d C -> hidden, no activation (:197)
         float v = a.b_big[j];
+#pragma unroll 16
         for (int c = 0; c < a.C; ++c) v += feat[c] * a.W_big[(size_t)c * a.hidden + j];
         big[j] = v;
     }

@@ -526,6 +526,8 @@ __device__ __forceinline__ void small_layer(const float (&x)[32], float (&y)[32]
     }
 }
 
+constexpr int SMALL_STEPS = 5;                    // window steps of 32 slots held in flight: windows up to 160 slots
+
 template <int CIN, int N1, int N2, int N3>
 __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setconv_args a)
 {
@@ -535,17 +537,30 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
     __shared__ float wsm[WEND];
     __shared__ int slot_hw[PER_BLOCK][G];
     const int tid = threadIdx.x;
-    for (int i = tid; i < WEND; i += ELO_BLOCK) {
-        float v;
-        if (i < B1) v = a.layers[0].w_plain[i - W1];
-        else if (i < W2) v = a.layers[0].bias[i - B1];
-        else if (i < B2) v = a.layers[1].w_plain[i - W2];
-        else if (i < W3) v = a.layers[1].bias[i - B2];
-        else if (i < B3) v = a.layers[2].w_plain[i - W3];
-        else v = a.layers[2].bias[i - B3];
-        wsm[i] = v;
+    // The kernel is a chain of dependent L2 round trips, so everything whose address is known is requested at once and
+    // only consumed later: (1) the weights (into registers; written to LDS just before the MLP), (2) the visiting
+    // order of all window steps; then, once the centre is known, (3) every window slot of every step.  Loads are
+    // unconditional (clamped indices, selected pointers): a conditional load costs its own s_waitcnt vmcnt(0).
+    constexpr int WITER = (WEND + ELO_BLOCK - 1) / ELO_BLOCK;
+    float wv[WITER];
+#pragma unroll
+    for (int u = 0; u < WITER; ++u) {
+        const int i = tid + u * ELO_BLOCK < WEND ? tid + u * ELO_BLOCK : WEND - 1;
+        const float *src = i < B1 ? a.layers[0].w_plain + (i - W1) : i < W2 ? a.layers[0].bias + (i - B1)
+                         : i < B2 ? a.layers[1].w_plain + (i - W2) : i < W3 ? a.layers[1].bias + (i - B2)
+                         : i < B3 ? a.layers[2].w_plain + (i - W3) : a.layers[2].bias + (i - B3);
+        wv[u] = *src;
     }
     const int g = tid / G, lane = tid % G, shift = (tid & 63) / G * G;
+    const elo_group_spec &gs = a.group;
+    const int KT = gs.kernel_h * gs.kernel_w, kW = gs.kernel_w, hh = gs.kernel_h / 2, hw2 = gs.kernel_w / 2;
+    int off[SMALL_STEPS];
+#pragma unroll
+    for (int st = 0; st < SMALL_STEPS; ++st) {
+        const int i = st * G + lane;
+        const int p = gs.random_hw[i < KT ? i : 0];
+        off[st] = ((p / kW - hh) << 16) | ((p % kW - hw2) & 0xffff);
+    }
     const long total = (long)a.batch * a.npoints;
     const long pt = (long)xcd_tile(blockIdx.x, gridDim.x) * PER_BLOCK + g;
     const bool live = pt < total;
@@ -554,28 +569,30 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
     const int hc = a.centre_hw ? a.centre_hw[ptc * 2 + 0] : n / a.W, wc = a.centre_hw ? a.centre_hw[ptc * 2 + 1] : n - (n / a.W) * a.W;
     const float *cp = a.xyz1_grid + (((long)b * a.H + hc) * a.W + wc) * 3;
     const float cx = cp[0], cy = cp[1], cz = cp[2];
-    if (live && lane < 3 && a.new_xyz) a.new_xyz[pt * 3 + lane] = lane == 0 ? cx : lane == 1 ? cy : cz;
-
-    // ---- random-k, 32 window slots per step (fused_conv_g.cu:74-152)
-    const elo_group_spec &gs = a.group;
-    const int KT = gs.kernel_h * gs.kernel_w, kW = gs.kernel_w, hh = gs.kernel_h / 2, hw2 = gs.kernel_w / 2;
-    const float r2 = gs.distance * gs.distance;
     const float *grid2 = a.src_xyz + (size_t)b * a.H2 * a.W2 * 3;
     const int base_h = hc / gs.stride_h, base_w = wc / gs.stride_w;
+    RawSlot raw[SMALL_STEPS];
+#pragma unroll
+    for (int st = 0; st < SMALL_STEPS; ++st) raw[st] = fetch_slot(grid2, a.H2, a.W2, off[st], base_h, base_w, st * G + lane < KT);
+    if (live && lane < 3 && a.new_xyz) a.new_xyz[pt * 3 + lane] = lane == 0 ? cx : lane == 1 ? cy : cz;
+
+    // ---- random-k, 32 window slots per step (fused_conv_g.cu:74-152): the walk stops once 32 hits are taken
+    const float r2 = gs.distance * gs.distance;
     slot_hw[g][lane] = -1;
     int taken = 0;
-    if (!(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS)) {
-        for (int base = 0; base < KT && taken < G; base += G) {
-            const int i = base + lane;
-            const int p = gs.random_hw[i < KT ? i : 0];
-            const int off = ((p / kW - hh) << 16) | ((p % kW - hw2) & 0xffff);
-            const Probe pr = judge(fetch_slot(grid2, a.H2, a.W2, off, base_h, base_w, i < KT), cx, cy, cz, r2);
-            const unsigned long long mh = group_ballot<G>(pr.hit, shift);
-            const int slot = taken + __popcll(mh & ((1ull << lane) - 1ull));
-            if (pr.hit && slot < G) slot_hw[g][slot] = pr.hw;
-            taken += __popcll(mh);
-        }
+    const bool centre_ok = !(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS);
+#pragma unroll
+    for (int st = 0; st < SMALL_STEPS; ++st) {
+        const Probe pr = judge(raw[st], cx, cy, cz, r2);
+        const bool hit = pr.hit && centre_ok && taken < G;          // (st * G < KT is in raw[st].in_grid)
+        const unsigned long long mh = group_ballot<G>(hit, shift);
+        const int slot = taken + __popcll(mh & ((1ull << lane) - 1ull));
+        if (hit && slot < G) slot_hw[g][slot] = pr.hw;
+        taken += __popcll(mh);
     }
+#pragma unroll
+    for (int u = 0; u < WITER; ++u)
+        if (tid + u * ELO_BLOCK < WEND) wsm[tid + u * ELO_BLOCK] = wv[u];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int hw = slot_hw[g][lane];                         // this lane's neighbour (row `lane` of the centre)
@@ -871,7 +888,7 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
     const long points = (long)a->batch * a->npoints;
     if (points == 0) return ELO_OK;
     if (!b && a->group.random_hw && a->K == 32 && a->n_layers == 3 && a->layers[0].w_plain && a->layers[1].w_plain &&
-        a->layers[2].w_plain) {                     // narrow chains: wave-per-point VALU kernel
+        a->layers[2].w_plain && a->group.kernel_h * a->group.kernel_w <= SMALL_STEPS * 32) {                     // narrow chains: wave-per-point VALU kernel
         const int cin = 3 + a->C, n1 = a->layers[0].N, n2 = a->layers[1].N, n3 = a->layers[2].N;
         const unsigned grid = (unsigned)((points + 7) / 8);
         if (int rc = check_group(a->group, a->H2, a->W2, 0, who)) return rc;
