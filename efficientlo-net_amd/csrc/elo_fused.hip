@@ -554,19 +554,21 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
     const int g = tid / G, lane = tid % G, shift = (tid & 63) / G * G;
     const elo_group_spec &gs = a.group;
     const int KT = gs.kernel_h * gs.kernel_w, kW = gs.kernel_w, hh = gs.kernel_h / 2, hw2 = gs.kernel_w / 2;
-    int off[SMALL_STEPS];
+    int off[SMALL_STEPS];                                    // the visiting order first, decoded after the centre load is out
 #pragma unroll
-    for (int st = 0; st < SMALL_STEPS; ++st) {
-        const int i = st * G + lane;
-        const int p = gs.random_hw[i < KT ? i : 0];
-        off[st] = ((p / kW - hh) << 16) | ((p % kW - hw2) & 0xffff);
-    }
+    for (int st = 0; st < SMALL_STEPS; ++st) off[st] = gs.random_hw[st * G + lane < KT ? st * G + lane : 0];
     const long total = (long)a.batch * a.npoints;
     const long pt = (long)xcd_tile(blockIdx.x, gridDim.x) * PER_BLOCK + g;
     const bool live = pt < total;
     const long ptc = live ? pt : total - 1;                 // dead groups shadow the last point and store nothing
     const int b = (int)(ptc / a.npoints), n = (int)(ptc - (long)b * a.npoints);
-    const int hc = a.centre_hw ? a.centre_hw[ptc * 2 + 0] : n / a.W, wc = a.centre_hw ? a.centre_hw[ptc * 2 + 1] : n - (n / a.W) * a.W;
+    int hc = n / a.W, wc = n - (n / a.W) * a.W;
+    if (a.centre_hw) {                                       // one 8-byte load, in the first batch
+        const int2 c2 = reinterpret_cast<const int2 *>(a.centre_hw)[ptc];
+        hc = c2.x; wc = c2.y;
+    }
+#pragma unroll
+    for (int st = 0; st < SMALL_STEPS; ++st) off[st] = ((off[st] / kW - hh) << 16) | ((off[st] % kW - hw2) & 0xffff);
     const float *cp = a.xyz1_grid + (((long)b * a.H + hc) * a.W + wc) * 3;
     const float cx = cp[0], cy = cp[1], cz = cp[2];
     const float *grid2 = a.src_xyz + (size_t)b * a.H2 * a.W2 * 3;
@@ -606,11 +608,13 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
 
     // ---- gather + centre-subtract + concat, then the MLP in registers (:203-222)
     float x[32], y[32];
-    const float *sx = a.src_xyz + cell * 3;
-    x[0] = sx[0] * m - cx; x[1] = sx[1] * m - cy; x[2] = sx[2] * m - cz;
-    const float *sf = a.src_feat + cell * C;
+    const float *sx = a.src_xyz + cell * 3, *sf = a.src_feat + cell * C;
+    const float s0 = sx[0], s1 = sx[1], s2 = sx[2];
 #pragma unroll
-    for (int c = 0; c < C; ++c) x[3 + c] = sf[c] * m;
+    for (int c = 0; c < C; ++c) x[3 + c] = sf[c];              // all of the row's loads go out before the first use
+    x[0] = s0 * m - cx; x[1] = s1 * m - cy; x[2] = s2 * m - cz;
+#pragma unroll
+    for (int c = 0; c < C; ++c) x[3 + c] *= m;
     __syncthreads();                                          // weights staged (issued first, needed only now)
     small_layer<CIN, N1>(x, y, wsm + W1, wsm + B1, a.layers[0].relu);
     small_layer<N1, N2>(y, x, wsm + W2, wsm + B2, a.layers[1].relu);
