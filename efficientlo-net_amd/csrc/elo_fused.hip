@@ -353,6 +353,92 @@ __device__ __forceinline__ float geo_channel(const float *p, const float *g, flo
     return sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + 1e-20f);
 }
 
+// ---- staging a tile's rows: vector loads, ALL requested before the first LDS write --------------------------
+// A segment = W consecutive floats of one global row per tile row (W % 4 == 0, 16-byte aligned), written to
+// act[row*S + col0 ..) times a per-row scale (the mask), zeros for rows not in use.  A thread owns the 16-byte items
+// tid, tid+256, ... of the TILE*(W/4) of a segment; the segments of a gather are loaded back to back and stored
+// afterwards, so the whole gather is ONE round trip to L2.  (The element-per-thread loops this replaces had their
+// load under a condition, which costs a full s_waitcnt vmcnt(0) per iteration: 4...13 dependent round trips per tile.)
+constexpr int SEG_ITEMS = 4;                        // per thread: TILE(32) * W(128) / 4 / FUSED_BLOCK
+
+__device__ __forceinline__ bool seg_ok(const void *p, int W, int rows)
+{
+    return W > 0 && (W & 3) == 0 && ((uintptr_t)p & 15) == 0 && rows * (W >> 2) <= SEG_ITEMS * FUSED_BLOCK;
+}
+
+__device__ __forceinline__ void seg_split(int it, int q, int &row, int &c4)
+{
+    if ((q & (q - 1)) == 0) { const int sh = __builtin_ctz(q); row = it >> sh; c4 = it & (q - 1); }   // uniform branch
+    else { row = it / q; c4 = it - row * q; }
+}
+
+// rowof(row) -> source row (long), negative = row not in use (the load then reads source row 0 and is dropped)
+template <int TILE, class RowOf>
+__device__ __forceinline__ void seg_load(float4 (&r)[SEG_ITEMS], const float *__restrict__ src, int W, RowOf rowof)
+{
+    const int q = W >> 2, items = TILE * q;
+#pragma unroll
+    for (int u = 0; u < SEG_ITEMS; ++u) {
+        const int it = threadIdx.x + u * FUSED_BLOCK < items ? threadIdx.x + u * FUSED_BLOCK : items - 1;
+        int row, c4;
+        seg_split(it, q, row, c4);
+        const long sr = rowof(row);
+        r[u] = reinterpret_cast<const float4 *>(src + (sr < 0 ? 0 : sr) * W)[c4];
+    }
+}
+
+template <int TILE, class RowOf, class ScaleOf>
+__device__ __forceinline__ void seg_store(float *act, int S, int col0, int W, const float4 (&r)[SEG_ITEMS], RowOf rowof,
+                                          ScaleOf scaleof)
+{
+    const int q = W >> 2, items = TILE * q;
+#pragma unroll
+    for (int u = 0; u < SEG_ITEMS; ++u) {
+        const int it = threadIdx.x + u * FUSED_BLOCK;
+        if (it < items) {
+            int row, c4;
+            seg_split(it, q, row, c4);
+            const bool used = rowof(row) >= 0;
+            const float sc = scaleof(row);
+            float *o = act + row * S + col0 + 4 * c4;
+            o[0] = used ? r[u].x * sc : 0.0f; o[1] = used ? r[u].y * sc : 0.0f;
+            o[2] = used ? r[u].z * sc : 0.0f; o[3] = used ? r[u].w * sc : 0.0f;
+        }
+    }
+}
+
+// zero the padding columns [from, to) of every tile row
+template <int TILE>
+__device__ __forceinline__ void zero_cols(float *act, int S, int from, int to)
+{
+    const int w = to - from;
+    for (int e = threadIdx.x; e < TILE * w; e += FUSED_BLOCK) act[(e / w) * S + from + e % w] = 0.0f;
+}
+
+// the 10 geometry floats of a row (PAD: + 6 zeros): [p, g*m, g*m - p, |g*m - p|]   utils/pointnet_util.py:54-62.
+// Thread r < TILE loads its row's centre p and neighbour g (unconditional, clamped) -- call geo_load with the other
+// loads of the gather, geo_store with the stores.
+struct GeoRow { float p[3], g[3]; };
+
+__device__ __forceinline__ GeoRow geo_load(const float *__restrict__ pc, const float *__restrict__ pg)
+{
+    return GeoRow{{pc[0], pc[1], pc[2]}, {pg[0], pg[1], pg[2]}};
+}
+
+template <bool PAD>
+__device__ __forceinline__ void geo_store(float *o, const GeoRow &r, float m, bool used)
+{
+    const float g0 = r.g[0] * m, g1 = r.g[1] * m, g2 = r.g[2] * m;
+    const float d0 = g0 - r.p[0], d1 = g1 - r.p[1], d2 = g2 - r.p[2];
+    const float v[10] = {r.p[0], r.p[1], r.p[2], g0, g1, g2, d0, d1, d2, sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + 1e-20f)};
+#pragma unroll
+    for (int i = 0; i < 10; ++i) o[i] = used ? v[i] : 0.0f;
+    if (PAD) {
+#pragma unroll
+        for (int i = 10; i < 16; ++i) o[i] = 0.0f;
+    }
+}
+
 // ---- poolings over the K rows of each point of the tile (one (point, channel) per thread) ------
 // The K rows of a point are fetched in chunks of 8 INDEPENDENT LDS reads (a serial "read mask -> branch -> read
 // value" chain cost ~0.3 us per neighbour, 7 us per cost-volume tile).
@@ -468,16 +554,28 @@ __global__ __launch_bounds__(FUSED_BLOCK, 4) void setconv_kernel(const JobPair<e
     }
     // gather + centre-subtract + concat into act[row][0 .. CTp)                   :203-213 / :277-284
     const int CT = 3 + a.C, CTp = ceil16(CT);
-    for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {
-        const int row = e / CTp, ch = e - row * CTp;
-        const int cell = meta.cell[row];
-        float v = 0.0f;
-        if (cell >= 0 && ch < CT) {
-            const float m = meta.mask[row];
-            v = ch < 3 ? a.src_xyz[(long)cell * 3 + ch] * m - meta.cxyz[(row / K) * 3 + ch]
-                       : a.src_feat[(long)cell * a.C + (ch - 3)] * m;
+    if (seg_ok(a.src_feat, a.C, TILE)) {
+        auto cell_of = [&](int row) { return (long)meta.cell[row]; };
+        float4 rf[SEG_ITEMS];
+        seg_load<TILE>(rf, a.src_feat, a.C, cell_of);
+        float xyz = 0.0f;
+        const int xr = tid / 3, xc = tid - xr * 3;                           // thread t < 3*TILE: one coordinate of row t/3
+        if (tid < TILE * 3) xyz = a.src_xyz[(long)(meta.cell[xr] < 0 ? 0 : meta.cell[xr]) * 3 + xc];
+        seg_store<TILE>(act, S, 3, a.C, rf, cell_of, [&](int row) { return meta.mask[row]; });
+        if (tid < TILE * 3) act[xr * S + xc] = meta.cell[xr] >= 0 ? xyz * meta.mask[xr] - meta.cxyz[(xr / K) * 3 + xc] : 0.0f;
+        zero_cols<TILE>(act, S, CT, CTp);
+    } else {
+        for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {
+            const int row = e / CTp, ch = e - row * CTp;
+            const int cell = meta.cell[row];
+            float v = 0.0f;
+            if (cell >= 0 && ch < CT) {
+                const float m = meta.mask[row];
+                v = ch < 3 ? a.src_xyz[(long)cell * 3 + ch] * m - meta.cxyz[(row / K) * 3 + ch]
+                           : a.src_feat[(long)cell * a.C + (ch - 3)] * m;
+            }
+            act[row * S + ch] = v;
         }
-        act[row * S + ch] = v;
     }
     __syncthreads();
     for (int l = 0; l < a.n_layers; ++l) dense<TILE>(act, S, 0, 0, a.layers[l]);    // in place, :217-222
@@ -641,16 +739,29 @@ __global__ __launch_bounds__(FUSED_BLOCK, 4) void mlp_kernel(const JobPair<elo_m
     if (first >= a.rows) return;
     const int w0 = a.src_width[0], w1 = a.n_sources > 1 ? a.src_width[1] : 0, w2 = a.n_sources > 2 ? a.src_width[2] : 0;
     const int CT = w0 + w1 + w2, CTp = ceil16(CT);
-    for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {
-        const int row = e / CTp, ch = e - row * CTp;
-        const long gr = first + row;
-        float v = 0.0f;
-        if (gr < a.rows && ch < CT) {
-            v = ch < w0 ? a.src[0][gr * w0 + ch]
-              : ch < w0 + w1 ? a.src[1][gr * w1 + (ch - w0)]
-                             : a.src[2][gr * w2 + (ch - w0 - w1)];
+    if (seg_ok(a.src[0], w0, TILE) && (w1 == 0 || seg_ok(a.src[1], w1, TILE)) && (w2 == 0 || seg_ok(a.src[2], w2, TILE))) {
+        auto row_of = [&](int row) { return first + row < a.rows ? first + row : -1L; };
+        auto one = [](int) { return 1.0f; };
+        float4 r0[SEG_ITEMS], r1[SEG_ITEMS], r2[SEG_ITEMS];
+        seg_load<TILE>(r0, a.src[0], w0, row_of);
+        if (w1) seg_load<TILE>(r1, a.src[1], w1, row_of);
+        if (w2) seg_load<TILE>(r2, a.src[2], w2, row_of);
+        seg_store<TILE>(act, S, 0, w0, r0, row_of, one);
+        if (w1) seg_store<TILE>(act, S, w0, w1, r1, row_of, one);
+        if (w2) seg_store<TILE>(act, S, w0 + w1, w2, r2, row_of, one);
+        zero_cols<TILE>(act, S, CT, CTp);
+    } else {
+        for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {
+            const int row = e / CTp, ch = e - row * CTp;
+            const long gr = first + row;
+            float v = 0.0f;
+            if (gr < a.rows && ch < CT) {
+                v = ch < w0 ? a.src[0][gr * w0 + ch]
+                  : ch < w0 + w1 ? a.src[1][gr * w1 + (ch - w0)]
+                                 : a.src[2][gr * w2 + (ch - w0 - w1)];
+            }
+            act[row * S + ch] = v;
         }
-        act[row * S + ch] = v;
     }
     __syncthreads();
     for (int l = 0; l < a.n_layers; ++l) dense<TILE>(act, S, 0, 0, a.layers[l]);
@@ -685,18 +796,34 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv1_kernel(const elo_cv1_args a, 
         __syncthreads();
     }
     const int F = 128, CT = 10 + 2 * C, CTp = ceil16(CT);
-    for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {                             // :54-66
-        const int row = e / CTp, ch = e - row * CTp;
-        const int cell = meta.cell[row];
-        float v = 0.0f;
-        if (cell >= 0 && ch < CT) {
-            const float m = meta.mask[row];
-            const long pt = first_point + row / K;
-            if (ch < 10) v = geo_channel(a.xyz1 + pt * 3, a.xyz2 + (long)cell * 3, m, ch);
-            else if (ch < 10 + C) v = a.feat1[pt * C + (ch - 10)];
-            else v = a.feat2[(long)cell * C + (ch - 10 - C)] * m;
+    if (seg_ok(a.feat1, C, TILE) && seg_ok(a.feat2, C, TILE)) {                                   // :54-66
+        auto cell_of = [&](int row) { return (long)meta.cell[row]; };
+        auto centre_of = [&](int row) { return meta.cell[row] >= 0 ? first_point + row / K : -1L; };
+        float4 r1[SEG_ITEMS], r2[SEG_ITEMS];
+        seg_load<TILE>(r1, a.feat1, C, centre_of);
+        seg_load<TILE>(r2, a.feat2, C, cell_of);
+        GeoRow gr;
+        const bool grow = tid < TILE;
+        const int gcell = grow ? meta.cell[tid] : -1;
+        if (grow) gr = geo_load(a.xyz1 + (gcell >= 0 ? first_point + tid / K : 0) * 3, a.xyz2 + (long)(gcell >= 0 ? gcell : 0) * 3);
+        seg_store<TILE>(act, S, F + 10, C, r1, centre_of, [](int) { return 1.0f; });
+        seg_store<TILE>(act, S, F + 10 + C, C, r2, cell_of, [&](int row) { return meta.mask[row]; });
+        if (grow) geo_store<false>(act + tid * S + F, gr, meta.mask[tid], gcell >= 0);   // columns [F, F+10)
+        zero_cols<TILE>(act, S, F + CT, F + CTp);
+    } else {
+        for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {
+            const int row = e / CTp, ch = e - row * CTp;
+            const int cell = meta.cell[row];
+            float v = 0.0f;
+            if (cell >= 0 && ch < CT) {
+                const float m = meta.mask[row];
+                const long pt = first_point + row / K;
+                if (ch < 10) v = geo_channel(a.xyz1 + pt * 3, a.xyz2 + (long)cell * 3, m, ch);
+                else if (ch < 10 + C) v = a.feat1[pt * C + (ch - 10)];
+                else v = a.feat2[(long)cell * C + (ch - 10 - C)] * m;
+            }
+            act[row * S + F + ch] = v;
         }
-        act[row * S + F + ch] = v;
     }
     Pre<TILE, 128> p128;
     Pre<TILE, 64> p64;
@@ -734,22 +861,38 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv2_kernel(const elo_cv2_args a, 
         __syncthreads();
     }
     const int Cp = ceil16(C), XYZ = 192;
-    for (int e = tid; e < TILE * 64; e += FUSED_BLOCK) {                              // grouped cost * mask  :110
-        const int row = e >> 6, ch = e & 63;
-        const int cell = meta.cell[row];
-        act[row * S + ch] = cell >= 0 ? a.cost[(long)cell * 64 + ch] * meta.mask[row] : 0.0f;
-    }
-    for (int e = tid; e < TILE * Cp; e += FUSED_BLOCK) {                              // centre features      :115
-        const int row = e / Cp, ch = e - row * Cp;
-        const long pt = first_point + row / K;
-        act[row * S + 128 + ch] = (meta.cell[row] >= 0 && ch < C) ? a.feat1[pt * C + ch] : 0.0f;
-    }
-    for (int e = tid; e < TILE * 16; e += FUSED_BLOCK) {                              // 10-channel geometry  :111-120
-        const int row = e >> 4, ch = e & 15;
-        const int cell = meta.cell[row];
-        const long pt = first_point + row / K;
-        act[row * S + XYZ + ch] = (cell >= 0 && ch < 10)
-            ? geo_channel(a.xyz1 + pt * 3, a.xyz1 + (long)cell * 3, meta.mask[row], ch) : 0.0f;
+    if (seg_ok(a.cost, 64, TILE) && seg_ok(a.feat1, C, TILE)) {
+        auto cell_of = [&](int row) { return (long)meta.cell[row]; };
+        auto centre_of = [&](int row) { return meta.cell[row] >= 0 ? first_point + row / K : -1L; };
+        float4 rc[SEG_ITEMS], rf[SEG_ITEMS];
+        seg_load<TILE>(rc, a.cost, 64, cell_of);                                      // grouped cost * mask  :110
+        seg_load<TILE>(rf, a.feat1, C, centre_of);                                    // centre features      :115
+        GeoRow gr;
+        const bool grow = tid < TILE;
+        const int gcell = grow ? meta.cell[tid] : -1;
+        if (grow) gr = geo_load(a.xyz1 + (gcell >= 0 ? first_point + tid / K : 0) * 3, a.xyz1 + (long)(gcell >= 0 ? gcell : 0) * 3);
+        seg_store<TILE>(act, S, 0, 64, rc, cell_of, [&](int row) { return meta.mask[row]; });
+        seg_store<TILE>(act, S, 128, C, rf, centre_of, [](int) { return 1.0f; });
+        zero_cols<TILE>(act, S, 128 + C, 128 + Cp);
+        if (grow) geo_store<true>(act + tid * S + XYZ, gr, meta.mask[tid], gcell >= 0);   // 10-channel geometry + 6 zeros  :111-120
+    } else {
+        for (int e = tid; e < TILE * 64; e += FUSED_BLOCK) {
+            const int row = e >> 6, ch = e & 63;
+            const int cell = meta.cell[row];
+            act[row * S + ch] = cell >= 0 ? a.cost[(long)cell * 64 + ch] * meta.mask[row] : 0.0f;
+        }
+        for (int e = tid; e < TILE * Cp; e += FUSED_BLOCK) {
+            const int row = e / Cp, ch = e - row * Cp;
+            const long pt = first_point + row / K;
+            act[row * S + 128 + ch] = (meta.cell[row] >= 0 && ch < C) ? a.feat1[pt * C + ch] : 0.0f;
+        }
+        for (int e = tid; e < TILE * 16; e += FUSED_BLOCK) {
+            const int row = e >> 4, ch = e & 15;
+            const int cell = meta.cell[row];
+            const long pt = first_point + row / K;
+            act[row * S + XYZ + ch] = (cell >= 0 && ch < 10)
+                ? geo_channel(a.xyz1 + pt * 3, a.xyz1 + (long)cell * 3, meta.mask[row], ch) : 0.0f;
+        }
     }
     Pre<TILE, 128> p128;
     Pre<TILE, 64> p64;
