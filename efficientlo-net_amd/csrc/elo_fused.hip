@@ -54,7 +54,9 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
     constexpr int RB = TILE / 16;                 // row blocks: 1 or 2
     constexpr int CSTEP = FUSED_WAVES / RB;       // column-block stride between a wave's sub-tiles
     constexpr int GS = MAXT >= 4 ? 2 : 4;         // K steps per prefetch group (register budget: 2*GS*MAXT float4)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a SCALAR: row block, column blocks and with them every W / bias base address live in SGPRs,
+    // so a W fragment load is `global_load_dwordx4 v, v_lane_off, s[base] offset:imm` with no vector address arithmetic
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     const int rb = wave % RB, cb0 = wave / RB;
     const int KS = ceil16(L.K) >> 4, CB = ceil16(L.N) >> 4;
@@ -66,7 +68,8 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
         acc[t] = f32x4{bv, bv, bv, bv};
     }
     const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
-    const float4 *w = reinterpret_cast<const float4 *>(L.w_packed) + lane;
+    const char *wbase = reinterpret_cast<const char *>(L.w_packed);
+    const unsigned lane_off = (unsigned)lane * 16u;
 
     // W is streamed from L2 with a load-to-use distance of one whole group of K steps (two register sets).
     // Loads are UNCONDITIONAL (indices clamped into the packed array): with per-lane predicates around them the
@@ -80,7 +83,7 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 const int cb = min(cb0 + t * CSTEP, CB - 1);
-                buf[s][t] = w[(size_t)(cb * KS + ks) * 64];
+                buf[s][t] = *reinterpret_cast<const float4 *>(wbase + (size_t)(cb * KS + ks) * 1024 + lane_off);
             }
         }
     };
@@ -159,18 +162,19 @@ template <int TILE, int N>
 __device__ __forceinline__ void prefetch(const elo_dense &L, Pre<TILE, N> &pre)
 {
     constexpr int RB = TILE / 16, CSTEP = Sub<TILE, N>::CSTEP, MAXT = Sub<TILE, N>::MAXT, GS = Sub<TILE, N>::GS;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, cb0 = wave / RB;
     const int KS = ceil16(L.K) >> 4;
     constexpr int CB = (N + 15) / 16;
-    const float4 *w = reinterpret_cast<const float4 *>(L.w_packed) + lane;
+    const char *wbase = reinterpret_cast<const char *>(L.w_packed);
+    const unsigned lane_off = (unsigned)lane * 16u;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         const int cb = cb0 + t * CSTEP;
         const int cbc = min(cb, CB - 1);
         pre.b[t] = L.bias[cbc * 16 + i16];
 #pragma unroll
-        for (int s = 0; s < GS; ++s) pre.w[s][t] = w[(size_t)(cbc * KS + min(s, KS - 1)) * 64];
+        for (int s = 0; s < GS; ++s) pre.w[s][t] = *reinterpret_cast<const float4 *>(wbase + (size_t)(cbc * KS + min(s, KS - 1)) * 1024 + lane_off);
     }
 }
 
@@ -181,7 +185,9 @@ __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_
 {
     constexpr int RB = TILE / 16, CSTEP = Sub<TILE, N>::CSTEP, MAXT = Sub<TILE, N>::MAXT, GS = Sub<TILE, N>::GS;
     constexpr int CB = (N + 15) / 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a SCALAR: row block, column blocks and with them every W / bias base address live in SGPRs,
+    // so a W fragment load is `global_load_dwordx4 v, v_lane_off, s[base] offset:imm` with no vector address arithmetic
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     const int rb = wave % RB, cb0 = wave / RB;
     const int KS = ceil16(L.K) >> 4;
@@ -190,7 +196,8 @@ __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) acc[t] = f32x4{pre.b[t], pre.b[t], pre.b[t], pre.b[t]};
     const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
-    const float4 *w = reinterpret_cast<const float4 *>(L.w_packed) + lane;
+    const char *wbase = reinterpret_cast<const char *>(L.w_packed);
+    const unsigned lane_off = (unsigned)lane * 16u;
     // Loads are UNCONDITIONAL (indices clamped into the packed array): with per-lane predicates around them the
     // compiler loses track of the outstanding loads and waits vmcnt(0) before every MFMA group, which serialises
     // "prefetch" and compute (measured: 6.5 us for a 128x128 layer whose MFMAs take 1.7 us).  Clamped duplicates are
@@ -202,7 +209,7 @@ __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 const int cb = min(cb0 + t * CSTEP, CB - 1);
-                buf[s][t] = w[(size_t)(cb * KS + ks) * 64];
+                buf[s][t] = *reinterpret_cast<const float4 *>(wbase + (size_t)(cb * KS + ks) * 1024 + lane_off);
             }
         }
     };
