@@ -40,6 +40,20 @@ __host__ __device__ __forceinline__ int row_stride(int cols)
     return s;
 }
 
+// ---- W fragments through buffer addressing ------------------------------------------------------------------
+// buffer_load_dwordx4 v, v_lane_off, s[rsrc], s_off: the 128-bit resource and the fragment's byte offset are scalars,
+// the only vector operand is lane*16 -- no vector address arithmetic per load (a flat/global load needs a 64-bit
+// vector address: 2-4 VALU per fragment, ~90 fragments per wave and tile in the cost-volume kernel).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const float *w)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w), 0, 0x7fffffff, 0x00020000);   // raw, DATA_FORMAT_32
+}
+
+__device__ __forceinline__ float4 weight_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, int byte_off)
+{
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, 0));
+}
+
 // ---- one dense layer on the block's tile ---------------------------------------------------
 // D[TILE x Np] = relu?(A[TILE x Kp] * W + bias) on v_mfma_f32_16x16x4_f32 (exact fp32).  The tile is cut
 // into 16x16 output sub-tiles; wave w owns row block (w % RB) and every (4/RB)-th column block, keeps
@@ -68,7 +82,7 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
         acc[t] = f32x4{bv, bv, bv, bv};
     }
     const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
-    const char *wbase = reinterpret_cast<const char *>(L.w_packed);
+    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);      // buffer addressing: V# + lane offset + scalar offset
     const unsigned lane_off = (unsigned)lane * 16u;
 
     // W is streamed from L2 with a load-to-use distance of one whole group of K steps (two register sets).
@@ -83,7 +97,7 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 const int cb = min(cb0 + t * CSTEP, CB - 1);
-                buf[s][t] = *reinterpret_cast<const float4 *>(wbase + (size_t)(cb * KS + ks) * 1024 + lane_off);
+                buf[s][t] = weight_load(wrsrc, lane_off, (cb * KS + ks) * 1024);
             }
         }
     };
@@ -166,7 +180,7 @@ __device__ __forceinline__ void prefetch(const elo_dense &L, Pre<TILE, N> &pre)
     const int i16 = lane & 15, cb0 = wave / RB;
     const int KS = ceil16(L.K) >> 4;
     constexpr int CB = (N + 15) / 16;
-    const char *wbase = reinterpret_cast<const char *>(L.w_packed);
+    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);      // buffer addressing: V# + lane offset + scalar offset
     const unsigned lane_off = (unsigned)lane * 16u;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
@@ -174,7 +188,7 @@ __device__ __forceinline__ void prefetch(const elo_dense &L, Pre<TILE, N> &pre)
         const int cbc = min(cb, CB - 1);
         pre.b[t] = L.bias[cbc * 16 + i16];
 #pragma unroll
-        for (int s = 0; s < GS; ++s) pre.w[s][t] = *reinterpret_cast<const float4 *>(wbase + (size_t)(cbc * KS + min(s, KS - 1)) * 1024 + lane_off);
+        for (int s = 0; s < GS; ++s) pre.w[s][t] = weight_load(wrsrc, lane_off, (cbc * KS + min(s, KS - 1)) * 1024);
     }
 }
 
@@ -196,7 +210,7 @@ __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) acc[t] = f32x4{pre.b[t], pre.b[t], pre.b[t], pre.b[t]};
     const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
-    const char *wbase = reinterpret_cast<const char *>(L.w_packed);
+    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);      // buffer addressing: V# + lane offset + scalar offset
     const unsigned lane_off = (unsigned)lane * 16u;
     // Loads are UNCONDITIONAL (indices clamped into the packed array): with per-lane predicates around them the
     // compiler loses track of the outstanding loads and waits vmcnt(0) before every MFMA group, which serialises
@@ -209,7 +223,7 @@ __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 const int cb = min(cb0 + t * CSTEP, CB - 1);
-                buf[s][t] = *reinterpret_cast<const float4 *>(wbase + (size_t)(cb * KS + ks) * 1024 + lane_off);
+                buf[s][t] = weight_load(wrsrc, lane_off, (cb * KS + ks) * 1024);
             }
         }
     };
