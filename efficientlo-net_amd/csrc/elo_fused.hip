@@ -797,7 +797,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, 4) void mlp_kernel(const JobPair<elo_m
 // ================================================================ cost volume, stage 1
 // LDS columns: [0,128) = X (CV chain, later [x3 | enc]),  [128, 128 + max(CTp,128)) = F (feat_cat, later sum_CV)
 template <int TILE>
-__global__ __launch_bounds__(FUSED_BLOCK) void cv1_kernel(const elo_cv1_args a, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_kernel(const elo_cv1_args a, const int S)
 {
     extern __shared__ float lds[];
     float *act = lds;
@@ -816,6 +816,10 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv1_kernel(const elo_cv1_args a, 
         load_meta<TILE>(meta, first_point, total_points, P, K, a.idx, a.mask, a.H2, a.W2);
         __syncthreads();
     }
+#if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 1
+    if (tid == 0) a.out[first_point * 64] = meta.mask[0];
+    return;
+#endif
     const int F = 128, CT = 10 + 2 * C, CTp = ceil16(CT);
     if (seg_ok(a.feat1, C, TILE) && seg_ok(a.feat2, C, TILE)) {                                   // :54-66
         auto cell_of = [&](int row) { return (long)meta.cell[row]; };
@@ -850,12 +854,20 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv1_kernel(const elo_cv1_args a, 
     Pre<TILE, 64> p64;
     prefetch<TILE, 128>(a.cv0, p128);           // in flight while the barrier drains the gather
     __syncthreads();
+#if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 2
+    if (tid == 0) a.out[first_point * 64] = act[F] + p128.b[0];
+    return;
+#endif
     dense_pf<TILE, 128, 64>(act, S, F, 0, a.cv0, p128, &a.cv1, &p64);          // feat_cat -> 128          :72-76
     dense_pf<TILE, 64, 64>(act, S, 0, 0, a.cv1, p64, &a.cv2, &p64);            // -> 64 (in place)
     dense_pf<TILE, 64, 64>(act, S, 0, 0, a.cv2, p64, &a.cv_xyz, &p64);         // -> 64 = x   (values of the pooling)
     dense_pf<TILE, 64, 128>(act, S, F, 64, a.cv_xyz, p64, &a.sum_cv0, &p128);  // xyz_cat -> enc at [64,128)   :79-82
     dense_pf<TILE, 128, 64>(act, S, 0, F, a.sum_cv0, p128, &a.sum_cv1, &p64);  // [x | enc] -> 128 into F      :84-90
     dense_pf<TILE, 64, 0>(act, S, F, F, a.sum_cv1, p64, nullptr, nullptr);     // -> 64 logits (in place)
+#if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 3
+    if (tid == 0) a.out[first_point * 64] = act[F];
+    return;
+#endif
     pool_masked_softmax(act, S, F, 0, meta, P, K, first_point, total_points, a.out);    // :92-98
 }
 
@@ -863,7 +875,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void cv1_kernel(const elo_cv1_args a, 
 // LDS columns: [0,64) grouped cost, [64,128) xyz-encoding, [128,128+C) feat1, [192,208) xyz_cat;
 // sum_cost0 reads [0,128+C) and writes [64,192); sum_cost1 maps [64,192) -> [64,128).
 template <int TILE>
-__global__ __launch_bounds__(FUSED_BLOCK) void cv2_kernel(const elo_cv2_args a, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK, 5) void cv2_kernel(const elo_cv2_args a, const int S)
 {
     extern __shared__ float lds[];
     float *act = lds;
