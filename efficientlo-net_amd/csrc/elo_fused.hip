@@ -535,10 +535,11 @@ __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int
 template <typename Args>
 struct JobPair { Args job[2]; };                  // one kernarg block: job[blockIdx.y] is a uniform (scalar) access
 
-// 4 waves per SIMD: caps the kernel at 128 VGPRs (140 uncapped = 3 workgroups per CU); costs 12 bytes of scratch and
-// measured +4 % at batch 8 (6490 -> 6750 pairs/s); a cap of 5 (96 VGPRs, 100-156 bytes of scratch) is 12 % slower.
+// 5 waves per SIMD (<= 102 VGPRs).  History: 140 VGPRs uncapped (3 workgroups per CU); a cap of 4 cost 12 bytes of
+// scratch and gave +4 % at batch 8; with the scalar wave index and buffer-addressed W fragments the kernels need 92-96
+// VGPRs without any spill.  A cap of 6 (80 VGPRs) spills 36-144 bytes in the cost-volume kernels: not taken.
 template <int TILE>
-__global__ __launch_bounds__(FUSED_BLOCK, 4) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK, 5) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
 {
     const elo_setconv_args &a = jobs.job[blockIdx.y];
     extern __shared__ float lds[];
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
 
 // ================================================================ row-wise MLP over concatenated sources
 template <int TILE>
-__global__ __launch_bounds__(FUSED_BLOCK, 4) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK, 5) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
 {
     const elo_mlp_args &a = jobs.job[blockIdx.y];
     extern __shared__ float lds[];
