@@ -6,8 +6,8 @@
 //   tf_ops/2d_conv_select_k/fused_conv_g.cu:11-209   (K nearest, selection sort with swaps)
 // How it computes it is not: the reference runs ONE thread per centre in
 // `batch` blocks and walks the window serially out of global memory.  Here
-//   * a group of G lanes (16/32/64, picked from the window size) owns a centre
-//     and probes G window slots per step;
+//   * a group of G lanes (16/32, picked from the window size and K) owns a centre
+//     and examines G*U window slots per step (U loads in flight per lane);
 //   * the (dh,dw) of every slot in visiting order is decoded once per block
 //     into LDS (no per-candidate integer division);
 //   * output slots are assigned with __ballot + popcount prefix sums, so the
@@ -44,54 +44,69 @@ __device__ __forceinline__ Centre load_centre(const elo_group_args &a, long u)
 }
 
 // ---------------------------------------------------------------- random-k
-template <int G>
+// G lanes own a centre and examine G*U window slots per step: every lane requests its U slots (unconditional,
+// clamped loads) before the first one is judged, so a step is one L2 round trip whatever U is, and a wave carries
+// 64/G centres.  The kernel is a chain of dependent round trips per centre (visiting order, centre index, centre,
+// window), so centres in flight are what it is bound by: for windows above 32 slots G follows K (16 lanes up to
+// K = 16, else 32) with U = 64/G instead of one wave per centre -- 60 -> 40 us on BASELINE configs[0].
+template <int G, int U>
 __global__ __launch_bounds__(ELO_BLOCK) void group_random_k(const elo_group_args a, const long total)
 {
     extern __shared__ int lds_off[];
-    stage_offsets(lds_off, a.random_hw, a.kernel_h, a.kernel_w);
-
     constexpr int PER_BLOCK = ELO_BLOCK / G;
     const int lane = threadIdx.x % G;
     const int shift = (threadIdx.x % ELO_WAVE) / G * G;      // group's first lane in its wave
-    const long u = (long)xcd_tile(blockIdx.x, gridDim.x) * PER_BLOCK + threadIdx.x / G;
-    if (u >= total) return;
+    const long u0 = (long)xcd_tile(blockIdx.x, gridDim.x) * PER_BLOCK + threadIdx.x / G;
+    const long u = u0 < total ? u0 : total - 1;              // a group past the end shadows the last centre, stores nothing
+    const Centre c = load_centre(a, u);                      // requested before the order is staged: overlaps it
+    stage_offsets(lds_off, a.random_hw, a.kernel_h, a.kernel_w);
+    if (u0 >= total) return;
 
     const int KT = a.kernel_h * a.kernel_w, K = a.K;
-    const Centre c = load_centre(a, u);
     const float r2 = a.distance * a.distance;
     const float *grid2 = a.xyz2 + (size_t)c.b * a.H2 * a.W2 * 3;
     int *o_sel = a.selected_bhw_idx + u * K * 3;
     float *o_mask = a.selected_mask + u * K;
 
     int taken = 0, seen = 0, first_hw = -1;
+    bool full = false;
     if (c.ok) {
-        for (int base = 0; base < KT; base += G) {
-            const int i = base + lane;
-            Probe p{false, false, ELO_FAR, 0};
-            if (i < KT) p = probe_slot(grid2, a.H2, a.W2, lds_off[i], c.base_h, c.base_w, c.x, c.y, c.z, r2);
-            const unsigned long long mv = group_ballot<G>(p.valid, shift);
-            const unsigned long long mh = group_ballot<G>(p.hit, shift);
-            if (mh == 0) { seen += __popcll(mv); continue; }
-            const int before = __popcll(mh & ((1ull << lane) - 1ull));
-            const int slot = taken + before;
-            if (p.hit && slot < K) {
-                o_sel[slot * 3 + 0] = c.b;
-                o_sel[slot * 3 + 1] = p.hw >> 16;
-                o_sel[slot * 3 + 2] = p.hw & 0xffff;
-                o_mask[slot] = 1.0f;
+        for (int base = 0; base < KT && !full; base += G * U) {
+            RawSlot raw[U];
+#pragma unroll
+            for (int v = 0; v < U; ++v) {
+                const int i = base + v * G + lane;
+                raw[v] = fetch_slot(grid2, a.H2, a.W2, lds_off[i < KT ? i : 0], c.base_h, c.base_w, i < KT);
             }
-            if (taken == 0) first_hw = __shfl(p.hw, shift + __ffsll((long long)mh) - 1, ELO_WAVE);
-            const int nh = __popcll(mh);
-            if (taken + nh >= K) {
-                // the walk stops AT the K-th hit: valid pixels after it are never counted (:149-150)
-                const unsigned long long kth = group_ballot<G>(p.hit && before == K - taken - 1, shift);
-                const int kl = __ffsll((long long)kth) - 1;
-                seen += __popcll(mv & ((2ull << kl) - 1ull));
-                taken = K;
-                break;
+#pragma unroll
+            for (int v = 0; v < U; ++v) {
+                if (full || base + v * G >= KT) break;
+                const Probe p = judge(raw[v], c.x, c.y, c.z, r2);
+                const unsigned long long mv = group_ballot<G>(p.valid, shift);
+                const unsigned long long mh = group_ballot<G>(p.hit, shift);
+                if (mh == 0) { seen += __popcll(mv); continue; }
+                const int before = __popcll(mh & ((1ull << lane) - 1ull));
+                const int slot = taken + before;
+                if (p.hit && slot < K) {
+                    o_sel[slot * 3 + 0] = c.b;
+                    o_sel[slot * 3 + 1] = p.hw >> 16;
+                    o_sel[slot * 3 + 2] = p.hw & 0xffff;
+                    o_mask[slot] = 1.0f;
+                }
+                if (taken == 0) first_hw = __shfl(p.hw, shift + __ffsll((long long)mh) - 1, ELO_WAVE);
+                const int nh = __popcll(mh);
+                if (taken + nh >= K) {
+                    // the walk stops AT the K-th hit: valid pixels after it are never counted (:149-150)
+                    const unsigned long long kth = group_ballot<G>(p.hit && before == K - taken - 1, shift);
+                    const int kl = __ffsll((long long)kth) - 1;
+                    seen += __popcll(mv & ((2ull << kl) - 1ull));
+                    taken = K;
+                    full = true;
+                    break;
+                }
+                seen += __popcll(mv);
+                taken += nh;
             }
-            seen += __popcll(mv);
-            taken += nh;
         }
     }
     // slots that never got a hit: zeros, or copies of the first hit (flag_copy, :126-138)
@@ -253,16 +268,15 @@ extern "C" int elo_fused_conv_random_k(const elo_group_args *a, elo_stream_t str
     const int KT = a->kernel_h * a->kernel_w;
     const size_t lds = sizeof(int) * KT;
     hipStream_t s = (hipStream_t)stream;
-    if (KT <= 16) {
-        const unsigned grid = (unsigned)((total + ELO_BLOCK / 16 - 1) / (ELO_BLOCK / 16));
-        hipLaunchKernelGGL(group_random_k<16>, dim3(grid), dim3(ELO_BLOCK), lds, s, *a, total);
-    } else if (KT <= 32) {
-        const unsigned grid = (unsigned)((total + ELO_BLOCK / 32 - 1) / (ELO_BLOCK / 32));
-        hipLaunchKernelGGL(group_random_k<32>, dim3(grid), dim3(ELO_BLOCK), lds, s, *a, total);
-    } else {
-        const unsigned grid = (unsigned)((total + ELO_BLOCK / 64 - 1) / (ELO_BLOCK / 64));
-        hipLaunchKernelGGL(group_random_k<64>, dim3(grid), dim3(ELO_BLOCK), lds, s, *a, total);
-    }
+    const auto grid = [&](int G) { return dim3((unsigned)((total + ELO_BLOCK / G - 1) / (ELO_BLOCK / G))); };
+    if (KT <= 16)
+        hipLaunchKernelGGL((group_random_k<16, 1>), grid(16), dim3(ELO_BLOCK), lds, s, *a, total);
+    else if (KT <= 32)
+        hipLaunchKernelGGL((group_random_k<32, 1>), grid(32), dim3(ELO_BLOCK), lds, s, *a, total);
+    else if (a->K <= 16)
+        hipLaunchKernelGGL((group_random_k<16, 4>), grid(16), dim3(ELO_BLOCK), lds, s, *a, total);
+    else
+        hipLaunchKernelGGL((group_random_k<32, 2>), grid(32), dim3(ELO_BLOCK), lds, s, *a, total);
     return check_launch("elo_fused_conv_random_k");
 }
 
