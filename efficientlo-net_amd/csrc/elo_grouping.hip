@@ -136,15 +136,14 @@ __global__ __launch_bounds__(ELO_BLOCK) void group_select_k(const elo_group_args
     extern __shared__ int lds[];
     const int KT = a.kernel_h * a.kernel_w, K = a.K;
     int *lds_off = lds;
-    stage_offsets(lds_off, a.random_hw, a.kernel_h, a.kernel_w);
-
     const int wave = threadIdx.x / ELO_WAVE, lane = threadIdx.x % ELO_WAVE;
     unsigned *dist = (unsigned *)(lds + KT) + (size_t)wave * 2 * KT;
     int *pay = (int *)dist + KT;
-    const long u = (long)xcd_tile(blockIdx.x, gridDim.x) * waves_per_block + wave;
-    if (u >= total) return;
-
-    const Centre c = load_centre(a, u);
+    const long u0 = (long)xcd_tile(blockIdx.x, gridDim.x) * waves_per_block + wave;
+    const long u = u0 < total ? u0 : total - 1;
+    const Centre c = load_centre(a, u);                      // requested before the order is staged: overlaps it
+    stage_offsets(lds_off, a.random_hw, a.kernel_h, a.kernel_w);
+    if (u0 >= total) return;
     const float r2 = a.distance * a.distance;
     const float *grid2 = a.xyz2 + (size_t)c.b * a.H2 * a.W2 * 3;
     int *o_sel = a.selected_bhw_idx + u * K * 3;
