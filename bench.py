@@ -141,15 +141,18 @@ def roofline_leg(args, dev, net, reps=50):
     flops = cv1_flops(N, C, Kq) * B
     cvb = cost_volume_bytes(N, C, Kq, 4)
     tfs = flops / sec / 1e12
-    def per_operator_leg(batch):
+    def per_operator_leg(batch, half=False):
         """The four cost-volume kernels of the ELO_FUSED=0 path at l0 (SURVEY 8(d) terms A1, P1, A2, P2), each
-        against its own algorithmic bytes, and the four together."""
+        against its own algorithmic bytes, and the four together.  `half`: fp16 feature storage (s = 2; BASELINE
+        configs[2]), fp32 arithmetic."""
+        cvb = cost_volume_bytes(N, C, Kq, 4, 2 if half else 4)
+        cast = (lambda x: x.half()) if half else (lambda x: x)
         elo = pkg()
         Kp = 4
         fb1, fb2 = synth.frame_pair(batch, H, W, seed=6)
         x1, x2 = torch.from_numpy(fb1).to(dev), torch.from_numpy(fb2).to(dev)
-        ft1 = torch.randn((batch, H, W, C), generator=g).to(dev)
-        ft2 = torch.randn((batch, H, W, C), generator=g).to(dev)
+        ft1 = cast(torch.randn((batch, H, W, C), generator=g).to(dev))
+        ft2 = cast(torch.randn((batch, H, W, C), generator=g).to(dev))
         hw = torch.from_numpy(synth.hw_index(batch, H, W)).to(dev)
         idx_q, _, _, m_q = elo.fused_conv_select_k(x1, x2, hw, order, H, W, N, 11, 41, Kq, 0, 1000.0, 1, 1,
                                                   want_valid=False)
@@ -157,9 +160,9 @@ def roofline_leg(args, dev, net, reps=50):
         idx_p, _, _, m_p = elo.fused_conv_random_k(x1, x1, hw, order_p, H, W, N, 3, 5, Kp, 0, 1000.0, 1, 1,
                                                   want_valid=False)
         m_q, m_p = m_q.reshape(batch, N, Kq), m_p.reshape(batch, N, Kp)
-        cost = torch.randn((batch, H, W, 64), generator=g).to(dev)
-        lq, vq = (torch.randn((batch, N, Kq, 64), generator=g).to(dev) for _ in range(2))
-        lp, vp = (torch.randn((batch, N, Kp, 64), generator=g).to(dev) for _ in range(2))
+        cost = cast(torch.randn((batch, H, W, 64), generator=g).to(dev))
+        lq, vq = (cast(torch.randn((batch, N, Kq, 64), generator=g).to(dev)) for _ in range(2))
+        lp, vp = (cast(torch.randn((batch, N, Kp, 64), generator=g).to(dev)) for _ in range(2))
         legs = {"A1": ("cv_encode1_vec_kernel", lambda: ops.cv_encode1(x1.reshape(batch, N, 3), ft1.reshape(batch, N, C),
                                                                         x2, ft2, idx_q, m_q)),
                 "P1": ("softmax_pool_vec_kernel", lambda: ops.masked_softmax_pool(lq, vq, m_q)),
@@ -171,11 +174,12 @@ def roofline_leg(args, dev, net, reps=50):
             nbytes = cvb[term] * batch
             terms[term] = {"kernel": name, "bytes": int(nbytes), "us": round(s * 1e6, 3),
                            "GBps": round(nbytes / s / 1e9, 1), "frac": round(nbytes / s / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic": PMC_TRAFFIC.get((term, batch))}
+                           "traffic": None if half else PMC_TRAFFIC.get((term, batch))}
             tot_b, tot_s = tot_b + nbytes, tot_s + s
         gbs = tot_b / tot_s / 1e9
-        return {"kernel": "cost volume at l0, ELO_FUSED=0 path: encode1 + pool + encode2 + pool (A1+P1+A2+P2)",
-                "batch": batch, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        return {"kernel": "cost volume at l0, ELO_FUSED=0 path: encode1 + pool + encode2 + pool (A1+P1+A2+P2)" +
+                          (", fp16 feature storage" if half else ""),
+                "batch": batch, "dtype": "f16 storage, f32 arithmetic" if half else "f32", "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes_per_launch": int(tot_b), "us_per_launch": round(tot_s * 1e6, 3),
                 "terms": terms}
 
@@ -185,7 +189,8 @@ def roofline_leg(args, dev, net, reps=50):
             "flops_per_launch": int(flops), "us_per_launch": round(sec * 1e6, 3),
             "algorithmic_bytes_per_launch": int((cvb["A1"] + cvb["P1"]) * B),
             "hbm_equivalent_GBps": round((cvb["A1"] + cvb["P1"]) * B / sec / 1e9, 2),
-            "per_operator": per_operator_leg(B), "per_operator_b8": per_operator_leg(8)}
+            "per_operator": per_operator_leg(B), "per_operator_b8": per_operator_leg(8),
+            "per_operator_b8_f16": per_operator_leg(8, half=True), "per_operator_b64_f16": per_operator_leg(64, half=True)}
 
 
 # ----------------------------------------------------------------------------- CPU baseline leg

@@ -35,13 +35,16 @@ MaskedMaxpoolArgs = _struct("elo_masked_maxpool_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("C", _i), ("x", _vp), ("mask", _vp), ("out", _vp)])
 CvEncode1Args = _struct("elo_cv_encode1_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
-    ("xyz1", _vp), ("feat1", _vp), ("xyz2", _vp), ("feat2", _vp), ("idx", _vp), ("mask", _vp), ("out", _vp)])
+    ("xyz1", _vp), ("feat1", _vp), ("xyz2", _vp), ("feat2", _vp), ("idx", _vp), ("mask", _vp), ("out", _vp),
+    ("dtype", _i)])
 CvEncode2Args = _struct("elo_cv_encode2_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("C", _i), ("Cc", _i),
-    ("xyz1", _vp), ("feat1", _vp), ("cost", _vp), ("idx", _vp), ("mask", _vp), ("xyz_cat", _vp), ("rest", _vp)])
+    ("xyz1", _vp), ("feat1", _vp), ("cost", _vp), ("idx", _vp), ("mask", _vp), ("xyz_cat", _vp), ("rest", _vp),
+    ("dtype", _i)])
 SoftmaxPoolArgs = _struct("elo_softmax_pool_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("C", _i), ("logits", _vp), ("values", _vp),
-    ("values_stride", _i), ("mask", _vp), ("out", _vp)])
+    ("values_stride", _i), ("mask", _vp), ("out", _vp), ("dtype", _i)])
+ELO_F32, ELO_F16 = 0, 1
 SoftmaxValidArgs = _struct("elo_softmax_valid_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp), ("out", _vp),
     ("scratch", _vp)])

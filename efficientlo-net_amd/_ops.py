@@ -18,6 +18,15 @@ def active():
     return sys.modules[__name__]
 
 
+def _feature_dtype(*ts):
+    """The three cost-volume kernels store features as fp32 or fp16 (fp32 arithmetic either way): all feature
+    tensors of a call share one of the two; returns (contiguous tensors, torch dtype, ELO_F32 / ELO_F16)."""
+    dt = ts[0].dtype
+    if dt not in (torch.float32, torch.float16) or any(t.dtype != dt for t in ts):
+        raise TypeError("cost-volume feature tensors are all float32 or all float16 (got %s)" % [str(t.dtype) for t in ts])
+    return [t.contiguous() for t in ts], dt, L.ELO_F16 if dt == torch.float16 else L.ELO_F32
+
+
 def _f32(*ts):
     out = []
     for t in ts:
@@ -54,13 +63,14 @@ def masked_maxpool(x, mask):
 def cv_encode1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask):
     """(B,N,K,10+2C) = [p, q, q-p, |q-p|, feat1, feat2[idx]*m].  pointnet_util.py:54-66."""
     L.require_gpu(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask)
-    xyz1, feat1, xyz2_proj, feat2_proj, mask = _f32(xyz1, feat1, xyz2_proj, feat2_proj, mask)
+    xyz1, xyz2_proj, mask = _f32(xyz1, xyz2_proj, mask)
+    (feat1, feat2_proj), dt, code = _feature_dtype(feat1, feat2_proj)
     idx = idx.contiguous()
     B, N, K, _ = idx.shape
     _, H2, W2, C = feat2_proj.shape
-    out = torch.empty((B, N, K, 10 + 2 * C), dtype=torch.float32, device=idx.device)
+    out = torch.empty((B, N, K, 10 + 2 * C), dtype=dt, device=idx.device)
     a = L.CvEncode1Args(B, N, K, H2, W2, C, xyz1.data_ptr(), feat1.data_ptr(), xyz2_proj.data_ptr(),
-                        feat2_proj.data_ptr(), idx.data_ptr(), mask.data_ptr(), out.data_ptr())
+                        feat2_proj.data_ptr(), idx.data_ptr(), mask.data_ptr(), out.data_ptr(), code)
     L.call("elo_cv_encode1", a, out)
     return out
 
@@ -68,15 +78,16 @@ def cv_encode1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask):
 def cv_encode2(xyz1_proj, feat1_proj, cost_proj, idx, mask):
     """xyz_cat (B,N,K,10) and rest (B,N,K,C+Cc) = [feat1, cost[idx]*m].  pointnet_util.py:110-129."""
     L.require_gpu(xyz1_proj, feat1_proj, cost_proj, idx, mask)
-    xyz1_proj, feat1_proj, cost_proj, mask = _f32(xyz1_proj, feat1_proj, cost_proj, mask)
+    xyz1_proj, mask = _f32(xyz1_proj, mask)
+    (feat1_proj, cost_proj), dt, code = _feature_dtype(feat1_proj, cost_proj)
     idx = idx.contiguous()
     B, N, K, _ = idx.shape
     _, H, W, C = feat1_proj.shape
     Cc = cost_proj.shape[-1]
-    xyz_cat = torch.empty((B, N, K, 10), dtype=torch.float32, device=idx.device)
-    rest = torch.empty((B, N, K, C + Cc), dtype=torch.float32, device=idx.device)
+    xyz_cat = torch.empty((B, N, K, 10), dtype=dt, device=idx.device)
+    rest = torch.empty((B, N, K, C + Cc), dtype=dt, device=idx.device)
     a = L.CvEncode2Args(B, N, K, H, W, C, Cc, xyz1_proj.data_ptr(), feat1_proj.data_ptr(), cost_proj.data_ptr(),
-                        idx.data_ptr(), mask.data_ptr(), xyz_cat.data_ptr(), rest.data_ptr())
+                        idx.data_ptr(), mask.data_ptr(), xyz_cat.data_ptr(), rest.data_ptr(), code)
     L.call("elo_cv_encode2", a, rest)
     return xyz_cat, rest
 
@@ -85,15 +96,19 @@ def masked_softmax_pool(logits, values, mask):
     """sum_k softmax_k(where(mask==1, logits, -1e10)) * values -> (B,N,C).  pointnet_util.py:92-98, :137-146.
     `values` may be a last-dim slice of a wider contiguous tensor (no copy)."""
     L.require_gpu(logits, values, mask)
-    logits, mask = _f32(logits, mask)
+    (mask,) = _f32(mask)
+    if logits.dtype not in (torch.float32, torch.float16):
+        raise TypeError("logits are float32 or float16 (got %s)" % logits.dtype)
+    logits = logits.contiguous()
+    dt, code = logits.dtype, L.ELO_F16 if logits.dtype == torch.float16 else L.ELO_F32
     B, N, K, C = logits.shape
-    if values.dtype != torch.float32 or values.shape != logits.shape:
-        raise ValueError("values must be float32 with the shape of logits")
+    if values.dtype != dt or values.shape != logits.shape:
+        raise ValueError("values must have the dtype and shape of logits")
     if values.stride(-1) != 1 or values.stride(1) != K * values.stride(2) or values.stride(0) != N * values.stride(1):
         values = values.contiguous()
-    out = torch.empty((B, N, C), dtype=torch.float32, device=logits.device)
+    out = torch.empty((B, N, C), dtype=dt, device=logits.device)
     a = L.SoftmaxPoolArgs(B, N, K, C, logits.data_ptr(), values.data_ptr(), values.stride(2), mask.data_ptr(),
-                          out.data_ptr())
+                          out.data_ptr(), code)
     L.call("elo_masked_softmax_pool", a, out)
     return out
 

@@ -147,10 +147,11 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_kernel(const elo_cv_enco
         const float mk = m.mask[lr];
         const long bn = (first + lr) / a.K;
         tile[e] = ch < 10 ? geo_value(a.xyz1 + bn * 3, a.xyz2 + cell * 3, mk, ch)
-                : ch < 10 + C ? a.feat1[bn * C + (ch - 10)] : a.feat2[cell * C + (ch - 10 - C)] * mk;
+                : ch < 10 + C ? static_cast<const float *>(a.feat1)[bn * C + (ch - 10)]
+                              : static_cast<const float *>(a.feat2)[cell * C + (ch - 10 - C)] * mk;
     }
     __syncthreads();
-    stream_out(tile, a.out, first, rows, CT);
+    stream_out(tile, static_cast<float *>(a.out), first, rows, CT);
 }
 
 __global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_kernel(const elo_cv_encode2_args a, const long rows)
@@ -168,12 +169,12 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_kernel(const elo_cv_enco
         const float mk = m.mask[lr];
         const long bn = (first + lr) / a.K;
         if (ch < 10) geo[lr * 10 + ch] = geo_value(a.xyz1 + bn * 3, a.xyz1 + cell * 3, mk, ch);
-        else if (ch < 10 + a.C) rest[lr * CT + (ch - 10)] = a.feat1[bn * a.C + (ch - 10)];
-        else rest[lr * CT + (ch - 10)] = a.cost[cell * a.Cc + (ch - 10 - a.C)] * mk;
+        else if (ch < 10 + a.C) rest[lr * CT + (ch - 10)] = static_cast<const float *>(a.feat1)[bn * a.C + (ch - 10)];
+        else rest[lr * CT + (ch - 10)] = static_cast<const float *>(a.cost)[cell * a.Cc + (ch - 10 - a.C)] * mk;
     }
     __syncthreads();
-    stream_out(geo, a.xyz_cat, first, rows, 10);
-    stream_out(rest, a.rest, first, rows, CT);
+    stream_out(geo, static_cast<float *>(a.xyz_cat), first, rows, 10);
+    stream_out(rest, static_cast<float *>(a.rest), first, rows, CT);
 }
 
 // ------------------------------------------------------------ cost volume: encode, vector form
@@ -228,21 +229,40 @@ __device__ __forceinline__ void resolve_rows(RowFacts<ENC_ROWS> &rf, long first,
 
 constexpr int ENC_UNROLL = 3;                        // slots in flight per thread
 
-template <int ENC_ROWS>
+// ---- storage types of the feature tensors: fp32, or fp16 storage with fp32 arithmetic (elo.h: ELO_F16) -----------
+using half_t = _Float16;
+
+template <class T> struct Store;                     // V2: two elements (a geometry / feature pair), V16: 16 bytes
+template <> struct Store<float> {
+    typedef float V2 __attribute__((ext_vector_type(2)));
+    typedef float V4 __attribute__((ext_vector_type(4)));
+    typedef V4 V16;
+    static constexpr int PER16 = 4;
+};
+template <> struct Store<half_t> {
+    typedef half_t V2 __attribute__((ext_vector_type(2)));
+    typedef half_t V4 __attribute__((ext_vector_type(4)));
+    typedef half_t V16 __attribute__((ext_vector_type(8)));
+    static constexpr int PER16 = 8;
+};
+
+template <int ENC_ROWS, class T>
 __global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_vec_kernel(const elo_cv_encode1_args a, const long rows,
                                                                    const FastDiv by_slots, const FastDiv by_K)
 {
+    typedef typename Store<T>::V2 V2;
     __shared__ RowFacts<ENC_ROWS> rf;
     const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * ENC_ROWS;
     if (first >= rows) return;
-    const int C = a.C, HC = C >> 1, HP = 5 + C;      // 8-byte slots per row: 5 geometry, C/2 + C/2 features
+    const int C = a.C, HC = C >> 1, HP = 5 + C;      // two-element slots per row: 5 geometry, C/2 + C/2 features
     const int nrows = (int)(rows - first < ENC_ROWS ? rows - first : ENC_ROWS), nslots = nrows * HP;
     const long bn0 = first / a.K;
     const unsigned rem0 = (unsigned)(first - bn0 * a.K);
     resolve_rows(rf, first, nrows, bn0, rem0, by_K, a.idx, a.mask, a.xyz1, a.xyz2, a.H2, a.W2);
-    float2 *__restrict__ out = reinterpret_cast<float2 *>(a.out + first * (2 * HP));
+    const T *feat1 = static_cast<const T *>(a.feat1), *feat2 = static_cast<const T *>(a.feat2);
+    V2 *__restrict__ out = reinterpret_cast<V2 *>(static_cast<T *>(a.out) + first * (2 * HP));
     for (int s0 = threadIdx.x; s0 < nslots; s0 += ELO_BLOCK * ENC_UNROLL) {
-        float2 f[ENC_UNROLL];
+        V2 f[ENC_UNROLL];
         int j[ENC_UNROLL];
         unsigned lr[ENC_UNROLL];
 #pragma unroll
@@ -251,37 +271,41 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_vec_kernel(const elo_cv_
             lr[u] = by_slots((unsigned)s);
             j[u] = s - (int)lr[u] * HP;
             const long bn = bn0 + by_K(rem0 + lr[u]);
-            const float *src = j[u] < 5 + HC ? a.feat1 + bn * C + 2 * (j[u] < 5 ? 0 : j[u] - 5)     // geometry lanes: unused
-                                             : a.feat2 + rf.cell[lr[u]] * C + 2 * (j[u] - 5 - HC);
-            f[u] = *reinterpret_cast<const float2 *>(src);
+            const T *src = j[u] < 5 + HC ? feat1 + bn * C + 2 * (j[u] < 5 ? 0 : j[u] - 5)             // geometry lanes: unused
+                                         : feat2 + rf.cell[lr[u]] * C + 2 * (j[u] - 5 - HC);
+            f[u] = *reinterpret_cast<const V2 *>(src);
         }
 #pragma unroll
         for (int u = 0; u < ENC_UNROLL; ++u) {
             const float sc = j[u] < 5 + HC ? 1.0f : rf.mask[lr[u]];
             const float2 geo = *reinterpret_cast<const float2 *>(&rf.geo[lr[u]][j[u] < 5 ? 2 * j[u] : 0]);
-            const float2 v = j[u] < 5 ? geo : float2{f[u].x * sc, f[u].y * sc};
-            if (s0 + u * ELO_BLOCK < nslots) out[s0 + u * ELO_BLOCK] = v;
+            const float lo = j[u] < 5 ? geo.x : (float)f[u].x * sc, hi = j[u] < 5 ? geo.y : (float)f[u].y * sc;
+            if (s0 + u * ELO_BLOCK < nslots) out[s0 + u * ELO_BLOCK] = V2{(T)lo, (T)hi};
         }
     }
 }
 
-// Stage 2 has two outputs: xyz_cat rows of 10 floats (8-byte slots, straight from the row facts) and rest rows of
-// C + Cc floats, which are 16-byte aligned when C and Cc are multiples of 4: 16-byte slots, (C + Cc)/4 per row.
-template <int ENC_ROWS>
+// Stage 2 has two outputs: xyz_cat rows of 10 elements (two-element slots, straight from the row facts) and rest
+// rows of C + Cc elements in 16-byte slots (4 floats / 8 halves: C and Cc multiples of that).
+template <int ENC_ROWS, class T>
 __global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_vec_kernel(const elo_cv_encode2_args a, const long rows,
                                                                    const FastDiv by_slots, const FastDiv by_K)
 {
+    typedef typename Store<T>::V2 V2;
+    typedef typename Store<T>::V16 V16;
+    constexpr int E = Store<T>::PER16;
     __shared__ RowFacts<ENC_ROWS> rf;
     const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * ENC_ROWS;
     if (first >= rows) return;
-    const int C = a.C, Cc = a.Cc, QC = C >> 2, QP = (C + Cc) >> 2;
+    const int C = a.C, Cc = a.Cc, QC = C / E, QP = (C + Cc) / E;
     const int nrows = (int)(rows - first < ENC_ROWS ? rows - first : ENC_ROWS), nslots = nrows * QP;
     const long bn0 = first / a.K;
     const unsigned rem0 = (unsigned)(first - bn0 * a.K);
     resolve_rows(rf, first, nrows, bn0, rem0, by_K, a.idx, a.mask, a.xyz1, a.xyz1, a.H, a.W);
-    float4 *__restrict__ rest = reinterpret_cast<float4 *>(a.rest + first * (long)(C + Cc));
+    const T *feat1 = static_cast<const T *>(a.feat1), *cost = static_cast<const T *>(a.cost);
+    V16 *__restrict__ rest = reinterpret_cast<V16 *>(static_cast<T *>(a.rest) + first * (long)(C + Cc));
     for (int s0 = threadIdx.x; s0 < nslots; s0 += ELO_BLOCK * ENC_UNROLL) {
-        float4 f[ENC_UNROLL];
+        V16 f[ENC_UNROLL];
         float sc[ENC_UNROLL];
 #pragma unroll
         for (int u = 0; u < ENC_UNROLL; ++u) {
@@ -289,38 +313,47 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_vec_kernel(const elo_cv_
             const unsigned lr = by_slots((unsigned)s);
             const int j = s - (int)lr * QP;
             const long bn = bn0 + by_K(rem0 + lr);
-            const float *src = j < QC ? a.feat1 + bn * C + 4 * j : a.cost + rf.cell[lr] * Cc + 4 * (j - QC);
-            f[u] = *reinterpret_cast<const float4 *>(src);
+            const T *src = j < QC ? feat1 + bn * C + E * j : cost + rf.cell[lr] * Cc + E * (j - QC);
+            f[u] = *reinterpret_cast<const V16 *>(src);
             sc[u] = j < QC ? 1.0f : rf.mask[lr];
         }
 #pragma unroll
-        for (int u = 0; u < ENC_UNROLL; ++u)
-            if (s0 + u * ELO_BLOCK < nslots)
-                rest[s0 + u * ELO_BLOCK] = float4{f[u].x * sc[u], f[u].y * sc[u], f[u].z * sc[u], f[u].w * sc[u]};
+        for (int u = 0; u < ENC_UNROLL; ++u) {
+            V16 v;
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = (T)((float)f[u][e] * sc[u]);
+            if (s0 + u * ELO_BLOCK < nslots) rest[s0 + u * ELO_BLOCK] = v;
+        }
     }
-    float2 *__restrict__ geo = reinterpret_cast<float2 *>(a.xyz_cat + first * 10);
+    V2 *__restrict__ geo = reinterpret_cast<V2 *>(static_cast<T *>(a.xyz_cat) + first * 10);
     const float2 *staged = reinterpret_cast<const float2 *>(&rf.geo[0][0]);
-    for (int s = threadIdx.x; s < nrows * 5; s += ELO_BLOCK) geo[s] = staged[s];
+    for (int s = threadIdx.x; s < nrows * 5; s += ELO_BLOCK) geo[s] = V2{(T)staged[s].x, (T)staged[s].y};
 }
 
 // ------------------------------------------------------------ masked softmax-pool over K
-// Vectorised form (C % 4 == 0, 16-byte aligned rows): a quarter-wave (16 lanes x float4 = 64 channels) owns one
-// (b,n) point, so a wave streams 4 points' K x C logits and values with 16-byte loads -- every load instruction
-// of the wave covers four full 256-byte rows -- in ONE pass (online softmax), and writes 16 bytes per lane.
+// Vectorised form (C % 4 == 0, aligned rows): a quarter-wave (16 lanes x 4 channels = 64 channels) owns one (b,n)
+// point, so a wave streams 4 points' K x C logits and values with 16-byte (fp32) / 8-byte (fp16) loads -- every load
+// instruction of the wave covers four full rows -- in ONE pass (online softmax, fp32 arithmetic) and writes 4 channels
+// per lane.
+template <class T>
 __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_vec_kernel(const elo_softmax_pool_args a, const long rows)
 {
+    typedef typename Store<T>::V4 V4;
     const int lanes_per_row = a.C >> 2;                              // 16 for C = 64
     const int rows_per_block = ELO_BLOCK / lanes_per_row;
     const int sub = threadIdx.x % lanes_per_row;
     const long r = (long)xcd_tile(blockIdx.x, gridDim.x) * rows_per_block + threadIdx.x / lanes_per_row;
     if (r >= rows) return;
-    const float4 *lg = reinterpret_cast<const float4 *>(a.logits + r * a.K * a.C) + sub;
-    const float4 *vl = reinterpret_cast<const float4 *>(a.values + r * a.K * (long)a.values_stride) + sub;
+    const V4 *lg = reinterpret_cast<const V4 *>(static_cast<const T *>(a.logits) + r * a.K * a.C) + sub;
+    const V4 *vl = reinterpret_cast<const V4 *>(static_cast<const T *>(a.values) + r * a.K * (long)a.values_stride) + sub;
     const int lstep = a.C >> 2, vstep = a.values_stride >> 2;
     const float *m = a.mask + r * a.K;
     float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, den[4] = {0, 0, 0, 0}, acc[4] = {0, 0, 0, 0};
+    // fp16 results carry 11 bits: the hardware exp2 (v_exp_f32, ~1 ulp of fp32) is exact enough there and a fifth of
+    // the instructions of expf, which is what bounds this kernel once the bytes are halved.  fp32 keeps expf.
+    auto ex = [](float x) { return sizeof(T) == 2 ? __builtin_amdgcn_exp2f(x * 1.44269504088896f) : expf(x); };
     for (int k0 = 0; k0 < a.K; k0 += 4) {
-        float4 l4[4], v4[4];
+        V4 l4[4], v4[4];
         float mk[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                                // four neighbour rows in flight
@@ -332,24 +365,24 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_vec_kernel(const elo_s
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (k0 + u >= a.K) break;
-            const float lv[4] = {l4[u].x, l4[u].y, l4[u].z, l4[u].w}, vv[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float l = mk[u] == 1.0f ? lv[c] : -1e10f;
+                const float l = mk[u] == 1.0f ? (float)l4[u][c] : -1e10f, vv = (float)v4[u][c];
                 if (l > mx[c]) {
-                    const float sc = expf(mx[c] - l);
+                    const float sc = ex(mx[c] - l);
                     den[c] = den[c] * sc + 1.0f;
-                    acc[c] = acc[c] * sc + vv[c];
+                    acc[c] = acc[c] * sc + vv;
                     mx[c] = l;
                 } else {
-                    const float e = expf(l - mx[c]);
+                    const float e = ex(l - mx[c]);
                     den[c] += e;
-                    acc[c] += e * vv[c];
+                    acc[c] += e * vv;
                 }
             }
         }
     }
-    reinterpret_cast<float4 *>(a.out + r * a.C)[sub] = float4{acc[0] / den[0], acc[1] / den[1], acc[2] / den[2], acc[3] / den[3]};
+    reinterpret_cast<V4 *>(static_cast<T *>(a.out) + r * a.C)[sub] =
+        V4{(T)(acc[0] / den[0]), (T)(acc[1] / den[1]), (T)(acc[2] / den[2]), (T)(acc[3] / den[3])};
 }
 
 // scalar form for any C / alignment
@@ -358,9 +391,10 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_kernel(const elo_softm
     const long r = row_of_wave(rows);                  // r = b*N + n
     if (r < 0) return;
     const int lane = threadIdx.x % ELO_WAVE;
-    const float *lg = a.logits + r * a.K * a.C;
-    const float *vl = a.values + r * a.K * (long)a.values_stride;
+    const float *lg = static_cast<const float *>(a.logits) + r * a.K * a.C;
+    const float *vl = static_cast<const float *>(a.values) + r * a.K * (long)a.values_stride;
     const float *m = a.mask + r * a.K;
+    float *outp = static_cast<float *>(a.out);
     for (int c = lane; c < a.C; c += ELO_WAVE) {
         float mx = -INFINITY;
         for (int k = 0; k < a.K; ++k) {
@@ -374,7 +408,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_kernel(const elo_softm
             den += e;
             acc += e * vl[(long)k * a.values_stride + c];
         }
-        a.out[r * a.C + c] = acc / den;
+        outp[r * a.C + c] = acc / den;
     }
 }
 
@@ -728,10 +762,23 @@ extern "C" int elo_cv_encode1(const elo_cv_encode1_args *a, elo_stream_t stream)
     ELO_REQUIRE(a->xyz1 && a->feat1 && a->xyz2 && a->feat2 && a->idx && a->mask && a->out, who, "null tensor pointer");
     const long rows = (long)a->batch * a->npoints * a->K;
     if (rows == 0) return ELO_OK;
-    if (a->C % 2 == 0 && a->C < 500 && a->K < 32768 && ((uintptr_t)a->feat1 | (uintptr_t)a->feat2 | (uintptr_t)a->out) % 8 == 0) {
+    ELO_REQUIRE(a->dtype == ELO_F32 || a->dtype == ELO_F16, who, "dtype must be ELO_F32 or ELO_F16");
+    const int esz = a->dtype == ELO_F16 ? 2 : 4;
+    const bool vec = a->C % 2 == 0 && a->C < 500 && a->K < 32768 &&
+                     ((uintptr_t)a->feat1 | (uintptr_t)a->feat2 | (uintptr_t)a->out) % (2 * esz) == 0;
+    if (a->dtype == ELO_F16 && !vec) return fail(ELO_ERR_ARG, "%s: fp16 needs an even C < 500 and 4-byte aligned tensors", who);
+    if (vec) {
         const int per = enc_rows(rows);
-        hipLaunchKernelGGL(per == 128 ? cv_encode1_vec_kernel<128> : cv_encode1_vec_kernel<64>, dim3((unsigned)((rows + per - 1) / per)),
-                           dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows, fast_div(5 + a->C), fast_div(a->K));
+        const dim3 grid((unsigned)((rows + per - 1) / per));
+        const FastDiv ds = fast_div(5 + a->C), dk = fast_div(a->K);
+        hipStream_t s = (hipStream_t)stream;
+        if (a->dtype == ELO_F16) {
+            if (per == 128) hipLaunchKernelGGL((cv_encode1_vec_kernel<128, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+            else hipLaunchKernelGGL((cv_encode1_vec_kernel<64, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+        } else {
+            if (per == 128) hipLaunchKernelGGL((cv_encode1_vec_kernel<128, float>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+            else hipLaunchKernelGGL((cv_encode1_vec_kernel<64, float>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+        }
         return check_launch(who);
     }
     hipLaunchKernelGGL(cv_encode1_kernel, dim3(grid_for_stage(rows)), dim3(ELO_BLOCK), sizeof(float) * (STAGE_ROWS * (10 + 2 * a->C) + 1) + STAGE_META_BYTES,
@@ -748,11 +795,23 @@ extern "C" int elo_cv_encode2(const elo_cv_encode2_args *a, elo_stream_t stream)
     ELO_REQUIRE(a->xyz1 && a->feat1 && a->cost && a->idx && a->mask && a->xyz_cat && a->rest, who, "null tensor pointer");
     const long rows = (long)a->batch * a->npoints * a->K;
     if (rows == 0) return ELO_OK;
-    if (a->C % 4 == 0 && a->Cc % 4 == 0 && a->C + a->Cc < 2000 && a->K < 32768 &&
-        ((uintptr_t)a->feat1 | (uintptr_t)a->cost | (uintptr_t)a->rest) % 16 == 0 && (uintptr_t)a->xyz_cat % 8 == 0) {
+    ELO_REQUIRE(a->dtype == ELO_F32 || a->dtype == ELO_F16, who, "dtype must be ELO_F32 or ELO_F16");
+    const int esz = a->dtype == ELO_F16 ? 2 : 4, per16 = 16 / esz;
+    const bool vec = a->C % per16 == 0 && a->Cc % per16 == 0 && a->C + a->Cc < 2000 && a->K < 32768 &&
+                     ((uintptr_t)a->feat1 | (uintptr_t)a->cost | (uintptr_t)a->rest) % 16 == 0 && (uintptr_t)a->xyz_cat % (2 * esz) == 0;
+    if (a->dtype == ELO_F16 && !vec) return fail(ELO_ERR_ARG, "%s: fp16 needs C and Cc multiples of 8 and 16-byte aligned tensors", who);
+    if (vec) {
         const int per = enc_rows(rows);
-        hipLaunchKernelGGL(per == 128 ? cv_encode2_vec_kernel<128> : cv_encode2_vec_kernel<64>, dim3((unsigned)((rows + per - 1) / per)),
-                           dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows, fast_div((a->C + a->Cc) / 4), fast_div(a->K));
+        const dim3 grid((unsigned)((rows + per - 1) / per));
+        const FastDiv ds = fast_div((a->C + a->Cc) / per16), dk = fast_div(a->K);
+        hipStream_t s = (hipStream_t)stream;
+        if (a->dtype == ELO_F16) {
+            if (per == 128) hipLaunchKernelGGL((cv_encode2_vec_kernel<128, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+            else hipLaunchKernelGGL((cv_encode2_vec_kernel<64, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+        } else {
+            if (per == 128) hipLaunchKernelGGL((cv_encode2_vec_kernel<128, float>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+            else hipLaunchKernelGGL((cv_encode2_vec_kernel<64, float>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+        }
         return check_launch(who);
     }
     hipLaunchKernelGGL(cv_encode2_kernel, dim3(grid_for_stage(rows)), dim3(ELO_BLOCK), sizeof(float) * (STAGE_ROWS * (10 + a->C + a->Cc) + 1) + STAGE_META_BYTES,
@@ -768,12 +827,16 @@ extern "C" int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_strea
     ELO_REQUIRE(a->logits && a->values && a->mask && a->out, who, "null tensor pointer");
     const long rows = (long)a->batch * a->npoints;
     if (rows == 0) return ELO_OK;
+    ELO_REQUIRE(a->dtype == ELO_F32 || a->dtype == ELO_F16, who, "dtype must be ELO_F32 or ELO_F16");
+    const int esz = a->dtype == ELO_F16 ? 2 : 4;
     const bool vec = a->C % 4 == 0 && a->C <= 1024 && ELO_BLOCK % (a->C / 4) == 0 && a->values_stride % 4 == 0 &&
-                     ((uintptr_t)a->logits | (uintptr_t)a->values | (uintptr_t)a->out) % 16 == 0;
+                     ((uintptr_t)a->logits | (uintptr_t)a->values | (uintptr_t)a->out) % (4 * esz) == 0;
+    if (a->dtype == ELO_F16 && !vec) return fail(ELO_ERR_ARG, "%s: fp16 needs C % 4 == 0 and 8-byte aligned tensors", who);
     if (vec) {
         const int rows_per_block = ELO_BLOCK / (a->C / 4);
-        hipLaunchKernelGGL(softmax_pool_vec_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(ELO_BLOCK),
-                           0, (hipStream_t)stream, *a, rows);
+        const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
+        if (a->dtype == ELO_F16) hipLaunchKernelGGL(softmax_pool_vec_kernel<half_t>, grid, dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
+        else hipLaunchKernelGGL(softmax_pool_vec_kernel<float>, grid, dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
         return check_launch(who);
     }
     hipLaunchKernelGGL(softmax_pool_kernel, dim3(grid_for_rows(rows)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);

@@ -119,6 +119,11 @@ typedef struct elo_masked_maxpool_args {
 } elo_masked_maxpool_args;
 int elo_masked_maxpool(const elo_masked_maxpool_args *a, elo_stream_t stream);
 
+/* Storage type of the FEATURE tensors of the three cost-volume kernels below (fields typed `void *`): fp32, or fp16
+ * storage with fp32 arithmetic (BASELINE configs[2]; SURVEY.md section 8(d): s = 2).  Geometry inputs (xyz), indices
+ * and masks are always fp32 / int32. */
+enum { ELO_F32 = 0, ELO_F16 = 1 };
+
 /* Cost volume, stage 1 (point -> patch of frame 2), utils/pointnet_util.py:54-66:
  *   q = xyz2[idx]*m, diff = q - p, euc = sqrt(sum(diff^2) + 1e-20)
  *   out[b,n,k,:] = [ p(3), q(3), diff(3), euc(1), feat1[b,n](C), feat2[idx]*m (C) ]      (10+2C channels) */
@@ -126,12 +131,13 @@ typedef struct elo_cv_encode1_args {
     int batch, npoints, K;
     int H2, W2, C;
     const float *xyz1;            /* (batch,npoints,3)  warped frame-1 points      */
-    const float *feat1;           /* (batch,npoints,C)                             */
+    const void *feat1;            /* (batch,npoints,C)        dtype                */
     const float *xyz2;            /* (batch,H2,W2,3)                               */
-    const float *feat2;           /* (batch,H2,W2,C)                               */
+    const void *feat2;            /* (batch,H2,W2,C)          dtype                */
     const int *idx;
     const float *mask;
-    float *out;                   /* (batch,npoints,K,10+2C) */
+    void *out;                    /* (batch,npoints,K,10+2C)  dtype                */
+    int dtype;                    /* ELO_F32 / ELO_F16 */
 } elo_cv_encode1_args;
 int elo_cv_encode1(const elo_cv_encode1_args *a, elo_stream_t stream);
 
@@ -145,12 +151,13 @@ typedef struct elo_cv_encode2_args {
     int batch, npoints, K;
     int H, W, C, Cc;              /* xyz1 grid (npoints == H*W), feat1 and cost channels */
     const float *xyz1;            /* (batch,H,W,3)  */
-    const float *feat1;           /* (batch,H,W,C)  */
-    const float *cost;            /* (batch,H,W,Cc) stage-1 output */
+    const void *feat1;            /* (batch,H,W,C)   dtype */
+    const void *cost;             /* (batch,H,W,Cc)  dtype: stage-1 output */
     const int *idx;
     const float *mask;
-    float *xyz_cat;               /* (batch,npoints,K,10)   */
-    float *rest;                  /* (batch,npoints,K,C+Cc) */
+    void *xyz_cat;                /* (batch,npoints,K,10)    dtype */
+    void *rest;                   /* (batch,npoints,K,C+Cc)  dtype */
+    int dtype;                    /* ELO_F32 / ELO_F16 */
 } elo_cv_encode2_args;
 int elo_cv_encode2(const elo_cv_encode2_args *a, elo_stream_t stream);
 
@@ -159,11 +166,12 @@ int elo_cv_encode2(const elo_cv_encode2_args *a, elo_stream_t stream);
  * slice of a wider tensor: element (row,c) is values[row*values_stride + c]. */
 typedef struct elo_softmax_pool_args {
     int batch, npoints, K, C;
-    const float *logits;          /* (batch,npoints,K,C) */
-    const float *values;
-    int values_stride;            /* floats between consecutive (b,n,k) rows, >= C */
+    const void *logits;           /* (batch,npoints,K,C)  dtype */
+    const void *values;           /*                      dtype */
+    int values_stride;            /* elements between consecutive (b,n,k) rows, >= C */
     const float *mask;
-    float *out;                   /* (batch,npoints,C) */
+    void *out;                    /* (batch,npoints,C)    dtype; the softmax itself runs in fp32 */
+    int dtype;                    /* ELO_F32 / ELO_F16 */
 } elo_softmax_pool_args;
 int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_stream_t stream);
 

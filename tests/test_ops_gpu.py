@@ -239,3 +239,47 @@ def test_pose_head_clears_the_next_projection():
     assert torch.allclose(got[2], want[2], atol=1e-4)
     with pytest.raises(ValueError, match="ProjectionBuffers"):
         ops.warp_project(t(pc), feat, q, tt, H, W + 1, buffers=buf)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 113, 16), (1, 16, 225, 32)])
+def test_cost_volume_kernels_with_fp16_storage(B, H, W, C):
+    """BASELINE configs[2]: the three cost-volume kernels with fp16 feature storage (ELO_F16: fp16 in HBM, fp32
+    arithmetic).  On fp16-representable inputs they must equal the fp32 kernels' outputs rounded to fp16 -- copies and
+    masking are exact, the geometry runs the same fp32 instructions; the softmax-pool agrees to fp16 rounding -- and the
+    fp32 kernels are the ones the oracle pins (test_cost_volume)."""
+    ops, elo, synth = load_pkg("_ops"), load_pkg(), load_pkg("synth")
+    rng = np.random.default_rng(31)
+    N, Kq, Kp = H * W, 6, 4
+    f1, f2 = synth.frame_pair(B, H, W, seed=17)
+    x1, x2 = t(f1), t(f2)
+    hw = t(synth.hw_index(B, H, W))
+    order_q, order_p = t(rng.permutation(5 * 15).astype(np.int32)), t(rng.permutation(3 * 5).astype(np.int32))
+    idx_q, _, _, m_q = elo.fused_conv_select_k(x1, x2, hw, order_q, H, W, N, 5, 15, Kq, 0, 6.0, 1, 1, want_valid=False)
+    idx_p, _, _, m_p = elo.fused_conv_random_k(x1, x1, hw, order_p, H, W, N, 3, 5, Kp, 0, 6.0, 1, 1, want_valid=False)
+    m_q, m_p = m_q.reshape(B, N, Kq), m_p.reshape(B, N, Kp)
+    h = lambda *shape: t(rng.normal(0, 1, shape).astype(np.float32)).half()
+    ft1, ft2, cost = h(B, H, W, C), h(B, H, W, C), h(B, H, W, 64)
+
+    e1_16 = ops.cv_encode1(x1.reshape(B, N, 3), ft1.reshape(B, N, C), x2, ft2, idx_q, m_q)
+    e1_32 = ops.cv_encode1(x1.reshape(B, N, 3), ft1.float().reshape(B, N, C), x2, ft2.float(), idx_q, m_q)
+    assert e1_16.dtype == torch.float16 and e1_16.shape == e1_32.shape and torch.equal(e1_16, e1_32.half())
+
+    g16, r16 = ops.cv_encode2(x1, ft1, cost, idx_p, m_p)
+    g32, r32 = ops.cv_encode2(x1, ft1.float(), cost.float(), idx_p, m_p)
+    assert g16.dtype == r16.dtype == torch.float16
+    assert torch.equal(g16, g32.half()) and torch.equal(r16, r32.half())
+
+    for K, mask in ((Kq, m_q), (Kp, m_p)):
+        lg, vl = h(B, N, K, 64) * 3, h(B, N, K, 64)
+        p16 = ops.masked_softmax_pool(lg, vl, mask)
+        p32 = ops.masked_softmax_pool(lg.float(), vl.float(), mask)
+        # the fp16 instantiation uses the hardware exp2 instead of expf: equal to within fp16 rounding, not bit-equal
+        assert p16.dtype == torch.float16 and torch.allclose(p16.float(), p32, rtol=2e-3, atol=1e-3)
+        wide = h(B, N, K, 128)                               # values as a channel slice of a wider tensor (stride 128)
+        assert torch.allclose(ops.masked_softmax_pool(lg, wide[..., :64], mask).float(),
+                              ops.masked_softmax_pool(lg.float(), wide[..., :64].float().contiguous(), mask),
+                              rtol=2e-3, atol=1e-3)
+    with pytest.raises(TypeError, match="all float32 or all float16"):
+        ops.cv_encode1(x1.reshape(B, N, 3), ft1.reshape(B, N, C), x2, ft2.float(), idx_q, m_q)
+    with pytest.raises(RuntimeError, match="fp16 needs C and Cc multiples of 8"):
+        ops.cv_encode2(x1, ft1[..., :4].contiguous(), cost, idx_p, m_p)
