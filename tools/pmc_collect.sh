@@ -7,8 +7,9 @@ OUT=$(realpath -m "${1:-gpurun_out/pmc3}"); REPO=$(pwd)
 mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
 SPECS=${ELO_PMC_SPECS:-"cv1:1 cv1:8 encode1:8 pool:8 encode2:8 pool2:8 encode1:64 pool:64 encode2:64 pool2:64 select32:1 select32:8 select32_l2:8 random16:1 random16:8"}
 for spec in $SPECS; do
-    k=${spec%%:*}; b=${spec##*:}; tag=${k}_b${b}
-    cmd="python $REPO/tools/roofline_micro.py --kernel $k --batch $b --reps 25"
+    k=${spec%%:*}; b=${spec##*:}; tag=${k}_b${b}; half=""
+    case "$k" in *_f16) k=${k%_f16}; half="--half";; esac      # e.g. encode1_f16:64
+    cmd="python $REPO/tools/roofline_micro.py --kernel $k --batch $b --reps 25 $half"
     $cmd > "$OUT/$tag.info" 2>/dev/null
     rocprofv3 --kernel-trace --output-format csv -d "$OUT/$tag.trace" -o t -- $cmd > /dev/null 2>&1
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$tag.fetch" -o f -- $cmd > /dev/null 2>&1

@@ -17,6 +17,7 @@ import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--kernel", default="cv1"); ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--reps", type=int, default=20); ap.add_argument("--pregrouped", action="store_true"); ap.add_argument("--time", action="store_true")
+ap.add_argument("--half", action="store_true", help="fp16 feature storage (encode1/encode2/pool/pool2)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ops, fused, tf_util, synth, elo = pkg("_ops"), pkg("fused"), pkg("tf_util"), pkg("synth"), pkg()
@@ -27,7 +28,8 @@ f1, f2 = synth.frame_pair(B, H, W, seed=5)
 xyz1, xyz2 = torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev)
 feat1 = torch.randn((B, H, W, C), generator=g).to(dev); feat2 = torch.randn((B, H, W, C), generator=g).to(dev)
 order = torch.randperm(11 * 41, generator=g).to(torch.int32).to(dev)
-cvb = bench.cost_volume_bytes(N, C, Kq, 4)
+cvb = bench.cost_volume_bytes(N, C, Kq, 4, 2 if a.half else 4)
+cast = (lambda x: x.half()) if a.half else (lambda x: x)
 if a.kernel == "cv1":
     store = tf_util.VariableStore(dev, seed=0)
     with tf_util.default_store(store), torch.no_grad():
@@ -45,7 +47,7 @@ if a.kernel == "cv1":
     info = {"flops": bench.cv1_flops(N, C, Kq) * B, "algorithmic_bytes": (cvb["A1"] + cvb["P1"]) * B}
 elif a.kernel in ("pool", "pool2"):
     K = Kq if a.kernel == "pool" else 4
-    logits = torch.randn((B, N, K, 64), generator=g).to(dev); values = torch.randn((B, N, K, 64), generator=g).to(dev)
+    logits = cast(torch.randn((B, N, K, 64), generator=g).to(dev)); values = cast(torch.randn((B, N, K, 64), generator=g).to(dev))
     mask = (torch.rand((B, N, K), generator=g) > 0.1).float().to(dev)
     run = lambda: ops.masked_softmax_pool(logits, values, mask)
     info = {"algorithmic_bytes": cvb["P1" if a.kernel == "pool" else "P2"] * B}
@@ -69,18 +71,20 @@ elif a.kernel == "encode2":
     hw = torch.from_numpy(synth.hw_index(B, H, W)).to(dev)
     idx, _, _, m = elo.fused_conv_random_k(xyz1, xyz1, hw, order2, H, W, N, 3, 5, Kp, 0, 1000.0, 1, 1, want_valid=False)
     m = m.reshape(B, N, Kp)
-    cost = torch.randn((B, H, W, 64), generator=g).to(dev)
-    run = lambda: ops.cv_encode2(xyz1, feat1, cost, idx, m)
+    cost = cast(torch.randn((B, H, W, 64), generator=g).to(dev))
+    h1 = cast(feat1)
+    run = lambda: ops.cv_encode2(xyz1, h1, cost, idx, m)
     info = {"algorithmic_bytes": cvb["A2"] * B}
 else:
     hw = torch.from_numpy(synth.hw_index(B, H, W)).to(dev)
     idx, _, _, m = elo.fused_conv_select_k(xyz1, xyz2, hw, order, H, W, N, 11, 41, Kq, 0, 1000.0, 1, 1, want_valid=False)
     m = m.reshape(B, N, Kq)
-    run = lambda: ops.cv_encode1(xyz1.reshape(B, N, 3), feat1.reshape(B, N, C), xyz2, feat2, idx, m)
+    h1, h2 = cast(feat1), cast(feat2)
+    run = lambda: ops.cv_encode1(xyz1.reshape(B, N, 3), h1.reshape(B, N, C), xyz2, h2, idx, m)
     info = {"algorithmic_bytes": cvb["A1"] * B}
 for _ in range(a.reps):
     run()
 torch.cuda.synchronize()
 if a.time:
     info["us"] = round(bench._time_launches(run, dev, 200) * 1e6, 2)
-print(json.dumps({"kernel": a.kernel, "batch": B, **info}))
+print(json.dumps({"kernel": a.kernel, "batch": B, "half": a.half, **info}))
