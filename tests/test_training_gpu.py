@@ -138,9 +138,10 @@ def test_training_steps_reduce_the_loss_and_reach_every_layer():
     assert all(torch.isfinite(o).all() for o in out)
 
 
-def test_trainer_checkpoints_resume_bit_exactly(tmp_path):
+def test_trainer_checkpoints_resume(tmp_path):
     """save -> load into a fresh trainer -> the next step equals the original's next step (variables, moving
-    statistics, loss weights, Adam moments, step count); the TensorFlow-bundle form restores the variables."""
+    statistics, loss weights, Adam moments, step count) up to the summation order of the atomic scatter-adds in the
+    backward pass; the TensorFlow-bundle form restores the variables exactly."""
     model, training, synth = load_pkg("model"), load_pkg("training"), load_pkg("synth")
     f1, f2 = synth.frame_pair(1, 64, 900, seed=21)
     a, b = t(f1), t(f2)
@@ -161,15 +162,21 @@ def test_trainer_checkpoints_resume_bit_exactly(tmp_path):
 
     tr2 = fresh(9).load(str(tmp_path / "ck.npz"))
     assert tr2.step_count == 2
+    saved = dict(np.load(str(tmp_path / "ck.npz")))
+    for k, v in tr2.net.store.state_dict().items():          # the restore itself is exact
+        assert np.array_equal(v.cpu().numpy(), saved[k]), k
+    for i, p in enumerate(tr2.params):
+        assert np.array_equal(tr2.opt.state_dict()["state"][i]["exp_avg"].cpu().numpy(), saved["adam_m/%d" % i])
     tr2.net.perms = perm_state
     torch.manual_seed(5)
     got = float(tr2.step(a, b, q_gt, t_gt))
-    assert got == want
+    assert abs(got - want) <= 1e-5 * max(1.0, abs(want))
+    # Adam turns the summation-order noise of a (mathematically zero) gradient -- a conv bias in front of a batch
+    # norm -- into a full +-lr step, so variables are compared to within two steps of lr = 1e-3
     for k, v in tr2.net.store.state_dict().items():
-        assert torch.equal(v, want_vars[k]), k
+        assert torch.allclose(v, want_vars[k], rtol=1e-3, atol=2.1e-3), k
 
     tr3 = fresh(11).load(str(tmp_path / "ck_tf"))
-    saved = dict(np.load(str(tmp_path / "ck.npz")))
     for k, v in tr3.net.store.state_dict().items():
         assert np.array_equal(v.cpu().numpy(), saved[k]), k
     assert float(tr3.w_q.detach()) == float(saved["w_q"])
