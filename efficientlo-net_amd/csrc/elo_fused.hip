@@ -796,7 +796,10 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void mlp_kernel(const JobPair<elo_m
 }
 
 // ================================================================ cost volume, stage 1
-// LDS columns: [0,128) = X (CV chain, later [x3 | enc]),  [128, 128 + max(CTp,128)) = F (feat_cat, later sum_CV)
+// LDS columns: [0,128) = X (CV chain, later [x | enc]); [128, 128 + CTp) = F (feat_cat; its first 16 columns, the
+// geometry, live until CV_xyz); sum_CV_0 then writes its 128 outputs to [64,192) -- over enc, its own input: the
+// layer's barrier separates the reads from the write -- so x at [0,64) survives for the pooling and the tile is
+// max(192, 128 + CTp) columns wide instead of 256 (27.5 KB instead of 35.7 KB at 32 rows: a fifth workgroup per CU).
 template <int TILE>
 __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_kernel(const elo_cv1_args a, const int S)
 {
@@ -863,13 +866,13 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_kernel(const elo_cv1_args 
     dense_pf<TILE, 64, 64>(act, S, 0, 0, a.cv1, p64, &a.cv2, &p64);            // -> 64 (in place)
     dense_pf<TILE, 64, 64>(act, S, 0, 0, a.cv2, p64, &a.cv_xyz, &p64);         // -> 64 = x   (values of the pooling)
     dense_pf<TILE, 64, 128>(act, S, F, 64, a.cv_xyz, p64, &a.sum_cv0, &p128);  // xyz_cat -> enc at [64,128)   :79-82
-    dense_pf<TILE, 128, 64>(act, S, 0, F, a.sum_cv0, p128, &a.sum_cv1, &p64);  // [x | enc] -> 128 into F      :84-90
-    dense_pf<TILE, 64, 0>(act, S, F, F, a.sum_cv1, p64, nullptr, nullptr);     // -> 64 logits (in place)
+    dense_pf<TILE, 128, 64>(act, S, 0, 64, a.sum_cv0, p128, &a.sum_cv1, &p64); // [x | enc] -> 128 at [64,192): over enc, x stays  :84-90
+    dense_pf<TILE, 64, 0>(act, S, 64, 64, a.sum_cv1, p64, nullptr, nullptr);   // -> 64 logits at [64,128) (in place)
 #if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 3
     if (tid == 0) a.out[first_point * 64] = act[F];
     return;
 #endif
-    pool_masked_softmax(act, S, F, 0, meta, P, K, first_point, total_points, a.out);    // :92-98
+    pool_masked_softmax(act, S, 64, 0, meta, P, K, first_point, total_points, a.out);   // :92-98
 }
 
 // ================================================================ cost volume, stage 2
@@ -1151,7 +1154,7 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
     const long points = (long)a->batch * a->npoints;
     if (points == 0) return ELO_OK;
     const int CTp = pad16(CT);
-    const int S = row_stride(128 + (CTp > 128 ? CTp : 128));
+    const int S = row_stride(128 + CTp > 192 ? 128 + CTp : 192);
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
     return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv1_kernel<32>, cv1_kernel<16>,
