@@ -71,7 +71,9 @@ SetconvArgs = _struct("elo_setconv_args", [
     ("idx", _vp), ("mask", _vp), ("n_layers", _i), ("layers", Dense * 3), ("out", _vp), ("new_xyz", _vp), ("group", GroupSpec)])
 MlpArgs = _struct("elo_mlp_args", [
     ("rows", _l), ("n_sources", _i), ("src", _vp * 3), ("src_width", _i * 3), ("n_layers", _i),
-    ("layers", Dense * 3), ("out", _vp)])
+    ("layers", Dense * 3), ("out", _vp),
+    ("n_layers2", _i), ("layers2", Dense * 3), ("before", _vp), ("w_before", _i), ("after", _vp), ("w_after", _i),
+    ("out2", _vp)])
 Cv1Args = _struct("elo_cv1_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("xyz2", _vp), ("feat2", _vp), ("idx", _vp), ("mask", _vp),

@@ -786,12 +786,44 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void mlp_kernel(const JobPair<elo_m
         }
     }
     __syncthreads();
-    for (int l = 0; l < a.n_layers; ++l) dense<TILE>(act, S, 0, 0, a.layers[l]);
+    // with a second stage the first stage's LAST layer writes its output at column w_before -- where the second stage's
+    // concat [before | out | after] wants it (the layer's barrier separates its reads at [0, K) from that write)
+    const int shift = a.n_layers2 > 0 ? a.w_before : 0;
+    for (int l = 0; l < a.n_layers; ++l) dense<TILE>(act, S, 0, l == a.n_layers - 1 ? shift : 0, a.layers[l]);
     const int N = a.layers[a.n_layers - 1].N;
     for (int e = tid; e < TILE * N; e += FUSED_BLOCK) {
         const int row = e / N, c = e - row * N;
         const long gr = first + row;
-        if (gr < a.rows) a.out[gr * N + c] = act[row * S + c];
+        if (gr < a.rows) a.out[gr * N + c] = act[row * S + shift + c];
+    }
+    if (a.n_layers2 <= 0) return;
+    // ---- second stage: [before | out | after] -> layers2 -> out2
+    const int wb = a.w_before, wa = a.w_after, CT2 = wb + N + wa;
+    auto row_of = [&](int row) { return first + row < a.rows ? first + row : -1L; };
+    auto one = [](int) { return 1.0f; };
+    if ((wb == 0 || seg_ok(a.before, wb, TILE)) && (wa == 0 || seg_ok(a.after, wa, TILE))) {
+        float4 rb[SEG_ITEMS], ra[SEG_ITEMS];
+        if (wb) seg_load<TILE>(rb, a.before, wb, row_of);
+        if (wa) seg_load<TILE>(ra, a.after, wa, row_of);
+        if (wb) seg_store<TILE>(act, S, 0, wb, rb, row_of, one);
+        if (wa) seg_store<TILE>(act, S, wb + N, wa, ra, row_of, one);
+    } else {
+        for (int e = tid; e < TILE * (wb + wa); e += FUSED_BLOCK) {
+            const int row = e / (wb + wa), ch = e - row * (wb + wa);
+            const long gr = first + row;
+            const long grc = gr < a.rows ? gr : a.rows - 1;
+            const float v = ch < wb ? a.before[grc * wb + ch] : a.after[grc * wa + (ch - wb)];
+            act[row * S + (ch < wb ? ch : N + ch)] = gr < a.rows ? v : 0.0f;
+        }
+    }
+    zero_cols<TILE>(act, S, CT2, ceil16(CT2));
+    __syncthreads();
+    for (int l = 0; l < a.n_layers2; ++l) dense<TILE>(act, S, 0, 0, a.layers2[l]);
+    const int N2 = a.layers2[a.n_layers2 - 1].N;
+    for (int e = tid; e < TILE * N2; e += FUSED_BLOCK) {
+        const int row = e / N2, c = e - row * N2;
+        const long gr = first + row;
+        if (gr < a.rows) a.out2[gr * N2 + c] = act[row * S + c];
     }
 }
 
@@ -1112,7 +1144,30 @@ static int check_mlp(const elo_mlp_args *a, const char *who, int *in_width)
         if (int rc = check_dense(a->layers[l], width, 0, who, "mlp")) return rc;
         width = a->layers[l].N;
     }
+    ELO_REQUIRE(a->n_layers2 >= 0 && a->n_layers2 <= ELO_MAX_CHAIN, who, "0..3 second-stage layers");
+    if (a->n_layers2 > 0) {
+        ELO_REQUIRE(a->out2 && a->w_before >= 0 && a->w_after >= 0 && (a->before || a->w_before == 0) &&
+                    (a->after || a->w_after == 0), who, "incomplete second stage");
+        width += a->w_before + a->w_after;
+        for (int l = 0; l < a->n_layers2; ++l) {
+            if (int rc = check_dense(a->layers2[l], width, 0, who, "mlp stage 2")) return rc;
+            width = a->layers2[l].N;
+        }
+    }
     return ELO_OK;
+}
+
+// column budget of a (possibly two-stage) row-wise MLP tile
+static int mlp_cols(const elo_mlp_args *a, int in_width)
+{
+    int cols = chain_cols(a->layers, a->n_layers, in_width);
+    if (a->n_layers2 > 0) {
+        const int n1 = a->layers[a->n_layers - 1].N, in2 = a->w_before + n1 + a->w_after;
+        const int c2 = chain_cols(a->layers2, a->n_layers2, in2);
+        cols = cols > c2 ? cols : c2;
+        cols = cols > pad16(a->w_before + n1) ? cols : pad16(a->w_before + n1);
+    }
+    return cols;
 }
 
 extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_stream_t stream)
@@ -1122,12 +1177,14 @@ extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_
     if (int rc = check_mlp(a, who, &in_width)) return rc;
     if (b) {
         if (int rc = check_mlp(b, who, &in_width_b)) return rc;
-        bool same = a->rows == b->rows && in_width == in_width_b && a->n_layers == b->n_layers;
+        bool same = a->rows == b->rows && in_width == in_width_b && a->n_layers == b->n_layers &&
+                    a->n_layers2 == b->n_layers2 && a->w_before == b->w_before && a->w_after == b->w_after;
         for (int l = 0; same && l < a->n_layers; ++l) same = a->layers[l].N == b->layers[l].N;
+        for (int l = 0; same && l < a->n_layers2; ++l) same = a->layers2[l].N == b->layers2[l].N;
         if (!same) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must have the same shape", who);
     }
     if (a->rows == 0) return ELO_OK;
-    const int S = row_stride(chain_cols(a->layers, a->n_layers, in_width));
+    const int S = row_stride(mlp_cols(a, in_width));
     const long u32 = (a->rows + 31) / 32, u16 = (a->rows + 15) / 16;
     return launch_tile2(who, small_tile(u32 * (b ? 2 : 1), 1), u16, u32, S, (hipStream_t)stream, *a, b, mlp_kernel<32>,
                         mlp_kernel<16>);

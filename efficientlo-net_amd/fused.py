@@ -159,6 +159,30 @@ def mlp_pair(sources_a, layers_a, sources_b, layers_b):
     return out_a.reshape(lead + (layers_a[-1].N,)), out_b.reshape(lead + (layers_b[-1].N,))
 
 
+def _mlp2_args(sources, layers, before, after, layers2):
+    a, out, keep = _mlp_args(sources, layers)
+    rows = out.shape[0]
+    flat = lambda t: None if t is None else _f32c(t).reshape(rows, t.shape[-1])
+    before, after = flat(before), flat(after)
+    out2 = torch.empty((rows, layers2[-1].N), dtype=torch.float32, device=out.device)
+    a.n_layers2, a.layers2, a.out2 = len(layers2), _chain(layers2), out2.data_ptr()
+    a.before, a.w_before = (before.data_ptr(), before.shape[1]) if before is not None else (None, 0)
+    a.after, a.w_after = (after.data_ptr(), after.shape[1]) if after is not None else (None, 0)
+    return a, out, out2, (keep, before, after, layers2)
+
+
+def mlp2_pair(job_a, job_b):
+    """Two jobs of identical shape, each TWO chained row-wise MLPs, in ONE launch:
+    out = layers(concat(sources)); out2 = layers2(concat(before, out, after)).  job: dict(sources, layers, before,
+    after, layers2).  Returns ((out_a, out2_a), (out_b, out2_b))."""
+    a, out_a, out2_a, _ka = _mlp2_args(**job_a)
+    b, out_b, out2_b, _kb = _mlp2_args(**job_b)
+    L.call2("elo_mlp_fused2", a, b, out_a)
+    lead = job_a["sources"][0].shape[:-1]
+    shape = lambda t: t.reshape(lead + (t.shape[-1],))
+    return (shape(out_a), shape(out2_a)), (shape(out_b), shape(out2_b))
+
+
 def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1, group=None, K=None):
     L.require_gpu(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask)
     xyz1, feat1, xyz2_proj, feat2_proj = (_f32c(t) for t in (xyz1, feat1, xyz2_proj, feat2_proj))

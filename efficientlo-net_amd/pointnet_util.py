@@ -251,6 +251,39 @@ def up_conv_pair(call_a, call_b):
     return fused.mlp_pair([up_a, stage2[0][0]], stage2[0][1], [up_b, stage2[1][0]], stage2[1][1])
 
 
+def up_conv_predict_pair(up_a, up_b, fp_a, fp_b):
+    """The two set-upconvs of a refinement level and the two flow predictors they feed (pwclo_model.py:247-254) in
+    TWO launches: the paired set-conv stage, then ONE launch that runs each up_conv's stage-2 MLP and, on its
+    output, the predictor's MLP (flow_predictor's concat [points_f1, upsampled_feat, cost_volume] with
+    upsampled_feat coming straight from the tile).  up_x / fp_x: the keyword dicts of up_conv_pair /
+    flow_predictor_pair; fp_x's upsampled_feat is up_x's output.  Returns (up_out_a, predictor_a, up_out_b, predictor_b)."""
+    jobs, stage2 = [], []
+    for up, fp in ((up_a, fp_a), (up_b, fp_b)):
+        P = fused.packed_layer
+        with tf_util.variable_scope(up["scope"]):
+            xyz1_proj, feat1_proj, feat2_proj = up["xyz1_proj"], up["feat1_proj"], up["feat2_proj"]
+            B, H, W, _ = xyz1_proj.shape
+            ks, mlp, mlp2 = up["kernel_size"], up["mlp"], up["mlp2"]
+            random_HW = random_shuffle(tf_util.scope_name(), "random_HW", ks[0] * ks[1], xyz1_proj.device)
+            w1 = [3 + feat2_proj.shape[-1]] + list(mlp)
+            jobs.append(dict(src_xyz=up["xyz2_proj"], src_feat=feat2_proj, idx=None, mask=None,
+                             layers=[P('up_1_%d' % j, w1[j], w1[j + 1]) for j in range(len(mlp))],
+                             xyz1_grid=xyz1_proj, K=up["nsample"],
+                             group=fused.Grouping(random_HW, ks, up["distance"], up["stride_h"], up["stride_w"])))
+            points1 = feat1_proj.reshape(B, H * W, -1)
+            w2 = [mlp[-1] + points1.shape[-1]] + list(mlp2)
+            layers = [P('up_2_%d' % i, w2[i], w2[i + 1]) for i in range(len(mlp2))]
+        with tf_util.variable_scope(fp["scope"]):
+            before, after = fp["points_f1"], fp["cost_volume"]
+            wp = [sum(p.shape[-1] for p in (before, after) if p is not None) + mlp2[-1]] + list(fp["mlp"])
+            layers2 = [P('conv_predictor%d' % i, wp[i], wp[i + 1], bn=fp.get("bn", True)) for i in range(len(fp["mlp"]))]
+        stage2.append(dict(sources=[None, points1], layers=layers, before=before, after=after, layers2=layers2))
+    (up_a_pooled, _), (up_b_pooled, _) = fused.setconv_pair(jobs[0], jobs[1])
+    stage2[0]["sources"][0], stage2[1]["sources"][0] = up_a_pooled, up_b_pooled
+    (out_a, pred_a), (out_b, pred_b) = fused.mlp2_pair(stage2[0], stage2[1])
+    return out_a, pred_a, out_b, pred_b
+
+
 def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distance, mlp, mlp2, flag_add, is_training,
               bn_decay, scope, bn=True, pooling='max', knn=False, use_xyz=True, use_nchw=False):
     """Set-conv, utils/pointnet_util.py:179-250.  Returns ((B, n, mlp[-1]), new_xyz_proj (B,H',W',3))."""

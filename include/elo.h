@@ -326,6 +326,17 @@ typedef struct elo_mlp_args {
     int n_layers;
     elo_dense layers[ELO_MAX_CHAIN];
     float *out;                   /* (rows, layers[last].N) */
+    /* Optional SECOND row-wise MLP in the same launch (n_layers2 > 0), fed by the first one's output: its input rows
+     * are  [ before (w_before) | out | after (w_after) ]  -- flow_predictor's concat [points_f1, upsampled_feat,
+     * cost_volume] (utils/pointnet_util.py:161-166) with the set-upconv stage 2 (:303-311) as the first MLP.
+     * `out` is still written; the second output goes to out2. */
+    int n_layers2;
+    elo_dense layers2[ELO_MAX_CHAIN];
+    const float *before;          /* (rows, w_before) or NULL with w_before == 0 */
+    int w_before;
+    const float *after;           /* (rows, w_after)  or NULL with w_after == 0  */
+    int w_after;
+    float *out2;                  /* (rows, layers2[last].N) */
 } elo_mlp_args;
 int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream);
 int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_stream_t stream);   /* paired launch, as above */

@@ -283,3 +283,32 @@ def test_cost_volume_kernels_with_fp16_storage(B, H, W, C):
         ops.cv_encode1(x1.reshape(B, N, 3), ft1.reshape(B, N, C), x2, ft2.float(), idx_q, m_q)
     with pytest.raises(RuntimeError, match="fp16 needs C and Cc multiples of 8"):
         ops.cv_encode2(x1, ft1[..., :4].contiguous(), cost, idx_p, m_p)
+
+
+@pytest.mark.parametrize("rows,w_src,w_before,w_after", [(904, (64, 32), 32, 64), (3600, (64, 16), 16, 64),
+                                                         (45, (64, 6), 10, 0), (17, (20,), 0, 7)])
+def test_two_stage_mlp_equals_two_launches(rows, w_src, w_before, w_after):
+    """elo_mlp_args second stage (set-upconv stage 2 -> flow predictor in one launch): out and out2 equal the two
+    separate launches bit for bit (same layers, same summation order), for aligned and unaligned widths, ragged last
+    tile, paired jobs."""
+    fused, tf_util = load_pkg("fused"), load_pkg("tf_util")
+    rng = np.random.default_rng(rows)
+    store = tf_util.VariableStore(DEV, seed=rows)
+    r = lambda *s: t(rng.normal(0, 1, s).astype(np.float32))
+
+    def job(tag):
+        with tf_util.default_store(store), torch.no_grad(), tf_util.variable_scope("two_stage_%s" % tag):
+            P = fused.packed_layer
+            k1 = sum(w_src)
+            layers = [P("a0", k1, 128), P("a1", 128, 64)]
+            k2 = w_before + 64 + w_after
+            layers2 = [P("b0", k2, 128), P("b1", 128, 64)]
+        return dict(sources=[r(rows, w) for w in w_src], layers=layers, before=r(rows, w_before) if w_before else None,
+                    after=r(rows, w_after) if w_after else None, layers2=layers2)
+    ja, jb = job("a"), job("b")
+    (o1a, o2a), (o1b, o2b) = fused.mlp2_pair(ja, jb)
+    for j, o1, o2 in ((ja, o1a, o2a), (jb, o1b, o2b)):
+        want1 = fused.mlp(j["sources"], j["layers"])
+        parts = [p for p in (j["before"], want1, j["after"]) if p is not None]
+        want2 = fused.mlp(parts, j["layers2"])
+        assert torch.equal(o1, want1) and torch.equal(o2, want2)
