@@ -98,6 +98,7 @@ SYMBOLS = [
     ("elo_softmax_valid", ctypes.c_int, [ctypes.POINTER(SoftmaxValidArgs), _vp]),
     ("elo_pose_head", ctypes.c_int, [ctypes.POINTER(PoseHeadArgs), _vp]),
     ("elo_warp_project", ctypes.c_int, [ctypes.POINTER(WarpProjectArgs), _vp]),
+    ("elo_pose_head_warp", ctypes.c_int, [ctypes.POINTER(PoseHeadArgs), ctypes.POINTER(WarpProjectArgs), _vp]),
     ("elo_setconv_fused", ctypes.c_int, [ctypes.POINTER(SetconvArgs), _vp]),
     ("elo_mlp_fused", ctypes.c_int, [ctypes.POINTER(MlpArgs), _vp]),
     ("elo_setconv_fused2", ctypes.c_int, [ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),

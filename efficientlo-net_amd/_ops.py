@@ -136,12 +136,17 @@ class ProjectionBuffers:
         self.out_feat = torch.empty((B, H, W, C), dtype=torch.float32, device=device) if C else None
         self.scratch = torch.empty((B * H * W + 2 * B * N,), dtype=torch.int32, device=device)
         self.cleared = False
+        self.result = None          # (warped, out_xyz, out_feat) once a pose head has run the projection itself
 
 
 def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse=None, t_coarse=None, pose7=None,
-              clear=None):
+              clear=None, warp=None):
     """softmax_valid -> conv1d(256) -> q,t heads -> normalise -> compose with the coarse pose, two launches.
-    pwclo_model.py:194-208 / :262-280.  Returns (q (B,4), t (B,3), q_norm (B,4)); `pose7` (B,7), if given, also receives [q_norm | t]."""
+    pwclo_model.py:194-208 / :262-280.  Returns (q (B,4), t (B,3), q_norm (B,4)); `pose7` (B,7), if given, also receives [q_norm | t].
+    `clear`: ProjectionBuffers of the projection that will consume this pose (cleared on the side).
+    `warp` = (xyz (B,N,3), feat (B,N,C) or None) with `clear`: that projection itself -- warp by this pose, spherical
+    re-projection -- is run by this call (elo_pose_head_warp: 3 launches instead of 2 + 2); its result is left in
+    `clear.result` for the warp_project call that follows."""
     L.require_gpu(feature_bnc, weight_bnc, xyz_bn3, W_big, W_q, W_t, q_coarse, t_coarse)
     feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t = _f32(
         feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t)
@@ -161,6 +166,23 @@ def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t
                        ptr(pose7), *((clear.scratch.data_ptr(), clear.out_xyz.data_ptr(), ptr(clear.out_feat),
                                       clear.shape[0] * clear.shape[2] * clear.shape[3], clear.shape[4])
                                      if clear is not None else (None, None, None, 0, 0)))
+    if warp is not None:
+        if clear is None:
+            raise ValueError("warp= needs clear= (the ProjectionBuffers the projection writes)")
+        xyz_w, feat_w = warp
+        (xyz_w,) = _f32(xyz_w)
+        Bw, Nw, Hw, Ww, Cw = clear.shape
+        if xyz_w.shape != (Bw, Nw, 3) or (Cw and (feat_w is None or feat_w.shape != (Bw, Nw, Cw))):
+            raise ValueError("warp inputs do not match the ProjectionBuffers %s" % (clear.shape,))
+        if feat_w is not None:
+            (feat_w,) = _f32(feat_w)
+        warped = torch.empty((Bw, Nw, 3), dtype=torch.float32, device=dev)
+        az, vres, voff = projection_constants(Hw, Ww)
+        w = L.WarpProjectArgs(Bw, Nw, Cw, Hw, Ww, az, vres, voff, xyz_w.data_ptr(), ptr(feat_w), None, None,
+                              warped.data_ptr(), clear.out_xyz.data_ptr(), ptr(clear.out_feat), clear.scratch.data_ptr(), 1)
+        L.call2("elo_pose_head_warp", a, w, q)
+        clear.result = (warped, clear.out_xyz, clear.out_feat)
+        return q, t, q_norm
     L.call("elo_pose_head", a, q)
     if clear is not None:
         clear.cleared = True
@@ -180,6 +202,9 @@ def warp_project(xyz, feat, q, t, H, W, buffers=None):
     """Optional quaternion warp (q,t: (B,4),(B,3) or None) + ProjectPC2SphericalRing.
     Returns (warped (B,N,3) or None, xyz_proj (B,H,W,3), feat_proj (B,H,W,C) or None).
     `buffers`: a ProjectionBuffers of this call's shape, used (and, if a pose head cleared it, not re-initialised)."""
+    if buffers is not None and buffers.result is not None:   # the pose head that produced (q, t) already did it
+        result, buffers.result = buffers.result, None
+        return result
     L.require_gpu(xyz, feat, q, t)
     (xyz,) = _f32(xyz)
     B, N, _ = xyz.shape

@@ -532,6 +532,45 @@ __global__ void softmax_valid_merge_kernel(float *scratch, int batch, int C, int
     out[i] = sv_merge(sv_partials(scratch, batch, C), i / C, i % C, C, parts);
 }
 
+// pass A of the projection for ONE point: warp by (q, t) (q == nullptr: no warp), range bits, cell id, atomicMin of the
+// cell's range.  q, t may live in LDS (the fused pose-head + warp launch) or in global memory.
+__device__ __forceinline__ void warp_cell_point(const elo_warp_project_args &a, long i, int b, const float *q, const float *t,
+                                                unsigned *minr, int *cell_of, unsigned *rbits)
+{
+    float x = a.xyz[i * 3 + 0], y = a.xyz[i * 3 + 1], z = a.xyz[i * 3 + 2];
+    if (q) {
+        const bool keep = !(x == 0.0f && y == 0.0f && z == 0.0f);          // pwclo_model.py:219-221
+        const float q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        // mul_q_point(q, [0,p])      model_util.py:17-36
+        const float v0 = q0 * 0.0f - q1 * x - q2 * y - q3 * z;
+        const float v1 = q0 * x + q1 * 0.0f + q2 * z - q3 * y;
+        const float v2 = q0 * y - q1 * z + q2 * 0.0f + q3 * x;
+        const float v3 = q0 * z + q1 * y - q2 * x + q3 * 0.0f;
+        // inv_q                      model_util.py:61-69
+        const float n2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3 + 1e-10f;
+        const float i0 = q0 / n2, i1 = -q1 / n2, i2 = -q2 / n2, i3 = -q3 / n2;
+        // mul_point_q(v, q^-1)[1:]   model_util.py:39-58
+        const float w1 = v0 * i1 + v1 * i0 + v2 * i3 - v3 * i2;
+        const float w2 = v0 * i2 - v1 * i3 + v2 * i0 + v3 * i1;
+        const float w3 = v0 * i3 + v1 * i2 - v2 * i1 + v3 * i0;
+        const float k = keep ? 1.0f : 0.0f;
+        x = (w1 + t[0]) * k; y = (w2 + t[1]) * k; z = (w3 + t[2]) * k;
+        a.warped[i * 3 + 0] = x; a.warped[i * 3 + 1] = y; a.warped[i * 3 + 2] = z;
+    }
+    const float r = sqrtf(x * x + y * y + z * z);
+    const float PI_F = 3.14159265358979323846f;
+    int col = (int)((PI_F - atan2f(y, x)) / a.az_res);                       // model_util.py:234-235
+    const float beta = asinf(z / r);
+    int row = a.H - (int)(beta / a.vert_res + a.vert_off);                   // NaN -> 0, :237-242
+    row = row < 0 ? 0 : row > a.H - 1 ? a.H - 1 : row;
+    col = col < 0 ? 0 : col > a.W - 1 ? a.W - 1 : col;
+    const int cell = row * a.W + col;
+    const unsigned rb = __float_as_uint(r);        // r >= 0: bit order == float order; NaN sorts last
+    cell_of[i] = cell;
+    rbits[i] = rb;
+    atomicMin(minr + (long)b * a.H * a.W + cell, rb);
+}
+
 // ------------------------------------------------------------ pose head (one block per batch element)
 __device__ __forceinline__ void hamilton(const float *a, const float *b, float *r)
 {   // model_util.py:21-34
@@ -547,12 +586,17 @@ __device__ __forceinline__ void normalise_q(const float *q, float *o)
     for (int i = 0; i < 4; ++i) o[i] = q[i] / n;
 }
 
-__global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_head_args a, const int parts)
+// grid (X, batch).  X = 1: the plain pose head.  X > 1 (elo_pose_head_warp): every block of a batch element computes the
+// same head redundantly -- identical instructions on identical inputs, a few microseconds -- block 0 stores it, and
+// then each block warps its 256 points of the NEXT level's cloud by that pose and does pass A of the projection:
+// the warp no longer waits for a kernel boundary after the pose head.
+__global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_head_args a, const int parts,
+                                                              const elo_warp_project_args w, const int with_warp)
 {
     extern __shared__ float sm[];                      // [C] pooled feature, [hidden] big, [8] heads
     float *feat = sm, *big = sm + a.C, *head = big + a.hidden;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const SvPartials s = sv_partials(a.scratch, gridDim.x, a.C);
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const SvPartials s = sv_partials(a.scratch, gridDim.y, a.C);
     {   // merge the slices: 4 threads per channel (C <= 64), each over every 4th slice, then a 4-way combine
         float *mpart = head + 8 + 8 * (ELO_BLOCK / ELO_WAVE);          // [3][4][64]
         const int c = tid & 63, q = tid >> 6;
@@ -639,12 +683,26 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
             for (int i = 0; i < 3; ++i) t[i] = t_det[i];
         }
         normalise_q(q, qn);
-        for (int i = 0; i < 4; ++i) { a.q[b * 4 + i] = q[i]; a.q_norm[b * 4 + i] = qn[i]; }
-        for (int i = 0; i < 3; ++i) a.t[b * 3 + i] = t[i];
-        if (a.pose7) {
-            for (int i = 0; i < 4; ++i) a.pose7[b * 7 + i] = qn[i];
-            for (int i = 0; i < 3; ++i) a.pose7[b * 7 + 4 + i] = t[i];
+        if (blockIdx.x == 0) {
+            for (int i = 0; i < 4; ++i) { a.q[b * 4 + i] = q[i]; a.q_norm[b * 4 + i] = qn[i]; }
+            for (int i = 0; i < 3; ++i) a.t[b * 3 + i] = t[i];
+            if (a.pose7) {
+                for (int i = 0; i < 4; ++i) a.pose7[b * 7 + i] = qn[i];
+                for (int i = 0; i < 3; ++i) a.pose7[b * 7 + 4 + i] = t[i];
+            }
         }
+        if (with_warp) {
+            for (int i = 0; i < 4; ++i) head[8 + i] = q[i];                   // head[8..15): this level's (q, t) for the warp
+            for (int i = 0; i < 3; ++i) head[12 + i] = t[i];
+        }
+    }
+    if (!with_warp) return;
+    __syncthreads();
+    const long n = (long)blockIdx.x * blockDim.x + tid;
+    if (n < w.npoints) {
+        const size_t cells = (size_t)w.batch * w.H * w.W, pts = (size_t)w.batch * w.npoints;
+        warp_cell_point(w, (long)b * w.npoints + n, b, head + 8, head + 12, w.scratch, (int *)(w.scratch + cells),
+                        w.scratch + cells + pts);
     }
 }
 
@@ -660,46 +718,14 @@ __global__ __launch_bounds__(ELO_BLOCK) void project_init_kernel(unsigned *minr,
     }
 }
 
-// pass A: one thread per point -> warped xyz, range bits, cell id, atomicMin of the cell's range.
+// pass A: one thread per point
 __global__ __launch_bounds__(ELO_BLOCK) void warp_cell_kernel(const elo_warp_project_args a, unsigned *minr,
                                                               int *cell_of, unsigned *rbits)
 {
     const long total = (long)a.batch * a.npoints;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / a.npoints);
-        float x = a.xyz[i * 3 + 0], y = a.xyz[i * 3 + 1], z = a.xyz[i * 3 + 2];
-        if (a.q) {
-            const bool keep = !(x == 0.0f && y == 0.0f && z == 0.0f);          // pwclo_model.py:219-221
-            const float *q = a.q + b * 4, *t = a.t + b * 3;
-            const float q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            // mul_q_point(q, [0,p])      model_util.py:17-36
-            const float v0 = q0 * 0.0f - q1 * x - q2 * y - q3 * z;
-            const float v1 = q0 * x + q1 * 0.0f + q2 * z - q3 * y;
-            const float v2 = q0 * y - q1 * z + q2 * 0.0f + q3 * x;
-            const float v3 = q0 * z + q1 * y - q2 * x + q3 * 0.0f;
-            // inv_q                      model_util.py:61-69
-            const float n2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3 + 1e-10f;
-            const float i0 = q0 / n2, i1 = -q1 / n2, i2 = -q2 / n2, i3 = -q3 / n2;
-            // mul_point_q(v, q^-1)[1:]   model_util.py:39-58
-            const float w1 = v0 * i1 + v1 * i0 + v2 * i3 - v3 * i2;
-            const float w2 = v0 * i2 - v1 * i3 + v2 * i0 + v3 * i1;
-            const float w3 = v0 * i3 + v1 * i2 - v2 * i1 + v3 * i0;
-            const float k = keep ? 1.0f : 0.0f;
-            x = (w1 + t[0]) * k; y = (w2 + t[1]) * k; z = (w3 + t[2]) * k;
-            a.warped[i * 3 + 0] = x; a.warped[i * 3 + 1] = y; a.warped[i * 3 + 2] = z;
-        }
-        const float r = sqrtf(x * x + y * y + z * z);
-        const float PI_F = 3.14159265358979323846f;
-        int col = (int)((PI_F - atan2f(y, x)) / a.az_res);                       // model_util.py:234-235
-        const float beta = asinf(z / r);
-        int row = a.H - (int)(beta / a.vert_res + a.vert_off);                   // NaN -> 0, :237-242
-        row = row < 0 ? 0 : row > a.H - 1 ? a.H - 1 : row;
-        col = col < 0 ? 0 : col > a.W - 1 ? a.W - 1 : col;
-        const int cell = row * a.W + col;
-        const unsigned rb = __float_as_uint(r);        // r >= 0: bit order == float order; NaN sorts last
-        cell_of[i] = cell;
-        rbits[i] = rb;
-        atomicMin(minr + (long)b * a.H * a.W + cell, rb);
+        warp_cell_point(a, i, b, a.q ? a.q + b * 4 : nullptr, a.q ? a.t + b * 3 : nullptr, minr, cell_of, rbits);
     }
 }
 
@@ -865,34 +891,72 @@ extern "C" int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t s
     return check_launch(who);
 }
 
-extern "C" int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream)
+static int check_warp_project(const elo_warp_project_args *a, const char *who)
 {
-    const char *who = "elo_pose_head";
-    ELO_REQUIRE(a, who, "null argument block");
-    ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->C > 0 && a->hidden > 0, who, "bad sizes");
-    ELO_REQUIRE(a->feature && a->weight && a->xyz && a->W_big && a->b_big && a->W_q && a->b_q && a->W_t && a->b_t &&
-                a->q && a->t && a->q_norm && a->scratch, who, "null tensor pointer");
-    ELO_REQUIRE((a->q_coarse == nullptr) == (a->t_coarse == nullptr), who, "q_coarse and t_coarse go together");
-    if (a->batch == 0) return ELO_OK;
-    ELO_REQUIRE(!a->clear_scratch || (a->clear_xyz && a->clear_cells > 0 && a->clear_C >= 0 && (a->clear_feat || a->clear_C == 0)),
-                who, "incomplete clear_* side job");
-    const int parts = sv_parts(a->npoints);
-    hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
-                       dim3(ELO_BLOCK), 0, (hipStream_t)stream, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
-                       a->scratch, ProjectionClear{a->clear_scratch, a->clear_xyz, a->clear_feat, a->clear_cells, a->clear_C});
-    const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (ELO_BLOCK / ELO_WAVE) + 3 * 4 * 64);
-    hipLaunchKernelGGL(pose_head_kernel, dim3(a->batch), dim3(ELO_BLOCK), lds, (hipStream_t)stream, *a, parts);
-    return check_launch(who);
-}
-
-extern "C" int elo_warp_project(const elo_warp_project_args *a, elo_stream_t stream)
-{
-    const char *who = "elo_warp_project";
     ELO_REQUIRE(a, who, "null argument block");
     ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->C >= 0 && a->H > 0 && a->W > 0, who, "bad sizes");
     ELO_REQUIRE(a->xyz && a->out_xyz && a->scratch, who, "null tensor pointer");
     ELO_REQUIRE(a->C == 0 || (a->feat && a->out_feat), who, "features requested without buffers");
     ELO_REQUIRE(!a->q || (a->t && a->warped), who, "warp requested without t / warped");
+    return ELO_OK;
+}
+
+// pose head, optionally followed in the same launches by the warp + projection of `w` (nullptr: none)
+static int pose_head_impl(const elo_pose_head_args *a, const elo_warp_project_args *w, elo_stream_t stream, const char *who)
+{
+    ELO_REQUIRE(a, who, "null argument block");
+    ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->C > 0 && a->hidden > 0, who, "bad sizes");
+    ELO_REQUIRE(a->feature && a->weight && a->xyz && a->W_big && a->b_big && a->W_q && a->b_q && a->W_t && a->b_t &&
+                a->q && a->t && a->q_norm && a->scratch, who, "null tensor pointer");
+    ELO_REQUIRE((a->q_coarse == nullptr) == (a->t_coarse == nullptr), who, "q_coarse and t_coarse go together");
+    ELO_REQUIRE(!a->clear_scratch || (a->clear_xyz && a->clear_cells > 0 && a->clear_C >= 0 && (a->clear_feat || a->clear_C == 0)),
+                who, "incomplete clear_* side job");
+    elo_warp_project_args wv{};
+    if (w) {
+        if (int rc = check_warp_project(w, who)) return rc;
+        ELO_REQUIRE(w->batch == a->batch && w->warped, who, "the warp must have the pose head's batch and a `warped` output");
+        ELO_REQUIRE(a->clear_scratch == w->scratch && a->clear_xyz == w->out_xyz && a->clear_feat == w->out_feat &&
+                    a->clear_cells == (long)w->batch * w->H * w->W && a->clear_C == w->C, who,
+                    "the warp's buffers must be the ones this call clears (clear_*)");
+        wv = *w;
+        wv.q = a->q;                                  // pass B only asks whether a warp happened (reads `warped`)
+        wv.t = a->t;
+    }
+    if (a->batch == 0) return ELO_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int parts = sv_parts(a->npoints);
+    hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
+                       dim3(ELO_BLOCK), 0, s, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
+                       a->scratch, ProjectionClear{a->clear_scratch, a->clear_xyz, a->clear_feat, a->clear_cells, a->clear_C});
+    const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (ELO_BLOCK / ELO_WAVE) + 3 * 4 * 64);
+    const unsigned xb = w ? (unsigned)((w->npoints + ELO_BLOCK - 1) / ELO_BLOCK) : 1u;
+    hipLaunchKernelGGL(pose_head_kernel, dim3(xb, a->batch), dim3(ELO_BLOCK), lds, s, *a, parts, wv, w ? 1 : 0);
+    if (w) {
+        const size_t cells = (size_t)w->batch * w->H * w->W, pts = (size_t)w->batch * w->npoints;
+        const size_t elems = pts * (3 + w->C);
+        const unsigned gb = (unsigned)((elems + ELO_BLOCK - 1) / ELO_BLOCK);
+        hipLaunchKernelGGL(scatter_min_kernel, dim3(gb > 4096 ? 4096 : gb), dim3(ELO_BLOCK), 0, s, wv, w->scratch,
+                           (const int *)(w->scratch + cells), (const unsigned *)(w->scratch + cells + pts));
+    }
+    return check_launch(who);
+}
+
+extern "C" int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream)
+{
+    return pose_head_impl(a, nullptr, stream, "elo_pose_head");
+}
+
+extern "C" int elo_pose_head_warp(const elo_pose_head_args *a, const elo_warp_project_args *w, elo_stream_t stream)
+{
+    const char *who = "elo_pose_head_warp";
+    ELO_REQUIRE(w, who, "null warp block");
+    return pose_head_impl(a, w, stream, who);
+}
+
+extern "C" int elo_warp_project(const elo_warp_project_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_warp_project";
+    if (int rc = check_warp_project(a, who)) return rc;
     if (a->batch == 0) return ELO_OK;
     hipStream_t s = (hipStream_t)stream;
     const size_t cells = (size_t)a->batch * a->H * a->W, pts = (size_t)a->batch * a->npoints;

@@ -170,7 +170,7 @@ def _pose_head(feat_b1c, level, coarse, is_training):
     return q, t
 
 
-def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training, pose7=None, clear=None):
+def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training, pose7=None, clear=None, warp=None):
     """softmax_valid + pose head + composition with the coarse pose (q_coarse None at l3).
     Returns (q (B,4), t (B,3), q_norm (B,4)): the level's pose and its final normalisation (:427-430).
     Inference: two fused HIP launches (_ops.pose_head).  Training: the literal operator chain."""
@@ -181,7 +181,7 @@ def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training,
         W_big, b_big = tf_util.folded_variables('l%d_big' % level, predict.shape[-1], 256, (1,), bn=False)
         W_q, b_q = tf_util.folded_variables(qn % level, 256, 4, (1,), bn=False)
         W_t, b_t = tf_util.folded_variables(tn % level, 256, 3, (1,), bn=False)
-        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7, clear)
+        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7, clear, warp)
     summed = softmax_valid(feature_bnc=predict, weight_bnc=weight, mask_valid=xyz)                  # :194 / :262
     q_det, t_det = _pose_head(summed, level, coarse, is_training)                                   # :197-208 / :264-273
     if coarse:
@@ -286,9 +286,11 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
             return None
         return _ops.ProjectionBuffers(batch_size, xyz_proj_f1[level].shape[1] * xyz_proj_f1[level].shape[2],
                                       out_h_list[g], out_w_list[g], pts_f1[level].shape[-1], dev)
+    def next_warp(level):          # the cloud + features the NEXT warp moves: run by the pose head's own launches
+        return (xyz_proj_f1[level].reshape(batch_size, -1, 3), pts_f1[level]) if inference else None
     next_buffers = projection_buffers(2, 4)
     l3_q, l3_t, l3_q_norm = _estimate_pose(l3_points_predict, l3_cost_volume_w, l3_xyz_f1, 3, None, None,
-                                           is_training, clear=next_buffers)                        # :194-208
+                                           is_training, clear=next_buffers, warp=next_warp(2))     # :194-208
 
     # three warp-refinement levels (:211-425); one loop instead of three pasted blocks
     cv_kernel2 = {2: [5, 15], 1: [7, 25], 0: [11, 41]}                                              # :243,:317,:391
@@ -344,7 +346,8 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                                        bn_decay=bn_decay, scope='l%d_w_predict' % level)])             # :254
         q_prev, t_prev, q_norm = _estimate_pose(predict, weight, xyz_warp_f1, level, q_coarse, t_coarse,
                                                 is_training, pose_out if level == 0 else None,
-                                                clear=next_buffers)                                # :262-280
+                                                clear=next_buffers,
+                                                warp=next_warp(level - 1) if level > 0 else None)  # :262-280
         poses[level] = (q_norm, t_prev)
 
         coarse_w_proj = weight.reshape(batch_size, out_h_list[g], out_w_list[g], -1)                # :256-257

@@ -250,6 +250,13 @@ typedef struct elo_warp_project_args {
 } elo_warp_project_args;
 int elo_warp_project(const elo_warp_project_args *a, elo_stream_t stream);
 
+/* elo_pose_head followed by elo_warp_project of the NEXT level's cloud by the pose it just computed
+ * (pwclo_model.py:211-236 after :194-208 / :262-280), in three launches instead of five: the projection's buffers
+ * are cleared by the pose head's first launch (a->clear_* must name w's scratch / out_xyz / out_feat), every workgroup
+ * of the second launch recomputes the head (block 0 stores it) and warps + bins its 256 points with the (q, t) it holds,
+ * the third launch is the projection's scatter.  w->q / w->t are ignored (the pose is a->q, a->t); w->warped is required. */
+int elo_pose_head_warp(const elo_pose_head_args *a, const elo_warp_project_args *w, elo_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * Fused inference kernels: gather/encode -> chain of 1x1 convolutions (BN and
  * bias folded, ReLU) -> pooling, in ONE launch with the activations of a

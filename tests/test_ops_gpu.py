@@ -239,6 +239,16 @@ def test_pose_head_clears_the_next_projection():
     assert torch.allclose(got[2], want[2], atol=1e-4)
     with pytest.raises(ValueError, match="ProjectionBuffers"):
         ops.warp_project(t(pc), feat, q, tt, H, W + 1, buffers=buf)
+    # elo_pose_head_warp: the pose head runs the projection itself (every block recomputes the head, warps its points)
+    buf2 = ops.ProjectionBuffers(B, N, H, W, C, DEV)
+    buf2.out_xyz.fill_(float("nan")); buf2.out_feat.fill_(-3.0); buf2.scratch.fill_(5)
+    q2, t2, qn2 = ops.pose_head(f, w, xyz_small, Wb, bb, Wq, bq, Wt, bt, clear=buf2, warp=(t(pc), feat))
+    assert all(torch.equal(a, b) for a, b in zip((q2, t2, qn2), plain)) and buf2.result is not None
+    got2 = ops.warp_project(t(pc), feat, q2, t2, H, W, buffers=buf2)           # hands the stored result over
+    assert buf2.result is None
+    assert torch.equal(got2[0], want[0]) and torch.equal(got2[1], want[1]) and torch.allclose(got2[2], want[2], atol=1e-4)
+    with pytest.raises(ValueError, match="needs clear="):
+        ops.pose_head(f, w, xyz_small, Wb, bb, Wq, bq, Wt, bt, warp=(t(pc), feat))
 
 
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 113, 16), (1, 16, 225, 32)])
