@@ -68,7 +68,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 den
 # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_v3/summary.json, collected by
 # tools/pmc_collect.sh: FETCH_SIZE x2 + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); counters cannot
 # be read from inside bench.py.  Only for the exact shapes captured (l0 = 16x225, i.e. 64x1800 inputs); otherwise null.
-PMC_TRAFFIC = {("cv1", 1): 3.65e6, ("cv1", 8): 13.63e6, ("A1", 8): 36.19e6, ("P1", 8): 96.95e6, ("A2", 8): 52.57e6,
+PMC_TRAFFIC = {("cv1", 1): 3.67e6, ("cv1", 8): 13.65e6, ("A1", 8): 36.19e6, ("P1", 8): 96.95e6, ("A2", 8): 52.57e6,
                ("P2", 8): 66.92e6, ("A1", 64): 289.58e6, ("P1", 64): 773.96e6, ("A2", 64): 425.74e6, ("P2", 64): 534.63e6}
 
 
