@@ -228,11 +228,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
+    local %= torch.cuda.device_count()               # (only differs when a test runs several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # nccl == RCCL on ROCm
+        backend = os.environ.get("ELO_BENCH_BACKEND", "nccl")                            # nccl == RCCL on ROCm
+        if backend == "nccl":                        # (gloo: the 2-ranks-on-1-GPU rehearsal of this code path)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     model, synth = pkg("model"), pkg("synth")
     net = model.PWCLONet(dev, seed=0)
