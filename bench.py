@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1800)
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic pairs kept in HBM")
     ap.add_argument("--lanes", type=int, default=8,
-                    help="independent forwards in flight (hipGraphs, spread over the hardware queues)")
+                    help="independent forwards in flight (hipGraphs, dealt over the 4 hardware queues: use a multiple of 4)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=60, help="pairs in the CPU-oracle sample")
