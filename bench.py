@@ -49,8 +49,8 @@ def pkg(sub=None):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=1, help="frame pairs per step per GPU (configs[1]: 1)")
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--width", type=int, default=1800)
