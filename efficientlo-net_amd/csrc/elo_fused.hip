@@ -54,6 +54,57 @@ __device__ __forceinline__ float4 weight_load(__amdgpu_buffer_rsrc_t rsrc, unsig
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, 0));
 }
 
+// ---- fp32-class products on the fp16 matrix cores ---------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 costs 32 cycles per 1024 multiply-adds and, measured (SQ_VALU_MFMA_COEXEC_CYCLES = 0), does
+// not overlap with vector work, so its busy time adds to the kernel time.  v_mfma_f32_16x16x16_f16 does 4096
+// multiply-adds in 8 cycles.  Both operands are therefore split into fp16 hi + lo (x = hi + lo to 2^-20 relative: hi is
+// x with the low 13 mantissa bits cleared -- exactly an fp16 value --, lo = x - hi, both packed with round-toward-zero,
+// which saturates instead of producing inf) and a 16-k block is  hi*hi + hi*lo + lo*hi  with fp32 accumulation: 3 x 8
+// cycles instead of 4 x 32, the dropped lo*lo term is 2^-20 relative.  W is split at packing time (fused.PackedDense:
+// a lane's 16 bytes are [4 halves hi | 4 halves lo]); an A fragment is split when it is read (12 vector instructions
+// per 16-k block and wave, shared by all of the wave's column blocks).  ELO_DENSE_F32 restores the fp32 MFMA path.
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+struct HiLo { half4 hi, lo; };
+
+__device__ __forceinline__ HiLo split_fragment(const float4 a)
+{
+    const float h0 = __uint_as_float(__float_as_uint(a.x) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(a.y) & 0xffffe000u);
+    const float h2 = __uint_as_float(__float_as_uint(a.z) & 0xffffe000u), h3 = __uint_as_float(__float_as_uint(a.w) & 0xffffe000u);
+    auto pk = [](float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); };
+    return HiLo{__builtin_bit_cast(half4, uint2{pk(h0, h1), pk(h2, h3)}),
+                __builtin_bit_cast(half4, uint2{pk(a.x - h0, a.y - h1), pk(a.z - h2, a.w - h3)})};
+}
+
+// one 16-k block of MAXT column blocks: acc[t] += A(16 rows x 16 k) * W_t(16 k x 16 n)
+template <int MAXT>
+__device__ __forceinline__ void mma_block(f32x4 (&acc)[MAXT], const float4 a, const float4 (&w)[MAXT])
+{
+#ifdef ELO_DENSE_F32
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[t].w, acc[t], 0, 0, 0);
+#else
+    const HiLo A = split_fragment(a);
+    half4 bhi[MAXT], blo[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        bhi[t] = __builtin_bit_cast(half4, float2{w[t].x, w[t].y});
+        blo[t] = __builtin_bit_cast(half4, float2{w[t].z, w[t].w});
+    }
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(A.hi, bhi[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(A.hi, blo[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(A.lo, bhi[t], acc[t], 0, 0, 0);
+#endif
+}
+
 // ---- one dense layer on the block's tile ---------------------------------------------------
 // D[TILE x Np] = relu?(A[TILE x Kp] * W + bias) on v_mfma_f32_16x16x4_f32 (exact fp32).  The tile is cut
 // into 16x16 output sub-tiles; wave w owns row block (w % RB) and every (4/RB)-th column block, keeps
@@ -108,14 +159,7 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
 #pragma unroll
         for (int s = 0; s < GS; ++s) {
             if (g * GS + s >= KS) break;
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].x, buf[s][t].x, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].y, buf[s][t].y, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].z, buf[s][t].z, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].w, buf[s][t].w, acc[t], 0, 0, 0);
+            mma_block<MAXT>(acc, a[s], buf[s]);
         }
     };
     float4 b0[GS][MAXT], b1[GS][MAXT];
@@ -234,14 +278,7 @@ __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_
 #pragma unroll
         for (int s = 0; s < GS; ++s) {
             if (g * GS + s >= KS) break;
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].x, buf[s][t].x, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].y, buf[s][t].y, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].z, buf[s][t].z, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].w, buf[s][t].w, acc[t], 0, 0, 0);
+            mma_block<MAXT>(acc, a[s], buf[s]);
         }
     };
     float4 b0[GS][MAXT], b1[GS][MAXT];

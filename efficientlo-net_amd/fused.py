@@ -9,8 +9,13 @@ from . import _lib as L
 from . import tf_util
 
 
+FP32_MFMA = False        # True only with a library built with -DELO_DENSE_F32 (the fp32 MFMA path kept for comparison)
+
+
 class PackedDense:
-    """One inference layer y = act(x @ W + b) with BN folded, packed for v_mfma_f32_16x16x4_f32."""
+    """One inference layer y = act(x @ W + b) with BN folded, packed in MFMA B-fragment order.  Each weight is split
+    into fp16 hi + lo (w = hi + lo to 2^-22 relative) for the three-product fp16 MFMA scheme of elo_fused.hip; a lane's
+    16 bytes of a 16-k x 16-n block are [hi k0..k3 | lo k0..k3]."""
 
     def __init__(self, W, b, relu=True, row_order=None):
         if row_order is not None:                         # the kernel's LDS column order differs from the concat order
@@ -19,8 +24,14 @@ class PackedDense:
         Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
         Wp = torch.zeros((Kp, Np), dtype=torch.float32, device=W.device)
         Wp[:K, :N] = W
-        # packed[((cb*KS + ks)*64 + lane)*4 + s] = Wp[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)]
-        self.w = Wp.reshape(Kp // 16, 4, 4, Np // 16, 16).permute(3, 0, 1, 4, 2).contiguous()
+        # element (cb, ks, lane, s) = Wp[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)], s = 0..3
+        frag = Wp.reshape(Kp // 16, 4, 4, Np // 16, 16).permute(3, 0, 1, 4, 2).contiguous()       # (cb, ks, kq, n, s) fp32
+        if FP32_MFMA:
+            self.w = frag
+        else:
+            hi = frag.to(torch.float16)
+            lo = (frag - hi.to(torch.float32)).to(torch.float16)
+            self.w = torch.stack([hi, lo], dim=-2).contiguous()                                    # (cb, ks, kq, n, 2, 4) fp16
         self.b = torch.zeros((Np,), dtype=torch.float32, device=W.device)
         self.b[:N] = b
         self.K, self.N, self.relu = K, N, relu

@@ -266,11 +266,14 @@ int elo_pose_head_warp(const elo_pose_head_args *a, const elo_warp_project_args 
  * the launch-bound small-batch regime.
  *
  * A layer is  y = act(x[K] @ W[K,N] + b[N]).  `w_packed` is W zero-padded to
- * (Kp = ceil16(K), Np = ceil16(N)) and stored in v_mfma_f32_16x16x4_f32 B-fragment order
- *     w_packed[((cb*(Kp/16) + ks)*64 + lane)*4 + s] = W[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)]
- * so that one wave-wide 16-byte load is a contiguous 1 KiB; `bias` has Np
- * entries (zero padded).  Packing is done once per parameter update by the
- * host (efficientlo-net_amd/fused.py).
+ * (Kp = ceil16(K), Np = ceil16(N)) and stored in MFMA B-fragment order: 16 bytes per (cb, ks, lane),
+ *     element s = 0..3  <->  W[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)]
+ * so that one wave-wide 16-byte load is a contiguous 1 KiB.  The 16 bytes hold the four weights SPLIT into fp16
+ * hi + lo, [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] with hi = fp16(w), lo = fp16(w - hi): the kernels compute
+ * hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x16_f16 with fp32 accumulation (2^-20 relative per product; fp16 range:
+ * |x| < 65504 saturates).  (A library built with -DELO_DENSE_F32 expects four fp32 weights instead and uses
+ * v_mfma_f32_16x16x4_f32.)  `bias` has Np fp32 entries (zero padded).  Packing is done once per parameter update by
+ * the host (efficientlo-net_amd/fused.py).
  * ------------------------------------------------------------------------- */
 typedef struct elo_dense {
     const float *w_packed;
