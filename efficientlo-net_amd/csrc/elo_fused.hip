@@ -118,7 +118,10 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
 {
     constexpr int RB = TILE / 16;                 // row blocks: 1 or 2
     constexpr int CSTEP = FUSED_WAVES / RB;       // column-block stride between a wave's sub-tiles
-    constexpr int GS = MAXT >= 4 ? 2 : 4;         // K steps per prefetch group (register budget: 2*GS*MAXT float4)
+    // 16-k blocks per prefetch group (register budget: 2*GS*MAXT float4).  Half of what it was before the MFMAs moved to
+    // the fp16 cores: the two W buffers were most of the 96 VGPRs; at 64-67 the kernels run 7 waves per SIMD, which hides
+    // more than the deeper prefetch did (+5 % at 8 lanes, +12 % at batch 8, -1 % at one lane).
+    constexpr int GS = MAXT >= 4 ? 1 : 2;
     // the wave index as a SCALAR: row block, column blocks and with them every W / bias base address live in SGPRs,
     // so a W fragment load is `global_load_dwordx4 v, v_lane_off, s[base] offset:imm` with no vector address arithmetic
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -207,7 +210,7 @@ template <int TILE, int N>
 struct Sub {                                          // sub-tiles per wave, K steps per prefetch group
     static constexpr int CSTEP = FUSED_WAVES / (TILE / 16);
     static constexpr int MAXT = ((N + 15) / 16 + CSTEP - 1) / CSTEP;
-    static constexpr int GS = MAXT >= 4 ? 2 : 4;
+    static constexpr int GS = MAXT >= 4 ? 1 : 2;
 };
 
 template <int TILE, int N>
