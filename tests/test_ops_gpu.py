@@ -322,3 +322,25 @@ def test_two_stage_mlp_equals_two_launches(rows, w_src, w_before, w_after):
         parts = [p for p in (j["before"], want1, j["after"]) if p is not None]
         want2 = fused.mlp(parts, j["layers2"])
         assert torch.equal(o1, want1) and torch.equal(o2, want2)
+
+
+def test_dense_layers_keep_fp32_class_accuracy_across_magnitudes():
+    """The fused 1x1 convolutions run as hi*hi + hi*lo + lo*hi of fp16-split operands on the fp16 matrix cores: the
+    result must stay at fp32-class accuracy (not fp16's 1e-3) for inputs from 1e-6 (below fp16's normal range) to 1e3,
+    mixed in one row, against a float64 reference."""
+    fused, tf_util = load_pkg("fused"), load_pkg("tf_util")
+    rng = np.random.default_rng(5)
+    rows, K, N = 333, 144, 128
+    mag = 10.0 ** rng.uniform(-6, 3, (rows, K))
+    x = (rng.normal(0, 1, (rows, K)) * mag).astype(np.float32)
+    W = rng.normal(0, 0.2, (K, N)).astype(np.float32) * (10.0 ** rng.uniform(-3, 0, (K, 1))).astype(np.float32)
+    b = rng.normal(0, 1, (N,)).astype(np.float32)
+    layer = fused.PackedDense(t(W), t(b), relu=False)
+    got = fused.mlp([t(x)], [layer]).cpu().numpy().astype(np.float64)
+    want = x.astype(np.float64) @ W.astype(np.float64) + b
+    scale = np.abs(x.astype(np.float64)) @ np.abs(W.astype(np.float64)) + np.abs(b)      # sum of |terms|: the error scale
+    err = np.abs(got - want) / scale
+    assert err.max() < 1e-5 and np.median(err) < 5e-7, (err.max(), np.median(err))   # ~2^-20 per product; fp16 alone: 5e-4
+    # exact zeros and a zero row stay exact
+    z = np.zeros((16, K), np.float32)
+    assert np.array_equal(fused.mlp([t(z)], [layer]).cpu().numpy(), np.tile(b, (16, 1)))
