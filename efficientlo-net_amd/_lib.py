@@ -64,7 +64,7 @@ Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N",
 _l = ctypes.c_long
 GroupSpec = _struct("elo_group_spec", [
     ("random_hw", _vp), ("kernel_h", _i), ("kernel_w", _i), ("distance", _f), ("stride_h", _i), ("stride_w", _i),
-    ("idx_out", _vp), ("mask_out", _vp)])
+    ("idx_out", _vp), ("mask_out", _vp), ("decoded_hw", _vp)])
 SetconvArgs = _struct("elo_setconv_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1_grid", _vp), ("centre_hw", _vp), ("centre_xyz", _vp), ("src_xyz", _vp), ("src_feat", _vp),

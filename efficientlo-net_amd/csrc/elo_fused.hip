@@ -362,7 +362,7 @@ __device__ __forceinline__ void group_tile(const TileMeta &m, int *lds_off, unsi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int KT = g.kernel_h * g.kernel_w;
     if (tid < TILE) { m.cell[tid] = -1; m.mask[tid] = 0.0f; }
-    stage_offsets(lds_off, g.random_hw, g.kernel_h, g.kernel_w);              // ends with __syncthreads()
+    stage_offsets(lds_off, g.random_hw, g.kernel_h, g.kernel_w, g.decoded_hw);   // ends with __syncthreads()
     const float r2 = g.distance * g.distance;
     for (int pi = wave; pi < P; pi += FUSED_WAVES) {
         const long pt = first_point + pi;
@@ -719,8 +719,9 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
     const elo_group_spec &gs = a.group;
     const int KT = gs.kernel_h * gs.kernel_w, kW = gs.kernel_w, hh = gs.kernel_h / 2, hw2 = gs.kernel_w / 2;
     int off[SMALL_STEPS];                                    // the visiting order first, decoded after the centre load is out
+    const int *order = gs.decoded_hw ? gs.decoded_hw : gs.random_hw;        // decoded by the host, or raw (decoded below)
 #pragma unroll
-    for (int st = 0; st < SMALL_STEPS; ++st) off[st] = gs.random_hw[st * G + lane < KT ? st * G + lane : 0];
+    for (int st = 0; st < SMALL_STEPS; ++st) off[st] = order[st * G + lane < KT ? st * G + lane : 0];
     const long total = (long)a.batch * a.npoints;
     const long pt = (long)xcd_tile(blockIdx.x, gridDim.x) * PER_BLOCK + g;
     const bool live = pt < total;
@@ -731,8 +732,10 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
         const int2 c2 = reinterpret_cast<const int2 *>(a.centre_hw)[ptc];
         hc = c2.x; wc = c2.y;
     }
+    if (!gs.decoded_hw) {
 #pragma unroll
-    for (int st = 0; st < SMALL_STEPS; ++st) off[st] = ((off[st] / kW - hh) << 16) | ((off[st] % kW - hw2) & 0xffff);
+        for (int st = 0; st < SMALL_STEPS; ++st) off[st] = ((off[st] / kW - hh) << 16) | ((off[st] % kW - hw2) & 0xffff);
+    }
     const float *cp = a.xyz1_grid + (((long)b * a.H + hc) * a.W + wc) * 3;
     const float cx = cp[0], cy = cp[1], cz = cp[2];
     const float *grid2 = a.src_xyz + (size_t)b * a.H2 * a.W2 * 3;

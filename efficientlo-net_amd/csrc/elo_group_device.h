@@ -37,9 +37,15 @@ __device__ __forceinline__ Probe probe_slot(const float *__restrict__ grid2, int
 }
 
 // Decode the visiting order once per block: LDS[i] = (dh << 16) | (dw & 0xffff).
-__device__ __forceinline__ void stage_offsets(int *lds_off, const int *__restrict__ perm, int kH, int kW)
+__device__ __forceinline__ void stage_offsets(int *lds_off, const int *__restrict__ perm, int kH, int kW,
+                                              const int *__restrict__ decoded = nullptr)
 {
     const int KT = kH * kW, hh = kH / 2, hw = kW / 2;
+    if (decoded) {                                   // the host decoded the order once (elo_group_spec.decoded_hw)
+        for (int i = threadIdx.x; i < KT; i += blockDim.x) lds_off[i] = decoded[i];
+        __syncthreads();
+        return;
+    }
     for (int i = threadIdx.x; i < KT; i += blockDim.x) {
         const int p = perm[i];
         const int dh = p / kW - hh, dw = p % kW - hw;

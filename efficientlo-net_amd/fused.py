@@ -88,10 +88,33 @@ class Grouping:
             self.mask = torch.empty((B, N, K), dtype=torch.float32, device=device)
         return L.GroupSpec(self.random_hw.data_ptr(), self.kernel_h, self.kernel_w, self.distance, self.stride_h,
                            self.stride_w, self.idx.data_ptr() if self.want_indices else None,
-                           self.mask.data_ptr() if self.want_indices else None)
+                           self.mask.data_ptr() if self.want_indices else None,
+                           _decoded_order(self.random_hw, self.kernel_h, self.kernel_w))
 
 
-_NO_GROUP = L.GroupSpec(None, 0, 0, 0.0, 0, 0, None, None)
+_DECODED = {}
+
+
+def _decoded_order(random_hw, kH, kW):
+    """The visiting order as packed (dh, dw) window offsets (elo_group_spec.decoded_hw), computed once per content of
+    the order tensor (keyed by storage and in-place version counter: PermSource.reshuffle() invalidates it) instead of
+    two integer divisions per slot in every tile.  Never computed while a graph is being captured (the few torch
+    kernels would be recorded into it): the capture's warm-up forwards have filled the cache by then."""
+    key = (random_hw.data_ptr(), kH, kW)
+    hit = _DECODED.get(key)
+    if hit is not None and hit[0] is random_hw and hit[1] == random_hw._version:
+        return hit[2].data_ptr()
+    if random_hw.is_cuda and torch.cuda.is_current_stream_capturing():
+        return None
+    p = random_hw.to(torch.int64)
+    dec = ((((p // kW) - kH // 2) << 16) | (((p % kW) - kW // 2) & 0xffff)).to(torch.int32).contiguous()
+    if len(_DECODED) >= 512:
+        _DECODED.clear()
+    _DECODED[key] = (random_hw, random_hw._version, dec)     # holds the order tensor: its address cannot be reused meanwhile
+    return dec.data_ptr()
+
+
+_NO_GROUP = L.GroupSpec(None, 0, 0, 0.0, 0, 0, None, None, None)
 
 
 def _setconv_args(src_xyz, src_feat, idx, mask, layers, centre_xyz=None, xyz1_grid=None, centre_hw=None, group=None,

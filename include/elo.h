@@ -298,6 +298,9 @@ typedef struct elo_group_spec {
     int stride_h, stride_w;
     int *idx_out;                 /* nullable */
     float *mask_out;              /* nullable */
+    const int *decoded_hw;        /* nullable: random_hw already decoded, entry i = (dh << 16) | (dw & 0xffff) with
+                                   * dh = random_hw[i] / kernel_w - kernel_h/2, dw = random_hw[i] % kernel_w - kernel_w/2;
+                                   * spares every tile two integer divisions per window slot */
 } elo_group_spec;
 
 /* set-conv / set-upconv stage 1:  group_concat -> chain -> masked max over K.
