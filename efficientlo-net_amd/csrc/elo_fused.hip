@@ -359,7 +359,7 @@ __device__ __forceinline__ void group_tile(const TileMeta &m, int *lds_off, unsi
                                            const int *__restrict__ centre_hw, const float *__restrict__ grid2,
                                            int H2, int W2, float *__restrict__ new_xyz)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: point index, batch, centre address stay off the vector unit
     const int KT = g.kernel_h * g.kernel_w;
     if (tid < TILE) { m.cell[tid] = -1; m.mask[tid] = 0.0f; }
     stage_offsets(lds_off, g.random_hw, g.kernel_h, g.kernel_w, g.decoded_hw);   // ends with __syncthreads()
