@@ -70,7 +70,7 @@ MFMA_PRODUCTS = 3              # fp16 matrix-core products per fp32-class produc
 # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_v3/summary.json, collected by
 # tools/pmc_collect.sh: FETCH_SIZE x2 + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); counters cannot
 # be read from inside bench.py.  Only for the exact shapes captured (l0 = 16x225, i.e. 64x1800 inputs); otherwise null.
-PMC_TRAFFIC = {("cv1", 1): 3.59e6, ("cv1", 8): 13.58e6, ("A1", 8): 36.19e6, ("P1", 8): 96.95e6, ("A2", 8): 52.57e6,
+PMC_TRAFFIC = {("cv1", 1): 3.61e6, ("cv1", 8): 13.59e6, ("A1", 8): 36.19e6, ("P1", 8): 96.95e6, ("A2", 8): 52.57e6,
                ("P2", 8): 66.92e6, ("A1", 64): 289.58e6, ("P1", 64): 773.96e6, ("A2", 64): 425.74e6, ("P2", 64): 534.63e6}
 
 
