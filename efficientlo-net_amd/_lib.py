@@ -87,6 +87,7 @@ Cv2Args = _struct("elo_cv2_args", [
 # every symbol include/elo.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("elo_abi_version", ctypes.c_int, []),
+    ("elo_dense_f32", ctypes.c_int, []),
     ("elo_last_error", ctypes.c_char_p, []),
     ("elo_fused_conv_random_k", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
     ("elo_fused_conv_select_k", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),

@@ -1140,6 +1140,15 @@ static bool same_shape(const elo_setconv_args *a, const elo_setconv_args *b)
     return true;
 }
 
+extern "C" int elo_dense_f32(void)
+{
+#ifdef ELO_DENSE_F32
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_args *b, elo_stream_t stream)
 {
     const char *who = "elo_setconv_fused";

@@ -9,7 +9,10 @@ from . import _lib as L
 from . import tf_util
 
 
-FP32_MFMA = False        # True only with a library built with -DELO_DENSE_F32 (the fp32 MFMA path kept for comparison)
+def fp32_mfma():
+    """True when libelo_hip.so was built with -DELO_DENSE_F32 (the fp32 MFMA path kept for comparison): the packed
+    weights then stay fp32.  Asked of the library itself so that host packing and kernels cannot disagree."""
+    return bool(L.lib().elo_dense_f32())
 
 
 class PackedDense:
@@ -26,7 +29,7 @@ class PackedDense:
         Wp[:K, :N] = W
         # element (cb, ks, lane, s) = Wp[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)], s = 0..3
         frag = Wp.reshape(Kp // 16, 4, 4, Np // 16, 16).permute(3, 0, 1, 4, 2).contiguous()       # (cb, ks, kq, n, s) fp32
-        if FP32_MFMA:
+        if fp32_mfma():
             self.w = frag
         else:
             hi = frag.to(torch.float16)

@@ -30,6 +30,7 @@ typedef enum elo_status {
 } elo_status;
 
 int elo_abi_version(void);          /* bumps when a struct below changes layout */
+int elo_dense_f32(void);            /* 1: built with -DELO_DENSE_F32 (elo_dense.w_packed holds fp32 weights), 0: fp16 hi|lo */
 const char *elo_last_error(void);   /* thread-local, never NULL                 */
 
 /* ------------------------------------------------------------------------- *
