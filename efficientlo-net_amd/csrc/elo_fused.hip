@@ -386,7 +386,7 @@ __device__ __forceinline__ void group_tile(const TileMeta &m, int *lds_off, unsi
         };
         int count = 0;
         if (!(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS)) {                // valid centre (:62-70)
-            const float *gb = grid2 + (size_t)b * H2 * W2 * 3;
+            const GridBuf gb = grid_buffer(grid2 + (size_t)b * H2 * W2 * 3);      // b is scalar: the resource lives in SGPRs
             if (SELECT)
                 count = wave_select_k(gb, H2, W2, KT, K, lds_off, hc / g.stride_h, wc / g.stride_w, cx, cy, cz, r2,
                                       scratch + (size_t)wave * 2 * KT, reinterpret_cast<int *>(scratch) + (size_t)wave * 2 * KT + KT, emit);
@@ -1054,6 +1054,7 @@ int check_group(const elo_group_spec &g, int H2, int W2, size_t lds_bytes, const
     if (g.kernel_w / 2 > W2)
         return fail(ELO_ERR_LIMIT, "%s: kernel_size_W/2 = %d exceeds the queried width %d (single wrap)", who, g.kernel_w / 2, W2);
     if (H2 >= 32768 || W2 >= 65536) return fail(ELO_ERR_LIMIT, "%s: queried grid larger than 32767 x 65535", who);
+    if ((long)H2 * W2 * 12 >= 0x7fffffffL) return fail(ELO_ERR_LIMIT, "%s: queried grid beyond 2 GB per batch element (buffer addressing)", who);
     if (lds_bytes > 64 * 1024)
         return fail(ELO_ERR_LIMIT, "%s: window %dx%d needs %zu bytes of LDS for in-kernel grouping", who, g.kernel_h, g.kernel_w, lds_bytes);
     return ELO_OK;

@@ -16,8 +16,33 @@ struct Probe {
     int hw;       // (h << 16) | w of the probed pixel
 };
 
+// The queried grid is read either through a plain pointer (stand-alone kernels) or through a buffer resource (fused
+// kernels: the base is wave-uniform, so it lives in scalar registers and a probe's address is one 32-bit pixel*12
+// instead of a 64-bit vector multiply-add per load -- three of those per probe in the ISA of the pointer form).
+struct GridBuf { __amdgpu_buffer_rsrc_t rsrc; };
+struct Xyz { float x, y, z; };
+
+__device__ __forceinline__ GridBuf grid_buffer(const float *base)
+{
+    return GridBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000)};
+}
+
+__device__ __forceinline__ Xyz pixel3(const float *__restrict__ grid, int pixel)
+{
+    const float *q = grid + (size_t)pixel * 3;
+    return Xyz{q[0], q[1], q[2]};
+}
+
+__device__ __forceinline__ Xyz pixel3(const GridBuf &grid, int pixel)
+{
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    const f32x3 v = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(grid.rsrc, pixel * 12, 0, 0));
+    return Xyz{v.x, v.y, v.z};
+}
+
 // One window slot of one centre. fused_conv_g.cu:80-123.
-__device__ __forceinline__ Probe probe_slot(const float *__restrict__ grid2, int H2, int W2, int off,
+template <class Grid>
+__device__ __forceinline__ Probe probe_slot(const Grid &grid2, int H2, int W2, int off,
                                             int base_h, int base_w, float cx, float cy, float cz, float r2)
 {
     Probe p{false, false, ELO_FAR, 0};
@@ -26,8 +51,8 @@ __device__ __forceinline__ Probe probe_slot(const float *__restrict__ grid2, int
     if (h < 0 || h >= H2) return p;
     if (w < 0) w += W2;
     if (w >= W2) w -= W2;
-    const float *q = grid2 + ((size_t)h * W2 + w) * 3;
-    const float qx = q[0], qy = q[1], qz = q[2];
+    const Xyz q = pixel3(grid2, h * W2 + w);
+    const float qx = q.x, qy = q.y, qz = q.z;
     if (sq3(qx, qy, qz) <= ELO_EPS) return p;
     p.valid = true;
     p.d = pick_max(sq3(__fsub_rn(cx, qx), __fsub_rn(cy, qy), __fsub_rn(cz, qz)), ELO_EPS);
@@ -60,8 +85,8 @@ __device__ __forceinline__ void stage_offsets(int *lds_off, const int *__restric
 // slots count..K-1 are the reference's zero-filled slots (index (0,0,0), mask 0).
 
 // first K in-range neighbours in visiting order
-template <class Emit>
-__device__ __forceinline__ int wave_random_k(const float *__restrict__ grid2, int H2, int W2, int KT, int K,
+template <class Grid, class Emit>
+__device__ __forceinline__ int wave_random_k(const Grid &grid2, int H2, int W2, int KT, int K,
                                              const int *lds_off, int base_h, int base_w, float cx, float cy, float cz,
                                              float r2, Emit emit)
 {
@@ -85,7 +110,8 @@ __device__ __forceinline__ int wave_random_k(const float *__restrict__ grid2, in
 // several probes can have their loads in flight together; judge() then applies fused_conv_g.cu:83-123.
 struct RawSlot { float x, y, z; int hw; bool in_grid; };
 
-__device__ __forceinline__ RawSlot fetch_slot(const float *__restrict__ grid2, int H2, int W2, int off, int base_h,
+template <class Grid>
+__device__ __forceinline__ RawSlot fetch_slot(const Grid &grid2, int H2, int W2, int off, int base_h,
                                               int base_w, bool active)
 {
     int h = base_h + (off >> 16);
@@ -95,8 +121,8 @@ __device__ __forceinline__ RawSlot fetch_slot(const float *__restrict__ grid2, i
     if (w < 0) w += W2;
     if (w >= W2) w -= W2;
     w = w < 0 ? 0 : w >= W2 ? W2 - 1 : w;               // only reachable for inactive lanes
-    const float *q = grid2 + ((size_t)h * W2 + w) * 3;
-    return RawSlot{q[0], q[1], q[2], (h << 16) | w, in_grid};
+    const Xyz q = pixel3(grid2, h * W2 + w);
+    return RawSlot{q.x, q.y, q.z, (h << 16) | w, in_grid};
 }
 
 __device__ __forceinline__ Probe judge(const RawSlot &r, float cx, float cy, float cz, float r2)
@@ -118,8 +144,8 @@ __host__ __device__ __forceinline__ bool select_in_registers(int KT, int K) { re
 // Windows up to 512 slots with K <= 8 (the three refinement cost volumes) keep the whole (distance, hw) array in REGISTERS --
 // position j*64 + lane lives in register j of that lane -- and run the K rounds with DPP reductions and three
 // lane broadcasts per round; larger windows use the LDS arrays dist/pay ([KT] wave-private each).
-template <class Emit>
-__device__ __forceinline__ int wave_select_k(const float *__restrict__ grid2, int H2, int W2, int KT, int K,
+template <class Grid, class Emit>
+__device__ __forceinline__ int wave_select_k(const Grid &grid2, int H2, int W2, int KT, int K,
                                              const int *lds_off, int base_h, int base_w, float cx, float cy, float cz,
                                              float r2, unsigned *dist, int *pay, Emit emit)
 {
