@@ -349,9 +349,10 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_vec_kernel(const elo_s
     const int lstep = a.C >> 2, vstep = a.values_stride >> 2;
     const float *m = a.mask + r * a.K;
     float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, den[4] = {0, 0, 0, 0}, acc[4] = {0, 0, 0, 0};
-    // fp16 results carry 11 bits: the hardware exp2 (v_exp_f32, ~1 ulp of fp32) is exact enough there and a fifth of
-    // the instructions of expf, which is what bounds this kernel once the bytes are halved.  fp32 keeps expf.
-    auto ex = [](float x) { return sizeof(T) == 2 ? __builtin_amdgcn_exp2f(x * 1.44269504088896f) : expf(x); };
+    // e^x on the hardware exp2 (v_exp_f32, ~1 ulp of fp32): a fifth of the instructions of expf's range-reduced
+    // polynomial, and the exponentials are what bounds this kernel (the softmax weights feed a convex combination: the
+    // result moves by ~1e-7 relative, far inside the 1e-4 parity tolerance).
+    auto ex = [](float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896f); };
     for (int k0 = 0; k0 < a.K; k0 += 4) {
         V4 l4[4], v4[4];
         float mk[4];
