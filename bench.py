@@ -67,11 +67,13 @@ def parse():
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak (= the fp32 vector peak)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (2495 TF measured)
 MFMA_PRODUCTS = 3              # fp16 matrix-core products per fp32-class product: hi*hi + hi*lo + lo*hi (elo_fused.hip)
-# HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_v3/summary.json, collected by
+# HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_v3 and r01_pmc_v4/summary.json, collected by
 # tools/pmc_collect.sh: FETCH_SIZE x2 + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); counters cannot
 # be read from inside bench.py.  Only for the exact shapes captured (l0 = 16x225, i.e. 64x1800 inputs); otherwise null.
-PMC_TRAFFIC = {("cv1", 1): 3.61e6, ("cv1", 8): 13.59e6, ("A1", 8): 36.19e6, ("P1", 8): 96.95e6, ("A2", 8): 52.57e6,
-               ("P2", 8): 66.92e6, ("A1", 64): 289.58e6, ("P1", 64): 773.96e6, ("A2", 64): 425.74e6, ("P2", 64): 534.63e6}
+PMC_TRAFFIC = {("cv1", 1): 3.61e6, ("cv1", 8): 13.59e6, ("A1", 8): 36.98e6, ("P1", 8): 96.68e6, ("A2", 8): 52.56e6,
+               ("P2", 8): 66.88e6, ("A1", 64): 298.34e6, ("P1", 64): 772.78e6, ("A2", 64): 420.23e6, ("P2", 64): 534.60e6,
+               ("A1", 64, "f16"): 168.88e6, ("P1", 64, "f16"): 389.00e6, ("A2", 64, "f16"): 218.92e6,
+               ("P2", 64, "f16"): 269.17e6}
 
 
 def cost_volume_bytes(N, C, Kq, Kp, s=4):
@@ -171,7 +173,7 @@ def roofline_leg(args, dev, net, reps=50):
         cost = cast(torch.randn((batch, H, W, 64), generator=g).to(dev))
         lq, vq = (cast(torch.randn((batch, N, Kq, 64), generator=g).to(dev)) for _ in range(2))
         lp, vp = (cast(torch.randn((batch, N, Kp, 64), generator=g).to(dev)) for _ in range(2))
-        legs = {"A1": ("cv_encode1_vec_kernel", lambda: ops.cv_encode1(x1.reshape(batch, N, 3), ft1.reshape(batch, N, C),
+        legs = {"A1": ("cv_encode1_col_kernel", lambda: ops.cv_encode1(x1.reshape(batch, N, 3), ft1.reshape(batch, N, C),
                                                                         x2, ft2, idx_q, m_q)),
                 "P1": ("softmax_pool_vec_kernel", lambda: ops.masked_softmax_pool(lq, vq, m_q)),
                 "A2": ("cv_encode2_vec_kernel", lambda: ops.cv_encode2(x1, ft1, cost, idx_p, m_p)),
@@ -182,7 +184,7 @@ def roofline_leg(args, dev, net, reps=50):
             nbytes = cvb[term] * batch
             terms[term] = {"kernel": name, "bytes": int(nbytes), "us": round(s * 1e6, 3),
                            "GBps": round(nbytes / s / 1e9, 1), "frac": round(nbytes / s / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic": None if half else PMC_TRAFFIC.get((term, batch))}
+                           "traffic": PMC_TRAFFIC.get((term, batch, "f16") if half else (term, batch))}
             tot_b, tot_s = tot_b + nbytes, tot_s + s
         gbs = tot_b / tot_s / 1e9
         return {"kernel": "cost volume at l0, ELO_FUSED=0 path: encode1 + pool + encode2 + pool (A1+P1+A2+P2)" +
@@ -201,7 +203,7 @@ def roofline_leg(args, dev, net, reps=50):
             "us_per_launch": round(sec * 1e6, 3),
             "algorithmic_bytes_per_launch": int((cvb["A1"] + cvb["P1"]) * B),
             "hbm_equivalent_GBps": round((cvb["A1"] + cvb["P1"]) * B / sec / 1e9, 2),
-            "per_operator": per_operator_leg(B), "per_operator_b8": per_operator_leg(8),
+            "per_operator": per_operator_leg(B), "per_operator_b8": per_operator_leg(8), "per_operator_b64": per_operator_leg(64),
             "per_operator_b8_f16": per_operator_leg(8, half=True), "per_operator_b64_f16": per_operator_leg(64, half=True)}
 
 

@@ -227,6 +227,11 @@ __device__ __forceinline__ void resolve_rows(RowFacts<ENC_ROWS> &rf, long first,
     __syncthreads();
 }
 
+// Outputs of the encode / pool kernels are written once and read by a later launch: non-temporal stores keep them from
+// allocating in L2 on the way out (measured at l0: A1 9.5 -> 8.4 us at B=8 and 70 -> 53 us at B=64, A2 99 -> 61 us at
+// B=64).  Non-temporal LOADS of the pool's inputs were mixed (P1 B=8 15.8 -> 17.1 us, P2 11.9 -> 10.4) and are not used.
+#define STREAM_STORE(v, p) __builtin_nontemporal_store(v, p)
+
 constexpr int ENC_UNROLL = 3;                        // slots in flight per thread
 
 // ---- storage types of the feature tensors: fp32, or fp16 storage with fp32 arithmetic (elo.h: ELO_F16) -----------
@@ -280,7 +285,57 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_vec_kernel(const elo_cv_
             const float sc = j[u] < 5 + HC ? 1.0f : rf.mask[lr[u]];
             const float2 geo = *reinterpret_cast<const float2 *>(&rf.geo[lr[u]][j[u] < 5 ? 2 * j[u] : 0]);
             const float lo = j[u] < 5 ? geo.x : (float)f[u].x * sc, hi = j[u] < 5 ? geo.y : (float)f[u].y * sc;
-            if (s0 + u * ELO_BLOCK < nslots) out[s0 + u * ELO_BLOCK] = V2{(T)lo, (T)hi};
+            if (s0 + u * ELO_BLOCK < nslots) STREAM_STORE((V2{(T)lo, (T)hi}), &out[s0 + u * ELO_BLOCK]);
+        }
+    }
+}
+
+// Column-owner form of stage 1, for row lengths that tile the workgroup: RPI = 256 / (5 + C) whole rows fit the 256
+// threads with few lanes over (C = 16: 12 rows x 21 slots = 252).  Thread t keeps ONE slot column j = t % (5 + C) for
+// its whole life and walks rows t / (5 + C), + RPI, ...: what a slot is (geometry / own feature / neighbour feature),
+// its source tensor and its channel offset are loop invariants, the per-slot work is one row-fact read, one 8-byte
+// load and one 8-byte store, and the wave's stores stay contiguous (slot index = row * (5 + C) + j = t + RPI*(5+C)*i).
+// A workgroup spans RPI * ENC_BATCH * rounds rows (a whole number of ENC_BATCH-deep load batches: no clamped tail
+// inside a span).
+constexpr int ENC_BATCH = 5;
+
+template <int ENC_ROWS, class T>
+__global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_col_kernel(const elo_cv_encode1_args a, const long rows,
+                                                                   const FastDiv by_slots, const FastDiv by_K,
+                                                                   const int rpi, const int span)
+{
+    typedef typename Store<T>::V2 V2;
+    __shared__ RowFacts<ENC_ROWS> rf;
+    const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * span;
+    if (first >= rows) return;
+    const int C = a.C, HC = C >> 1, HP = 5 + C;
+    const int nrows = (int)(rows - first < span ? rows - first : span);
+    const long bn0 = first / a.K;
+    const unsigned rem0 = (unsigned)(first - bn0 * a.K);
+    resolve_rows(rf, first, nrows, bn0, rem0, by_K, a.idx, a.mask, a.xyz1, a.xyz2, a.H2, a.W2);
+    const int r0 = (int)by_slots(threadIdx.x), j = (int)threadIdx.x - r0 * HP;
+    if (r0 >= rpi) return;                           // the 256 % (5 + C) lanes over
+    const bool geo = j < 5, own = j < 5 + HC;
+    const T *src = own ? static_cast<const T *>(a.feat1) + (geo ? 0 : 2 * (j - 5))
+                       : static_cast<const T *>(a.feat2) + 2 * (j - 5 - HC);
+    const int g2 = geo ? 2 * j : 0;
+    V2 *__restrict__ out = reinterpret_cast<V2 *>(static_cast<T *>(a.out) + first * (2 * HP)) + threadIdx.x;
+    const int step = rpi * HP;
+    for (int lr0 = r0; lr0 < nrows; lr0 += rpi * ENC_BATCH, out += step * ENC_BATCH) {
+        V2 f[ENC_BATCH];
+        int lr[ENC_BATCH];
+#pragma unroll
+        for (int u = 0; u < ENC_BATCH; ++u) {
+            lr[u] = lr0 + u * rpi < nrows ? lr0 + u * rpi : nrows - 1;          // clamped (last workgroup only)
+            const long from = own ? bn0 + by_K(rem0 + lr[u]) : rf.cell[lr[u]];
+            f[u] = *reinterpret_cast<const V2 *>(src + from * C);
+        }
+#pragma unroll
+        for (int u = 0; u < ENC_BATCH; ++u) {
+            const float sc = own ? 1.0f : rf.mask[lr[u]];
+            const float2 gv = *reinterpret_cast<const float2 *>(&rf.geo[lr[u]][g2]);
+            const float lo = geo ? gv.x : (float)f[u].x * sc, hi = geo ? gv.y : (float)f[u].y * sc;
+            if (lr0 + u * rpi < nrows) STREAM_STORE((V2{(T)lo, (T)hi}), &out[u * step]);
         }
     }
 }
@@ -322,12 +377,12 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_vec_kernel(const elo_cv_
             V16 v;
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = (T)((float)f[u][e] * sc[u]);
-            if (s0 + u * ELO_BLOCK < nslots) rest[s0 + u * ELO_BLOCK] = v;
+            if (s0 + u * ELO_BLOCK < nslots) STREAM_STORE(v, &rest[s0 + u * ELO_BLOCK]);
         }
     }
     V2 *__restrict__ geo = reinterpret_cast<V2 *>(static_cast<T *>(a.xyz_cat) + first * 10);
     const float2 *staged = reinterpret_cast<const float2 *>(&rf.geo[0][0]);
-    for (int s = threadIdx.x; s < nrows * 5; s += ELO_BLOCK) geo[s] = V2{(T)staged[s].x, (T)staged[s].y};
+    for (int s = threadIdx.x; s < nrows * 5; s += ELO_BLOCK) STREAM_STORE((V2{(T)staged[s].x, (T)staged[s].y}), &geo[s]);
 }
 
 // ------------------------------------------------------------ masked softmax-pool over K
@@ -335,7 +390,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_vec_kernel(const elo_cv_
 // point, so a wave streams 4 points' K x C logits and values with 16-byte (fp32) / 8-byte (fp16) loads -- every load
 // instruction of the wave covers four full rows -- in ONE pass (online softmax, fp32 arithmetic) and writes 4 channels
 // per lane.
-template <class T>
+template <class T, int U>                           // U neighbour rows in flight per lane (6 when K is a multiple of 6, else 4)
 __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_vec_kernel(const elo_softmax_pool_args a, const long rows)
 {
     typedef typename Store<T>::V4 V4;
@@ -353,18 +408,18 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_vec_kernel(const elo_s
     // polynomial, and the exponentials are what bounds this kernel (the softmax weights feed a convex combination: the
     // result moves by ~1e-7 relative, far inside the 1e-4 parity tolerance).
     auto ex = [](float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896f); };
-    for (int k0 = 0; k0 < a.K; k0 += 4) {
-        V4 l4[4], v4[4];
-        float mk[4];
+    for (int k0 = 0; k0 < a.K; k0 += U) {
+        V4 l4[U], v4[U];
+        float mk[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                                // four neighbour rows in flight
+        for (int u = 0; u < U; ++u) {
             const int k = k0 + u < a.K ? k0 + u : a.K - 1;
             l4[u] = lg[(long)k * lstep];
             v4[u] = vl[(long)k * vstep];
             mk[u] = m[k];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (k0 + u >= a.K) break;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -382,8 +437,8 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_vec_kernel(const elo_s
             }
         }
     }
-    reinterpret_cast<V4 *>(static_cast<T *>(a.out) + r * a.C)[sub] =
-        V4{(T)(acc[0] / den[0]), (T)(acc[1] / den[1]), (T)(acc[2] / den[2]), (T)(acc[3] / den[3])};
+    STREAM_STORE((V4{(T)(acc[0] / den[0]), (T)(acc[1] / den[1]), (T)(acc[2] / den[2]), (T)(acc[3] / den[3])}),
+                 &reinterpret_cast<V4 *>(static_cast<T *>(a.out) + r * a.C)[sub]);
 }
 
 // scalar form for any C / alignment
@@ -796,9 +851,22 @@ extern "C" int elo_cv_encode1(const elo_cv_encode1_args *a, elo_stream_t stream)
     if (a->dtype == ELO_F16 && !vec) return fail(ELO_ERR_ARG, "%s: fp16 needs an even C < 500 and 4-byte aligned tensors", who);
     if (vec) {
         const int per = enc_rows(rows);
-        const dim3 grid((unsigned)((rows + per - 1) / per));
         const FastDiv ds = fast_div(5 + a->C), dk = fast_div(a->K);
         hipStream_t s = (hipStream_t)stream;
+        const int rpi = ELO_BLOCK / (5 + a->C), batch_rows = rpi * ENC_BATCH;
+        if (batch_rows <= per && rpi * (5 + a->C) * 16 >= ELO_BLOCK * 15 && !getenv("ELO_ENCODE1_SLOTS")) {   // <= 1/16 of the lanes idle
+            const int span = per / batch_rows * batch_rows;
+            const dim3 cgrid((unsigned)((rows + span - 1) / span));
+            if (a->dtype == ELO_F16) {
+                if (per == 128) hipLaunchKernelGGL((cv_encode1_col_kernel<128, half_t>), cgrid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk, rpi, span);
+                else hipLaunchKernelGGL((cv_encode1_col_kernel<64, half_t>), cgrid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk, rpi, span);
+            } else {
+                if (per == 128) hipLaunchKernelGGL((cv_encode1_col_kernel<128, float>), cgrid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk, rpi, span);
+                else hipLaunchKernelGGL((cv_encode1_col_kernel<64, float>), cgrid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk, rpi, span);
+            }
+            return check_launch(who);
+        }
+        const dim3 grid((unsigned)((rows + per - 1) / per));
         if (a->dtype == ELO_F16) {
             if (per == 128) hipLaunchKernelGGL((cv_encode1_vec_kernel<128, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
             else hipLaunchKernelGGL((cv_encode1_vec_kernel<64, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
@@ -862,8 +930,14 @@ extern "C" int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_strea
     if (vec) {
         const int rows_per_block = ELO_BLOCK / (a->C / 4);
         const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
-        if (a->dtype == ELO_F16) hipLaunchKernelGGL(softmax_pool_vec_kernel<half_t>, grid, dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
-        else hipLaunchKernelGGL(softmax_pool_vec_kernel<float>, grid, dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
+        hipStream_t s = (hipStream_t)stream;
+        if (a->K % 6 == 0) {
+            if (a->dtype == ELO_F16) hipLaunchKernelGGL((softmax_pool_vec_kernel<half_t, 6>), grid, dim3(ELO_BLOCK), 0, s, *a, rows);
+            else hipLaunchKernelGGL((softmax_pool_vec_kernel<float, 6>), grid, dim3(ELO_BLOCK), 0, s, *a, rows);
+        } else {
+            if (a->dtype == ELO_F16) hipLaunchKernelGGL((softmax_pool_vec_kernel<half_t, 4>), grid, dim3(ELO_BLOCK), 0, s, *a, rows);
+            else hipLaunchKernelGGL((softmax_pool_vec_kernel<float, 4>), grid, dim3(ELO_BLOCK), 0, s, *a, rows);
+        }
         return check_launch(who);
     }
     hipLaunchKernelGGL(softmax_pool_kernel, dim3(grid_for_rows(rows)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);

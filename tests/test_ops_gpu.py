@@ -283,8 +283,8 @@ def test_cost_volume_kernels_with_fp16_storage(B, H, W, C):
         lg, vl = h(B, N, K, 64) * 3, h(B, N, K, 64)
         p16 = ops.masked_softmax_pool(lg, vl, mask)
         p32 = ops.masked_softmax_pool(lg.float(), vl.float(), mask)
-        # the fp16 instantiation uses the hardware exp2 instead of expf: equal to within fp16 rounding, not bit-equal
-        assert p16.dtype == torch.float16 and torch.allclose(p16.float(), p32, rtol=2e-3, atol=1e-3)
+        # same fp32 arithmetic on the same (fp16-representable) inputs: the fp16 result is the fp32 one rounded once
+        assert p16.dtype == torch.float16 and torch.equal(p16, p32.half())
         wide = h(B, N, K, 128)                               # values as a channel slice of a wider tensor (stride 128)
         assert torch.allclose(ops.masked_softmax_pool(lg, wide[..., :64], mask).float(),
                               ops.masked_softmax_pool(lg.float(), wide[..., :64].float().contiguous(), mask),

@@ -4,7 +4,7 @@
 cv1     = fused stage 1 at l0 (16x225, K=6, C=16)          -> cv1_kernel
 pool    = per-operator masked softmax pool, K=6 (P1 term)  -> softmax_pool_vec_kernel
 pool2   = the same with K=4 (P2 term)
-encode1 = per-operator gather + geometry encode (A1 term)  -> cv_encode1_vec_kernel
+encode1 = per-operator gather + geometry encode (A1 term)  -> cv_encode1_col_kernel (C = 16), cv_encode1_vec_kernel otherwise
 encode2 = per-operator stage-2 gather + encode (A2 term)    -> cv_encode2_vec_kernel
 Prints the algorithmic bytes / flops per launch it used.
 """
