@@ -151,10 +151,16 @@ def roofline_leg(args, dev, net, reps=50):
     flops = cv1_flops(N, C, Kq) * B
     cvb = cost_volume_bytes(N, C, Kq, 4)
     tfs = flops / sec / 1e12
-    def per_operator_leg(batch, half=False):
-        """The four cost-volume kernels of the ELO_FUSED=0 path at l0 (SURVEY 8(d) terms A1, P1, A2, P2), each
+    LEVELS = {"l0": (oh[2], ow[2], 16, 6, (11, 41)), "l1": (oh[3], ow[3], 32, 6, (7, 25)),
+              "l2": (oh[4], ow[4], 64, 6, (5, 15)), "l2_origin": (oh[4], ow[4], 64, 32, (5, 35))}      # pwclo_model.py cost_volume calls
+
+    def per_operator_leg(batch, half=False, level="l0"):
+        """The four cost-volume kernels of the ELO_FUSED=0 path at one level (SURVEY 8(d) terms A1, P1, A2, P2), each
         against its own algorithmic bytes, and the four together.  `half`: fp16 feature storage (s = 2; BASELINE
         configs[2]), fp32 arithmetic."""
+        H, W, C, Kq, win = LEVELS[level]
+        N = H * W
+        order = torch.randperm(win[0] * win[1], generator=g).to(torch.int32).to(dev)
         cvb = cost_volume_bytes(N, C, Kq, 4, 2 if half else 4)
         cast = (lambda x: x.half()) if half else (lambda x: x)
         elo = pkg()
@@ -164,7 +170,7 @@ def roofline_leg(args, dev, net, reps=50):
         ft1 = cast(torch.randn((batch, H, W, C), generator=g).to(dev))
         ft2 = cast(torch.randn((batch, H, W, C), generator=g).to(dev))
         hw = torch.from_numpy(synth.hw_index(batch, H, W)).to(dev)
-        idx_q, _, _, m_q = elo.fused_conv_select_k(x1, x2, hw, order, H, W, N, 11, 41, Kq, 0, 1000.0, 1, 1,
+        idx_q, _, _, m_q = elo.fused_conv_select_k(x1, x2, hw, order, H, W, N, win[0], win[1], Kq, 0, 1000.0, 1, 1,
                                                   want_valid=False)
         order_p = torch.randperm(3 * 5, generator=g).to(torch.int32).to(dev)
         idx_p, _, _, m_p = elo.fused_conv_random_k(x1, x1, hw, order_p, H, W, N, 3, 5, Kp, 0, 1000.0, 1, 1,
@@ -173,7 +179,7 @@ def roofline_leg(args, dev, net, reps=50):
         cost = cast(torch.randn((batch, H, W, 64), generator=g).to(dev))
         lq, vq = (cast(torch.randn((batch, N, Kq, 64), generator=g).to(dev)) for _ in range(2))
         lp, vp = (cast(torch.randn((batch, N, Kp, 64), generator=g).to(dev)) for _ in range(2))
-        legs = {"A1": ("cv_encode1_col_kernel", lambda: ops.cv_encode1(x1.reshape(batch, N, 3), ft1.reshape(batch, N, C),
+        legs = {"A1": ("cv_encode1_col_kernel" if C == 16 else "cv_encode1_vec_kernel", lambda: ops.cv_encode1(x1.reshape(batch, N, 3), ft1.reshape(batch, N, C),
                                                                         x2, ft2, idx_q, m_q)),
                 "P1": ("softmax_pool_vec_kernel", lambda: ops.masked_softmax_pool(lq, vq, m_q)),
                 "A2": ("cv_encode2_vec_kernel", lambda: ops.cv_encode2(x1, ft1, cost, idx_p, m_p)),
@@ -184,14 +190,27 @@ def roofline_leg(args, dev, net, reps=50):
             nbytes = cvb[term] * batch
             terms[term] = {"kernel": name, "bytes": int(nbytes), "us": round(s * 1e6, 3),
                            "GBps": round(nbytes / s / 1e9, 1), "frac": round(nbytes / s / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic": PMC_TRAFFIC.get((term, batch, "f16") if half else (term, batch))}
+                           "traffic": PMC_TRAFFIC.get((term, batch, "f16") if half else (term, batch)) if level == "l0" else None}
             tot_b, tot_s = tot_b + nbytes, tot_s + s
         gbs = tot_b / tot_s / 1e9
-        return {"kernel": "cost volume at l0, ELO_FUSED=0 path: encode1 + pool + encode2 + pool (A1+P1+A2+P2)" +
+        return {"kernel": "cost volume at %s, ELO_FUSED=0 path: encode1 + pool + encode2 + pool (A1+P1+A2+P2)" % level +
                           (", fp16 feature storage" if half else ""),
                 "batch": batch, "dtype": "f16 storage, f32 arithmetic" if half else "f32", "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes_per_launch": int(tot_b), "us_per_launch": round(tot_s * 1e6, 3),
                 "terms": terms}
+
+    def all_levels_leg(batch, half=False):
+        """SURVEY 8(d)'s "cost-volume kernel bytes per pair": the four cost_volume calls of a forward (l0, l1, l2,
+        l2_origin), 16 launches, bytes x batch / the sum of the kernel times."""
+        per = {lv: per_operator_leg(batch, half, lv) for lv in LEVELS}
+        tot_b = sum(v["bytes_per_launch"] for v in per.values())
+        tot_us = sum(v["us_per_launch"] for v in per.values())
+        gbs = tot_b / tot_us / 1e3
+        return {"kernel": "all four cost_volume calls of a forward, ELO_FUSED=0 path (16 launches)", "batch": batch,
+                "dtype": "f16 storage, f32 arithmetic" if half else "f32", "bound": "hbm", "achieved": round(gbs, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b),
+                "us": round(tot_us, 3),
+                "levels": {lv: {"bytes": v["bytes_per_launch"], "us": v["us_per_launch"], "frac": v["frac"]} for lv, v in per.items()}}
 
     return {"bound": "mfma", "kernel": "cv1_kernel (fused cost volume stage 1, l0: %dx%d, K=%d, batch %d)" % (H, W, Kq, B),
             "achieved": round(tfs, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -204,7 +223,9 @@ def roofline_leg(args, dev, net, reps=50):
             "algorithmic_bytes_per_launch": int((cvb["A1"] + cvb["P1"]) * B),
             "hbm_equivalent_GBps": round((cvb["A1"] + cvb["P1"]) * B / sec / 1e9, 2),
             "per_operator": per_operator_leg(B), "per_operator_b8": per_operator_leg(8), "per_operator_b64": per_operator_leg(64),
-            "per_operator_b8_f16": per_operator_leg(8, half=True), "per_operator_b64_f16": per_operator_leg(64, half=True)}
+            "per_operator_b8_f16": per_operator_leg(8, half=True), "per_operator_b64_f16": per_operator_leg(64, half=True),
+            "per_operator_all_levels_b8": all_levels_leg(8), "per_operator_all_levels_b8_f16": all_levels_leg(8, half=True),
+            "per_operator_all_levels_b64": all_levels_leg(64)}
 
 
 # ----------------------------------------------------------------------------- CPU baseline leg
