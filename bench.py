@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic pairs kept in HBM")
     ap.add_argument("--lanes", type=int, default=8,
                     help="independent forwards in flight (hipGraphs, dealt over the 4 hardware queues: use a multiple of 4)")
+    ap.add_argument("--products", choices=("split", "half"), default="split",
+                    help="dense products of the fused kernels: split = fp32-class (three fp16 MFMA products, the headline); "
+                         "half = ONE fp16 product (fp16 arithmetic, BASELINE configs[2]; not the fp32 parity path)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=60, help="pairs in the CPU-oracle sample")
@@ -255,6 +258,26 @@ def cpu_baseline_leg(args, net, pairs):
                       "grouping oracle), single thread, %.1f s" % (pairs, args.height, args.width, sec)}
 
 
+def batch_rate(dev, B, H, W, lanes, products, steps=240):
+    """frame-pairs/s of a fresh net at batch B through `lanes` captured graphs, inputs resident in HBM."""
+    model, synth, fused = pkg("model"), pkg("synth"), pkg("fused")
+    with fused.products(products):
+        net = model.PWCLONet(dev, seed=0)
+        pairs = []
+        for i in range(4):
+            f1, f2 = synth.frame_pair(B, H, W, seed=77 + i)
+            pairs.append(torch.cat([torch.from_numpy(f1), torch.from_numpy(f2)], 0).to(dev))
+        net.capture(B, H, W, lanes=lanes)
+        for i in range(2 * lanes):
+            net.submit(i % lanes, pairs[i % 4])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            net.submit(i % lanes, pairs[i % 4])
+        torch.cuda.synchronize(dev)
+        return round(B * steps / (time.perf_counter() - t0), 1)
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     args = parse()
@@ -275,6 +298,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     model, synth = pkg("model"), pkg("synth")
+    pkg("fused").products(args.products).__enter__()          # for the whole run: packing, capture and the roofline leg
     net = model.PWCLONet(dev, seed=0)
     B, H, W = args.batch, args.height, args.width
     pool = []
@@ -332,7 +356,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (1x1 convolutions as 3 fp16-MFMA products of hi/lo-split fp32 operands, fp32 accumulate)",
+        "dtype": "f32 (1x1 convolutions as 3 fp16-MFMA products of hi/lo-split fp32 operands, fp32 accumulate)"
+                 if args.products == "split" else
+                 "f16 products (--products half: 1x1 convolutions as ONE fp16-MFMA product of fp16-rounded operands, fp32 "
+                 "accumulate; storage and everything else fp32) -- not the fp32 parity path",
         "data": "synthetic",
         "config": {"workload": "full 4-level PWC pyramid (set-conv + attentive cost volume + warp-refinement + "
                                "set-upconv), %dx%d range-image pairs, batch %d per GPU, fp32, random-init weights, "
@@ -344,6 +371,11 @@ def main():
         line["roofline"] = roofline_leg(args, dev, net)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_leg(args, net, args.cpu_pairs)
+        if (B, H, W) == (1, 64, 1800) and not args.no_graph and args.products == "split":
+            # BASELINE configs[2]'s batch (8 pairs per step), same pyramid: fp32-class products, and fp16 products
+            line["batch8"] = {"unit": "frame-pairs/s", "lanes": lanes,
+                              "f32": batch_rate(dev, 8, H, W, lanes, "split"),
+                              "f16_products": batch_rate(dev, 8, H, W, lanes, "half")}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -60,7 +60,8 @@ WarpProjectArgs = _struct("elo_warp_project_args", [
     ("xyz", _vp), ("feat", _vp), ("q", _vp), ("t", _vp), ("warped", _vp), ("out_xyz", _vp), ("out_feat", _vp),
     ("scratch", _vp), ("prepared", _i)])
 
-Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i), ("w_plain", _vp)])
+Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i), ("w_plain", _vp),
+                              ("products", _i)])
 _l = ctypes.c_long
 GroupSpec = _struct("elo_group_spec", [
     ("random_hw", _vp), ("kernel_h", _i), ("kernel_w", _i), ("distance", _f), ("stride_h", _i), ("stride_w", _i),

@@ -54,6 +54,18 @@ __device__ __forceinline__ float4 weight_load(__amdgpu_buffer_rsrc_t rsrc, unsig
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, 0));
 }
 
+// A lane's share of one 16-k x 16-n block of W: 16 bytes [4 halves hi | 4 halves lo] (ELO_PRODUCTS_SPLIT), or the 8
+// bytes of four round-to-nearest halves (ELO_PRODUCTS_HALF).  BLOCK_BYTES is the wave's contiguous load.
+template <bool HALF> struct WFrag { typedef float4 type; static constexpr int LANE_BYTES = 16, BLOCK_BYTES = 1024; };
+template <> struct WFrag<true> { typedef float2 type; static constexpr int LANE_BYTES = 8, BLOCK_BYTES = 512; };
+
+template <bool HALF>
+__device__ __forceinline__ typename WFrag<HALF>::type frag_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, int byte_off)
+{
+    if constexpr (HALF) return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_off, byte_off, 0));
+    else return weight_load(rsrc, lane_off, byte_off);
+}
+
 // ---- fp32-class products on the fp16 matrix cores ---------------------------------------------------------------
 // v_mfma_f32_16x16x4_f32 costs 32 cycles per 1024 multiply-adds and, measured (SQ_VALU_MFMA_COEXEC_CYCLES = 0), does
 // not overlap with vector work, so its busy time adds to the kernel time.  v_mfma_f32_16x16x16_f16 does 4096
@@ -73,6 +85,19 @@ __device__ __forceinline__ HiLo split_fragment(const float4 a)
     auto pk = [](float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); };
     return HiLo{__builtin_bit_cast(half4, uint2{pk(h0, h1), pk(h2, h3)}),
                 __builtin_bit_cast(half4, uint2{pk(a.x - h0, a.y - h1), pk(a.z - h2, a.w - h3)})};
+}
+
+// ELO_PRODUCTS_HALF: ONE fp16 product per 16-k block, both operands rounded to nearest fp16 (2^-11 relative each),
+// fp32 accumulation -- fp16 arithmetic on the matrix cores for BASELINE configs[2]; not the fp32-class path.
+template <int MAXT>
+__device__ __forceinline__ void mma_block(f32x4 (&acc)[MAXT], const float4 a, const float2 (&w)[MAXT])
+{
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const half2v lo = half2v{(_Float16)a.x, (_Float16)a.y}, hi = half2v{(_Float16)a.z, (_Float16)a.w};
+    const half4 A = __builtin_bit_cast(half4, uint2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)});
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(A, __builtin_bit_cast(half4, w[t]), acc[t], 0, 0, 0);
 }
 
 // one 16-k block of MAXT column blocks: acc[t] += A(16 rows x 16 k) * W_t(16 k x 16 n)
@@ -113,9 +138,10 @@ __device__ __forceinline__ void mma_block(f32x4 (&acc)[MAXT], const float4 a, co
 //     w_packed[((cb*KS + ks)*64 + lane)*4 + s] = W[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)]
 // A comes from LDS, 16 bytes per lane per 16 k's.  Layers run IN PLACE on the tile: barrier after the
 // K loop (every wave has finished reading A), write D, barrier.
-template <int TILE, int MAXT>
+template <int TILE, int MAXT, bool HALF>
 __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_off, const elo_dense &L)
 {
+    typedef typename WFrag<HALF>::type W_t;
     constexpr int RB = TILE / 16;                 // row blocks: 1 or 2
     constexpr int CSTEP = FUSED_WAVES / RB;       // column-block stride between a wave's sub-tiles
     // 16-k blocks per prefetch group (register budget: 2*GS*MAXT float4).  Half of what it was before the MFMAs moved to
@@ -137,25 +163,25 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
     }
     const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
     const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);      // buffer addressing: V# + lane offset + scalar offset
-    const unsigned lane_off = (unsigned)lane * 16u;
+    const unsigned lane_off = (unsigned)lane * WFrag<HALF>::LANE_BYTES;
 
     // W is streamed from L2 with a load-to-use distance of one whole group of K steps (two register sets).
     // Loads are UNCONDITIONAL (indices clamped into the packed array): with per-lane predicates around them the
     // compiler loses track of the outstanding loads and waits vmcnt(0) before every MFMA group, which serialises
     // "prefetch" and compute (measured: 6.5 us for a 128x128 layer whose MFMAs take 1.7 us).  Clamped duplicates are
     // never used: steps past KS are skipped by a scalar branch, sub-tiles past CB are computed but not stored.
-    auto fetch = [&](int g, float4 (&buf)[GS][MAXT]) {
+    auto fetch = [&](int g, W_t (&buf)[GS][MAXT]) {
 #pragma unroll
         for (int s = 0; s < GS; ++s) {
             const int ks = min(g * GS + s, KS - 1);
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 const int cb = min(cb0 + t * CSTEP, CB - 1);
-                buf[s][t] = weight_load(wrsrc, lane_off, (cb * KS + ks) * 1024);
+                buf[s][t] = frag_load<HALF>(wrsrc, lane_off, (cb * KS + ks) * WFrag<HALF>::BLOCK_BYTES);
             }
         }
     };
-    auto compute = [&](int g, const float4 (&buf)[GS][MAXT]) {
+    auto compute = [&](int g, const W_t (&buf)[GS][MAXT]) {
         float4 a[GS];
 #pragma unroll
         for (int s = 0; s < GS; ++s) a[s] = *reinterpret_cast<const float4 *>(arow + min(g * GS + s, KS - 1) * 16);
@@ -165,7 +191,7 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
             mma_block<MAXT>(acc, a[s], buf[s]);
         }
     };
-    float4 b0[GS][MAXT], b1[GS][MAXT];
+    W_t b0[GS][MAXT], b1[GS][MAXT];
     fetch(0, b0);
     for (int g = 0; g < NG; g += 2) {
         if (g + 1 < NG) fetch(g + 1, b1);
@@ -192,14 +218,14 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
     __syncthreads();
 }
 
-template <int TILE>
+template <int TILE, bool HALF>
 __device__ __forceinline__ void dense(float *act, int S, int in_off, int out_off, const elo_dense &L)
 {
     constexpr int CSTEP = FUSED_WAVES / (TILE / 16);
     const int per_wave = ((ceil16(L.N) >> 4) + CSTEP - 1) / CSTEP;      // sub-tiles per wave, <= 4 for N <= 128
-    if (per_wave <= 1) dense_t<TILE, 1>(act, S, in_off, out_off, L);
-    else if (per_wave <= 2) dense_t<TILE, 2>(act, S, in_off, out_off, L);
-    else dense_t<TILE, 4>(act, S, in_off, out_off, L);
+    if (per_wave <= 1) dense_t<TILE, 1, HALF>(act, S, in_off, out_off, L);
+    else if (per_wave <= 2) dense_t<TILE, 2, HALF>(act, S, in_off, out_off, L);
+    else dense_t<TILE, 4, HALF>(act, S, in_off, out_off, L);
 }
 
 // ---- the same layer with compile-time widths and a cross-layer prefetch (cost-volume kernels) -------------
@@ -213,14 +239,14 @@ struct Sub {                                          // sub-tiles per wave, K s
     static constexpr int GS = MAXT >= 4 ? 1 : 2;
 };
 
-template <int TILE, int N>
+template <int TILE, int N, bool HALF>
 struct Pre {
-    float4 w[Sub<TILE, N>::GS][Sub<TILE, N>::MAXT];
+    typename WFrag<HALF>::type w[Sub<TILE, N>::GS][Sub<TILE, N>::MAXT];
     float b[Sub<TILE, N>::MAXT];
 };
 
-template <int TILE, int N>
-__device__ __forceinline__ void prefetch(const elo_dense &L, Pre<TILE, N> &pre)
+template <int TILE, int N, bool HALF>
+__device__ __forceinline__ void prefetch(const elo_dense &L, Pre<TILE, N, HALF> &pre)
 {
     constexpr int RB = TILE / 16, CSTEP = Sub<TILE, N>::CSTEP, MAXT = Sub<TILE, N>::MAXT, GS = Sub<TILE, N>::GS;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -228,22 +254,25 @@ __device__ __forceinline__ void prefetch(const elo_dense &L, Pre<TILE, N> &pre)
     const int KS = ceil16(L.K) >> 4;
     constexpr int CB = (N + 15) / 16;
     const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);      // buffer addressing: V# + lane offset + scalar offset
-    const unsigned lane_off = (unsigned)lane * 16u;
+    const unsigned lane_off = (unsigned)lane * WFrag<HALF>::LANE_BYTES;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         const int cb = cb0 + t * CSTEP;
         const int cbc = min(cb, CB - 1);
         pre.b[t] = L.bias[cbc * 16 + i16];
 #pragma unroll
-        for (int s = 0; s < GS; ++s) pre.w[s][t] = weight_load(wrsrc, lane_off, (cbc * KS + min(s, KS - 1)) * 1024);
+        for (int s = 0; s < GS; ++s)
+            pre.w[s][t] = frag_load<HALF>(wrsrc, lane_off, (cbc * KS + min(s, KS - 1)) * WFrag<HALF>::BLOCK_BYTES);
     }
 }
 
 // layer with width N; NEXT = width of the following layer (0 = none)
-template <int TILE, int N, int NEXT>
+template <int TILE, int N, int NEXT, bool HALF>
 __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_off, const elo_dense &L,
-                                         const Pre<TILE, N> &pre, const elo_dense *next, Pre<TILE, NEXT ? NEXT : 16> *next_pre)
+                                         const Pre<TILE, N, HALF> &pre, const elo_dense *next,
+                                         Pre<TILE, NEXT ? NEXT : 16, HALF> *next_pre)
 {
+    typedef typename WFrag<HALF>::type W_t;
     constexpr int RB = TILE / 16, CSTEP = Sub<TILE, N>::CSTEP, MAXT = Sub<TILE, N>::MAXT, GS = Sub<TILE, N>::GS;
     constexpr int CB = (N + 15) / 16;
     // the wave index as a SCALAR: row block, column blocks and with them every W / bias base address live in SGPRs,
@@ -258,23 +287,23 @@ __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_
     for (int t = 0; t < MAXT; ++t) acc[t] = f32x4{pre.b[t], pre.b[t], pre.b[t], pre.b[t]};
     const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
     const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);      // buffer addressing: V# + lane offset + scalar offset
-    const unsigned lane_off = (unsigned)lane * 16u;
+    const unsigned lane_off = (unsigned)lane * WFrag<HALF>::LANE_BYTES;
     // Loads are UNCONDITIONAL (indices clamped into the packed array): with per-lane predicates around them the
     // compiler loses track of the outstanding loads and waits vmcnt(0) before every MFMA group, which serialises
     // "prefetch" and compute (measured: 6.5 us for a 128x128 layer whose MFMAs take 1.7 us).  Clamped duplicates are
     // never used: steps past KS are skipped by a scalar branch, sub-tiles past CB are computed but not stored.
-    auto fetch = [&](int g, float4 (&buf)[GS][MAXT]) {
+    auto fetch = [&](int g, W_t (&buf)[GS][MAXT]) {
 #pragma unroll
         for (int s = 0; s < GS; ++s) {
             const int ks = min(g * GS + s, KS - 1);
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 const int cb = min(cb0 + t * CSTEP, CB - 1);
-                buf[s][t] = weight_load(wrsrc, lane_off, (cb * KS + ks) * 1024);
+                buf[s][t] = frag_load<HALF>(wrsrc, lane_off, (cb * KS + ks) * WFrag<HALF>::BLOCK_BYTES);
             }
         }
     };
-    auto compute = [&](int g, const float4 (&buf)[GS][MAXT]) {
+    auto compute = [&](int g, const W_t (&buf)[GS][MAXT]) {
         float4 a[GS];
 #pragma unroll
         for (int s = 0; s < GS; ++s) a[s] = *reinterpret_cast<const float4 *>(arow + min(g * GS + s, KS - 1) * 16);
@@ -284,7 +313,7 @@ __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_
             mma_block<MAXT>(acc, a[s], buf[s]);
         }
     };
-    float4 b0[GS][MAXT], b1[GS][MAXT];
+    W_t b0[GS][MAXT], b1[GS][MAXT];
 #pragma unroll
     for (int s = 0; s < GS; ++s)
 #pragma unroll
@@ -297,7 +326,7 @@ __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_
             compute(g + 1, b1);
         }
     }
-    if (NEXT) prefetch<TILE, NEXT ? NEXT : 16>(*next, *next_pre);              // rides behind the two barriers
+    if (NEXT) prefetch<TILE, NEXT ? NEXT : 16, HALF>(*next, *next_pre);              // rides behind the two barriers
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
@@ -582,7 +611,7 @@ struct JobPair { Args job[2]; };                  // one kernarg block: job[bloc
 // 5 waves per SIMD (<= 102 VGPRs).  History: 140 VGPRs uncapped (3 workgroups per CU); a cap of 4 cost 12 bytes of
 // scratch and gave +4 % at batch 8; with the scalar wave index and buffer-addressed W fragments the kernels need 92-96
 // VGPRs without any spill.  A cap of 6 (80 VGPRs) spills 36-144 bytes in the cost-volume kernels: not taken.
-template <int TILE>
+template <int TILE, bool HALF>
 __global__ __launch_bounds__(FUSED_BLOCK, 5) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
 {
     const elo_setconv_args &a = jobs.job[blockIdx.y];
@@ -644,7 +673,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void setconv_kernel(const JobPair<e
         }
     }
     __syncthreads();
-    for (int l = 0; l < a.n_layers; ++l) dense<TILE>(act, S, 0, 0, a.layers[l]);    // in place, :217-222
+    for (int l = 0; l < a.n_layers; ++l) dense<TILE, HALF>(act, S, 0, 0, a.layers[l]);    // in place, :217-222
     pool_masked_max(act, S, 0, a.layers[a.n_layers - 1].N, meta, P, K, first_point, total_points, a.out);   // :224-230
 }
 
@@ -797,7 +826,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
 }
 
 // ================================================================ row-wise MLP over concatenated sources
-template <int TILE>
+template <int TILE, bool HALF>
 __global__ __launch_bounds__(FUSED_BLOCK, 5) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
 {
     const elo_mlp_args &a = jobs.job[blockIdx.y];
@@ -836,7 +865,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void mlp_kernel(const JobPair<elo_m
     // with a second stage the first stage's LAST layer writes its output at column w_before -- where the second stage's
     // concat [before | out | after] wants it (the layer's barrier separates its reads at [0, K) from that write)
     const int shift = a.n_layers2 > 0 ? a.w_before : 0;
-    for (int l = 0; l < a.n_layers; ++l) dense<TILE>(act, S, 0, l == a.n_layers - 1 ? shift : 0, a.layers[l]);
+    for (int l = 0; l < a.n_layers; ++l) dense<TILE, HALF>(act, S, 0, l == a.n_layers - 1 ? shift : 0, a.layers[l]);
     const int N = a.layers[a.n_layers - 1].N;
     for (int e = tid; e < TILE * N; e += FUSED_BLOCK) {
         const int row = e / N, c = e - row * N;
@@ -865,7 +894,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void mlp_kernel(const JobPair<elo_m
     }
     zero_cols<TILE>(act, S, CT2, ceil16(CT2));
     __syncthreads();
-    for (int l = 0; l < a.n_layers2; ++l) dense<TILE>(act, S, 0, 0, a.layers2[l]);
+    for (int l = 0; l < a.n_layers2; ++l) dense<TILE, HALF>(act, S, 0, 0, a.layers2[l]);
     const int N2 = a.layers2[a.n_layers2 - 1].N;
     for (int e = tid; e < TILE * N2; e += FUSED_BLOCK) {
         const int row = e / N2, c = e - row * N2;
@@ -879,7 +908,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void mlp_kernel(const JobPair<elo_m
 // geometry, live until CV_xyz); sum_CV_0 then writes its 128 outputs to [64,192) -- over enc, its own input: the
 // layer's barrier separates the reads from the write -- so x at [0,64) survives for the pooling and the tile is
 // max(192, 128 + CTp) columns wide instead of 256 (27.5 KB instead of 35.7 KB at 32 rows: a fifth workgroup per CU).
-template <int TILE>
+template <int TILE, bool HALF>
 __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_kernel(const elo_cv1_args a, const int S)
 {
     extern __shared__ float lds[];
@@ -933,20 +962,20 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_kernel(const elo_cv1_args 
             act[row * S + F + ch] = v;
         }
     }
-    Pre<TILE, 128> p128;
-    Pre<TILE, 64> p64;
-    prefetch<TILE, 128>(a.cv0, p128);           // in flight while the barrier drains the gather
+    Pre<TILE, 128, HALF> p128;
+    Pre<TILE, 64, HALF> p64;
+    prefetch<TILE, 128, HALF>(a.cv0, p128);           // in flight while the barrier drains the gather
     __syncthreads();
 #if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 2
     if (tid == 0) a.out[first_point * 64] = act[F] + p128.b[0];
     return;
 #endif
-    dense_pf<TILE, 128, 64>(act, S, F, 0, a.cv0, p128, &a.cv1, &p64);          // feat_cat -> 128          :72-76
-    dense_pf<TILE, 64, 64>(act, S, 0, 0, a.cv1, p64, &a.cv2, &p64);            // -> 64 (in place)
-    dense_pf<TILE, 64, 64>(act, S, 0, 0, a.cv2, p64, &a.cv_xyz, &p64);         // -> 64 = x   (values of the pooling)
-    dense_pf<TILE, 64, 128>(act, S, F, 64, a.cv_xyz, p64, &a.sum_cv0, &p128);  // xyz_cat -> enc at [64,128)   :79-82
-    dense_pf<TILE, 128, 64>(act, S, 0, 64, a.sum_cv0, p128, &a.sum_cv1, &p64); // [x | enc] -> 128 at [64,192): over enc, x stays  :84-90
-    dense_pf<TILE, 64, 0>(act, S, 64, 64, a.sum_cv1, p64, nullptr, nullptr);   // -> 64 logits at [64,128) (in place)
+    dense_pf<TILE, 128, 64, HALF>(act, S, F, 0, a.cv0, p128, &a.cv1, &p64);          // feat_cat -> 128          :72-76
+    dense_pf<TILE, 64, 64, HALF>(act, S, 0, 0, a.cv1, p64, &a.cv2, &p64);            // -> 64 (in place)
+    dense_pf<TILE, 64, 64, HALF>(act, S, 0, 0, a.cv2, p64, &a.cv_xyz, &p64);         // -> 64 = x   (values of the pooling)
+    dense_pf<TILE, 64, 128, HALF>(act, S, F, 64, a.cv_xyz, p64, &a.sum_cv0, &p128);  // xyz_cat -> enc at [64,128)   :79-82
+    dense_pf<TILE, 128, 64, HALF>(act, S, 0, 64, a.sum_cv0, p128, &a.sum_cv1, &p64); // [x | enc] -> 128 at [64,192): over enc, x stays  :84-90
+    dense_pf<TILE, 64, 0, HALF>(act, S, 64, 64, a.sum_cv1, p64, nullptr, nullptr);   // -> 64 logits at [64,128) (in place)
 #if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 3
     if (tid == 0) a.out[first_point * 64] = act[F];
     return;
@@ -957,7 +986,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_kernel(const elo_cv1_args 
 // ================================================================ cost volume, stage 2
 // LDS columns: [0,64) grouped cost, [64,128) xyz-encoding, [128,128+C) feat1, [192,208) xyz_cat;
 // sum_cost0 reads [0,128+C) and writes [64,192); sum_cost1 maps [64,192) -> [64,128).
-template <int TILE>
+template <int TILE, bool HALF>
 __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv2_kernel(const elo_cv2_args a, const int S)
 {
     extern __shared__ float lds[];
@@ -1010,13 +1039,13 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv2_kernel(const elo_cv2_args 
                 ? geo_channel(a.xyz1 + pt * 3, a.xyz1 + (long)cell * 3, meta.mask[row], ch) : 0.0f;
         }
     }
-    Pre<TILE, 128> p128;
-    Pre<TILE, 64> p64;
-    prefetch<TILE, 64>(a.xyz_enc, p64);
+    Pre<TILE, 128, HALF> p128;
+    Pre<TILE, 64, HALF> p64;
+    prefetch<TILE, 64, HALF>(a.xyz_enc, p64);
     __syncthreads();
-    dense_pf<TILE, 64, 128>(act, S, XYZ, 64, a.xyz_enc, p64, &a.sum_cost0, &p128);   // -> enc at [64,128)       :123-126
-    dense_pf<TILE, 128, 64>(act, S, 0, 64, a.sum_cost0, p128, &a.sum_cost1, &p64);   // [grouped | enc | feat1] -> [64,192)   :129-135
-    dense_pf<TILE, 64, 0>(act, S, 64, 64, a.sum_cost1, p64, nullptr, nullptr);       // -> 64 logits at [64,128)
+    dense_pf<TILE, 64, 128, HALF>(act, S, XYZ, 64, a.xyz_enc, p64, &a.sum_cost0, &p128);   // -> enc at [64,128)       :123-126
+    dense_pf<TILE, 128, 64, HALF>(act, S, 0, 64, a.sum_cost0, p128, &a.sum_cost1, &p64);   // [grouped | enc | feat1] -> [64,192)   :129-135
+    dense_pf<TILE, 64, 0, HALF>(act, S, 64, 64, a.sum_cost1, p64, nullptr, nullptr);       // -> 64 logits at [64,128)
     pool_masked_softmax(act, S, 64, 0, meta, P, K, first_point, total_points, a.out);   // :137-146
 }
 
@@ -1035,6 +1064,33 @@ int check_dense(const elo_dense &L, int K, int N, const char *who, const char *n
     if (L.K != K || (N > 0 && L.N != N))
         return fail(ELO_ERR_ARG, "%s: layer %s is %dx%d, expected %dx%d", who, name, L.K, L.N, K, N);
     if (L.N <= 0 || L.N > 128) return fail(ELO_ERR_LIMIT, "%s: layer %s width %d outside 1..128", who, name, L.N);
+    if (L.products != ELO_PRODUCTS_SPLIT && L.products != ELO_PRODUCTS_HALF)
+        return fail(ELO_ERR_ARG, "%s: layer %s: products must be ELO_PRODUCTS_SPLIT or ELO_PRODUCTS_HALF", who, name);
+#ifdef ELO_DENSE_F32
+    if (L.products != ELO_PRODUCTS_SPLIT) return fail(ELO_ERR_ARG, "%s: this library was built with -DELO_DENSE_F32 (fp32 MFMA only)", who);
+#endif
+    return ELO_OK;
+}
+
+// the products mode is a property of the LAUNCH (the kernels are instantiated per mode): every layer must agree
+template <typename... Rest>
+int products_mode(const char *who, bool *half, const elo_dense &first, const Rest &...rest)
+{
+    const int mode = first.products;
+    for (const elo_dense *L : {&rest...})
+        if (L->products != mode) return fail(ELO_ERR_ARG, "%s: the layers of one launch must share one products mode", who);
+    *half = mode == ELO_PRODUCTS_HALF;
+    return ELO_OK;
+}
+
+int products_mode(const char *who, bool *half, const elo_dense *layers, int n, const elo_dense *layers2 = nullptr, int n2 = 0)
+{
+    const int mode = layers[0].products;
+    for (int l = 0; l < n; ++l)
+        if (layers[l].products != mode) return fail(ELO_ERR_ARG, "%s: the layers of one launch must share one products mode", who);
+    for (int l = 0; l < n2; ++l)
+        if (layers2[l].products != mode) return fail(ELO_ERR_ARG, "%s: the layers of one launch must share one products mode", who);
+    *half = mode == ELO_PRODUCTS_HALF;
     return ELO_OK;
 }
 
@@ -1177,8 +1233,18 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
     const int S = row_stride(chain_cols(a->layers, a->n_layers, 3 + a->C));
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
-    return launch_tile2(who, small_tile(u32 * (b ? 2 : 1), a->K), u16, u32, S, (hipStream_t)stream, *a, b, setconv_kernel<32>,
-                        setconv_kernel<16>, &a->group, a->H2, a->W2);
+    bool half = false, half_b = false;
+    if (int rc = products_mode(who, &half, a->layers, a->n_layers)) return rc;
+    if (b) {
+        if (int rc = products_mode(who, &half_b, b->layers, b->n_layers)) return rc;
+        if (half != half_b) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must share one products mode", who);
+    }
+    const bool t16 = small_tile(u32 * (b ? 2 : 1), a->K);
+    if (half)
+        return launch_tile2(who, t16, u16, u32, S, (hipStream_t)stream, *a, b, setconv_kernel<32, true>, setconv_kernel<16, true>,
+                            &a->group, a->H2, a->W2);
+    return launch_tile2(who, t16, u16, u32, S, (hipStream_t)stream, *a, b, setconv_kernel<32, false>, setconv_kernel<16, false>,
+                        &a->group, a->H2, a->W2);
 }
 
 extern "C" int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream)
@@ -1243,8 +1309,16 @@ extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_
     if (a->rows == 0) return ELO_OK;
     const int S = row_stride(mlp_cols(a, in_width));
     const long u32 = (a->rows + 31) / 32, u16 = (a->rows + 15) / 16;
-    return launch_tile2(who, small_tile(u32 * (b ? 2 : 1), 1), u16, u32, S, (hipStream_t)stream, *a, b, mlp_kernel<32>,
-                        mlp_kernel<16>);
+    bool half = false, half_b = false;
+    if (int rc = products_mode(who, &half, a->layers, a->n_layers, a->layers2, a->n_layers2)) return rc;
+    if (b) {
+        if (int rc = products_mode(who, &half_b, b->layers, b->n_layers, b->layers2, b->n_layers2)) return rc;
+        if (half != half_b) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must share one products mode", who);
+    }
+    const bool t16 = small_tile(u32 * (b ? 2 : 1), 1);
+    if (half)
+        return launch_tile2(who, t16, u16, u32, S, (hipStream_t)stream, *a, b, mlp_kernel<32, true>, mlp_kernel<16, true>);
+    return launch_tile2(who, t16, u16, u32, S, (hipStream_t)stream, *a, b, mlp_kernel<32, false>, mlp_kernel<16, false>);
 }
 
 extern "C" int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream) { return elo_mlp_fused2(a, nullptr, stream); }
@@ -1271,8 +1345,13 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
     const int S = row_stride(128 + CTp > 192 ? 128 + CTp : 192);
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
-    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv1_kernel<32>, cv1_kernel<16>,
-                       &a->group, a->H2, a->W2, true, a->K);
+    bool half = false;
+    if (int rc = products_mode(who, &half, a->cv0, a->cv1, a->cv2, a->cv_xyz, a->sum_cv0, a->sum_cv1)) return rc;
+    if (half)
+        return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv1_kernel<32, true>,
+                           cv1_kernel<16, true>, &a->group, a->H2, a->W2, true, a->K);
+    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv1_kernel<32, false>,
+                       cv1_kernel<16, false>, &a->group, a->H2, a->W2, true, a->K);
 }
 
 extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
@@ -1293,6 +1372,11 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
     const int S = row_stride(208);
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
-    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv2_kernel<32>, cv2_kernel<16>,
-                       &a->group, a->H, a->W, false);
+    bool half = false;
+    if (int rc = products_mode(who, &half, a->xyz_enc, a->sum_cost0, a->sum_cost1)) return rc;
+    if (half)
+        return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv2_kernel<32, true>,
+                           cv2_kernel<16, true>, &a->group, a->H, a->W, false);
+    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv2_kernel<32, false>,
+                       cv2_kernel<16, false>, &a->group, a->H, a->W, false);
 }

@@ -15,12 +15,43 @@ def fp32_mfma():
     return bool(L.lib().elo_dense_f32())
 
 
+PRODUCTS_SPLIT, PRODUCTS_HALF = 0, 1               # include/elo.h ELO_PRODUCTS_*
+_products = PRODUCTS_SPLIT
+
+
+def products_mode():
+    return _products
+
+
+class products:
+    """`with fused.products("half"):` -- run the dense layers of the fused kernels as ONE fp16 product per 16-k block
+    (operands rounded to nearest fp16, fp32 accumulation) instead of the fp32-class three-product split: fp16
+    arithmetic for BASELINE configs[2].  The mode is read when a layer is packed and when a kernel is launched (a
+    captured graph keeps the mode it was captured under)."""
+
+    def __init__(self, mode):
+        self.mode = {"split": PRODUCTS_SPLIT, "half": PRODUCTS_HALF, PRODUCTS_SPLIT: PRODUCTS_SPLIT,
+                     PRODUCTS_HALF: PRODUCTS_HALF}[mode]
+        if self.mode == PRODUCTS_HALF and fp32_mfma():
+            raise RuntimeError("libelo_hip.so was built with -DELO_DENSE_F32: no fp16 products")
+
+    def __enter__(self):
+        global _products
+        self.prev, _products = _products, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _products
+        _products = self.prev
+
+
 class PackedDense:
     """One inference layer y = act(x @ W + b) with BN folded, packed in MFMA B-fragment order.  Each weight is split
     into fp16 hi + lo (w = hi + lo to 2^-22 relative) for the three-product fp16 MFMA scheme of elo_fused.hip; a lane's
-    16 bytes of a 16-k x 16-n block are [hi k0..k3 | lo k0..k3]."""
+    16 bytes of a 16-k x 16-n block are [hi k0..k3 | lo k0..k3].  With `half` the lane holds the four weights rounded
+    to fp16 (8 bytes) for the single-product mode."""
 
-    def __init__(self, W, b, relu=True, row_order=None):
+    def __init__(self, W, b, relu=True, row_order=None, half=False):
         if row_order is not None:                         # the kernel's LDS column order differs from the concat order
             W = W[row_order]
         K, N = W.shape
@@ -29,7 +60,10 @@ class PackedDense:
         Wp[:K, :N] = W
         # element (cb, ks, lane, s) = Wp[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)], s = 0..3
         frag = Wp.reshape(Kp // 16, 4, 4, Np // 16, 16).permute(3, 0, 1, 4, 2).contiguous()       # (cb, ks, kq, n, s) fp32
-        if fp32_mfma():
+        self.products = PRODUCTS_HALF if half else PRODUCTS_SPLIT
+        if half:
+            self.w = frag.to(torch.float16).contiguous()                                           # (cb, ks, kq, n, 4) fp16
+        elif fp32_mfma():
             self.w = frag
         else:
             hi = frag.to(torch.float16)
@@ -42,19 +76,20 @@ class PackedDense:
 
     def struct(self):
         return L.Dense(self.w.data_ptr(), self.b.data_ptr(), self.K, self.N, 1 if self.relu else 0,
-                       self.plain.data_ptr() if self.plain is not None else None)
+                       self.plain.data_ptr() if self.plain is not None else None, self.products)
 
 
 def packed_layer(scope, cin, cout, bn=True, relu=True, row_order=None, tf_kernel_dims=(1, 1)):
     """get-or-create the layer's variables under the active scope, fold, pack, cache."""
     store = tf_util.get_store()
     name, W, b, bn_vars = tf_util.dense_variables(scope, cin, cout, tf_kernel_dims, bn)
-    key = ("packed", name, None if row_order is None else tuple(row_order), relu)
+    half = _products == PRODUCTS_HALF
+    key = ("packed", name, None if row_order is None else tuple(row_order), relu, half)
     hit = store._folded.get(key)
     if hit is None:
         Wf, bf = store.folded(name, W, b, bn_vars)
         order = None if row_order is None else torch.as_tensor(row_order, device=Wf.device)
-        hit = PackedDense(Wf, bf, relu, order)
+        hit = PackedDense(Wf, bf, relu, order, half)
         store._folded[key] = hit
     return hit
 

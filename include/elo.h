@@ -276,13 +276,19 @@ int elo_pose_head_warp(const elo_pose_head_args *a, const elo_warp_project_args 
  * v_mfma_f32_16x16x4_f32.)  `bias` has Np fp32 entries (zero padded).  Packing is done once per parameter update by
  * the host (efficientlo-net_amd/fused.py).
  * ------------------------------------------------------------------------- */
+enum { ELO_PRODUCTS_SPLIT = 0,      /* fp32-class: hi/lo split operands, three fp16 MFMA products (default)     */
+       ELO_PRODUCTS_HALF = 1 };     /* fp16 arithmetic: operands rounded to nearest fp16, ONE product, fp32 accumulate;
+                                       `w_packed` then holds 8 bytes per (cb, ks, lane): the four weights as fp16.
+                                       All layers of one launch must use the same mode.  (BASELINE configs[2].)   */
+
 typedef struct elo_dense {
     const float *w_packed;
     const float *bias;
     int K, N;
     int relu;
     const float *w_plain;         /* optional: the same folded W as plain row-major (K,N); lets narrow chains
-                                     (all widths <= 32) run on the wave-per-point VALU kernel */
+                                     (all widths <= 32) run on the wave-per-point VALU kernel (fp32 in either mode) */
+    int products;                 /* ELO_PRODUCTS_SPLIT / ELO_PRODUCTS_HALF */
 } elo_dense;
 
 #define ELO_MAX_CHAIN 3

@@ -95,3 +95,25 @@ def test_lanes_take_a_stacked_pair_and_log_the_pose_row():
         for e, o in zip(eager, out):
             assert torch.equal(e, o)
         assert torch.equal(net.lane_pose(lane), row)
+
+
+def test_half_products_forward(kernel_path):
+    """`with fused.products("half")`: the fused kernels' 1x1 convolutions as single fp16 products.  Not the parity path
+    (north_star's 1e-4 is an fp32 tolerance): the coarsest pose, which no grouping decision downstream of a rounded
+    value has touched yet, stays within 2e-3 of the fp32-class result; finer levels re-group around the warped cloud
+    and may differ by more.  The split path is untouched by a half-mode run in between."""
+    if kernel_path != "fused":
+        pytest.skip("the per-operator path has no fused dense layers")
+    synth, fused = load_pkg("synth"), load_pkg("fused")
+    f1, f2 = synth.frame_pair(1, 64, 1800, seed=41)
+    a, b = torch.from_numpy(f1).to(DEV), torch.from_numpy(f2).to(DEV)
+    net = _net()
+    ref = [x.clone() for x in net.forward(a, b)[:8]]
+    with fused.products("half"):
+        out = [x.clone() for x in net.forward(a, b)[:8]]
+    again = net.forward(a, b)[:8]
+    assert all(torch.equal(x, y) for x, y in zip(ref, again))
+    assert all(torch.isfinite(x).all() for x in out)
+    assert not torch.equal(ref[6], out[6])                                   # the mode was engaged
+    assert (ref[6] - out[6]).abs().max() < 2e-3 and (ref[7] - out[7]).abs().max() < 2e-3      # l3 (q, t)
+    assert (ref[0] - out[0]).abs().max() < 0.2                               # l0 q: same motion, fp16-class + regrouping

@@ -344,3 +344,26 @@ def test_dense_layers_keep_fp32_class_accuracy_across_magnitudes():
     # exact zeros and a zero row stay exact
     z = np.zeros((16, K), np.float32)
     assert np.array_equal(fused.mlp([t(z)], [layer]).cpu().numpy(), np.tile(b, (16, 1)))
+
+
+def test_half_products_are_one_fp16_product_with_fp32_accumulation():
+    """ELO_PRODUCTS_HALF (BASELINE configs[2]'s fp16 arithmetic): a layer computes fp16(x) @ fp16(W) + b with fp32
+    accumulation -- checked against exactly that in float64 (tolerance: fp32 summation), and against the unrounded
+    product at fp16's 1e-3.  Mixing modes inside one launch is an argument error."""
+    fused = load_pkg("fused")
+    rng = np.random.default_rng(6)
+    rows, K, N = 333, 144, 128
+    x = (rng.normal(0, 1, (rows, K)) * 10.0 ** rng.uniform(-2, 3, (rows, K))).astype(np.float32)
+    W = rng.normal(0, 0.2, (K, N)).astype(np.float32)
+    b = rng.normal(0, 1, (N,)).astype(np.float32)
+    half = fused.PackedDense(t(W), t(b), relu=False, half=True)
+    got = fused.mlp([t(x)], [half]).cpu().numpy().astype(np.float64)
+    x16, W16 = x.astype(np.float16).astype(np.float64), W.astype(np.float16).astype(np.float64)
+    scale = np.abs(x16) @ np.abs(W16) + np.abs(b)
+    assert (np.abs(got - (x16 @ W16 + b)) / scale).max() < 2e-6              # the spec: rounded operands, fp32 sums
+    exact = x.astype(np.float64) @ W.astype(np.float64) + b
+    err = np.abs(got - exact) / scale
+    assert 1e-5 < err.max() < 2e-3                                          # fp16-class, and really not the split path
+    full = fused.PackedDense(t(rng.normal(0, 0.2, (N, 64)).astype(np.float32)), t(np.zeros(64, np.float32)))
+    with pytest.raises(RuntimeError, match="products mode"):
+        fused.mlp([t(x)], [half, full])
