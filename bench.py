@@ -278,6 +278,32 @@ def batch_rate(dev, B, H, W, lanes, products, steps=240):
         return round(B * steps / (time.perf_counter() - t0), 1)
 
 
+def raw_cloud_rate(dev, B, H, W, lanes, points=150000, steps=400):
+    """frame-pairs/s when a step starts from RAW clouds: 2 x `points` KITTI-shaped points per pair
+    (5 % zero padding, ranges to 60 m so the 35 m crop bites) -> elo_input_stage -> the pyramid, all inside the lane's
+    graph; clouds resident in HBM."""
+    model = pkg("model")
+    net = model.PWCLONet(dev, seed=0)
+    rng = np.random.default_rng(3)
+    clouds = []
+    for _ in range(4):
+        az = rng.uniform(-np.pi, np.pi, (B, 2 * points))
+        el = np.deg2rad(rng.uniform(-24.8, 2.0, (B, 2 * points)))
+        r = rng.uniform(2.0, 60.0, (B, 2 * points))
+        c = np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], -1).astype(np.float32)
+        c[rng.random((B, 2 * points)) < 0.05] = 0
+        clouds.append(torch.from_numpy(c).to(dev))
+    net.capture(B, H, W, lanes=lanes, num_points=points)
+    for i in range(2 * lanes):
+        net.submit_points(i % lanes, clouds[i % 4])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        net.submit_points(i % lanes, clouds[i % 4])
+    torch.cuda.synchronize(dev)
+    return round(B * steps / (time.perf_counter() - t0), 1)
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     args = parse()
@@ -373,6 +399,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline_leg(args, net, args.cpu_pairs)
         if (B, H, W) == (1, 64, 1800) and not args.no_graph and args.products == "split":
             # BASELINE configs[2]'s batch (8 pairs per step), same pyramid: fp32-class products, and fp16 products
+            line["from_raw_clouds"] = {"unit": "frame-pairs/s", "lanes": lanes, "points_per_frame": 150000,
+                                       "value": raw_cloud_rate(dev, B, H, W, lanes)}
             line["batch8"] = {"unit": "frame-pairs/s", "lanes": lanes,
                               "f32": batch_rate(dev, 8, H, W, lanes, "split"),
                               "f16_products": batch_rate(dev, 8, H, W, lanes, "half")}

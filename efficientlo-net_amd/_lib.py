@@ -60,6 +60,11 @@ WarpProjectArgs = _struct("elo_warp_project_args", [
     ("xyz", _vp), ("feat", _vp), ("q", _vp), ("t", _vp), ("warped", _vp), ("out_xyz", _vp), ("out_feat", _vp),
     ("scratch", _vp), ("prepared", _i)])
 
+InputStageArgs = _struct("elo_input_stage_args", [
+    ("batch", _i), ("npoints", _i), ("point_stride", _i), ("H", _i), ("W", _i), ("az_res", _f), ("vert_res", _f),
+    ("vert_off", _f), ("crop_xy", _f), ("cloud", _vp), ("T_trans", _vp), ("aug_frame", _vp), ("points", _vp),
+    ("out_xyz", _vp), ("scratch", _vp)])
+
 Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i), ("w_plain", _vp),
                               ("products", _i)])
 _l = ctypes.c_long
@@ -100,6 +105,7 @@ SYMBOLS = [
     ("elo_softmax_valid", ctypes.c_int, [ctypes.POINTER(SoftmaxValidArgs), _vp]),
     ("elo_pose_head", ctypes.c_int, [ctypes.POINTER(PoseHeadArgs), _vp]),
     ("elo_warp_project", ctypes.c_int, [ctypes.POINTER(WarpProjectArgs), _vp]),
+    ("elo_input_stage", ctypes.c_int, [ctypes.POINTER(InputStageArgs), _vp]),
     ("elo_pose_head_warp", ctypes.c_int, [ctypes.POINTER(PoseHeadArgs), ctypes.POINTER(WarpProjectArgs), _vp]),
     ("elo_setconv_fused", ctypes.c_int, [ctypes.POINTER(SetconvArgs), _vp]),
     ("elo_mlp_fused", ctypes.c_int, [ctypes.POINTER(MlpArgs), _vp]),

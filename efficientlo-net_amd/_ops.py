@@ -3,6 +3,8 @@ csrc/elo_features.hip).  Forward only at this layer; shapes are validated in C
 as well.  No CPU fallback: CPU tensors raise."""
 import math
 
+import numpy as np
+
 import torch
 
 from . import _lib as L
@@ -134,7 +136,7 @@ class ProjectionBuffers:
         self.shape = (B, N, H, W, C)
         self.out_xyz = torch.empty((B, H, W, 3), dtype=torch.float32, device=device)
         self.out_feat = torch.empty((B, H, W, C), dtype=torch.float32, device=device) if C else None
-        self.scratch = torch.empty((B * H * W + 2 * B * N,), dtype=torch.int32, device=device)
+        self.scratch = torch.empty((B * H * W + 4 * B + 2 * B * N,), dtype=torch.int32, device=device)   # include/elo.h
         self.cleared = False
         self.result = None          # (warped, out_xyz, out_feat) once a pose head has run the projection itself
 
@@ -196,6 +198,30 @@ def projection_constants(H_input, W_input):
     down, up = -24.8 * d2r, 2.0 * d2r
     vres = (up - down) / (H_input - 1)
     return az, vres, -down / vres
+
+
+def input_stage(cloud, T_trans, aug_frame, H, W, crop_xy=35.0):
+    """elo_input_stage: cloud (B, 2N, S>=3) fp32, T_trans (B,4,4) or None, aug_frame (B) of 1/2 (array-like) ->
+    (points (2B,N,3), xyz_proj (2B,H,W,3))."""
+    L.require_gpu(cloud, T_trans)
+    (cloud,) = _f32(cloud)
+    B, N2, S = cloud.shape
+    if N2 % 2 or S < 3:
+        raise ValueError("point_cloud must be (B, 2*N, >=3)")
+    N, dev = N2 // 2, cloud.device
+    if T_trans is not None:
+        (T_trans,) = _f32(T_trans.reshape(B, 4, 4))
+        aug = torch.as_tensor(np.asarray(aug_frame).reshape(B), dtype=torch.int32).to(dev)
+    points = torch.empty((2 * B, N, 3), dtype=torch.float32, device=dev)
+    out_xyz = torch.empty((2 * B, H, W, 3), dtype=torch.float32, device=dev)
+    scratch = torch.empty((2 * B * H * W + 4 * 2 * B + 2 * 2 * B * N,), dtype=torch.int32, device=dev)
+    az, vres, voff = projection_constants(H, W)
+    a = L.InputStageArgs(B, N, S, H, W, az, vres, voff, float(crop_xy), cloud.data_ptr(),
+                         T_trans.data_ptr() if T_trans is not None else None,
+                         aug.data_ptr() if T_trans is not None else None, points.data_ptr(), out_xyz.data_ptr(),
+                         scratch.data_ptr())
+    L.call("elo_input_stage", a, out_xyz)
+    return points, out_xyz
 
 
 def warp_project(xyz, feat, q, t, H, W, buffers=None):

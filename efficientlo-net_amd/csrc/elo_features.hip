@@ -484,7 +484,8 @@ __device__ __forceinline__ SvPartials sv_partials(float *scratch, int batch, int
 
 // Side job of the partial kernel (elo_pose_head_args.clear_*): its workgroups also clear the buffers of the
 // projection that follows the pose head, which saves that call's init launch (three per forward).
-struct ProjectionClear { unsigned *minr; float *xyz, *feat; long cells; int C; };
+constexpr int ZFLAGS = 4;                          // projection scratch, per image: one flag per cell a zero point can fall in (3 used)
+struct ProjectionClear { unsigned *minr; float *xyz, *feat; long cells; int C; int images; };   // minr: cells + images words
 
 __device__ __forceinline__ void clear_projection(const ProjectionClear &c)
 {
@@ -492,6 +493,7 @@ __device__ __forceinline__ void clear_projection(const ProjectionClear &c)
     const long n_xyz = c.cells * 3, total = c.cells + n_xyz + c.cells * c.C;
     const long nthreads = (long)gridDim.x * gridDim.y * gridDim.z * blockDim.x;
     const long me = (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    for (long i = me; i < (long)c.images * ZFLAGS; i += nthreads) c.minr[c.cells + i] = 0x7f7f7f7fu;   // the zero-point flags
     for (long i = me; i < total; i += nthreads) {
         if (i < c.cells) c.minr[i] = 0x7f7f7f7fu;
         else if (i < c.cells + n_xyz) c.xyz[i - c.cells] = 0.0f;
@@ -588,10 +590,67 @@ __global__ void softmax_valid_merge_kernel(float *scratch, int batch, int C, int
     out[i] = sv_merge(sv_partials(scratch, batch, C), i / C, i % C, C, parts);
 }
 
+// Scratch of a projection over `images` range images of H*W cells and `pts` points in total (32-bit words):
+//   minr[cells] (min range bits per cell) | zflag[ZFLAGS * images] | cell_of[pts] | rbits[pts]
+struct ProjScratch { unsigned *minr, *zflag; int *cell_of; unsigned *rbits; };
+
+__host__ __device__ inline ProjScratch proj_scratch(unsigned *s, size_t cells, size_t images, size_t pts)
+{
+    return ProjScratch{s, s + cells, (int *)(s + cells + ZFLAGS * images), s + cells + ZFLAGS * images + pts};
+}
+
+// `at` = atan2f(y, x)
+__device__ __forceinline__ int cell_of_point(float at, float z, float r, int H, int W, float az_res, float vert_res,
+                                             float vert_off)
+{
+    const float PI_F = 3.14159265358979323846f;
+    // float -> int of a NaN is 0 (the GPU convention, SURVEY a-10) -- spelled out, so that the compiler's constant
+    // folder (scatter_min_kernel evaluates this for the literal zero point) and v_cvt_i32_f32 agree
+    auto to_int = [](float v) { return v != v ? 0 : (int)v; };
+    int col = to_int((PI_F - at) / az_res);                                  // model_util.py:234-235
+    const float beta = asinf(z / r);
+    int row = H - to_int(beta / vert_res + vert_off);                        // NaN -> 0, :237-242
+    row = row < 0 ? 0 : row > H - 1 ? H - 1 : row;
+    col = col < 0 ? 0 : col > W - 1 ? W - 1 : col;
+    return row * W + col;
+}
+
+// which of a zero point's three possible cells: by atan2f of its signed zeros (0: +-0, 1: pi, 2: -pi)
+__device__ __forceinline__ int zero_kind(float at) { return at > 1.0f ? 1 : at < -1.0f ? 2 : 0; }
+
+// range bits, cell id and the atomicMin of the cell's range for one (already transformed) point of image b.
+// The zero points of a padded / cropped scan (r = 0: tens of thousands in a 150 000-point KITTI cloud) all fall in ONE
+// cell and win it (one of three, by the signs of the zeros: atan2f(+-0, +0) = +-0, atan2f(+0, -0) = pi, atan2f(-0, -0)
+// = -pi; a warped invalid point is (w + t) * 0 = -0 where w + t < 0; asinf(0/0) is NaN whatever the sign: one row).
+// As atomics they queue on one address at ~170 ns each (measured: 940 us for 300 000 points, 5.6 us without atomics;
+// one speaker per wave behind a load filter still 200 us), so they do not touch minr at all: one lane per wave raises
+// the flag of (image, zero cell) -- zflag <- 0, a plain store of a constant to a word no atomic touches -- and pass B
+// lets nothing else win that cell.  For the other points a cell's value only ever decreases, so a (possibly stale)
+// read that is already <= rb proves the atomicMin would change nothing.
+__device__ __forceinline__ void bin_point(float x, float y, float z, long i, int b, int H, int W, float az_res, float vert_res,
+                                          float vert_off, const ProjScratch &ps)
+{
+    const float r = sqrtf(x * x + y * y + z * z);
+    const float at = atan2f(y, x);
+    const int cell = cell_of_point(at, z, r, H, W, az_res, vert_res, vert_off);
+    const unsigned rb = __float_as_uint(r);        // r >= 0: bit order == float order; NaN sorts last
+    ps.cell_of[i] = cell;
+    ps.rbits[i] = rb;
+    if (rb == 0) {
+        const int flag = b * ZFLAGS + zero_kind(at);
+        const unsigned long long zeros = __ballot(1);
+        const int leader = __ffsll((long long)zeros) - 1;
+        if ((int)(threadIdx.x & 63) == leader || flag != __shfl(flag, leader)) ps.zflag[flag] = 0u;
+        return;
+    }
+    unsigned *slot = ps.minr + (long)b * H * W + cell;
+    if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > rb) atomicMin(slot, rb);
+}
+
 // pass A of the projection for ONE point: warp by (q, t) (q == nullptr: no warp), range bits, cell id, atomicMin of the
 // cell's range.  q, t may live in LDS (the fused pose-head + warp launch) or in global memory.
 __device__ __forceinline__ void warp_cell_point(const elo_warp_project_args &a, long i, int b, const float *q, const float *t,
-                                                unsigned *minr, int *cell_of, unsigned *rbits)
+                                                const ProjScratch &ps)
 {
     float x = a.xyz[i * 3 + 0], y = a.xyz[i * 3 + 1], z = a.xyz[i * 3 + 2];
     if (q) {
@@ -613,18 +672,7 @@ __device__ __forceinline__ void warp_cell_point(const elo_warp_project_args &a, 
         x = (w1 + t[0]) * k; y = (w2 + t[1]) * k; z = (w3 + t[2]) * k;
         a.warped[i * 3 + 0] = x; a.warped[i * 3 + 1] = y; a.warped[i * 3 + 2] = z;
     }
-    const float r = sqrtf(x * x + y * y + z * z);
-    const float PI_F = 3.14159265358979323846f;
-    int col = (int)((PI_F - atan2f(y, x)) / a.az_res);                       // model_util.py:234-235
-    const float beta = asinf(z / r);
-    int row = a.H - (int)(beta / a.vert_res + a.vert_off);                   // NaN -> 0, :237-242
-    row = row < 0 ? 0 : row > a.H - 1 ? a.H - 1 : row;
-    col = col < 0 ? 0 : col > a.W - 1 ? a.W - 1 : col;
-    const int cell = row * a.W + col;
-    const unsigned rb = __float_as_uint(r);        // r >= 0: bit order == float order; NaN sorts last
-    cell_of[i] = cell;
-    rbits[i] = rb;
-    atomicMin(minr + (long)b * a.H * a.W + cell, rb);
+    bin_point(x, y, z, i, b, a.H, a.W, a.az_res, a.vert_res, a.vert_off, ps);
 }
 
 // ------------------------------------------------------------ pose head (one block per batch element)
@@ -756,17 +804,18 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
     __syncthreads();
     const long n = (long)blockIdx.x * blockDim.x + tid;
     if (n < w.npoints) {
-        const size_t cells = (size_t)w.batch * w.H * w.W, pts = (size_t)w.batch * w.npoints;
-        warp_cell_point(w, (long)b * w.npoints + n, b, head + 8, head + 12, w.scratch, (int *)(w.scratch + cells),
-                        w.scratch + cells + pts);
+        warp_cell_point(w, (long)b * w.npoints + n, b, head + 8, head + 12,
+                        proj_scratch(w.scratch, (size_t)w.batch * w.H * w.W, w.batch, (size_t)w.batch * w.npoints));
     }
 }
 
 // ------------------------------------------------------------ warp + spherical re-projection
 __global__ __launch_bounds__(ELO_BLOCK) void project_init_kernel(unsigned *minr, float *out_xyz, float *out_feat,
-                                                                 size_t cells, int C)
+                                                                 size_t cells, int C, int images)
 {
     const size_t n_xyz = cells * 3, n_feat = cells * (size_t)C, total = cells + n_xyz + n_feat;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)images * ZFLAGS; i += (size_t)gridDim.x * blockDim.x)
+        minr[cells + i] = 0x7f7f7f7fu;                                    // zflag: "no zero point seen"
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         if (i < cells) minr[i] = 0x7f7f7f7fu;
         else if (i < cells + n_xyz) out_xyz[i - cells] = 0.0f;
@@ -775,31 +824,68 @@ __global__ __launch_bounds__(ELO_BLOCK) void project_init_kernel(unsigned *minr,
 }
 
 // pass A: one thread per point
-__global__ __launch_bounds__(ELO_BLOCK) void warp_cell_kernel(const elo_warp_project_args a, unsigned *minr,
-                                                              int *cell_of, unsigned *rbits)
+__global__ __launch_bounds__(ELO_BLOCK) void warp_cell_kernel(const elo_warp_project_args a, const ProjScratch ps)
 {
     const long total = (long)a.batch * a.npoints;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / a.npoints);
-        warp_cell_point(a, i, b, a.q ? a.q + b * 4 : nullptr, a.q ? a.t + b * 3 : nullptr, minr, cell_of, rbits);
+        warp_cell_point(a, i, b, a.q ? a.q + b * 4 : nullptr, a.q ? a.t + b * 3 : nullptr, ps);
+    }
+}
+
+// pass A of the raw-cloud input stage: PreProcess of one point of frame f (model_util.py:346-422) + binning.
+// Stacked index: frame f of batch element b is image f*batch + b.
+__global__ __launch_bounds__(ELO_BLOCK) void input_cell_kernel(const elo_input_stage_args a, const ProjScratch ps)
+{
+    const long per_frame = (long)a.batch * a.npoints, total = 2 * per_frame;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int f = i >= per_frame;                                     // 0: frame 1, 1: frame 2
+        const long j = i - f * per_frame;
+        const int b = (int)(j / a.npoints);
+        const long n = j - (long)b * a.npoints;
+        const float *p = a.cloud + ((long)b * 2 * a.npoints + (long)f * a.npoints + n) * a.point_stride;
+        float x = p[0], y = p[1], z = p[2], w = 1.0f;
+        const float valid = (x != 0.0f || y != 0.0f || z != 0.0f) ? 1.0f : 0.0f;                  // :357-363
+        if (sqrtf(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y))) > a.crop_xy) x = y = z = w = 0.0f;   // :380-383 (no FMA: the
+                                                                                                  // threshold decides like numpy's)
+        if (a.T_trans && a.aug_frame[b] == f + 1) {                                               // :392-394, :408-410
+            const float *T = a.T_trans + b * 16;
+            const float nx = T[0] * x + T[1] * y + T[2] * z + T[3] * w;
+            const float ny = T[4] * x + T[5] * y + T[6] * z + T[7] * w;
+            const float nz = T[8] * x + T[9] * y + T[10] * z + T[11] * w;
+            x = nx; y = ny; z = nz;
+        }
+        x *= valid; y *= valid; z *= valid;                                                       // :421-422
+        a.points[i * 3 + 0] = x; a.points[i * 3 + 1] = y; a.points[i * 3 + 2] = z;
+        bin_point(x, y, z, i, f * a.batch + b, a.H, a.W, a.az_res, a.vert_res, a.vert_off, ps);
     }
 }
 
 // pass B: the point(s) holding the cell minimum are summed into the cell (tf.scatter_nd adds duplicates).
-__global__ __launch_bounds__(ELO_BLOCK) void scatter_min_kernel(const elo_warp_project_args a, const unsigned *minr,
-                                                                const int *cell_of, const unsigned *rbits)
+__global__ __launch_bounds__(ELO_BLOCK) void scatter_min_kernel(const elo_warp_project_args a, const ProjScratch ps)
 {
     const int CT = 3 + a.C;
     const long total = (long)a.batch * a.npoints * CT;
     const float *pts = a.q ? a.warped : a.xyz;
+    const int zc0 = cell_of_point(0.0f, 0.0f, 0.0f, a.H, a.W, a.az_res, a.vert_res, a.vert_off);          // zero_kind 0
+    const int zc1 = cell_of_point(atan2f(0.0f, -0.0f), 0.0f, 0.0f, a.H, a.W, a.az_res, a.vert_res, a.vert_off);
+    const int zc2 = cell_of_point(atan2f(-0.0f, -0.0f), 0.0f, 0.0f, a.H, a.W, a.az_res, a.vert_res, a.vert_off);
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long i = e / CT;
         const int ch = (int)(e - i * CT);
         const int b = (int)(i / a.npoints);
-        const long cell = (long)b * a.H * a.W + cell_of[i];
-        if (rbits[i] != minr[cell]) continue;
-        if (ch < 3) atomicAdd(a.out_xyz + cell * 3 + ch, pts[i * 3 + ch]);
-        else atomicAdd(a.out_feat + cell * a.C + (ch - 3), a.feat[i * a.C + (ch - 3)]);
+        const int c = ps.cell_of[i];
+        const long cell = (long)b * a.H * a.W + c;
+        // an image's zero points (range 0) win their cell: only they add there (zeros to xyz, their features to feat)
+        const bool zero_won = (c == zc0 && ps.zflag[b * ZFLAGS] == 0u) || (c == zc1 && ps.zflag[b * ZFLAGS + 1] == 0u) ||
+                              (c == zc2 && ps.zflag[b * ZFLAGS + 2] == 0u);
+        if (ps.rbits[i] != (zero_won ? 0u : ps.minr[cell])) continue;
+        // adding +-0 never changes a sum that started at +0 (x + 0 = x; 0 + -0 = +0): skipped, so the zero points of a
+        // padded scan -- all winners of one cell -- do not queue on its three words
+        const float v = ch < 3 ? pts[i * 3 + ch] : a.feat[i * a.C + (ch - 3)];
+        if (v == 0.0f) continue;
+        if (ch < 3) atomicAdd(a.out_xyz + cell * 3 + ch, v);
+        else atomicAdd(a.out_feat + cell * a.C + (ch - 3), v);
     }
 }
 
@@ -960,7 +1046,7 @@ extern "C" int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t s
     const int parts = sv_parts(a->npoints);
     hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
                        dim3(ELO_BLOCK), 0, (hipStream_t)stream, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
-                       a->scratch, ProjectionClear{nullptr, nullptr, nullptr, 0, 0});
+                       a->scratch, ProjectionClear{nullptr, nullptr, nullptr, 0, 0, 0});
     hipLaunchKernelGGL(softmax_valid_merge_kernel, dim3((a->batch * a->C + ELO_BLOCK - 1) / ELO_BLOCK), dim3(ELO_BLOCK),
                        0, (hipStream_t)stream, a->scratch, a->batch, a->C, parts, a->out);
     return check_launch(who);
@@ -1002,7 +1088,7 @@ static int pose_head_impl(const elo_pose_head_args *a, const elo_warp_project_ar
     const int parts = sv_parts(a->npoints);
     hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
                        dim3(ELO_BLOCK), 0, s, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
-                       a->scratch, ProjectionClear{a->clear_scratch, a->clear_xyz, a->clear_feat, a->clear_cells, a->clear_C});
+                       a->scratch, ProjectionClear{a->clear_scratch, a->clear_xyz, a->clear_feat, a->clear_cells, a->clear_C, a->batch});
     const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (ELO_BLOCK / ELO_WAVE) + 3 * 4 * 64);
     const unsigned xb = w ? (unsigned)((w->npoints + ELO_BLOCK - 1) / ELO_BLOCK) : 1u;
     hipLaunchKernelGGL(pose_head_kernel, dim3(xb, a->batch), dim3(ELO_BLOCK), lds, s, *a, parts, wv, w ? 1 : 0);
@@ -1010,8 +1096,8 @@ static int pose_head_impl(const elo_pose_head_args *a, const elo_warp_project_ar
         const size_t cells = (size_t)w->batch * w->H * w->W, pts = (size_t)w->batch * w->npoints;
         const size_t elems = pts * (3 + w->C);
         const unsigned gb = (unsigned)((elems + ELO_BLOCK - 1) / ELO_BLOCK);
-        hipLaunchKernelGGL(scatter_min_kernel, dim3(gb > 4096 ? 4096 : gb), dim3(ELO_BLOCK), 0, s, wv, w->scratch,
-                           (const int *)(w->scratch + cells), (const unsigned *)(w->scratch + cells + pts));
+        hipLaunchKernelGGL(scatter_min_kernel, dim3(gb > 4096 ? 4096 : gb), dim3(ELO_BLOCK), 0, s, wv,
+                           proj_scratch(w->scratch, cells, w->batch, pts));
     }
     return check_launch(who);
 }
@@ -1028,6 +1114,33 @@ extern "C" int elo_pose_head_warp(const elo_pose_head_args *a, const elo_warp_pr
     return pose_head_impl(a, w, stream, who);
 }
 
+extern "C" int elo_input_stage(const elo_input_stage_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_input_stage";
+    ELO_REQUIRE(a, who, "null argument block");
+    ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->H > 0 && a->W > 0 && a->point_stride >= 3, who, "bad sizes");
+    ELO_REQUIRE(a->cloud && a->points && a->out_xyz && a->scratch, who, "null tensor pointer");
+    ELO_REQUIRE((a->T_trans == nullptr) == (a->aug_frame == nullptr), who, "T_trans and aug_frame come together");
+    ELO_REQUIRE(a->az_res > 0.0f && a->vert_res > 0.0f, who, "bad projection constants");
+    if (a->batch == 0) return ELO_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t images = 2 * (size_t)a->batch, cells = images * a->H * a->W, pts = images * a->npoints;
+    const ProjScratch ps = proj_scratch(a->scratch, cells, images, pts);
+    const unsigned gi = (unsigned)((cells * 4 + ELO_BLOCK - 1) / ELO_BLOCK);
+    hipLaunchKernelGGL(project_init_kernel, dim3(gi > 4096 ? 4096 : gi), dim3(ELO_BLOCK), 0, s, ps.minr, a->out_xyz,
+                       (float *)nullptr, cells, 0, (int)images);
+    const unsigned ga = (unsigned)((pts + ELO_BLOCK - 1) / ELO_BLOCK);
+    hipLaunchKernelGGL(input_cell_kernel, dim3(ga > 8192 ? 8192 : ga), dim3(ELO_BLOCK), 0, s, *a, ps);
+    elo_warp_project_args w = {};
+    w.batch = (int)images; w.npoints = a->npoints; w.C = 0; w.H = a->H; w.W = a->W;
+    w.az_res = a->az_res; w.vert_res = a->vert_res; w.vert_off = a->vert_off;
+    w.xyz = a->points; w.out_xyz = a->out_xyz; w.scratch = a->scratch;
+    const size_t elems = pts * 3;
+    const unsigned gb = (unsigned)((elems + ELO_BLOCK - 1) / ELO_BLOCK);
+    hipLaunchKernelGGL(scatter_min_kernel, dim3(gb > 8192 ? 8192 : gb), dim3(ELO_BLOCK), 0, s, w, ps);
+    return check_launch(who);
+}
+
 extern "C" int elo_warp_project(const elo_warp_project_args *a, elo_stream_t stream)
 {
     const char *who = "elo_warp_project";
@@ -1035,21 +1148,19 @@ extern "C" int elo_warp_project(const elo_warp_project_args *a, elo_stream_t str
     if (a->batch == 0) return ELO_OK;
     hipStream_t s = (hipStream_t)stream;
     const size_t cells = (size_t)a->batch * a->H * a->W, pts = (size_t)a->batch * a->npoints;
-    unsigned *minr = a->scratch;
-    int *cell_of = (int *)(a->scratch + cells);
-    unsigned *rbits = a->scratch + cells + pts;
+    const ProjScratch ps = proj_scratch(a->scratch, cells, a->batch, pts);
     // one init launch instead of three memsets (memset nodes inside a captured hipGraph proved unreliable):
     // minr <- 0x7f7f7f7f (3.39e38f: above every finite range, below NaN bit patterns), outputs <- 0
     if (!a->prepared) {
         const size_t words = cells * (1 + 3 + (size_t)a->C);
         const unsigned gi = (unsigned)((words + ELO_BLOCK - 1) / ELO_BLOCK);
-        hipLaunchKernelGGL(project_init_kernel, dim3(gi > 4096 ? 4096 : gi), dim3(ELO_BLOCK), 0, s, minr, a->out_xyz,
-                           a->out_feat, cells, a->C);
+        hipLaunchKernelGGL(project_init_kernel, dim3(gi > 4096 ? 4096 : gi), dim3(ELO_BLOCK), 0, s, ps.minr, a->out_xyz,
+                           a->out_feat, cells, a->C, a->batch);
     }
     const unsigned ga = (unsigned)((pts + ELO_BLOCK - 1) / ELO_BLOCK);
-    hipLaunchKernelGGL(warp_cell_kernel, dim3(ga > 4096 ? 4096 : ga), dim3(ELO_BLOCK), 0, s, *a, minr, cell_of, rbits);
+    hipLaunchKernelGGL(warp_cell_kernel, dim3(ga > 4096 ? 4096 : ga), dim3(ELO_BLOCK), 0, s, *a, ps);
     const size_t elems = pts * (3 + a->C);
     const unsigned gb = (unsigned)((elems + ELO_BLOCK - 1) / ELO_BLOCK);
-    hipLaunchKernelGGL(scatter_min_kernel, dim3(gb > 4096 ? 4096 : gb), dim3(ELO_BLOCK), 0, s, *a, minr, cell_of, rbits);
+    hipLaunchKernelGGL(scatter_min_kernel, dim3(gb > 4096 ? 4096 : gb), dim3(ELO_BLOCK), 0, s, *a, ps);
     return check_launch(who);
 }

@@ -12,7 +12,7 @@ import time
 
 import torch
 
-from . import perm, pwclo_model, tf_util
+from . import model_util, perm, pwclo_model, tf_util
 
 
 def distinct_queue_streams(device, want, candidates=16, cycles=500_000):
@@ -81,8 +81,11 @@ class PWCLONet:
                                              bn_decay, aug_frame)
 
     # -- HIP graph -----------------------------------------------------------
-    def capture(self, batch_size, H_input, W_input, warmup=3, lanes=1):
+    def capture(self, batch_size, H_input, W_input, warmup=3, lanes=1, num_points=None, point_stride=3):
         """Record the inference forward into `lanes` independent hipGraphs (torch.cuda.CUDAGraph on ROCm).
+        With `num_points` the graph starts from RAW clouds: a lane owns a (B, 2*num_points, point_stride) cloud buffer
+        and records the input stage (model_util.input_stage: 35 m crop + both projections, no augmentation) in front
+        of the pyramid; feed it with `submit_points`.
 
         One frame pair keeps only a few of the 256 CUs busy per kernel, and frame pairs are independent,
         so several forwards can be in flight: lane i owns a graph and its static input / output buffers and
@@ -103,12 +106,23 @@ class PWCLONet:
         torch.cuda.synchronize(dev)
         self._lanes = []
         streams = distinct_queue_streams(dev, lanes)
+        if num_points is not None:                   # warm the input stage's allocations up as well
+            with torch.cuda.stream(side):
+                model_util.input_stage(torch.zeros((batch_size, 2 * num_points, point_stride), device=dev), None, None,
+                                       H_input, W_input)
+            torch.cuda.synchronize(dev)
         for i in range(lanes):
             both = zeros()
             lane = {"stream": streams[i % len(streams)], "pair": both, "in": (both[:batch_size], both[batch_size:]),
                     "graph": torch.cuda.CUDAGraph(), "pose": torch.zeros((batch_size, 7), device=dev)}
+            if num_points is not None:
+                lane["cloud"] = torch.zeros((batch_size, 2 * num_points, point_stride), device=dev)
             with torch.cuda.graph(lane["graph"]):
-                lane["out"] = self.forward(*lane["in"], pose_out=lane["pose"])
+                if num_points is not None:
+                    _pts, staged = model_util.input_stage(lane["cloud"], None, None, H_input, W_input)
+                    lane["out"] = self.forward(staged[:batch_size], staged[batch_size:], pose_out=lane["pose"])
+                else:
+                    lane["out"] = self.forward(*lane["in"], pose_out=lane["pose"])
             self._lanes.append(lane)
         torch.cuda.synchronize(dev)
         self._graph, self._static_in, self._static_out = (self._lanes[0]["graph"], self._lanes[0]["in"],
@@ -134,6 +148,14 @@ class PWCLONet:
             else:
                 lane["in"][0].copy_(xyz_f1_proj, non_blocking=True)
                 lane["in"][1].copy_(xyz_f2_proj, non_blocking=True)
+            lane["graph"].replay()
+        return lane["out"]
+
+    def submit_points(self, lane_index, point_cloud):
+        """Enqueue one forward from raw clouds (B, 2N, stride) on a lane captured with `num_points`."""
+        lane = self._lanes[lane_index]
+        with torch.cuda.stream(lane["stream"]):
+            lane["cloud"].copy_(point_cloud, non_blocking=True)
             lane["graph"].replay()
         return lane["out"]
 

@@ -135,11 +135,27 @@ def PreProcess(PC_f1, PC_f2, T_gt, T_trans, T_trans_inv, aug_frame):
     p2_aug = torch.matmul(p2, T_trans.transpose(1, 2))                                            # :392-394
     p1 = torch.where(aug == 1, p1_aug, p1)
     p2 = torch.where(aug == 2, p2_aug, p2)
-    T = torch.where(aug == 2, torch.matmul(T_trans, T_gt),
-                    torch.where(aug == 1, torch.matmul(T_gt, T_trans_inv), T_gt))                 # :403,:419
     out1 = p1[..., :3] * valid1                                                                   # :421-422
     out2 = p2[..., :3] * valid2
+    q_gt, t_gt = preprocess_gt(T_gt, T_trans, T_trans_inv, aug_frame)
+    return out1, out2, q_gt, t_gt
+
+
+def preprocess_gt(T_gt, T_trans, T_trans_inv, aug_frame):
+    """The ground-truth half of PreProcess (model_util.py:403,:419,:427-445): the (augmented) T_gt as (q_gt (B,4),
+    t_gt (B,3,1))."""
+    B = T_gt.shape[0]
+    aug = torch.as_tensor(aug_frame, device=T_gt.device).view(B, 1, 1)
+    T = torch.where(aug == 2, torch.matmul(T_trans, T_gt),
+                    torch.where(aug == 1, torch.matmul(T_gt, T_trans_inv), T_gt))                 # :403,:419
     z, y, x = mat2euler(T[:, :3, :3])
     q_gt = euler2quat(z, y, x)                                                                    # :427-428 -> (B,4)
     t_gt = T[:, :3, 3:]                                                                           # (B,3,1)
-    return out1, out2, q_gt, t_gt
+    return q_gt, t_gt
+
+
+def input_stage(point_cloud, T_trans, aug_frame, H_input, W_input):
+    """The point half of PreProcess + both input projections (pwclo_model.py:54-67) as ONE C-ABI call
+    (`elo_input_stage`: three launches).  point_cloud (B, 2N, >=3) -> (points (2B,N,3), xyz_proj (2B,H,W,3)), frame 1
+    of every batch element first.  Inference only (the reference wraps this stage in stop_gradient, :66-67)."""
+    return _ops.input_stage(point_cloud, T_trans, aug_frame, H_input, W_input)

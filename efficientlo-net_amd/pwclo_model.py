@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _ops, tf_util
-from .model_util import (PreProcess, ProjectPC2SphericalRing, get_selected_idx, inv_q, mul_point_q, mul_q_point,
+from .model_util import (PreProcess, ProjectPC2SphericalRing, input_stage, preprocess_gt, get_selected_idx, inv_q, mul_point_q, mul_q_point,
                          softmax_valid, warp_and_project)
 from .pointnet_util import (cost_volume, down_conv, flow_predictor, fused_pairs_available, up_conv,
                             up_conv_predict_pair)
@@ -363,16 +363,13 @@ def get_model(point_cloud, H_input, W_input, T_gt, T_trans, T_trans_inv, is_trai
     """pwclo_model.py:30-433 with the reference's signature: point_cloud (B, 2*N, >=3), three (B,4,4).
     Returns the reference's 11-tuple."""
     batch_size = point_cloud.shape[0]
-    num_points = point_cloud.shape[1] // 2
-    xyz_f1_input = point_cloud[:, :num_points, 0:3]
-    xyz_f2_input = point_cloud[:, num_points:, 0:3]
     if aug_frame is None:
         aug_frame = np.random.choice([1, 2], size=batch_size, replace=True)                         # :59
     with torch.no_grad():                                                                           # tf.stop_gradient, :66-67
-        xyz_f1_aug, xyz_f2_aug, q_gt, t_gt = PreProcess(xyz_f1_input, xyz_f2_input, T_gt, T_trans, T_trans_inv,
-                                                        aug_frame)
-        xyz_f1_proj, _ = ProjectPC2SphericalRing(xyz_f1_aug, None, H_input, W_input)
-        xyz_f2_proj, _ = ProjectPC2SphericalRing(xyz_f2_aug, None, H_input, W_input)
+        # PreProcess's crop + augmentation and both ProjectPC2SphericalRing calls in one C-ABI call (three launches)
+        _points, both = input_stage(point_cloud, T_trans, aug_frame, H_input, W_input)
+        xyz_f1_proj, xyz_f2_proj = both[:batch_size], both[batch_size:]         # adjacent: one 2B Siamese batch
+        q_gt, t_gt = preprocess_gt(T_gt, T_trans, T_trans_inv, aug_frame)
     out = get_model_from_projection(xyz_f1_proj, xyz_f2_proj, is_training, bn_decay)
     return out + (q_gt, t_gt)
 

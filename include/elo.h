@@ -217,7 +217,7 @@ typedef struct elo_pose_head_args {
     /* Optional side job for the workgroups of the first launch: clear the buffers of the elo_warp_project call
      * that will consume this pose (its scratch min-range words and its two outputs), so that call can set
      * `prepared` and skip its own init launch.  clear_scratch == NULL: no side job. */
-    unsigned *clear_scratch;      /* the warp call's `scratch`: the first clear_cells words are set to 0x7f7f7f7f */
+    unsigned *clear_scratch;      /* the warp call's `scratch`: its first clear_cells + 4*batch words are set to 0x7f7f7f7f */
     float *clear_xyz;             /* its out_xyz  (clear_cells*3 floats  <- 0) */
     float *clear_feat;            /* its out_feat (clear_cells*clear_C floats <- 0), NULL when clear_C == 0 */
     long clear_cells;             /* batch*H*W of that call */
@@ -234,7 +234,8 @@ int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream);
  *          with the minimum r of a cell are SUMMED into it (tf.scatter_nd adds).
  * az_res / vert_res / vert_off are computed by the caller exactly as
  * model_util.py:189-200 does (python double -> float32).
- * scratch: (batch*H*W) + 2*(batch*npoints) 32-bit device words. */
+ * scratch: (batch*H*W) + 4*batch + 2*(batch*npoints) 32-bit device words
+ *          [min range per cell | 4 zero-point flags per image | cell of point | range bits of point]. */
 typedef struct elo_warp_project_args {
     int batch, npoints, C;        /* C may be 0 (no features) */
     int H, W;
@@ -250,6 +251,29 @@ typedef struct elo_warp_project_args {
     int prepared;                 /* 1: scratch / out_xyz / out_feat were cleared by elo_pose_head (clear_*): no init launch */
 } elo_warp_project_args;
 int elo_warp_project(const elo_warp_project_args *a, elo_stream_t stream);
+
+/* Raw-cloud input stage: PreProcess (model_util.py:346-445; the point part) + the input ProjectPC2SphericalRing of
+ * BOTH frames (pwclo_model.py:54-67) in three launches (clear, per-point pass, scatter).  Per point p of frame f:
+ *   valid = any(p != 0);  p4 = [p, 1], zeroed (all four) where sqrt(x^2 + y^2) > crop_xy  (model_util.py:380-383);
+ *   p4 <- T_trans[b] . p4  when aug_frame[b] == f  (:392-394, :408-410);  out = p4[:3] * valid  (:421-422)
+ * then the projection of elo_warp_project (no warp).  Outputs are STACKED over frames, frame 1 of every batch element
+ * first: points (2*batch, npoints, 3), out_xyz (2*batch, H, W, 3) -- the layout the Siamese pyramid runs as one batch.
+ * q_gt / t_gt of PreProcess (a 4x4 product and an Euler round trip per batch element) stay with the caller.
+ * scratch: (2*batch*H*W) + 4*(2*batch) + 2*(2*batch*npoints) 32-bit device words. */
+typedef struct elo_input_stage_args {
+    int batch, npoints;           /* points per frame */
+    int point_stride;             /* floats per point in `cloud` (>= 3: x, y, z first; main.py feeds 6) */
+    int H, W;
+    float az_res, vert_res, vert_off;   /* as in elo_warp_project_args */
+    float crop_xy;                /* 35 (model_util.py:380) */
+    const float *cloud;           /* (batch, 2*npoints, point_stride): frame 1's points, then frame 2's (pwclo_model.py:56-57) */
+    const float *T_trans;         /* (batch,4,4) row-major, or NULL = no augmentation */
+    const int *aug_frame;         /* (batch) 1 or 2: the frame T_trans applies to (NULL with T_trans == NULL) */
+    float *points;                /* (2*batch, npoints, 3) OUT */
+    float *out_xyz;               /* (2*batch, H, W, 3) OUT */
+    unsigned *scratch;
+} elo_input_stage_args;
+int elo_input_stage(const elo_input_stage_args *a, elo_stream_t stream);
 
 /* elo_pose_head followed by elo_warp_project of the NEXT level's cloud by the pose it just computed
  * (pwclo_model.py:211-236 after :194-208 / :262-280), in three launches instead of five: the projection's buffers

@@ -117,3 +117,26 @@ def test_half_products_forward(kernel_path):
     assert not torch.equal(ref[6], out[6])                                   # the mode was engaged
     assert (ref[6] - out[6]).abs().max() < 2e-3 and (ref[7] - out[7]).abs().max() < 2e-3      # l3 (q, t)
     assert (ref[0] - out[0]).abs().max() < 0.2                               # l0 q: same motion, fp16-class + regrouping
+
+
+def test_graph_from_raw_clouds_equals_forward_points(kernel_path):
+    """capture(num_points=N): the input stage (crop + both projections) is recorded in front of the pyramid; a replay
+    fed with raw clouds gives what the eager get_model gives for the same clouds (identity augmentation)."""
+    synth = load_pkg("synth")
+    H, W, B = 64, 900, 1
+    f1, f2 = synth.frame_pair(B, H, W, seed=13)
+    rng = np.random.default_rng(0)
+    far = (rng.normal(0, 30, (B, 500, 3)) + 40).astype(np.float32)                       # beyond the 35 m crop
+    pad = np.zeros((B, 300, 3), np.float32)
+    cloud = np.concatenate([f1.reshape(B, -1, 3), far, pad, f2.reshape(B, -1, 3), pad, far], 1)
+    cloud = torch.from_numpy(cloud).to(DEV)
+    n = cloud.shape[1] // 2
+    eye = torch.eye(4, device=DEV).repeat(B, 1, 1)
+    net = _net()
+    want = [x.clone() for x in net.forward_points(cloud, H, W, eye, eye, eye, aug_frame=np.array([1]))[:8]]
+    net.capture(B, H, W, lanes=2, num_points=n)
+    for lane in (0, 1, 0):
+        out = net.submit_points(lane, cloud)
+        torch.cuda.synchronize()
+        for g, w_ in zip(out[:8], want):
+            assert torch.equal(g, w_)

@@ -367,3 +367,42 @@ def test_half_products_are_one_fp16_product_with_fp32_accumulation():
     full = fused.PackedDense(t(rng.normal(0, 0.2, (N, 64)).astype(np.float32)), t(np.zeros(64, np.float32)))
     with pytest.raises(RuntimeError, match="products mode"):
         fused.mlp([t(x)], [half, full])
+
+
+@pytest.mark.parametrize("B,N,stride,H,W", [(3, 5000, 3, 64, 900), (1, 20000, 6, 64, 1800), (2, 777, 4, 16, 225)])
+def test_input_stage_is_preprocess_plus_both_projections(B, N, stride, H, W):
+    """elo_input_stage: the point half of PreProcess against the oracle (crop at 35 m, T_trans on
+    the frame aug_frame names, validity re-mask; tolerance = the 4-term dot product's rounding), and its range images
+    against the product's own projection of those points (same kernel code: equal up to the order duplicates add)."""
+    mu = load_pkg("model_util")
+    rng = np.random.default_rng(B * 1000 + N)
+    cloud = rng.normal(0, 15, (B, 2 * N, stride)).astype(np.float32)
+    cloud[:, :N // 20, :3] = 0                                    # invalid points in frame 1 ...
+    cloud[:, -N // 10:, :3] = 0                                   # ... and frame 2
+
+    def rigid(seed):
+        r = np.random.default_rng(seed)
+        a = r.normal(0, 0.05, 3)
+        Rz = np.array([[np.cos(a[0]), -np.sin(a[0]), 0], [np.sin(a[0]), np.cos(a[0]), 0], [0, 0, 1]])
+        Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
+        T = np.eye(4); T[:3, :3] = Rz @ Ry; T[:3, 3] = r.normal(0, 0.5, 3)
+        return T.astype(np.float32)
+    T_tr = np.stack([rigid(10 + i) for i in range(B)])
+    aug = np.array([1, 2, 1][:B])
+    eye = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    pts, proj = mu.input_stage(t(cloud), t(T_tr), aug, H, W)
+    w1, w2, _q, _t = O.PreProcess(cloud[:, :N, :3], cloud[:, N:, :3], eye, T_tr, np.linalg.inv(T_tr).astype(np.float32), aug)
+    assert pts.shape == (2 * B, N, 3) and proj.shape == (2 * B, H, W, 3)
+    close(pts[:B], w1, atol=2e-4)
+    close(pts[B:], w2, atol=2e-4)
+    assert (pts[:B, :N // 20] == 0).all() and (pts[B:, -N // 10:] == 0).all()            # translated zeros are re-masked
+    far = np.sqrt((cloud[:, :N, :2] ** 2).sum(-1)) > 35
+    assert far.any() and (pts[:B].cpu().numpy()[far] == 0).all()
+    with torch.no_grad():
+        again = mu.ProjectPC2SphericalRing(pts, None, H, W)[0]
+    assert torch.allclose(proj, again, rtol=0, atol=1e-5)
+    # no augmentation: T_trans = None
+    pts0, proj0 = mu.input_stage(t(cloud), None, None, H, W)
+    crop = cloud[..., :3].copy()
+    crop[np.sqrt((crop[..., :2] ** 2).sum(-1)) > 35] = 0
+    assert np.array_equal(pts0.cpu().numpy(), np.concatenate([crop[:, :N], crop[:, N:]], 0))
