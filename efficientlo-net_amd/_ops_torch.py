@@ -18,19 +18,61 @@ def _cell(idx, H, W):
     return (idx[..., 0].long() * H + idx[..., 1].long()) * W + idx[..., 2].long()
 
 
-def _gather(grid, idx):
-    """tf.gather_nd(grid (B,H,W,C), idx (...,3)) -> (..., C).
+_SPREAD = 8192                                      # dummy rows that absorb the adds of rows without a contribution
+_spread_cache = {}
+
+
+def _spread_rows(n, base, device):
+    """base + (0..n-1) % _SPREAD: distinct-enough targets for rows whose contribution is zero."""
+    key = (n, str(device))
+    if key not in _spread_cache:
+        if len(_spread_cache) > 64:
+            _spread_cache.clear()
+        _spread_cache[key] = torch.arange(n, device=device) % _SPREAD
+    return _spread_cache[key] + base
+
+
+def _index_add_live(rows, C, target, values, live):
+    """zeros((rows, C)).index_add(0, target, values) for the rows where `live`; the others (their value is zero by
+    construction) are sent to dummy rows instead of their nominal target.  The nominal target of a masked slot is
+    cell (0,0,0) and of an invalid point the one "zero cell": as atomic adds they all queue on
+    ONE row -- same-address atomics serialise at ~170 ns each on this GPU (projection) -- which was most
+    of the 41 % of a training step spent in index_add_."""
+    tgt = torch.where(live, target, _spread_rows(target.numel(), rows, target.device))
+    out = torch.zeros((rows + _SPREAD, C), dtype=values.dtype, device=values.device).index_add_(0, tgt, values)
+    return out[:rows]
+
+
+class _GatherMasked(torch.autograd.Function):
+    """flat (R,C), cell (n,) long, mask (n,) of 0/1 -> flat[cell] * mask[:, None]; backward: the scatter-add of TF's
+    gather_nd gradient, restricted to the unmasked slots."""
+
+    @staticmethod
+    def forward(ctx, flat, cell, mask):
+        ctx.save_for_backward(cell, mask)
+        ctx.rows = flat.shape[0]
+        return flat.index_select(0, cell) * mask.unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, grad):
+        cell, mask = ctx.saved_tensors
+        g = grad * mask.unsqueeze(-1)
+        return _index_add_live(ctx.rows, grad.shape[-1], cell, g, mask != 0), None, None
+
+
+def _gather(grid, idx, mask):
+    """tf.gather_nd(grid (B,H,W,C), idx (...,3)) * mask[..., None] -> (..., C)   (utils/pointnet_util.py:54-55).
     index_select, not advanced indexing: its backward is one atomic index_add_ (the scatter-add of TF's gather_nd
     gradient), where the backward of `flat[cell]` is a sort-based index_put that took 80 % of a training step
     (5.3 ms per call, 27 calls: tools/train_profile.py)."""
     B, H, W, C = grid.shape
     cell = _cell(idx, H, W)
-    return grid.reshape(B * H * W, C).index_select(0, cell.reshape(-1)).reshape(*cell.shape, C)
+    out = _GatherMasked.apply(grid.reshape(B * H * W, C), cell.reshape(-1), mask.reshape(-1).to(grid.dtype))
+    return out.reshape(*cell.shape, C)
 
 
 def group_concat(centre_xyz, src_xyz, src_feat, idx, mask):
-    m = mask.unsqueeze(-1)
-    return torch.cat([_gather(src_xyz, idx) * m - centre_xyz.unsqueeze(2), _gather(src_feat, idx) * m], -1)
+    return torch.cat([_gather(src_xyz, idx, mask) - centre_xyz.unsqueeze(2), _gather(src_feat, idx, mask)], -1)
 
 
 def masked_maxpool(x, mask):
@@ -44,20 +86,18 @@ def _geometry(p, g):
 
 
 def cv_encode1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask):
-    m = mask.unsqueeze(-1)
     K = idx.shape[2]
-    q = _gather(xyz2_proj, idx) * m
-    f2 = _gather(feat2_proj, idx) * m
+    q = _gather(xyz2_proj, idx, mask)
+    f2 = _gather(feat2_proj, idx, mask)
     return torch.cat([_geometry(xyz1.unsqueeze(2), q), feat1.unsqueeze(2).expand(-1, -1, K, -1), f2], -1)
 
 
 def cv_encode2(xyz1_proj, feat1_proj, cost_proj, idx, mask):
     B, H, W, C = feat1_proj.shape
-    m = mask.unsqueeze(-1)
     K = idx.shape[2]
     p = xyz1_proj.reshape(B, H * W, 1, 3)
-    g = _gather(xyz1_proj, idx) * m
-    rest = torch.cat([feat1_proj.reshape(B, H * W, 1, C).expand(-1, -1, K, -1), _gather(cost_proj, idx) * m], -1)
+    g = _gather(xyz1_proj, idx, mask)
+    rest = torch.cat([feat1_proj.reshape(B, H * W, 1, C).expand(-1, -1, K, -1), _gather(cost_proj, idx, mask)], -1)
     return _geometry(p, g), rest
 
 
@@ -108,13 +148,21 @@ def warp_project(xyz, feat, q, t, H, W):
         row = (H - torch.nan_to_num(torch.asin(z / r) / vres + voff, nan=0.0).trunc().long()).clamp(0, H - 1)
         cell = (torch.arange(B, device=xyz.device).view(B, 1) * H + row) * W + col
         flat_cell, flat_r = cell.reshape(-1), r.reshape(-1)
-        min_r = torch.full((B * H * W,), float("inf"), device=xyz.device).scatter_reduce(0, flat_cell, flat_r, "amin")
-        same = (flat_r == min_r[flat_cell]).to(xyz.dtype).unsqueeze(-1)
-    out_xyz = torch.zeros((B * H * W, 3), dtype=xyz.dtype, device=xyz.device).index_add(
-        0, flat_cell, pts.reshape(-1, 3) * same).reshape(B, H, W, 3)
+        cells = B * H * W
+        # the invalid points (r = 0) all sit in one cell per image: kept out of the atomic min (they would queue on
+        # one address), their cells are set to 0 by a plain indexed store afterwards
+        zero = flat_r == 0
+        spread = _spread_rows(flat_cell.numel(), cells, xyz.device)
+        min_r = torch.full((cells + _SPREAD,), float("inf"), device=xyz.device).scatter_reduce(
+            0, torch.where(zero, spread, flat_cell), flat_r, "amin")
+        min_r.index_fill_(0, torch.where(zero, flat_cell, spread), 0.0)          # (no boolean indexing: no host sync)
+        min_r = min_r[:cells]
+        win = flat_r == min_r[flat_cell]
+        same = win.to(xyz.dtype).unsqueeze(-1)
+    # losers add nothing; winning zero points add zeros to xyz (skipped) and their features to feat (kept)
+    out_xyz = _index_add_live(cells, 3, flat_cell, pts.reshape(-1, 3) * same, win & ~zero).reshape(B, H, W, 3)
     out_feat = None
     if feat is not None:
         C = feat.shape[-1]
-        out_feat = torch.zeros((B * H * W, C), dtype=feat.dtype, device=feat.device).index_add(
-            0, flat_cell, feat.reshape(-1, C) * same).reshape(B, H, W, C)
+        out_feat = _index_add_live(cells, C, flat_cell, feat.reshape(-1, C) * same, win).reshape(B, H, W, C)
     return warped, out_xyz, out_feat
