@@ -62,6 +62,8 @@ def parse():
                          "half = ONE fp16 product (fp16 arithmetic, BASELINE configs[2]; not the fp32 parity path)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="only the timed loop: no roofline / cpu_baseline / from_raw_clouds / batch8 legs (profiling runs)")
     ap.add_argument("--cpu-pairs", type=int, default=60, help="pairs in the CPU-oracle sample")
     return ap.parse_args()
 
@@ -393,7 +395,7 @@ def main():
                                       "hipGraph replay, %d forwards in flight" % lanes),
                    "global_batch": B * world, "parallelism": "dp%d" % world},
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_legs:
         line["roofline"] = roofline_leg(args, dev, net)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_leg(args, net, args.cpu_pairs)
