@@ -1119,10 +1119,10 @@ extern "C" int elo_input_stage(const elo_input_stage_args *a, elo_stream_t strea
     const char *who = "elo_input_stage";
     ELO_REQUIRE(a, who, "null argument block");
     ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->H > 0 && a->W > 0 && a->point_stride >= 3, who, "bad sizes");
-    ELO_REQUIRE(a->cloud && a->points && a->out_xyz && a->scratch, who, "null tensor pointer");
     ELO_REQUIRE((a->T_trans == nullptr) == (a->aug_frame == nullptr), who, "T_trans and aug_frame come together");
     ELO_REQUIRE(a->az_res > 0.0f && a->vert_res > 0.0f, who, "bad projection constants");
-    if (a->batch == 0) return ELO_OK;
+    if (a->batch == 0) return ELO_OK;                 // (an empty batch has no buffers to name)
+    ELO_REQUIRE(a->cloud && a->points && a->out_xyz && a->scratch, who, "null tensor pointer");
     hipStream_t s = (hipStream_t)stream;
     const size_t images = 2 * (size_t)a->batch, cells = images * a->H * a->W, pts = images * a->npoints;
     const ProjScratch ps = proj_scratch(a->scratch, cells, images, pts);

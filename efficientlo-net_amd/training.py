@@ -51,35 +51,101 @@ def data_augmentation(rng=None):
 
 
 class Trainer:
-    def __init__(self, net):
+    def __init__(self, net, capturable=False):
+        """`capturable`: Adam keeps its step counts and learning rate on the device, so that a whole optimisation step
+        can be recorded into a hipGraph (`capture` / `step_graph`)."""
         self.net = net
+        self.capturable = capturable
+        self._graph = None
         pwclo_model.create_variables(net.store)
         dev = net.device
         self.w_x = torch.nn.Parameter(torch.tensor(0.0, device=dev))     # main.py:151
         self.w_q = torch.nn.Parameter(torch.tensor(-2.5, device=dev))    # main.py:152
         self.params = net.store.parameters() + [self.w_x, self.w_q]      # 382 tensors, 899 134 values
         self.bucket = FlatGradBucket(self.params)
-        self.opt = torch.optim.Adam(self.params, lr=BASE_LEARNING_RATE)  # main.py:174
+        if capturable:
+            self._lr = torch.tensor(BASE_LEARNING_RATE, device=dev)
+            self.opt = torch.optim.Adam(self.params, lr=self._lr, capturable=True)
+        else:
+            self.opt = torch.optim.Adam(self.params, lr=BASE_LEARNING_RATE)  # main.py:174
         self.step_count = 0
 
-    def step(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt):
-        """One optimisation step on this rank's batch; returns the (local) loss."""
-        B = xyz_f1_proj.shape[0]
-        for g in self.opt.param_groups:
-            g["lr"] = learning_rate(self.step_count, B)
-        self.net.perms.reshuffle()                                       # tf.random_shuffle draws per step
+    def _set_lr(self, B):
+        lr = learning_rate(self.step_count, B)
+        if self.capturable:
+            self._lr.fill_(lr)
+        else:
+            for g in self.opt.param_groups:
+                g["lr"] = lr
+
+    def _body(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, decay):
+        """zero grads -> forward -> loss -> backward -> all-reduce -> Adam: everything of a step that runs on the GPU."""
         self.bucket.zero()
         with torch.enable_grad():
             with tf_util.default_store(self.net.store), perm.default_perm_source(self.net.perms):
-                out = pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, True,
-                                                            bn_decay(self.step_count, B))
+                out = pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, True, decay)
             loss = pwclo_model.get_loss(*out[:8], q_gt, t_gt, self.w_x, self.w_q)
             loss.backward()
         self.bucket.all_reduce_mean()                                    # the one collective of a training step
         self.opt.step()
+        return loss.detach()
+
+    def step(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt):
+        """One optimisation step on this rank's batch; returns the (local) loss."""
+        B = xyz_f1_proj.shape[0]
+        self._set_lr(B)
+        self.net.perms.reshuffle()                                       # tf.random_shuffle draws per step
+        loss = self._body(xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, bn_decay(self.step_count, B))
         self.net.store.invalidate()                                      # folded / packed inference weights are stale
         self.step_count += 1
-        return loss.detach()
+        return loss
+
+    # -- the step as ONE hipGraph ----------------------------------------------
+    def capture(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, warmup=3):
+        """Record `_body` for this batch shape (needs `capturable=True`).  An eager step is ~4800 launches and is bound
+        by the host; the replay is bound by the GPU.  The sample batch is used for the warm-up steps (they are real
+        optimisation steps).  Learning rate and visiting orders change between replays through device tensors the
+        graph reads; the BN decay is baked in, so `step_graph` re-captures when the schedule moves it (every 200 000
+        samples, main.py:130-138)."""
+        if not self.capturable:
+            raise RuntimeError("Trainer(net, capturable=True) is needed to capture a training step")
+        dev = self.net.device
+        self._static = [torch.empty_like(x) for x in (xyz_f1_proj, xyz_f2_proj, q_gt, t_gt)]
+        for s, x in zip(self._static, (xyz_f1_proj, xyz_f2_proj, q_gt, t_gt)):
+            s.copy_(x)
+        B = xyz_f1_proj.shape[0]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(*self._static)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._decay = bn_decay(self.step_count, B)
+        self._set_lr(B)
+        self.net.perms.reshuffle()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._loss = self._body(*self._static, self._decay)
+        self.net.store.invalidate()
+        self.step_count += 1                                             # the capture itself does not run the step...
+        self._graph.replay()                                             # ... this replay does
+        return self
+
+    def step_graph(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt):
+        """`step` through the captured graph (same batch shape as `capture`)."""
+        B = xyz_f1_proj.shape[0]
+        if self._graph is None or bn_decay(self.step_count, B) != self._decay:
+            self.capture(xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, warmup=1 if self._graph is not None else 3)
+            return self._loss
+        for s, x in zip(self._static, (xyz_f1_proj, xyz_f2_proj, q_gt, t_gt)):
+            s.copy_(x, non_blocking=True)
+        self._set_lr(B)
+        self.net.perms.reshuffle()
+        self._graph.replay()
+        self.net.store.invalidate()
+        self.step_count += 1
+        return self._loss
 
     # -- checkpoints -----------------------------------------------------------
     def save(self, path, tf_bundle=False):
@@ -117,7 +183,8 @@ class Trainer:
             opt_state = self.opt.state_dict()
             for i, p in enumerate(self.params):
                 if "adam_m/%d" % i in adam:
-                    opt_state["state"][i] = {"step": torch.tensor(float(adam["adam_t/%d" % i])),
+                    opt_state["state"][i] = {"step": torch.tensor(float(adam["adam_t/%d" % i]),
+                                                                  device=dev if self.capturable else "cpu"),
                                              "exp_avg": torch.from_numpy(adam["adam_m/%d" % i]).to(dev),
                                              "exp_avg_sq": torch.from_numpy(adam["adam_v/%d" % i]).to(dev)}
             self.opt.load_state_dict(opt_state)

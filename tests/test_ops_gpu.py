@@ -406,3 +406,19 @@ def test_input_stage_is_preprocess_plus_both_projections(B, N, stride, H, W):
     crop = cloud[..., :3].copy()
     crop[np.sqrt((crop[..., :2] ** 2).sum(-1)) > 35] = 0
     assert np.array_equal(pts0.cpu().numpy(), np.concatenate([crop[:, :N], crop[:, N:]], 0))
+
+
+def test_input_stage_edges():
+    """Empty batch, malformed clouds, and a T_trans without aug_frame are argument errors, not launches."""
+    mu, ops = load_pkg("model_util"), load_pkg("_ops")
+    pts, proj = mu.input_stage(torch.zeros((0, 200, 3), device=DEV), None, None, 16, 64)
+    assert pts.shape == (0, 100, 3) and proj.shape == (0, 16, 64, 3)
+    with pytest.raises(ValueError, match="2\\*N"):
+        mu.input_stage(torch.zeros((1, 201, 3), device=DEV), None, None, 16, 64)
+    with pytest.raises(ValueError, match="2\\*N"):
+        mu.input_stage(torch.zeros((1, 200, 2), device=DEV), None, None, 16, 64)
+    with pytest.raises(RuntimeError, match="AMD GPU"):
+        mu.input_stage(torch.zeros((1, 200, 3)), None, None, 16, 64)
+    # all-zero clouds: every cell stays empty
+    pts, proj = mu.input_stage(torch.zeros((2, 200, 3), device=DEV), None, None, 16, 64)
+    assert not pts.any() and not proj.any()

@@ -193,3 +193,27 @@ def test_runs_at_128x2048():
     want = O.get_model_from_projection(export(net.store), shuffle_fn, f1, f2)
     for g, w_ in zip(got, want):
         close(g, w_, atol=1e-4, rtol=1e-4)
+
+
+def test_captured_training_step_trains():
+    """Trainer(capturable=True).capture / step_graph: the whole optimisation step as one hipGraph.  Same data every
+    step: the loss falls, the step counter and the device-side learning rate follow the schedule, and the graph reads
+    new inputs through its static buffers (a different batch gives a different loss)."""
+    model, training, synth = load_pkg("model"), load_pkg("training"), load_pkg("synth")
+    torch.manual_seed(0)
+    net = model.PWCLONet(DEV, seed=3)
+    tr = training.Trainer(net, capturable=True)
+    f1, f2 = synth.frame_pair(2, 64, 900, seed=20)
+    a, b = t(f1), t(f2)
+    q_gt = t(np.array([[0.99995, 0.0, 0.0, 0.01]] * 2, np.float32))
+    t_gt = t(np.array([[[0.8], [0.0], [0.0]]] * 2, np.float32))
+    tr.capture(a, b, q_gt, t_gt)
+    start = tr.step_count
+    losses = [float(tr.step_graph(a, b, q_gt, t_gt)) for _ in range(8)]
+    assert tr.step_count == start + 8 and all(np.isfinite(losses)) and min(losses[4:]) < losses[0], losses
+    assert abs(float(tr._lr) - training.learning_rate(tr.step_count - 1, 2)) < 1e-9
+    g1, g2 = synth.frame_pair(2, 64, 900, seed=21)
+    other = float(tr.step_graph(t(g1), t(g2), q_gt, t_gt))
+    assert np.isfinite(other) and other != losses[-1]
+    with pytest.raises(RuntimeError, match="capturable"):
+        training.Trainer(model.PWCLONet(DEV, seed=3)).capture(a, b, q_gt, t_gt)

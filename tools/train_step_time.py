@@ -17,3 +17,8 @@ for B in (1, 4, 8):
     for _ in range(n): tr.step(a, b, q, t)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print("batch %d: %.1f ms per training step, %.1f pairs/s, peak memory %.2f GB" % (B, dt * 1e3, B / dt, torch.cuda.max_memory_allocated() / 2**30))
+    tg = training.Trainer(model.PWCLONet(dev, seed=0), capturable=True).capture(a, b, q, t)      # the step as one hipGraph
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): tg.step_graph(a, b, q, t)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    print("batch %d: %.1f ms per CAPTURED training step, %.1f pairs/s" % (B, dt * 1e3, B / dt))
