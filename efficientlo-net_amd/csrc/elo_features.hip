@@ -701,6 +701,21 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
     float *feat = sm, *big = sm + a.C, *head = big + a.hidden;
     const int b = blockIdx.y, tid = threadIdx.x;
     const SvPartials s = sv_partials(a.scratch, gridDim.y, a.C);
+    // The model's head (C = 64, hidden = 256 = one unit per thread): this thread's column of W_big and its rows of
+    // W_q / W_t do not depend on anything computed here -- requested now, they arrive while the slices are merged
+    // (otherwise four dependent batches of 16 loads sit between the merge and the heads).
+    constexpr int HEAD_C = 64;
+    const bool model_head = a.C == HEAD_C && a.hidden == (int)blockDim.x;
+    float wb[HEAD_C], wq[4], wt[3], bias_big = 0.0f;
+    if (model_head) {
+#pragma unroll
+        for (int c = 0; c < HEAD_C; ++c) wb[c] = a.W_big[(size_t)c * a.hidden + tid];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) wq[o] = a.W_q[(size_t)tid * 4 + o];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) wt[o] = a.W_t[(size_t)tid * 3 + o];
+        bias_big = a.b_big[tid];
+    }
     {   // merge the slices: 4 threads per channel (C <= 64), each over every 4th slice, then a 4-way combine
         float *mpart = head + 8 + 8 * (ELO_BLOCK / ELO_WAVE);          // [3][4][64]
         const int c = tid & 63, q = tid >> 6;
@@ -738,21 +753,36 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
         for (int c2 = 64 + tid; c2 < a.C; c2 += blockDim.x) feat[c2] = sv_merge(s, b, c2, a.C, parts);   // C > 64 (not the model)
     }
     __syncthreads();
-    for (int j = tid; j < a.hidden; j += blockDim.x) {     // conv1d C -> hidden, no activation (:197)
-        float v = a.b_big[j];
+    if (model_head) {                                      // conv1d C -> hidden, no activation (:197), same summation order
+        float v = bias_big;
+#pragma unroll
+        for (int c = 0; c < HEAD_C; ++c) v += feat[c] * wb[c];
+        big[tid] = v;
+    } else {
+        for (int j = tid; j < a.hidden; j += blockDim.x) {
+            float v = a.b_big[j];
 #pragma unroll 16
-        for (int c = 0; c < a.C; ++c) v += feat[c] * a.W_big[(size_t)c * a.hidden + j];
-        big[j] = v;
+            for (int c = 0; c < a.C; ++c) v += feat[c] * a.W_big[(size_t)c * a.hidden + j];
+            big[j] = v;
+        }
     }
     __syncthreads();
     {   // conv1d hidden -> 4 (q) and hidden -> 3 (t): 7 dot products over `hidden`, reduced wave-wide then across waves
         float part[7] = {0, 0, 0, 0, 0, 0, 0};
-        for (int j = tid; j < a.hidden; j += blockDim.x) {
-            const float bj = big[j];
+        if (model_head) {
+            const float bj = big[tid];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) part[o] += bj * a.W_q[(size_t)j * 4 + o];
+            for (int o = 0; o < 4; ++o) part[o] += bj * wq[o];
 #pragma unroll
-            for (int o = 0; o < 3; ++o) part[4 + o] += bj * a.W_t[(size_t)j * 3 + o];
+            for (int o = 0; o < 3; ++o) part[4 + o] += bj * wt[o];
+        } else {
+            for (int j = tid; j < a.hidden; j += blockDim.x) {
+                const float bj = big[j];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) part[o] += bj * a.W_q[(size_t)j * 4 + o];
+#pragma unroll
+                for (int o = 0; o < 3; ++o) part[4 + o] += bj * a.W_t[(size_t)j * 3 + o];
+            }
         }
 #pragma unroll
         for (int o = 0; o < 7; ++o)
