@@ -35,15 +35,21 @@ def pose_rows(q_n4, t_n3, Tr):
     return np.stack(rows) if rows else np.zeros((0, 12))
 
 
-def predict_sequence(net, root, seq, T_diff, H_input=64, W_input=1800, batch_size=1, num_points=150000, frames=None):
+def predict_sequence(net, root, seq, T_diff, H_input=64, W_input=1800, batch_size=1, num_points=150000, frames=None,
+                     lanes=0):
     """Run the network over samples `frames` (default: all scans found) of sequence `seq`; returns (q (n,4), t (n,3))
     = the l0 pose of every sample, in sample order.  Batches are padded by repeating the last sample
-    (main.py:497-509 keeps stale rows instead; either way the padding rows are dropped)."""
+    (main.py:497-509 keeps stale rows instead; either way the padding rows are dropped).
+    `lanes` > 0: through `lanes` hipGraphs recorded from the raw clouds on (`PWCLONet.capture(num_points=...)`: input
+    stage + pyramid in one replay, several batches in flight while the host reads the next scans) instead of the eager
+    `forward_points`; same results (no augmentation in evaluation: the identity T_trans of the eager call is a no-op)."""
     seq_dir = os.path.join(root, seq)
     if frames is None:
         frames = range(len([f for f in os.listdir(os.path.join(seq_dir, "velodyne")) if f.endswith(".bin")]))
     frames = list(frames)
     dev = net.device
+    if lanes > 0:
+        return _predict_sequence_lanes(net, root, seq, T_diff, H_input, W_input, batch_size, num_points, frames, lanes)
     eye = torch.eye(4, dtype=torch.float32, device=dev).repeat(batch_size, 1, 1)      # main.py:308-309: no augmentation
     qs, ts = [], []
     for start in range(0, len(frames), batch_size):
@@ -57,6 +63,33 @@ def predict_sequence(net, root, seq, T_diff, H_input=64, W_input=1800, batch_siz
                                  eye, eye, is_training=False, aug_frame=np.ones(batch_size, np.int64))
         qs.append(out[0][:len(chunk)].reshape(-1, 4).cpu().numpy())
         ts.append(out[1][:len(chunk)].reshape(-1, 3).cpu().numpy())
+    return np.concatenate(qs), np.concatenate(ts)
+
+
+def _predict_sequence_lanes(net, root, seq, T_diff, H_input, W_input, batch_size, num_points, frames, lanes):
+    dev = net.device
+    net.capture(batch_size, H_input, W_input, lanes=lanes, num_points=num_points)
+    chunks = [frames[s:s + batch_size] for s in range(0, len(frames), batch_size)]
+    qs, ts = [None] * len(chunks), [None] * len(chunks)
+    pinned = [torch.empty((batch_size, 2 * num_points, 3), dtype=torch.float32).pin_memory() for _ in range(lanes)]
+
+    def collect(ci):                                         # the lane's stream has finished chunk ci
+        lane = ci % lanes
+        net.lane_stream(lane).synchronize()
+        pose = net.lane_pose(lane)[:len(chunks[ci])].cpu().numpy()        # (b,7) = [q_norm | t] of l0
+        qs[ci], ts[ci] = pose[:, :4].copy(), pose[:, 4:].copy()
+
+    for ci, chunk in enumerate(chunks):
+        lane = ci % lanes
+        if ci >= lanes:
+            collect(ci - lanes)                              # frees the lane (and its pinned staging buffer)
+        cloud = pinned[lane].numpy()
+        for j in range(batch_size):
+            pos2, pos1, _n2, _n1, _T = kitti.load_pair(root, seq, chunk[min(j, len(chunk) - 1)], T_diff, num_points)
+            cloud[j, :num_points], cloud[j, num_points:] = pos2, pos1                      # main.py:316-320
+        net.submit_points(lane, pinned[lane])                # async H2D into the lane's cloud buffer + one replay
+    for ci in range(max(0, len(chunks) - lanes), len(chunks)):
+        collect(ci)
     return np.concatenate(qs), np.concatenate(ts)
 
 

@@ -50,6 +50,10 @@ def test_sequence_pipeline_from_scans_to_errors(tmp_path):
     q2, t2 = ev.predict_sequence(net, str(tmp_path), "04", T_diff, batch_size=2, **kw)
     q1, t1 = ev.predict_sequence(net, str(tmp_path), "04", T_diff, batch_size=1, **kw)
     assert q2.shape == (n, 4) and np.allclose(q1, q2, atol=1e-5) and np.allclose(t1, t2, atol=1e-4)
+    # through graph lanes recorded from the raw clouds on: same poses as the eager forward_points path
+    net2 = model.PWCLONet(DEV, seed=0)
+    q3, t3 = ev.predict_sequence(net2, str(tmp_path), "04", T_diff, batch_size=1, lanes=2, **kw)
+    assert np.array_equal(q3, q1) and np.array_equal(t3, t1)
     # row 0 is sample 0's own prediction (scan 0 paired with itself), rows chain as T_i = T_{i-1} . Tr [R|t] Tr^-1
     dist = load_pkg("distributed")
     Tr = kitti.to_4x4(TR)
