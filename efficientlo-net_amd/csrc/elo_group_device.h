@@ -136,14 +136,76 @@ __device__ __forceinline__ Probe judge(const RawSlot &r, float cx, float cy, flo
     return p;
 }
 
-// Measured at 64x1800 (tools/grouping_micro.py): with K = 6 the register form wins (11x41: 158 vs ~190 us); with
-// K = 32 every round pays 8 register compares + 3 lane broadcasts and the LDS form wins (5x35: 379 vs 439 us).
-__host__ __device__ __forceinline__ bool select_in_registers(int KT, int K) { return KT <= 512 && K <= 8; }
+// The register form keeps the window in J = 2, 3 or 8 registers per lane (position j*64 + lane in register j), so a
+// round costs J compares: K <= 8 with any window up to 512 slots (the refinement cost volumes: 11x41 -> J = 8,
+// 7x25 -> 3, 5x15 -> 2), and K <= 32 when the window fits three registers (the l2 cost volume's 5x35, K = 32).
+// Measured at 64x1800 (tools/grouping_micro.py) with J fixed at 8: K = 6 register form 158 vs ~190 us (11x41); K = 32
+// register form 439 vs 379 us (5x35) -- eight compares per round for a three-register window; hence J by window size.
+__host__ __device__ __forceinline__ bool select_in_registers(int KT, int K)
+{
+    return (KT <= 512 && K <= 8) || (KT <= 192 && K <= 32);
+}
 
-// K nearest in-range neighbours, reference tie order (selection sort with swaps).
-// Windows up to 512 slots with K <= 8 (the three refinement cost volumes) keep the whole (distance, hw) array in REGISTERS --
-// position j*64 + lane lives in register j of that lane -- and run the K rounds with DPP reductions and three
-// lane broadcasts per round; larger windows use the LDS arrays dist/pay ([KT] wave-private each).
+// K rounds of the reference's selection sort on a register-resident window of J*64 slots.
+template <int J, class Grid, class Emit>
+__device__ __forceinline__ int select_rounds_in_registers(const Grid &grid2, int H2, int W2, int KT, int rounds,
+                                                          const int *lds_off, int base_h, int base_w, float cx, float cy,
+                                                          float cz, float r2, Emit emit)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
+    constexpr int BATCH = J < 4 ? J : 4;                   // probes in flight per lane
+    unsigned d[J];
+    int pw[J];
+#pragma unroll
+    for (int b0 = 0; b0 < J; b0 += BATCH) {
+        RawSlot raw[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int i = (b0 + u) * 64 + lane;
+            raw[u] = fetch_slot(grid2, H2, W2, lds_off[i < KT ? i : 0], base_h, base_w, i < KT);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const Probe p = judge(raw[u], cx, cy, cz, r2);
+            d[b0 + u] = p.hit ? __float_as_uint(p.d) : FAR_BITS;        // d > 0: bit order == float order
+            pw[b0 + u] = p.hit ? p.hw : 0;
+        }
+        if (J == 8 && KT <= 256 && b0 == 0) {               // the second batch would be all padding
+#pragma unroll
+            for (int u = BATCH; u < J; ++u) { d[u] = FAR_BITS; pw[u] = 0; }
+            break;
+        }
+    }
+    for (int s = 0; s < rounds; ++s) {
+        unsigned best = 0xffffffffu;
+        int where = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const bool open = j > 0 || lane >= s;            // positions < s are already placed (s < 64)
+            if (open && d[j] < best) { best = d[j]; where = j * 64 + lane; }
+        }
+        const unsigned long long key = wave_min_u64(((unsigned long long)best << 32) | (unsigned)where);
+        if ((unsigned)(key >> 32) >= FAR_BITS) return s;                 // sorted: everything left is empty
+        const int m = (int)(key & 0xffffffffu), mj = m >> 6, ml = m & 63;
+        int sel_pw = pw[0];
+#pragma unroll
+        for (int j = 1; j < J; ++j) sel_pw = mj == j ? pw[j] : sel_pw;
+        const int pm = __shfl(sel_pw, ml, ELO_WAVE);
+        const unsigned ds = (unsigned)__shfl((int)d[0], s, ELO_WAVE);       // element at position s (lane s, register 0)
+        const int ps = __shfl(pw[0], s, ELO_WAVE);
+        if (m != s && lane == ml) {                                      // the reference's swap: s moves to m
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                if (mj == j) { d[j] = ds; pw[j] = ps; }
+        }
+        if (lane == 0) emit(s, pm);
+    }
+    return rounds;
+}
+
+// K nearest in-range neighbours, reference tie order (selection sort with swaps): register form (above) where
+// select_in_registers() says so, otherwise the LDS arrays dist/pay ([KT] wave-private each).
 template <class Grid, class Emit>
 __device__ __forceinline__ int wave_select_k(const Grid &grid2, int H2, int W2, int KT, int K,
                                              const int *lds_off, int base_h, int base_w, float cx, float cy, float cz,
@@ -153,54 +215,11 @@ __device__ __forceinline__ int wave_select_k(const Grid &grid2, int H2, int W2, 
     const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
     const int rounds = K < KT ? K : KT;
     if (select_in_registers(KT, K)) {
-        constexpr int J = 8;
-        unsigned d[J];
-        int pw[J];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {             // two batches of four probes: 4 loads in flight per lane
-            RawSlot raw[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = (half * 4 + u) * 64 + lane;
-                raw[u] = fetch_slot(grid2, H2, W2, lds_off[i < KT ? i : 0], base_h, base_w, i < KT);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const Probe p = judge(raw[u], cx, cy, cz, r2);
-                d[half * 4 + u] = p.hit ? __float_as_uint(p.d) : FAR_BITS;    // d > 0: bit order == float order
-                pw[half * 4 + u] = p.hit ? p.hw : 0;
-            }
-            if (KT <= 256 && half == 0) {                   // the second batch would be all padding
-#pragma unroll
-                for (int u = 4; u < J; ++u) { d[u] = FAR_BITS; pw[u] = 0; }
-                break;
-            }
-        }
-        for (int s = 0; s < rounds; ++s) {
-            unsigned best = 0xffffffffu;
-            int where = 0x7fffffff;
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const bool open = j > 0 || lane >= s;        // positions < s are already placed
-                if (open && d[j] < best) { best = d[j]; where = j * 64 + lane; }
-            }
-            const unsigned long long key = wave_min_u64(((unsigned long long)best << 32) | (unsigned)where);
-            if ((unsigned)(key >> 32) >= FAR_BITS) return s;                 // sorted: everything left is empty
-            const int m = (int)(key & 0xffffffffu), mj = m >> 6, ml = m & 63;
-            int sel_pw = pw[0];
-#pragma unroll
-            for (int j = 1; j < J; ++j) sel_pw = mj == j ? pw[j] : sel_pw;
-            const int pm = __shfl(sel_pw, ml, ELO_WAVE);
-            const unsigned ds = (unsigned)__shfl((int)d[0], s, ELO_WAVE);       // element at position s (lane s, register 0)
-            const int ps = __shfl(pw[0], s, ELO_WAVE);
-            if (m != s && lane == ml) {                                      // the reference's swap: s moves to m
-#pragma unroll
-                for (int j = 0; j < J; ++j)
-                    if (mj == j) { d[j] = ds; pw[j] = ps; }
-            }
-            if (lane == 0) emit(s, pm);
-        }
-        return rounds;
+        if (KT <= 128)
+            return select_rounds_in_registers<2>(grid2, H2, W2, KT, rounds, lds_off, base_h, base_w, cx, cy, cz, r2, emit);
+        if (KT <= 192)
+            return select_rounds_in_registers<3>(grid2, H2, W2, KT, rounds, lds_off, base_h, base_w, cx, cy, cz, r2, emit);
+        return select_rounds_in_registers<8>(grid2, H2, W2, KT, rounds, lds_off, base_h, base_w, cx, cy, cz, r2, emit);
     }
     for (int base = 0; base < KT; base += ELO_WAVE) {
         const int i = base + lane;
