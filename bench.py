@@ -75,7 +75,7 @@ MFMA_PRODUCTS = 3              # fp16 matrix-core products per fp32-class produc
 # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_v3 and r01_pmc_v4/summary.json, collected by
 # tools/pmc_collect.sh: FETCH_SIZE x2 + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); counters cannot
 # be read from inside bench.py.  Only for the exact shapes captured (l0 = 16x225, i.e. 64x1800 inputs); otherwise null.
-PMC_TRAFFIC = {("cv1", 1): 3.61e6, ("cv1", 8): 13.59e6, ("A1", 8): 36.98e6, ("P1", 8): 96.68e6, ("A2", 8): 52.56e6,
+PMC_TRAFFIC = {("cv1", 1): 3.65e6, ("cv1", 8): 13.64e6, ("A1", 8): 36.98e6, ("P1", 8): 96.68e6, ("A2", 8): 52.56e6,
                ("P2", 8): 66.88e6, ("A1", 64): 298.34e6, ("P1", 64): 772.78e6, ("A2", 64): 420.23e6, ("P2", 64): 534.60e6,
                ("A1", 64, "f16"): 168.88e6, ("P1", 64, "f16"): 389.00e6, ("A2", 64, "f16"): 218.92e6,
                ("P2", 64, "f16"): 269.17e6}
