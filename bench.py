@@ -11,35 +11,49 @@ A "step" is one forward pass over one batch of pairs already resident in HBM
 (a pool of pre-generated pairs; each step copies the next pair into the captured
 graph's input buffers, device-to-device, inside the timed region).
 
-One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE); frame pairs are
-independent, so ranks shard the stream with no data-path collective; every step's pose is
-logged on the device and the logs are all-gathered (7 floats per pair) once, inside the timed
-region, so rank 0 can chain them (main.py:557-572): the only exchange the path has.  scaling = weak.
+One process per GPU.  Under torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this process is one rank;
+started plainly with --gpus N > 1 it re-launches itself as N ranks (torch.distributed.run, 127.0.0.1 rendezvous) and
+relays rank 0's line.  Frame pairs are independent, so ranks shard the stream with no data-path collective; every
+step's pose is logged on the device and the logs are all-gathered (7 floats per pair) once per timed repeat, inside
+the timed region, so rank 0 can chain them (main.py:557-572): the only exchange inference has.  scaling = weak.
+
+Timing: W untimed warm-up steps (at least 2 per lane), then repeats of EXACTLY K steps, each bracketed by a barrier +
+torch.cuda.synchronize() on both sides and reduced with MAX over ranks; repeats continue until 0.25 s have been
+measured (a 20-step run at batch 1 is 2.5 ms of signal otherwise) and `ms_per_step` / `value` come from the MEDIAN
+repeat (`repeats`, `ms_per_step_repeats` show them all).
 
 Throughput design: the whole forward is one hipGraph; `--lanes` graphs (default 8), each with its own static
 buffers, dealt over one stream per hardware queue (model.distinct_queue_streams), keep independent forwards
 in flight (step i rides lane i % lanes).
 
-Besides the contract line this prints, on rank 0 at N=1:
-  roofline     -- the dominant cost-volume kernel (fused stage 1 at l0) timed live with HIP events
-  cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on a bounded sample
+Besides the contract keys the line carries (rank 0):
+  roofline     -- SURVEY.md section 8(d): the dominant kernel of the timed path (fused cost-volume stage 1 at l0) timed
+                  live with HIP events, its algorithmic bytes against the 8 TB/s HBM roofline and its executed
+                  matrix-core flops against the peak of the dtype it issues; plus `cost_volume_*`: ALL cost-volume
+                  kernels of a forward (four levels) at batch 8, fp32 and fp16 feature storage (configs[2])
+  cpu_baseline -- the CPU oracle (oracle/, kind "port") on one core and on all host cores
+  batch8, from_raw_clouds, dense_f32, train_dp -- see the functions below
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+F16_MFMA_PEAK_TFLOPS = 2500.0  # ibid.: BF16/FP16 MFMA ~2.5 PFLOP/s dense -- the dtype the split products are ISSUED in
+F32_MFMA_PEAK_TFLOPS = 157.3   # ibid.: v_mfma_f32_16x16x4_f32 dense peak -- only for the -DELO_DENSE_F32 comparison build
+MFMA_PRODUCTS = 3              # fp16 matrix-core products per fp32-class product: hi*hi + hi*lo + lo*hi (elo_fused.hip)
+MIN_TIMED_S = 0.25
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc", "summary.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 
 
 def pkg(sub=None):
@@ -59,28 +73,41 @@ def parse():
                     help="independent forwards in flight (hipGraphs, dealt over the 4 hardware queues: use a multiple of 4)")
     ap.add_argument("--products", choices=("split", "half"), default="split",
                     help="dense products of the fused kernels: split = fp32-class (three fp16 MFMA products, the headline); "
-                         "half = ONE fp16 product (fp16 arithmetic, BASELINE configs[2]; not the fp32 parity path)")
+                         "half = ONE fp16 product (fp16 arithmetic; not the fp32 parity path)")
+    ap.add_argument("--features", choices=("f32", "f16"), default="f32",
+                    help="storage of the feature tensors in HBM (f16: BASELINE configs[2]); arithmetic is unchanged")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true",
-                    help="only the timed loop: no roofline / cpu_baseline / from_raw_clouds / batch8 legs (profiling runs)")
-    ap.add_argument("--cpu-pairs", type=int, default=60, help="pairs in the CPU-oracle sample")
+                    help="only the timed loop: no roofline / cpu_baseline / from_raw_clouds / batch8 / dense_f32 / train_dp legs")
+    ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs in the one-core CPU sample (all cores: 3 per core)")
+    ap.add_argument("--train-steps", type=int, default=8, help="timed steps of the train_dp leg (0: skip)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the multi-process path WITHOUT a GPU: ranks, barriers, the pose all-gather and the line, "
+                         "with an empty step (value is null, data says so)")
     return ap.parse_args()
 
 
-# ----------------------------------------------------------------------------- roofline leg
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak (= the fp32 vector peak)
-F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (2495 TF measured)
-MFMA_PRODUCTS = 3              # fp16 matrix-core products per fp32-class product: hi*hi + hi*lo + lo*hi (elo_fused.hip)
-# HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_v3 and r01_pmc_v4/summary.json, collected by
-# tools/pmc_collect.sh: FETCH_SIZE x2 + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); counters cannot
-# be read from inside bench.py.  Only for the exact shapes captured (l0 = 16x225, i.e. 64x1800 inputs); otherwise null.
-PMC_TRAFFIC = {("cv1", 1): 3.65e6, ("cv1", 8): 13.64e6, ("A1", 8): 36.98e6, ("P1", 8): 96.68e6, ("A2", 8): 52.56e6,
-               ("P2", 8): 66.88e6, ("A1", 64): 298.34e6, ("P1", 64): 772.78e6, ("A2", 64): 420.23e6, ("P2", 64): 534.60e6,
-               ("A1", 64, "f16"): 168.88e6, ("P1", 64, "f16"): 389.00e6, ("A2", 64, "f16"): 218.92e6,
-               ("P2", 64, "f16"): 269.17e6}
+# ----------------------------------------------------------------------------- self-launch of N ranks
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a torchrun environment: become N ranks on this node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this driver
+    print("[bench] launching %d ranks: %s" % (n, " ".join(cmd[1:])), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------- SURVEY 8(d) byte / flop counts
 def cost_volume_bytes(N, C, Kq, Kp, s=4):
     """algorithmic (operator-boundary) bytes of the cost volume per batch element."""
     A1 = 2 * N * 12 + 2 * N * C * s + N * Kq * 16 + N * Kq * (10 + 2 * C) * s
@@ -96,10 +123,16 @@ def cv1_flops(N, C, Kq):
     return 2 * N * Kq * per_row
 
 
+def cv2_flops(N, C, Kp):
+    """... of the three convolutions of stage 2 (pointnet_util.py:123-135)."""
+    return 2 * N * Kp * (10 * 64 + (128 + C) * 128 + 128 * 64)
+
+
 def _time_launches(fn, dev, reps):
     """Average duration of one launch of `fn`: `reps` back-to-back launches captured in a hipGraph (so the host's
     per-call cost, ~12 us from Python, is not in the number), replayed between two HIP events on torch's current
     stream == the stream _lib.stream_ptr() hands to the C ABI."""
+    import torch
     for _ in range(3):
         fn()
     torch.cuda.synchronize(dev)
@@ -119,152 +152,185 @@ def _time_launches(fn, dev, reps):
     return sec
 
 
-def roofline_leg(args, dev, net, reps=50):
-    """The dominant cost-volume kernel of the timed path, timed live with HIP events on the stream it is launched
-    on: the fused stage-1 kernel at l0 (select-k grouping + encode + six 1x1 convs on the matrix cores + masked
-    softmax pooling in one launch).  It never materialises the operator-boundary tensors, so it is on the MFMA
-    roofline, not the HBM one.  Its products are fp32-class but run on the FP16 matrix cores (each operand split
-    into fp16 hi + lo, three v_mfma_f32_16x16x16_f16 per 16-k block, fp32 accumulation).  `achieved` is the
-    ALGORITHMIC fp32 flops of the launch (2 x MACs of the six convolutions) over its duration, `peak` the dense MFMA
-    peak of the dtype the path computes in (fp32: 157.3 TFLOP/s -- what the native fp32 MFMA could deliver at best);
-    `executed_mfma_TFLOPs` / `frac_of_fp16_mfma_peak` count the three fp16 products actually issued against the
-    2.5 PFLOP/s fp16 peak -- small by construction: with the matrix work this cheap the kernel is bound by vector
-    instruction issue and latency.  `hbm_equivalent_GBps` is SURVEY 8(d)'s algorithmic bytes (A1+P1) over the
-    same duration for comparison with the per-operator kernels (`per_operator`: the four HBM-bound kernels of the
-    ELO_FUSED=0 cost volume, each against its own algorithmic bytes)."""
-    ops, fused, tf_util, perm, pm = pkg("_ops"), pkg("fused"), pkg("tf_util"), pkg("perm"), pkg("pwclo_model")
-    oh, ow = pm.pyramid_sizes(args.height, args.width)
-    B, H, W, C, Kq = args.batch, oh[2], ow[2], 16, 6
+def _pmc_traffic(kernel, batch, features="f32"):
+    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r02_pmc/summary.json, collected by
+    tools/pmc_collect.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, FETCH_SIZE x2 per the gfx950
+    note of MI355X_MICROARCH.md).  Counters cannot be read from inside this process: null when the shape was not captured."""
+    try:
+        table = json.load(open(PMC_SUMMARY))
+    except (OSError, ValueError):
+        return None
+    hit = table.get("%s/b%d/%s" % (kernel, batch, features))
+    return None if hit is None else hit.get("traffic_bytes")
+
+
+class CostVolumeLevel:
+    """The two fused cost-volume launches of one pyramid level (pwclo_model.py:170, :242, :316, :390) on synthetic inputs
+    of that level's shape: run1() = stage 1 (select-k + encode + six convolutions + softmax pooling), run2() = stage 2."""
+    SHAPES = {"l0": (2, 16, 6, (11, 41)), "l1": (3, 32, 6, (7, 25)), "l2": (4, 64, 6, (5, 15)), "l2_origin": (4, 64, 32, (5, 35))}
+
+    def __init__(self, level, B, H_in, W_in, dev, net, half):
+        import torch
+        fused, tf_util, pm, synth = pkg("fused"), pkg("tf_util"), pkg("pwclo_model"), pkg("synth")
+        oh, ow = pm.pyramid_sizes(H_in, W_in)
+        gi, C, Kq, win = self.SHAPES[level]
+        H, W = oh[gi], ow[gi]
+        self.level, self.B, self.N, self.C, self.Kq, self.Kp = level, B, H * W, C, Kq, 4
+        g = torch.Generator(device="cpu").manual_seed(11)
+        f1, f2 = synth.frame_pair(B, H, W, seed=5)
+        x1, x2 = torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev)
+        cast = (lambda t: t.half()) if half else (lambda t: t)
+        ft1, ft2 = (cast(torch.randn((B, H, W, C), generator=g).to(dev)) for _ in range(2))
+        cost = cast(torch.randn((B, H, W, 64), generator=g).to(dev))
+        oq = torch.randperm(win[0] * win[1], generator=g).to(torch.int32).to(dev)
+        op = torch.randperm(15, generator=g).to(torch.int32).to(dev)
+        scope = "flow_embedding_" + level
+        with tf_util.default_store(net.store), torch.no_grad(), tf_util.variable_scope(scope):
+            P = fused.packed_layer
+            l1 = (P('CV_0', 10 + 2 * C, 128, row_order=fused.cv0_row_order(C)), P('CV_1', 128, 64), P('CV_2', 64, 64),
+                  P('CV_xyz', 10, 64), P('sum_CV_0', 128, 128, row_order=list(range(64, 128)) + list(range(64))),
+                  P('sum_CV_1', 128, 64))
+            order = list(range(64 + C, 128 + C)) + list(range(64)) + list(range(64, 64 + C))
+            l2 = (P('sum_xyz_encoding', 10, 64), P('sum_cost_volume_0', 128 + C, 128, row_order=order),
+                  P('sum_cost_volume_1', 128, 64))
+        g1, g2 = fused.Grouping(oq, win, 1000), fused.Grouping(op, [3, 5], {"l0": 1.0, "l1": 2.0}.get(level, 4.0))
+        N = self.N
+        self.run1 = lambda: fused.cv_stage1(x1.reshape(B, N, 3), ft1.reshape(B, N, C), x2, ft2, None, None, *l1, group=g1, K=Kq)
+        self.run2 = lambda: fused.cv_stage2(x1, ft1, cost, None, None, *l2, group=g2, K=4)
+
+    def bytes(self, s):
+        return cost_volume_bytes(self.N, self.C, self.Kq, self.Kp, s)
+
+
+def cost_volume_leg(dev, net, B, H_in, W_in, half, reps=20):
+    """SURVEY 8(d)'s cost-volume figure ON THE PATH THE VALUE RUNS: the eight fused launches (stage 1 + stage 2 at l0,
+    l1, l2, l2_origin) of one forward at batch B, each timed with HIP events; achieved = the operator-boundary bytes
+    (A1+P1 / A2+P2, s = 4 or 2) of all of them x B / the sum of the kernel times, against 8 TB/s.  The fused kernels
+    never materialise those tensors (their HBM traffic is the compulsory bytes only, `traffic`), so this is the
+    section-8(d) accounting figure, not a bandwidth they could reach: what bounds them is the matrix + vector work,
+    `mfma` (executed fp16 products against the 2.5 PFLOP/s fp16 peak)."""
+    s = 2 if half else 4
+    levels, tot_b, tot_s, tot_f = {}, 0, 0.0, 0
+    for lv in CostVolumeLevel.SHAPES:
+        L = CostVolumeLevel(lv, B, H_in, W_in, dev, net, half)
+        t1, t2 = _time_launches(L.run1, dev, reps), _time_launches(L.run2, dev, reps)
+        cb = L.bytes(s)
+        b1, b2 = (cb["A1"] + cb["P1"]) * B, (cb["A2"] + cb["P2"]) * B
+        fl = (cv1_flops(L.N, L.C, L.Kq) + cv2_flops(L.N, L.C, L.Kp)) * B
+        levels[lv] = {"cv1_us": round(t1 * 1e6, 2), "cv2_us": round(t2 * 1e6, 2), "bytes": int(b1 + b2),
+                      "GBps": round((b1 + b2) / (t1 + t2) / 1e9, 1), "frac": round((b1 + b2) / (t1 + t2) / 1e9 / HBM_PEAK_GBS, 4)}
+        tot_b, tot_s, tot_f = tot_b + b1 + b2, tot_s + t1 + t2, tot_f + fl
+    gbs = tot_b / tot_s / 1e9
+    tfs = MFMA_PRODUCTS * tot_f / tot_s / 1e12
+    return {"kernel": "cv1_kernel + cv2_kernel at l0, l1, l2, l2_origin (the 8 cost-volume launches of a forward)",
+            "batch": B, "features": "f16" if half else "f32", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b), "us": round(tot_s * 1e6, 2),
+            "target_us_at_60pct": round(tot_b / (0.6 * HBM_PEAK_GBS * 1e9) * 1e6, 1),
+            "mfma": {"executed_TFLOPs": round(tfs, 1), "peak": F16_MFMA_PEAK_TFLOPS,
+                     "frac": round(tfs / F16_MFMA_PEAK_TFLOPS, 5), "issued_as": "v_mfma_f32_16x16x16_f16 x3 per 16-k block"},
+            "levels": levels}
+
+
+def per_operator_leg(dev, batch, half, reps=20):
+    """The four HBM-bound kernels of the ELO_FUSED=0 cost volume at l0 (SURVEY 8(d) terms A1, P1, A2, P2: gather/encode
+    and masked softmax pooling with the GEMMs between them left to hipBLASLt), each against its own algorithmic bytes."""
+    import torch
+    ops, synth, elo = pkg("_ops"), pkg("synth"), pkg()
+    H, W, C, Kq, Kp, win = 16, 225, 16, 6, 4, (11, 41)
     N = H * W
-    if (args.height, args.width) != (64, 1800):
-        PMC_TRAFFIC.clear()
-    g = torch.Generator(device="cpu").manual_seed(0)
-    synth = pkg("synth")
-    f1, f2 = synth.frame_pair(B, H, W, seed=5)
-    xyz1, xyz2 = torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev)
-    feat1 = torch.randn((B, H, W, C), generator=g).to(dev)
-    feat2 = torch.randn((B, H, W, C), generator=g).to(dev)
-    order = torch.randperm(11 * 41, generator=g).to(torch.int32).to(dev)
-    with tf_util.default_store(net.store), torch.no_grad(), tf_util.variable_scope('flow_embedding_l0'):
-        P = fused.packed_layer
-        layers = (P('CV_0', 10 + 2 * C, 128), P('CV_1', 128, 64), P('CV_2', 64, 64), P('CV_xyz', 10, 64),
-                  P('sum_CV_0', 128, 128, row_order=list(range(64, 128)) + list(range(64))), P('sum_CV_1', 128, 64))
-    grouping = fused.Grouping(order, [11, 41], 1000)
-    run = lambda: fused.cv_stage1(xyz1.reshape(B, N, 3), feat1.reshape(B, N, C), xyz2, feat2, None, None, *layers,
-                                  group=grouping, K=Kq)
-    sec = _time_launches(run, dev, reps)
-    flops = cv1_flops(N, C, Kq) * B
-    cvb = cost_volume_bytes(N, C, Kq, 4)
-    tfs = flops / sec / 1e12
-    LEVELS = {"l0": (oh[2], ow[2], 16, 6, (11, 41)), "l1": (oh[3], ow[3], 32, 6, (7, 25)),
-              "l2": (oh[4], ow[4], 64, 6, (5, 15)), "l2_origin": (oh[4], ow[4], 64, 32, (5, 35))}      # pwclo_model.py cost_volume calls
+    g = torch.Generator(device="cpu").manual_seed(3)
+    cvb = cost_volume_bytes(N, C, Kq, Kp, 2 if half else 4)
+    cast = (lambda x: x.half()) if half else (lambda x: x)
+    fb1, fb2 = synth.frame_pair(batch, H, W, seed=6)
+    x1, x2 = torch.from_numpy(fb1).to(dev), torch.from_numpy(fb2).to(dev)
+    ft1, ft2 = (cast(torch.randn((batch, H, W, C), generator=g).to(dev)) for _ in range(2))
+    hw = torch.from_numpy(synth.hw_index(batch, H, W)).to(dev)
+    order = torch.randperm(win[0] * win[1], generator=g).to(torch.int32).to(dev)
+    idx_q, _, _, m_q = elo.fused_conv_select_k(x1, x2, hw, order, H, W, N, win[0], win[1], Kq, 0, 1000.0, 1, 1, want_valid=False)
+    order_p = torch.randperm(15, generator=g).to(torch.int32).to(dev)
+    idx_p, _, _, m_p = elo.fused_conv_random_k(x1, x1, hw, order_p, H, W, N, 3, 5, Kp, 0, 1000.0, 1, 1, want_valid=False)
+    m_q, m_p = m_q.reshape(batch, N, Kq), m_p.reshape(batch, N, Kp)
+    cost = cast(torch.randn((batch, H, W, 64), generator=g).to(dev))
+    lq, vq = (cast(torch.randn((batch, N, Kq, 64), generator=g).to(dev)) for _ in range(2))
+    lp, vp = (cast(torch.randn((batch, N, Kp, 64), generator=g).to(dev)) for _ in range(2))
+    legs = {"A1": lambda: ops.cv_encode1(x1.reshape(batch, N, 3), ft1.reshape(batch, N, C), x2, ft2, idx_q, m_q),
+            "P1": lambda: ops.masked_softmax_pool(lq, vq, m_q),
+            "A2": lambda: ops.cv_encode2(x1, ft1, cost, idx_p, m_p),
+            "P2": lambda: ops.masked_softmax_pool(lp, vp, m_p)}
+    terms, tot_b, tot_s = {}, 0, 0.0
+    for term, fn in legs.items():
+        sec = _time_launches(fn, dev, reps)
+        nbytes = cvb[term] * batch
+        terms[term] = {"bytes": int(nbytes), "us": round(sec * 1e6, 2), "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4)}
+        tot_b, tot_s = tot_b + nbytes, tot_s + sec
+    gbs = tot_b / tot_s / 1e9
+    return {"kernel": "ELO_FUSED=0 cost volume at l0: cv_encode1 + softmax_pool + cv_encode2 + softmax_pool", "batch": batch,
+            "features": "f16" if half else "f32", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b), "us": round(tot_s * 1e6, 2), "terms": terms}
 
-    def per_operator_leg(batch, half=False, level="l0"):
-        """The four cost-volume kernels of the ELO_FUSED=0 path at one level (SURVEY 8(d) terms A1, P1, A2, P2), each
-        against its own algorithmic bytes, and the four together.  `half`: fp16 feature storage (s = 2; BASELINE
-        configs[2]), fp32 arithmetic."""
-        H, W, C, Kq, win = LEVELS[level]
-        N = H * W
-        order = torch.randperm(win[0] * win[1], generator=g).to(torch.int32).to(dev)
-        cvb = cost_volume_bytes(N, C, Kq, 4, 2 if half else 4)
-        cast = (lambda x: x.half()) if half else (lambda x: x)
-        elo = pkg()
-        Kp = 4
-        fb1, fb2 = synth.frame_pair(batch, H, W, seed=6)
-        x1, x2 = torch.from_numpy(fb1).to(dev), torch.from_numpy(fb2).to(dev)
-        ft1 = cast(torch.randn((batch, H, W, C), generator=g).to(dev))
-        ft2 = cast(torch.randn((batch, H, W, C), generator=g).to(dev))
-        hw = torch.from_numpy(synth.hw_index(batch, H, W)).to(dev)
-        idx_q, _, _, m_q = elo.fused_conv_select_k(x1, x2, hw, order, H, W, N, win[0], win[1], Kq, 0, 1000.0, 1, 1,
-                                                  want_valid=False)
-        order_p = torch.randperm(3 * 5, generator=g).to(torch.int32).to(dev)
-        idx_p, _, _, m_p = elo.fused_conv_random_k(x1, x1, hw, order_p, H, W, N, 3, 5, Kp, 0, 1000.0, 1, 1,
-                                                  want_valid=False)
-        m_q, m_p = m_q.reshape(batch, N, Kq), m_p.reshape(batch, N, Kp)
-        cost = cast(torch.randn((batch, H, W, 64), generator=g).to(dev))
-        lq, vq = (cast(torch.randn((batch, N, Kq, 64), generator=g).to(dev)) for _ in range(2))
-        lp, vp = (cast(torch.randn((batch, N, Kp, 64), generator=g).to(dev)) for _ in range(2))
-        legs = {"A1": ("cv_encode1_col_kernel" if C == 16 else "cv_encode1_vec_kernel", lambda: ops.cv_encode1(x1.reshape(batch, N, 3), ft1.reshape(batch, N, C),
-                                                                        x2, ft2, idx_q, m_q)),
-                "P1": ("softmax_pool_vec_kernel", lambda: ops.masked_softmax_pool(lq, vq, m_q)),
-                "A2": ("cv_encode2_vec_kernel", lambda: ops.cv_encode2(x1, ft1, cost, idx_p, m_p)),
-                "P2": ("softmax_pool_vec_kernel", lambda: ops.masked_softmax_pool(lp, vp, m_p))}
-        terms, tot_b, tot_s = {}, 0, 0.0
-        for term, (name, fn) in legs.items():
-            s = _time_launches(fn, dev, 20)
-            nbytes = cvb[term] * batch
-            terms[term] = {"kernel": name, "bytes": int(nbytes), "us": round(s * 1e6, 3),
-                           "GBps": round(nbytes / s / 1e9, 1), "frac": round(nbytes / s / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic": PMC_TRAFFIC.get((term, batch, "f16") if half else (term, batch)) if level == "l0" else None}
-            tot_b, tot_s = tot_b + nbytes, tot_s + s
-        gbs = tot_b / tot_s / 1e9
-        return {"kernel": "cost volume at %s, ELO_FUSED=0 path: encode1 + pool + encode2 + pool (A1+P1+A2+P2)" % level +
-                          (", fp16 feature storage" if half else ""),
-                "batch": batch, "dtype": "f16 storage, f32 arithmetic" if half else "f32", "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes_per_launch": int(tot_b), "us_per_launch": round(tot_s * 1e6, 3),
-                "terms": terms}
 
-    def all_levels_leg(batch, half=False):
-        """SURVEY 8(d)'s "cost-volume kernel bytes per pair": the four cost_volume calls of a forward (l0, l1, l2,
-        l2_origin), 16 launches, bytes x batch / the sum of the kernel times."""
-        per = {lv: per_operator_leg(batch, half, lv) for lv in LEVELS}
-        tot_b = sum(v["bytes_per_launch"] for v in per.values())
-        tot_us = sum(v["us_per_launch"] for v in per.values())
-        gbs = tot_b / tot_us / 1e3
-        return {"kernel": "all four cost_volume calls of a forward, ELO_FUSED=0 path (16 launches)", "batch": batch,
-                "dtype": "f16 storage, f32 arithmetic" if half else "f32", "bound": "hbm", "achieved": round(gbs, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b),
-                "us": round(tot_us, 3),
-                "levels": {lv: {"bytes": v["bytes_per_launch"], "us": v["us_per_launch"], "frac": v["frac"]} for lv, v in per.items()}}
-
-    return {"bound": "mfma", "kernel": "cv1_kernel (fused cost volume stage 1, l0: %dx%d, K=%d, batch %d)" % (H, W, Kq, B),
-            "achieved": round(tfs, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tfs / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": PMC_TRAFFIC.get(("cv1", B)),
-            "mfma": "v_mfma_f32_16x16x16_f16 x3 per 16-k block (fp16 hi+lo split operands, fp32 accumulate)",
-            "executed_mfma_TFLOPs": round(MFMA_PRODUCTS * tfs, 3), "fp16_mfma_peak": F16_MFMA_PEAK_TFLOPS,
-            "frac_of_fp16_mfma_peak": round(MFMA_PRODUCTS * tfs / F16_MFMA_PEAK_TFLOPS, 5),
-            "flops_per_launch": int(flops), "executed_mfma_flops_per_launch": int(MFMA_PRODUCTS * flops),
-            "us_per_launch": round(sec * 1e6, 3),
-            "algorithmic_bytes_per_launch": int((cvb["A1"] + cvb["P1"]) * B),
-            "hbm_equivalent_GBps": round((cvb["A1"] + cvb["P1"]) * B / sec / 1e9, 2),
-            "per_operator": per_operator_leg(B), "per_operator_b8": per_operator_leg(8), "per_operator_b64": per_operator_leg(64),
-            "per_operator_b8_f16": per_operator_leg(8, half=True), "per_operator_b64_f16": per_operator_leg(64, half=True),
-            "per_operator_all_levels_b8": all_levels_leg(8), "per_operator_all_levels_b8_f16": all_levels_leg(8, half=True),
-            "per_operator_all_levels_b64": all_levels_leg(64)}
+def roofline_leg(args, dev, net, reps=50):
+    """Primary object: the dominant kernel of the timed path -- the fused cost-volume stage 1 at l0 (`cv1_kernel`: in-kernel
+    select-k grouping + gather/encode + six 1x1 convolutions + masked softmax pooling) at the timed batch -- with
+    SURVEY 8(d)'s accounting: achieved = its algorithmic bytes (A1 + P1) per launch / its average launch duration
+    (HIP events on the launch stream), peak 8 TB/s.  `traffic` is its measured HBM traffic per launch from the committed
+    counter passes (`traffic_source`).  The kernel does not move the algorithmic bytes (it keeps the (N,K,10+2C) /
+    (N,K,64) tensors in LDS): `mfma` gives the executed matrix-core rate against the peak of the dtype issued (fp16,
+    2.5 PFLOP/s)."""
+    B = args.batch
+    half = args.features == "f16"
+    L = CostVolumeLevel("l0", B, args.height, args.width, dev, net, half)
+    sec = _time_launches(L.run1, dev, reps)
+    cb = L.bytes(2 if half else 4)
+    nbytes = (cb["A1"] + cb["P1"]) * B
+    flops = cv1_flops(L.N, L.C, L.Kq) * B
+    gbs = nbytes / sec / 1e9
+    ex = MFMA_PRODUCTS if args.products == "split" else 1
+    out = {"bound": "hbm", "kernel": "cv1_kernel (fused cost-volume stage 1 at l0: %d points, K=%d, batch %d, %s features)"
+                                     % (L.N, L.Kq, B, args.features),
+           "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+           "traffic": _pmc_traffic("cv1_kernel", B, args.features),
+           "traffic_source": os.path.relpath(PMC_SUMMARY, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                             "not measured in this run)",
+           "us_per_launch": round(sec * 1e6, 3), "algorithmic_bytes_per_launch": int(nbytes),
+           "mfma": {"executed_TFLOPs": round(ex * flops / sec / 1e12, 2), "algorithmic_TFLOPs": round(flops / sec / 1e12, 2),
+                    "peak": F16_MFMA_PEAK_TFLOPS, "frac": round(ex * flops / sec / 1e12 / F16_MFMA_PEAK_TFLOPS, 5),
+                    "issued_as": "v_mfma_f32_16x16x16_f16 x%d per 16-k block (%s)" % (
+                        ex, "fp16 hi+lo split operands, fp32 accumulate" if ex == 3 else "fp16-rounded operands")}}
+    if (args.height, args.width) == (64, 1800):
+        out["cost_volume_b8_f32"] = cost_volume_leg(dev, net, 8, args.height, args.width, False)
+        out["cost_volume_b8_f16"] = cost_volume_leg(dev, net, 8, args.height, args.width, True)
+        out["per_operator_b8_f32"] = per_operator_leg(dev, 8, False)
+        out["per_operator_b8_f16"] = per_operator_leg(dev, 8, True)
+        out["per_operator_b64_f32"] = per_operator_leg(dev, 64, False)
+        out["per_operator_b64_f16"] = per_operator_leg(dev, 64, True)
+    return out
 
 
 # ----------------------------------------------------------------------------- CPU baseline leg
-def cpu_baseline_leg(args, net, pairs):
-    """The numpy/C restatement of the SAME forward (oracle/, kind 'port'), one core, on `pairs` pairs."""
-    from threadpoolctl import threadpool_limits
-
-    from oracle import ops_np as O
+def cpu_baseline_leg(args, net):
+    """The numpy/C restatement of the SAME forward (oracle/, kind 'port') on the host: one core, and all cores
+    (one single-threaded worker process per core, whole pairs each -- oracle/cpu_bench.py)."""
+    from oracle import cpu_bench
     synth = pkg("synth")
     params = {k: v.detach().cpu().numpy() for k, v in net.store.state_dict().items()}
-    rng_perm = {}
-
-    def shuffle(scope, tag, KT):
-        key = (scope, tag, KT)
-        if key not in rng_perm:
-            rng_perm[key] = np.random.default_rng(len(rng_perm)).permutation(KT).astype(np.int32)
-        return rng_perm[key]
-
     f1, f2 = synth.frame_pair(1, args.height, args.width, seed=900)
-    with threadpool_limits(limits=1):
-        t0 = time.perf_counter()
-        for _ in range(pairs):
-            O.get_model_from_projection(params, shuffle, f1, f2)
-        sec = time.perf_counter() - t0
-    return {"value": round(pairs / sec, 4), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-            "sample": "%d x one %dx%d pair through oracle/ops_np.get_model_from_projection (numpy fp32 + C "
-                      "grouping oracle), single thread, %.1f s" % (pairs, args.height, args.width, sec)}
+    cores = os.cpu_count() or 1
+    per_worker = 3
+    r = cpu_bench.run(params, f1, f2, args.cpu_pairs, per_worker, cores)
+    return {"value": round(r["all_cores"], 3), "unit": "frame-pairs/s", "cores": cores, "cores_available": cores, "kind": "port",
+            "one_core": round(r["one_core"], 4),
+            "sample": "oracle/ops_np.get_model_from_projection (numpy fp32 + C grouping oracle) on one %dx%d pair: "
+                      "one core %d pairs in %.1f s; all cores = %d single-threaded worker processes x %d pairs in %.1f s"
+                      % (args.height, args.width, args.cpu_pairs, r["seconds"][0], cores, per_worker, r["seconds"][1])}
 
 
-def batch_rate(dev, B, H, W, lanes, products, steps=240):
+def batch_rate(dev, B, H, W, lanes, products, features, steps=240):
     """frame-pairs/s of a fresh net at batch B through `lanes` captured graphs, inputs resident in HBM."""
+    import torch
     model, synth, fused = pkg("model"), pkg("synth"), pkg("fused")
     with fused.products(products):
-        net = model.PWCLONet(dev, seed=0)
+        net = model.PWCLONet(dev, seed=0, feature_dtype=torch.float16 if features == "f16" else torch.float32)
         pairs = []
         for i in range(4):
             f1, f2 = synth.frame_pair(B, H, W, seed=77 + i)
@@ -284,6 +350,8 @@ def raw_cloud_rate(dev, B, H, W, lanes, points=150000, steps=400):
     """frame-pairs/s when a step starts from RAW clouds: 2 x `points` KITTI-shaped points per pair
     (5 % zero padding, ranges to 60 m so the 35 m crop bites) -> elo_input_stage -> the pyramid, all inside the lane's
     graph; clouds resident in HBM."""
+    import numpy as np
+    import torch
     model = pkg("model")
     net = model.PWCLONet(dev, seed=0)
     rng = np.random.default_rng(3)
@@ -306,106 +374,209 @@ def raw_cloud_rate(dev, B, H, W, lanes, points=150000, steps=400):
     return round(B * steps / (time.perf_counter() - t0), 1)
 
 
+def dense_f32_leg(args):
+    """The same timed loop on the comparison build (libelo_hip_f32.so, -DELO_DENSE_F32: every 1x1 convolution on
+    v_mfma_f32_16x16x4_f32, true fp32 products) in a child process: what the fp16 hi/lo split buys."""
+    env = dict(os.environ, ELO_DENSE_F32="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-legs", "--steps", str(max(args.steps, 200)), "--warmup",
+           str(args.warmup), "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width),
+           "--lanes", str(args.lanes)]
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                "mfma": "v_mfma_f32_16x16x4_f32 (peak %.1f TFLOP/s)" % F32_MFMA_PEAK_TFLOPS}
+    except Exception as e:                                  # the comparison build is optional: say why it is missing
+        return {"value": None, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
+def train_dp_leg(args, dev, rank, world, dist):
+    """BASELINE configs[3]'s exchange under a clock: per-GPU batch 8, one optimisation step = zero grads -> forward
+    (batch-statistics BN, dropout) -> get_loss -> backward -> ONE all-reduce of the flat 899 134-float gradient bucket
+    (RCCL over xGMI when world > 1) -> Adam (main.py:344-397 + SURVEY 8(e)), captured as hipGraphs around the eager
+    collective (training.Trainer.step_graph).  All ranks run it; barrier + synchronize on both sides, MAX over ranks."""
+    import torch
+    model, training, synth, mu = pkg("model"), pkg("training"), pkg("synth"), pkg("model_util")
+    B, H, W = 8, args.height, args.width
+    net = model.PWCLONet(dev, seed=0)
+    tr = training.Trainer(net, capturable=True)
+    f1, f2 = synth.frame_pair(B, H, W, seed=500 + rank)
+    a, b = torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev)
+    T = torch.eye(4, device=dev).repeat(B, 1, 1)
+    T[:, 0, 3] = 0.8
+    q_gt, t_gt = mu.preprocess_gt(T, T, T, [0] * B)
+    tr.capture(a, b, q_gt, t_gt)
+    for _ in range(2):
+        tr.step_graph(a, b, q_gt, t_gt)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        loss = tr.step_graph(a, b, q_gt, t_gt)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    assert torch.isfinite(loss).all()
+    return {"value": round(world * B * args.train_steps / el, 2), "unit": "frame-pairs/s (training)", "n_gpus": world,
+            "batch_per_gpu": B, "steps": args.train_steps, "ms_per_step": round(el / args.train_steps * 1e3, 3),
+            "collective": "one all_reduce(SUM) of the flat gradient bucket per step, %d floats = %.2f MB, backend %s"
+                          % (tr.bucket.flat.numel(), tr.bucket.flat.numel() * 4 / 1e6,
+                             dist.get_backend() if world > 1 else "none (1 rank)")}
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
-    local %= torch.cuda.device_count()               # (only differs when a test runs several ranks on one GPU)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        print("[bench] --gpus %d but the launcher started %d ranks: reporting n_gpus = %d" % (args.gpus, world, world),
+              file=sys.stderr, flush=True)
+    dry = args.dry_run
+    if not dry and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback (--dry-run rehearses the "
+                         "multi-process path without one)")
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        local %= torch.cuda.device_count()           # (only differs when a test runs several ranks on one GPU)
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    sync = (lambda: None) if dry else (lambda: torch.cuda.synchronize(dev))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("ELO_BENCH_BACKEND", "nccl")                            # nccl == RCCL on ROCm
-        if backend == "nccl":                        # (gloo: the 2-ranks-on-1-GPU rehearsal of this code path)
+        backend = os.environ.get("ELO_BENCH_BACKEND", "gloo" if dry else "nccl")          # nccl == RCCL on ROCm
+        if backend == "nccl":
+            os.environ.setdefault("NCCL_DEBUG", "INFO")                                   # ring / tree choice and the transport
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/elo_bench_rccl_%h_%p.log")     # (RCCL logs to stdout otherwise)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if rank == 0:
+            print("[bench] %s process group up: %d ranks (dist.get_world_size() = %d)"
+                  % (backend, world, dist.get_world_size()), file=sys.stderr, flush=True)
 
-    model, synth = pkg("model"), pkg("synth")
-    pkg("fused").products(args.products).__enter__()          # for the whole run: packing, capture and the roofline leg
-    net = model.PWCLONet(dev, seed=0)
     B, H, W = args.batch, args.height, args.width
-    pool = []
-    for i in range(args.pool):                       # inputs resident in HBM before the timed region
-        f1, f2 = synth.frame_pair(B, H, W, seed=1000 * rank + 10 * i)
-        pool.append(torch.cat([torch.from_numpy(f1), torch.from_numpy(f2)], 0).to(dev))   # (2B,H,W,3) = [f1 | f2]
-    lanes = 1 if args.no_graph else max(1, args.lanes)
-    if args.no_graph:
-        net.forward(pool[0][:B], pool[0][B:])
+    lanes = 1 if (args.no_graph or dry) else max(1, args.lanes)
+    warmup = max(args.warmup, 2 * lanes)
+    if dry:
+        net = None
+        pose_log = torch.zeros((max(args.steps, warmup), B, 7))
+
+        def step(i):
+            pose_log[i, :, 0] = 1.0
     else:
-        net.capture(B, H, W, lanes=lanes)
-    # every step's l0 pose [q | t] is kept (a lane's static outputs are overwritten `lanes` steps later): one (B,7)
-    # row block per step in HBM; with N > 1 ranks the blocks are all-gathered ONCE, inside the timed region
-    # (7 floats per pair: the only exchange of the inference path, main.py:557-572)
-    pose_log = torch.empty((max(args.steps, args.warmup), B, 7), device=dev)
+        model, synth = pkg("model"), pkg("synth")
+        pkg("fused").products(args.products).__enter__()          # for the whole run: packing, capture and the roofline leg
+        net = model.PWCLONet(dev, seed=0, feature_dtype=torch.float16 if args.features == "f16" else torch.float32)
+        pool = []
+        for i in range(args.pool):                       # inputs resident in HBM before the timed region
+            f1, f2 = synth.frame_pair(B, H, W, seed=1000 * rank + 10 * i)
+            pool.append(torch.cat([torch.from_numpy(f1), torch.from_numpy(f2)], 0).to(dev))   # (2B,H,W,3) = [f1 | f2]
+        if args.no_graph:
+            net.forward(pool[0][:B], pool[0][B:])
+        else:
+            net.capture(B, H, W, lanes=lanes)
+        # every step's l0 pose [q | t] is kept (a lane's static outputs are overwritten `lanes` steps later): one (B,7)
+        # row block per step in HBM; with N > 1 ranks the blocks are all-gathered ONCE per repeat, inside the timed
+        # region (7 floats per pair: the only exchange of the inference path, main.py:557-572)
+        pose_log = torch.empty((max(args.steps, warmup), B, 7), device=dev)
+
+        def step(i):
+            pair = pool[i % len(pool)]
+            if args.no_graph:                            # the l0 pose-head kernel writes the log row itself
+                return net.forward(pair[:B], pair[B:], pose_out=pose_log[i])
+            lane = i % lanes                             # step i rides lane i % lanes; lanes overlap on the GPU
+            out = net.submit(lane, pair)                 # one copy in (the stacked pair), graph replay ...
+            with torch.cuda.stream(net.lane_stream(lane)):
+                pose_log[i].copy_(net.lane_pose(lane), non_blocking=True)      # ... one copy out (B,7)
+            return out
     gathered = [torch.empty_like(pose_log[:args.steps]) for _ in range(world)] if world > 1 else None
 
-    def step(i):
-        pair = pool[i % len(pool)]
-        if args.no_graph:                            # the l0 pose-head kernel writes the log row itself
-            return net.forward(pair[:B], pair[B:], pose_out=pose_log[i])
-        lane = i % lanes                             # step i rides lane i % lanes; lanes overlap on the GPU
-        out = net.submit(lane, pair)                 # one copy in (the stacked pair), graph replay ...
-        with torch.cuda.stream(net.lane_stream(lane)):
-            pose_log[i].copy_(net.lane_pose(lane), non_blocking=True)      # ... one copy out (B,7)
-        return out
-
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
-    torch.cuda.synchronize(dev)
+    sync()
     if world > 1:
         dist.all_gather(gathered, pose_log[:args.steps].contiguous())     # untimed: RCCL sets its channels up on first use
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.all_gather(gathered, pose_log[:args.steps].contiguous())
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    repeats, total = [], 0.0
+    while total < MIN_TIMED_S and len(repeats) < 200:
+        sync()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        sync()
+        if world > 1:
+            dist.all_gather(gathered, pose_log[:args.steps].contiguous())
+            sync()
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:                                     # the clock of a repeat is its slowest rank
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        repeats.append(elapsed)
+        total += elapsed
+        if dry:
+            break
     assert torch.isfinite(pose_log[:args.steps]).all()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = statistics.median(repeats)
 
     line = {
         "metric": "frame-pairs/sec (KITTI 64x1800 range image)" if (H, W) == (64, 1800)
                   else "frame-pairs/sec (%dx%d range image)" % (H, W),
-        "value": round(world * B * args.steps / elapsed, 3),
+        "value": None if dry else round(world * B * args.steps / elapsed, 3),
         "unit": "frame-pairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": args.steps, "warmup": warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "repeats": len(repeats), "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in repeats[:16]],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (1x1 convolutions as 3 fp16-MFMA products of hi/lo-split fp32 operands, fp32 accumulate)"
+        "dtype": ("f32 (1x1 convolutions as 3 fp16-MFMA products of hi/lo-split fp32 operands, fp32 accumulate%s)"
+                  % ("; true-fp32 MFMA comparison build" if os.environ.get("ELO_DENSE_F32") == "1" else ""))
                  if args.products == "split" else
                  "f16 products (--products half: 1x1 convolutions as ONE fp16-MFMA product of fp16-rounded operands, fp32 "
-                 "accumulate; storage and everything else fp32) -- not the fp32 parity path",
-        "data": "synthetic",
+                 "accumulate) -- not the fp32 parity path",
+        "data": "dry-run (no GPU work: rehearsal of the multi-process path)" if dry else "synthetic",
         "config": {"workload": "full 4-level PWC pyramid (set-conv + attentive cost volume + warp-refinement + "
-                               "set-upconv), %dx%d range-image pairs, batch %d per GPU, fp32, random-init weights, "
-                               "%s" % (H, W, B, "eager launches" if args.no_graph else
-                                      "hipGraph replay, %d forwards in flight" % lanes),
+                               "set-upconv), %dx%d range-image pairs, batch %d per GPU, %s feature storage, "
+                               "random-init weights, %s" % (H, W, B, "fp16" if args.features == "f16" else "fp32",
+                                                           "eager launches" if args.no_graph else
+                                                           "hipGraph replay, %d forwards in flight" % lanes),
                    "global_batch": B * world, "parallelism": "dp%d" % world},
     }
-    if rank == 0 and world == 1 and not args.no_legs:
+    legs = not args.no_legs and not dry
+    if legs and args.train_steps > 0 and (H, W) == (64, 1800):
+        train = train_dp_leg(args, dev, rank, world, dist)          # every rank takes part (one collective per step)
+        line["train_dp"] = train
+    if legs and rank == 0 and world == 1:
         line["roofline"] = roofline_leg(args, dev, net)
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_leg(args, net, args.cpu_pairs)
-        if (B, H, W) == (1, 64, 1800) and not args.no_graph and args.products == "split":
-            # BASELINE configs[2]'s batch (8 pairs per step), same pyramid: fp32-class products, and fp16 products
+            line["cpu_baseline"] = cpu_baseline_leg(args, net)
+        if (B, H, W) == (1, 64, 1800) and not args.no_graph and args.products == "split" and args.features == "f32":
             line["from_raw_clouds"] = {"unit": "frame-pairs/s", "lanes": lanes, "points_per_frame": 150000,
                                        "value": raw_cloud_rate(dev, B, H, W, lanes)}
+            # BASELINE configs[2]: batch 8 through the same lanes -- fp32 storage, fp16 feature storage (the configuration
+            # configs[2] names), and fp16 storage with fp16 products on top
             line["batch8"] = {"unit": "frame-pairs/s", "lanes": lanes,
-                              "f32": batch_rate(dev, 8, H, W, lanes, "split"),
-                              "f16_products": batch_rate(dev, 8, H, W, lanes, "half")}
+                              "f32": batch_rate(dev, 8, H, W, lanes, "split", "f32"),
+                              "f16_features": batch_rate(dev, 8, H, W, lanes, "split", "f16"),
+                              "f16_features_f16_products": batch_rate(dev, 8, H, W, lanes, "half", "f16")}
+            if os.environ.get("ELO_DENSE_F32") != "1":
+                line["dense_f32"] = dense_f32_leg(args)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

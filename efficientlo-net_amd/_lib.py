@@ -6,7 +6,8 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libelo_hip.so")
+# ELO_DENSE_F32=1: the comparison build (true fp32 MFMA instead of the fp16 hi/lo split products; build.py)
+LIB_PATH = os.path.join(_PKG, "libelo_hip_f32.so" if os.environ.get("ELO_DENSE_F32", "0") == "1" else "libelo_hip.so")
 
 _vp = ctypes.c_void_p
 
@@ -53,12 +54,13 @@ PoseHeadArgs = _struct("elo_pose_head_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("hidden", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp),
     ("W_big", _vp), ("b_big", _vp), ("W_q", _vp), ("b_q", _vp), ("W_t", _vp), ("b_t", _vp),
     ("q_coarse", _vp), ("t_coarse", _vp), ("q", _vp), ("t", _vp), ("q_norm", _vp), ("scratch", _vp), ("pose7", _vp),
-    ("clear_scratch", _vp), ("clear_xyz", _vp), ("clear_feat", _vp), ("clear_cells", ctypes.c_long), ("clear_C", _i)])
+    ("clear_scratch", _vp), ("clear_xyz", _vp), ("clear_feat", _vp), ("clear_cells", ctypes.c_long), ("clear_C", _i),
+    ("feat_dtype", _i)])
 WarpProjectArgs = _struct("elo_warp_project_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("H", _i), ("W", _i),
     ("az_res", _f), ("vert_res", _f), ("vert_off", _f),
     ("xyz", _vp), ("feat", _vp), ("q", _vp), ("t", _vp), ("warped", _vp), ("out_xyz", _vp), ("out_feat", _vp),
-    ("scratch", _vp), ("prepared", _i)])
+    ("scratch", _vp), ("prepared", _i), ("feat_dtype", _i)])
 
 InputStageArgs = _struct("elo_input_stage_args", [
     ("batch", _i), ("npoints", _i), ("point_stride", _i), ("H", _i), ("W", _i), ("az_res", _f), ("vert_res", _f),
@@ -74,27 +76,30 @@ GroupSpec = _struct("elo_group_spec", [
 SetconvArgs = _struct("elo_setconv_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1_grid", _vp), ("centre_hw", _vp), ("centre_xyz", _vp), ("src_xyz", _vp), ("src_feat", _vp),
-    ("idx", _vp), ("mask", _vp), ("n_layers", _i), ("layers", Dense * 3), ("out", _vp), ("new_xyz", _vp), ("group", GroupSpec)])
+    ("idx", _vp), ("mask", _vp), ("n_layers", _i), ("layers", Dense * 3), ("out", _vp), ("new_xyz", _vp), ("group", GroupSpec),
+    ("feat_dtype", _i)])
 MlpArgs = _struct("elo_mlp_args", [
     ("rows", _l), ("n_sources", _i), ("src", _vp * 3), ("src_width", _i * 3), ("n_layers", _i),
     ("layers", Dense * 3), ("out", _vp),
     ("n_layers2", _i), ("layers2", Dense * 3), ("before", _vp), ("w_before", _i), ("after", _vp), ("w_after", _i),
-    ("out2", _vp)])
+    ("out2", _vp), ("feat_dtype", _i)])
 Cv1Args = _struct("elo_cv1_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("xyz2", _vp), ("feat2", _vp), ("idx", _vp), ("mask", _vp),
     ("cv0", Dense), ("cv1", Dense), ("cv2", Dense), ("cv_xyz", Dense), ("sum_cv0", Dense), ("sum_cv1", Dense),
-    ("out", _vp), ("group", GroupSpec)])
+    ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i)])
 Cv2Args = _struct("elo_cv2_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("cost", _vp), ("idx", _vp), ("mask", _vp),
-    ("xyz_enc", Dense), ("sum_cost0", Dense), ("sum_cost1", Dense), ("out", _vp), ("group", GroupSpec)])
+    ("xyz_enc", Dense), ("sum_cost0", Dense), ("sum_cost1", Dense), ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i)])
 
 # every symbol include/elo.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("elo_abi_version", ctypes.c_int, []),
     ("elo_dense_f32", ctypes.c_int, []),
     ("elo_last_error", ctypes.c_char_p, []),
+    ("elo_range_check", ctypes.c_int, [ctypes.c_int]),
+    ("elo_range_violations", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), _vp]),
     ("elo_fused_conv_random_k", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
     ("elo_fused_conv_select_k", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
     ("elo_group_concat", ctypes.c_int, [ctypes.POINTER(GroupConcatArgs), _vp]),
@@ -164,3 +169,25 @@ def require_gpu(*tensors):
         if t is not None and not t.is_cuda:
             raise EloError("the EfficientLO-Net hot path runs on an AMD GPU only (got a %s tensor); "
                            "there is no CPU fallback" % t.device)
+
+
+def dtype_code(t):
+    """ELO_F32 / ELO_F16 of a feature tensor (include/elo.h feat_dtype)."""
+    if t.dtype == torch.float32:
+        return ELO_F32
+    if t.dtype == torch.float16:
+        return ELO_F16
+    raise TypeError("feature tensors are float32 or float16 (got %s)" % t.dtype)
+
+
+def range_check(enable):
+    """Switch the operand range check of the fused kernels (include/elo.h elo_range_check); returns the previous setting."""
+    return lib().elo_range_check(1 if enable else 0)
+
+
+def range_violations(like):
+    """Operands with |x| >= 65504 or NaN seen by the checked kernels since the last call (synchronises the stream)."""
+    n = ctypes.c_ulonglong(0)
+    with torch.cuda.device(like.device):
+        check(lib().elo_range_violations(ctypes.byref(n), stream_ptr(like)))
+    return int(n.value)

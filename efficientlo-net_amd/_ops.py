@@ -21,8 +21,8 @@ def active():
 
 
 def _feature_dtype(*ts):
-    """The three cost-volume kernels store features as fp32 or fp16 (fp32 arithmetic either way): all feature
-    tensors of a call share one of the two; returns (contiguous tensors, torch dtype, ELO_F32 / ELO_F16)."""
+    """Feature tensors are stored as fp32 or fp16 (fp32 arithmetic either way): all feature tensors of a call share one
+    of the two; returns (contiguous tensors, torch dtype, ELO_F32 / ELO_F16)."""
     dt = ts[0].dtype
     if dt not in (torch.float32, torch.float16) or any(t.dtype != dt for t in ts):
         raise TypeError("cost-volume feature tensors are all float32 or all float16 (got %s)" % [str(t.dtype) for t in ts])
@@ -132,10 +132,10 @@ class ProjectionBuffers:
     """Outputs + scratch of one warp_project call, allocated ahead of it so that the pose head that produces its
     (q, t) can clear them on the side (`pose_head(clear=...)`): the warp call then skips its init launch."""
 
-    def __init__(self, B, N, H, W, C, device):
+    def __init__(self, B, N, H, W, C, device, dtype=torch.float32):
         self.shape = (B, N, H, W, C)
         self.out_xyz = torch.empty((B, H, W, 3), dtype=torch.float32, device=device)
-        self.out_feat = torch.empty((B, H, W, C), dtype=torch.float32, device=device) if C else None
+        self.out_feat = torch.empty((B, H, W, C), dtype=dtype, device=device) if C else None
         self.scratch = torch.empty((B * H * W + 4 * B + 2 * B * N,), dtype=torch.int32, device=device)   # include/elo.h
         self.cleared = False
         self.result = None          # (warped, out_xyz, out_feat) once a pose head has run the projection itself
@@ -150,8 +150,8 @@ def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t
     re-projection -- is run by this call (elo_pose_head_warp: 3 launches instead of 2 + 2); its result is left in
     `clear.result` for the warp_project call that follows."""
     L.require_gpu(feature_bnc, weight_bnc, xyz_bn3, W_big, W_q, W_t, q_coarse, t_coarse)
-    feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t = _f32(
-        feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t)
+    xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t = _f32(xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t)
+    (feature_bnc, weight_bnc), fdt, fcode = _feature_dtype(feature_bnc, weight_bnc)      # fp32 or fp16 storage
     B, N, C = feature_bnc.shape
     hidden = W_big.shape[1]
     dev = feature_bnc.device
@@ -167,7 +167,9 @@ def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t
                        ptr(q_coarse), ptr(t_coarse), q.data_ptr(), t.data_ptr(), q_norm.data_ptr(), scratch.data_ptr(),
                        ptr(pose7), *((clear.scratch.data_ptr(), clear.out_xyz.data_ptr(), ptr(clear.out_feat),
                                       clear.shape[0] * clear.shape[2] * clear.shape[3], clear.shape[4])
-                                     if clear is not None else (None, None, None, 0, 0)))
+                                     if clear is not None else (None, None, None, 0, 0)), fcode)
+    if clear is not None and clear.out_feat is not None and clear.out_feat.dtype != fdt:
+        raise TypeError("the projection buffers and the pose head's features must share one storage dtype")
     if warp is not None:
         if clear is None:
             raise ValueError("warp= needs clear= (the ProjectionBuffers the projection writes)")
@@ -177,11 +179,13 @@ def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t
         if xyz_w.shape != (Bw, Nw, 3) or (Cw and (feat_w is None or feat_w.shape != (Bw, Nw, Cw))):
             raise ValueError("warp inputs do not match the ProjectionBuffers %s" % (clear.shape,))
         if feat_w is not None:
-            (feat_w,) = _f32(feat_w)
+            if feat_w.dtype != fdt:
+                raise TypeError("the warped features and the pose head's features must share one storage dtype")
+            feat_w = feat_w.contiguous()
         warped = torch.empty((Bw, Nw, 3), dtype=torch.float32, device=dev)
         az, vres, voff = projection_constants(Hw, Ww)
         w = L.WarpProjectArgs(Bw, Nw, Cw, Hw, Ww, az, vres, voff, xyz_w.data_ptr(), ptr(feat_w), None, None,
-                              warped.data_ptr(), clear.out_xyz.data_ptr(), ptr(clear.out_feat), clear.scratch.data_ptr(), 1)
+                              warped.data_ptr(), clear.out_xyz.data_ptr(), ptr(clear.out_feat), clear.scratch.data_ptr(), 1, fcode)
         L.call2("elo_pose_head_warp", a, w, q)
         clear.result = (warped, clear.out_xyz, clear.out_feat)
         return q, t, q_norm
@@ -235,8 +239,9 @@ def warp_project(xyz, feat, q, t, H, W, buffers=None):
     (xyz,) = _f32(xyz)
     B, N, _ = xyz.shape
     C = 0 if feat is None else feat.shape[-1]
+    fdt, fcode = torch.float32, L.ELO_F32
     if feat is not None:
-        (feat,) = _f32(feat)
+        (feat,), fdt, fcode = _feature_dtype(feat)
     if q is not None:
         q, t = _f32(q.reshape(B, 4), t.reshape(B, 3))
     dev = xyz.device
@@ -244,12 +249,14 @@ def warp_project(xyz, feat, q, t, H, W, buffers=None):
     if buffers is not None and buffers.shape != (B, N, H, W, C):
         raise ValueError("ProjectionBuffers of shape %s given to a %s projection" % (buffers.shape, (B, N, H, W, C)))
     if buffers is None:
-        buffers = ProjectionBuffers(B, N, H, W, C, dev)
+        buffers = ProjectionBuffers(B, N, H, W, C, dev, fdt)
+    if buffers.out_feat is not None and buffers.out_feat.dtype != fdt:
+        raise TypeError("ProjectionBuffers of dtype %s given to a projection of %s features" % (buffers.out_feat.dtype, fdt))
     out_xyz, out_feat, scratch = buffers.out_xyz, buffers.out_feat, buffers.scratch
     az, vres, voff = projection_constants(H, W)
     ptr = lambda x: x.data_ptr() if x is not None else None
     a = L.WarpProjectArgs(B, N, C, H, W, az, vres, voff, xyz.data_ptr(), ptr(feat), ptr(q), ptr(t), ptr(warped),
-                          out_xyz.data_ptr(), ptr(out_feat), scratch.data_ptr(), 1 if buffers.cleared else 0)
+                          out_xyz.data_ptr(), ptr(out_feat), scratch.data_ptr(), 1 if buffers.cleared else 0, fcode)
     buffers.cleared = False                               # single use: the outputs now hold this call's result
     L.call("elo_warp_project", a, out_xyz)
     return warped, out_xyz, out_feat

@@ -11,6 +11,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libelo_hip.so")
+LIB_F32 = os.path.join(PKG, "libelo_hip_f32.so")      # the same sources with -DELO_DENSE_F32: true-fp32 MFMA, the comparison build
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off",          # arithmetic contract: no FMA contraction
@@ -21,21 +22,24 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
 
 
-def stale():
-    if not os.path.exists(LIB):
+def stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(PKG, "..", "include", "elo.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=False):
-    if not force and not stale():
-        return LIB
-    cmd = [HIPCC] + FLAGS + sources() + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    """libelo_hip.so (the product) and libelo_hip_f32.so (ELO_DENSE_F32=1 selects it: every 1x1 convolution on
+    v_mfma_f32_16x16x4_f32, kept to bench and test the fp16-split products against)."""
+    for lib, extra in ((LIB, []), (LIB_F32, ["-DELO_DENSE_F32"])):
+        if not force and not stale(lib):
+            continue
+        cmd = [HIPCC] + FLAGS + extra + sources() + ["-o", lib]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return LIB
 
 

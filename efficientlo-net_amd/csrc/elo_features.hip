@@ -485,7 +485,7 @@ __device__ __forceinline__ SvPartials sv_partials(float *scratch, int batch, int
 // Side job of the partial kernel (elo_pose_head_args.clear_*): its workgroups also clear the buffers of the
 // projection that follows the pose head, which saves that call's init launch (three per forward).
 constexpr int ZFLAGS = 4;                          // projection scratch, per image: one flag per cell a zero point can fall in (3 used)
-struct ProjectionClear { unsigned *minr; float *xyz, *feat; long cells; int C; int images; };   // minr: cells + images words
+struct ProjectionClear { unsigned *minr; float *xyz; unsigned *feat; long cells; int C; int images; };   // minr: cells + images words; C: 32-bit words of features per cell
 
 __device__ __forceinline__ void clear_projection(const ProjectionClear &c)
 {
@@ -497,15 +497,20 @@ __device__ __forceinline__ void clear_projection(const ProjectionClear &c)
     for (long i = me; i < total; i += nthreads) {
         if (i < c.cells) c.minr[i] = 0x7f7f7f7fu;
         else if (i < c.cells + n_xyz) c.xyz[i - c.cells] = 0.0f;
-        else c.feat[i - c.cells - n_xyz] = 0.0f;
+        else c.feat[i - c.cells - n_xyz] = 0u;
     }
 }
 
-__global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_partial_kernel(const float *__restrict__ feature,
-                                                                          const float *__restrict__ weight,
+__device__ __forceinline__ float feat_at(const void *p, long i, int f16)
+{
+    return f16 ? (float)reinterpret_cast<const _Float16 *>(p)[i] : reinterpret_cast<const float *>(p)[i];
+}
+
+__global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_partial_kernel(const void *__restrict__ feature,
+                                                                          const void *__restrict__ weight,
                                                                           const float *__restrict__ xyz, int npoints,
                                                                           int C, int parts, float *scratch,
-                                                                          const ProjectionClear clear)
+                                                                          const ProjectionClear clear, const int f16)
 {
     __shared__ float part[3][ROWS_PER_BLOCK][ELO_WAVE];
     clear_projection(clear);
@@ -513,8 +518,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_partial_kernel(const 
     const int c = blockIdx.z * ELO_WAVE + lane;
     const bool live = c < C;
     const int cc = live ? c : C - 1;                  // clamped: dead lanes load a real channel and drop it
-    const float *f = feature + (long)b * npoints * C;
-    const float *w = weight + (long)b * npoints * C;
+    const long fbase = (long)b * npoints * C;
     const float *p = xyz + (long)b * npoints * 3;
     const int per = (npoints + parts - 1) / parts;
     const int lo = slice * per, hi = min(npoints, lo + per);
@@ -530,8 +534,8 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_partial_kernel(const 
             // plain loads, no short-circuit: a conditional load costs a full s_waitcnt vmcnt(0) each (measured: the
             // `a && b && c` form of the zero test serialised three round trips per row)
             const float px = p[nn * 3 + 0], py = p[nn * 3 + 1], pz = p[nn * 3 + 2];
-            l[u] = w[(long)nn * C + cc];
-            v[u] = f[(long)nn * C + cc];
+            l[u] = feat_at(weight, fbase + (long)nn * C + cc, f16);
+            v[u] = feat_at(feature, fbase + (long)nn * C + cc, f16);
             ok[u] = (n < hi) & live & !((px == 0.0f) & (py == 0.0f) & (pz == 0.0f));
         }
 #pragma unroll
@@ -840,7 +844,8 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
 }
 
 // ------------------------------------------------------------ warp + spherical re-projection
-__global__ __launch_bounds__(ELO_BLOCK) void project_init_kernel(unsigned *minr, float *out_xyz, float *out_feat,
+// C: 32-bit words of features per cell (fp16 storage: channels / 2)
+__global__ __launch_bounds__(ELO_BLOCK) void project_init_kernel(unsigned *minr, float *out_xyz, unsigned *out_feat,
                                                                  size_t cells, int C, int images)
 {
     const size_t n_xyz = cells * 3, n_feat = cells * (size_t)C, total = cells + n_xyz + n_feat;
@@ -849,7 +854,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void project_init_kernel(unsigned *minr,
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         if (i < cells) minr[i] = 0x7f7f7f7fu;
         else if (i < cells + n_xyz) out_xyz[i - cells] = 0.0f;
-        else out_feat[i - cells - n_xyz] = 0.0f;
+        else out_feat[i - cells - n_xyz] = 0u;
     }
 }
 
@@ -892,9 +897,11 @@ __global__ __launch_bounds__(ELO_BLOCK) void input_cell_kernel(const elo_input_s
 }
 
 // pass B: the point(s) holding the cell minimum are summed into the cell (tf.scatter_nd adds duplicates).
+// fp16 feature storage: a work item is a PAIR of channels, added with one packed fp16 atomic
 __global__ __launch_bounds__(ELO_BLOCK) void scatter_min_kernel(const elo_warp_project_args a, const ProjScratch ps)
 {
-    const int CT = 3 + a.C;
+    const int f16 = a.feat_dtype == ELO_F16;
+    const int CT = 3 + (f16 ? a.C / 2 : a.C);
     const long total = (long)a.batch * a.npoints * CT;
     const float *pts = a.q ? a.warped : a.xyz;
     const int zc0 = cell_of_point(0.0f, 0.0f, 0.0f, a.H, a.W, a.az_res, a.vert_res, a.vert_off);          // zero_kind 0
@@ -912,10 +919,17 @@ __global__ __launch_bounds__(ELO_BLOCK) void scatter_min_kernel(const elo_warp_p
         if (ps.rbits[i] != (zero_won ? 0u : ps.minr[cell])) continue;
         // adding +-0 never changes a sum that started at +0 (x + 0 = x; 0 + -0 = +0): skipped, so the zero points of a
         // padded scan -- all winners of one cell -- do not queue on its three words
-        const float v = ch < 3 ? pts[i * 3 + ch] : a.feat[i * a.C + (ch - 3)];
+        if (ch >= 3 && f16) {
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+            const half2v hv = reinterpret_cast<const half2v *>(a.feat)[(i * a.C) / 2 + (ch - 3)];
+            if (hv.x == (_Float16)0.0f && hv.y == (_Float16)0.0f) continue;
+            __builtin_amdgcn_global_atomic_fadd_v2f16(reinterpret_cast<half2v *>(a.out_feat) + (cell * a.C) / 2 + (ch - 3), hv);
+            continue;
+        }
+        const float v = ch < 3 ? pts[i * 3 + ch] : reinterpret_cast<const float *>(a.feat)[i * a.C + (ch - 3)];
         if (v == 0.0f) continue;
         if (ch < 3) atomicAdd(a.out_xyz + cell * 3 + ch, v);
-        else atomicAdd(a.out_feat + cell * a.C + (ch - 3), v);
+        else atomicAdd(reinterpret_cast<float *>(a.out_feat) + cell * a.C + (ch - 3), v);
     }
 }
 
@@ -1076,7 +1090,7 @@ extern "C" int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t s
     const int parts = sv_parts(a->npoints);
     hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
                        dim3(ELO_BLOCK), 0, (hipStream_t)stream, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
-                       a->scratch, ProjectionClear{nullptr, nullptr, nullptr, 0, 0, 0});
+                       a->scratch, ProjectionClear{nullptr, nullptr, nullptr, 0, 0, 0}, 0);
     hipLaunchKernelGGL(softmax_valid_merge_kernel, dim3((a->batch * a->C + ELO_BLOCK - 1) / ELO_BLOCK), dim3(ELO_BLOCK),
                        0, (hipStream_t)stream, a->scratch, a->batch, a->C, parts, a->out);
     return check_launch(who);
@@ -1089,6 +1103,8 @@ static int check_warp_project(const elo_warp_project_args *a, const char *who)
     ELO_REQUIRE(a->xyz && a->out_xyz && a->scratch, who, "null tensor pointer");
     ELO_REQUIRE(a->C == 0 || (a->feat && a->out_feat), who, "features requested without buffers");
     ELO_REQUIRE(!a->q || (a->t && a->warped), who, "warp requested without t / warped");
+    ELO_REQUIRE(a->feat_dtype == ELO_F32 || a->feat_dtype == ELO_F16, who, "feat_dtype must be ELO_F32 or ELO_F16");
+    ELO_REQUIRE(a->feat_dtype == ELO_F32 || a->C % 2 == 0, who, "fp16 feature storage needs an even C");
     return ELO_OK;
 }
 
@@ -1102,10 +1118,14 @@ static int pose_head_impl(const elo_pose_head_args *a, const elo_warp_project_ar
     ELO_REQUIRE((a->q_coarse == nullptr) == (a->t_coarse == nullptr), who, "q_coarse and t_coarse go together");
     ELO_REQUIRE(!a->clear_scratch || (a->clear_xyz && a->clear_cells > 0 && a->clear_C >= 0 && (a->clear_feat || a->clear_C == 0)),
                 who, "incomplete clear_* side job");
+    ELO_REQUIRE(a->feat_dtype == ELO_F32 || a->feat_dtype == ELO_F16, who, "feat_dtype must be ELO_F32 or ELO_F16");
+    const int f16 = a->feat_dtype == ELO_F16;
+    ELO_REQUIRE(!f16 || a->clear_C % 2 == 0, who, "fp16 feature storage needs an even clear_C");
     elo_warp_project_args wv{};
     if (w) {
         if (int rc = check_warp_project(w, who)) return rc;
         ELO_REQUIRE(w->batch == a->batch && w->warped, who, "the warp must have the pose head's batch and a `warped` output");
+        ELO_REQUIRE(w->feat_dtype == a->feat_dtype, who, "the warp and the pose head must share one feat_dtype");
         ELO_REQUIRE(a->clear_scratch == w->scratch && a->clear_xyz == w->out_xyz && a->clear_feat == w->out_feat &&
                     a->clear_cells == (long)w->batch * w->H * w->W && a->clear_C == w->C, who,
                     "the warp's buffers must be the ones this call clears (clear_*)");
@@ -1118,13 +1138,14 @@ static int pose_head_impl(const elo_pose_head_args *a, const elo_warp_project_ar
     const int parts = sv_parts(a->npoints);
     hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
                        dim3(ELO_BLOCK), 0, s, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
-                       a->scratch, ProjectionClear{a->clear_scratch, a->clear_xyz, a->clear_feat, a->clear_cells, a->clear_C, a->batch});
+                       a->scratch, ProjectionClear{a->clear_scratch, a->clear_xyz, (unsigned *)a->clear_feat, a->clear_cells,
+                                                   f16 ? a->clear_C / 2 : a->clear_C, a->batch}, f16);
     const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (ELO_BLOCK / ELO_WAVE) + 3 * 4 * 64);
     const unsigned xb = w ? (unsigned)((w->npoints + ELO_BLOCK - 1) / ELO_BLOCK) : 1u;
     hipLaunchKernelGGL(pose_head_kernel, dim3(xb, a->batch), dim3(ELO_BLOCK), lds, s, *a, parts, wv, w ? 1 : 0);
     if (w) {
         const size_t cells = (size_t)w->batch * w->H * w->W, pts = (size_t)w->batch * w->npoints;
-        const size_t elems = pts * (3 + w->C);
+        const size_t elems = pts * (3 + (f16 ? w->C / 2 : w->C));
         const unsigned gb = (unsigned)((elems + ELO_BLOCK - 1) / ELO_BLOCK);
         hipLaunchKernelGGL(scatter_min_kernel, dim3(gb > 4096 ? 4096 : gb), dim3(ELO_BLOCK), 0, s, wv,
                            proj_scratch(w->scratch, cells, w->batch, pts));
@@ -1158,7 +1179,7 @@ extern "C" int elo_input_stage(const elo_input_stage_args *a, elo_stream_t strea
     const ProjScratch ps = proj_scratch(a->scratch, cells, images, pts);
     const unsigned gi = (unsigned)((cells * 4 + ELO_BLOCK - 1) / ELO_BLOCK);
     hipLaunchKernelGGL(project_init_kernel, dim3(gi > 4096 ? 4096 : gi), dim3(ELO_BLOCK), 0, s, ps.minr, a->out_xyz,
-                       (float *)nullptr, cells, 0, (int)images);
+                       (unsigned *)nullptr, cells, 0, (int)images);
     const unsigned ga = (unsigned)((pts + ELO_BLOCK - 1) / ELO_BLOCK);
     hipLaunchKernelGGL(input_cell_kernel, dim3(ga > 8192 ? 8192 : ga), dim3(ELO_BLOCK), 0, s, *a, ps);
     elo_warp_project_args w = {};
@@ -1181,15 +1202,16 @@ extern "C" int elo_warp_project(const elo_warp_project_args *a, elo_stream_t str
     const ProjScratch ps = proj_scratch(a->scratch, cells, a->batch, pts);
     // one init launch instead of three memsets (memset nodes inside a captured hipGraph proved unreliable):
     // minr <- 0x7f7f7f7f (3.39e38f: above every finite range, below NaN bit patterns), outputs <- 0
+    const int f16 = a->feat_dtype == ELO_F16, feat_words = f16 ? a->C / 2 : a->C;
     if (!a->prepared) {
-        const size_t words = cells * (1 + 3 + (size_t)a->C);
+        const size_t words = cells * (1 + 3 + (size_t)feat_words);
         const unsigned gi = (unsigned)((words + ELO_BLOCK - 1) / ELO_BLOCK);
         hipLaunchKernelGGL(project_init_kernel, dim3(gi > 4096 ? 4096 : gi), dim3(ELO_BLOCK), 0, s, ps.minr, a->out_xyz,
-                           a->out_feat, cells, a->C, a->batch);
+                           (unsigned *)a->out_feat, cells, feat_words, a->batch);
     }
     const unsigned ga = (unsigned)((pts + ELO_BLOCK - 1) / ELO_BLOCK);
     hipLaunchKernelGGL(warp_cell_kernel, dim3(ga > 4096 ? 4096 : ga), dim3(ELO_BLOCK), 0, s, *a, ps);
-    const size_t elems = pts * (3 + a->C);
+    const size_t elems = pts * (3 + (size_t)feat_words);
     const unsigned gb = (unsigned)((elems + ELO_BLOCK - 1) / ELO_BLOCK);
     hipLaunchKernelGGL(scatter_min_kernel, dim3(gb > 4096 ? 4096 : gb), dim3(ELO_BLOCK), 0, s, *a, ps);
     return check_launch(who);

@@ -5,16 +5,19 @@
 // command processor, not HBM or the matrix cores, is the limit.  These kernels collapse every
 // operator between two poolings into ONE launch.
 //
-// How: one wavefront owns a tile of 32 consecutive rows (a row = one (b,n,k) neighbour slot, or one
-// point for the row-wise MLPs).  The tile's activations live in a wave-private LDS image
-// act[32][S] (S/4 odd => ds_read_b128 of a column block is bank-conflict free).  A layer is
-//     D[32 x Np] = A[32 x Kp] * W[Kp x Np] + bias      on v_mfma_f32_32x32x2_f32 (exact fp32)
-// with A read from LDS 16 bytes per lane per 8 k's, W streamed from L2 in pre-packed B-fragment
-// order (one contiguous 1 KiB load per wave-instruction, prefetched one step ahead) and D written
-// back over the tile IN PLACE (a wave has consumed all its A reads before its first D write, and a
-// wave's LDS operations execute in order), so consecutive layers need no barrier at all.
-// Poolings (masked max / masked softmax-weighted sum over the K rows of a point) read the
-// final activations column-wise from LDS and write (b,n,C) rows coalesced.
+// How: four waves own a tile of 16 or 32 consecutive rows (a row = one (b,n,k) neighbour slot, or one
+// point for the row-wise MLPs).  The tile's activations live in LDS as MATRIX-CORE OPERANDS: every four
+// consecutive columns of a row are one 16-byte "quad" [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] of fp16 halves
+// (x = hi + lo to 2^-20), written once by whoever produces them (the gather, or the previous layer's
+// epilogue) and read with ONE ds_read_b128 and no conversion by every wave that consumes them.  A layer is
+//     D^T[Np x TILE] = W^T[Np x Kp] * A^T[Kp x TILE]       on v_mfma_f32_16x16x16_f16, three products
+// -- the TRANSPOSED product: the W fragment is the MFMA's A operand, the activation quad its B operand, so
+// a lane ends up with four CONSECUTIVE output channels of one row: one quad, one ds_write_b128 (or one
+// 16-byte / 8-byte global store for a layer whose output leaves the kernel).  W is streamed from L2 in
+// pre-packed fragment order (one contiguous 1 KiB load per wave-instruction, prefetched one step ahead).
+// Layers run in place on the tile (barrier, write, barrier).  Poolings (masked max / masked
+// softmax-weighted sum over the K rows of a point) read the last layer's plain-fp32 output column-wise from
+// LDS and write (b,n,C) rows coalesced.  Feature tensors in HBM are fp32 or fp16 (feat_dtype).
 //
 // Interfaces and the reference lines covered: include/elo.h ("Fused inference kernels").
 #include "elo_group_device.h"
@@ -24,15 +27,24 @@ namespace elo {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 constexpr int FUSED_BLOCK = 256;   // 4 waves cooperate on one tile of rows
 constexpr int FUSED_WAVES = 4;
 
+// how a kernel instance computes its products (template parameter MODE)
+constexpr int MODE_SPLIT = 0;      // fp32-class: hi/lo split operands, three fp16 MFMA products
+constexpr int MODE_HALF = 1;       // ELO_PRODUCTS_HALF: operands rounded to nearest fp16, one product
+constexpr int MODE_CHECKED = 2;    // MODE_SPLIT + a count of operands outside the fp16 range (elo_range_check)
+
+__device__ unsigned long long g_range_violations;      // written by MODE_CHECKED instances only
+
 __device__ __forceinline__ int ceil8(int x) { return (x + 7) & ~7; }
 __device__ __forceinline__ int ceil16(int x) { return (x + 15) & ~15; }
 
-// LDS row stride (floats) for `cols` columns: a multiple of 4 with (S/4) odd, so that the 16 rows a
-// ds_read_b128 A-fragment touches fall into 16 different 16-byte bank slots.
+// LDS row stride (32-bit words) for `cols` columns: a multiple of 4 with (S/4) odd, so that the 16 rows a
+// ds_read_b128 operand fragment touches fall into 16 different 16-byte bank slots.
 __host__ __device__ __forceinline__ int row_stride(int cols)
 {
     int s = (cols + 3) & ~3;
@@ -54,94 +66,233 @@ __device__ __forceinline__ float4 weight_load(__amdgpu_buffer_rsrc_t rsrc, unsig
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, 0));
 }
 
-// A lane's share of one 16-k x 16-n block of W: 16 bytes [4 halves hi | 4 halves lo] (ELO_PRODUCTS_SPLIT), or the 8
-// bytes of four round-to-nearest halves (ELO_PRODUCTS_HALF).  BLOCK_BYTES is the wave's contiguous load.
-template <bool HALF> struct WFrag { typedef float4 type; static constexpr int LANE_BYTES = 16, BLOCK_BYTES = 1024; };
-template <> struct WFrag<true> { typedef float2 type; static constexpr int LANE_BYTES = 8, BLOCK_BYTES = 512; };
+// A lane's share of one 16-k x 16-n block of W: 16 bytes [4 halves hi | 4 halves lo] (split modes), or the 8
+// bytes of four round-to-nearest halves (MODE_HALF).  BLOCK_BYTES is the wave's contiguous load.
+template <int MODE> struct WFrag { typedef float4 type; static constexpr int LANE_BYTES = 16, BLOCK_BYTES = 1024; };
+#ifndef ELO_DENSE_F32
+template <> struct WFrag<MODE_HALF> { typedef float2 type; static constexpr int LANE_BYTES = 8, BLOCK_BYTES = 512; };
+#endif
 
-template <bool HALF>
-__device__ __forceinline__ typename WFrag<HALF>::type frag_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, int byte_off)
+template <int MODE>
+__device__ __forceinline__ typename WFrag<MODE>::type frag_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, int byte_off)
 {
-    if constexpr (HALF) return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_off, byte_off, 0));
+    if constexpr (MODE == MODE_HALF) return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_off, byte_off, 0));
     else return weight_load(rsrc, lane_off, byte_off);
 }
 
-// ---- fp32-class products on the fp16 matrix cores ---------------------------------------------------------------
+// ---- the tile's element format ------------------------------------------------------------------------------------
 // v_mfma_f32_16x16x4_f32 costs 32 cycles per 1024 multiply-adds and, measured (SQ_VALU_MFMA_COEXEC_CYCLES = 0), does
 // not overlap with vector work, so its busy time adds to the kernel time.  v_mfma_f32_16x16x16_f16 does 4096
 // multiply-adds in 8 cycles.  Both operands are therefore split into fp16 hi + lo (x = hi + lo to 2^-20 relative: hi is
 // x with the low 13 mantissa bits cleared -- exactly an fp16 value --, lo = x - hi, both packed with round-toward-zero,
 // which saturates instead of producing inf) and a 16-k block is  hi*hi + hi*lo + lo*hi  with fp32 accumulation: 3 x 8
-// cycles instead of 4 x 32, the dropped lo*lo term is 2^-20 relative.  W is split at packing time (fused.PackedDense:
-// a lane's 16 bytes are [4 halves hi | 4 halves lo]); an A fragment is split when it is read (12 vector instructions
-// per 16-k block and wave, shared by all of the wave's column blocks).  ELO_DENSE_F32 restores the fp32 MFMA path.
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-struct HiLo { half4 hi, lo; };
+// cycles instead of 4 x 32, the dropped lo*lo term is 2^-20 relative.  W is split at packing time (fused.PackedDense);
+// an activation is split ONCE, when it is written to the tile (12 vector instructions per quad; round 1 split it on
+// every read: once per column-block pass of every wave, 384 of the 838 vector instructions of a cost-volume tile's
+// layers).  ELO_DENSE_F32 keeps plain fp32 in the tile and uses the fp32 MFMA.
+//
+// A quad = four consecutive columns of one tile row = 16 bytes at word index row*S + col (col % 4 == 0):
+//   split modes   [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3]        MODE_HALF   [rn0 rn1 rn2 rn3 | unused]
+//   ELO_DENSE_F32 / "plain" layers (the input of a pooling)   four floats
+__device__ __forceinline__ unsigned pk_rtz(float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); }
 
-__device__ __forceinline__ HiLo split_fragment(const float4 a)
-{
-    const float h0 = __uint_as_float(__float_as_uint(a.x) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(a.y) & 0xffffe000u);
-    const float h2 = __uint_as_float(__float_as_uint(a.z) & 0xffffe000u), h3 = __uint_as_float(__float_as_uint(a.w) & 0xffffe000u);
-    auto pk = [](float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); };
-    return HiLo{__builtin_bit_cast(half4, uint2{pk(h0, h1), pk(h2, h3)}),
-                __builtin_bit_cast(half4, uint2{pk(a.x - h0, a.y - h1), pk(a.z - h2, a.w - h3)})};
-}
-
-// ELO_PRODUCTS_HALF: ONE fp16 product per 16-k block, both operands rounded to nearest fp16 (2^-11 relative each),
-// fp32 accumulation -- fp16 arithmetic on the matrix cores for BASELINE configs[2]; not the fp32-class path.
-template <int MAXT>
-__device__ __forceinline__ void mma_block(f32x4 (&acc)[MAXT], const float4 a, const float2 (&w)[MAXT])
-{
-    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-    const half2v lo = half2v{(_Float16)a.x, (_Float16)a.y}, hi = half2v{(_Float16)a.z, (_Float16)a.w};
-    const half4 A = __builtin_bit_cast(half4, uint2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)});
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(A, __builtin_bit_cast(half4, w[t]), acc[t], 0, 0, 0);
-}
-
-// one 16-k block of MAXT column blocks: acc[t] += A(16 rows x 16 k) * W_t(16 k x 16 n)
-template <int MAXT>
-__device__ __forceinline__ void mma_block(f32x4 (&acc)[MAXT], const float4 a, const float4 (&w)[MAXT])
+template <int MODE>
+__device__ __forceinline__ uint4 pack_quad(const float4 a, unsigned &violations)
 {
 #ifdef ELO_DENSE_F32
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[t].w, acc[t], 0, 0, 0);
+    return __builtin_bit_cast(uint4, a);
 #else
-    const HiLo A = split_fragment(a);
-    half4 bhi[MAXT], blo[MAXT];
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        bhi[t] = __builtin_bit_cast(half4, float2{w[t].x, w[t].y});
-        blo[t] = __builtin_bit_cast(half4, float2{w[t].z, w[t].w});
+    if constexpr (MODE == MODE_HALF) {
+        const half2v p0 = half2v{(_Float16)a.x, (_Float16)a.y}, p1 = half2v{(_Float16)a.z, (_Float16)a.w};
+        return uint4{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1), 0u, 0u};
+    } else {
+        if constexpr (MODE == MODE_CHECKED) {
+            const float m = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
+            violations += !(m < 65504.0f);                    // also counts NaN
+        }
+        const float h0 = __uint_as_float(__float_as_uint(a.x) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(a.y) & 0xffffe000u);
+        const float h2 = __uint_as_float(__float_as_uint(a.z) & 0xffffe000u), h3 = __uint_as_float(__float_as_uint(a.w) & 0xffffe000u);
+        return uint4{pk_rtz(h0, h1), pk_rtz(h2, h3), pk_rtz(a.x - h0, a.y - h1), pk_rtz(a.z - h2, a.w - h3)};
     }
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(A.hi, bhi[t], acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(A.hi, blo[t], acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(A.lo, bhi[t], acc[t], 0, 0, 0);
 #endif
 }
 
-// ---- one dense layer on the block's tile ---------------------------------------------------
-// D[TILE x Np] = relu?(A[TILE x Kp] * W + bias) on v_mfma_f32_16x16x4_f32 (exact fp32).  The tile is cut
-// into 16x16 output sub-tiles; wave w owns row block (w % RB) and every (4/RB)-th column block, keeps
-// its <= 4 accumulators in registers over the whole K loop, and streams its columns of W from L2 in
-// packed B-fragment order (one contiguous 1 KiB load per wave-instruction, prefetched one step ahead):
-//     w_packed[((cb*KS + ks)*64 + lane)*4 + s] = W[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)]
-// A comes from LDS, 16 bytes per lane per 16 k's.  Layers run IN PLACE on the tile: barrier after the
-// K loop (every wave has finished reading A), write D, barrier.
-template <int TILE, int MAXT, bool HALF>
-__device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_off, const elo_dense &L)
+// four fp16 values read from HBM (fp16 feature storage): exact operands, hi = x, lo = 0
+__device__ __forceinline__ uint4 quad_of_halves(const uint2 h)
 {
-    typedef typename WFrag<HALF>::type W_t;
+#ifdef ELO_DENSE_F32
+    const half4 v = __builtin_bit_cast(half4, h);
+    return __builtin_bit_cast(uint4, float4{(float)v.x, (float)v.y, (float)v.z, (float)v.w});
+#else
+    return uint4{h.x, h.y, 0u, 0u};
+#endif
+}
+
+__device__ __forceinline__ void quad_store(float *act, int word, const uint4 q) { *reinterpret_cast<uint4 *>(act + word) = q; }
+
+// one element of an operand-format region, as fp32 (the poolings read their VALUES this way: hi + lo is x to 2^-22)
+__device__ __forceinline__ float act_get(const float *act, int word)
+{
+#ifdef ELO_DENSE_F32
+    return act[word];
+#else
+    const unsigned short *h = reinterpret_cast<const unsigned short *>(act + (word & ~3)) + (word & 3);
+    return (float)__builtin_bit_cast(_Float16, h[0]) + (float)__builtin_bit_cast(_Float16, h[4]);
+#endif
+}
+
+// one element written on its own (the element-wise staging paths for widths that are not multiples of a quad)
+template <int MODE>
+__device__ __forceinline__ void act_put(float *act, int word, float v, unsigned &violations)
+{
+#ifdef ELO_DENSE_F32
+    act[word] = v;
+#else
+    unsigned short *h = reinterpret_cast<unsigned short *>(act + (word & ~3)) + (word & 3);
+    if constexpr (MODE == MODE_HALF) {
+        h[0] = __builtin_bit_cast(unsigned short, (_Float16)v);
+        h[4] = 0;
+    } else {
+        if constexpr (MODE == MODE_CHECKED) violations += !(fabsf(v) < 65504.0f);
+        const float hi = __uint_as_float(__float_as_uint(v) & 0xffffe000u);
+        const unsigned p = pk_rtz(hi, v - hi);
+        h[0] = (unsigned short)p;
+        h[4] = (unsigned short)(p >> 16);
+    }
+#endif
+}
+
+// MODE_CHECKED: one atomic per thread that saw something (none in a healthy run)
+template <int MODE>
+__device__ __forceinline__ void report_violations(unsigned violations)
+{
+    if constexpr (MODE == MODE_CHECKED)
+        if (violations) atomicAdd(&g_range_violations, (unsigned long long)violations);
+}
+
+// ---- feature tensors in HBM: fp32 or fp16 ------------------------------------------------------------------------
+__device__ __forceinline__ float feat_load(const void *p, long i, int f16)
+{
+    return f16 ? (float)reinterpret_cast<const _Float16 *>(p)[i] : reinterpret_cast<const float *>(p)[i];
+}
+
+__device__ __forceinline__ void feat_store(void *p, long i, float v, int f16)
+{
+    if (f16) reinterpret_cast<_Float16 *>(p)[i] = (_Float16)v;
+    else reinterpret_cast<float *>(p)[i] = v;
+}
+
+// four consecutive channels, i % 4 == 0 and the row 16-byte (fp16: 8-byte) aligned
+__device__ __forceinline__ void feat_store4(void *p, long i, const float4 v, int f16)
+{
+    if (f16) {
+        const half2v a = half2v{(_Float16)v.x, (_Float16)v.y}, b = half2v{(_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<uint2 *>(reinterpret_cast<_Float16 *>(p) + i) = uint2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+    } else {
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p) + i) = v;
+    }
+}
+
+// ---- one 16-k block of MAXT column blocks, transposed: acc[t] += W_t^T(16 n x 16 k) * A^T(16 k x 16 rows) ----------
+// operand layouts of v_mfma_f32_16x16x16_f16 (lane = i16 + 16*kq): A[m = i16][k = 4kq..4kq+3], B[k = 4kq..4kq+3][n = i16],
+// D[m = 4kq + r][n = i16] in acc[r].  With A := the W fragment (m = output channel) and B := the activation quad
+// (n = tile row), a lane holds channels cb*16 + 4kq + 0..3 of row i16.
+template <int MODE, int MAXT>
+__device__ __forceinline__ void mma_block(f32x4 (&acc)[MAXT], const uint4 a, const typename WFrag<MODE>::type (&w)[MAXT])
+{
+#ifdef ELO_DENSE_F32
+    const float4 x = __builtin_bit_cast(float4, a);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].x, x.x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].y, x.y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].z, x.z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].w, x.w, acc[t], 0, 0, 0);
+#else
+    const half4 ahi = __builtin_bit_cast(half4, uint2{a.x, a.y});
+    if constexpr (MODE == MODE_HALF) {
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, w[t]), ahi, acc[t], 0, 0, 0);
+    } else {
+        const half4 alo = __builtin_bit_cast(half4, uint2{a.z, a.w});
+        half4 bhi[MAXT], blo[MAXT];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            bhi[t] = __builtin_bit_cast(half4, float2{w[t].x, w[t].y});
+            blo[t] = __builtin_bit_cast(half4, float2{w[t].z, w[t].w});
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(bhi[t], ahi, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(blo[t], ahi, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(bhi[t], alo, acc[t], 0, 0, 0);
+    }
+#endif
+}
+
+// ---- where a layer's output goes ----------------------------------------------------------------------------------
+struct LayerOut {
+    int lds_off;        // column of the tile the output starts at; < 0: not written to LDS
+    int plain;          // 1: four plain floats per quad (the input of a pooling); 0: operand format (the next layer's input)
+    void *gout;         // optional copy to HBM: (rows x N) feature tensor, nullptr = none
+    long grow0, grows;  // global row of tile row 0, number of global rows
+    int gf16;
+};
+
+__device__ __forceinline__ LayerOut to_tile(int col) { return LayerOut{col, 0, nullptr, 0, 0, 0}; }
+__device__ __forceinline__ LayerOut to_pool(int col) { return LayerOut{col, 1, nullptr, 0, 0, 0}; }
+
+// epilogue of one 16 x 16 sub-tile: this lane's four consecutive channels cb*16 + 4kq + 0..3 of tile row `row`
+template <int MODE>
+__device__ __forceinline__ void store_quad(float *act, int S, int row, int col, int N, const f32x4 acc, bool relu,
+                                           const LayerOut &o, unsigned &violations)
+{
+    float4 v{acc[0], acc[1], acc[2], acc[3]};
+    if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+    // an output that also goes to HBM as fp16 continues in the tile AS STORED (rounded to fp16): a fused pair of layers
+    // then computes exactly what the two separate launches would (and an fp16 value is an exact operand: no split)
+    uint2 stored{0u, 0u};
+    if (o.gout && o.gf16) {
+        const half2v a = half2v{(_Float16)v.x, (_Float16)v.y}, b = half2v{(_Float16)v.z, (_Float16)v.w};
+        stored = uint2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+    }
+    if (o.lds_off >= 0) {
+        const int word = row * S + o.lds_off + col;
+        if (o.plain) quad_store(act, word, __builtin_bit_cast(uint4, v));
+        else if (o.gout && o.gf16) quad_store(act, word, quad_of_halves(stored));
+        else quad_store(act, word, pack_quad<MODE>(v, violations));          // columns >= N hold relu(0 + 0) = 0: the next layer's K padding
+    }
+    if (o.gout) {
+        const long gr = o.grow0 + row;
+        if (gr < o.grows) {
+            if (col + 3 < N && (N & 3) == 0) {
+                if (o.gf16) *reinterpret_cast<uint2 *>(reinterpret_cast<_Float16 *>(o.gout) + gr * N + col) = stored;
+                else *reinterpret_cast<float4 *>(reinterpret_cast<float *>(o.gout) + gr * N + col) = v;
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+                for (int r = 0; r < 4; ++r)
+                    if (col + r < N) feat_store(o.gout, gr * N + col + r, e[r], o.gf16);
+            }
+        }
+    }
+}
+
+// ---- one dense layer on the block's tile ---------------------------------------------------
+// D[TILE x Np] = relu?(A[TILE x Kp] * W + bias).  The tile is cut into 16x16 output sub-tiles; wave w owns row block
+// (w % RB) and every (4/RB)-th column block, keeps its <= 4 accumulators in registers over the whole K loop, and
+// streams its columns of W from L2 in packed fragment order (one contiguous 1 KiB load per wave-instruction,
+// prefetched one step ahead):
+//     w_packed[((cb*KS + ks)*64 + lane)*4 + s] = W[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)]
+// A comes from LDS, one 16-byte quad per lane per 16 k's.  Layers run IN PLACE on the tile: barrier after the
+// K loop (every wave has finished reading A), write D, barrier.
+template <int TILE, int MAXT, int MODE>
+__device__ __forceinline__ void dense_t(float *act, int S, int in_off, const elo_dense &L, const LayerOut &out, unsigned &violations)
+{
+    typedef typename WFrag<MODE>::type W_t;
     constexpr int RB = TILE / 16;                 // row blocks: 1 or 2
     constexpr int CSTEP = FUSED_WAVES / RB;       // column-block stride between a wave's sub-tiles
     // 16-k blocks per prefetch group (register budget: 2*GS*MAXT float4).  Half of what it was before the MFMAs moved to
@@ -149,7 +300,7 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
     // more than the deeper prefetch did (+5 % at 8 lanes, +12 % at batch 8, -1 % at one lane).
     constexpr int GS = MAXT >= 4 ? 1 : 2;
     // the wave index as a SCALAR: row block, column blocks and with them every W / bias base address live in SGPRs,
-    // so a W fragment load is `global_load_dwordx4 v, v_lane_off, s[base] offset:imm` with no vector address arithmetic
+    // so a W fragment load is `buffer_load_dwordx4 v, v_lane_off, s[rsrc], s_off` with no vector address arithmetic
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     const int rb = wave % RB, cb0 = wave / RB;
@@ -158,12 +309,12 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
     f32x4 acc[MAXT];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-        const float bv = L.bias[min(cb0 + t * CSTEP, CB - 1) * 16 + i16];
-        acc[t] = f32x4{bv, bv, bv, bv};
+        const float4 bv = *reinterpret_cast<const float4 *>(L.bias + min(cb0 + t * CSTEP, CB - 1) * 16 + 4 * kq);
+        acc[t] = f32x4{bv.x, bv.y, bv.z, bv.w};
     }
     const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
     const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);      // buffer addressing: V# + lane offset + scalar offset
-    const unsigned lane_off = (unsigned)lane * WFrag<HALF>::LANE_BYTES;
+    const unsigned lane_off = (unsigned)lane * WFrag<MODE>::LANE_BYTES;
 
     // W is streamed from L2 with a load-to-use distance of one whole group of K steps (two register sets).
     // Loads are UNCONDITIONAL (indices clamped into the packed array): with per-lane predicates around them the
@@ -177,18 +328,18 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 const int cb = min(cb0 + t * CSTEP, CB - 1);
-                buf[s][t] = frag_load<HALF>(wrsrc, lane_off, (cb * KS + ks) * WFrag<HALF>::BLOCK_BYTES);
+                buf[s][t] = frag_load<MODE>(wrsrc, lane_off, (cb * KS + ks) * WFrag<MODE>::BLOCK_BYTES);
             }
         }
     };
     auto compute = [&](int g, const W_t (&buf)[GS][MAXT]) {
-        float4 a[GS];
+        uint4 a[GS];
 #pragma unroll
-        for (int s = 0; s < GS; ++s) a[s] = *reinterpret_cast<const float4 *>(arow + min(g * GS + s, KS - 1) * 16);
+        for (int s = 0; s < GS; ++s) a[s] = *reinterpret_cast<const uint4 *>(arow + min(g * GS + s, KS - 1) * 16);
 #pragma unroll
         for (int s = 0; s < GS; ++s) {
             if (g * GS + s >= KS) break;
-            mma_block<MAXT>(acc, a[s], buf[s]);
+            mma_block<MODE, MAXT>(acc, a[s], buf[s]);
         }
     };
     W_t b0[GS][MAXT], b1[GS][MAXT];
@@ -202,30 +353,22 @@ __device__ __forceinline__ void dense_t(float *act, int S, int in_off, int out_o
         }
     }
     __syncthreads();                               // all A reads done: the tile may be overwritten
-    // C/D layout of a 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + r
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         const int cb = cb0 + t * CSTEP;
-        if (cb < CB) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[t][r];
-                if (L.relu) v = fmaxf(v, 0.0f);
-                act[(rb * 16 + kq * 4 + r) * S + out_off + cb * 16 + i16] = v;
-            }
-        }
+        if (cb < CB) store_quad<MODE>(act, S, rb * 16 + i16, cb * 16 + 4 * kq, L.N, acc[t], L.relu, out, violations);
     }
     __syncthreads();
 }
 
-template <int TILE, bool HALF>
-__device__ __forceinline__ void dense(float *act, int S, int in_off, int out_off, const elo_dense &L)
+template <int TILE, int MODE>
+__device__ __forceinline__ void dense(float *act, int S, int in_off, const elo_dense &L, const LayerOut &out, unsigned &violations)
 {
     constexpr int CSTEP = FUSED_WAVES / (TILE / 16);
     const int per_wave = ((ceil16(L.N) >> 4) + CSTEP - 1) / CSTEP;      // sub-tiles per wave, <= 4 for N <= 128
-    if (per_wave <= 1) dense_t<TILE, 1, HALF>(act, S, in_off, out_off, L);
-    else if (per_wave <= 2) dense_t<TILE, 2, HALF>(act, S, in_off, out_off, L);
-    else dense_t<TILE, 4, HALF>(act, S, in_off, out_off, L);
+    if (per_wave <= 1) dense_t<TILE, 1, MODE>(act, S, in_off, L, out, violations);
+    else if (per_wave <= 2) dense_t<TILE, 2, MODE>(act, S, in_off, L, out, violations);
+    else dense_t<TILE, 4, MODE>(act, S, in_off, L, out, violations);
 }
 
 // ---- the same layer with compile-time widths and a cross-layer prefetch (cost-volume kernels) -------------
@@ -239,44 +382,42 @@ struct Sub {                                          // sub-tiles per wave, K s
     static constexpr int GS = MAXT >= 4 ? 1 : 2;
 };
 
-template <int TILE, int N, bool HALF>
+template <int TILE, int N, int MODE>
 struct Pre {
-    typename WFrag<HALF>::type w[Sub<TILE, N>::GS][Sub<TILE, N>::MAXT];
-    float b[Sub<TILE, N>::MAXT];
+    typename WFrag<MODE>::type w[Sub<TILE, N>::GS][Sub<TILE, N>::MAXT];
+    float4 b[Sub<TILE, N>::MAXT];
 };
 
-template <int TILE, int N, bool HALF>
-__device__ __forceinline__ void prefetch(const elo_dense &L, Pre<TILE, N, HALF> &pre)
+template <int TILE, int N, int MODE>
+__device__ __forceinline__ void prefetch(const elo_dense &L, Pre<TILE, N, MODE> &pre)
 {
     constexpr int RB = TILE / 16, CSTEP = Sub<TILE, N>::CSTEP, MAXT = Sub<TILE, N>::MAXT, GS = Sub<TILE, N>::GS;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i16 = lane & 15, cb0 = wave / RB;
+    const int kq = lane >> 4, cb0 = wave / RB;
     const int KS = ceil16(L.K) >> 4;
     constexpr int CB = (N + 15) / 16;
     const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);      // buffer addressing: V# + lane offset + scalar offset
-    const unsigned lane_off = (unsigned)lane * WFrag<HALF>::LANE_BYTES;
+    const unsigned lane_off = (unsigned)lane * WFrag<MODE>::LANE_BYTES;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         const int cb = cb0 + t * CSTEP;
         const int cbc = min(cb, CB - 1);
-        pre.b[t] = L.bias[cbc * 16 + i16];
+        pre.b[t] = *reinterpret_cast<const float4 *>(L.bias + cbc * 16 + 4 * kq);
 #pragma unroll
         for (int s = 0; s < GS; ++s)
-            pre.w[s][t] = frag_load<HALF>(wrsrc, lane_off, (cbc * KS + min(s, KS - 1)) * WFrag<HALF>::BLOCK_BYTES);
+            pre.w[s][t] = frag_load<MODE>(wrsrc, lane_off, (cbc * KS + min(s, KS - 1)) * WFrag<MODE>::BLOCK_BYTES);
     }
 }
 
 // layer with width N; NEXT = width of the following layer (0 = none)
-template <int TILE, int N, int NEXT, bool HALF>
-__device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_off, const elo_dense &L,
-                                         const Pre<TILE, N, HALF> &pre, const elo_dense *next,
-                                         Pre<TILE, NEXT ? NEXT : 16, HALF> *next_pre)
+template <int TILE, int N, int NEXT, int MODE>
+__device__ __forceinline__ void dense_pf(float *act, int S, int in_off, const LayerOut &out, const elo_dense &L,
+                                         const Pre<TILE, N, MODE> &pre, const elo_dense *next,
+                                         Pre<TILE, NEXT ? NEXT : 16, MODE> *next_pre, unsigned &violations)
 {
-    typedef typename WFrag<HALF>::type W_t;
+    typedef typename WFrag<MODE>::type W_t;
     constexpr int RB = TILE / 16, CSTEP = Sub<TILE, N>::CSTEP, MAXT = Sub<TILE, N>::MAXT, GS = Sub<TILE, N>::GS;
     constexpr int CB = (N + 15) / 16;
-    // the wave index as a SCALAR: row block, column blocks and with them every W / bias base address live in SGPRs,
-    // so a W fragment load is `global_load_dwordx4 v, v_lane_off, s[base] offset:imm` with no vector address arithmetic
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     const int rb = wave % RB, cb0 = wave / RB;
@@ -284,14 +425,11 @@ __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_
     const int NG = (KS + GS - 1) / GS;
     f32x4 acc[MAXT];
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = f32x4{pre.b[t], pre.b[t], pre.b[t], pre.b[t]};
+    for (int t = 0; t < MAXT; ++t) acc[t] = f32x4{pre.b[t].x, pre.b[t].y, pre.b[t].z, pre.b[t].w};
     const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
     const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);      // buffer addressing: V# + lane offset + scalar offset
-    const unsigned lane_off = (unsigned)lane * WFrag<HALF>::LANE_BYTES;
-    // Loads are UNCONDITIONAL (indices clamped into the packed array): with per-lane predicates around them the
-    // compiler loses track of the outstanding loads and waits vmcnt(0) before every MFMA group, which serialises
-    // "prefetch" and compute (measured: 6.5 us for a 128x128 layer whose MFMAs take 1.7 us).  Clamped duplicates are
-    // never used: steps past KS are skipped by a scalar branch, sub-tiles past CB are computed but not stored.
+    const unsigned lane_off = (unsigned)lane * WFrag<MODE>::LANE_BYTES;
+    // Loads are UNCONDITIONAL (indices clamped into the packed array), see dense_t
     auto fetch = [&](int g, W_t (&buf)[GS][MAXT]) {
 #pragma unroll
         for (int s = 0; s < GS; ++s) {
@@ -299,18 +437,18 @@ __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 const int cb = min(cb0 + t * CSTEP, CB - 1);
-                buf[s][t] = frag_load<HALF>(wrsrc, lane_off, (cb * KS + ks) * WFrag<HALF>::BLOCK_BYTES);
+                buf[s][t] = frag_load<MODE>(wrsrc, lane_off, (cb * KS + ks) * WFrag<MODE>::BLOCK_BYTES);
             }
         }
     };
     auto compute = [&](int g, const W_t (&buf)[GS][MAXT]) {
-        float4 a[GS];
+        uint4 a[GS];
 #pragma unroll
-        for (int s = 0; s < GS; ++s) a[s] = *reinterpret_cast<const float4 *>(arow + min(g * GS + s, KS - 1) * 16);
+        for (int s = 0; s < GS; ++s) a[s] = *reinterpret_cast<const uint4 *>(arow + min(g * GS + s, KS - 1) * 16);
 #pragma unroll
         for (int s = 0; s < GS; ++s) {
             if (g * GS + s >= KS) break;
-            mma_block<MAXT>(acc, a[s], buf[s]);
+            mma_block<MODE, MAXT>(acc, a[s], buf[s]);
         }
     };
     W_t b0[GS][MAXT], b1[GS][MAXT];
@@ -326,19 +464,12 @@ __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, int out_
             compute(g + 1, b1);
         }
     }
-    if (NEXT) prefetch<TILE, NEXT ? NEXT : 16, HALF>(*next, *next_pre);              // rides behind the two barriers
+    if (NEXT) prefetch<TILE, NEXT ? NEXT : 16, MODE>(*next, *next_pre);              // rides behind the two barriers
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         const int cb = cb0 + t * CSTEP;
-        if (cb < CB) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[t][r];
-                if (L.relu) v = fmaxf(v, 0.0f);
-                act[(rb * 16 + kq * 4 + r) * S + out_off + cb * 16 + i16] = v;
-            }
-        }
+        if (cb < CB) store_quad<MODE>(act, S, rb * 16 + i16, cb * 16 + 4 * kq, N, acc[t], L.relu, out, violations);
     }
     __syncthreads();
 }
@@ -432,28 +563,20 @@ __device__ __forceinline__ void group_tile(const TileMeta &m, int *lds_off, unsi
     __syncthreads();
 }
 
-__device__ __forceinline__ float geo_channel(const float *p, const float *g, float m, int ch)
-{   // [p, g*m, g*m - p, sqrt(sum((g*m-p)^2) + 1e-20)]   utils/pointnet_util.py:54-62
-    float gm[3], d[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { gm[i] = g[i] * m; d[i] = gm[i] - p[i]; }
-    if (ch < 3) return p[ch];
-    if (ch < 6) return gm[ch - 3];
-    if (ch < 9) return d[ch - 6];
-    return sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + 1e-20f);
-}
 
 // ---- staging a tile's rows: vector loads, ALL requested before the first LDS write --------------------------
-// A segment = W consecutive floats of one global row per tile row (W % 4 == 0, 16-byte aligned), written to
-// act[row*S + col0 ..) times a per-row scale (the mask), zeros for rows not in use.  A thread owns the 16-byte items
-// tid, tid+256, ... of the TILE*(W/4) of a segment; the segments of a gather are loaded back to back and stored
-// afterwards, so the whole gather is ONE round trip to L2.  (The element-per-thread loops this replaces had their
-// load under a condition, which costs a full s_waitcnt vmcnt(0) per iteration: 4...13 dependent round trips per tile.)
-constexpr int SEG_ITEMS = 4;                        // per thread: TILE(32) * W(128) / 4 / FUSED_BLOCK
+// A segment = W consecutive elements of one global feature row per tile row (fp32: W % 4 == 0, fp16: W % 8 == 0,
+// rows 16-byte aligned), written to the tile's columns [col0, col0 + W) in operand format where the row's mask says so,
+// zeros for masked rows and rows not in use.  A thread owns the 16-byte items tid, tid+256, ... of a segment; the
+// segments of a gather are loaded back to back and stored afterwards, so the whole gather is ONE round trip to L2.
+// (The element-per-thread loops this replaces had their load under a condition, which costs a full s_waitcnt vmcnt(0)
+// per iteration: 4...13 dependent round trips per tile.)
+constexpr int SEG_ITEMS = 4;                        // per thread: TILE(32) * W(128) * 4 bytes / 16 / FUSED_BLOCK
 
-__device__ __forceinline__ bool seg_ok(const void *p, int W, int rows)
+__device__ __forceinline__ bool seg_ok(const void *p, int W, int rows, int f16)
 {
-    return W > 0 && (W & 3) == 0 && ((uintptr_t)p & 15) == 0 && rows * (W >> 2) <= SEG_ITEMS * FUSED_BLOCK;
+    const int per = f16 ? 8 : 4;
+    return W > 0 && W % per == 0 && ((uintptr_t)p & 15) == 0 && rows * (W / per) <= SEG_ITEMS * FUSED_BLOCK;
 }
 
 __device__ __forceinline__ void seg_split(int it, int q, int &row, int &c4)
@@ -464,48 +587,59 @@ __device__ __forceinline__ void seg_split(int it, int q, int &row, int &c4)
 
 // rowof(row) -> source row (long), negative = row not in use (the load then reads source row 0 and is dropped)
 template <int TILE, class RowOf>
-__device__ __forceinline__ void seg_load(float4 (&r)[SEG_ITEMS], const float *__restrict__ src, int W, RowOf rowof)
+__device__ __forceinline__ void seg_load(uint4 (&r)[SEG_ITEMS], const void *__restrict__ src, int W, int f16, RowOf rowof)
 {
-    const int q = W >> 2, items = TILE * q;
+    const int q = W >> (f16 ? 3 : 2), items = TILE * q;
 #pragma unroll
     for (int u = 0; u < SEG_ITEMS; ++u) {
         const int it = threadIdx.x + u * FUSED_BLOCK < items ? threadIdx.x + u * FUSED_BLOCK : items - 1;
         int row, c4;
         seg_split(it, q, row, c4);
         const long sr = rowof(row);
-        r[u] = reinterpret_cast<const float4 *>(src + (sr < 0 ? 0 : sr) * W)[c4];
+        r[u] = reinterpret_cast<const uint4 *>(src)[(sr < 0 ? 0 : sr) * q + c4];
     }
 }
 
-template <int TILE, class RowOf, class ScaleOf>
-__device__ __forceinline__ void seg_store(float *act, int S, int col0, int W, const float4 (&r)[SEG_ITEMS], RowOf rowof,
-                                          ScaleOf scaleof)
+// keepof(row): the row's mask as a bool (masks are 0/1: x * mask is a select)
+template <int TILE, int MODE, class RowOf, class KeepOf>
+__device__ __forceinline__ void seg_store(float *act, int S, int col0, int W, int f16, const uint4 (&r)[SEG_ITEMS], RowOf rowof,
+                                          KeepOf keepof, unsigned &violations)
 {
-    const int q = W >> 2, items = TILE * q;
+    const int q = W >> (f16 ? 3 : 2), items = TILE * q;
 #pragma unroll
     for (int u = 0; u < SEG_ITEMS; ++u) {
         const int it = threadIdx.x + u * FUSED_BLOCK;
         if (it < items) {
             int row, c4;
             seg_split(it, q, row, c4);
-            const bool used = rowof(row) >= 0;
-            const float sc = scaleof(row);
-            float *o = act + row * S + col0 + 4 * c4;
-            o[0] = used ? r[u].x * sc : 0.0f; o[1] = used ? r[u].y * sc : 0.0f;
-            o[2] = used ? r[u].z * sc : 0.0f; o[3] = used ? r[u].w * sc : 0.0f;
+            const bool keep = rowof(row) >= 0 && keepof(row);
+            const uint4 z{0u, 0u, 0u, 0u};
+            if (f16) {
+                const int word = row * S + col0 + 8 * c4;
+                quad_store(act, word, keep ? quad_of_halves(uint2{r[u].x, r[u].y}) : z);
+                quad_store(act, word + 4, keep ? quad_of_halves(uint2{r[u].z, r[u].w}) : z);
+            } else {
+                quad_store(act, row * S + col0 + 4 * c4, keep ? pack_quad<MODE>(__builtin_bit_cast(float4, r[u]), violations) : z);
+            }
         }
     }
 }
 
-// zero the padding columns [from, to) of every tile row
-template <int TILE>
+// zero the columns [from, to) of every tile row (from, to multiples of 4: whole quads; else element-wise)
+template <int TILE, int MODE>
 __device__ __forceinline__ void zero_cols(float *act, int S, int from, int to)
 {
-    const int w = to - from;
-    for (int e = threadIdx.x; e < TILE * w; e += FUSED_BLOCK) act[(e / w) * S + from + e % w] = 0.0f;
+    if (((from | to) & 3) == 0) {
+        const int w = (to - from) >> 2;
+        for (int e = threadIdx.x; e < TILE * w; e += FUSED_BLOCK) quad_store(act, (e / w) * S + from + 4 * (e % w), uint4{0u, 0u, 0u, 0u});
+    } else {
+        const int w = to - from;
+        unsigned none = 0;
+        for (int e = threadIdx.x; e < TILE * w; e += FUSED_BLOCK) act_put<MODE>(act, (e / w) * S + from + e % w, 0.0f, none);
+    }
 }
 
-// the 10 geometry floats of a row (PAD: + 6 zeros): [p, g*m, g*m - p, |g*m - p|]   utils/pointnet_util.py:54-62.
+// the 10 geometry floats of a row + 6 zeros: [p, g*m, g*m - p, |g*m - p|]   utils/pointnet_util.py:54-62.
 // Thread r < TILE loads its row's centre p and neighbour g (unconditional, clamped) -- call geo_load with the other
 // loads of the gather, geo_store with the stores.
 struct GeoRow { float p[3], g[3]; };
@@ -515,25 +649,25 @@ __device__ __forceinline__ GeoRow geo_load(const float *__restrict__ pc, const f
     return GeoRow{{pc[0], pc[1], pc[2]}, {pg[0], pg[1], pg[2]}};
 }
 
-template <bool PAD>
-__device__ __forceinline__ void geo_store(float *o, const GeoRow &r, float m, bool used)
+// four quads at word `word`: the 10 geometry channels and the K padding of a 16-k block
+template <int MODE>
+__device__ __forceinline__ void geo_store(float *act, int word, const GeoRow &r, float m, bool used, unsigned &violations)
 {
     const float g0 = r.g[0] * m, g1 = r.g[1] * m, g2 = r.g[2] * m;
     const float d0 = g0 - r.p[0], d1 = g1 - r.p[1], d2 = g2 - r.p[2];
-    const float v[10] = {r.p[0], r.p[1], r.p[2], g0, g1, g2, d0, d1, d2, sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + 1e-20f)};
-#pragma unroll
-    for (int i = 0; i < 10; ++i) o[i] = used ? v[i] : 0.0f;
-    if (PAD) {
-#pragma unroll
-        for (int i = 10; i < 16; ++i) o[i] = 0.0f;
-    }
+    const float e = sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + 1e-20f);
+    const uint4 z{0u, 0u, 0u, 0u};
+    quad_store(act, word, used ? pack_quad<MODE>(float4{r.p[0], r.p[1], r.p[2], g0}, violations) : z);
+    quad_store(act, word + 4, used ? pack_quad<MODE>(float4{g1, g2, d0, d1}, violations) : z);
+    quad_store(act, word + 8, used ? pack_quad<MODE>(float4{d2, e, 0.0f, 0.0f}, violations) : z);
+    quad_store(act, word + 12, z);
 }
 
 // ---- poolings over the K rows of each point of the tile (one (point, channel) per thread) ------
 // The K rows of a point are fetched in chunks of 8 INDEPENDENT LDS reads (a serial "read mask -> branch -> read
-// value" chain cost ~0.3 us per neighbour, 7 us per cost-volume tile).
+// value" chain cost ~0.3 us per neighbour, 7 us per cost-volume tile).  `off` names a PLAIN fp32 region.
 __device__ __forceinline__ void pool_masked_max(const float *act, int S, int off, int C, const TileMeta &m, int P, int K,
-                                                long first_point, long total_points, float *__restrict__ out)
+                                                long first_point, long total_points, void *__restrict__ out, int f16)
 {
     for (int q = threadIdx.x; q < P * C; q += FUSED_BLOCK) {
         const int pi = q / C, c = q - pi * C;
@@ -553,24 +687,26 @@ __device__ __forceinline__ void pool_masked_max(const float *act, int S, int off
 #pragma unroll
             for (int u = 0; u < 8; ++u) best = fmaxf(best, v[u] * w[u]);
         }
-        out[pt * C + c] = best;
+        feat_store(out, pt * C + c, best, f16);
     }
 }
 
 // out = sum_k softmax_k(mask == 1 ? logit : -1e10) * value      (64 channels), one pass (online softmax)
 // e^x on the hardware exp2 (v_exp_f32: ~1 ulp), a fifth of the instructions of expf's range-reduced polynomial; the
 // pooled softmax weights feed a convex combination, far inside the 1e-4 parity tolerance.
+// logits: a PLAIN fp32 region; values: an OPERAND-format region (they were a layer's input).
 __device__ __forceinline__ float exp_hw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896f); }
 
 __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int logit_off, int value_off,
                                                     const TileMeta &m, int P, int K, long first_point,
-                                                    long total_points, float *__restrict__ out)
+                                                    long total_points, void *__restrict__ out, int f16)
 {
     for (int q = threadIdx.x; q < P * 64; q += FUSED_BLOCK) {
         const int pi = q >> 6, c = q & 63;
         const long pt = first_point + pi;
         if (pt >= total_points) continue;
-        const float *lcol = act + (pi * K) * S + logit_off + c, *vcol = act + (pi * K) * S + value_off + c;
+        const float *lcol = act + (pi * K) * S + logit_off + c;
+        const int vword = (pi * K) * S + value_off + c;
         const float *mk = m.mask + pi * K;
         float mx = -INFINITY, den = 0.0f, acc = 0.0f;
         for (int k0 = 0; k0 < K; k0 += 8) {
@@ -579,7 +715,7 @@ __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int
             for (int u = 0; u < 8; ++u) {
                 const int k = min(k0 + u, K - 1);
                 l[u] = lcol[k * S];
-                v[u] = vcol[k * S];
+                v[u] = act_get(act, vword + k * S);
                 w[u] = mk[k];
             }
 #pragma unroll
@@ -598,7 +734,7 @@ __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int
                 }
             }
         }
-        out[pt * 64 + c] = acc / den;
+        feat_store(out, pt * 64 + c, acc / den, f16);
     }
 }
 
@@ -608,10 +744,11 @@ __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int
 template <typename Args>
 struct JobPair { Args job[2]; };                  // one kernarg block: job[blockIdx.y] is a uniform (scalar) access
 
+// LDS columns: [0, C) gathered features * mask, [C, C+3) gathered xyz * mask - centre, zeros up to ceil16(3 + C).
 // 5 waves per SIMD (<= 102 VGPRs).  History: 140 VGPRs uncapped (3 workgroups per CU); a cap of 4 cost 12 bytes of
 // scratch and gave +4 % at batch 8; with the scalar wave index and buffer-addressed W fragments the kernels need 92-96
 // VGPRs without any spill.  A cap of 6 (80 VGPRs) spills 36-144 bytes in the cost-volume kernels: not taken.
-template <int TILE, bool HALF>
+template <int TILE, int MODE>
 __global__ __launch_bounds__(FUSED_BLOCK, 5) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
 {
     const elo_setconv_args &a = jobs.job[blockIdx.y];
@@ -619,7 +756,8 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void setconv_kernel(const JobPair<e
     float *act = lds;
     const TileMeta meta = tile_meta(lds, TILE, S);
     const int tid = threadIdx.x;
-    const int K = a.K, P = TILE / K;
+    const int K = a.K, P = TILE / K, f16 = a.feat_dtype == ELO_F16;
+    unsigned bad = 0;
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     if (first_point >= total_points) return;
@@ -648,17 +786,24 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void setconv_kernel(const JobPair<e
         __syncthreads();
     }
     // gather + centre-subtract + concat into act[row][0 .. CTp)                   :203-213 / :277-284
-    const int CT = 3 + a.C, CTp = ceil16(CT);
-    if (seg_ok(a.src_feat, a.C, TILE)) {
+    const int C = a.C, CT = 3 + C, CTp = ceil16(CT);
+    if (seg_ok(a.src_feat, C, TILE, f16)) {
         auto cell_of = [&](int row) { return (long)meta.cell[row]; };
-        float4 rf[SEG_ITEMS];
-        seg_load<TILE>(rf, a.src_feat, a.C, cell_of);
-        float xyz = 0.0f;
-        const int xr = tid / 3, xc = tid - xr * 3;                           // thread t < 3*TILE: one coordinate of row t/3
-        if (tid < TILE * 3) xyz = a.src_xyz[(long)(meta.cell[xr] < 0 ? 0 : meta.cell[xr]) * 3 + xc];
-        seg_store<TILE>(act, S, 3, a.C, rf, cell_of, [&](int row) { return meta.mask[row]; });
-        if (tid < TILE * 3) act[xr * S + xc] = meta.cell[xr] >= 0 ? xyz * meta.mask[xr] - meta.cxyz[(xr / K) * 3 + xc] : 0.0f;
-        zero_cols<TILE>(act, S, CT, CTp);
+        uint4 rf[SEG_ITEMS];
+        seg_load<TILE>(rf, a.src_feat, C, f16, cell_of);
+        float x = 0.0f, y = 0.0f, z = 0.0f;
+        if (tid < TILE) {                                                     // thread t < TILE: the xyz quad of row t
+            const float *p = a.src_xyz + (long)(meta.cell[tid] < 0 ? 0 : meta.cell[tid]) * 3;
+            x = p[0]; y = p[1]; z = p[2];
+        }
+        seg_store<TILE, MODE>(act, S, 0, C, f16, rf, cell_of, [&](int row) { return meta.mask[row] != 0.0f; }, bad);
+        if (tid < TILE) {
+            const float m = meta.mask[tid];
+            const float *c = meta.cxyz + (tid / K) * 3;
+            const float4 d{x * m - c[0], y * m - c[1], z * m - c[2], 0.0f};
+            quad_store(act, tid * S + C, meta.cell[tid] >= 0 ? pack_quad<MODE>(d, bad) : uint4{0u, 0u, 0u, 0u});
+        }
+        zero_cols<TILE, MODE>(act, S, C + 4, CTp);
     } else {
         for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {
             const int row = e / CTp, ch = e - row * CTp;
@@ -666,15 +811,17 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void setconv_kernel(const JobPair<e
             float v = 0.0f;
             if (cell >= 0 && ch < CT) {
                 const float m = meta.mask[row];
-                v = ch < 3 ? a.src_xyz[(long)cell * 3 + ch] * m - meta.cxyz[(row / K) * 3 + ch]
-                           : a.src_feat[(long)cell * a.C + (ch - 3)] * m;
+                v = ch < C ? feat_load(a.src_feat, (long)cell * C + ch, f16) * m
+                           : a.src_xyz[(long)cell * 3 + (ch - C)] * m - meta.cxyz[(row / K) * 3 + (ch - C)];
             }
-            act[row * S + ch] = v;
+            act_put<MODE>(act, row * S + ch, v, bad);
         }
     }
     __syncthreads();
-    for (int l = 0; l < a.n_layers; ++l) dense<TILE, HALF>(act, S, 0, 0, a.layers[l]);    // in place, :217-222
-    pool_masked_max(act, S, 0, a.layers[a.n_layers - 1].N, meta, P, K, first_point, total_points, a.out);   // :224-230
+    for (int l = 0; l < a.n_layers; ++l)                                       // in place, :217-222
+        dense<TILE, MODE>(act, S, 0, a.layers[l], l == a.n_layers - 1 ? to_pool(0) : to_tile(0), bad);
+    pool_masked_max(act, S, 0, a.layers[a.n_layers - 1].N, meta, P, K, first_point, total_points, a.out, f16);   // :224-230
+    report_violations<MODE>(bad);
 }
 
 
@@ -802,15 +949,23 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
     }
     if (live && gs.mask_out) gs.mask_out[pt * G + lane] = m;
 
-    // ---- gather + centre-subtract + concat, then the MLP in registers (:203-222)
+    // ---- gather + centre-subtract + concat [features | xyz difference], then the MLP in registers (:203-222)
     float x[32], y[32];
-    const float *sx = a.src_xyz + cell * 3, *sf = a.src_feat + cell * C;
+    const int f16 = a.feat_dtype == ELO_F16;
+    const float *sx = a.src_xyz + cell * 3;
     const float s0 = sx[0], s1 = sx[1], s2 = sx[2];
+    if (f16) {
+        const _Float16 *sf = reinterpret_cast<const _Float16 *>(a.src_feat) + cell * C;
 #pragma unroll
-    for (int c = 0; c < C; ++c) x[3 + c] = sf[c];              // all of the row's loads go out before the first use
-    x[0] = s0 * m - cx; x[1] = s1 * m - cy; x[2] = s2 * m - cz;
+        for (int c = 0; c < C; ++c) x[c] = (float)sf[c];
+    } else {
+        const float *sf = reinterpret_cast<const float *>(a.src_feat) + cell * C;
 #pragma unroll
-    for (int c = 0; c < C; ++c) x[3 + c] *= m;
+        for (int c = 0; c < C; ++c) x[c] = sf[c];               // all of the row's loads go out before the first use
+    }
+    x[C + 0] = s0 * m - cx; x[C + 1] = s1 * m - cy; x[C + 2] = s2 * m - cz;
+#pragma unroll
+    for (int c = 0; c < C; ++c) x[c] *= m;
     __syncthreads();                                          // weights staged (issued first, needed only now)
     small_layer<CIN, N1>(x, y, wsm + W1, wsm + B1, a.layers[0].relu);
     small_layer<N1, N2>(y, x, wsm + W2, wsm + B2, a.layers[1].relu);
@@ -819,103 +974,104 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
 #pragma unroll
     for (int c = 0; c < N3; ++c) y[c] = half_wave_max(y[c] * m);
     if (live && lane == G - 1) {
-        float4 *o = reinterpret_cast<float4 *>(a.out + pt * N3);
 #pragma unroll
-        for (int c = 0; c < N3; c += 4) o[c / 4] = float4{y[c], y[c + 1], y[c + 2], y[c + 3]};
+        for (int c = 0; c < N3; c += 4) feat_store4(a.out, pt * N3 + c, float4{y[c], y[c + 1], y[c + 2], y[c + 3]}, f16);
     }
 }
 
 // ================================================================ row-wise MLP over concatenated sources
-template <int TILE, bool HALF>
+// stage 1: columns [0, w0 + w1 + w2) = the sources; its last layer writes `out` to HBM straight from the accumulators
+// and, with a second stage, to columns [0, N) of the tile; stage 2: [out (N) | before | after] -> layers2 -> out2.
+template <int TILE, int MODE>
 __global__ __launch_bounds__(FUSED_BLOCK, 5) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
 {
     const elo_mlp_args &a = jobs.job[blockIdx.y];
     extern __shared__ float lds[];
     float *act = lds;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, f16 = a.feat_dtype == ELO_F16;
+    unsigned bad = 0;
     const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * TILE;
     if (first >= a.rows) return;
+    auto row_of = [&](int row) { return first + row < a.rows ? first + row : -1L; };
+    auto all = [](int) { return true; };
     const int w0 = a.src_width[0], w1 = a.n_sources > 1 ? a.src_width[1] : 0, w2 = a.n_sources > 2 ? a.src_width[2] : 0;
     const int CT = w0 + w1 + w2, CTp = ceil16(CT);
-    if (seg_ok(a.src[0], w0, TILE) && (w1 == 0 || seg_ok(a.src[1], w1, TILE)) && (w2 == 0 || seg_ok(a.src[2], w2, TILE))) {
-        auto row_of = [&](int row) { return first + row < a.rows ? first + row : -1L; };
-        auto one = [](int) { return 1.0f; };
-        float4 r0[SEG_ITEMS], r1[SEG_ITEMS], r2[SEG_ITEMS];
-        seg_load<TILE>(r0, a.src[0], w0, row_of);
-        if (w1) seg_load<TILE>(r1, a.src[1], w1, row_of);
-        if (w2) seg_load<TILE>(r2, a.src[2], w2, row_of);
-        seg_store<TILE>(act, S, 0, w0, r0, row_of, one);
-        if (w1) seg_store<TILE>(act, S, w0, w1, r1, row_of, one);
-        if (w2) seg_store<TILE>(act, S, w0 + w1, w2, r2, row_of, one);
-        zero_cols<TILE>(act, S, CT, CTp);
+    if (seg_ok(a.src[0], w0, TILE, f16) && (w1 == 0 || seg_ok(a.src[1], w1, TILE, f16)) && (w2 == 0 || seg_ok(a.src[2], w2, TILE, f16))) {
+        uint4 r0[SEG_ITEMS], r1[SEG_ITEMS], r2[SEG_ITEMS];
+        seg_load<TILE>(r0, a.src[0], w0, f16, row_of);
+        if (w1) seg_load<TILE>(r1, a.src[1], w1, f16, row_of);
+        if (w2) seg_load<TILE>(r2, a.src[2], w2, f16, row_of);
+        seg_store<TILE, MODE>(act, S, 0, w0, f16, r0, row_of, all, bad);
+        if (w1) seg_store<TILE, MODE>(act, S, w0, w1, f16, r1, row_of, all, bad);
+        if (w2) seg_store<TILE, MODE>(act, S, w0 + w1, w2, f16, r2, row_of, all, bad);
+        zero_cols<TILE, MODE>(act, S, CT, CTp);
     } else {
         for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {
             const int row = e / CTp, ch = e - row * CTp;
             const long gr = first + row;
             float v = 0.0f;
             if (gr < a.rows && ch < CT) {
-                v = ch < w0 ? a.src[0][gr * w0 + ch]
-                  : ch < w0 + w1 ? a.src[1][gr * w1 + (ch - w0)]
-                                 : a.src[2][gr * w2 + (ch - w0 - w1)];
+                v = ch < w0 ? feat_load(a.src[0], gr * w0 + ch, f16)
+                  : ch < w0 + w1 ? feat_load(a.src[1], gr * w1 + (ch - w0), f16)
+                                 : feat_load(a.src[2], gr * w2 + (ch - w0 - w1), f16);
             }
-            act[row * S + ch] = v;
+            act_put<MODE>(act, row * S + ch, v, bad);
         }
     }
     __syncthreads();
-    // with a second stage the first stage's LAST layer writes its output at column w_before -- where the second stage's
-    // concat [before | out | after] wants it (the layer's barrier separates its reads at [0, K) from that write)
-    const int shift = a.n_layers2 > 0 ? a.w_before : 0;
-    for (int l = 0; l < a.n_layers; ++l) dense<TILE, HALF>(act, S, 0, l == a.n_layers - 1 ? shift : 0, a.layers[l]);
     const int N = a.layers[a.n_layers - 1].N;
-    for (int e = tid; e < TILE * N; e += FUSED_BLOCK) {
-        const int row = e / N, c = e - row * N;
-        const long gr = first + row;
-        if (gr < a.rows) a.out[gr * N + c] = act[row * S + shift + c];
-    }
-    if (a.n_layers2 <= 0) return;
-    // ---- second stage: [before | out | after] -> layers2 -> out2
-    const int wb = a.w_before, wa = a.w_after, CT2 = wb + N + wa;
-    auto row_of = [&](int row) { return first + row < a.rows ? first + row : -1L; };
-    auto one = [](int) { return 1.0f; };
-    if ((wb == 0 || seg_ok(a.before, wb, TILE)) && (wa == 0 || seg_ok(a.after, wa, TILE))) {
-        float4 rb[SEG_ITEMS], ra[SEG_ITEMS];
-        if (wb) seg_load<TILE>(rb, a.before, wb, row_of);
-        if (wa) seg_load<TILE>(ra, a.after, wa, row_of);
-        if (wb) seg_store<TILE>(act, S, 0, wb, rb, row_of, one);
-        if (wa) seg_store<TILE>(act, S, wb + N, wa, ra, row_of, one);
+    const bool two = a.n_layers2 > 0;
+    for (int l = 0; l < a.n_layers; ++l)
+        dense<TILE, MODE>(act, S, 0, a.layers[l],
+                          l == a.n_layers - 1 ? LayerOut{two ? 0 : -1, 0, a.out, first, a.rows, f16} : to_tile(0), bad);
+    if (!two) { report_violations<MODE>(bad); return; }
+    // ---- second stage: [out | before | after] -> layers2 -> out2       (`out` already sits at columns [0, N))
+    const int wb = a.w_before, wa = a.w_after, CT2 = N + wb + wa;
+    if ((N & 3) == 0 && (wb == 0 || seg_ok(a.before, wb, TILE, f16)) && (wa == 0 || seg_ok(a.after, wa, TILE, f16))) {
+        uint4 rb[SEG_ITEMS], ra[SEG_ITEMS];
+        if (wb) seg_load<TILE>(rb, a.before, wb, f16, row_of);
+        if (wa) seg_load<TILE>(ra, a.after, wa, f16, row_of);
+        if (wb) seg_store<TILE, MODE>(act, S, N, wb, f16, rb, row_of, all, bad);
+        if (wa) seg_store<TILE, MODE>(act, S, N + wb, wa, f16, ra, row_of, all, bad);
     } else {
         for (int e = tid; e < TILE * (wb + wa); e += FUSED_BLOCK) {
             const int row = e / (wb + wa), ch = e - row * (wb + wa);
             const long gr = first + row;
             const long grc = gr < a.rows ? gr : a.rows - 1;
-            const float v = ch < wb ? a.before[grc * wb + ch] : a.after[grc * wa + (ch - wb)];
-            act[row * S + (ch < wb ? ch : N + ch)] = gr < a.rows ? v : 0.0f;
+            const float v = ch < wb ? feat_load(a.before, grc * wb + ch, f16) : feat_load(a.after, grc * wa + (ch - wb), f16);
+            act_put<MODE>(act, row * S + N + ch, gr < a.rows ? v : 0.0f, bad);
         }
     }
-    zero_cols<TILE>(act, S, CT2, ceil16(CT2));
+    zero_cols<TILE, MODE>(act, S, CT2, ceil16(CT2));
     __syncthreads();
-    for (int l = 0; l < a.n_layers2; ++l) dense<TILE, HALF>(act, S, 0, 0, a.layers2[l]);
-    const int N2 = a.layers2[a.n_layers2 - 1].N;
-    for (int e = tid; e < TILE * N2; e += FUSED_BLOCK) {
-        const int row = e / N2, c = e - row * N2;
-        const long gr = first + row;
-        if (gr < a.rows) a.out2[gr * N2 + c] = act[row * S + c];
-    }
+    for (int l = 0; l < a.n_layers2; ++l)
+        dense<TILE, MODE>(act, S, 0, a.layers2[l],
+                          l == a.n_layers2 - 1 ? LayerOut{-1, 0, a.out2, first, a.rows, f16} : to_tile(0), bad);
+    report_violations<MODE>(bad);
 }
 
 // ================================================================ cost volume, stage 1
-// LDS columns: [0,128) = X (CV chain, later [x | enc]); [128, 128 + CTp) = F (feat_cat; its first 16 columns, the
-// geometry, live until CV_xyz); sum_CV_0 then writes its 128 outputs to [64,192) -- over enc, its own input: the
-// layer's barrier separates the reads from the write -- so x at [0,64) survives for the pooling and the tile is
-// max(192, 128 + CTp) columns wide instead of 256 (27.5 KB instead of 35.7 KB at 32 rows: a fifth workgroup per CU).
-template <int TILE, bool HALF>
+// LDS columns: [0,128) = X (CV chain, later [x | enc]); F = 128: [F, F+C) feat1, [F+C, F+2C) feat2[idx]*m,
+// [F+2C, F+2C+10) the geometry [p, q, q-p, |q-p|] and zeros up to the 16-k block boundary (CV_0's input rows are
+// ordered that way by the host; the geometry block alone is CV_xyz's input and lives until then); sum_CV_0 then
+// writes its 128 outputs to [64,192) -- over enc, its own input: the layer's barrier separates the reads from the
+// write -- so x at [0,64) survives for the pooling and the tile is max(192, 128 + 2C + 16) columns wide instead of 256
+// (27.5 KB instead of 35.7 KB at 32 rows: a fifth workgroup per CU).
+__host__ __device__ __forceinline__ int cv1_feat_cols(int C)
+{
+    const int kp = (10 + 2 * C + 15) & ~15;       // CV_0's padded K
+    return kp > 2 * C + 16 ? kp : 2 * C + 16;     // and CV_xyz's 16-k block at 2C
+}
+
+template <int TILE, int MODE>
 __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_kernel(const elo_cv1_args a, const int S)
 {
     extern __shared__ float lds[];
     float *act = lds;
     const TileMeta meta = tile_meta(lds, TILE, S);
     const int tid = threadIdx.x;
-    const int K = a.K, P = TILE / K, C = a.C;
+    const int K = a.K, P = TILE / K, C = a.C, f16 = a.feat_dtype == ELO_F16;
+    unsigned bad = 0;
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     if (first_point >= total_points) return;
@@ -929,71 +1085,59 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_kernel(const elo_cv1_args 
         __syncthreads();
     }
 #if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 1
-    if (tid == 0) a.out[first_point * 64] = meta.mask[0];
+    if (tid == 0) feat_store(a.out, first_point * 64, meta.mask[0], f16);
     return;
 #endif
-    const int F = 128, CT = 10 + 2 * C, CTp = ceil16(CT);
-    if (seg_ok(a.feat1, C, TILE) && seg_ok(a.feat2, C, TILE)) {                                   // :54-66
+    const int F = 128, G = F + 2 * C;                                                             // :54-66
+    {
         auto cell_of = [&](int row) { return (long)meta.cell[row]; };
         auto centre_of = [&](int row) { return meta.cell[row] >= 0 ? first_point + row / K : -1L; };
-        float4 r1[SEG_ITEMS], r2[SEG_ITEMS];
-        seg_load<TILE>(r1, a.feat1, C, centre_of);
-        seg_load<TILE>(r2, a.feat2, C, cell_of);
+        uint4 r1[SEG_ITEMS], r2[SEG_ITEMS];
+        seg_load<TILE>(r1, a.feat1, C, f16, centre_of);
+        seg_load<TILE>(r2, a.feat2, C, f16, cell_of);
         GeoRow gr;
         const bool grow = tid < TILE;
         const int gcell = grow ? meta.cell[tid] : -1;
         if (grow) gr = geo_load(a.xyz1 + (gcell >= 0 ? first_point + tid / K : 0) * 3, a.xyz2 + (long)(gcell >= 0 ? gcell : 0) * 3);
-        seg_store<TILE>(act, S, F + 10, C, r1, centre_of, [](int) { return 1.0f; });
-        seg_store<TILE>(act, S, F + 10 + C, C, r2, cell_of, [&](int row) { return meta.mask[row]; });
-        if (grow) geo_store<false>(act + tid * S + F, gr, meta.mask[tid], gcell >= 0);   // columns [F, F+10)
-        zero_cols<TILE>(act, S, F + CT, F + CTp);
-    } else {
-        for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {
-            const int row = e / CTp, ch = e - row * CTp;
-            const int cell = meta.cell[row];
-            float v = 0.0f;
-            if (cell >= 0 && ch < CT) {
-                const float m = meta.mask[row];
-                const long pt = first_point + row / K;
-                if (ch < 10) v = geo_channel(a.xyz1 + pt * 3, a.xyz2 + (long)cell * 3, m, ch);
-                else if (ch < 10 + C) v = a.feat1[pt * C + (ch - 10)];
-                else v = a.feat2[(long)cell * C + (ch - 10 - C)] * m;
-            }
-            act[row * S + F + ch] = v;
-        }
+        seg_store<TILE, MODE>(act, S, F, C, f16, r1, centre_of, [](int) { return true; }, bad);
+        seg_store<TILE, MODE>(act, S, F + C, C, f16, r2, cell_of, [&](int row) { return meta.mask[row] != 0.0f; }, bad);
+        if (grow) geo_store<MODE>(act, tid * S + G, gr, meta.mask[tid], gcell >= 0, bad);           // columns [G, G+16)
+        zero_cols<TILE, MODE>(act, S, G + 16, F + cv1_feat_cols(C));
     }
-    Pre<TILE, 128, HALF> p128;
-    Pre<TILE, 64, HALF> p64;
-    prefetch<TILE, 128, HALF>(a.cv0, p128);           // in flight while the barrier drains the gather
+    Pre<TILE, 128, MODE> p128;
+    Pre<TILE, 64, MODE> p64;
+    prefetch<TILE, 128, MODE>(a.cv0, p128);           // in flight while the barrier drains the gather
     __syncthreads();
 #if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 2
-    if (tid == 0) a.out[first_point * 64] = act[F] + p128.b[0];
+    if (tid == 0) feat_store(a.out, first_point * 64, act[F] + p128.b[0].x, f16);
     return;
 #endif
-    dense_pf<TILE, 128, 64, HALF>(act, S, F, 0, a.cv0, p128, &a.cv1, &p64);          // feat_cat -> 128          :72-76
-    dense_pf<TILE, 64, 64, HALF>(act, S, 0, 0, a.cv1, p64, &a.cv2, &p64);            // -> 64 (in place)
-    dense_pf<TILE, 64, 64, HALF>(act, S, 0, 0, a.cv2, p64, &a.cv_xyz, &p64);         // -> 64 = x   (values of the pooling)
-    dense_pf<TILE, 64, 128, HALF>(act, S, F, 64, a.cv_xyz, p64, &a.sum_cv0, &p128);  // xyz_cat -> enc at [64,128)   :79-82
-    dense_pf<TILE, 128, 64, HALF>(act, S, 0, 64, a.sum_cv0, p128, &a.sum_cv1, &p64); // [x | enc] -> 128 at [64,192): over enc, x stays  :84-90
-    dense_pf<TILE, 64, 0, HALF>(act, S, 64, 64, a.sum_cv1, p64, nullptr, nullptr);   // -> 64 logits at [64,128) (in place)
+    dense_pf<TILE, 128, 64, MODE>(act, S, F, to_tile(0), a.cv0, p128, &a.cv1, &p64, bad);          // feat_cat -> 128          :72-76
+    dense_pf<TILE, 64, 64, MODE>(act, S, 0, to_tile(0), a.cv1, p64, &a.cv2, &p64, bad);            // -> 64 (in place)
+    dense_pf<TILE, 64, 64, MODE>(act, S, 0, to_tile(0), a.cv2, p64, &a.cv_xyz, &p64, bad);         // -> 64 = x   (values of the pooling)
+    dense_pf<TILE, 64, 128, MODE>(act, S, G, to_tile(64), a.cv_xyz, p64, &a.sum_cv0, &p128, bad);  // xyz_cat -> enc at [64,128)   :79-82
+    dense_pf<TILE, 128, 64, MODE>(act, S, 0, to_tile(64), a.sum_cv0, p128, &a.sum_cv1, &p64, bad); // [x | enc] -> 128 at [64,192): over enc, x stays  :84-90
+    dense_pf<TILE, 64, 0, MODE>(act, S, 64, to_pool(64), a.sum_cv1, p64, nullptr, nullptr, bad);   // -> 64 logits at [64,128) (plain fp32)
 #if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 3
-    if (tid == 0) a.out[first_point * 64] = act[F];
+    if (tid == 0) feat_store(a.out, first_point * 64, act[F], f16);
     return;
 #endif
-    pool_masked_softmax(act, S, 64, 0, meta, P, K, first_point, total_points, a.out);   // :92-98
+    pool_masked_softmax(act, S, 64, 0, meta, P, K, first_point, total_points, a.out, f16);   // :92-98
+    report_violations<MODE>(bad);
 }
 
 // ================================================================ cost volume, stage 2
 // LDS columns: [0,64) grouped cost, [64,128) xyz-encoding, [128,128+C) feat1, [192,208) xyz_cat;
 // sum_cost0 reads [0,128+C) and writes [64,192); sum_cost1 maps [64,192) -> [64,128).
-template <int TILE, bool HALF>
+template <int TILE, int MODE>
 __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv2_kernel(const elo_cv2_args a, const int S)
 {
     extern __shared__ float lds[];
     float *act = lds;
     const TileMeta meta = tile_meta(lds, TILE, S);
     const int tid = threadIdx.x;
-    const int K = a.K, P = TILE / K, C = a.C;
+    const int K = a.K, P = TILE / K, C = a.C, f16 = a.feat_dtype == ELO_F16;
+    unsigned bad = 0;
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     if (first_point >= total_points) return;
@@ -1006,47 +1150,30 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv2_kernel(const elo_cv2_args 
         __syncthreads();
     }
     const int Cp = ceil16(C), XYZ = 192;
-    if (seg_ok(a.cost, 64, TILE) && seg_ok(a.feat1, C, TILE)) {
+    {
         auto cell_of = [&](int row) { return (long)meta.cell[row]; };
         auto centre_of = [&](int row) { return meta.cell[row] >= 0 ? first_point + row / K : -1L; };
-        float4 rc[SEG_ITEMS], rf[SEG_ITEMS];
-        seg_load<TILE>(rc, a.cost, 64, cell_of);                                      // grouped cost * mask  :110
-        seg_load<TILE>(rf, a.feat1, C, centre_of);                                    // centre features      :115
+        uint4 rc[SEG_ITEMS], rf[SEG_ITEMS];
+        seg_load<TILE>(rc, a.cost, 64, f16, cell_of);                                 // grouped cost * mask  :110
+        seg_load<TILE>(rf, a.feat1, C, f16, centre_of);                               // centre features      :115
         GeoRow gr;
         const bool grow = tid < TILE;
         const int gcell = grow ? meta.cell[tid] : -1;
         if (grow) gr = geo_load(a.xyz1 + (gcell >= 0 ? first_point + tid / K : 0) * 3, a.xyz1 + (long)(gcell >= 0 ? gcell : 0) * 3);
-        seg_store<TILE>(act, S, 0, 64, rc, cell_of, [&](int row) { return meta.mask[row]; });
-        seg_store<TILE>(act, S, 128, C, rf, centre_of, [](int) { return 1.0f; });
-        zero_cols<TILE>(act, S, 128 + C, 128 + Cp);
-        if (grow) geo_store<true>(act + tid * S + XYZ, gr, meta.mask[tid], gcell >= 0);   // 10-channel geometry + 6 zeros  :111-120
-    } else {
-        for (int e = tid; e < TILE * 64; e += FUSED_BLOCK) {
-            const int row = e >> 6, ch = e & 63;
-            const int cell = meta.cell[row];
-            act[row * S + ch] = cell >= 0 ? a.cost[(long)cell * 64 + ch] * meta.mask[row] : 0.0f;
-        }
-        for (int e = tid; e < TILE * Cp; e += FUSED_BLOCK) {
-            const int row = e / Cp, ch = e - row * Cp;
-            const long pt = first_point + row / K;
-            act[row * S + 128 + ch] = (meta.cell[row] >= 0 && ch < C) ? a.feat1[pt * C + ch] : 0.0f;
-        }
-        for (int e = tid; e < TILE * 16; e += FUSED_BLOCK) {
-            const int row = e >> 4, ch = e & 15;
-            const int cell = meta.cell[row];
-            const long pt = first_point + row / K;
-            act[row * S + XYZ + ch] = (cell >= 0 && ch < 10)
-                ? geo_channel(a.xyz1 + pt * 3, a.xyz1 + (long)cell * 3, meta.mask[row], ch) : 0.0f;
-        }
+        seg_store<TILE, MODE>(act, S, 0, 64, f16, rc, cell_of, [&](int row) { return meta.mask[row] != 0.0f; }, bad);
+        seg_store<TILE, MODE>(act, S, 128, C, f16, rf, centre_of, [](int) { return true; }, bad);
+        zero_cols<TILE, MODE>(act, S, 128 + C, 128 + Cp);
+        if (grow) geo_store<MODE>(act, tid * S + XYZ, gr, meta.mask[tid], gcell >= 0, bad);   // 10-channel geometry + 6 zeros  :111-120
     }
-    Pre<TILE, 128, HALF> p128;
-    Pre<TILE, 64, HALF> p64;
-    prefetch<TILE, 64, HALF>(a.xyz_enc, p64);
+    Pre<TILE, 128, MODE> p128;
+    Pre<TILE, 64, MODE> p64;
+    prefetch<TILE, 64, MODE>(a.xyz_enc, p64);
     __syncthreads();
-    dense_pf<TILE, 64, 128, HALF>(act, S, XYZ, 64, a.xyz_enc, p64, &a.sum_cost0, &p128);   // -> enc at [64,128)       :123-126
-    dense_pf<TILE, 128, 64, HALF>(act, S, 0, 64, a.sum_cost0, p128, &a.sum_cost1, &p64);   // [grouped | enc | feat1] -> [64,192)   :129-135
-    dense_pf<TILE, 64, 0, HALF>(act, S, 64, 64, a.sum_cost1, p64, nullptr, nullptr);       // -> 64 logits at [64,128)
-    pool_masked_softmax(act, S, 64, 0, meta, P, K, first_point, total_points, a.out);   // :137-146
+    dense_pf<TILE, 64, 128, MODE>(act, S, XYZ, to_tile(64), a.xyz_enc, p64, &a.sum_cost0, &p128, bad);   // -> enc at [64,128)       :123-126
+    dense_pf<TILE, 128, 64, MODE>(act, S, 0, to_tile(64), a.sum_cost0, p128, &a.sum_cost1, &p64, bad);   // [grouped | enc | feat1] -> [64,192)   :129-135
+    dense_pf<TILE, 64, 0, MODE>(act, S, 64, to_pool(64), a.sum_cost1, p64, nullptr, nullptr, bad);       // -> 64 logits at [64,128)
+    pool_masked_softmax(act, S, 64, 0, meta, P, K, first_point, total_points, a.out, f16);   // :137-146
+    report_violations<MODE>(bad);
 }
 
 // A 16-row tile halves the serial work per workgroup and doubles their number: take it whenever the
@@ -1072,25 +1199,38 @@ int check_dense(const elo_dense &L, int K, int N, const char *who, const char *n
     return ELO_OK;
 }
 
-// the products mode is a property of the LAUNCH (the kernels are instantiated per mode): every layer must agree
-template <typename... Rest>
-int products_mode(const char *who, bool *half, const elo_dense &first, const Rest &...rest)
+int check_dtype(int feat_dtype, const char *who)
 {
-    const int mode = first.products;
-    for (const elo_dense *L : {&rest...})
-        if (L->products != mode) return fail(ELO_ERR_ARG, "%s: the layers of one launch must share one products mode", who);
-    *half = mode == ELO_PRODUCTS_HALF;
+    if (feat_dtype != ELO_F32 && feat_dtype != ELO_F16) return fail(ELO_ERR_ARG, "%s: feat_dtype must be ELO_F32 or ELO_F16", who);
     return ELO_OK;
 }
 
-int products_mode(const char *who, bool *half, const elo_dense *layers, int n, const elo_dense *layers2 = nullptr, int n2 = 0)
+// the range check is a process-wide debugging switch (elo_range_check / ELO_RANGE_CHECK=1)
+int &range_check_flag()
 {
-    const int mode = layers[0].products;
+    static int flag = [] { const char *e = getenv("ELO_RANGE_CHECK"); return e && atoi(e) != 0 ? 1 : 0; }();
+    return flag;
+}
+
+// the products mode is a property of the LAUNCH (the kernels are instantiated per mode): every layer must agree
+template <typename... Rest>
+int products_mode(const char *who, int *mode, const elo_dense &first, const Rest &...rest)
+{
+    const int m = first.products;
+    for (const elo_dense *L : {&rest...})
+        if (L->products != m) return fail(ELO_ERR_ARG, "%s: the layers of one launch must share one products mode", who);
+    *mode = m == ELO_PRODUCTS_HALF ? MODE_HALF : range_check_flag() ? MODE_CHECKED : MODE_SPLIT;
+    return ELO_OK;
+}
+
+int products_mode(const char *who, int *mode, const elo_dense *layers, int n, const elo_dense *layers2 = nullptr, int n2 = 0)
+{
+    const int m = layers[0].products;
     for (int l = 0; l < n; ++l)
-        if (layers[l].products != mode) return fail(ELO_ERR_ARG, "%s: the layers of one launch must share one products mode", who);
+        if (layers[l].products != m) return fail(ELO_ERR_ARG, "%s: the layers of one launch must share one products mode", who);
     for (int l = 0; l < n2; ++l)
-        if (layers2[l].products != mode) return fail(ELO_ERR_ARG, "%s: the layers of one launch must share one products mode", who);
-    *half = mode == ELO_PRODUCTS_HALF;
+        if (layers2[l].products != m) return fail(ELO_ERR_ARG, "%s: the layers of one launch must share one products mode", who);
+    *mode = m == ELO_PRODUCTS_HALF ? MODE_HALF : range_check_flag() ? MODE_CHECKED : MODE_SPLIT;
     return ELO_OK;
 }
 
@@ -1126,39 +1266,21 @@ using namespace elo;
 
 static inline int pad16(int x) { return (x + 15) & ~15; }
 
-template <typename Args, typename K32, typename K16>
-static int launch_tile(const char *who, bool tile16, long units16, long units32, int S, hipStream_t s, const Args &a,
-                       K32 k32, K16 k16, const elo_group_spec *g = nullptr, int H2 = 0, int W2 = 0, bool select = false,
-                       int K = 0)
-{
-    const int KT = (g && g->random_hw) ? g->kernel_h * g->kernel_w : 0;
-    const size_t lds = tile_lds_bytes(tile16 ? 16 : 32, S, KT, select, K);
-    if (g) if (int rc = check_group(*g, H2, W2, lds, who)) return rc;
-    if (tile16)
-        hipLaunchKernelGGL(k16, dim3((unsigned)units16), dim3(FUSED_BLOCK), lds, s, a, S);
-    else
-        hipLaunchKernelGGL(k32, dim3((unsigned)units32), dim3(FUSED_BLOCK), lds, s, a, S);
-    return check_launch(who);
-}
-
-// two jobs of identical shape in one launch (grid.y = 2); b == nullptr: one job
-template <typename Args, typename K32, typename K16>
-static int launch_tile2(const char *who, bool tile16, long units16, long units32, int S, hipStream_t s, const Args &a,
-                        const Args *b, K32 k32, K16 k16, const elo_group_spec *g = nullptr, int H2 = 0, int W2 = 0)
-{
-    const int KT = (g && g->random_hw) ? g->kernel_h * g->kernel_w : 0;
-    const size_t lds = tile_lds_bytes(tile16 ? 16 : 32, S, KT, false);
-    if (g) if (int rc = check_group(*g, H2, W2, lds, who)) return rc;
-    const unsigned jobs = b ? 2 : 1;
-    JobPair<Args> pair;
-    pair.job[0] = a;
-    pair.job[1] = b ? *b : a;
-    if (tile16)
-        hipLaunchKernelGGL(k16, dim3((unsigned)units16, jobs), dim3(FUSED_BLOCK), lds, s, pair, S);
-    else
-        hipLaunchKernelGGL(k32, dim3((unsigned)units32, jobs), dim3(FUSED_BLOCK), lds, s, pair, S);
-    return check_launch(who);
-}
+// KERNEL<TILE, MODE> for TILE in {32, 16}, picked by (tile16, mode); a -DELO_DENSE_F32 library has no fp16-product kernels
+#ifdef ELO_DENSE_F32
+#define ELO_PICK(KERNEL, tile16, mode, CALL)                                                              \
+    do {                                                                                                  \
+        if ((mode) == MODE_CHECKED) { if (tile16) CALL((KERNEL<16, MODE_CHECKED>)); else CALL((KERNEL<32, MODE_CHECKED>)); } \
+        else { if (tile16) CALL((KERNEL<16, MODE_SPLIT>)); else CALL((KERNEL<32, MODE_SPLIT>)); }         \
+    } while (0)
+#else
+#define ELO_PICK(KERNEL, tile16, mode, CALL)                                                              \
+    do {                                                                                                  \
+        if ((mode) == MODE_HALF) { if (tile16) CALL((KERNEL<16, MODE_HALF>)); else CALL((KERNEL<32, MODE_HALF>)); } \
+        else if ((mode) == MODE_CHECKED) { if (tile16) CALL((KERNEL<16, MODE_CHECKED>)); else CALL((KERNEL<32, MODE_CHECKED>)); } \
+        else { if (tile16) CALL((KERNEL<16, MODE_SPLIT>)); else CALL((KERNEL<32, MODE_SPLIT>)); }         \
+    } while (0)
+#endif
 
 // column budget of an in-place chain starting from `width` input columns
 static int chain_cols(const elo_dense *layers, int n_layers, int width)
@@ -1178,6 +1300,7 @@ static int check_setconv(const elo_setconv_args *a, const char *who)
     ELO_REQUIRE(a->group.random_hw || (a->idx && a->mask), who, "neither idx/mask nor a grouping spec");
     ELO_REQUIRE((a->xyz1_grid && a->H > 0 && a->W > 0 && (a->centre_hw || a->group.random_hw)) || a->centre_xyz, who, "no centre source");
     ELO_REQUIRE(!a->group.random_hw || (a->xyz1_grid && a->H > 0 && a->W > 0), who, "in-kernel grouping needs xyz1_grid");
+    if (int rc = check_dtype(a->feat_dtype, who)) return rc;
     int width = 3 + a->C;
     for (int l = 0; l < a->n_layers; ++l) {
         if (int rc = check_dense(a->layers[l], width, 0, who, "mlp")) return rc;
@@ -1190,7 +1313,7 @@ static bool same_shape(const elo_setconv_args *a, const elo_setconv_args *b)
 {
     if (a->batch != b->batch || a->npoints != b->npoints || a->K != b->K || a->C != b->C || a->n_layers != b->n_layers ||
         a->H2 != b->H2 || a->W2 != b->W2 || a->group.kernel_h != b->group.kernel_h || a->group.kernel_w != b->group.kernel_w ||
-        (a->group.random_hw == nullptr) != (b->group.random_hw == nullptr))
+        (a->group.random_hw == nullptr) != (b->group.random_hw == nullptr) || a->feat_dtype != b->feat_dtype)
         return false;
     for (int l = 0; l < a->n_layers; ++l)
         if (a->layers[l].K != b->layers[l].K || a->layers[l].N != b->layers[l].N) return false;
@@ -1206,6 +1329,27 @@ extern "C" int elo_dense_f32(void)
 #endif
 }
 
+extern "C" int elo_range_check(int enable)
+{
+    const int prev = range_check_flag();
+    if (enable >= 0) range_check_flag() = enable ? 1 : 0;
+    return prev;
+}
+
+extern "C" int elo_range_violations(unsigned long long *count, elo_stream_t stream)
+{
+    const char *who = "elo_range_violations";
+    ELO_REQUIRE(count, who, "null count");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long zero = 0;
+    if (hipMemcpyFromSymbolAsync(count, HIP_SYMBOL(g_range_violations), sizeof(*count), 0, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess ||
+        hipMemcpyToSymbolAsync(HIP_SYMBOL(g_range_violations), &zero, sizeof(zero), 0, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return fail(ELO_ERR_LAUNCH, "%s: %s", who, hipGetErrorString(hipGetLastError()));
+    return ELO_OK;
+}
+
 extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_args *b, elo_stream_t stream)
 {
     const char *who = "elo_setconv_fused";
@@ -1216,35 +1360,42 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
     }
     const long points = (long)a->batch * a->npoints;
     if (points == 0) return ELO_OK;
+    hipStream_t s = (hipStream_t)stream;
     if (!b && a->group.random_hw && a->K == 32 && a->n_layers == 3 && a->layers[0].w_plain && a->layers[1].w_plain &&
         a->layers[2].w_plain && a->group.kernel_h * a->group.kernel_w <= SMALL_STEPS * 32) {                     // narrow chains: wave-per-point VALU kernel
         const int cin = 3 + a->C, n1 = a->layers[0].N, n2 = a->layers[1].N, n3 = a->layers[2].N;
         const unsigned grid = (unsigned)((points + 7) / 8);
         if (int rc = check_group(a->group, a->H2, a->W2, 0, who)) return rc;
         if (cin == 6 && n1 == 8 && n2 == 8 && n3 == 16) {
-            hipLaunchKernelGGL((setconv_small_kernel<6, 8, 8, 16>), dim3(grid), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a);
+            hipLaunchKernelGGL((setconv_small_kernel<6, 8, 8, 16>), dim3(grid), dim3(ELO_BLOCK), 0, s, *a);
             return check_launch(who);
         }
         if (cin == 19 && n1 == 16 && n2 == 16 && n3 == 32) {
-            hipLaunchKernelGGL((setconv_small_kernel<19, 16, 16, 32>), dim3(grid), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a);
+            hipLaunchKernelGGL((setconv_small_kernel<19, 16, 16, 32>), dim3(grid), dim3(ELO_BLOCK), 0, s, *a);
             return check_launch(who);
         }
     }
     const int S = row_stride(chain_cols(a->layers, a->n_layers, 3 + a->C));
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
-    bool half = false, half_b = false;
-    if (int rc = products_mode(who, &half, a->layers, a->n_layers)) return rc;
+    int mode = 0, mode_b = 0;
+    if (int rc = products_mode(who, &mode, a->layers, a->n_layers)) return rc;
     if (b) {
-        if (int rc = products_mode(who, &half_b, b->layers, b->n_layers)) return rc;
-        if (half != half_b) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must share one products mode", who);
+        if (int rc = products_mode(who, &mode_b, b->layers, b->n_layers)) return rc;
+        if (mode != mode_b) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must share one products mode", who);
     }
     const bool t16 = small_tile(u32 * (b ? 2 : 1), a->K);
-    if (half)
-        return launch_tile2(who, t16, u16, u32, S, (hipStream_t)stream, *a, b, setconv_kernel<32, true>, setconv_kernel<16, true>,
-                            &a->group, a->H2, a->W2);
-    return launch_tile2(who, t16, u16, u32, S, (hipStream_t)stream, *a, b, setconv_kernel<32, false>, setconv_kernel<16, false>,
-                        &a->group, a->H2, a->W2);
+    const int KT = a->group.random_hw ? a->group.kernel_h * a->group.kernel_w : 0;
+    const size_t lds = tile_lds_bytes(t16 ? 16 : 32, S, KT, false);
+    if (int rc = check_group(a->group, a->H2, a->W2, lds, who)) return rc;
+    JobPair<elo_setconv_args> pair;
+    pair.job[0] = *a;
+    pair.job[1] = b ? *b : *a;
+    const dim3 grid((unsigned)(t16 ? u16 : u32), b ? 2u : 1u);
+#define CALL(k) hipLaunchKernelGGL(k, grid, dim3(FUSED_BLOCK), lds, s, pair, S)
+    ELO_PICK(setconv_kernel, t16, mode, CALL);
+#undef CALL
+    return check_launch(who);
 }
 
 extern "C" int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream)
@@ -1257,6 +1408,7 @@ static int check_mlp(const elo_mlp_args *a, const char *who, int *in_width)
     ELO_REQUIRE(a, who, "null argument block");
     ELO_REQUIRE(a->rows >= 0 && a->n_sources >= 1 && a->n_sources <= 3, who, "bad sizes");
     ELO_REQUIRE(a->n_layers >= 1 && a->n_layers <= ELO_MAX_CHAIN && a->out, who, "1..3 layers and an output");
+    if (int rc = check_dtype(a->feat_dtype, who)) return rc;
     int width = 0;
     for (int s = 0; s < a->n_sources; ++s) {
         ELO_REQUIRE(a->src[s] && a->src_width[s] > 0, who, "null / empty source");
@@ -1271,6 +1423,7 @@ static int check_mlp(const elo_mlp_args *a, const char *who, int *in_width)
     if (a->n_layers2 > 0) {
         ELO_REQUIRE(a->out2 && a->w_before >= 0 && a->w_after >= 0 && (a->before || a->w_before == 0) &&
                     (a->after || a->w_after == 0), who, "incomplete second stage");
+        ELO_REQUIRE(width % 4 == 0, who, "a second stage needs a first-stage output width that is a multiple of 4");
         width += a->w_before + a->w_after;
         for (int l = 0; l < a->n_layers2; ++l) {
             if (int rc = check_dense(a->layers2[l], width, 0, who, "mlp stage 2")) return rc;
@@ -1288,7 +1441,6 @@ static int mlp_cols(const elo_mlp_args *a, int in_width)
         const int n1 = a->layers[a->n_layers - 1].N, in2 = a->w_before + n1 + a->w_after;
         const int c2 = chain_cols(a->layers2, a->n_layers2, in2);
         cols = cols > c2 ? cols : c2;
-        cols = cols > pad16(a->w_before + n1) ? cols : pad16(a->w_before + n1);
     }
     return cols;
 }
@@ -1301,7 +1453,8 @@ extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_
     if (b) {
         if (int rc = check_mlp(b, who, &in_width_b)) return rc;
         bool same = a->rows == b->rows && in_width == in_width_b && a->n_layers == b->n_layers &&
-                    a->n_layers2 == b->n_layers2 && a->w_before == b->w_before && a->w_after == b->w_after;
+                    a->n_layers2 == b->n_layers2 && a->w_before == b->w_before && a->w_after == b->w_after &&
+                    a->feat_dtype == b->feat_dtype;
         for (int l = 0; same && l < a->n_layers; ++l) same = a->layers[l].N == b->layers[l].N;
         for (int l = 0; same && l < a->n_layers2; ++l) same = a->layers2[l].N == b->layers2[l].N;
         if (!same) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must have the same shape", who);
@@ -1309,19 +1462,37 @@ extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_
     if (a->rows == 0) return ELO_OK;
     const int S = row_stride(mlp_cols(a, in_width));
     const long u32 = (a->rows + 31) / 32, u16 = (a->rows + 15) / 16;
-    bool half = false, half_b = false;
-    if (int rc = products_mode(who, &half, a->layers, a->n_layers, a->layers2, a->n_layers2)) return rc;
+    int mode = 0, mode_b = 0;
+    if (int rc = products_mode(who, &mode, a->layers, a->n_layers, a->layers2, a->n_layers2)) return rc;
     if (b) {
-        if (int rc = products_mode(who, &half_b, b->layers, b->n_layers, b->layers2, b->n_layers2)) return rc;
-        if (half != half_b) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must share one products mode", who);
+        if (int rc = products_mode(who, &mode_b, b->layers, b->n_layers, b->layers2, b->n_layers2)) return rc;
+        if (mode != mode_b) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must share one products mode", who);
     }
     const bool t16 = small_tile(u32 * (b ? 2 : 1), 1);
-    if (half)
-        return launch_tile2(who, t16, u16, u32, S, (hipStream_t)stream, *a, b, mlp_kernel<32, true>, mlp_kernel<16, true>);
-    return launch_tile2(who, t16, u16, u32, S, (hipStream_t)stream, *a, b, mlp_kernel<32, false>, mlp_kernel<16, false>);
+    const size_t lds = tile_lds_bytes(t16 ? 16 : 32, S);
+    JobPair<elo_mlp_args> pair;
+    pair.job[0] = *a;
+    pair.job[1] = b ? *b : *a;
+    const dim3 grid((unsigned)(t16 ? u16 : u32), b ? 2u : 1u);
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(k) hipLaunchKernelGGL(k, grid, dim3(FUSED_BLOCK), lds, s, pair, S)
+    ELO_PICK(mlp_kernel, t16, mode, CALL);
+#undef CALL
+    return check_launch(who);
 }
 
 extern "C" int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream) { return elo_mlp_fused2(a, nullptr, stream); }
+
+// vector gathers only: channel counts must be whole 16-byte items, tensors 16-byte aligned
+static int check_cv_features(const char *who, int C, int f16, std::initializer_list<const void *> tensors)
+{
+    const int per = f16 ? 8 : 4;
+    if (C % per != 0) return fail(ELO_ERR_LIMIT, "%s: C = %d must be a multiple of %d (%s feature storage)", who, C, per, f16 ? "fp16" : "fp32");
+    if (32 * (C / per) > SEG_ITEMS * FUSED_BLOCK) return fail(ELO_ERR_LIMIT, "%s: C = %d too wide for the tile gather", who, C);
+    for (const void *p : tensors)
+        if ((uintptr_t)p & 15) return fail(ELO_ERR_ARG, "%s: feature tensors must be 16-byte aligned", who);
+    return ELO_OK;
+}
 
 extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
 {
@@ -1332,6 +1503,8 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
     ELO_REQUIRE(a->xyz1 && a->feat1 && a->xyz2 && a->feat2 && a->out, who, "null tensor pointer");
     ELO_REQUIRE(a->group.random_hw || (a->idx && a->mask), who, "neither idx/mask nor a grouping spec");
     ELO_REQUIRE(!a->group.random_hw || a->npoints == a->H2 * a->W2, who, "in-kernel grouping needs npoints == H2*W2");
+    if (int rc = check_dtype(a->feat_dtype, who)) return rc;
+    if (int rc = check_cv_features(who, a->C, a->feat_dtype == ELO_F16, {a->feat1, a->feat2})) return rc;
     const int CT = 10 + 2 * a->C;
     if (int rc = check_dense(a->cv0, CT, 128, who, "CV_0")) return rc;
     if (int rc = check_dense(a->cv1, 128, 64, who, "CV_1")) return rc;
@@ -1341,17 +1514,22 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
     if (int rc = check_dense(a->sum_cv1, 128, 64, who, "sum_CV_1")) return rc;
     const long points = (long)a->batch * a->npoints;
     if (points == 0) return ELO_OK;
-    const int CTp = pad16(CT);
-    const int S = row_stride(128 + CTp > 192 ? 128 + CTp : 192);
+    const int cols = 128 + cv1_feat_cols(a->C);
+    const int S = row_stride(cols > 192 ? cols : 192);
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
-    bool half = false;
-    if (int rc = products_mode(who, &half, a->cv0, a->cv1, a->cv2, a->cv_xyz, a->sum_cv0, a->sum_cv1)) return rc;
-    if (half)
-        return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv1_kernel<32, true>,
-                           cv1_kernel<16, true>, &a->group, a->H2, a->W2, true, a->K);
-    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv1_kernel<32, false>,
-                       cv1_kernel<16, false>, &a->group, a->H2, a->W2, true, a->K);
+    int mode = 0;
+    if (int rc = products_mode(who, &mode, a->cv0, a->cv1, a->cv2, a->cv_xyz, a->sum_cv0, a->sum_cv1)) return rc;
+    const bool t16 = small_tile(u32, a->K);
+    const int KT = a->group.random_hw ? a->group.kernel_h * a->group.kernel_w : 0;
+    const size_t lds = tile_lds_bytes(t16 ? 16 : 32, S, KT, true, a->K);
+    if (int rc = check_group(a->group, a->H2, a->W2, lds, who)) return rc;
+    const dim3 grid((unsigned)(t16 ? u16 : u32));
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(k) hipLaunchKernelGGL(k, grid, dim3(FUSED_BLOCK), lds, s, *a, S)
+    ELO_PICK(cv1_kernel, t16, mode, CALL);
+#undef CALL
+    return check_launch(who);
 }
 
 extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
@@ -1364,6 +1542,8 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
     if (a->C > 64) return fail(ELO_ERR_LIMIT, "%s: C = %d exceeds 64", who, a->C);
     ELO_REQUIRE(a->xyz1 && a->feat1 && a->cost && a->out, who, "null tensor pointer");
     ELO_REQUIRE(a->group.random_hw || (a->idx && a->mask), who, "neither idx/mask nor a grouping spec");
+    if (int rc = check_dtype(a->feat_dtype, who)) return rc;
+    if (int rc = check_cv_features(who, a->C, a->feat_dtype == ELO_F16, {a->feat1, a->cost})) return rc;
     if (int rc = check_dense(a->xyz_enc, 10, 64, who, "sum_xyz_encoding")) return rc;
     if (int rc = check_dense(a->sum_cost0, 128 + a->C, 128, who, "sum_cost_volume_0")) return rc;
     if (int rc = check_dense(a->sum_cost1, 128, 64, who, "sum_cost_volume_1")) return rc;
@@ -1372,11 +1552,16 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
     const int S = row_stride(208);
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
-    bool half = false;
-    if (int rc = products_mode(who, &half, a->xyz_enc, a->sum_cost0, a->sum_cost1)) return rc;
-    if (half)
-        return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv2_kernel<32, true>,
-                           cv2_kernel<16, true>, &a->group, a->H, a->W, false);
-    return launch_tile(who, small_tile(u32, a->K), u16, u32, S, (hipStream_t)stream, *a, cv2_kernel<32, false>,
-                       cv2_kernel<16, false>, &a->group, a->H, a->W, false);
+    int mode = 0;
+    if (int rc = products_mode(who, &mode, a->xyz_enc, a->sum_cost0, a->sum_cost1)) return rc;
+    const bool t16 = small_tile(u32, a->K);
+    const int KT = a->group.random_hw ? a->group.kernel_h * a->group.kernel_w : 0;
+    const size_t lds = tile_lds_bytes(t16 ? 16 : 32, S, KT, false);
+    if (int rc = check_group(a->group, a->H, a->W, lds, who)) return rc;
+    const dim3 grid((unsigned)(t16 ? u16 : u32));
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(k) hipLaunchKernelGGL(k, grid, dim3(FUSED_BLOCK), lds, s, *a, S)
+    ELO_PICK(cv2_kernel, t16, mode, CALL);
+#undef CALL
+    return check_launch(who);
 }

@@ -91,6 +91,10 @@ class FlatGradBucket:
     def zero(self):
         self.flat.zero_()
 
+    @staticmethod
+    def world_size():
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
     def all_reduce_mean(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)

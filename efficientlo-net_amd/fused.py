@@ -45,6 +45,43 @@ class products:
         _products = self.prev
 
 
+_storage = torch.float32
+
+
+def storage_dtype():
+    """Storage type of the feature tensors the fused path creates from scratch (the all-zero input features); every
+    kernel front-end below then gives its outputs the dtype of its feature inputs."""
+    return _storage
+
+
+class storage:
+    """`with fused.storage(torch.float16):` -- fp16 FEATURE STORAGE in HBM (BASELINE configs[2]; SURVEY.md 8(d): s = 2):
+    every feature tensor between two fused kernels is fp16; geometry, indices, masks and all arithmetic stay as they are."""
+
+    def __init__(self, dtype):
+        if dtype not in (torch.float32, torch.float16):
+            raise TypeError("feature storage is torch.float32 or torch.float16")
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _storage
+        self.prev, _storage = _storage, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global _storage
+        _storage = self.prev
+
+
+def _features(*ts):
+    """Contiguous feature tensors of ONE storage dtype (fp32 or fp16); returns (tensors, dtype, ELO_F32 / ELO_F16)."""
+    live = [t for t in ts if t is not None]
+    dt = live[0].dtype
+    if dt not in (torch.float32, torch.float16) or any(t.dtype != dt for t in live):
+        raise TypeError("the feature tensors of a call are all float32 or all float16 (got %s)" % [str(t.dtype) for t in live])
+    return [None if t is None else t.contiguous() for t in ts], dt, L.dtype_code(live[0])
+
+
 class PackedDense:
     """One inference layer y = act(x @ W + b) with BN folded, packed in MFMA B-fragment order.  Each weight is split
     into fp16 hi + lo (w = hi + lo to 2^-22 relative) for the three-product fp16 MFMA scheme of elo_fused.hip; a lane's
@@ -94,9 +131,28 @@ def packed_layer(scope, cin, cout, bn=True, relu=True, row_order=None, tf_kernel
     return hit
 
 
+def setconv_row_order(C):
+    """Weight rows of a set-conv's first layer in the kernel's column order [features (C) | xyz difference (3)]
+    (reference concat: [xyz_diff, features], utils/pointnet_util.py:213)."""
+    return list(range(3, 3 + C)) + [0, 1, 2]
+
+
+def cv0_row_order(C):
+    """CV_0's rows in the kernel's order [feat1 (C) | feat2 grouped (C) | geometry (10)] (reference: [geometry, feat1,
+    feat2], utils/pointnet_util.py:62-66)."""
+    return list(range(10, 10 + 2 * C)) + list(range(10))
+
+
+def stage2_row_order(w_before, n_out, w_after):
+    """Second-stage rows of a two-stage row-wise MLP in the kernel's order [out | before | after] (reference concat:
+    [before, out, after], utils/pointnet_util.py:161-166)."""
+    return (list(range(w_before, w_before + n_out)) + list(range(w_before)) +
+            list(range(w_before + n_out, w_before + n_out + w_after)))
+
+
 def _f32c(t):
     if t.dtype != torch.float32:
-        raise TypeError("feature-path tensors are float32")
+        raise TypeError("geometry tensors (xyz, masks) are float32")
     return t.contiguous()
 
 
@@ -158,7 +214,8 @@ _NO_GROUP = L.GroupSpec(None, 0, 0, 0.0, 0, 0, None, None, None)
 def _setconv_args(src_xyz, src_feat, idx, mask, layers, centre_xyz=None, xyz1_grid=None, centre_hw=None, group=None,
                   K=None):
     L.require_gpu(src_xyz, src_feat, idx, mask, centre_xyz, xyz1_grid, centre_hw)
-    src_xyz, src_feat = _f32c(src_xyz), _f32c(src_feat)
+    src_xyz = _f32c(src_xyz)
+    (src_feat,), dt, code = _features(src_feat)
     _, H2, W2, C = src_feat.shape
     dev = src_xyz.device
     ptr = lambda x: x.data_ptr() if x is not None else None
@@ -178,10 +235,10 @@ def _setconv_args(src_xyz, src_feat, idx, mask, layers, centre_xyz=None, xyz1_gr
         new_xyz = torch.empty((B, n, 3), dtype=torch.float32, device=dev)
     elif centre_xyz is not None:
         centre_xyz = _f32c(centre_xyz)
-    out = torch.empty((B, n, layers[-1].N), dtype=torch.float32, device=dev)
+    out = torch.empty((B, n, layers[-1].N), dtype=dt, device=dev)
     a = L.SetconvArgs(B, n, K, H, W, H2, W2, C, ptr(xyz1_grid), ptr(centre_hw), ptr(centre_xyz), src_xyz.data_ptr(),
                       src_feat.data_ptr(), ptr(idx), ptr(mask), len(layers), _chain(layers), out.data_ptr(), ptr(new_xyz),
-                      group.struct(B, n, K, dev) if group is not None else _NO_GROUP)
+                      group.struct(B, n, K, dev) if group is not None else _NO_GROUP, code)
     keep = (src_xyz, src_feat, idx, mask, centre_xyz, xyz1_grid, centre_hw, layers, group)   # alive until the launch
     return a, out, new_xyz, keep
 
@@ -189,7 +246,8 @@ def _setconv_args(src_xyz, src_feat, idx, mask, layers, centre_xyz=None, xyz1_gr
 def setconv(src_xyz, src_feat, idx, mask, layers, centre_xyz=None, xyz1_grid=None, centre_hw=None, group=None, K=None):
     """group_concat -> MLP chain -> masked max over K in one launch.  Either (idx, mask) from a grouping op, or
     group=Grouping(...) + K to group in-kernel (needs xyz1_grid; centre_hw None = every pixel of xyz1_grid).
-    Returns (out (B,n,Cout), new_xyz (B,n,3) or None)."""
+    layers[0] is packed with `row_order=setconv_row_order(C)` (the kernel's columns are [features | xyz difference]).
+    Returns (out (B,n,Cout) in src_feat's dtype, new_xyz (B,n,3) or None)."""
     a, out, new_xyz, _keep = _setconv_args(src_xyz, src_feat, idx, mask, layers, centre_xyz, xyz1_grid, centre_hw, group, K)
     L.call("elo_setconv_fused", a, out)
     return out, new_xyz
@@ -205,11 +263,13 @@ def setconv_pair(job_a, job_b):
 
 def _mlp_args(sources, layers):
     L.require_gpu(*sources)
-    srcs = [_f32c(s).reshape(-1, s.shape[-1]) for s in sources]
+    srcs, dt, code = _features(*sources)
+    srcs = [s.reshape(-1, s.shape[-1]) for s in srcs]
     rows = srcs[0].shape[0]
-    out = torch.empty((rows, layers[-1].N), dtype=torch.float32, device=srcs[0].device)
+    out = torch.empty((rows, layers[-1].N), dtype=dt, device=srcs[0].device)
     a = L.MlpArgs()
     a.rows, a.n_sources, a.n_layers, a.layers, a.out = rows, len(srcs), len(layers), _chain(layers), out.data_ptr()
+    a.feat_dtype = code
     for i, s in enumerate(srcs):
         a.src[i], a.src_width[i] = s.data_ptr(), s.shape[1]
     return a, out, (srcs, layers)
@@ -234,9 +294,10 @@ def mlp_pair(sources_a, layers_a, sources_b, layers_b):
 def _mlp2_args(sources, layers, before, after, layers2):
     a, out, keep = _mlp_args(sources, layers)
     rows = out.shape[0]
-    flat = lambda t: None if t is None else _f32c(t).reshape(rows, t.shape[-1])
+    before, after = _features(before, after, out)[0][:2]          # same storage dtype as the first stage
+    flat = lambda t: None if t is None else t.reshape(rows, t.shape[-1])
     before, after = flat(before), flat(after)
-    out2 = torch.empty((rows, layers2[-1].N), dtype=torch.float32, device=out.device)
+    out2 = torch.empty((rows, layers2[-1].N), dtype=out.dtype, device=out.device)
     a.n_layers2, a.layers2, a.out2 = len(layers2), _chain(layers2), out2.data_ptr()
     a.before, a.w_before = (before.data_ptr(), before.shape[1]) if before is not None else (None, 0)
     a.after, a.w_after = (after.data_ptr(), after.shape[1]) if after is not None else (None, 0)
@@ -246,7 +307,8 @@ def _mlp2_args(sources, layers, before, after, layers2):
 def mlp2_pair(job_a, job_b):
     """Two jobs of identical shape, each TWO chained row-wise MLPs, in ONE launch:
     out = layers(concat(sources)); out2 = layers2(concat(before, out, after)).  job: dict(sources, layers, before,
-    after, layers2).  Returns ((out_a, out2_a), (out_b, out2_b))."""
+    after, layers2); layers2[0] is packed with `row_order=stage2_row_order(w_before, N, w_after)` (the kernel's columns
+    are [out | before | after]).  Returns ((out_a, out2_a), (out_b, out2_b))."""
     a, out_a, out2_a, _ka = _mlp2_args(**job_a)
     b, out_b, out2_b, _kb = _mlp2_args(**job_b)
     L.call2("elo_mlp_fused2", a, b, out_a)
@@ -257,34 +319,36 @@ def mlp2_pair(job_a, job_b):
 
 def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1, group=None, K=None):
     L.require_gpu(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask)
-    xyz1, feat1, xyz2_proj, feat2_proj = (_f32c(t) for t in (xyz1, feat1, xyz2_proj, feat2_proj))
+    xyz1, xyz2_proj = _f32c(xyz1), _f32c(xyz2_proj)
+    (feat1, feat2_proj), dt, code = _features(feat1, feat2_proj)
     _, H2, W2, C = feat2_proj.shape
     B, N = xyz1.shape[0], xyz1.shape[1]
     ptr = lambda x: x.data_ptr() if x is not None else None
     if group is None:
         idx, mask = idx.contiguous(), _f32c(mask)
         K = idx.shape[2]
-    out = torch.empty((B, N, 64), dtype=torch.float32, device=xyz1.device)
+    out = torch.empty((B, N, 64), dtype=dt, device=xyz1.device)
     a = L.Cv1Args(B, N, K, H2, W2, C, xyz1.data_ptr(), feat1.data_ptr(), xyz2_proj.data_ptr(), feat2_proj.data_ptr(),
                   ptr(idx), ptr(mask), cv0.struct(), cv1.struct(), cv2.struct(), cv_xyz.struct(),
                   sum_cv0.struct(), sum_cv1.struct(), out.data_ptr(),
-                  group.struct(B, N, K, xyz1.device) if group is not None else _NO_GROUP)
+                  group.struct(B, N, K, xyz1.device) if group is not None else _NO_GROUP, code)
     L.call("elo_cv_stage1_fused", a, out)
     return out
 
 
 def cv_stage2(xyz1_proj, feat1_proj, cost_proj, idx, mask, xyz_enc, sum_cost0, sum_cost1, group=None, K=None):
     L.require_gpu(xyz1_proj, feat1_proj, cost_proj, idx, mask)
-    xyz1_proj, feat1_proj, cost_proj = (_f32c(t) for t in (xyz1_proj, feat1_proj, cost_proj))
+    xyz1_proj = _f32c(xyz1_proj)
+    (feat1_proj, cost_proj), dt, code = _features(feat1_proj, cost_proj)
     B, H, W, C = feat1_proj.shape
     N = H * W
     ptr = lambda x: x.data_ptr() if x is not None else None
     if group is None:
         idx, mask = idx.contiguous(), _f32c(mask)
         K = idx.shape[2]
-    out = torch.empty((B, N, 64), dtype=torch.float32, device=xyz1_proj.device)
+    out = torch.empty((B, N, 64), dtype=dt, device=xyz1_proj.device)
     a = L.Cv2Args(B, N, K, H, W, C, xyz1_proj.data_ptr(), feat1_proj.data_ptr(), cost_proj.data_ptr(), ptr(idx),
                   ptr(mask), xyz_enc.struct(), sum_cost0.struct(), sum_cost1.struct(), out.data_ptr(),
-                  group.struct(B, N, K, xyz1_proj.device) if group is not None else _NO_GROUP)
+                  group.struct(B, N, K, xyz1_proj.device) if group is not None else _NO_GROUP, code)
     L.call("elo_cv_stage2_fused", a, out)
     return out

@@ -12,7 +12,7 @@ import time
 
 import torch
 
-from . import model_util, perm, pwclo_model, tf_util
+from . import fused, model_util, perm, pwclo_model, tf_util
 
 
 def distinct_queue_streams(device, want, candidates=16, cycles=500_000):
@@ -53,8 +53,11 @@ def distinct_queue_streams(device, want, candidates=16, cycles=500_000):
 
 
 class PWCLONet:
-    def __init__(self, device="cuda:0", seed=0, perm_source=None):
+    def __init__(self, device="cuda:0", seed=0, perm_source=None, feature_dtype=torch.float32):
+        """feature_dtype=torch.float16: fp16 feature STORAGE in HBM between the fused kernels (BASELINE configs[2]);
+        geometry, weights and arithmetic are unchanged (fused inference path only)."""
         self.device = torch.device(device)
+        self.feature_dtype = feature_dtype
         self.store = tf_util.VariableStore(self.device, seed=seed)
         self.perms = perm_source if perm_source is not None else perm.PermSource(seed=seed)
         self._graph = None
@@ -65,8 +68,10 @@ class PWCLONet:
     # -- eager ---------------------------------------------------------------
     def forward(self, xyz_f1_proj, xyz_f2_proj, is_training=False, bn_decay=None, pose_out=None):
         """get_model_from_projection under this net's variables and permutations."""
-        with tf_util.default_store(self.store), perm.default_perm_source(self.perms):
+        with tf_util.default_store(self.store), perm.default_perm_source(self.perms), fused.storage(self.feature_dtype):
             if is_training:
+                if self.feature_dtype != torch.float32:
+                    raise NotImplementedError("training stores its features in fp32")
                 return pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, True, bn_decay, pose_out)
             with torch.no_grad():
                 return pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, False, bn_decay, pose_out)
@@ -74,7 +79,7 @@ class PWCLONet:
     def forward_points(self, point_cloud, H_input, W_input, T_gt, T_trans, T_trans_inv, is_training=False,
                        bn_decay=None, aug_frame=None):
         """get_model with the reference's full signature (raw clouds in)."""
-        with tf_util.default_store(self.store), perm.default_perm_source(self.perms):
+        with tf_util.default_store(self.store), perm.default_perm_source(self.perms), fused.storage(self.feature_dtype):
             ctx = torch.enable_grad() if is_training else torch.no_grad()
             with ctx:
                 return pwclo_model.get_model(point_cloud, H_input, W_input, T_gt, T_trans, T_trans_inv, is_training,

@@ -118,7 +118,8 @@ def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_
             P = fused.packed_layer
             pi_feat1_new = fused.cv_stage1(
                 warped_xyz1, points1, xyz2_proj, points2_proj, None, None,
-                P('CV_0', 10 + 2 * C, 128), P('CV_1', 128, 64), P('CV_2', 64, 64), P('CV_xyz', 10, 64),
+                P('CV_0', 10 + 2 * C, 128, row_order=fused.cv0_row_order(C)), P('CV_1', 128, 64), P('CV_2', 64, 64),
+                P('CV_xyz', 10, 64),
                 P('sum_CV_0', 128, 128, row_order=list(range(64, 128)) + list(range(64))),      # kernel order [x | enc]
                 P('sum_CV_1', 128, 64),
                 group=fused.Grouping(random_HW_q, kernel_size2, 1000), K=nsample_q).reshape(B, H, W, -1)   # :49-100
@@ -241,7 +242,9 @@ def up_conv_pair(call_a, call_b):
             P = fused.packed_layer
             w1 = [3 + feat2_proj.shape[-1]] + list(mlp)
             jobs.append(dict(src_xyz=c["xyz2_proj"], src_feat=feat2_proj, idx=None, mask=None,
-                             layers=[P('up_1_%d' % j, w1[j], w1[j + 1]) for j in range(len(mlp))],
+                             layers=[P('up_1_%d' % j, w1[j], w1[j + 1],
+                                       row_order=fused.setconv_row_order(w1[0] - 3) if j == 0 else None)
+                                     for j in range(len(mlp))],
                              xyz1_grid=xyz1_proj, K=c["nsample"],
                              group=fused.Grouping(random_HW, ks, c["distance"], c["stride_h"], c["stride_w"])))
             points1 = feat1_proj.reshape(B, H * W, -1)
@@ -267,7 +270,9 @@ def up_conv_predict_pair(up_a, up_b, fp_a, fp_b):
             random_HW = random_shuffle(tf_util.scope_name(), "random_HW", ks[0] * ks[1], xyz1_proj.device)
             w1 = [3 + feat2_proj.shape[-1]] + list(mlp)
             jobs.append(dict(src_xyz=up["xyz2_proj"], src_feat=feat2_proj, idx=None, mask=None,
-                             layers=[P('up_1_%d' % j, w1[j], w1[j + 1]) for j in range(len(mlp))],
+                             layers=[P('up_1_%d' % j, w1[j], w1[j + 1],
+                                       row_order=fused.setconv_row_order(w1[0] - 3) if j == 0 else None)
+                                     for j in range(len(mlp))],
                              xyz1_grid=xyz1_proj, K=up["nsample"],
                              group=fused.Grouping(random_HW, ks, up["distance"], up["stride_h"], up["stride_w"])))
             points1 = feat1_proj.reshape(B, H * W, -1)
@@ -276,7 +281,11 @@ def up_conv_predict_pair(up_a, up_b, fp_a, fp_b):
         with tf_util.variable_scope(fp["scope"]):
             before, after = fp["points_f1"], fp["cost_volume"]
             wp = [sum(p.shape[-1] for p in (before, after) if p is not None) + mlp2[-1]] + list(fp["mlp"])
-            layers2 = [P('conv_predictor%d' % i, wp[i], wp[i + 1], bn=fp.get("bn", True)) for i in range(len(fp["mlp"]))]
+            w_before = before.shape[-1] if before is not None else 0
+            w_after = after.shape[-1] if after is not None else 0
+            layers2 = [P('conv_predictor%d' % i, wp[i], wp[i + 1], bn=fp.get("bn", True),
+                         row_order=fused.stage2_row_order(w_before, mlp2[-1], w_after) if i == 0 else None)
+                       for i in range(len(fp["mlp"]))]
         stage2.append(dict(sources=[None, points1], layers=layers, before=before, after=after, layers2=layers2))
     (up_a_pooled, _), (up_b_pooled, _) = fused.setconv_pair(jobs[0], jobs[1])
     stage2[0]["sources"][0], stage2[1]["sources"][0] = up_a_pooled, up_b_pooled
@@ -301,7 +310,9 @@ def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distan
             # The centre is xyz_proj[b, h, w] (selected_idx's batch column is the batch index, as
             # get_selected_idx builds it)                                                           :197-230
             widths = [3 + points_proj.shape[-1]] + list(mlp)
-            layers = [fused.packed_layer('conv%d' % i, widths[i], widths[i + 1], bn=bn) for i in range(len(mlp))]
+            layers = [fused.packed_layer('conv%d' % i, widths[i], widths[i + 1], bn=bn,
+                                         row_order=fused.setconv_row_order(widths[0] - 3) if i == 0 else None)
+                      for i in range(len(mlp))]
             out, new_xyz = fused.setconv(xyz_proj, points_proj, None, None, layers, xyz1_grid=xyz_proj,
                                          centre_hw=centre_hw, K=K_sample,
                                          group=fused.Grouping(random_HW, kernel_size, distance))
@@ -334,7 +345,9 @@ def up_conv(xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kernel_size, stride_h,
             P = fused.packed_layer
             w1 = [3 + feat2_proj.shape[-1]] + list(mlp)
             up_feat, _ = fused.setconv(xyz2_proj, feat2_proj, None, None,
-                                       [P('up_1_%d' % j, w1[j], w1[j + 1]) for j in range(len(mlp))],
+                                       [P('up_1_%d' % j, w1[j], w1[j + 1],
+                                          row_order=fused.setconv_row_order(w1[0] - 3) if j == 0 else None)
+                                        for j in range(len(mlp))],
                                        xyz1_grid=xyz1_proj, K=nsample,
                                        group=fused.Grouping(random_HW, kernel_size, distance, stride_h, stride_w))  # :272-298
             w2 = [mlp[-1] + points1.shape[-1]] + list(mlp2)

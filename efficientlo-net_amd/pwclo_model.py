@@ -16,7 +16,7 @@ import math
 import numpy as np
 import torch
 
-from . import _ops, tf_util
+from . import _ops, fused, tf_util
 from .model_util import (PreProcess, ProjectPC2SphericalRing, input_stage, preprocess_gt, get_selected_idx, inv_q, mul_point_q, mul_q_point,
                          softmax_valid, warp_and_project)
 from .pointnet_util import (cost_volume, down_conv, flow_predictor, fused_pairs_available, up_conv,
@@ -147,11 +147,12 @@ def _zero_features(like):
     instead of a fill launch per forward."""
     if torch.is_grad_enabled():
         return torch.zeros_like(like)
-    key = (tuple(like.shape), like.device)
+    dtype = fused.storage_dtype()                   # fp16 feature storage starts here: every kernel keeps its inputs' dtype
+    key = (tuple(like.shape), like.device, dtype)
     if key not in _ZEROS:
         if like.is_cuda and torch.cuda.is_current_stream_capturing():
-            return torch.zeros_like(like)           # never cache a tensor that lives in a graph's private pool
-        _ZEROS[key] = torch.zeros_like(like)
+            return torch.zeros_like(like, dtype=dtype)   # never cache a tensor that lives in a graph's private pool
+        _ZEROS[key] = torch.zeros_like(like, dtype=dtype)
     return _ZEROS[key]
 
 
@@ -285,7 +286,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
         if not inference:
             return None
         return _ops.ProjectionBuffers(batch_size, xyz_proj_f1[level].shape[1] * xyz_proj_f1[level].shape[2],
-                                      out_h_list[g], out_w_list[g], pts_f1[level].shape[-1], dev)
+                                      out_h_list[g], out_w_list[g], pts_f1[level].shape[-1], dev, pts_f1[level].dtype)
     def next_warp(level):          # the cloud + features the NEXT warp moves: run by the pose head's own launches
         return (xyz_proj_f1[level].reshape(batch_size, -1, 3), pts_f1[level]) if inference else None
     next_buffers = projection_buffers(2, 4)

@@ -70,32 +70,41 @@ class Trainer:
             self.opt = torch.optim.Adam(self.params, lr=BASE_LEARNING_RATE)  # main.py:174
         self.step_count = 0
 
+    def _global_batch(self, B):
+        """Samples per step over all ranks: the staircase schedules of main.py:120-138 count samples seen."""
+        return B * self.bucket.world_size()
+
     def _set_lr(self, B):
-        lr = learning_rate(self.step_count, B)
+        lr = learning_rate(self.step_count, self._global_batch(B))
         if self.capturable:
             self._lr.fill_(lr)
         else:
             for g in self.opt.param_groups:
                 g["lr"] = lr
 
-    def _body(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, decay):
-        """zero grads -> forward -> loss -> backward -> all-reduce -> Adam: everything of a step that runs on the GPU."""
+    def _gradients(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, decay):
+        """zero grads -> forward -> loss -> backward: this rank's gradients, in the flat bucket."""
         self.bucket.zero()
         with torch.enable_grad():
             with tf_util.default_store(self.net.store), perm.default_perm_source(self.net.perms):
                 out = pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, True, decay)
             loss = pwclo_model.get_loss(*out[:8], q_gt, t_gt, self.w_x, self.w_q)
             loss.backward()
+        return loss.detach()
+
+    def _body(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, decay):
+        """gradients -> all-reduce -> Adam: everything of a step that runs on the GPU."""
+        loss = self._gradients(xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, decay)
         self.bucket.all_reduce_mean()                                    # the one collective of a training step
         self.opt.step()
-        return loss.detach()
+        return loss
 
     def step(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt):
         """One optimisation step on this rank's batch; returns the (local) loss."""
         B = xyz_f1_proj.shape[0]
         self._set_lr(B)
         self.net.perms.reshuffle()                                       # tf.random_shuffle draws per step
-        loss = self._body(xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, bn_decay(self.step_count, B))
+        loss = self._body(xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, bn_decay(self.step_count, self._global_batch(B)))
         self.net.store.invalidate()                                      # folded / packed inference weights are stale
         self.step_count += 1
         return loss
@@ -121,28 +130,42 @@ class Trainer:
                 self.step(*self._static)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self._decay = bn_decay(self.step_count, B)
+        self._decay = bn_decay(self.step_count, self._global_batch(B))
         self._set_lr(B)
         self.net.perms.reshuffle()
+        # With several ranks the collective stays OUTSIDE the graphs: [gradients] -> eager RCCL all-reduce of the flat
+        # bucket -> [Adam] (two graphs); one rank: the whole step is one graph.
+        self._split = self.bucket.world_size() > 1
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self._loss = self._body(*self._static, self._decay)
+            self._loss = (self._gradients if self._split else self._body)(*self._static, self._decay)
+        self._graph_opt = None
+        if self._split:
+            self._graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_opt):
+                self.opt.step()
         self.net.store.invalidate()
         self.step_count += 1                                             # the capture itself does not run the step...
-        self._graph.replay()                                             # ... this replay does
+        self._replay()                                                   # ... this replay does
         return self
+
+    def _replay(self):
+        self._graph.replay()
+        if self._split:
+            self.bucket.all_reduce_mean()
+            self._graph_opt.replay()
 
     def step_graph(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt):
         """`step` through the captured graph (same batch shape as `capture`)."""
         B = xyz_f1_proj.shape[0]
-        if self._graph is None or bn_decay(self.step_count, B) != self._decay:
+        if self._graph is None or bn_decay(self.step_count, self._global_batch(B)) != self._decay:
             self.capture(xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, warmup=1 if self._graph is not None else 3)
             return self._loss
         for s, x in zip(self._static, (xyz_f1_proj, xyz_f2_proj, q_gt, t_gt)):
             s.copy_(x, non_blocking=True)
         self._set_lr(B)
         self.net.perms.reshuffle()
-        self._graph.replay()
+        self._replay()
         self.net.store.invalidate()
         self.step_count += 1
         return self._loss

@@ -32,6 +32,13 @@ typedef enum elo_status {
 int elo_abi_version(void);          /* bumps when a struct below changes layout */
 int elo_dense_f32(void);            /* 1: built with -DELO_DENSE_F32 (elo_dense.w_packed holds fp32 weights), 0: fp16 hi|lo */
 const char *elo_last_error(void);   /* thread-local, never NULL                 */
+/* Range check of the fp16-split operands (a debugging switch, process-wide; also ELO_RANGE_CHECK=1 in the environment):
+ * while enabled, the fused kernels run instances that COUNT every activation / gathered feature with |x| >= 65504 or
+ * NaN on its way into a matrix-core operand (where the fp16 split saturates instead of raising).
+ * elo_range_check(1 / 0) switches it and returns the previous setting (-1: only query);
+ * elo_range_violations() synchronises `stream`, returns the count since the last call and resets it. */
+int elo_range_check(int enable);
+int elo_range_violations(unsigned long long *count, elo_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Neighbour grouping on the H x W range image.
@@ -205,7 +212,8 @@ int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t stream);
  * scratch: as elo_softmax_valid. */
 typedef struct elo_pose_head_args {
     int batch, npoints, C, hidden;
-    const float *feature, *weight, *xyz;
+    const void *feature, *weight; /* (batch,npoints,C) feat_dtype */
+    const float *xyz;
     const float *W_big, *b_big;   /* (C,hidden), (hidden) */
     const float *W_q, *b_q;       /* (hidden,4), (4)      */
     const float *W_t, *b_t;       /* (hidden,3), (3)      */
@@ -219,9 +227,10 @@ typedef struct elo_pose_head_args {
      * `prepared` and skip its own init launch.  clear_scratch == NULL: no side job. */
     unsigned *clear_scratch;      /* the warp call's `scratch`: its first clear_cells + 4*batch words are set to 0x7f7f7f7f */
     float *clear_xyz;             /* its out_xyz  (clear_cells*3 floats  <- 0) */
-    float *clear_feat;            /* its out_feat (clear_cells*clear_C floats <- 0), NULL when clear_C == 0 */
+    void *clear_feat;             /* its out_feat (clear_cells*clear_C elements of feat_dtype <- 0), NULL when clear_C == 0 */
     long clear_cells;             /* batch*H*W of that call */
     int clear_C;
+    int feat_dtype;               /* ELO_F32 / ELO_F16: storage of feature, weight and of clear_feat (C, clear_C even for fp16) */
 } elo_pose_head_args;
 int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream);
 
@@ -241,14 +250,16 @@ typedef struct elo_warp_project_args {
     int H, W;
     float az_res, vert_res, vert_off;
     const float *xyz;             /* (batch,npoints,3) */
-    const float *feat;            /* (batch,npoints,C) or NULL */
+    const void *feat;             /* (batch,npoints,C) feat_dtype, or NULL */
     const float *q;               /* (batch,4) or NULL = no warp */
     const float *t;               /* (batch,3) */
     float *warped;                /* (batch,npoints,3) OUT (nullable when q == NULL) */
     float *out_xyz;               /* (batch,H,W,3) OUT */
-    float *out_feat;              /* (batch,H,W,C) OUT or NULL */
+    void *out_feat;               /* (batch,H,W,C) feat_dtype OUT, or NULL */
     unsigned *scratch;
     int prepared;                 /* 1: scratch / out_xyz / out_feat were cleared by elo_pose_head (clear_*): no init launch */
+    int feat_dtype;               /* ELO_F32 / ELO_F16 storage of feat / out_feat (fp16: C even; duplicates are summed with
+                                     packed fp16 atomics, i.e. rounded per addition) */
 } elo_warp_project_args;
 int elo_warp_project(const elo_warp_project_args *a, elo_stream_t stream);
 
@@ -285,20 +296,31 @@ int elo_pose_head_warp(const elo_pose_head_args *a, const elo_warp_project_args 
 /* ------------------------------------------------------------------------- *
  * Fused inference kernels: gather/encode -> chain of 1x1 convolutions (BN and
  * bias folded, ReLU) -> pooling, in ONE launch with the activations of a
- * 16/32-row tile resident in LDS and the contractions on the fp32 matrix cores
- * (v_mfma_f32_16x16x4_f32: exact fp32, bit-equal to an fmaf chain).  They
- * compute what the unfused kernels above + the hipBLASLt GEMMs compute, for
- * the launch-bound small-batch regime.
+ * 16/32-row tile resident in LDS and the contractions on the matrix cores.
+ * They compute what the unfused kernels above + the hipBLASLt GEMMs compute,
+ * for the launch-bound small-batch regime.
  *
  * A layer is  y = act(x[K] @ W[K,N] + b[N]).  `w_packed` is W zero-padded to
- * (Kp = ceil16(K), Np = ceil16(N)) and stored in MFMA B-fragment order: 16 bytes per (cb, ks, lane),
+ * (Kp = ceil16(K), Np = ceil16(N)) and stored in MFMA fragment order: 16 bytes per (cb, ks, lane),
  *     element s = 0..3  <->  W[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)]
  * so that one wave-wide 16-byte load is a contiguous 1 KiB.  The 16 bytes hold the four weights SPLIT into fp16
  * hi + lo, [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] with hi = fp16(w), lo = fp16(w - hi): the kernels compute
  * hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x16_f16 with fp32 accumulation (2^-20 relative per product; fp16 range:
- * |x| < 65504 saturates).  (A library built with -DELO_DENSE_F32 expects four fp32 weights instead and uses
- * v_mfma_f32_16x16x4_f32.)  `bias` has Np fp32 entries (zero padded).  Packing is done once per parameter update by
- * the host (efficientlo-net_amd/fused.py).
+ * |x| < 65504 saturates -- see ELO_RANGE_CHECK below).  Activations are split the same way ONCE, by the layer (or the
+ * gather) that produces them, and live in the LDS tile as [hi x4 | lo x4] per four consecutive columns.
+ * (A library built with -DELO_DENSE_F32 expects four fp32 weights instead and uses v_mfma_f32_16x16x4_f32.)
+ * `bias` has Np fp32 entries (zero padded).  Packing is done once per parameter update by the host
+ * (efficientlo-net_amd/fused.py).
+ *
+ * Feature storage.  Every FEATURE tensor these kernels read or write in HBM (fields typed `void *`) is fp32 or fp16
+ * according to the call's `feat_dtype` (ELO_F32 / ELO_F16; BASELINE configs[2]: s = 2 in SURVEY.md section 8(d)).
+ * Geometry (xyz, centres, new_xyz), indices and masks are always fp32 / int32; all arithmetic is as described above
+ * whatever the storage (an fp16 input is an exact operand: hi = x, lo = 0).  fp16 rows are read 16 bytes at a time:
+ * channel counts must be multiples of 8 (fp32: of 4) for the vector paths; other widths take an element-wise path
+ * where one exists (set-conv, row-wise MLP) and are an ELO_ERR_LIMIT otherwise (cost volume).
+ * Masks are 0/1 by contract: `x * mask` is implemented as a select.
+ *
+ * Operands beyond the fp16 range saturate: elo_range_check() above counts them in a debugging run.
  * ------------------------------------------------------------------------- */
 enum { ELO_PRODUCTS_SPLIT = 0,      /* fp32-class: hi/lo split operands, three fp16 MFMA products (default)     */
        ELO_PRODUCTS_HALF = 1 };     /* fp16 arithmetic: operands rounded to nearest fp16, ONE product, fp32 accumulate;
@@ -337,7 +359,9 @@ typedef struct elo_group_spec {
 /* set-conv / set-upconv stage 1:  group_concat -> chain -> masked max over K.
  * utils/pointnet_util.py:197-230 (down_conv) and :272-298 (up_conv). K <= 32.
  * centre_hw != NULL: centre = xyz1_grid[b, centre_hw[b,n,0], centre_hw[b,n,1]] and is also
- * written to new_xyz (the `new_xyz_proj` output of down_conv, :206); else centre = centre_xyz[b,n]. */
+ * written to new_xyz (the `new_xyz_proj` output of down_conv, :206); else centre = centre_xyz[b,n].
+ * layers[0] expects its input rows ordered [features (C), xyz difference (3)] (the reference concatenates
+ * [xyz_diff, features], :213: the host permutes the weight rows when packing; `w_plain` likewise). */
 typedef struct elo_setconv_args {
     int batch, npoints, K;
     int H, W;                     /* xyz1 grid (only with centre_hw)        */
@@ -346,14 +370,15 @@ typedef struct elo_setconv_args {
     const int *centre_hw;         /* (batch,npoints,2) or NULL              */
     const float *centre_xyz;      /* (batch,npoints,3) or NULL              */
     const float *src_xyz;         /* (batch,H2,W2,3)                        */
-    const float *src_feat;        /* (batch,H2,W2,C)                        */
+    const void *src_feat;         /* (batch,H2,W2,C)   feat_dtype           */
     const int *idx;
     const float *mask;
     int n_layers;
     elo_dense layers[ELO_MAX_CHAIN];
-    float *out;                   /* (batch,npoints,layers[last].N)         */
+    void *out;                    /* (batch,npoints,layers[last].N) feat_dtype */
     float *new_xyz;               /* (batch,npoints,3) or NULL              */
     elo_group_spec group;         /* random-k; needs xyz1_grid; centre_hw == NULL: centre n is pixel (n / W, n % W) */
+    int feat_dtype;               /* ELO_F32 / ELO_F16 */
 } elo_setconv_args;
 int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream);
 /* two independent jobs of identical shape in ONE launch (b may be NULL): the embedding and the embedding-mask
@@ -365,57 +390,64 @@ int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_args *b, elo
 typedef struct elo_mlp_args {
     long rows;
     int n_sources;
-    const float *src[3];
+    const void *src[3];           /* (rows, src_width[i]) feat_dtype */
     int src_width[3];
     int n_layers;
     elo_dense layers[ELO_MAX_CHAIN];
-    float *out;                   /* (rows, layers[last].N) */
+    void *out;                    /* (rows, layers[last].N) feat_dtype */
     /* Optional SECOND row-wise MLP in the same launch (n_layers2 > 0), fed by the first one's output: its input rows
-     * are  [ before (w_before) | out | after (w_after) ]  -- flow_predictor's concat [points_f1, upsampled_feat,
-     * cost_volume] (utils/pointnet_util.py:161-166) with the set-upconv stage 2 (:303-311) as the first MLP.
+     * are  [ out | before (w_before) | after (w_after) ]  -- flow_predictor's concat [points_f1, upsampled_feat,
+     * cost_volume] (utils/pointnet_util.py:161-166) with the set-upconv stage 2 (:303-311) as the first MLP and its
+     * output moved to the front (the host permutes the rows of layers2[0] when packing; layers[last].N % 4 == 0).
      * `out` is still written; the second output goes to out2. */
     int n_layers2;
     elo_dense layers2[ELO_MAX_CHAIN];
-    const float *before;          /* (rows, w_before) or NULL with w_before == 0 */
+    const void *before;           /* (rows, w_before) feat_dtype, or NULL with w_before == 0 */
     int w_before;
-    const float *after;           /* (rows, w_after)  or NULL with w_after == 0  */
+    const void *after;            /* (rows, w_after)  feat_dtype, or NULL with w_after == 0  */
     int w_after;
-    float *out2;                  /* (rows, layers2[last].N) */
+    void *out2;                   /* (rows, layers2[last].N) feat_dtype */
+    int feat_dtype;               /* ELO_F32 / ELO_F16 */
 } elo_mlp_args;
 int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream);
 int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_stream_t stream);   /* paired launch, as above */
 
 /* Attentive cost volume, stage 1 (utils/pointnet_util.py:54-100) in one launch:
  * encode -> CV_0..2 -> CV_xyz -> sum_CV_0..1 -> masked softmax over K -> weighted sum.
- * sum_cv0 expects its input rows ordered [x (64), xyz-encoding (64)] (the reference
- * concatenates [encoding, x], :84: the host permutes the weight rows when packing). K <= 32. */
+ * cv0 expects its input rows ordered [feat1 (C), feat2 grouped (C), geometry (10)] (reference: [geometry, feat1,
+ * feat2], :62-66) and sum_cv0 [x (64), xyz-encoding (64)] (reference: [encoding, x], :84): the host permutes the
+ * weight rows when packing.  K <= 32, C % 4 == 0 (fp16 storage: C % 8 == 0). */
 typedef struct elo_cv1_args {
     int batch, npoints, K;
     int H2, W2, C;
-    const float *xyz1, *feat1;    /* (batch,npoints,3), (batch,npoints,C)  */
-    const float *xyz2, *feat2;    /* (batch,H2,W2,3),  (batch,H2,W2,C)     */
+    const float *xyz1;            /* (batch,npoints,3) */
+    const void *feat1;            /* (batch,npoints,C)  feat_dtype */
+    const float *xyz2;            /* (batch,H2,W2,3)   */
+    const void *feat2;            /* (batch,H2,W2,C)    feat_dtype */
     const int *idx;
     const float *mask;
     elo_dense cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1;     /* N: 128,64,64,64,128,64 */
-    float *out;                   /* (batch,npoints,64) */
+    void *out;                    /* (batch,npoints,64) feat_dtype */
     elo_group_spec group;         /* select-k of xyz2 around every pixel of xyz1 (npoints == H2*W2, stride 1) */
+    int feat_dtype;               /* ELO_F32 / ELO_F16 */
 } elo_cv1_args;
 int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream);
 
 /* Attentive cost volume, stage 2 (utils/pointnet_util.py:104-146) in one launch.
  * sum_cost0 expects input rows ordered [cost[idx]*m (64), xyz-encoding (64), feat1 (C)]
- * (reference order [encoding, feat1, grouped], :129). K <= 32, npoints == H*W. */
+ * (reference order [encoding, feat1, grouped], :129). K <= 32, npoints == H*W, C % 4 == 0 (fp16: % 8), C <= 64. */
 typedef struct elo_cv2_args {
     int batch, npoints, K;
     int H, W, C;
     const float *xyz1;            /* (batch,H,W,3)  */
-    const float *feat1;           /* (batch,H,W,C)  */
-    const float *cost;            /* (batch,H,W,64) */
+    const void *feat1;            /* (batch,H,W,C)  feat_dtype */
+    const void *cost;             /* (batch,H,W,64) feat_dtype */
     const int *idx;
     const float *mask;
     elo_dense xyz_enc, sum_cost0, sum_cost1;               /* N: 64,128,64 */
-    float *out;                   /* (batch,npoints,64) */
+    void *out;                    /* (batch,npoints,64) feat_dtype */
     elo_group_spec group;         /* random-k of xyz1 around every pixel of xyz1 (stride 1) */
+    int feat_dtype;               /* ELO_F32 / ELO_F16 */
 } elo_cv2_args;
 int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream);
 

@@ -31,6 +31,30 @@ from . import grouping as G
 F = np.float32
 BN_EPS = F(1e-3)     # tf.contrib.layers.batch_norm default epsilon (utils/tf_util.py:526-531)
 
+# Feature STORAGE type (BASELINE configs[2]: fp16 features in HBM, fp32 arithmetic).  With fp16 every feature tensor an
+# operator of the product hands to the next one through HBM is rounded to fp16 -- the outputs of down_conv,
+# flow_predictor, the projection, and both halves of cost_volume and up_conv (the product runs each half as one kernel).
+# Geometry (xyz) and everything inside an operator stay fp32.  The reference itself has no fp16 mode.
+_STORE = [None]
+
+
+class feature_storage:
+    """`with feature_storage(np.float16):` -- round the operator outputs listed above to fp16."""
+
+    def __init__(self, dtype):
+        self.dtype = None if dtype in (None, np.float32) else dtype
+
+    def __enter__(self):
+        _STORE.append(self.dtype)
+        return self
+
+    def __exit__(self, *exc):
+        _STORE.pop()
+
+
+def _st(x):
+    return x.astype(F) if _STORE[-1] is None else x.astype(_STORE[-1]).astype(F)
+
 
 # --------------------------------------------------------------------------- layers
 def conv(params, scope, x, bn=True, relu=True):
@@ -90,7 +114,7 @@ def down_conv(params, shuffle, xyz_proj, points_proj, selected_idx, K_sample, ke
     for i, _c in enumerate(mlp):
         x = conv(params, "%s/conv%d" % (scope, i), x)                                             # :217-222
     x = x * mask                                                                                  # :224
-    return x.max(axis=2), new_xyz_proj                                                            # :230,:248
+    return _st(x.max(axis=2)), new_xyz_proj                                                       # :230,:248
 
 
 # --------------------------------------------------------------------------- cost volume
@@ -121,7 +145,7 @@ def cost_volume(params, shuffle, warped_xyz1_proj, xyz2_proj, points1_proj, poin
         cat = conv(params, "%s/sum_CV_%d" % (scope, j), cat)                                      # :86-90
     logits = np.where(valid_mask == 1.0, cat, F(-1e10)).astype(F)                                 # :92-94
     WQ = softmax(logits, 2)                                                                       # :96
-    pi_feat1_new = (WQ * x).sum(2).reshape(B, H, W, -1)                                           # :97-100
+    pi_feat1_new = _st((WQ * x).sum(2)).reshape(B, H, W, -1)                                      # :97-100
 
     perm_p = shuffle(scope, "random_HW_p", kernel_size1[0] * kernel_size1[1])
     pc_idx, _, _, valid_mask2 = G.fused_conv_random_k(warped_xyz1_proj, warped_xyz1_proj, idx_hw, perm_p, H, W, H * W,
@@ -139,7 +163,7 @@ def cost_volume(params, shuffle, warped_xyz1_proj, xyz2_proj, points1_proj, poin
         pc_cat = conv(params, "%s/sum_cost_volume_%d" % (scope, j), pc_cat)                       # :131-135
     logits2 = np.where(valid_mask2 == 1.0, pc_cat, F(-1e10)).astype(F)                            # :137-140
     WP = softmax(logits2, 2)                                                                      # :142
-    return (WP * pc_points_grouped).sum(2).astype(F)                                              # :144-146
+    return _st((WP * pc_points_grouped).sum(2))                                                   # :144-146
 
 
 # --------------------------------------------------------------------------- flow predictor / up-conv
@@ -150,7 +174,7 @@ def flow_predictor(params, points_f1, upsampled_feat, cost_vol, mlp, scope):
     x = np.concatenate(parts, -1)[:, :, None, :]
     for i, _c in enumerate(mlp):
         x = conv(params, "%s/conv_predictor%d" % (scope, i), x)
-    return x[:, :, 0, :]
+    return _st(x[:, :, 0, :])
 
 
 def up_conv(params, shuffle, xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kernel_size, stride_h, stride_w, nsample,
@@ -170,11 +194,11 @@ def up_conv(params, shuffle, xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kerne
     for j, _c in enumerate(mlp):
         x = conv(params, "%s/up_1_%d" % (scope, j), x)                                            # :289-293
     x = x * mask                                                                                  # :295
-    up_feat = x.max(axis=2)                                                                       # :298
+    up_feat = _st(x.max(axis=2))                                                                  # :298
     y = np.concatenate([up_feat, points1], -1)[:, :, None, :]                                     # :303-305
     for i, _c in enumerate(mlp2):
         y = conv(params, "%s/up_2_%d" % (scope, i), y)                                            # :307-311
-    return y[:, :, 0, :]
+    return _st(y[:, :, 0, :])
 
 
 # --------------------------------------------------------------------------- quaternions
@@ -275,7 +299,7 @@ def ProjectPC2SphericalRing(PC, Feature, H_input, W_input):
         if Feature is not None:
             _, out_feat[b] = scatter_min_range(cell, r, Feature[b].astype(F), H_input * W_input,
                                                (H_input, W_input, Feature.shape[-1]))
-    return out_xyz, (out_feat if Feature is not None else out_xyz)
+    return out_xyz, (_st(out_feat) if Feature is not None else out_xyz)
 
 
 def softmax_valid(feature_bnc, weight_bnc, mask_valid):
@@ -356,9 +380,15 @@ def pose_head(params, feat_b1c, level, coarse):
     return q, t
 
 
-def get_model_from_projection(params, shuffle, xyz_f1_proj, xyz_f2_proj):
+def get_model_from_projection(params, shuffle, xyz_f1_proj, xyz_f2_proj, coarse_pose=None):
     """pwclo_model.py:69-433 (inference: dropout off, BN moving stats), starting from the two
-    (B,H,W,3) range images that PreProcess + ProjectPC2SphericalRing produce (:61-67)."""
+    (B,H,W,3) range images that PreProcess + ProjectPC2SphericalRing produce (:61-67).
+
+    `coarse_pose` (a test device, not in the reference): {level: (q (B,4), t (B,3))} -- the pose the NEXT finer level
+    warps by and composes with is taken from this table instead of from the oracle's own level `level` ("teacher
+    forcing" with the checked implementation's poses).  Each level's own output is still what the oracle computes, so
+    every level is compared on the same coarse pose and a discrete decision (a point changing its projection cell, a
+    neighbour entering a window) taken differently at a coarse level does not compound into the finer ones."""
     B, H_input, W_input, _ = xyz_f1_proj.shape
     Down_conv_dis, Up_conv_dis, Cost_volume_dis = [0.5, 3.0, 6.0, 12.0], [3.0, 6.0, 9.0], [1.0, 2.0, 4.0]   # :38-40
     sh, sw = [1, 1, 4, 2, 2, 1], [1, 1, 8, 2, 2, 2]                                                        # :42-43
@@ -402,6 +432,8 @@ def get_model_from_projection(params, shuffle, xyz_f1_proj, xyz_f2_proj):
     q, t = pose_head(params, l3_feat, 3, coarse=True)                                                      # :197-208
     l3_q, l3_t = q[:, 0, :], t[:, 0, :]
     outs = {3: (l3_q, l3_t)}
+    if coarse_pose and 3 in coarse_pose:
+        l3_q, l3_t = (np.asarray(v, F) for v in coarse_pose[3])
 
     prev_w_proj, prev_pred_proj, prev_xyz_proj = l3_w_proj, l3_pred_proj, f1["x"][3]
     cv_kernels = {2: [5, 15], 1: [7, 25], 0: [11, 41]}
@@ -426,6 +458,8 @@ def get_model_from_projection(params, shuffle, xyz_f1_proj, xyz_f2_proj):
         q_det, t_det = pose_head(params, feat, lvl, coarse=False)                                          # :264-273
         q_prev, t_prev = compose(q_det, t_det, q_coarse, t_coarse)                                         # :275-280
         outs[lvl] = (q_prev, t_prev)
+        if coarse_pose and lvl in coarse_pose:
+            q_prev, t_prev = (np.asarray(v, F) for v in coarse_pose[lvl])
         prev_w_proj = wgt.reshape(B, oh[gi], ow[gi], -1)
         prev_pred_proj = pred.reshape(B, oh[gi], ow[gi], -1)
         prev_xyz_proj = w_xyz_proj

@@ -220,3 +220,32 @@ def test_in_kernel_grouping_of_fused_kernels_is_bit_exact():
         want = G.fused_conv_random_k(f1, f1, hw_all, perm, 16, 225, 3600, 3, 5, 4, 0, 1.0, 1, 1)
         assert np.array_equal(g.idx.cpu().numpy(), want[0]) and np.array_equal(g.mask.cpu().numpy()[..., None], want[3])
     torch.cuda.synchronize()
+
+
+def test_select_k32_window_5x35_at_batch8_is_bit_exact():
+    """BASELINE configs[2]'s select-k: the l2_origin cost volume's call (5x35 window, K = 32, distance 1000, every pixel
+    of the 4x57 l2 grid of a 64x1800 scan; pwclo_model.py:170-172, utils/pointnet_util.py:49-51) at batch 8, run inside
+    the fused stage-1 kernel with fp16 feature storage: indices and mask equal the oracle's bit for bit."""
+    fused, tf_util = load_pkg("fused"), load_pkg("tf_util")
+    synth = load_pkg("synth")
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    B = 8
+    f1, f2 = synth.frame_pair(B, 64, 1800, seed=31)
+    x1, x2 = np.ascontiguousarray(f1[:, ::16, ::32]), np.ascontiguousarray(f2[:, ::16, ::32])   # the l2 grids: 4 x 57
+    assert x1.shape == (B, 4, 57, 3)
+    rng = np.random.default_rng(8)
+    C = 64
+    fa, fb = (rng.normal(0, 1, (B, 4, 57, C)).astype(np.float16) for _ in range(2))
+    perm = rng.permutation(175).astype(np.int32)
+    store = tf_util.VariableStore(dev, seed=0)
+    with tf_util.default_store(store), torch.no_grad():
+        P = fused.packed_layer
+        g = fused.Grouping(t(perm), [5, 35], 1000, want_indices=True)
+        out = fused.cv_stage1(t(x1).reshape(B, 228, 3), t(fa).reshape(B, 228, C), t(x2), t(fb), None, None,
+                              P("c0", 10 + 2 * C, 128, row_order=fused.cv0_row_order(C)), P("c1", 128, 64), P("c2", 64, 64),
+                              P("cx", 10, 64), P("s0", 128, 128), P("s1", 128, 64), group=g, K=32)
+    assert out.dtype == torch.float16
+    want = G.fused_conv_select_k(x1, x2, synth.hw_index(B, 4, 57), perm, 4, 57, 228, 5, 35, 32, 0, 1000.0, 1, 1)
+    assert np.array_equal(g.idx.cpu().numpy(), want[0]) and np.array_equal(g.mask.cpu().numpy()[..., None], want[3])
+    assert want[3].sum() > 0.5 * want[3].size          # a populated case, not an all-masked one

@@ -298,9 +298,10 @@ def test_cost_volume_kernels_with_fp16_storage(B, H, W, C):
 @pytest.mark.parametrize("rows,w_src,w_before,w_after", [(904, (64, 32), 32, 64), (3600, (64, 16), 16, 64),
                                                          (45, (64, 6), 10, 0), (17, (20,), 0, 7)])
 def test_two_stage_mlp_equals_two_launches(rows, w_src, w_before, w_after):
-    """elo_mlp_args second stage (set-upconv stage 2 -> flow predictor in one launch): out and out2 equal the two
-    separate launches bit for bit (same layers, same summation order), for aligned and unaligned widths, ragged last
-    tile, paired jobs."""
+    """elo_mlp_args second stage (set-upconv stage 2 -> flow predictor in one launch): `out` equals the separate launch
+    bit for bit (same layers, same summation order); `out2` equals the separate launch over concat[before, out, after]
+    to fp32 rounding (the fused kernel keeps its columns as [out | before | after] with the weight rows permuted to
+    match: a different summation order) -- for aligned and unaligned widths, ragged last tile, paired jobs."""
     fused, tf_util = load_pkg("fused"), load_pkg("tf_util")
     rng = np.random.default_rng(rows)
     store = tf_util.VariableStore(DEV, seed=rows)
@@ -312,16 +313,18 @@ def test_two_stage_mlp_equals_two_launches(rows, w_src, w_before, w_after):
             k1 = sum(w_src)
             layers = [P("a0", k1, 128), P("a1", 128, 64)]
             k2 = w_before + 64 + w_after
-            layers2 = [P("b0", k2, 128), P("b1", 128, 64)]
+            layers2 = [P("b0", k2, 128, row_order=fused.stage2_row_order(w_before, 64, w_after)), P("b1", 128, 64)]
+            plain2 = [P("b0", k2, 128), layers2[1]]                  # the same weights in the reference's concat order
         return dict(sources=[r(rows, w) for w in w_src], layers=layers, before=r(rows, w_before) if w_before else None,
-                    after=r(rows, w_after) if w_after else None, layers2=layers2)
-    ja, jb = job("a"), job("b")
+                    after=r(rows, w_after) if w_after else None, layers2=layers2), plain2
+    (ja, pa), (jb, pb) = job("a"), job("b")
     (o1a, o2a), (o1b, o2b) = fused.mlp2_pair(ja, jb)
-    for j, o1, o2 in ((ja, o1a, o2a), (jb, o1b, o2b)):
+    for j, plain2, o1, o2 in ((ja, pa, o1a, o2a), (jb, pb, o1b, o2b)):
         want1 = fused.mlp(j["sources"], j["layers"])
         parts = [p for p in (j["before"], want1, j["after"]) if p is not None]
-        want2 = fused.mlp(parts, j["layers2"])
-        assert torch.equal(o1, want1) and torch.equal(o2, want2)
+        want2 = fused.mlp(parts, plain2)
+        assert torch.equal(o1, want1)
+        assert torch.allclose(o2, want2, rtol=1e-5, atol=1e-5)
 
 
 def test_dense_layers_keep_fp32_class_accuracy_across_magnitudes():
