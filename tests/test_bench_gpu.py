@@ -1,5 +1,6 @@
 """GPU: bench.py keeps its output contract -- ONE JSON line with the driver's keys, the roofline and cpu_baseline
-objects, finite positive numbers -- on a short run."""
+objects, finite positive numbers -- on a short run; `--gpus 2` started plainly becomes two ranks (sharing the one GPU
+of the test box over gloo: a rehearsal of the launch path, not a scaling measurement)."""
 import json
 import math
 import os
@@ -12,28 +13,51 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _line(out):
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]      # (gloo announces its connections on stdout)
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
 def test_bench_line_contract():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "8", "--cpu-pairs", "2"],
-                         cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "8", "--cpu-pairs", "2",
+                          "--train-steps", "2"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    d = _line(out)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
-    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 8 and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 16 and d["higher_is_better"] is True   # warm-up >= 2 per lane
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and math.isfinite(d["value"]) and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-3   # B = 1
+    assert d["repeats"] >= 2 and d["repeats"] * 40 * d["ms_per_step"] / 1e3 > 0.15          # >= 0.25 s of timed signal
     r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
         assert key in r, key
-    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    for leg in ("per_operator_b8", "per_operator_b64", "per_operator_all_levels_b8"):
-        assert r[leg]["bound"] == "hbm" and 0 < r[leg]["frac"] < 1
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["mfma"]["peak"] == 2500.0 and 0 < r["mfma"]["frac"] < 1                          # the dtype ISSUED: fp16
+    for leg in ("cost_volume_b8_f32", "cost_volume_b8_f16", "per_operator_b8_f32", "per_operator_b64_f16"):
+        assert r[leg]["bound"] == "hbm" and 0 < r[leg]["frac"] < 1, leg
+    assert set(r["cost_volume_b8_f16"]["levels"]) == {"l0", "l1", "l2", "l2_origin"}
     c = d["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample", "one_core", "cores_available"):
         assert key in c, key
-    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
-    assert d["from_raw_clouds"]["value"] > 0 and d["batch8"]["f32"] > 0 and d["batch8"]["f16_products"] > 0
+    assert c["kind"] in ("reference", "port") and c["cores"] == os.cpu_count() and c["value"] > 0 and c["one_core"] > 0
+    assert d["from_raw_clouds"]["value"] > 0
+    b8 = d["batch8"]
+    assert b8["f32"] > 0 and b8["f16_features"] > 0 and b8["f16_features_f16_products"] > 0
+    assert d["dense_f32"]["value"] and d["dense_f32"]["value"] > 0
+    t = d["train_dp"]
+    assert t["n_gpus"] == 1 and t["value"] > 0 and t["batch_per_gpu"] == 8
+
+
+def test_bench_gpus_2_launches_two_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ELO_BENCH_BACKEND"] = "gloo"                    # two ranks on ONE GPU: RCCL would refuse the duplicate device
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "8",
+                          "--lanes", "4", "--train-steps", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    assert d["train_dp"]["n_gpus"] == 2 and d["train_dp"]["value"] > 0 and "gloo" in d["train_dp"]["collective"]
+    assert "roofline" not in d                            # the N = 1 legs stay with N = 1

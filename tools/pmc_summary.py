@@ -15,6 +15,7 @@ def main(src, dst):
         tag = os.path.basename(info)[:-5]
         meta = json.load(open(info))
         kname = KNAME[meta["kernel"]]
+        meta.setdefault("half", False)
         durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
                 for r in csv.DictReader(open(os.path.join(src, tag + ".trace", "t_kernel_trace.csv"))) if kname in r["Kernel_Name"]][5:]
         avg = sum(durs) / len(durs)
@@ -34,7 +35,11 @@ def main(src, dst):
             row["frac_of_fp32_mfma_peak"] = round(meta["flops"] / avg / 1e3 / 157.3, 4)
         res.append(row)
         print(row)
-    json.dump(res, open(dst, "w"), indent=1)
+    # keyed the way bench.py's `traffic` lookup wants it: "<kernel>/b<batch>/<f32|f16>" -> HBM bytes per launch (FETCH_SIZE x2)
+    table = {"%s/b%d/%s" % (r["kernel"], r["batch"], "f16" if r["tag"].split("_b")[0].endswith("_f16") else "f32"):
+             {"traffic_bytes": int(r["hbm_MB_fetch_x2"] * 1e6), "avg_us": r["avg_us"], "tag": r["tag"]} for r in res}
+    table["rows"] = res
+    json.dump(table, open(dst, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -17,7 +17,7 @@ import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--kernel", default="cv1"); ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--reps", type=int, default=20); ap.add_argument("--pregrouped", action="store_true"); ap.add_argument("--time", action="store_true")
-ap.add_argument("--half", action="store_true", help="fp16 feature storage (encode1/encode2/pool/pool2)")
+ap.add_argument("--half", action="store_true", help="fp16 feature storage (cv1/encode1/encode2/pool/pool2)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ops, fused, tf_util, synth, elo = pkg("_ops"), pkg("fused"), pkg("tf_util"), pkg("synth"), pkg()
@@ -34,8 +34,9 @@ if a.kernel == "cv1":
     store = tf_util.VariableStore(dev, seed=0)
     with tf_util.default_store(store), torch.no_grad():
         P = fused.packed_layer
-        layers = (P('CV_0', 10 + 2 * C, 128), P('CV_1', 128, 64), P('CV_2', 64, 64), P('CV_xyz', 10, 64),
-                  P('sum_CV_0', 128, 128), P('sum_CV_1', 128, 64))
+        layers = (P('CV_0', 10 + 2 * C, 128, row_order=fused.cv0_row_order(C)), P('CV_1', 128, 64), P('CV_2', 64, 64),
+                  P('CV_xyz', 10, 64), P('sum_CV_0', 128, 128), P('sum_CV_1', 128, 64))
+    feat1, feat2 = cast(feat1), cast(feat2)                  # --half: fp16 feature storage (BASELINE configs[2])
     grp = fused.Grouping(order, [11, 41], 1000)
     if a.pregrouped:
         hw = torch.from_numpy(synth.hw_index(B, H, W)).to(dev)
