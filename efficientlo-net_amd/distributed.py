@@ -60,19 +60,13 @@ def quat2mat(q):
 
 
 def chain_poses(poses_n7, Tr=None):
-    """Ordered running product of the per-pair transforms, main.py:557-572: TT = Tr [R|t] Tr^-1,
-    T_final <- T_final TT; returns (n+1, 12) rows (first row = identity) as the evaluator's *_pred.txt holds."""
-    Tr = np.eye(4) if Tr is None else np.asarray(Tr, dtype=np.float64)
-    Tr_inv = np.linalg.inv(Tr)
-    T_final = np.eye(4)
-    rows = [T_final[:3, :].reshape(12).copy()]
-    for p in np.asarray(poses_n7, dtype=np.float64):
-        T = np.eye(4)
-        T[:3, :3] = quat2mat(p[:4])
-        T[:3, 3] = p[4:7]
-        T_final = T_final @ (Tr @ T @ Tr_inv)
-        rows.append(T_final[:3, :].reshape(12).copy())
-    return np.stack(rows)
+    """Ordered running product of the per-sample transforms, main.py:557-572: TT = Tr [R|t] Tr^-1, T_final <- T_final TT
+    (T_final = TT for sample 0).  Returns (n, 12) rows, ONE per sample -- row 0 is sample 0's own prediction, not a
+    prepended identity -- exactly what the reference writes to *_pred.txt and what evaluate.pose_rows returns (this is the
+    same function on the gathered (n,7) [q | t] log of distributed.gather_poses)."""
+    from .evaluate import pose_rows
+    p = np.asarray(poses_n7, dtype=np.float64).reshape(-1, 7)
+    return pose_rows(p[:, :4], p[:, 4:7], np.eye(4) if Tr is None else Tr)
 
 
 class FlatGradBucket:

@@ -6,7 +6,8 @@
   * relative_from_absolute        how ground_truth_pose/kitti_T_diff/*.npy relates to ground_truth_pose/*.txt
   * write_pred_txt                main.py:574-583 (12 floats per line)
   * sequence_errors / overall     kitti_evaluation.py:103-195 (segment lengths 100..800 m, every 10th frame)
-Pose chaining of the network output lives in distributed.chain_poses (main.py:557-572).
+Pose chaining of the network output lives in evaluate.pose_rows (main.py:557-572; distributed.chain_poses is the same
+function on the gathered (n,7) pose log).
 """
 import os
 

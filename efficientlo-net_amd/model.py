@@ -64,6 +64,7 @@ class PWCLONet:
         self._static_in = None
         self._static_out = None
         self._lanes = []
+        self._captured_at = None          # (store.generation, perms.generation) the graphs were recorded under
 
     # -- eager ---------------------------------------------------------------
     def forward(self, xyz_f1_proj, xyz_f2_proj, is_training=False, bn_decay=None, pose_out=None):
@@ -132,13 +133,25 @@ class PWCLONet:
         torch.cuda.synchronize(dev)
         self._graph, self._static_in, self._static_out = (self._lanes[0]["graph"], self._lanes[0]["in"],
                                                           self._lanes[0]["out"])
+        self._captured_at = (self.store.generation, self.perms.generation)
         return self
+
+    def _check_fresh(self):
+        """A captured graph holds raw device pointers to the folded / packed inference weights and to the decoded
+        visiting orders.  VariableStore.invalidate() (load_state_dict, tf_checkpoint.load_into, a training step) and
+        PermSource.reshuffle() drop those tensors: replaying would read stale weights or recycled memory, silently."""
+        if self._graph is None:
+            raise RuntimeError("no captured graph: call capture() first")
+        if self._captured_at != (self.store.generation, self.perms.generation):
+            raise RuntimeError("the captured graph is stale: the variables or the visiting orders changed after capture() "
+                               "(checkpoint load, training step or reshuffle) -- call capture() again")
 
     def load_inputs(self, xyz_f1_proj, xyz_f2_proj):
         self._static_in[0].copy_(xyz_f1_proj, non_blocking=True)
         self._static_in[1].copy_(xyz_f2_proj, non_blocking=True)
 
     def replay(self):
+        self._check_fresh()
         self._graph.replay()
         return self._static_out
 
@@ -146,6 +159,7 @@ class PWCLONet:
         """Enqueue one forward on lane `lane_index` (its own stream); returns the lane's static outputs,
         valid once that stream has been synchronised (or waited on).  With `xyz_f2_proj` None the first
         argument is the stacked pair (2B,H,W,3) = [frame 1 | frame 2]: one copy instead of two."""
+        self._check_fresh()
         lane = self._lanes[lane_index]
         with torch.cuda.stream(lane["stream"]):
             if xyz_f2_proj is None:
@@ -158,6 +172,7 @@ class PWCLONet:
 
     def submit_points(self, lane_index, point_cloud):
         """Enqueue one forward from raw clouds (B, 2N, stride) on a lane captured with `num_points`."""
+        self._check_fresh()
         lane = self._lanes[lane_index]
         with torch.cuda.stream(lane["stream"]):
             lane["cloud"].copy_(point_cloud, non_blocking=True)

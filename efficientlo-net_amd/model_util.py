@@ -99,12 +99,18 @@ def get_selected_idx(array, stride_h, stride_w, out_h, out_w):
     """model_util.py:296-316 -> (B,out_h,out_w,3) int32 (b, i*stride_h, j*stride_w)."""
     batch = array.shape[0]
     key = (batch, stride_h, stride_w, out_h, out_w, str(array.device))
+    capturing = array.is_cuda and torch.cuda.is_current_stream_capturing()
     if key not in _sel_cache:
         dev = array.device
         hh = (torch.arange(out_h, dtype=torch.int32, device=dev) * stride_h).view(1, -1, 1, 1).expand(batch, out_h, out_w, 1)
         ww = (torch.arange(out_w, dtype=torch.int32, device=dev) * stride_w).view(1, 1, -1, 1).expand(batch, out_h, out_w, 1)
         bb = torch.arange(batch, dtype=torch.int32, device=dev).view(-1, 1, 1, 1).expand(batch, out_h, out_w, 1)
-        _sel_cache[key] = torch.cat([bb, hh, ww], -1).contiguous()
+        grid = torch.cat([bb, hh, ww], -1).contiguous()
+        if capturing:
+            return grid                     # a tensor born inside a graph's private pool is never cached
+        if len(_sel_cache) >= 256:
+            _sel_cache.clear()
+        _sel_cache[key] = grid
     return _sel_cache[key]
 
 

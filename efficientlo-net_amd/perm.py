@@ -23,6 +23,7 @@ class PermSource:
         self.fn = fn
         self._bufs = {}
         self._draws = 0
+        self.generation = 0       # bumped by reshuffle(): the decoded orders a captured inference graph points at are dropped
 
     def _draw(self, scope, tag, KT):
         if self.fn is not None:
@@ -41,6 +42,7 @@ class PermSource:
         """Draw a new order into every existing buffer (same storage)."""
         for (scope, tag, KT, _dev), buf in self._bufs.items():
             buf.copy_(torch.from_numpy(self._draw(scope, tag, KT).copy()), non_blocking=True)
+        self.generation += 1
 
 
 _current = [PermSource()]

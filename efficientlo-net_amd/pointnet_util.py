@@ -67,7 +67,12 @@ def get_hw_idx(B, H, W, device="cuda"):
     if key not in _hw_cache:
         hh = torch.arange(H, dtype=torch.int32, device=device).view(1, H, 1, 1).expand(B, H, W, 1)
         ww = torch.arange(W, dtype=torch.int32, device=device).view(1, 1, W, 1).expand(B, H, W, 1)
-        _hw_cache[key] = torch.cat([hh, ww], -1).reshape(B, H * W, 2).contiguous()
+        grid = torch.cat([hh, ww], -1).reshape(B, H * W, 2).contiguous()
+        if grid.is_cuda and torch.cuda.is_current_stream_capturing():
+            return grid                     # a tensor born inside a graph's private pool is never cached
+        if len(_hw_cache) >= 256:
+            _hw_cache.clear()
+        _hw_cache[key] = grid
     return _hw_cache[key]
 
 

@@ -40,6 +40,7 @@ class VariableStore:
         self.tf_shapes = {}       # name -> shape as the TF checkpoint stores it
         self._scope = []
         self._folded = {}
+        self.generation = 0       # bumped by invalidate(): a captured hipGraph holds pointers to the folded / packed tensors
         self._gen = torch.Generator(device="cpu")
         self._gen.manual_seed(seed)
 
@@ -93,8 +94,10 @@ class VariableStore:
         self.invalidate()
 
     def invalidate(self):
-        """Drop folded inference weights (call after any parameter update)."""
+        """Drop folded inference weights (call after any parameter update).  Graphs captured before this call read the
+        dropped tensors' memory: PWCLONet compares `generation` and refuses to replay them."""
         self._folded.clear()
+        self.generation += 1
 
     # -- inference folding --------------------------------------------------
     def folded(self, scope_name, W, b, bn):

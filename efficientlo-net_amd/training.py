@@ -177,8 +177,9 @@ class Trainer:
         (what main.py:233 `saver.save` produces, minus the optimiser slots)."""
         state = {k: v.detach().cpu().numpy() for k, v in self.net.store.state_dict().items()}
         state["w_x"], state["w_q"] = self.w_x.detach().cpu().numpy(), self.w_q.detach().cpu().numpy()
-        if tf_bundle:
-            return tf_checkpoint.save_checkpoint(path, state)
+        if tf_bundle:        # variables in the shapes TensorFlow stores them ([1,1,cin,cout] / [1,cin,cout] kernels): Saver.restore-able
+            shapes = self.net.store.tf_shapes
+            return tf_checkpoint.save_checkpoint(path, {k: v.reshape(shapes.get(k, v.shape)) for k, v in state.items()})
         opt = self.opt.state_dict()["state"]
         for i, p in enumerate(self.params):
             if i in opt:

@@ -78,3 +78,9 @@ g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared -w -I"$TMP" \
     "$TMP/elo_ref_fused_conv_random_k.cpp" "$TMP/elo_ref_fused_conv_select_k.cpp" \
     -o "$OUT/libelo_ref.so"
 echo "built $OUT/libelo_ref.so"
+# The same bodies WITH contraction (nvcc contracts a*b+c into fma by default, fused_conv.sh:2 passes no -fmad=false):
+# tests/test_oracle_vs_ref.py checks that the goldens and the sweep do not depend on it.
+g++ -O2 -std=c++17 -ffp-contract=fast -mfma -fPIC -shared -w -I"$TMP" \
+    "$TMP/elo_ref_fused_conv_random_k.cpp" "$TMP/elo_ref_fused_conv_select_k.cpp" \
+    -o "$OUT/libelo_ref_fma.so"
+echo "built $OUT/libelo_ref_fma.so"

@@ -16,6 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ORACLE_SO = os.path.join(_HERE, "libelo_oracle.so")
 _REF_SO = os.path.join(_HERE, "_ref", "libelo_ref.so")
+_REF_FMA_SO = os.path.join(_HERE, "_ref", "libelo_ref_fma.so")     # the same bodies built with -ffp-contract=fast -mfma
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 _i32p = ctypes.POINTER(ctypes.c_int)
@@ -30,7 +31,7 @@ def build(force=False):
     if force or not os.path.exists(_ORACLE_SO) or os.path.getmtime(_ORACLE_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "libelo_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir(os.environ.get("ELO_REFERENCE_DIR", "/root/reference")):
-        if force or not os.path.exists(_REF_SO):
+        if force or not os.path.exists(_REF_SO) or not os.path.exists(_REF_FMA_SO):
             subprocess.check_call(["bash", os.path.join(_HERE, "build_ref.sh")], stdout=subprocess.DEVNULL)
 
 
@@ -48,9 +49,10 @@ def _lib(which):
                 fn.argtypes = _COMMON + [ctypes.c_int]
                 fn.restype = ctypes.c_int
         else:
-            if not os.path.exists(_REF_SO):
-                raise FileNotFoundError(_REF_SO)
-            lib = ctypes.CDLL(_REF_SO)
+            path = _REF_FMA_SO if which == "ref_fma" else _REF_SO
+            if not os.path.exists(path):
+                raise FileNotFoundError(path)
+            lib = ctypes.CDLL(path)
             for op in ("random", "select"):
                 fn = getattr(lib, "elo_ref_fused_conv_%s_k" % op)
                 fn.argtypes = _COMMON
@@ -61,6 +63,10 @@ def _lib(which):
 
 def have_ref():
     return os.path.exists(_REF_SO)
+
+
+def have_ref_fma():
+    return os.path.exists(_REF_FMA_SO)
 
 
 def _run(op, impl, xyz1, xyz2, idx_n2, random_hw, npoints, kH, kW, K, flag_copy, distance,
@@ -86,7 +92,7 @@ def _run(op, impl, xyz1, xyz2, idx_n2, random_hw, npoints, kH, kW, K, flag_copy,
     if impl == "oracle":
         rc = getattr(_lib("oracle"), "elo_oracle_fused_conv_%s_k" % op)(*args, int(threads))
     else:
-        rc = getattr(_lib("ref"), "elo_ref_fused_conv_%s_k" % op)(*args)
+        rc = getattr(_lib(impl), "elo_ref_fused_conv_%s_k" % op)(*args)
     if rc != 0:
         raise ValueError("oracle rejected the arguments (rc=%d)" % rc)
     return sel, valid, indis, mask

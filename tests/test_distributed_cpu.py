@@ -84,11 +84,12 @@ def test_chain_poses_matches_direct_products():
     t = rng.normal(0, 1, (5, 3))
     Tr = np.eye(4); Tr[:3, :3] = D.quat2mat(rng.normal(0, 1, 4)); Tr[:3, 3] = [0.1, -0.2, 0.3]
     rows = D.chain_poses(np.concatenate([q, t], 1), Tr)
-    assert rows.shape == (6, 12) and np.allclose(rows[0], np.eye(4)[:3].reshape(12))
+    assert rows.shape == (5, 12)                                     # one row per sample, no prepended identity (main.py:557-572)
     T = np.eye(4)
     for i in range(5):
         M = np.eye(4); M[:3, :3] = D.quat2mat(q[i]); M[:3, 3] = t[i]
         T = T @ Tr @ M @ np.linalg.inv(Tr)
-        assert np.allclose(rows[i + 1], T[:3].reshape(12))
+        assert np.allclose(rows[i], T[:3].reshape(12))
+    assert np.array_equal(rows, load_pkg("evaluate").pose_rows(q, t, Tr))      # the one chaining convention
     R = D.quat2mat([np.cos(0.3), 0, 0, np.sin(0.3)])               # rotation about z by 0.6 rad
     assert np.allclose(R, [[np.cos(0.6), -np.sin(0.6), 0], [np.sin(0.6), np.cos(0.6), 0], [0, 0, 1]])

@@ -210,3 +210,39 @@ def test_data_augmentation_is_a_clipped_rigid_transform():
     Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
     Rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
     assert np.allclose(T[:3, :3], Rx @ Ry @ Rz, atol=1e-15)
+
+
+def test_trainer_tf_bundle_has_the_reference_checkpoint_shapes(tmp_path):
+    """Trainer.save(tf_bundle=True) writes every variable in the shape TensorFlow stores it (1x1 kernels as
+    [1,1,cin,cout], conv1d kernels as [1,cin,cout]): the written index equals the reference checkpoint's index fixture
+    name for name and shape for shape (a TF Saver.restore checks exactly that), and loads back bit for bit."""
+    model, training, tc = load_pkg("model"), load_pkg("training"), load_pkg("tf_checkpoint")
+    net = model.PWCLONet("cpu", seed=3)
+    tr = training.Trainer(net)
+    prefix = str(tmp_path / "model.ckpt")
+    tr.save(prefix, tf_bundle=True)
+    _, entries = tc.read_index(prefix, verify=True)
+    with open(os.path.join(GOLDEN, "ckpt_index_shapes.json")) as f:
+        fixture = {k: v for k, v in json.load(f).items() if k != "Variable"}          # the global step is the trainer's own
+    assert {k: list(e.shape) for k, e in entries.items()} == fixture
+    before = {k: v.clone() for k, v in net.store.state_dict().items()}
+    with torch.no_grad():
+        for p in net.store.parameters():
+            p.add_(1.0)
+    training.Trainer(net).load(prefix)
+    for k, v in net.store.state_dict().items():
+        assert torch.equal(v, before[k]), k
+
+
+def test_store_and_perm_generations_track_invalidation():
+    """What a captured inference graph depends on is versioned: VariableStore.invalidate() (checkpoint load, training
+    step) and PermSource.reshuffle() bump a generation that PWCLONet compares before every replay."""
+    tf_util, perm = load_pkg("tf_util"), load_pkg("perm")
+    store, src = tf_util.VariableStore("cpu"), perm.PermSource(seed=1)
+    g0, p0 = store.generation, src.generation
+    store.invalidate()
+    src.get("s", "t", 15, "cpu")
+    src.reshuffle()
+    assert store.generation == g0 + 1 and src.generation == p0 + 1
+    store.load_state_dict({})
+    assert store.generation == g0 + 2

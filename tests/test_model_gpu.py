@@ -232,3 +232,26 @@ def test_graph_from_raw_clouds_equals_forward_points(kernel_path):
         torch.cuda.synchronize()
         for g, w_ in zip(out[:8], want):
             assert torch.equal(g, w_)
+
+
+def test_stale_graph_refuses_to_replay():
+    """A captured graph points at the folded / packed weights and the decoded visiting orders; after
+    VariableStore.invalidate() (checkpoint load, training step) or PermSource.reshuffle() those tensors are gone:
+    replay / submit / __call__ raise instead of reading stale memory, and a new capture() works."""
+    model, synth = load_pkg("model"), load_pkg("synth")
+    f1, f2 = synth.frame_pair(1, 64, 900, seed=3)
+    a, b = torch.from_numpy(f1).to(DEV), torch.from_numpy(f2).to(DEV)
+    net = model.PWCLONet(DEV, seed=1)
+    net.capture(1, 64, 900, lanes=2)
+    first = [x.clone() for x in net(a, b)]
+    net.store.load_state_dict({k: v * 1.0 for k, v in net.store.state_dict().items()})     # same values, new tensors
+    for call in (lambda: net(a, b), net.replay, lambda: net.submit(0, a, b)):
+        with pytest.raises(RuntimeError, match="stale"):
+            call()
+    net.capture(1, 64, 900, lanes=2)
+    again = net(a, b)
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(first, again))
+    net.perms.reshuffle()
+    with pytest.raises(RuntimeError, match="stale"):
+        net.replay()
