@@ -123,7 +123,7 @@ def sequence_errors(poses_gt_n12, poses_pred_n12):
 
 def overall(err):
     """kitti_evaluation.py:183-195 -> (t_rel in %, r_rel in deg per 100 m), the numbers of doc/result.png."""
-    if not err:
+    if len(err) == 0:
         return float("nan"), float("nan")
     e = np.asarray(err)
     return float(e[:, 2].mean() * 100.0), float(e[:, 1].mean() / np.pi * 180.0 * 100.0)

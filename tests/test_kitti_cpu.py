@@ -87,3 +87,24 @@ def test_pose_rows_on_known_motion():
         assert np.allclose(rows[i].reshape(3, 4)[:, :3], np.eye(3), atol=1e-9)
         assert np.allclose(rows[i].reshape(3, 4)[:, 3], (i + 1) * step, atol=1e-9)
     assert ev.pose_rows(np.zeros((0, 4)), np.zeros((0, 3)), TR).shape == (0, 12)
+
+
+def test_metrics_equal_the_reference_evaluator():
+    """kitti.sequence_errors / overall against numbers produced by the REFERENCE'S OWN evaluator methods
+    (kitti_evaluation.py:103-195, run in the authoring container by tests/golden/make_kitti_metrics.py) on a committed
+    (ground truth, perturbed prediction) pair of sequence-04 trajectories: every per-segment row
+    [first_frame, r_err/len, t_err/len, len, speed], the cumulative distances and the overall averages -- including a
+    prediction that ends before the ground truth does."""
+    K = load_pkg("kitti")
+    d = np.load(os.path.join(GOLDEN, "kitti_metrics.npz"))
+    gt, pred = d["gt"], d["pred"]
+    assert np.allclose(K.trajectory_distances([K.to_4x4(r) for r in gt]), d["dist"], rtol=1e-12, atol=1e-9)
+    err = np.asarray(K.sequence_errors(gt, pred))
+    assert err.shape == d["err"].shape == (43, 5)
+    assert np.array_equal(err[:, [0, 3]], d["err"][:, [0, 3]])                       # same segments
+    assert np.allclose(err, d["err"], rtol=1e-9, atol=1e-12)
+    t_rel, r_rel = K.overall(err)
+    ave_t, ave_r = d["overall"]                                                        # the reference's raw averages ...
+    assert abs(t_rel - ave_t * 100.0) < 1e-9 and abs(r_rel - ave_r / np.pi * 180.0 * 100.0) < 1e-9   # ... in %, deg/100 m
+    short = np.asarray(K.sequence_errors(gt, pred[:200]))
+    assert short.shape == d["err_short"].shape and np.allclose(short, d["err_short"], rtol=1e-9, atol=1e-12)
