@@ -67,6 +67,31 @@ InputStageArgs = _struct("elo_input_stage_args", [
     ("vert_off", _f), ("crop_xy", _f), ("cloud", _vp), ("T_trans", _vp), ("aug_frame", _vp), ("points", _vp),
     ("out_xyz", _vp), ("scratch", _vp)])
 
+# backward passes (csrc/elo_backward.hip)
+GroupConcatBwdArgs = _struct("elo_group_concat_bwd_args", [
+    ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
+    ("grad_out", _vp), ("idx", _vp), ("mask", _vp), ("grad_centre", _vp), ("grad_src_xyz", _vp), ("grad_src_feat", _vp)])
+MaskedMaxpoolBwdArgs = _struct("elo_masked_maxpool_bwd_args", [
+    ("batch", _i), ("npoints", _i), ("K", _i), ("C", _i), ("x", _vp), ("mask", _vp), ("grad_out", _vp), ("grad_x", _vp)])
+CvEncode1BwdArgs = _struct("elo_cv_encode1_bwd_args", [
+    ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
+    ("xyz1", _vp), ("xyz2", _vp), ("idx", _vp), ("mask", _vp), ("grad_out", _vp),
+    ("grad_xyz1", _vp), ("grad_feat1", _vp), ("grad_xyz2", _vp), ("grad_feat2", _vp)])
+CvEncode2BwdArgs = _struct("elo_cv_encode2_bwd_args", [
+    ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("C", _i), ("Cc", _i),
+    ("xyz1", _vp), ("idx", _vp), ("mask", _vp), ("grad_xyz_cat", _vp), ("grad_rest", _vp),
+    ("grad_xyz1", _vp), ("grad_feat1", _vp), ("grad_cost", _vp)])
+SoftmaxPoolBwdArgs = _struct("elo_softmax_pool_bwd_args", [
+    ("batch", _i), ("npoints", _i), ("K", _i), ("C", _i), ("logits", _vp), ("values", _vp), ("values_stride", _i),
+    ("mask", _vp), ("grad_out", _vp), ("grad_logits", _vp), ("grad_values", _vp)])
+SoftmaxValidBwdArgs = _struct("elo_softmax_valid_bwd_args", [
+    ("batch", _i), ("npoints", _i), ("C", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp), ("grad_out", _vp),
+    ("grad_feature", _vp), ("grad_weight", _vp)])
+WarpProjectBwdArgs = _struct("elo_warp_project_bwd_args", [
+    ("batch", _i), ("npoints", _i), ("C", _i), ("H", _i), ("W", _i), ("az_res", _f), ("vert_res", _f), ("vert_off", _f),
+    ("xyz", _vp), ("q", _vp), ("t", _vp), ("scratch", _vp), ("grad_out_xyz", _vp), ("grad_out_feat", _vp),
+    ("grad_warped", _vp), ("grad_xyz", _vp), ("grad_feat", _vp), ("grad_q", _vp), ("grad_t", _vp)])
+
 Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i), ("w_plain", _vp),
                               ("products", _i)])
 _l = ctypes.c_long
@@ -112,6 +137,13 @@ SYMBOLS = [
     ("elo_warp_project", ctypes.c_int, [ctypes.POINTER(WarpProjectArgs), _vp]),
     ("elo_input_stage", ctypes.c_int, [ctypes.POINTER(InputStageArgs), _vp]),
     ("elo_pose_head_warp", ctypes.c_int, [ctypes.POINTER(PoseHeadArgs), ctypes.POINTER(WarpProjectArgs), _vp]),
+    ("elo_group_concat_backward", ctypes.c_int, [ctypes.POINTER(GroupConcatBwdArgs), _vp]),
+    ("elo_masked_maxpool_backward", ctypes.c_int, [ctypes.POINTER(MaskedMaxpoolBwdArgs), _vp]),
+    ("elo_cv_encode1_backward", ctypes.c_int, [ctypes.POINTER(CvEncode1BwdArgs), _vp]),
+    ("elo_cv_encode2_backward", ctypes.c_int, [ctypes.POINTER(CvEncode2BwdArgs), _vp]),
+    ("elo_masked_softmax_pool_backward", ctypes.c_int, [ctypes.POINTER(SoftmaxPoolBwdArgs), _vp]),
+    ("elo_softmax_valid_backward", ctypes.c_int, [ctypes.POINTER(SoftmaxValidBwdArgs), _vp]),
+    ("elo_warp_project_backward", ctypes.c_int, [ctypes.POINTER(WarpProjectBwdArgs), _vp]),
     ("elo_setconv_fused", ctypes.c_int, [ctypes.POINTER(SetconvArgs), _vp]),
     ("elo_mlp_fused", ctypes.c_int, [ctypes.POINTER(MlpArgs), _vp]),
     ("elo_setconv_fused2", ctypes.c_int, [ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),

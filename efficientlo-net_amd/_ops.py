@@ -1,6 +1,8 @@
-"""Thin torch-tensor front-ends of the fused feature kernels (include/elo.h,
-csrc/elo_features.hip).  Forward only at this layer; shapes are validated in C
-as well.  No CPU fallback: CPU tensors raise."""
+"""Thin torch-tensor front-ends of the feature kernels (include/elo.h, csrc/elo_features.hip) and of their hand-written
+backward passes (csrc/elo_backward.hip).  Every public operator here is ONE implementation: the HIP kernel.  When an
+input requires grad (training) the call goes through a torch.autograd.Function whose forward is that same kernel and
+whose backward is the matching `elo_*_backward` kernel -- there is no second (torch) implementation to fall onto and
+nothing here looks at the global autograd mode.  Shapes are validated in C as well.  No CPU fallback: CPU tensors raise."""
 import math
 
 import numpy as np
@@ -10,14 +12,11 @@ import torch
 from . import _lib as L
 
 
-def active():
-    """The op set for the current mode: hand-written HIP kernels for inference, their differentiable
-    torch twins (_ops_torch.py) when autograd is recording (training)."""
-    if torch.is_grad_enabled():
-        from . import _ops_torch
-        return _ops_torch
-    import sys
-    return sys.modules[__name__]
+def _wants_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+_ptr = lambda x: x.data_ptr() if x is not None else None
 
 
 def _feature_dtype(*ts):
@@ -38,8 +37,37 @@ def _f32(*ts):
     return out
 
 
+class _GroupConcat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, centre_xyz, src_xyz, src_feat, idx, mask):
+        ctx.save_for_backward(idx, mask)
+        ctx.shapes = (centre_xyz.shape, src_xyz.shape, src_feat.shape)
+        return _group_concat(centre_xyz, src_xyz, src_feat, idx, mask)
+
+    @staticmethod
+    def backward(ctx, grad):
+        idx, mask = ctx.saved_tensors
+        (cs, xs, fs), dev = ctx.shapes, grad.device
+        (grad,) = _f32(grad)
+        need = ctx.needs_input_grad
+        g_c = torch.empty(cs, dtype=torch.float32, device=dev) if need[0] else None
+        g_x = torch.zeros(xs, dtype=torch.float32, device=dev) if need[1] else None
+        g_f = torch.zeros(fs, dtype=torch.float32, device=dev) if need[2] else None
+        B, N, K, _ = idx.shape
+        a = L.GroupConcatBwdArgs(B, N, K, fs[1], fs[2], fs[3], grad.data_ptr(), idx.data_ptr(), mask.data_ptr(),
+                                 _ptr(g_c), _ptr(g_x), _ptr(g_f))
+        L.call("elo_group_concat_backward", a, grad)
+        return g_c, g_x, g_f, None, None
+
+
 def group_concat(centre_xyz, src_xyz, src_feat, idx, mask):
     """[src_xyz[idx]*m - centre, src_feat[idx]*m] -> (B,N,K,3+C).  pointnet_util.py:203-213, :277-284."""
+    if _wants_grad(centre_xyz, src_xyz, src_feat):
+        return _GroupConcat.apply(centre_xyz, src_xyz, src_feat, idx.contiguous(), _f32(mask)[0])
+    return _group_concat(centre_xyz, src_xyz, src_feat, idx, mask)
+
+
+def _group_concat(centre_xyz, src_xyz, src_feat, idx, mask):
     L.require_gpu(centre_xyz, src_xyz, src_feat, idx, mask)
     centre_xyz, src_xyz, src_feat, mask = _f32(centre_xyz, src_xyz, src_feat, mask)
     idx = idx.contiguous()
@@ -52,8 +80,31 @@ def group_concat(centre_xyz, src_xyz, src_feat, idx, mask):
     return out
 
 
+class _MaskedMaxpool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(x, mask)
+        return _masked_maxpool(x, mask)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, mask = ctx.saved_tensors
+        (grad,) = _f32(grad)
+        B, N, K, C = x.shape
+        g_x = torch.empty_like(x)
+        L.call("elo_masked_maxpool_backward",
+               L.MaskedMaxpoolBwdArgs(B, N, K, C, x.data_ptr(), mask.data_ptr(), grad.data_ptr(), g_x.data_ptr()), grad)
+        return g_x, None
+
+
 def masked_maxpool(x, mask):
     """max_k x*mask -> (B,N,C).  pointnet_util.py:224-230, :295-298."""
+    if _wants_grad(x):
+        return _MaskedMaxpool.apply(*_f32(x, mask))
+    return _masked_maxpool(x, mask)
+
+
+def _masked_maxpool(x, mask):
     L.require_gpu(x, mask)
     x, mask = _f32(x, mask)
     B, N, K, C = x.shape
@@ -62,8 +113,39 @@ def masked_maxpool(x, mask):
     return out
 
 
+class _CvEncode1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz1, feat1, xyz2_proj, feat2_proj, idx, mask):
+        ctx.save_for_backward(xyz1, xyz2_proj, idx, mask)
+        ctx.C = feat1.shape[-1]
+        return _cv_encode1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask)
+
+    @staticmethod
+    def backward(ctx, grad):
+        xyz1, xyz2, idx, mask = ctx.saved_tensors
+        (grad,) = _f32(grad)
+        B, N, K, _ = idx.shape
+        _, H2, W2, _ = xyz2.shape
+        C, dev, need = ctx.C, grad.device, ctx.needs_input_grad
+        new = lambda shape, zero: (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=dev)
+        g_x1 = new((B, N, 3), False) if need[0] else None
+        g_f1 = new((B, N, C), False) if need[1] else None
+        g_x2 = new((B, H2, W2, 3), True) if need[2] else None
+        g_f2 = new((B, H2, W2, C), True) if need[3] else None
+        a = L.CvEncode1BwdArgs(B, N, K, H2, W2, C, xyz1.data_ptr(), xyz2.data_ptr(), idx.data_ptr(), mask.data_ptr(),
+                               grad.data_ptr(), _ptr(g_x1), _ptr(g_f1), _ptr(g_x2), _ptr(g_f2))
+        L.call("elo_cv_encode1_backward", a, grad)
+        return g_x1, g_f1, g_x2, g_f2, None, None
+
+
 def cv_encode1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask):
     """(B,N,K,10+2C) = [p, q, q-p, |q-p|, feat1, feat2[idx]*m].  pointnet_util.py:54-66."""
+    if _wants_grad(xyz1, feat1, xyz2_proj, feat2_proj):
+        return _CvEncode1.apply(*_f32(xyz1, feat1, xyz2_proj, feat2_proj), idx.contiguous(), _f32(mask)[0])
+    return _cv_encode1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask)
+
+
+def _cv_encode1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask):
     L.require_gpu(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask)
     xyz1, xyz2_proj, mask = _f32(xyz1, xyz2_proj, mask)
     (feat1, feat2_proj), dt, code = _feature_dtype(feat1, feat2_proj)
@@ -77,8 +159,38 @@ def cv_encode1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask):
     return out
 
 
+class _CvEncode2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz1_proj, feat1_proj, cost_proj, idx, mask):
+        ctx.save_for_backward(xyz1_proj, idx, mask)
+        ctx.widths = (feat1_proj.shape[-1], cost_proj.shape[-1])
+        return _cv_encode2(xyz1_proj, feat1_proj, cost_proj, idx, mask)
+
+    @staticmethod
+    def backward(ctx, g_cat, g_rest):
+        xyz1, idx, mask = ctx.saved_tensors
+        B, H, W, _ = xyz1.shape
+        K, (C, Cc), dev, need = idx.shape[2], ctx.widths, xyz1.device, ctx.needs_input_grad
+        zeros = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        g_cat = zeros(B, H * W, K, 10) if g_cat is None else _f32(g_cat)[0]
+        g_rest = zeros(B, H * W, K, C + Cc) if g_rest is None else _f32(g_rest)[0]
+        g_x = zeros(B, H, W, 3) if need[0] else None
+        g_f = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if need[1] else None
+        g_c = zeros(B, H, W, Cc) if need[2] else None
+        a = L.CvEncode2BwdArgs(B, H * W, K, H, W, C, Cc, xyz1.data_ptr(), idx.data_ptr(), mask.data_ptr(), g_cat.data_ptr(),
+                               g_rest.data_ptr(), _ptr(g_x), _ptr(g_f), _ptr(g_c))
+        L.call("elo_cv_encode2_backward", a, xyz1)
+        return g_x, g_f, g_c, None, None
+
+
 def cv_encode2(xyz1_proj, feat1_proj, cost_proj, idx, mask):
     """xyz_cat (B,N,K,10) and rest (B,N,K,C+Cc) = [feat1, cost[idx]*m].  pointnet_util.py:110-129."""
+    if _wants_grad(xyz1_proj, feat1_proj, cost_proj):
+        return _CvEncode2.apply(*_f32(xyz1_proj, feat1_proj, cost_proj), idx.contiguous(), _f32(mask)[0])
+    return _cv_encode2(xyz1_proj, feat1_proj, cost_proj, idx, mask)
+
+
+def _cv_encode2(xyz1_proj, feat1_proj, cost_proj, idx, mask):
     L.require_gpu(xyz1_proj, feat1_proj, cost_proj, idx, mask)
     xyz1_proj, mask = _f32(xyz1_proj, mask)
     (feat1_proj, cost_proj), dt, code = _feature_dtype(feat1_proj, cost_proj)
@@ -94,9 +206,37 @@ def cv_encode2(xyz1_proj, feat1_proj, cost_proj, idx, mask):
     return xyz_cat, rest
 
 
+class _MaskedSoftmaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, values, mask):
+        ctx.save_for_backward(logits, values, mask)
+        return _masked_softmax_pool(logits, values, mask)
+
+    @staticmethod
+    def backward(ctx, grad):
+        logits, values, mask = ctx.saved_tensors
+        (grad,) = _f32(grad)
+        B, N, K, C = logits.shape
+        if values.stride(-1) != 1 or values.stride(1) != K * values.stride(2) or values.stride(0) != N * values.stride(1):
+            values = values.contiguous()
+        g_l, g_v = torch.empty_like(logits), torch.empty((B, N, K, C), dtype=torch.float32, device=grad.device)
+        a = L.SoftmaxPoolBwdArgs(B, N, K, C, logits.data_ptr(), values.data_ptr(), values.stride(2), mask.data_ptr(),
+                                 grad.data_ptr(), g_l.data_ptr(), g_v.data_ptr())
+        L.call("elo_masked_softmax_pool_backward", a, grad)
+        return g_l, g_v, None
+
+
 def masked_softmax_pool(logits, values, mask):
     """sum_k softmax_k(where(mask==1, logits, -1e10)) * values -> (B,N,C).  pointnet_util.py:92-98, :137-146.
     `values` may be a last-dim slice of a wider contiguous tensor (no copy)."""
+    if _wants_grad(logits, values):
+        if logits.dtype != torch.float32 or values.dtype != torch.float32:
+            raise TypeError("training stores its features in float32")
+        return _MaskedSoftmaxPool.apply(logits.contiguous(), values, _f32(mask)[0])
+    return _masked_softmax_pool(logits, values, mask)
+
+
+def _masked_softmax_pool(logits, values, mask):
     L.require_gpu(logits, values, mask)
     (mask,) = _f32(mask)
     if logits.dtype not in (torch.float32, torch.float16):
@@ -115,8 +255,32 @@ def masked_softmax_pool(logits, values, mask):
     return out
 
 
+class _SoftmaxValid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feature_bnc, weight_bnc, xyz_bn3):
+        ctx.save_for_backward(feature_bnc, weight_bnc, xyz_bn3)
+        return _softmax_valid(feature_bnc, weight_bnc, xyz_bn3)
+
+    @staticmethod
+    def backward(ctx, grad):
+        f, w, xyz = ctx.saved_tensors
+        (grad,) = _f32(grad)
+        B, N, C = f.shape
+        g_f, g_w = torch.empty_like(f), torch.empty_like(w)
+        a = L.SoftmaxValidBwdArgs(B, N, C, f.data_ptr(), w.data_ptr(), xyz.data_ptr(), grad.data_ptr(), g_f.data_ptr(),
+                                  g_w.data_ptr())
+        L.call("elo_softmax_valid_backward", a, grad)
+        return g_f, g_w, None
+
+
 def softmax_valid(feature_bnc, weight_bnc, xyz_bn3):
     """model_util.py:319-343 with mask_valid = any(xyz != 0) -> (B,1,C)."""
+    if _wants_grad(feature_bnc, weight_bnc):
+        return _SoftmaxValid.apply(*_f32(feature_bnc, weight_bnc, xyz_bn3.detach()))
+    return _softmax_valid(feature_bnc, weight_bnc, xyz_bn3)
+
+
+def _softmax_valid(feature_bnc, weight_bnc, xyz_bn3):
     L.require_gpu(feature_bnc, weight_bnc, xyz_bn3)
     feature_bnc, weight_bnc, xyz_bn3 = _f32(feature_bnc, weight_bnc, xyz_bn3)
     B, N, C = feature_bnc.shape
@@ -228,10 +392,54 @@ def input_stage(cloud, T_trans, aug_frame, H, W, crop_xy=35.0):
     return points, out_xyz
 
 
+class _WarpProject(torch.autograd.Function):
+    """elo_warp_project / elo_warp_project_backward.  The forward's scratch (who won each cell) is kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, xyz, feat, q, t, H, W):
+        B, N, _ = xyz.shape
+        C = 0 if feat is None else feat.shape[-1]
+        buffers = ProjectionBuffers(B, N, H, W, C, xyz.device)
+        warped, out_xyz, out_feat = _warp_project(xyz, feat, q, t, H, W, buffers)
+        ctx.save_for_backward(xyz, q, t, buffers.scratch)
+        ctx.dims = (B, N, C, H, W)
+        return warped, out_xyz, out_feat
+
+    @staticmethod
+    def backward(ctx, g_warped, g_xyz_proj, g_feat_proj):
+        xyz, q, t, scratch = ctx.saved_tensors
+        B, N, C, H, W = ctx.dims
+        dev, need = xyz.device, ctx.needs_input_grad
+        cont = lambda g: None if g is None else _f32(g)[0]
+        g_warped, g_xyz_proj, g_feat_proj = cont(g_warped), cont(g_xyz_proj), cont(g_feat_proj)
+        g_x = torch.empty((B, N, 3), dtype=torch.float32, device=dev) if need[0] else None
+        g_f = torch.empty((B, N, C), dtype=torch.float32, device=dev) if (need[1] and C) else None
+        if g_f is not None and g_feat_proj is None:
+            g_feat_proj = torch.zeros((B, H, W, C), dtype=torch.float32, device=dev)
+        g_q = torch.zeros((B, 4), dtype=torch.float32, device=dev) if q is not None else None
+        g_t = torch.zeros((B, 3), dtype=torch.float32, device=dev) if q is not None else None
+        az, vres, voff = projection_constants(H, W)
+        a = L.WarpProjectBwdArgs(B, N, C, H, W, az, vres, voff, xyz.data_ptr(), _ptr(q), _ptr(t), scratch.data_ptr(),
+                                 _ptr(g_xyz_proj), _ptr(g_feat_proj), _ptr(g_warped), _ptr(g_x), _ptr(g_f), _ptr(g_q), _ptr(g_t))
+        L.call("elo_warp_project_backward", a, xyz)
+        return g_x, g_f, g_q, g_t, None, None
+
+
 def warp_project(xyz, feat, q, t, H, W, buffers=None):
     """Optional quaternion warp (q,t: (B,4),(B,3) or None) + ProjectPC2SphericalRing.
     Returns (warped (B,N,3) or None, xyz_proj (B,H,W,3), feat_proj (B,H,W,C) or None).
     `buffers`: a ProjectionBuffers of this call's shape, used (and, if a pose head cleared it, not re-initialised)."""
+    if buffers is None and _wants_grad(xyz, feat, q, t):
+        B = xyz.shape[0]
+        if feat is not None and feat.dtype != torch.float32:
+            raise TypeError("training stores its features in float32")
+        return _WarpProject.apply(_f32(xyz)[0], None if feat is None else feat.contiguous(),
+                                  None if q is None else _f32(q.reshape(B, 4))[0],
+                                  None if q is None else _f32(t.reshape(B, 3))[0], H, W)
+    return _warp_project(xyz, feat, q, t, H, W, buffers)
+
+
+def _warp_project(xyz, feat, q, t, H, W, buffers=None):
     if buffers is not None and buffers.result is not None:   # the pose head that produced (q, t) already did it
         result, buffers.result = buffers.result, None
         return result

@@ -10,6 +10,7 @@
 // contiguous segment and every output row is written as one.  The dense 1x1
 // convolutions between them are GEMMs and stay with hipBLASLt.
 #include "elo_common.h"
+#include "elo_project_device.h"
 
 namespace elo {
 namespace {
@@ -602,25 +603,6 @@ __host__ __device__ inline ProjScratch proj_scratch(unsigned *s, size_t cells, s
 {
     return ProjScratch{s, s + cells, (int *)(s + cells + ZFLAGS * images), s + cells + ZFLAGS * images + pts};
 }
-
-// `at` = atan2f(y, x)
-__device__ __forceinline__ int cell_of_point(float at, float z, float r, int H, int W, float az_res, float vert_res,
-                                             float vert_off)
-{
-    const float PI_F = 3.14159265358979323846f;
-    // float -> int of a NaN is 0 (the GPU convention, SURVEY a-10) -- spelled out, so that the compiler's constant
-    // folder (scatter_min_kernel evaluates this for the literal zero point) and v_cvt_i32_f32 agree
-    auto to_int = [](float v) { return v != v ? 0 : (int)v; };
-    int col = to_int((PI_F - at) / az_res);                                  // model_util.py:234-235
-    const float beta = asinf(z / r);
-    int row = H - to_int(beta / vert_res + vert_off);                        // NaN -> 0, :237-242
-    row = row < 0 ? 0 : row > H - 1 ? H - 1 : row;
-    col = col < 0 ? 0 : col > W - 1 ? W - 1 : col;
-    return row * W + col;
-}
-
-// which of a zero point's three possible cells: by atan2f of its signed zeros (0: +-0, 1: pi, 2: -pi)
-__device__ __forceinline__ int zero_kind(float at) { return at > 1.0f ? 1 : at < -1.0f ? 2 : 0; }
 
 // range bits, cell id and the atomicMin of the cell's range for one (already transformed) point of image b.
 // The zero points of a padded / cropped scan (r = 0: tens of thousands in a 150 000-point KITTI cloud) all fall in ONE

@@ -79,7 +79,7 @@ def mat2euler(M, seq='zyx'):
 def ProjectPC2SphericalRing(PC, Feature, H_input, W_input):
     """model_util.py:181-292: (B,N,3[+]) points [+ (B,N,C) features] -> (B,H,W,3) [, (B,H,W,C)].
     One HIP launch pair for the whole batch (the reference loops over the batch in Python, :213)."""
-    _, xyz_proj, feat_proj = _ops.active().warp_project(PC[..., :3], Feature, None, None, H_input, W_input)
+    _, xyz_proj, feat_proj = _ops.warp_project(PC[..., :3], Feature, None, None, H_input, W_input)
     return (xyz_proj, feat_proj) if Feature is not None else (xyz_proj, xyz_proj)
 
 
@@ -89,7 +89,7 @@ def warp_and_project(xyz, feature, q_coarse, t_coarse, H_input, W_input, buffers
     `buffers` (inference only): _ops.ProjectionBuffers already cleared by the pose head that produced q, t."""
     if buffers is not None:
         return _ops.warp_project(xyz, feature, q_coarse, t_coarse, H_input, W_input, buffers)
-    return _ops.active().warp_project(xyz, feature, q_coarse, t_coarse, H_input, W_input)
+    return _ops.warp_project(xyz, feature, q_coarse, t_coarse, H_input, W_input)
 
 
 _sel_cache = {}
@@ -121,7 +121,7 @@ def softmax_valid(feature_bnc, weight_bnc, mask_valid):
         xyz = torch.zeros(mask_valid.shape + (3,), dtype=torch.float32, device=mask_valid.device)
         xyz[..., 0] = mask_valid.to(torch.float32)
         mask_valid = xyz
-    return _ops.active().softmax_valid(feature_bnc, weight_bnc, mask_valid)
+    return _ops.softmax_valid(feature_bnc, weight_bnc, mask_valid)
 
 
 def PreProcess(PC_f1, PC_f2, T_gt, T_trans, T_trans_inv, aug_frame):

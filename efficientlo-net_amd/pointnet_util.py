@@ -4,10 +4,13 @@ cost_volume (:33-149), flow_predictor (:153-175), down_conv (:179-250),
 up_conv (:254-316).
 
 Same call signatures, so the pyramid schedule (pwclo_model.py) calls them the
-way the reference does.  Inside, every chain of stock TF ops between two 1x1
-convolutions is ONE hand-written HIP kernel (csrc/elo_features.hip), the two
-custom ops are the HIP grouping kernels (csrc/elo_grouping.hip), and the 1x1
-convolutions are hipBLASLt GEMMs (tf_util.conv2d).  Concatenations feeding a
+way the reference does.  Inference (is_training False): everything between two
+poolings is ONE fused HIP kernel (csrc/elo_fused.hip).  Training, and
+inference with ELO_FUSED=0: every chain of stock TF ops between two 1x1
+convolutions is ONE hand-written HIP kernel (csrc/elo_features.hip; backward:
+csrc/elo_backward.hip through _ops' autograd Functions), the two custom ops
+are the HIP grouping kernels (csrc/elo_grouping.hip), and the 1x1 convolutions
+are hipBLASLt GEMMs (tf_util.conv2d).  Concatenations feeding a
 convolution are never materialised when they only join already-existing
 tensors: conv(concat[a, b]) is computed as a @ W[:Ca] + b @ W[Ca:] (two
 accumulating GEMMs on row-slices of the same weight variable).
@@ -35,7 +38,9 @@ def use_fused(flag):
 
 
 def _fused_path(is_training):
-    return _FUSED and not is_training and not torch.is_grad_enabled()
+    """The implementation is chosen by the CALLER's `is_training` (as in the reference, where it selects batch statistics
+    and dropout), never by the global autograd mode: inference under torch.enable_grad() stays on the fused kernels."""
+    return _FUSED and not is_training
 
 
 def warping_layers(xyz1, upsampled_flow):
@@ -80,8 +85,8 @@ def _split_conv(parts, num_output_channels, scope, is_training, bn_decay, bn=Tru
     """tf_util.conv2d(tf.concat(parts, -1), ...) without building the concat.
 
     In inference the folded weight rows are sliced per part and the GEMMs accumulate into one output;
-    when gradients are needed it falls back to the literal concat + conv."""
-    if is_training or torch.is_grad_enabled():
+    in training it is the literal concat + conv (batch statistics, autograd)."""
+    if is_training:
         return tf_util.conv2d(torch.cat(parts, -1), num_output_channels, [1, 1], padding='VALID', stride=[1, 1],
                               bn=bn, is_training=is_training, scope=scope, bn_decay=bn_decay)
     cin = sum(p.shape[-1] for p in parts)
@@ -155,7 +160,7 @@ def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_
 def _cost_volume_stage1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask, mlp1, mlp2, is_training, bn_decay):
     """utils/pointnet_util.py:54-100 as per-operator kernels + GEMMs (caller holds the variable scope)."""
     B, N, nsample_q = mask.shape
-    feat_cat = _ops.active().cv_encode1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask)       # :54-66
+    feat_cat = _ops.cv_encode1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask)       # :54-66
     xyz_cat = feat_cat.reshape(-1, feat_cat.shape[-1])[:, :10]      # :62 -- 2-D strided view, no copy (lda = 10+2C)
     x = feat_cat
     for j, num_out_channel in enumerate(mlp1):
@@ -171,13 +176,13 @@ def _cost_volume_stage1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, m
         else:
             cat = tf_util.conv2d(cat, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
                                  is_training=is_training, scope='sum_CV_%d' % j, bn_decay=bn_decay)
-    return _ops.active().masked_softmax_pool(cat, x, mask)                                                 # :92-98
+    return _ops.masked_softmax_pool(cat, x, mask)                                                 # :92-98
 
 
 def _cost_volume_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2, mlp1, mlp2, is_training, bn_decay):
     """utils/pointnet_util.py:110-146 as per-operator kernels + GEMMs (caller holds the variable scope)."""
     C = points1_proj.shape[-1]
-    pc_xyz_cat, rest = _ops.active().cv_encode2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2)  # :110-120
+    pc_xyz_cat, rest = _ops.cv_encode2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, mask2)  # :110-120
     pc_enc = tf_util.conv2d(pc_xyz_cat, mlp1[-1], [1, 1], padding='VALID', stride=[1, 1], bn=True,
                             is_training=is_training, scope='sum_xyz_encoding', bn_decay=bn_decay)    # :123-126
     pc_cat = None
@@ -188,7 +193,7 @@ def _cost_volume_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, ma
             pc_cat = tf_util.conv2d(pc_cat, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
                                     is_training=is_training, scope='sum_cost_volume_%d' % j, bn_decay=bn_decay)
     pc_points_grouped = rest[..., C:]                              # cost[idx]*mask, a channel slice of `rest`
-    return _ops.active().masked_softmax_pool(pc_cat, pc_points_grouped, mask2)                             # :137-146
+    return _ops.masked_softmax_pool(pc_cat, pc_points_grouped, mask2)                             # :137-146
 
 
 def flow_predictor(points_f1, upsampled_feat, cost_volume, mlp, is_training, bn_decay, scope, bn=True):
@@ -329,11 +334,11 @@ def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distan
         li = selected_idx.reshape(-1, 3).long()
         new_xyz_proj = xyz_proj[li[:, 0], li[:, 1], li[:, 2]].reshape(selected_idx.shape[:-1] + (3,))  # :206
         new_xyz = new_xyz_proj.reshape(B, -1, 3)
-        x = _ops.active().group_concat(new_xyz, xyz_proj, points_proj, sel, mask)                          # :203-213
+        x = _ops.group_concat(new_xyz, xyz_proj, points_proj, sel, mask)                          # :203-213
         for i, num_out_channel in enumerate(mlp):
             x = tf_util.conv2d(x, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
                                is_training=is_training, scope='conv%d' % i, bn_decay=bn_decay)    # :217-222
-        return _ops.active().masked_maxpool(x, mask), new_xyz_proj                                         # :224-230
+        return _ops.masked_maxpool(x, mask), new_xyz_proj                                         # :224-230
 
 
 def up_conv(xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kernel_size, stride_h, stride_w, nsample, distance, mlp,
@@ -362,11 +367,11 @@ def up_conv(xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kernel_size, stride_h,
             xyz1_proj, xyz2_proj, idx_hw, random_HW, H, W, N, kernel_size[0], kernel_size[1], nsample,
             flag_copy=0, distance=distance, stride_h=stride_h, stride_w=stride_w, want_valid=False)      # :272-274
         mask = valid_mask.reshape(B, N, nsample)
-        x = _ops.active().group_concat(xyz1, xyz2_proj, feat2_proj, sel, mask)                             # :277-284
+        x = _ops.group_concat(xyz1, xyz2_proj, feat2_proj, sel, mask)                             # :277-284
         for j, num_out_channel in enumerate(mlp):
             x = tf_util.conv2d(x, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
                                is_training=is_training, scope='up_1_%d' % j, bn_decay=bn_decay)   # :289-293
-        up_feat = _ops.active().masked_maxpool(x, mask)                                                    # :295-298
+        up_feat = _ops.masked_maxpool(x, mask)                                                    # :295-298
         y = None
         for i, num_out_channel in enumerate(mlp2):                                                # :303-311
             if i == 0:

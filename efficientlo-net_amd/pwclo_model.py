@@ -104,10 +104,10 @@ def set_concurrent_branches(flag):
     _CONCURRENT = bool(flag)
 
 
-def _parallel(branches):
-    """Run independent closures on forked streams and join; results in order.  Sequential when gradients are
-    enabled, on CPU tensors, or when switched off."""
-    if not _CONCURRENT or torch.is_grad_enabled() or len(branches) < 2 or not torch.cuda.is_available():
+def _parallel(branches, is_training=False):
+    """Run independent closures on forked streams and join; results in order.  Sequential in training, on CPU
+    tensors, or when switched off."""
+    if not _CONCURRENT or is_training or len(branches) < 2 or not torch.cuda.is_available():
         return [b() for b in branches]
     dev = torch.cuda.current_device()
     cur = torch.cuda.current_stream(dev)
@@ -143,10 +143,8 @@ _ZEROS = {}
 
 
 def _zero_features(like):
-    """The all-zero input features (pwclo_model.py:69-70).  Read-only, so inference shares one tensor per shape
+    """The all-zero input features (pwclo_model.py:69-70).  Read-only, so one tensor per shape is shared
     instead of a fill launch per forward."""
-    if torch.is_grad_enabled():
-        return torch.zeros_like(like)
     dtype = fused.storage_dtype()                   # fp16 feature storage starts here: every kernel keeps its inputs' dtype
     key = (tuple(like.shape), like.device, dtype)
     if key not in _ZEROS:
@@ -162,12 +160,13 @@ def _normalise_q(q):
 
 def _pose_head(feat_b1c, level, coarse, is_training):
     """pwclo_model.py:197-208 (l3) and :264-273 / :340-349 / :408-417 (refinement levels)."""
-    big = tf_util.conv1d(feat_b1c, 256, 1, padding='VALID', activation_fn=None, scope='l%d_big' % level)
+    # (the reference leaves is_training at its default for these BN-free layers; here it also selects the autograd path)
+    big = tf_util.conv1d(feat_b1c, 256, 1, padding='VALID', activation_fn=None, scope='l%d_big' % level, is_training=is_training)
     if is_training:
         big = torch.nn.functional.dropout(big, p=0.5, training=True)                                # :199
     qn, tn = ('l%d_q_coarse', 'l%d_t_coarse') if coarse else ('l%d_q_det', 'l%d_t_det')
-    q = _normalise_q(tf_util.conv1d(big, 4, 1, padding='VALID', activation_fn=None, scope=qn % level))
-    t = tf_util.conv1d(big, 3, 1, padding='VALID', activation_fn=None, scope=tn % level)
+    q = _normalise_q(tf_util.conv1d(big, 4, 1, padding='VALID', activation_fn=None, scope=qn % level, is_training=is_training))
+    t = tf_util.conv1d(big, 3, 1, padding='VALID', activation_fn=None, scope=tn % level, is_training=is_training)
     return q, t
 
 
@@ -177,7 +176,7 @@ def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training,
     Inference: two fused HIP launches (_ops.pose_head).  Training: the literal operator chain."""
     batch_size = predict.shape[0]
     coarse = q_coarse is None
-    if not (is_training or torch.is_grad_enabled()):
+    if not is_training:
         qn, tn = ('l%d_q_coarse', 'l%d_t_coarse') if coarse else ('l%d_q_det', 'l%d_t_det')
         W_big, b_big = tf_util.folded_variables('l%d_big' % level, predict.shape[-1], 256, (1,), bn=False)
         W_q, b_q = tf_util.folded_variables(qn % level, 256, 4, (1,), bn=False)
@@ -242,7 +241,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
 
     with tf_util.variable_scope('sa1') as scope:                                                    # :117
         both = _adjacent_frames(xyz_f1_input_proj, xyz_f2_input_proj) if not is_training else None
-        if both is not None and not torch.is_grad_enabled():
+        if both is not None:
             # Siamese pyramid in ONE pass: the two frames share every weight (:143), and inference BN uses moving
             # statistics, so frame 2 is just batch elements B..2B-1 -- half the launches, identical numbers.
             sel2 = [get_selected_idx(both, stride_h_list[i], stride_w_list[i], out_h_list[i], out_w_list[i])
@@ -280,7 +279,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
     l3_cost_volume_w_proj = l3_cost_volume_w.reshape(batch_size, out_h_list[5], out_w_list[5], -1)
     l3_xyz_f1 = xyz_proj_f1[3].reshape(batch_size, -1, 3)
     # inference: the pose head of level L+1 also clears the projection buffers of level L's warp (one launch less)
-    inference = not (is_training or torch.is_grad_enabled())
+    inference = not is_training
 
     def projection_buffers(level, g):
         if not inference:
@@ -339,12 +338,12 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
         else:
             # the cost volume and the two set-upconvs only share inputs: optional concurrent branches
             cost, w_up_sample, cost_up_sample = _parallel([branch_cost, lambda: branch_up('w', coarse_w_proj),
-                                                           lambda: branch_up('costvolume', coarse_predict_proj)])
+                                                           lambda: branch_up('costvolume', coarse_predict_proj)], is_training)
             predict, weight = _parallel([
                 lambda: flow_predictor(points_warp_f1, cost_up_sample, cost, mlp=[128, 64], is_training=is_training,
                                        bn_decay=bn_decay, scope='l%d_costvolume_predict' % level),     # :253
                 lambda: flow_predictor(points_warp_f1, w_up_sample, cost, mlp=[128, 64], is_training=is_training,
-                                       bn_decay=bn_decay, scope='l%d_w_predict' % level)])             # :254
+                                       bn_decay=bn_decay, scope='l%d_w_predict' % level)], is_training)  # :254
         q_prev, t_prev, q_norm = _estimate_pose(predict, weight, xyz_warp_f1, level, q_coarse, t_coarse,
                                                 is_training, pose_out if level == 0 else None,
                                                 clear=next_buffers,

@@ -185,7 +185,7 @@ def _dense(inputs, num_output_channels, scope, tf_kernel_dims, activation_fn, bn
     name, W, b, bn_vars = dense_variables(scope, cin, num_output_channels, tf_kernel_dims, bn)
     x2 = inputs.reshape(-1, cin)
     training = bool(is_training) if is_training is not None else False
-    if training or torch.is_grad_enabled():      # autograd-capable path (batch statistics when training)
+    if training:                                 # batch statistics, autograd (the caller's is_training decides, not the autograd mode)
         y = torch.addmm(b, x2, W)
         if bn:
             decay = _DEFAULT_BN_DECAY if bn_decay is None else float(bn_decay)

@@ -294,6 +294,106 @@ int elo_input_stage(const elo_input_stage_args *a, elo_stream_t stream);
 int elo_pose_head_warp(const elo_pose_head_args *a, const elo_warp_project_args *w, elo_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * Backward passes of the feature kernels above, for TRAINING (csrc/elo_backward.hip).
+ * The reference trains through TensorFlow's autodiff of its stock ops (main.py:171-176): gather_nd -> scatter-add of
+ * the incoming gradient (utils/pointnet_util.py:54-55, :110-111, :203-204, :277-278; masks are stop_gradient, indices
+ * integer), reduce_max -> the maximal entries (even split among exact ties), softmax, scatter_nd -> gather
+ * (model_util.py:264-273).  Each entry point is the adjoint of ONE forward entry point: same shapes, `grad_x` has the
+ * shape of `x`.  fp32.  Outputs marked ACC receive atomic adds and must be ZERO on entry; the others are written in full.
+ * Any gradient output may be NULL (not wanted).  Masked slots add nothing anywhere.
+ * ------------------------------------------------------------------------- */
+typedef struct elo_group_concat_bwd_args {
+    int batch, npoints, K;
+    int H2, W2, C;
+    const float *grad_out;        /* (batch,npoints,K,3+C) */
+    const int *idx;
+    const float *mask;
+    float *grad_centre;           /* (batch,npoints,3)  = -sum_k grad_out[..., :3]        */
+    float *grad_src_xyz;          /* (batch,H2,W2,3)  ACC                                  */
+    float *grad_src_feat;         /* (batch,H2,W2,C)  ACC                                  */
+} elo_group_concat_bwd_args;
+int elo_group_concat_backward(const elo_group_concat_bwd_args *a, elo_stream_t stream);
+
+typedef struct elo_masked_maxpool_bwd_args {
+    int batch, npoints, K, C;
+    const float *x;               /* the forward input (batch,npoints,K,C) */
+    const float *mask;
+    const float *grad_out;        /* (batch,npoints,C) */
+    float *grad_x;                /* (batch,npoints,K,C) */
+} elo_masked_maxpool_bwd_args;
+int elo_masked_maxpool_backward(const elo_masked_maxpool_bwd_args *a, elo_stream_t stream);
+
+typedef struct elo_cv_encode1_bwd_args {
+    int batch, npoints, K;
+    int H2, W2, C;
+    const float *xyz1;            /* forward inputs: the geometry code's norm needs them */
+    const float *xyz2;
+    const int *idx;
+    const float *mask;
+    const float *grad_out;        /* (batch,npoints,K,10+2C) */
+    float *grad_xyz1;             /* (batch,npoints,3) */
+    float *grad_feat1;            /* (batch,npoints,C) */
+    float *grad_xyz2;             /* (batch,H2,W2,3)  ACC */
+    float *grad_feat2;            /* (batch,H2,W2,C)  ACC */
+} elo_cv_encode1_bwd_args;
+int elo_cv_encode1_backward(const elo_cv_encode1_bwd_args *a, elo_stream_t stream);
+
+typedef struct elo_cv_encode2_bwd_args {
+    int batch, npoints, K;
+    int H, W, C, Cc;
+    const float *xyz1;            /* (batch,H,W,3) */
+    const int *idx;
+    const float *mask;
+    const float *grad_xyz_cat;    /* (batch,npoints,K,10)   */
+    const float *grad_rest;       /* (batch,npoints,K,C+Cc) */
+    float *grad_xyz1;             /* (batch,H,W,3)   ACC (centre and neighbours live in the same grid) */
+    float *grad_feat1;            /* (batch,H,W,C)   */
+    float *grad_cost;             /* (batch,H,W,Cc)  ACC */
+} elo_cv_encode2_bwd_args;
+int elo_cv_encode2_backward(const elo_cv_encode2_bwd_args *a, elo_stream_t stream);
+
+typedef struct elo_softmax_pool_bwd_args {
+    int batch, npoints, K, C;
+    const float *logits;          /* forward inputs */
+    const float *values;
+    int values_stride;
+    const float *mask;
+    const float *grad_out;        /* (batch,npoints,C) */
+    float *grad_logits;           /* (batch,npoints,K,C); 0 at masked slots (tf.where feeds a constant there) */
+    float *grad_values;           /* (batch,npoints,K,C) contiguous, whatever values_stride was */
+} elo_softmax_pool_bwd_args;
+int elo_masked_softmax_pool_backward(const elo_softmax_pool_bwd_args *a, elo_stream_t stream);
+
+typedef struct elo_softmax_valid_bwd_args {
+    int batch, npoints, C;
+    const float *feature, *weight, *xyz;     /* forward inputs */
+    const float *grad_out;        /* (batch,1,C) */
+    float *grad_feature;          /* (batch,npoints,C) */
+    float *grad_weight;           /* (batch,npoints,C) */
+} elo_softmax_valid_bwd_args;
+int elo_softmax_valid_backward(const elo_softmax_valid_bwd_args *a, elo_stream_t stream);
+
+/* Adjoint of elo_warp_project.  `scratch` is the forward call's scratch as it left it (per-cell minimum range, zero-point
+ * flags, per-point cell and range bits: who won each cell); the forward's projection constants come along because the
+ * cells a zero point can fall in are recomputed from them.  Gradients never reach the cell indices (model_util.py:255-273). */
+typedef struct elo_warp_project_bwd_args {
+    int batch, npoints, C;
+    int H, W;
+    float az_res, vert_res, vert_off;
+    const float *xyz;             /* forward input (batch,npoints,3) */
+    const float *q, *t;           /* forward inputs, or NULL = the forward did not warp */
+    const unsigned *scratch;
+    const float *grad_out_xyz;    /* (batch,H,W,3) or NULL */
+    const float *grad_out_feat;   /* (batch,H,W,C) or NULL */
+    const float *grad_warped;     /* (batch,npoints,3) or NULL: gradient on the forward's `warped` output */
+    float *grad_xyz;              /* (batch,npoints,3) */
+    float *grad_feat;             /* (batch,npoints,C) */
+    float *grad_q;                /* (batch,4)  ACC */
+    float *grad_t;                /* (batch,3)  ACC */
+} elo_warp_project_bwd_args;
+int elo_warp_project_backward(const elo_warp_project_bwd_args *a, elo_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Fused inference kernels: gather/encode -> chain of 1x1 convolutions (BN and
  * bias folded, ReLU) -> pooling, in ONE launch with the activations of a
  * 16/32-row tile resident in LDS and the contractions on the matrix cores.

@@ -1,5 +1,5 @@
-"""GPU: the training path -- differentiable torch twins equal the HIP kernels in the forward direction,
-gradients reach every layer, get_loss / PreProcess / the full get_model signature match the oracle, and a
+"""GPU: the training path -- the torch restatements used as gradient references (tests/twins_torch.py) equal the HIP
+kernels in the forward direction, gradients reach every layer, get_loss / PreProcess / the full get_model signature match the oracle, and a
 few optimisation steps reduce the loss."""
 import copy
 
@@ -17,7 +17,8 @@ t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
 def test_torch_twins_equal_hip_kernels():
-    ops, twin, elo, synth = load_pkg("_ops"), load_pkg("_ops_torch"), load_pkg(), load_pkg("synth")
+    import twins_torch as twin
+    ops, elo, synth = load_pkg("_ops"), load_pkg(), load_pkg("synth")
     rng = np.random.default_rng(0)
     B, H, W, C, K = 2, 8, 113, 32, 6
     f1, f2 = synth.frame_pair(B, H, W, seed=9)

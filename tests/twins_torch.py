@@ -1,9 +1,10 @@
-"""Differentiable twins of the feature kernels in _ops.py, written with PyTorch-ROCm ops (gather by
-advanced indexing, index_add, scatter_reduce ...) so that autograd provides the backward pass for
-TRAINING.  They run on the GPU like everything else -- this is not a CPU fallback and not the oracle;
-inference never takes this path (it uses the hand-written HIP kernels).  Neighbour indices and masks
-always come from the HIP grouping kernels (they carry no gradient: utils/pointnet_util.py:54-55 wraps
-the mask in stop_gradient and indices are integers).
+"""TEST INFRASTRUCTURE: differentiable restatements of the feature kernels of efficientlo-net_amd/_ops.py in plain
+PyTorch ops (index_select gathers, index_add, scatter_reduce ...), dtype-generic so that they run in float64.
+tests/test_backward_gpu.py differentiates them with torch.autograd in double precision and checks the hand-written
+backward kernels (csrc/elo_backward.hip) against those analytic gradients.  (Round 1 used these functions as the
+training path itself; the product no longer contains them: training runs the HIP kernels forward and backward.)
+Neighbour indices and masks carry no gradient (utils/pointnet_util.py:54-55 wraps the mask in stop_gradient, indices
+are integers).
 
 Gradient semantics follow the reference's TF graph: gather_nd -> scatter-add of the incoming
 gradient, reduce_max -> arg-max routing, and the re-projection passes gradients to the scattered
@@ -153,7 +154,7 @@ def warp_project(xyz, feat, q, t, H, W):
         # one address), their cells are set to 0 by a plain indexed store afterwards
         zero = flat_r == 0
         spread = _spread_rows(flat_cell.numel(), cells, xyz.device)
-        min_r = torch.full((cells + _SPREAD,), float("inf"), device=xyz.device).scatter_reduce(
+        min_r = torch.full((cells + _SPREAD,), float("inf"), device=xyz.device, dtype=flat_r.dtype).scatter_reduce(
             0, torch.where(zero, spread, flat_cell), flat_r, "amin")
         min_r.index_fill_(0, torch.where(zero, flat_cell, spread), 0.0)          # (no boolean indexing: no host sync)
         min_r = min_r[:cells]
