@@ -127,6 +127,7 @@ SYMBOLS = [
     ("elo_range_violations", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), _vp]),
     ("elo_fused_conv_random_k", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
     ("elo_fused_conv_select_k", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
+    ("elo_fused_conv_random_k_dense", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
     ("elo_group_concat", ctypes.c_int, [ctypes.POINTER(GroupConcatArgs), _vp]),
     ("elo_masked_maxpool", ctypes.c_int, [ctypes.POINTER(MaskedMaxpoolArgs), _vp]),
     ("elo_cv_encode1", ctypes.c_int, [ctypes.POINTER(CvEncode1Args), _vp]),

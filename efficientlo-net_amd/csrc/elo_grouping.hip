@@ -20,6 +20,7 @@
 //     glue's four cudaMemset calls, fused_conv.cpp:154-166, disappear).
 // Both are memory-latency bound gathers out of an L2-resident grid: no MFMA.
 #include "elo_group_device.h"
+#include <cstdlib>
 
 namespace elo {
 namespace {
@@ -127,6 +128,158 @@ __global__ __launch_bounds__(ELO_BLOCK) void group_random_k(const elo_group_args
     }
 }
 
+// ---------------------------------------------------------------- random-k, every pixel a centre: LDS-staged windows
+// When EVERY pixel of xyz1 is a centre in row-major order (idx_n2 = get_hw_idx, utils/pointnet_util.py:23-30: the
+// cost-volume and set-upconv calls, BASELINE configs[0]) neighbouring centres share almost their whole window.  A
+// workgroup owns a tile of DENSE_ROWS x 64 centres, stages the union of their windows -- (rows + kH - 1) x (64 + kW - 1)
+// points of the queried grid for stride 1 -- ONCE into LDS with coalesced row segments (16 bytes per point: x, y, z and
+// the "non-empty" test already evaluated; rows outside the grid are staged as empty points: the reference skips both the
+// same way, fused_conv_g.cu:83-86 / :106-111, neither counts as valid), and then ONE THREAD PER CENTRE walks the window in
+// the caller's visiting order exactly like the reference's loop (:74-152).  All 64 lanes of a wave look at the SAME
+// window offset at the same time, so a probe is one conflict-free ds_read_b128 at (lane's base + a wave-uniform offset):
+// no address arithmetic, no 12-byte gathers from L2, no ballots.  Hits are collected per centre in LDS and streamed
+// out as whole contiguous (64 centres x K) output rows at the end.
+constexpr int DENSE_COLS = 64;
+
+struct DenseGeom { int RH, RW; };      // staged region (rows, columns) of the queried grid per tile
+
+__host__ __device__ inline DenseGeom dense_geom(int rows, int kH, int kW, int sh, int sw)
+{
+    return DenseGeom{(rows - 1) / sh + kH, (DENSE_COLS - 1) / sw + kW};
+}
+
+constexpr int DENSE_CHUNK = 8;          // window slots examined per step: their LDS reads are independent and go out together
+// DENSE_ROWS x 64 centres per workgroup (one wave per tile row); hit lists are [K][threads + 1]: slot-major with an odd
+// pitch -> conflict-free for the per-centre writes and for the row-wise read-out
+template <int DENSE_ROWS>
+__global__ __launch_bounds__(DENSE_ROWS * 64) void group_random_k_dense(const elo_group_args a)
+{
+    extern __shared__ int lds[];
+    constexpr int THREADS = DENSE_ROWS * 64, DENSE_SEL_PITCH = THREADS + 1;
+    const int KT = a.kernel_h * a.kernel_w, K = a.K;
+    const int KTp = (KT + DENSE_CHUNK - 1) / DENSE_CHUNK * DENSE_CHUNK;
+    const DenseGeom g = dense_geom(DENSE_ROWS, a.kernel_h, a.kernel_w, a.stride_h, a.stride_w);
+    const int cells = g.RH * g.RW;
+    int *lds_off = lds;                                              // [KTp] visiting order as region offsets (padding: 0)
+    float4 *region = reinterpret_cast<float4 *>(lds + KTp);          // [RH * RW] x, y, z, and in .w the bits of (h << 16) | w of
+                                                                     // the staged point, -1 for an empty pixel / a row outside the grid
+    int *sel = reinterpret_cast<int *>(region + cells);              // [K][THREADS + 1] packed hw of the hits, -1 = none
+    int *count = sel + K * DENSE_SEL_PITCH;                          // [2][THREADS] num_valid, num_select of every centre
+    const int tid = threadIdx.x, lane = tid & 63, wrow = tid >> 6;
+    const int b = blockIdx.z, r0 = blockIdx.y * DENSE_ROWS, c0 = blockIdx.x * DENSE_COLS;
+    const int h0 = r0 / a.stride_h - a.kernel_h / 2, w0 = c0 / a.stride_w - a.kernel_w / 2;    // region origin (unwrapped)
+    // centre of this thread (requested first: overlaps the staging)
+    const int hc = r0 + wrow, wc = c0 + lane;
+    const bool live = hc < a.H && wc < a.W;
+    const float *cp = a.xyz1 + (((size_t)b * a.H + (live ? hc : 0)) * a.W + (live ? wc : 0)) * 3;
+    const float cx = cp[0], cy = cp[1], cz = cp[2];
+    {   // stage the region: consecutive threads along a row of the queried grid; all of a thread's loads go out first
+        const float *grid2 = a.xyz2 + (size_t)b * a.H2 * a.W2 * 3;
+        constexpr int PER = 8;                                        // points per thread in flight
+        for (int e0 = 0; e0 < cells; e0 += PER * THREADS) {
+            float x[PER], y[PER], z[PER];
+            int hw[PER];
+            bool in[PER];
+#pragma unroll
+            for (int v = 0; v < PER; ++v) {
+                const int e = min(e0 + v * THREADS + tid, cells - 1);
+                const int rr = e / g.RW, cc = e - rr * g.RW;
+                const int h = h0 + rr;
+                int w = (w0 + cc) % a.W2;
+                if (w < 0) w += a.W2;                                 // the cylindrical wrap (:89-97; kW/2 <= W2: one wrap = modulo)
+                in[v] = h >= 0 && h < a.H2;
+                hw[v] = (h << 16) | w;
+                const float *q = grid2 + ((size_t)(in[v] ? h : 0) * a.W2 + w) * 3;
+                x[v] = q[0]; y[v] = q[1]; z[v] = q[2];
+            }
+#pragma unroll
+            for (int v = 0; v < PER; ++v) {
+                const int e = e0 + v * THREADS + tid;
+                if (e < cells) {
+                    const bool ok = in[v] && !(sq3(x[v], y[v], z[v]) <= ELO_EPS);       // :106-111
+                    region[e] = float4{x[v], y[v], z[v], __int_as_float(ok ? hw[v] : -1)};
+                }
+            }
+        }
+        for (int i = tid; i < KTp; i += THREADS) {                    // visiting order -> offset in the region (float4 units)
+            const int p = a.random_hw[i < KT ? i : 0];
+            lds_off[i] = i < KT ? (p / a.kernel_w) * g.RW + (p % a.kernel_w) : 0;
+        }
+        for (int k = 0; k < K; ++k) sel[k * DENSE_SEL_PITCH + tid] = -1;
+    }
+    (void)h0; (void)w0;
+    __syncthreads();
+    // this thread's window origin inside the region: slot (dh, dw) of the window is region[(bh + dh) * RW + bw + dw] with
+    // dh, dw counted from the window's top-left corner (the -kH/2, -kW/2 of :80-81 is in h0, w0)
+    const int bh = hc / a.stride_h - (r0 / a.stride_h), bw = wc / a.stride_w - (c0 / a.stride_w);
+    const int origin = bh * g.RW + bw;
+    const float r2 = a.distance * a.distance;
+    const bool centre_ok = live && !(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS);           // :62-70
+    int taken = 0, seen = 0;
+    bool done = !centre_ok;
+    for (int i0 = 0; i0 < KT; i0 += DENSE_CHUNK) {
+        if (__all(done)) break;                                       // wave-uniform: every centre of the row is finished
+        int off[DENSE_CHUNK];
+        float4 q[DENSE_CHUNK];
+#pragma unroll
+        for (int v = 0; v < DENSE_CHUNK; ++v) off[v] = lds_off[i0 + v];          // the same word for all lanes: LDS broadcasts
+#pragma unroll
+        for (int v = 0; v < DENSE_CHUNK; ++v) q[v] = region[origin + off[v]];    // one conflict-free ds_read_b128 each
+#pragma unroll
+        for (int v = 0; v < DENSE_CHUNK; ++v) {
+            if (i0 + v >= KT) break;                                  // (uniform)
+            // branch-free up to the hit: a non-empty pixel counts as valid (:115-116), one within the radius is taken
+            // (:118-145); the walk of this centre stops at its K-th hit (:149-150)
+            const int hw = __float_as_int(q[v].w);
+            const bool valid = !done && hw >= 0;
+            const float d = pick_max(sq3(__fsub_rn(cx, q[v].x), __fsub_rn(cy, q[v].y), __fsub_rn(cz, q[v].z)), ELO_EPS);
+            const bool hit = valid && !(d > r2);
+            seen += valid;
+            if (hit) {
+                sel[taken * DENSE_SEL_PITCH + tid] = hw;
+                ++taken;
+            }
+            done = done || taken >= K;
+        }
+    }
+    if (a.flag_copy == 1 && taken > 0 && taken < K) {                 // :126-138: the first hit fills the empty slots
+        const int first = sel[tid];
+        for (int k = taken; k < K; ++k) sel[k * DENSE_SEL_PITCH + tid] = first;
+    }
+    count[tid] = seen;
+    count[THREADS + tid] = taken;
+    __syncthreads();
+    // stream the tile's outputs: the centres of a tile row are consecutive in npoints order, so each output of a row is
+    // ONE contiguous span, written as flat 4-byte words by consecutive threads
+    const int ncol = min(DENSE_COLS, a.W - c0);
+    for (int row = 0; row < DENSE_ROWS; ++row) {
+        const int hr = r0 + row;
+        if (hr >= a.H) break;
+        const long u0 = ((long)b * a.H + hr) * a.W + c0;              // first centre of the row (npoints == H * W)
+        // a thread per output slot (c, k): 12 + 4 bytes; with THREADS a multiple of K the slot's k never changes and c steps
+        // by THREADS / K: no division in the loop
+        int *o_sel = a.selected_bhw_idx + u0 * K * 3;
+        float *o_mask = a.selected_mask + u0 * K;
+        const bool even = THREADS % K == 0;
+        int c = tid / K, k = tid - c * K;
+        for (int e = tid; e < ncol * K; e += THREADS) {
+            if (!even) { c = e / K; k = e - c * K; }
+            const int hw = sel[k * DENSE_SEL_PITCH + row * DENSE_COLS + c];
+            int *o = o_sel + (long)e * 3;
+            o[0] = hw < 0 ? 0 : b; o[1] = hw < 0 ? 0 : hw >> 16; o[2] = hw < 0 ? 0 : hw & 0xffff;
+            o_mask[e] = hw >= 0 ? 1.0f : 0.0f;
+            if (even) c += THREADS / K;
+        }
+        if (a.valid_idx || a.valid_in_dis_idx) {                      // prefix ones of length num_valid / num_select
+            for (int e = tid; e < ncol * KT; e += THREADS) {
+                const int c = e / KT, i = e - c * KT;
+                if (a.valid_idx) a.valid_idx[u0 * KT + e] = i < count[row * DENSE_COLS + c] ? 1.0f : 0.0f;
+                if (a.valid_in_dis_idx) a.valid_in_dis_idx[u0 * KT + e] = i < count[THREADS + row * DENSE_COLS + c] ? 1.0f : 0.0f;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- select-k
 // One wave per centre. LDS: [KT] decoded offsets (block) + per wave [KT] distance
 // bits and [KT] packed hw.
@@ -230,7 +383,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void group_select_k(const elo_group_args
     }
 }
 
-int check_args(const elo_group_args *a, const char *who)
+int check_args(const elo_group_args *a, const char *who, bool dense = false)
 {
     if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
     if (a->batch < 0 || a->H <= 0 || a->W <= 0 || a->H2 <= 0 || a->W2 <= 0)
@@ -250,8 +403,10 @@ int check_args(const elo_group_args *a, const char *who)
     if (a->kernel_w / 2 > a->W2)
         return fail(ELO_ERR_LIMIT, "%s: kernel_size_W/2 = %d exceeds the queried width %d (single wrap)", who, a->kernel_w / 2, a->W2);
     if (a->H2 >= 32768 || a->W2 >= 65536) return fail(ELO_ERR_LIMIT, "%s: queried grid larger than 32767 x 65535", who);
-    if (!a->xyz1 || !a->xyz2 || !a->idx_n2 || !a->random_hw || !a->selected_bhw_idx || !a->selected_mask)
+    if (!a->xyz1 || !a->xyz2 || (!a->idx_n2 && !dense) || !a->random_hw || !a->selected_bhw_idx || !a->selected_mask)
         return fail(ELO_ERR_ARG, "%s: null tensor pointer", who);
+    if (dense && a->npoints != a->H * a->W)
+        return fail(ELO_ERR_ARG, "%s: every pixel is a centre: npoints must equal H*W", who);
     return ELO_OK;
 }
 
@@ -277,6 +432,39 @@ extern "C" int elo_fused_conv_random_k(const elo_group_args *a, elo_stream_t str
     else
         hipLaunchKernelGGL((group_random_k<32, 2>), grid(32), dim3(ELO_BLOCK), lds, s, *a, total);
     return check_launch("elo_fused_conv_random_k");
+}
+
+// LDS bytes of the dense form with `rows` x 64 centres per workgroup, 0 = it does not fit
+static size_t dense_lds_bytes(const elo_group_args *a, int rows)
+{
+    using namespace elo;
+    const int KT = a->kernel_h * a->kernel_w, threads = rows * 64;
+    const DenseGeom g = dense_geom(rows, a->kernel_h, a->kernel_w, a->stride_h, a->stride_w);
+    const int KTp = (KT + DENSE_CHUNK - 1) / DENSE_CHUNK * DENSE_CHUNK;
+    const size_t bytes = sizeof(int) * KTp + sizeof(float4) * (size_t)g.RH * g.RW +
+                         sizeof(int) * ((size_t)(threads + 1) * a->K + 2 * threads);
+    return bytes <= 64 * 1024 ? bytes : 0;
+}
+
+extern "C" int elo_fused_conv_random_k_dense(const elo_group_args *a, elo_stream_t stream)
+{
+    using namespace elo;
+    const char *who = "elo_fused_conv_random_k_dense";
+    if (int rc = check_args(a, who, true)) return rc;
+    if (a->batch == 0) return ELO_OK;
+    // 4 rows per workgroup share more of the window; 2 rows give twice the workgroups (small grids, large windows)
+    static const int forced = [] { const char *e = getenv("ELO_DENSE_ROWS"); return e ? atoi(e) : 0; }();
+    const long tiles4 = (long)((a->W + DENSE_COLS - 1) / DENSE_COLS) * ((a->H + 3) / 4) * a->batch;
+    int rows = forced ? forced : (tiles4 >= 1024 && dense_lds_bytes(a, 4) ? 4 : 2);
+    if (rows == 4 && !dense_lds_bytes(a, 4)) rows = 2;
+    const size_t lds = dense_lds_bytes(a, rows);
+    if ((rows != 2 && rows != 4) || lds == 0)
+        return fail(ELO_ERR_LIMIT, "%s: window %dx%d with K = %d does not fit the LDS tile (use elo_fused_conv_random_k)",
+                    who, a->kernel_h, a->kernel_w, a->K);
+    const dim3 grid((unsigned)((a->W + DENSE_COLS - 1) / DENSE_COLS), (unsigned)((a->H + rows - 1) / rows), (unsigned)a->batch);
+    if (rows == 4) hipLaunchKernelGGL(group_random_k_dense<4>, grid, dim3(256), lds, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(group_random_k_dense<2>, grid, dim3(128), lds, (hipStream_t)stream, *a);
+    return check_launch(who);
 }
 
 extern "C" int elo_fused_conv_select_k(const elo_group_args *a, elo_stream_t stream)

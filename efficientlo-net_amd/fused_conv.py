@@ -52,8 +52,26 @@ def _check(name, xyz1, xyz2, idx_n2, random_hw, npoints, kernel_size_H, kernel_s
     return B, H, W, H2, W2
 
 
+_DENSE_INDEX = {}        # data_ptr -> tensor: index tensors known to be "every pixel, row-major" (get_hw_idx's)
+
+
+def register_dense_index(idx_n2):
+    """Tell the wrappers that `idx_n2` (B, H*W, 2) lists every pixel in row-major order (pointnet_util.get_hw_idx builds
+    and registers such tensors): random-k calls with it take the LDS-tiled kernel (elo_fused_conv_random_k_dense)."""
+    if len(_DENSE_INDEX) >= 256:
+        _DENSE_INDEX.clear()
+    _DENSE_INDEX[idx_n2.data_ptr()] = idx_n2
+    return idx_n2
+
+
+def _dense_fits(kH, kW, K, stride_h, stride_w):
+    """dense_lds_bytes of csrc/elo_grouping.hip for its smaller (2 x 64) tile: window union + hit lists within 64 KB of LDS."""
+    RH, RW = 1 // stride_h + kH, 63 // stride_w + kW
+    return 4 * ((kH * kW + 7) & ~7) + 16 * RH * RW + 4 * (129 * K + 256) <= 64 * 1024
+
+
 def _launch(entry, name, xyz1, xyz2, idx_n2, random_hw, H, W, npoints, kernel_size_H, kernel_size_W, K,
-            flag_copy, distance, stride_h, stride_w, want_valid):
+            flag_copy, distance, stride_h, stride_w, want_valid, dense=None):
     # H, W attributes are unused by the reference's Compute as well: the real
     # sizes come from the tensor (fused_conv.cpp:108-110).
     B, H, W, H2, W2 = _check(name, xyz1, xyz2, idx_n2, random_hw, npoints, kernel_size_H, kernel_size_W,
@@ -62,6 +80,12 @@ def _launch(entry, name, xyz1, xyz2, idx_n2, random_hw, H, W, npoints, kernel_si
     idx_n2, random_hw = idx_n2.contiguous(), random_hw.contiguous()
     KT = kernel_size_H * kernel_size_W
     dev = xyz1.device
+    if entry == "elo_fused_conv_random_k" and dense is not False and npoints == H * W:
+        known = _DENSE_INDEX.get(idx_n2.data_ptr())
+        if dense or (known is idx_n2 and _dense_fits(kernel_size_H, kernel_size_W, K, stride_h, stride_w)):
+            entry = "elo_fused_conv_random_k_dense"
+    elif dense:
+        raise ValueError("the dense form needs npoints == H*W (every pixel a centre) and random-k")
     sel = torch.empty((B, npoints, K, 3), dtype=torch.int32, device=dev)
     mask = torch.empty((B, npoints, K, 1), dtype=torch.float32, device=dev)
     if want_valid:
@@ -80,17 +104,20 @@ def _launch(entry, name, xyz1, xyz2, idx_n2, random_hw, H, W, npoints, kernel_si
 
 
 def fused_conv_random_k(xyz1, xyz2, idx_n2, random_hw, H, W, npoints, kernel_size_H, kernel_size_W, K,
-                        flag_copy, distance, stride_h, stride_w, want_valid=True):
+                        flag_copy, distance, stride_h, stride_w, want_valid=True, dense=None):
     """First K in-range neighbours in the caller's visiting order.
 
     Returns (selected_bhw_idx i32 (B,N,K,3), valid_idx f32 (B,N,KT,1),
     valid_in_dis_idx f32 (B,N,KT,1), selected_mask f32 (B,N,K,1)).
     want_valid=False (an extension used by the model path) skips the two
     outputs no caller reads and returns None for them.
+    dense (extension): True = the caller vouches that idx_n2 lists EVERY pixel in row-major order (get_hw_idx) and the
+    LDS-tiled kernel is used; None = used automatically for index tensors registered with register_dense_index;
+    False = always the general kernel.  Same outputs bit for bit either way.
     """
     return _launch("elo_fused_conv_random_k", "FusedConvRandomK", xyz1, xyz2, idx_n2, random_hw, H, W,
                    npoints, kernel_size_H, kernel_size_W, K, flag_copy, distance, stride_h, stride_w,
-                   want_valid)
+                   want_valid, dense)
 
 
 def fused_conv_select_k(xyz1, xyz2, idx_n2, random_hw, H, W, npoints, kernel_size_H, kernel_size_W, K,

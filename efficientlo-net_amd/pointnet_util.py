@@ -23,7 +23,7 @@ import os
 import torch
 
 from . import _ops, fused, tf_util
-from .fused_conv import fused_conv_random_k, fused_conv_select_k
+from .fused_conv import fused_conv_random_k, fused_conv_select_k, register_dense_index
 from .perm import random_shuffle
 
 
@@ -77,7 +77,7 @@ def get_hw_idx(B, H, W, device="cuda"):
             return grid                     # a tensor born inside a graph's private pool is never cached
         if len(_hw_cache) >= 256:
             _hw_cache.clear()
-        _hw_cache[key] = grid
+        _hw_cache[key] = register_dense_index(grid)      # random-k calls with it take the LDS-tiled kernel
     return _hw_cache[key]
 
 

@@ -92,6 +92,12 @@ typedef struct elo_group_args {
 
 int elo_fused_conv_random_k(const elo_group_args *a, elo_stream_t stream);
 int elo_fused_conv_select_k(const elo_group_args *a, elo_stream_t stream);
+/* elo_fused_conv_random_k for the call shape "EVERY pixel of xyz1 is a centre, in row-major order" -- idx_n2 =
+ * get_hw_idx(...) (utils/pointnet_util.py:23-30), npoints == H*W: the cost-volume stage 2 and set-upconv calls
+ * (:106-108, :272-274) and BASELINE configs[0].  a->idx_n2 is IGNORED (may be NULL); same outputs bit for bit.
+ * The window union of a tile of 4 x 64 centres is staged once in LDS and every centre walks its window from there.
+ * ELO_ERR_LIMIT when the window / K do not fit the 64 KB tile: call the general entry point. */
+int elo_fused_conv_random_k_dense(const elo_group_args *a, elo_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Feature path: fused gather / encode / pool kernels.  These replace chains of

@@ -249,3 +249,35 @@ def test_select_k32_window_5x35_at_batch8_is_bit_exact():
     want = G.fused_conv_select_k(x1, x2, synth.hw_index(B, 4, 57), perm, 4, 57, 228, 5, 35, 32, 0, 1000.0, 1, 1)
     assert np.array_equal(g.idx.cpu().numpy(), want[0]) and np.array_equal(g.mask.cpu().numpy()[..., None], want[3])
     assert want[3].sum() > 0.5 * want[3].size          # a populated case, not an all-masked one
+
+
+@pytest.mark.parametrize("case", [dict(H=64, W=1800, win=(9, 15), K=16, d=0.5, stride=(1, 1), fc=0),      # BASELINE configs[0]
+                                  dict(H=16, W=225, win=(3, 5), K=4, d=1.0, stride=(1, 1), fc=0),          # cost-volume stage 2
+                                  dict(H=16, W=225, win=(7, 15), K=8, d=3.0, stride=(2, 2), fc=0),         # set-upconv, strided
+                                  dict(H=7, W=70, win=(5, 9), K=6, d=2.0, stride=(1, 2), fc=1),            # ragged tile, flag_copy
+                                  dict(H=5, W=33, win=(3, 41), K=5, d=1000.0, stride=(1, 1), fc=0),        # window wider than the image
+                                  dict(H=128, W=2048, win=(11, 41), K=6, d=4.0, stride=(1, 1), fc=0)])      # configs[4]'s grid
+def test_dense_lds_tiled_random_k_is_bit_exact(case):
+    """elo_fused_conv_random_k_dense (every pixel a centre, window union of a 4 x 64 tile staged in LDS, one thread per
+    centre walking it in the visiting order) against the oracle: all four outputs, bit for bit, incl. the cylindrical
+    wrap, rows outside the grid, empty pixels, strides, flag_copy, ragged last tiles; and it equals the general kernel."""
+    elo, synth = load_pkg(), load_pkg("synth")
+    H, W, (kH, kW), K, (sh, sw) = case["H"], case["W"], case["win"], case["K"], case["stride"]
+    B = 2 if H * W < 20000 else 1
+    f1, f2 = synth.frame_pair(B, H, W, seed=H + W)
+    x2 = np.ascontiguousarray(f2[:, ::sh, ::sw])
+    rng = np.random.default_rng(kH * kW)
+    perm = rng.permutation(kH * kW).astype(np.int32)
+    hw = synth.hw_index(B, H, W)
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = (t(f1), t(x2), t(hw), t(perm), H, W, H * W, kH, kW, K, case["fc"], case["d"], sh, sw)
+    got = elo.fused_conv_random_k(*args, dense=True)
+    gen = elo.fused_conv_random_k(*args, dense=False)
+    want = G.fused_conv_random_k(f1, x2, hw, perm, H, W, H * W, kH, kW, K, case["fc"], case["d"], sh, sw, threads=8)
+    for g, o, w_ in zip(got, gen, want):
+        assert np.array_equal(g.cpu().numpy(), w_) and torch.equal(g, o)
+    # the index tensors get_hw_idx hands out take the dense kernel on their own
+    pu = load_pkg("pointnet_util")
+    auto = elo.fused_conv_random_k(args[0], args[1], pu.get_hw_idx(B, H, W, dev), *args[3:], want_valid=False)
+    assert torch.equal(auto[0], got[0]) and torch.equal(auto[3], got[3])

@@ -22,3 +22,7 @@ for (name, fn, H, W, centres, win, K, dist) in [
         run = lambda: fn(a[0], a[1], a[2], a[3], H, W, idx.shape[1], win[0], win[1], K, 0, dist, 1, 1, want_valid=want)
         us = bench._time_launches(run, dev, 100) * 1e6
         print(json.dumps({"case": name, "valid_outputs": want, "us": round(us, 1)}))
+        if fn is elo.fused_conv_random_k and centres == "all":          # the LDS-tiled form (every pixel a centre)
+            run = lambda: fn(a[0], a[1], a[2], a[3], H, W, idx.shape[1], win[0], win[1], K, 0, dist, 1, 1, want_valid=want, dense=True)
+            us = bench._time_launches(run, dev, 100) * 1e6
+            print(json.dumps({"case": name + " [dense: LDS-staged windows]", "valid_outputs": want, "us": round(us, 1)}))
