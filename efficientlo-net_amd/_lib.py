@@ -151,6 +151,7 @@ SYMBOLS = [
     ("elo_mlp_fused2", ctypes.c_int, [ctypes.POINTER(MlpArgs), ctypes.POINTER(MlpArgs), _vp]),
     ("elo_cv_stage1_fused", ctypes.c_int, [ctypes.POINTER(Cv1Args), _vp]),
     ("elo_cv_stage2_fused", ctypes.c_int, [ctypes.POINTER(Cv2Args), _vp]),
+    ("elo_cv_stage1_setconv_fused", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
 ]
 
 _lib = None
@@ -184,6 +185,12 @@ def call(entry, args, like):
     """Launch `entry(args, current stream)` on like.device; raise on a non-zero status."""
     with torch.cuda.device(like.device):
         check(getattr(lib(), entry)(ctypes.byref(args), stream_ptr(like)))
+
+
+def call3(entry, a, b, c, like):
+    """`entry(a, b, c or NULL, current stream)`."""
+    with torch.cuda.device(like.device):
+        check(getattr(lib(), entry)(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c) if c is not None else None, stream_ptr(like)))
 
 
 def call2(entry, args_a, args_b, like):

@@ -748,18 +748,18 @@ struct JobPair { Args job[2]; };                  // one kernarg block: job[bloc
 // 5 waves per SIMD (<= 102 VGPRs).  History: 140 VGPRs uncapped (3 workgroups per CU); a cap of 4 cost 12 bytes of
 // scratch and gave +4 % at batch 8; with the scalar wave index and buffer-addressed W fragments the kernels need 92-96
 // VGPRs without any spill.  A cap of 6 (80 VGPRs) spills 36-144 bytes in the cost-volume kernels: not taken.
+// `block` of `nblocks`: the tile this workgroup works on (blockIdx.x / gridDim.x of a plain launch, or the workgroup's
+// position inside its share of a heterogeneous launch, cv1_setconv_kernel)
 template <int TILE, int MODE>
-__global__ __launch_bounds__(FUSED_BLOCK, 5) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
+__device__ __forceinline__ void setconv_tile(const elo_setconv_args &a, const int S, float *lds, unsigned block, unsigned nblocks)
 {
-    const elo_setconv_args &a = jobs.job[blockIdx.y];
-    extern __shared__ float lds[];
     float *act = lds;
     const TileMeta meta = tile_meta(lds, TILE, S);
     const int tid = threadIdx.x;
     const int K = a.K, P = TILE / K, f16 = a.feat_dtype == ELO_F16;
     unsigned bad = 0;
     const long total_points = (long)a.batch * a.npoints;
-    const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
+    const long first_point = (long)xcd_tile(block, nblocks) * P;
     if (first_point >= total_points) return;
     if (a.group.random_hw) {
         int *lds_off = reinterpret_cast<int *>(meta.cxyz + 96);
@@ -822,6 +822,13 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void setconv_kernel(const JobPair<e
         dense<TILE, MODE>(act, S, 0, a.layers[l], l == a.n_layers - 1 ? to_pool(0) : to_tile(0), bad);
     pool_masked_max(act, S, 0, a.layers[a.n_layers - 1].N, meta, P, K, first_point, total_points, a.out, f16);   // :224-230
     report_violations<MODE>(bad);
+}
+
+template <int TILE, int MODE>
+__global__ __launch_bounds__(FUSED_BLOCK, 5) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
+{
+    extern __shared__ float lds[];
+    setconv_tile<TILE, MODE>(jobs.job[blockIdx.y], S, lds, blockIdx.x, gridDim.x);
 }
 
 
@@ -1064,16 +1071,15 @@ __host__ __device__ __forceinline__ int cv1_feat_cols(int C)
 }
 
 template <int TILE, int MODE>
-__global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_kernel(const elo_cv1_args a, const int S)
+__device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, float *lds, unsigned block, unsigned nblocks)
 {
-    extern __shared__ float lds[];
     float *act = lds;
     const TileMeta meta = tile_meta(lds, TILE, S);
     const int tid = threadIdx.x;
     const int K = a.K, P = TILE / K, C = a.C, f16 = a.feat_dtype == ELO_F16;
     unsigned bad = 0;
     const long total_points = (long)a.batch * a.npoints;
-    const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
+    const long first_point = (long)xcd_tile(block, nblocks) * P;
     if (first_point >= total_points) return;
     if (a.group.random_hw) {                          // select-k of frame 2 around every warped frame-1 pixel (:49-51)
         int *lds_off = reinterpret_cast<int *>(meta.cxyz + 96);
@@ -1124,6 +1130,38 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_kernel(const elo_cv1_args 
 #endif
     pool_masked_softmax(act, S, 64, 0, meta, P, K, first_point, total_points, a.out, f16);   // :92-98
     report_violations<MODE>(bad);
+}
+
+template <int TILE, int MODE>
+__global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_kernel(const elo_cv1_args a, const int S)
+{
+    extern __shared__ float lds[];
+    cv1_tile<TILE, MODE>(a, S, lds, blockIdx.x, gridDim.x);
+}
+
+// ---- heterogeneous launch: cost-volume stage 1 and one or two set-conv jobs in ONE grid ---------------------------------
+// Inside a refinement level the cost volume (stage 1 -> stage 2) and the two set-upconvs only share INPUTS
+// (pwclo_model.py:242-250), and at the head of the pyramid the initial cost volume (:170) does not need the layer-3
+// set-conv (:138): as consecutive launches of a batch-1 forward each of them leaves most CUs idle and pays its own
+// ≈4.5 us launch boundary (forked streams inside the hipGraph cost more than they gain).  Here the first
+// n_cv workgroups run cost-volume tiles and the rest set-conv tiles: one launch, both branches in flight together.
+struct SideJobs {
+    elo_setconv_args job[2];
+    int njobs, S, blocks_per_job;
+};
+
+template <int TILE_CV, int TILE_SC, int MODE>
+__global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_setconv_kernel(const elo_cv1_args a, const int S, const unsigned n_cv,
+                                                                     const SideJobs side)
+{
+    extern __shared__ float lds[];
+    if (blockIdx.x < n_cv) {
+        cv1_tile<TILE_CV, MODE>(a, S, lds, blockIdx.x, n_cv);
+    } else {
+        const unsigned r = blockIdx.x - n_cv;
+        const unsigned j = r / side.blocks_per_job;                    // uniform: one scalar index into the kernarg block
+        setconv_tile<TILE_SC, MODE>(side.job[j], side.S, lds, r - j * side.blocks_per_job, side.blocks_per_job);
+    }
 }
 
 // ================================================================ cost volume, stage 2
@@ -1309,6 +1347,9 @@ static int check_setconv(const elo_setconv_args *a, const char *who)
     return ELO_OK;
 }
 
+// how a tile kernel is launched: LDS row stride, tile height, workgroups (per job), LDS bytes, products mode
+struct TilePlan { int S; bool t16; long units; size_t lds; int mode; };
+
 static bool same_shape(const elo_setconv_args *a, const elo_setconv_args *b)
 {
     if (a->batch != b->batch || a->npoints != b->npoints || a->K != b->K || a->C != b->C || a->n_layers != b->n_layers ||
@@ -1318,6 +1359,26 @@ static bool same_shape(const elo_setconv_args *a, const elo_setconv_args *b)
     for (int l = 0; l < a->n_layers; ++l)
         if (a->layers[l].K != b->layers[l].K || a->layers[l].N != b->layers[l].N) return false;
     return true;
+}
+
+// the tile-kernel launch of one or two (same-shape, already checked) set-conv jobs
+static int plan_setconv(const elo_setconv_args *a, const elo_setconv_args *b, TilePlan *p, const char *who)
+{
+    const long points = (long)a->batch * a->npoints;
+    p->S = row_stride(chain_cols(a->layers, a->n_layers, 3 + a->C));
+    const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
+    const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
+    int mode_b = 0;
+    if (int rc = products_mode(who, &p->mode, a->layers, a->n_layers)) return rc;
+    if (b) {
+        if (int rc = products_mode(who, &mode_b, b->layers, b->n_layers)) return rc;
+        if (p->mode != mode_b) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must share one products mode", who);
+    }
+    p->t16 = small_tile(u32 * (b ? 2 : 1), a->K);
+    p->units = p->t16 ? u16 : u32;
+    const int KT = a->group.random_hw ? a->group.kernel_h * a->group.kernel_w : 0;
+    p->lds = tile_lds_bytes(p->t16 ? 16 : 32, p->S, KT, false);
+    return check_group(a->group, a->H2, a->W2, p->lds, who);
 }
 
 extern "C" int elo_dense_f32(void)
@@ -1375,25 +1436,16 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
             return check_launch(who);
         }
     }
-    const int S = row_stride(chain_cols(a->layers, a->n_layers, 3 + a->C));
-    const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
-    const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
-    int mode = 0, mode_b = 0;
-    if (int rc = products_mode(who, &mode, a->layers, a->n_layers)) return rc;
-    if (b) {
-        if (int rc = products_mode(who, &mode_b, b->layers, b->n_layers)) return rc;
-        if (mode != mode_b) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must share one products mode", who);
-    }
-    const bool t16 = small_tile(u32 * (b ? 2 : 1), a->K);
-    const int KT = a->group.random_hw ? a->group.kernel_h * a->group.kernel_w : 0;
-    const size_t lds = tile_lds_bytes(t16 ? 16 : 32, S, KT, false);
-    if (int rc = check_group(a->group, a->H2, a->W2, lds, who)) return rc;
+    TilePlan plan;
+    if (int rc = plan_setconv(a, b, &plan, who)) return rc;
     JobPair<elo_setconv_args> pair;
     pair.job[0] = *a;
     pair.job[1] = b ? *b : *a;
-    const dim3 grid((unsigned)(t16 ? u16 : u32), b ? 2u : 1u);
+    const dim3 grid((unsigned)plan.units, b ? 2u : 1u);
+    const size_t lds = plan.lds;
+    const int S = plan.S;
 #define CALL(k) hipLaunchKernelGGL(k, grid, dim3(FUSED_BLOCK), lds, s, pair, S)
-    ELO_PICK(setconv_kernel, t16, mode, CALL);
+    ELO_PICK(setconv_kernel, plan.t16, plan.mode, CALL);
 #undef CALL
     return check_launch(who);
 }
@@ -1494,9 +1546,8 @@ static int check_cv_features(const char *who, int C, int f16, std::initializer_l
     return ELO_OK;
 }
 
-extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
+static int plan_cv1(const elo_cv1_args *a, TilePlan *p, const char *who)
 {
-    const char *who = "elo_cv_stage1_fused";
     ELO_REQUIRE(a, who, "null argument block");
     ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->K > 0 && a->H2 > 0 && a->W2 > 0 && a->C > 0, who, "bad sizes");
     if (a->K > 32) return fail(ELO_ERR_LIMIT, "%s: K = %d exceeds the 32-row tile", who, a->K);
@@ -1513,22 +1564,75 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
     if (int rc = check_dense(a->sum_cv0, 128, 128, who, "sum_CV_0")) return rc;
     if (int rc = check_dense(a->sum_cv1, 128, 64, who, "sum_CV_1")) return rc;
     const long points = (long)a->batch * a->npoints;
-    if (points == 0) return ELO_OK;
     const int cols = 128 + cv1_feat_cols(a->C);
-    const int S = row_stride(cols > 192 ? cols : 192);
+    p->S = row_stride(cols > 192 ? cols : 192);
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
-    int mode = 0;
-    if (int rc = products_mode(who, &mode, a->cv0, a->cv1, a->cv2, a->cv_xyz, a->sum_cv0, a->sum_cv1)) return rc;
-    const bool t16 = small_tile(u32, a->K);
+    if (int rc = products_mode(who, &p->mode, a->cv0, a->cv1, a->cv2, a->cv_xyz, a->sum_cv0, a->sum_cv1)) return rc;
+    p->t16 = small_tile(u32, a->K);
+    p->units = p->t16 ? u16 : u32;
     const int KT = a->group.random_hw ? a->group.kernel_h * a->group.kernel_w : 0;
-    const size_t lds = tile_lds_bytes(t16 ? 16 : 32, S, KT, true, a->K);
-    if (int rc = check_group(a->group, a->H2, a->W2, lds, who)) return rc;
-    const dim3 grid((unsigned)(t16 ? u16 : u32));
+    p->lds = tile_lds_bytes(p->t16 ? 16 : 32, p->S, KT, true, a->K);
+    return check_group(a->group, a->H2, a->W2, p->lds, who);
+}
+
+extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_cv_stage1_fused";
+    TilePlan plan;
+    if (int rc = plan_cv1(a, &plan, who)) return rc;
+    if ((long)a->batch * a->npoints == 0) return ELO_OK;
+    const dim3 grid((unsigned)plan.units);
+    const size_t lds = plan.lds;
+    const int S = plan.S;
     hipStream_t s = (hipStream_t)stream;
 #define CALL(k) hipLaunchKernelGGL(k, grid, dim3(FUSED_BLOCK), lds, s, *a, S)
-    ELO_PICK(cv1_kernel, t16, mode, CALL);
+    ELO_PICK(cv1_kernel, plan.t16, plan.mode, CALL);
 #undef CALL
+    return check_launch(who);
+}
+
+// KERNEL<TILE_CV, TILE_SC, MODE> for the heterogeneous launch
+#ifdef ELO_DENSE_F32
+#define ELO_PICK_MODE(M_, CALL_T) do { if ((M_) == MODE_CHECKED) CALL_T(MODE_CHECKED); else CALL_T(MODE_SPLIT); } while (0)
+#else
+#define ELO_PICK_MODE(M_, CALL_T) do { if ((M_) == MODE_HALF) CALL_T(MODE_HALF); else if ((M_) == MODE_CHECKED) CALL_T(MODE_CHECKED); else CALL_T(MODE_SPLIT); } while (0)
+#endif
+
+extern "C" int elo_cv_stage1_setconv_fused(const elo_cv1_args *a, const elo_setconv_args *ja, const elo_setconv_args *jb,
+                                           elo_stream_t stream)
+{
+    const char *who = "elo_cv_stage1_setconv_fused";
+    TilePlan pc, ps;
+    if (int rc = plan_cv1(a, &pc, who)) return rc;
+    if (int rc = check_setconv(ja, who)) return rc;
+    if (jb) {
+        if (int rc = check_setconv(jb, who)) return rc;
+        if (!same_shape(ja, jb)) return fail(ELO_ERR_ARG, "%s: the two set-conv jobs must have the same shape", who);
+    }
+    if (int rc = plan_setconv(ja, jb, &ps, who)) return rc;
+    if (ps.mode != pc.mode) return fail(ELO_ERR_ARG, "%s: the cost volume and the set-conv jobs must share one products mode", who);
+    if ((long)a->batch * a->npoints == 0 || (long)ja->batch * ja->npoints == 0)
+        return fail(ELO_ERR_ARG, "%s: empty batch (call the separate entry points)", who);
+    SideJobs side;
+    side.job[0] = *ja;
+    side.job[1] = jb ? *jb : *ja;
+    side.njobs = jb ? 2 : 1;
+    side.S = ps.S;
+    side.blocks_per_job = (int)ps.units;
+    const unsigned n_cv = (unsigned)pc.units;
+    const dim3 grid(n_cv + (unsigned)(ps.units * side.njobs));
+    const size_t lds = pc.lds > ps.lds ? pc.lds : ps.lds;
+    const int S = pc.S;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL_T(M) do {                                                                                                  \
+        if (pc.t16 && ps.t16) hipLaunchKernelGGL((cv1_setconv_kernel<16, 16, M>), grid, dim3(FUSED_BLOCK), lds, s, *a, S, n_cv, side);      \
+        else if (pc.t16) hipLaunchKernelGGL((cv1_setconv_kernel<16, 32, M>), grid, dim3(FUSED_BLOCK), lds, s, *a, S, n_cv, side);           \
+        else if (ps.t16) hipLaunchKernelGGL((cv1_setconv_kernel<32, 16, M>), grid, dim3(FUSED_BLOCK), lds, s, *a, S, n_cv, side);           \
+        else hipLaunchKernelGGL((cv1_setconv_kernel<32, 32, M>), grid, dim3(FUSED_BLOCK), lds, s, *a, S, n_cv, side);                        \
+    } while (0)
+    ELO_PICK_MODE(pc.mode, CALL_T);
+#undef CALL_T
     return check_launch(who);
 }
 

@@ -317,7 +317,11 @@ def mlp2_pair(job_a, job_b):
     return (shape(out_a), shape(out2_a)), (shape(out_b), shape(out2_b))
 
 
-def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1, group=None, K=None):
+def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1, group=None, K=None,
+              side=None):
+    """Cost-volume stage 1 in one launch.  `side`: one or two set-conv jobs (dicts of setconv() keyword arguments, same
+    shape) that only share inputs with the cost volume -- run INSIDE this launch (elo_cv_stage1_setconv_fused); the call
+    then returns (out, [(out_a, new_xyz_a), ...])."""
     L.require_gpu(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask)
     xyz1, xyz2_proj = _f32c(xyz1), _f32c(xyz2_proj)
     (feat1, feat2_proj), dt, code = _features(feat1, feat2_proj)
@@ -332,6 +336,10 @@ def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_x
                   ptr(idx), ptr(mask), cv0.struct(), cv1.struct(), cv2.struct(), cv_xyz.struct(),
                   sum_cv0.struct(), sum_cv1.struct(), out.data_ptr(),
                   group.struct(B, N, K, xyz1.device) if group is not None else _NO_GROUP, code)
+    if side:
+        jobs = [_setconv_args(**job) for job in side]                  # (args, out, new_xyz, keep-alive)
+        L.call3("elo_cv_stage1_setconv_fused", a, jobs[0][0], jobs[1][0] if len(jobs) > 1 else None, out)
+        return out, [(j[1], j[2]) for j in jobs]
     L.call("elo_cv_stage1_fused", a, out)
     return out
 

@@ -108,8 +108,10 @@ def _split_conv(parts, num_output_channels, scope, is_training, bn_decay, bn=Tru
 
 def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_size1, kernel_size2, nsample,
                 nsample_q, distance, mlp1, mlp2, is_training, bn_decay, scope, bn=True, pooling='max', knn=True,
-                corr_func='elementwise_product'):
-    """Attentive cost volume, utils/pointnet_util.py:33-149.  Returns (B, H*W, mlp2[-1])."""
+                corr_func='elementwise_product', side_jobs=None):
+    """Attentive cost volume, utils/pointnet_util.py:33-149.  Returns (B, H*W, mlp2[-1]).
+    `side_jobs` (fused inference path only): one or two set-conv jobs (fused.setconv keyword dicts) that only share
+    inputs with this cost volume; they run inside stage 1's launch and the call returns (cost, [(out, new_xyz), ...])."""
     with tf_util.variable_scope(scope):
         B, H, W, _ = warped_xyz1_proj.shape
         N = H * W
@@ -126,18 +128,23 @@ def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_
             if list(mlp1) != [128, 64, 64] or list(mlp2) != [128, 64]:
                 raise NotImplementedError("the fused cost volume is built for mlp1=[128,64,64], mlp2=[128,64]")
             P = fused.packed_layer
-            pi_feat1_new = fused.cv_stage1(
+            stage1 = fused.cv_stage1(
                 warped_xyz1, points1, xyz2_proj, points2_proj, None, None,
                 P('CV_0', 10 + 2 * C, 128, row_order=fused.cv0_row_order(C)), P('CV_1', 128, 64), P('CV_2', 64, 64),
                 P('CV_xyz', 10, 64),
                 P('sum_CV_0', 128, 128, row_order=list(range(64, 128)) + list(range(64))),      # kernel order [x | enc]
                 P('sum_CV_1', 128, 64),
-                group=fused.Grouping(random_HW_q, kernel_size2, 1000), K=nsample_q).reshape(B, H, W, -1)   # :49-100
+                group=fused.Grouping(random_HW_q, kernel_size2, 1000), K=nsample_q, side=side_jobs)       # :49-100
+            pi_feat1_new, side_out = stage1 if side_jobs else (stage1, None)
+            pi_feat1_new = pi_feat1_new.reshape(B, H, W, -1)
             order = list(range(64 + C, 128 + C)) + list(range(64)) + list(range(64, 64 + C))   # [grouped | enc | feat1]
-            return fused.cv_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, None, None,
+            cost = fused.cv_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, None, None,
                                    P('sum_xyz_encoding', 10, 64), P('sum_cost_volume_0', 128 + C, 128, row_order=order),
                                    P('sum_cost_volume_1', 128, 64),
                                    group=fused.Grouping(random_HW_p, kernel_size1, distance), K=nsample)   # :104-146
+            return (cost, side_out) if side_jobs else cost
+        if side_jobs:
+            raise NotImplementedError("side_jobs ride on the fused cost-volume launch only")
 
         # ---- stage 1: point -> patch in frame 2 (:47-100)
         idx_hw = get_hw_idx(B, H, W, dev)
@@ -225,6 +232,17 @@ def fused_pairs_available(is_training):
     return _fused_path(is_training)
 
 
+# Branches that only share inputs ride on ONE heterogeneous launch (fused.cv_stage1(side=...)) while the GPU is
+# underfilled: measured at 64x1800 (8 lanes) batch 1 8770 -> 9290 pairs/s, one lane 2700 -> 3020; at batch 8 the merged
+# grid is slower (15 800 -> 15 200: the set-conv tiles run at the cost-volume kernel's register / LDS footprint), so
+# the merge is taken up to this many centre points per launch (batch x H x W of the level; batch 2: 12 040 -> 12 410, batch 4: 14 620 -> 14 380).
+_MERGE_POINTS = int(os.environ.get("ELO_MERGE_POINTS", "8192"))
+
+
+def merge_branches(is_training, points):
+    return _fused_path(is_training) and points <= _MERGE_POINTS
+
+
 def flow_predictor_pair(call_a, call_b):
     """Two flow_predictor calls with identical shapes (dicts of flow_predictor keyword arguments) in ONE launch
     (pwclo_model.py:253-254: the embedding and the embedding-mask predictors of a refinement level)."""
@@ -270,21 +288,39 @@ def up_conv_predict_pair(up_a, up_b, fp_a, fp_b):
     output, the predictor's MLP (flow_predictor's concat [points_f1, upsampled_feat, cost_volume] with
     upsampled_feat coming straight from the tile).  up_x / fp_x: the keyword dicts of up_conv_pair /
     flow_predictor_pair; fp_x's upsampled_feat is up_x's output.  Returns (up_out_a, predictor_a, up_out_b, predictor_b)."""
-    jobs, stage2 = [], []
-    for up, fp in ((up_a, fp_a), (up_b, fp_b)):
+    jobs = up_conv_stage1_jobs(up_a, up_b)
+    (up_a_pooled, _), (up_b_pooled, _) = fused.setconv_pair(jobs[0], jobs[1])
+    return up_conv_predict_finish(up_a, up_b, fp_a, fp_b, up_a_pooled, up_b_pooled)
+
+
+def up_conv_stage1_jobs(up_a, up_b):
+    """Stage 1 (grouping + gather + MLP + max-pool, pointnet_util.py:272-298) of the two set-upconvs of a level as two
+    fused.setconv job dicts: for fused.setconv_pair, or as `side_jobs` of the level's cost volume (they only share
+    inputs with it, so they can ride on its first launch)."""
+    jobs = []
+    for up in (up_a, up_b):
         P = fused.packed_layer
         with tf_util.variable_scope(up["scope"]):
-            xyz1_proj, feat1_proj, feat2_proj = up["xyz1_proj"], up["feat1_proj"], up["feat2_proj"]
-            B, H, W, _ = xyz1_proj.shape
-            ks, mlp, mlp2 = up["kernel_size"], up["mlp"], up["mlp2"]
-            random_HW = random_shuffle(tf_util.scope_name(), "random_HW", ks[0] * ks[1], xyz1_proj.device)
+            feat2_proj, ks, mlp = up["feat2_proj"], up["kernel_size"], up["mlp"]
+            random_HW = random_shuffle(tf_util.scope_name(), "random_HW", ks[0] * ks[1], up["xyz1_proj"].device)
             w1 = [3 + feat2_proj.shape[-1]] + list(mlp)
             jobs.append(dict(src_xyz=up["xyz2_proj"], src_feat=feat2_proj, idx=None, mask=None,
                              layers=[P('up_1_%d' % j, w1[j], w1[j + 1],
                                        row_order=fused.setconv_row_order(w1[0] - 3) if j == 0 else None)
                                      for j in range(len(mlp))],
-                             xyz1_grid=xyz1_proj, K=up["nsample"],
+                             xyz1_grid=up["xyz1_proj"], K=up["nsample"],
                              group=fused.Grouping(random_HW, ks, up["distance"], up["stride_h"], up["stride_w"])))
+    return jobs
+
+
+def up_conv_predict_finish(up_a, up_b, fp_a, fp_b, up_a_pooled, up_b_pooled):
+    """Stage 2 of both set-upconvs and the two flow predictors they feed, in ONE launch (see up_conv_predict_pair)."""
+    stage2 = []
+    for up, fp, pooled in ((up_a, fp_a, up_a_pooled), (up_b, fp_b, up_b_pooled)):
+        P = fused.packed_layer
+        with tf_util.variable_scope(up["scope"]):
+            feat1_proj, mlp, mlp2 = up["feat1_proj"], up["mlp"], up["mlp2"]
+            B, H, W, _ = up["xyz1_proj"].shape
             points1 = feat1_proj.reshape(B, H * W, -1)
             w2 = [mlp[-1] + points1.shape[-1]] + list(mlp2)
             layers = [P('up_2_%d' % i, w2[i], w2[i + 1]) for i in range(len(mlp2))]
@@ -296,11 +332,24 @@ def up_conv_predict_pair(up_a, up_b, fp_a, fp_b):
             layers2 = [P('conv_predictor%d' % i, wp[i], wp[i + 1], bn=fp.get("bn", True),
                          row_order=fused.stage2_row_order(w_before, mlp2[-1], w_after) if i == 0 else None)
                        for i in range(len(fp["mlp"]))]
-        stage2.append(dict(sources=[None, points1], layers=layers, before=before, after=after, layers2=layers2))
-    (up_a_pooled, _), (up_b_pooled, _) = fused.setconv_pair(jobs[0], jobs[1])
-    stage2[0]["sources"][0], stage2[1]["sources"][0] = up_a_pooled, up_b_pooled
+        stage2.append(dict(sources=[pooled, points1], layers=layers, before=before, after=after, layers2=layers2))
     (out_a, pred_a), (out_b, pred_b) = fused.mlp2_pair(stage2[0], stage2[1])
     return out_a, pred_a, out_b, pred_b
+
+
+def down_conv_job(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distance, mlp, scope, bn=True):
+    """down_conv (fused inference form) as a DEFERRED job: returns (job, finish) where `job` is a fused.setconv keyword dict
+    -- to run on its own or as a `side_jobs` entry of a cost volume that only shares inputs with it -- and
+    finish(out, new_xyz) gives down_conv's return value."""
+    with tf_util.variable_scope(scope):
+        random_HW = random_shuffle(tf_util.scope_name(), "random_HW", kernel_size[0] * kernel_size[1], xyz_proj.device)
+        widths = [3 + points_proj.shape[-1]] + list(mlp)
+        layers = [fused.packed_layer('conv%d' % i, widths[i], widths[i + 1], bn=bn,
+                                     row_order=fused.setconv_row_order(widths[0] - 3) if i == 0 else None)
+                  for i in range(len(mlp))]
+    job = dict(src_xyz=xyz_proj, src_feat=points_proj, idx=None, mask=None, layers=layers, xyz1_grid=xyz_proj,
+               centre_hw=_centre_hw(selected_idx), K=K_sample, group=fused.Grouping(random_HW, kernel_size, distance))
+    return job, lambda out, new_xyz: (out, new_xyz.reshape(selected_idx.shape[:-1] + (3,)))
 
 
 def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distance, mlp, mlp2, flag_add, is_training,

@@ -19,8 +19,8 @@ import torch
 from . import _ops, fused, tf_util
 from .model_util import (PreProcess, ProjectPC2SphericalRing, input_stage, preprocess_gt, get_selected_idx, inv_q, mul_point_q, mul_q_point,
                          softmax_valid, warp_and_project)
-from .pointnet_util import (cost_volume, down_conv, flow_predictor, fused_pairs_available, up_conv,
-                            up_conv_predict_pair)
+from .pointnet_util import (cost_volume, down_conv, down_conv_job, flow_predictor, fused_pairs_available, merge_branches,
+                            up_conv, up_conv_predict_finish, up_conv_stage1_jobs)
 
 Down_conv_dis = [0.5, 3.0, 6.0, 12.0]       # pwclo_model.py:38
 Up_conv_dis = [3.0, 6.0, 9.0]               # :39
@@ -232,13 +232,21 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                                            kernel_size=[5, 9], distance=Down_conv_dis[2], mlp=[32, 32, 64], mlp2=None,
                                            flag_add=False, is_training=is_training, bn_decay=bn_decay, scope='layer2')
         l2_points_proj = l2_points.reshape(batch_size, out_h_list[4], out_w_list[4], -1)
-        l3_points, l3_xyz_proj = down_conv(l2_xyz_proj, l2_points_proj, l3_selected_idx, K_sample=16,
-                                           kernel_size=[5, 9], distance=Down_conv_dis[3], mlp=[64, 64, 128], mlp2=None,
-                                           flag_add=False, is_training=is_training, bn_decay=bn_decay, scope='layer3')
+        if merge_branches(is_training, l2_xyz_proj.shape[0] * l2_xyz_proj.shape[1] * l2_xyz_proj.shape[2]):
+            # inference: the layer-3 set-conv is only needed at the coarse pose (:187-194); it rides on the first launch of
+            # the initial cost volume (:170), which only shares its inputs -- one launch and one serial stage less
+            deferred.append(down_conv_job(l2_xyz_proj, l2_points_proj, l3_selected_idx, K_sample=16, kernel_size=[5, 9],
+                                          distance=Down_conv_dis[3], mlp=[64, 64, 128], scope='layer3'))
+            l3_points = l3_xyz_proj = None
+        else:
+            l3_points, l3_xyz_proj = down_conv(l2_xyz_proj, l2_points_proj, l3_selected_idx, K_sample=16,
+                                               kernel_size=[5, 9], distance=Down_conv_dis[3], mlp=[64, 64, 128], mlp2=None,
+                                               flag_add=False, is_training=is_training, bn_decay=bn_decay, scope='layer3')
         return ([l0_points, l1_points, l2_points, l3_points],
                 [l0_points_proj, l1_points_proj, l2_points_proj, None],
                 [l0_xyz_proj, l1_xyz_proj, l2_xyz_proj, l3_xyz_proj])
 
+    deferred = []                      # (job, finish) of set-convs that wait for a cost-volume launch to ride on
     with tf_util.variable_scope('sa1') as scope:                                                    # :117
         both = _adjacent_frames(xyz_f1_input_proj, xyz_f2_input_proj) if not is_training else None
         if both is not None:
@@ -248,10 +256,11 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                     for i in (2, 3, 4, 5)]
             pts, pts_proj, xyz_proj = feature_pyramid(both, zero_features(both), sel2)
             B = batch_size
-            pts_f1, pts_f2 = [p[:B] for p in pts], [p[B:] for p in pts]
-            pts_proj_f1 = [None if p is None else p[:B] for p in pts_proj]
-            pts_proj_f2 = [None if p is None else p[B:] for p in pts_proj]
-            xyz_proj_f1, xyz_proj_f2 = [x[:B] for x in xyz_proj], [x[B:] for x in xyz_proj]
+            half = lambda t, lo, hi: None if t is None else t[lo:hi]
+            pts_f1, pts_f2 = [half(p, 0, B) for p in pts], [half(p, B, 2 * B) for p in pts]
+            pts_proj_f1 = [half(p, 0, B) for p in pts_proj]
+            pts_proj_f2 = [half(p, B, 2 * B) for p in pts_proj]
+            xyz_proj_f1, xyz_proj_f2 = [half(x, 0, B) for x in xyz_proj], [half(x, B, 2 * B) for x in xyz_proj]
         else:
             sel1 = [l0_selected_idx, l1_selected_idx, l2_selected_idx, l3_selected_idx]
             points_input_proj = zero_features(xyz_f1_input_proj)
@@ -264,7 +273,18 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                                    kernel_size1=[3, 5], kernel_size2=[5, 35], nsample=4, nsample_q=32,
                                    distance=Cost_volume_dis[2], mlp1=[128, 64, 64], mlp2=[128, 64],
                                    is_training=is_training, bn_decay=bn_decay, scope='flow_embedding_l2_origin',
-                                   bn=True, pooling='max', knn=True, corr_func='concat')
+                                   bn=True, pooling='max', knn=True, corr_func='concat',
+                                   side_jobs=[job for job, _ in deferred] or None)
+    if deferred:                                      # the layer-3 set-conv(s) that rode on the cost volume's first launch
+        l2_points_f1_new, side = l2_points_f1_new
+        for f, ((_job, finish), (out, new_xyz)) in enumerate(zip(deferred, side)):
+            l3_points, l3_xyz_proj = finish(out, new_xyz)
+            if len(deferred) == 1 and l3_points.shape[0] == 2 * batch_size:          # the 2B Siamese batch: frame 1 | frame 2
+                pts_f1[3], pts_f2[3] = l3_points[:batch_size], l3_points[batch_size:]
+                xyz_proj_f1[3], xyz_proj_f2[3] = l3_xyz_proj[:batch_size], l3_xyz_proj[batch_size:]
+            else:
+                (pts_f1 if f == 0 else pts_f2)[3] = l3_points
+                (xyz_proj_f1 if f == 0 else xyz_proj_f2)[3] = l3_xyz_proj
     l2_points_new_proj_f1 = l2_points_f1_new.reshape(batch_size, out_h_list[4], out_w_list[4], -1)
     l3_points_f1_cost_volume, _ = down_conv(xyz_proj_f1[2], l2_points_new_proj_f1, l3_selected_idx, K_sample=16,
                                             kernel_size=[5, 9], distance=Down_conv_dis[3], mlp=[128, 64, 64], mlp2=None,
@@ -308,12 +328,12 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
         xyz_warp_f1 = xyz_warp_proj_f1.reshape(batch_size, -1, 3)
         points_warp_f1 = points_warp_proj_f1.reshape(batch_size, out_h_list[g] * out_w_list[g], -1)
 
-        def branch_cost():
+        def branch_cost(side_jobs=None):
             return cost_volume(xyz_warp_proj_f1, xyz_proj_f2[level], points_warp_proj_f1, pts_proj_f2[level],
                                kernel_size1=[3, 5], kernel_size2=cv_kernel2[level], nsample=4, nsample_q=6,
                                distance=Cost_volume_dis[level], mlp1=[128, 64, 64], mlp2=[128, 64],
                                is_training=is_training, bn_decay=bn_decay, scope='flow_embedding_l%d' % level,
-                               bn=True, pooling='max', knn=True, corr_func='concat')                # :242
+                               bn=True, pooling='max', knn=True, corr_func='concat', side_jobs=side_jobs)   # :242
 
         def branch_up(kind, coarse_feat_proj):
             return up_conv(xyz_warp_proj_f1, coarse_xyz_proj, points_warp_proj_f1, coarse_feat_proj,
@@ -325,16 +345,25 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
         if fused_pairs_available(is_training):
             # inference: the embedding / embedding-mask twins of a level run as PAIRED launches (same shapes,
             # different weights): 2 + 1 launches instead of 4 + 2
-            cost = branch_cost()
             up = dict(xyz1_proj=xyz_warp_proj_f1, xyz2_proj=coarse_xyz_proj, feat1_proj=points_warp_proj_f1,
                       kernel_size=[7, 15], stride_h=stride_h_list[g + 1], stride_w=stride_w_list[g + 1], nsample=8,
                       distance=Up_conv_dis[level], mlp=[128, 64], mlp2=[128, 64])
+            up_w = dict(up, feat2_proj=coarse_w_proj, scope='up_sa_layer_layer_l%dw' % level)
+            up_c = dict(up, feat2_proj=coarse_predict_proj, scope='up_sa_layer_layer_l%dcostvolume' % level)
+            # the cost volume and stage 1 of the two set-upconvs only share inputs (:242-250): while the GPU is underfilled
+            # ONE launch runs cost-volume stage 1 and both set-conv jobs (both branches in flight together, one launch
+            # boundary less); a full GPU takes them as two launches
+            jobs = up_conv_stage1_jobs(up_w, up_c)
+            if merge_branches(is_training, batch_size * out_h_list[g] * out_w_list[g]):
+                cost, ((up_w_pooled, _), (up_c_pooled, _)) = branch_cost(side_jobs=jobs)
+            else:
+                cost = branch_cost()
+                (up_w_pooled, _), (up_c_pooled, _) = fused.setconv_pair(jobs[0], jobs[1])
             fp = dict(points_f1=points_warp_f1, cost_volume=cost, mlp=[128, 64])
-            # set-upconv stage 2 and the predictor it feeds share a launch: 2 instead of 3 launches for the four calls
-            w_up_sample, weight, cost_up_sample, predict = up_conv_predict_pair(
-                dict(up, feat2_proj=coarse_w_proj, scope='up_sa_layer_layer_l%dw' % level),
-                dict(up, feat2_proj=coarse_predict_proj, scope='up_sa_layer_layer_l%dcostvolume' % level),
-                dict(fp, scope='l%d_w_predict' % level), dict(fp, scope='l%d_costvolume_predict' % level))
+            # set-upconv stage 2 and the predictor it feeds share a launch
+            w_up_sample, weight, cost_up_sample, predict = up_conv_predict_finish(
+                up_w, up_c, dict(fp, scope='l%d_w_predict' % level), dict(fp, scope='l%d_costvolume_predict' % level),
+                up_w_pooled, up_c_pooled)
         else:
             # the cost volume and the two set-upconvs only share inputs: optional concurrent branches
             cost, w_up_sample, cost_up_sample = _parallel([branch_cost, lambda: branch_up('w', coarse_w_proj),

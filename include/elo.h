@@ -538,6 +538,12 @@ typedef struct elo_cv1_args {
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
 } elo_cv1_args;
 int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream);
+/* elo_cv_stage1_fused AND one or two set-conv jobs (elo_setconv_fused / elo_setconv_fused2 semantics, tile-kernel form;
+ * jb may be NULL) in ONE launch: the first workgroups of the grid run cost-volume tiles, the rest set-conv tiles.
+ * For branches that only share inputs -- the cost volume and the two set-upconvs of a refinement level
+ * (pwclo_model.py:242-250), the initial cost volume and the layer-3 set-conv of the pyramid (:138, :170) -- so that a
+ * small-batch forward pays one launch boundary and keeps both branches in flight together.  Same results bit for bit. */
+int elo_cv_stage1_setconv_fused(const elo_cv1_args *a, const elo_setconv_args *ja, const elo_setconv_args *jb, elo_stream_t stream);
 
 /* Attentive cost volume, stage 2 (utils/pointnet_util.py:104-146) in one launch.
  * sum_cost0 expects input rows ordered [cost[idx]*m (64), xyz-encoding (64), feat1 (C)]

@@ -425,3 +425,34 @@ def test_input_stage_edges():
     # all-zero clouds: every cell stays empty
     pts, proj = mu.input_stage(torch.zeros((2, 200, 3), device=DEV), None, None, 16, 64)
     assert not pts.any() and not proj.any()
+
+
+@pytest.mark.parametrize("B,two", [(1, True), (2, False), (8, True)])
+def test_heterogeneous_launch_equals_separate_launches(B, two):
+    """elo_cv_stage1_setconv_fused: cost-volume stage 1 and one / two set-conv jobs in ONE grid give the bits of the
+    separate launches (every tile-height combination the launcher picks by size)."""
+    fused, tf_util, synth = load_pkg("fused"), load_pkg("tf_util"), load_pkg("synth")
+    rng = np.random.default_rng(40 + B)
+    H, W, C = 8, 113, 32
+    f1, f2 = synth.frame_pair(B, H, W, seed=61)
+    fa, fb = (t(rng.normal(0, 1, (B, H, W, C)).astype(np.float32)) for _ in range(2))
+    sparse = np.ascontiguousarray(f1[:, ::2, ::2])
+    sf = [t(rng.normal(0, 1, sparse.shape[:3] + (64,)).astype(np.float32)) for _ in range(2)]
+    store = tf_util.VariableStore(DEV, seed=B)
+    with tf_util.default_store(store), torch.no_grad():
+        P = fused.packed_layer
+        layers = (P("c0", 10 + 2 * C, 128, row_order=fused.cv0_row_order(C)), P("c1", 128, 64), P("c2", 64, 64), P("cx", 10, 64),
+                  P("s0", 128, 128), P("s1", 128, 64))
+        perm_q, perm_u = t(rng.permutation(175).astype(np.int32)), t(rng.permutation(105).astype(np.int32))
+        cv = lambda side=None: fused.cv_stage1(t(f1).reshape(B, H * W, 3), fa.reshape(B, H * W, C), t(f2), fb, None, None, *layers,
+                                               group=fused.Grouping(perm_q, [7, 25], 1000), K=6, side=side)
+        jobs = [dict(src_xyz=t(sparse), src_feat=sf[i], idx=None, mask=None,
+                     layers=[P("u%d0" % i, 67, 128, row_order=fused.setconv_row_order(64)), P("u%d1" % i, 128, 64)],
+                     xyz1_grid=t(f1), K=8, group=fused.Grouping(perm_u, [7, 15], 6.0, 2, 2)) for i in range(2 if two else 1)]
+        want_cv = cv()
+        want_side = [fused.setconv(**j) for j in jobs]
+        got_cv, got_side = cv(side=jobs)
+    torch.cuda.synchronize()
+    assert torch.equal(got_cv, want_cv)
+    for (g, gx), (w_, wx) in zip(got_side, want_side):
+        assert torch.equal(g, w_) and gx is None and wx is None
