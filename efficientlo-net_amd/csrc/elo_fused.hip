@@ -66,18 +66,45 @@ __device__ __forceinline__ float4 weight_load(__amdgpu_buffer_rsrc_t rsrc, unsig
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, 0));
 }
 
-// A lane's share of one 16-k x 16-n block of W: 16 bytes [4 halves hi | 4 halves lo] (split modes), or the 8
-// bytes of four round-to-nearest halves (MODE_HALF).  BLOCK_BYTES is the wave's contiguous load.
-template <int MODE> struct WFrag { typedef float4 type; static constexpr int LANE_BYTES = 16, BLOCK_BYTES = 1024; };
+// W is packed per column block in K-PAIRS of 32 k (for v_mfma_f32_16x16x32_f16: the gfx950 instruction that does 8192
+// multiply-adds in the 16 cycles v_mfma_f32_16x16x16_f16 needs for 4096) plus, for an odd number of 16-k blocks, one
+// 16-k TAIL:   per (cb):  [pair 0 | pair 1 | ... | tail],  KS * BLOCK_BYTES bytes in all (KS = 16-k blocks of the layer)
+//   pair (split modes):  2 KiB = [hi8 of every lane (1 KiB) | lo8 of every lane (1 KiB)], a lane's eight halves being
+//                        W[32p + 4kq + j][col] for j = 0..3 followed by W[32p + 16 + 4kq + j][col]  (kq = lane >> 4,
+//                        col = cb*16 + (lane & 15)) -- the k order in which the activation operand is assembled from the
+//                        two quads of the pair, so that no LDS layout changes
+//   tail (split modes):  1 KiB, a lane's 16 bytes = [hi4 | lo4] of W[16(KS-1) + 4kq + j][col]
+//   MODE_HALF:           the same with the round-to-nearest halves only: pair 1 KiB (16 bytes per lane), tail 512 B (8 bytes)
+//   ELO_DENSE_F32:       fp32 weights, a "pair" is simply two consecutive 16-k blocks of four floats per lane
+template <int MODE> struct WFrag { static constexpr int BLOCK_BYTES = 1024; };
 #ifndef ELO_DENSE_F32
-template <> struct WFrag<MODE_HALF> { typedef float2 type; static constexpr int LANE_BYTES = 8, BLOCK_BYTES = 512; };
+template <> struct WFrag<MODE_HALF> { static constexpr int BLOCK_BYTES = 512; };
 #endif
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+struct WPair { uint4 hi, lo; };                    // a lane's registers for one pair (MODE_HALF uses .hi only)
+struct ActPair { uint4 hi, lo; };                  // the matching activation operand
+
 template <int MODE>
-__device__ __forceinline__ typename WFrag<MODE>::type frag_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, int byte_off)
+__device__ __forceinline__ WPair pair_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane, int byte_off)
 {
-    if constexpr (MODE == MODE_HALF) return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_off, byte_off, 0));
-    else return weight_load(rsrc, lane_off, byte_off);
+    WPair w;
+    w.hi = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u, byte_off, 0));
+    if constexpr (MODE == MODE_HALF) w.lo = uint4{0u, 0u, 0u, 0u};
+    else w.lo = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u, byte_off + 1024, 0));
+    return w;
+}
+
+// the tail's fragment, in .x/.y (MODE_HALF: four halves) or all four words (split: [hi4 | lo4]; fp32: four floats)
+template <int MODE>
+__device__ __forceinline__ uint4 tail_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane, int byte_off)
+{
+    if constexpr (MODE == MODE_HALF) {
+        const uint2 v = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8u, byte_off, 0));
+        return uint4{v.x, v.y, 0u, 0u};
+    } else {
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u, byte_off, 0));
+    }
 }
 
 // ---- the tile's element format ------------------------------------------------------------------------------------
@@ -193,43 +220,87 @@ __device__ __forceinline__ void feat_store4(void *p, long i, const float4 v, int
     }
 }
 
-// ---- one 16-k block of MAXT column blocks, transposed: acc[t] += W_t^T(16 n x 16 k) * A^T(16 k x 16 rows) ----------
-// operand layouts of v_mfma_f32_16x16x16_f16 (lane = i16 + 16*kq): A[m = i16][k = 4kq..4kq+3], B[k = 4kq..4kq+3][n = i16],
-// D[m = 4kq + r][n = i16] in acc[r].  With A := the W fragment (m = output channel) and B := the activation quad
-// (n = tile row), a lane holds channels cb*16 + 4kq + 0..3 of row i16.
+// ---- matrix-core steps, transposed: acc[t] += W_t^T(16 n x k) * A^T(k x 16 rows) ------------------------------------
+// operand layouts (lane = i16 + 16*kq): A[m = i16][k-group kq], B[k-group kq][n = i16], D[m = 4kq + r][n = i16] in acc[r].
+// With A := the W fragment (m = output channel) and B := the activation (n = tile row) a lane holds channels
+// cb*16 + 4kq + 0..3 of row i16.  A PAIR is 32 k on v_mfma_f32_16x16x32_f16 (k-group = the eight halves described at
+// WFrag), a TAIL 16 k on v_mfma_f32_16x16x16_f16; fp32-class = hi*hi + lo*hi + hi*lo.
+
+// activation operand of pair p of the row `arow` points at (arow = act + row*S + in_off + 4*kq): the quads of its two
+// 16-k blocks are 16 words apart; hi4 of each are words 0-1, lo4 words 2-3
+__device__ __forceinline__ ActPair act_pair(const float *p)
+{
+#ifdef ELO_DENSE_F32
+    return ActPair{*reinterpret_cast<const uint4 *>(p), *reinterpret_cast<const uint4 *>(p + 16)};
+#else
+    const uint2 h0 = *reinterpret_cast<const uint2 *>(p), h1 = *reinterpret_cast<const uint2 *>(p + 16);
+    const uint2 l0 = *reinterpret_cast<const uint2 *>(p + 2), l1 = *reinterpret_cast<const uint2 *>(p + 18);
+    return ActPair{uint4{h0.x, h0.y, h1.x, h1.y}, uint4{l0.x, l0.y, l1.x, l1.y}};
+#endif
+}
+
 template <int MODE, int MAXT>
-__device__ __forceinline__ void mma_block(f32x4 (&acc)[MAXT], const uint4 a, const typename WFrag<MODE>::type (&w)[MAXT])
+__device__ __forceinline__ void mma_pair(f32x4 (&acc)[MAXT], const ActPair a, const WPair (&w)[MAXT])
+{
+#ifdef ELO_DENSE_F32
+    const float4 x0 = __builtin_bit_cast(float4, a.hi), x1 = __builtin_bit_cast(float4, a.lo);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float4 x = h ? x1 : x0;
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const float4 wv = __builtin_bit_cast(float4, h ? w[t].lo : w[t].hi);
+                const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[j], xs[j], acc[t], 0, 0, 0);
+            }
+    }
+#else
+    const half8 ahi = __builtin_bit_cast(half8, a.hi);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w[t].hi), ahi, acc[t], 0, 0, 0);
+    if constexpr (MODE != MODE_HALF) {
+        const half8 alo = __builtin_bit_cast(half8, a.lo);
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w[t].lo), ahi, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w[t].hi), alo, acc[t], 0, 0, 0);
+    }
+#endif
+}
+
+template <int MODE, int MAXT>
+__device__ __forceinline__ void mma_tail(f32x4 (&acc)[MAXT], const uint4 a, const uint4 (&w)[MAXT])
 {
 #ifdef ELO_DENSE_F32
     const float4 x = __builtin_bit_cast(float4, a);
+    const float xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].x, x.x, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].y, x.y, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].z, x.z, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].w, x.w, acc[t], 0, 0, 0);
-#else
-    const half4 ahi = __builtin_bit_cast(half4, uint2{a.x, a.y});
-    if constexpr (MODE == MODE_HALF) {
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, w[t]), ahi, acc[t], 0, 0, 0);
-    } else {
-        const half4 alo = __builtin_bit_cast(half4, uint2{a.z, a.w});
-        half4 bhi[MAXT], blo[MAXT];
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
-            bhi[t] = __builtin_bit_cast(half4, float2{w[t].x, w[t].y});
-            blo[t] = __builtin_bit_cast(half4, float2{w[t].z, w[t].w});
+            const float4 wv = __builtin_bit_cast(float4, w[t]);
+            const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[j], xs[j], acc[t], 0, 0, 0);
         }
+#else
+    const half4 ahi = __builtin_bit_cast(half4, uint2{a.x, a.y});
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(bhi[t], ahi, acc[t], 0, 0, 0);
+    for (int t = 0; t < MAXT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, uint2{w[t].x, w[t].y}), ahi, acc[t], 0, 0, 0);
+    if constexpr (MODE != MODE_HALF) {
+        const half4 alo = __builtin_bit_cast(half4, uint2{a.z, a.w});
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(blo[t], ahi, acc[t], 0, 0, 0);
+        for (int t = 0; t < MAXT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, uint2{w[t].z, w[t].w}), ahi, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(bhi[t], alo, acc[t], 0, 0, 0);
+        for (int t = 0; t < MAXT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, uint2{w[t].x, w[t].y}), alo, acc[t], 0, 0, 0);
     }
 #endif
 }
@@ -283,195 +354,150 @@ __device__ __forceinline__ void store_quad(float *act, int S, int row, int col, 
 
 // ---- one dense layer on the block's tile ---------------------------------------------------
 // D[TILE x Np] = relu?(A[TILE x Kp] * W + bias).  The tile is cut into 16x16 output sub-tiles; wave w owns row block
-// (w % RB) and every (4/RB)-th column block, keeps its <= 4 accumulators in registers over the whole K loop, and
-// streams its columns of W from L2 in packed fragment order (one contiguous 1 KiB load per wave-instruction,
-// prefetched one step ahead):
-//     w_packed[((cb*KS + ks)*64 + lane)*4 + s] = W[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)]
-// A comes from LDS, one 16-byte quad per lane per 16 k's.  Layers run IN PLACE on the tile: barrier after the
-// K loop (every wave has finished reading A), write D, barrier.
-template <int TILE, int MAXT, int MODE>
-__device__ __forceinline__ void dense_t(float *act, int S, int in_off, const elo_dense &L, const LayerOut &out, unsigned &violations)
+// (w % RB) and every (4/RB)-th column block: TPW = 1, 2 or 4 sub-tiles per wave, all accumulators in registers, worked
+// through in PASSES of at most two sub-tiles (the W registers of a 32-k pair are 8 per sub-tile; the A operand is
+// re-read from LDS per pass).  W streams from L2 in packed order (see WFrag), one pair ahead in a second register set;
+// loads are UNCONDITIONAL (indices clamped into the packed array): with per-lane predicates around them the compiler
+// loses track of the outstanding loads and waits vmcnt(0) before every MFMA group.  Layers run IN PLACE on the tile:
+// barrier after the K loops (every wave has finished reading A), write D, barrier.
+//
+// The cost-volume chains have fixed widths, so there the FIRST step of the next layer (its first pair, or its tail when
+// the layer has a single 16-k block) and its bias are fetched into registers (`Pre`) while this layer's epilogue runs:
+// a layer does not start with an exposed L2 round trip.
+template <int TPW>
+struct Pre {
+    static constexpr int MT = TPW < 2 ? TPW : 2;
+    WPair w[MT];                 // pass 0's first step: pair 0, or (KS == 1) the tail in .hi
+    float4 b[TPW];
+};
+
+template <int TILE, int N>
+struct Sub {                                          // sub-tiles per wave of a width-N layer: 1, 2 or 4
+    static constexpr int CSTEP = FUSED_WAVES / (TILE / 16);
+    static constexpr int RAW = ((N + 15) / 16 + CSTEP - 1) / CSTEP;
+    static constexpr int TPW = RAW <= 1 ? 1 : RAW <= 2 ? 2 : 4;
+};
+
+template <int TILE, int TPW, int MODE>
+__device__ __forceinline__ void prefetch(const elo_dense &L, Pre<TPW> &pre)
 {
-    typedef typename WFrag<MODE>::type W_t;
+    constexpr int RB = TILE / 16, CSTEP = FUSED_WAVES / RB, MT = Pre<TPW>::MT;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kq = lane >> 4, cb0 = wave / RB;
+    const int KS = ceil16(L.K) >> 4, CB = ceil16(L.N) >> 4;
+    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+        pre.b[t] = *reinterpret_cast<const float4 *>(L.bias + min(cb0 + t * CSTEP, CB - 1) * 16 + 4 * kq);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int base = min(cb0 + t * CSTEP, CB - 1) * KS * WFrag<MODE>::BLOCK_BYTES;
+        if (KS >= 2) pre.w[t] = pair_load<MODE>(wrsrc, lane, base);
+        else { pre.w[t].hi = tail_load<MODE>(wrsrc, lane, base); pre.w[t].lo = uint4{0u, 0u, 0u, 0u}; }
+    }
+}
+
+template <int TILE, int TPW, int MODE, bool HAS_PRE, int NEXT_TPW>
+__device__ __forceinline__ void dense_impl(float *act, int S, int in_off, const elo_dense &L, const LayerOut &out,
+                                           unsigned &violations, const Pre<TPW> *pre, const elo_dense *next, Pre<(NEXT_TPW ? NEXT_TPW : 1)> *next_pre)
+{
     constexpr int RB = TILE / 16;                 // row blocks: 1 or 2
     constexpr int CSTEP = FUSED_WAVES / RB;       // column-block stride between a wave's sub-tiles
-    // 16-k blocks per prefetch group (register budget: 2*GS*MAXT float4).  Half of what it was before the MFMAs moved to
-    // the fp16 cores: the two W buffers were most of the 96 VGPRs; at 64-67 the kernels run 7 waves per SIMD, which hides
-    // more than the deeper prefetch did (+5 % at 8 lanes, +12 % at batch 8, -1 % at one lane).
-    constexpr int GS = MAXT >= 4 ? 1 : 2;
+    constexpr int MT = TPW < 2 ? TPW : 2, PASSES = TPW / MT;
     // the wave index as a SCALAR: row block, column blocks and with them every W / bias base address live in SGPRs,
-    // so a W fragment load is `buffer_load_dwordx4 v, v_lane_off, s[rsrc], s_off` with no vector address arithmetic
+    // so a W load is `buffer_load_dwordx4 v, v_lane_off, s[rsrc], s_off` with no vector address arithmetic
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     const int rb = wave % RB, cb0 = wave / RB;
     const int KS = ceil16(L.K) >> 4, CB = ceil16(L.N) >> 4;
-    const int NG = (KS + GS - 1) / GS;
-    f32x4 acc[MAXT];
+    const int NP = KS >> 1;                        // 32-k pairs; KS & 1: a 16-k tail
+    const bool tail = KS & 1;
+    constexpr int BB = WFrag<MODE>::BLOCK_BYTES;
+    f32x4 acc[TPW];
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        const float4 bv = *reinterpret_cast<const float4 *>(L.bias + min(cb0 + t * CSTEP, CB - 1) * 16 + 4 * kq);
+    for (int t = 0; t < TPW; ++t) {
+        const float4 bv = HAS_PRE ? pre->b[t] : *reinterpret_cast<const float4 *>(L.bias + min(cb0 + t * CSTEP, CB - 1) * 16 + 4 * kq);
         acc[t] = f32x4{bv.x, bv.y, bv.z, bv.w};
     }
     const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
     const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);      // buffer addressing: V# + lane offset + scalar offset
-    const unsigned lane_off = (unsigned)lane * WFrag<MODE>::LANE_BYTES;
-
-    // W is streamed from L2 with a load-to-use distance of one whole group of K steps (two register sets).
-    // Loads are UNCONDITIONAL (indices clamped into the packed array): with per-lane predicates around them the
-    // compiler loses track of the outstanding loads and waits vmcnt(0) before every MFMA group, which serialises
-    // "prefetch" and compute (measured: 6.5 us for a 128x128 layer whose MFMAs take 1.7 us).  Clamped duplicates are
-    // never used: steps past KS are skipped by a scalar branch, sub-tiles past CB are computed but not stored.
-    auto fetch = [&](int g, W_t (&buf)[GS][MAXT]) {
 #pragma unroll
-        for (int s = 0; s < GS; ++s) {
-            const int ks = min(g * GS + s, KS - 1);
+    for (int pass = 0; pass < PASSES; ++pass) {
+        int base[MT];                                                  // byte offset of each sub-tile's column block
 #pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const int cb = min(cb0 + t * CSTEP, CB - 1);
-                buf[s][t] = frag_load<MODE>(wrsrc, lane_off, (cb * KS + ks) * WFrag<MODE>::BLOCK_BYTES);
-            }
+        for (int t = 0; t < MT; ++t) base[t] = min(cb0 + (pass * MT + t) * CSTEP, CB - 1) * KS * BB;
+        auto fetch = [&](int p, WPair (&buf)[MT]) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) buf[t] = pair_load<MODE>(wrsrc, lane, base[t] + min(p, NP - 1) * 2 * BB);
+        };
+        f32x4 (&pa)[MT] = *reinterpret_cast<f32x4 (*)[MT]>(&acc[pass * MT]);
+        WPair b0[MT], b1[MT];
+        const bool from_pre = HAS_PRE && pass == 0;
+        // the tail's fragment travels in the .hi of whichever register set the pair loop has released
+        auto fetch_tail = [&](WPair (&buf)[MT]) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) buf[t].hi = tail_load<MODE>(wrsrc, lane, base[t] + (KS - 1) * BB);
+        };
+        auto tail_step = [&](const WPair (&buf)[MT]) {
+            uint4 wt[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) wt[t] = buf[t].hi;
+            mma_tail<MODE, MT>(pa, *reinterpret_cast<const uint4 *>(arow + (KS - 1) * 16), wt);
+        };
+        if (from_pre) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) b0[t] = pre->w[t];                  // pair 0, or (NP == 0) the tail in .hi
+        } else if (NP > 0) {
+            fetch(0, b0);
+        } else {
+            fetch_tail(b0);
         }
-    };
-    auto compute = [&](int g, const W_t (&buf)[GS][MAXT]) {
-        uint4 a[GS];
-#pragma unroll
-        for (int s = 0; s < GS; ++s) a[s] = *reinterpret_cast<const uint4 *>(arow + min(g * GS + s, KS - 1) * 16);
-#pragma unroll
-        for (int s = 0; s < GS; ++s) {
-            if (g * GS + s >= KS) break;
-            mma_block<MODE, MAXT>(acc, a[s], buf[s]);
+        int p = 0;
+        for (; p + 1 < NP; p += 2) {                                         // two pairs per trip: b0, then b1
+            fetch(p + 1, b1);
+            mma_pair<MODE, MT>(pa, act_pair(arow + p * 32), b0);
+            if (p + 2 < NP) fetch(p + 2, b0);
+            else if (tail) fetch_tail(b0);
+            mma_pair<MODE, MT>(pa, act_pair(arow + (p + 1) * 32), b1);
         }
-    };
-    W_t b0[GS][MAXT], b1[GS][MAXT];
-    fetch(0, b0);
-    for (int g = 0; g < NG; g += 2) {
-        if (g + 1 < NG) fetch(g + 1, b1);
-        compute(g, b0);
-        if (g + 1 < NG) {
-            if (g + 2 < NG) fetch(g + 2, b0);
-            compute(g + 1, b1);
+        if (p < NP) {                                                        // an odd number of pairs: the last one sits in b0
+            if (tail) fetch_tail(b1);
+            mma_pair<MODE, MT>(pa, act_pair(arow + p * 32), b0);
+            if (tail) tail_step(b1);
+        } else if (tail) {
+            tail_step(b0);
         }
     }
+    if (NEXT_TPW) prefetch<TILE, NEXT_TPW ? NEXT_TPW : 1, MODE>(*next, *next_pre);       // rides behind the two barriers
     __syncthreads();                               // all A reads done: the tile may be overwritten
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
+    for (int t = 0; t < TPW; ++t) {
         const int cb = cb0 + t * CSTEP;
         if (cb < CB) store_quad<MODE>(act, S, rb * 16 + i16, cb * 16 + 4 * kq, L.N, acc[t], L.relu, out, violations);
     }
     __syncthreads();
 }
 
+// runtime width (set-conv, row-wise MLP)
 template <int TILE, int MODE>
 __device__ __forceinline__ void dense(float *act, int S, int in_off, const elo_dense &L, const LayerOut &out, unsigned &violations)
 {
     constexpr int CSTEP = FUSED_WAVES / (TILE / 16);
     const int per_wave = ((ceil16(L.N) >> 4) + CSTEP - 1) / CSTEP;      // sub-tiles per wave, <= 4 for N <= 128
-    if (per_wave <= 1) dense_t<TILE, 1, MODE>(act, S, in_off, L, out, violations);
-    else if (per_wave <= 2) dense_t<TILE, 2, MODE>(act, S, in_off, L, out, violations);
-    else dense_t<TILE, 4, MODE>(act, S, in_off, L, out, violations);
+    Pre<1> *none = nullptr;
+    if (per_wave <= 1) dense_impl<TILE, 1, MODE, false, 0>(act, S, in_off, L, out, violations, (const Pre<1> *)nullptr, nullptr, none);
+    else if (per_wave <= 2) dense_impl<TILE, 2, MODE, false, 0>(act, S, in_off, L, out, violations, (const Pre<2> *)nullptr, nullptr, none);
+    else dense_impl<TILE, 4, MODE, false, 0>(act, S, in_off, L, out, violations, (const Pre<4> *)nullptr, nullptr, none);
 }
 
-// ---- the same layer with compile-time widths and a cross-layer prefetch (cost-volume kernels) -------------
-// The cost-volume chains have fixed widths (128/64), so the number of sub-tiles per wave is a compile-time
-// constant and the FIRST weight group + bias of the next layer can be fetched into registers while this layer's
-// epilogue (two barriers + the D write) runs: a layer no longer starts with an exposed L2 round trip.
-template <int TILE, int N>
-struct Sub {                                          // sub-tiles per wave, K steps per prefetch group
-    static constexpr int CSTEP = FUSED_WAVES / (TILE / 16);
-    static constexpr int MAXT = ((N + 15) / 16 + CSTEP - 1) / CSTEP;
-    static constexpr int GS = MAXT >= 4 ? 1 : 2;
-};
-
-template <int TILE, int N, int MODE>
-struct Pre {
-    typename WFrag<MODE>::type w[Sub<TILE, N>::GS][Sub<TILE, N>::MAXT];
-    float4 b[Sub<TILE, N>::MAXT];
-};
-
-template <int TILE, int N, int MODE>
-__device__ __forceinline__ void prefetch(const elo_dense &L, Pre<TILE, N, MODE> &pre)
-{
-    constexpr int RB = TILE / 16, CSTEP = Sub<TILE, N>::CSTEP, MAXT = Sub<TILE, N>::MAXT, GS = Sub<TILE, N>::GS;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kq = lane >> 4, cb0 = wave / RB;
-    const int KS = ceil16(L.K) >> 4;
-    constexpr int CB = (N + 15) / 16;
-    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);      // buffer addressing: V# + lane offset + scalar offset
-    const unsigned lane_off = (unsigned)lane * WFrag<MODE>::LANE_BYTES;
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        const int cb = cb0 + t * CSTEP;
-        const int cbc = min(cb, CB - 1);
-        pre.b[t] = *reinterpret_cast<const float4 *>(L.bias + cbc * 16 + 4 * kq);
-#pragma unroll
-        for (int s = 0; s < GS; ++s)
-            pre.w[s][t] = frag_load<MODE>(wrsrc, lane_off, (cbc * KS + min(s, KS - 1)) * WFrag<MODE>::BLOCK_BYTES);
-    }
-}
-
-// layer with width N; NEXT = width of the following layer (0 = none)
+// compile-time width N with the cross-layer prefetch; NEXT = width of the following layer (0 = none)
 template <int TILE, int N, int NEXT, int MODE>
 __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, const LayerOut &out, const elo_dense &L,
-                                         const Pre<TILE, N, MODE> &pre, const elo_dense *next,
-                                         Pre<TILE, NEXT ? NEXT : 16, MODE> *next_pre, unsigned &violations)
+                                         const Pre<Sub<TILE, N>::TPW> &pre, const elo_dense *next,
+                                         Pre<(NEXT ? Sub<TILE, NEXT ? NEXT : 16>::TPW : 1)> *next_pre, unsigned &violations)
 {
-    typedef typename WFrag<MODE>::type W_t;
-    constexpr int RB = TILE / 16, CSTEP = Sub<TILE, N>::CSTEP, MAXT = Sub<TILE, N>::MAXT, GS = Sub<TILE, N>::GS;
-    constexpr int CB = (N + 15) / 16;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i16 = lane & 15, kq = lane >> 4;
-    const int rb = wave % RB, cb0 = wave / RB;
-    const int KS = ceil16(L.K) >> 4;
-    const int NG = (KS + GS - 1) / GS;
-    f32x4 acc[MAXT];
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = f32x4{pre.b[t].x, pre.b[t].y, pre.b[t].z, pre.b[t].w};
-    const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
-    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);      // buffer addressing: V# + lane offset + scalar offset
-    const unsigned lane_off = (unsigned)lane * WFrag<MODE>::LANE_BYTES;
-    // Loads are UNCONDITIONAL (indices clamped into the packed array), see dense_t
-    auto fetch = [&](int g, W_t (&buf)[GS][MAXT]) {
-#pragma unroll
-        for (int s = 0; s < GS; ++s) {
-            const int ks = min(g * GS + s, KS - 1);
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const int cb = min(cb0 + t * CSTEP, CB - 1);
-                buf[s][t] = frag_load<MODE>(wrsrc, lane_off, (cb * KS + ks) * WFrag<MODE>::BLOCK_BYTES);
-            }
-        }
-    };
-    auto compute = [&](int g, const W_t (&buf)[GS][MAXT]) {
-        uint4 a[GS];
-#pragma unroll
-        for (int s = 0; s < GS; ++s) a[s] = *reinterpret_cast<const uint4 *>(arow + min(g * GS + s, KS - 1) * 16);
-#pragma unroll
-        for (int s = 0; s < GS; ++s) {
-            if (g * GS + s >= KS) break;
-            mma_block<MODE, MAXT>(acc, a[s], buf[s]);
-        }
-    };
-    W_t b0[GS][MAXT], b1[GS][MAXT];
-#pragma unroll
-    for (int s = 0; s < GS; ++s)
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) b0[s][t] = pre.w[s][t];                // group 0 arrived ahead of time
-    for (int g = 0; g < NG; g += 2) {
-        if (g + 1 < NG) fetch(g + 1, b1);
-        compute(g, b0);
-        if (g + 1 < NG) {
-            if (g + 2 < NG) fetch(g + 2, b0);
-            compute(g + 1, b1);
-        }
-    }
-    if (NEXT) prefetch<TILE, NEXT ? NEXT : 16, MODE>(*next, *next_pre);              // rides behind the two barriers
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        const int cb = cb0 + t * CSTEP;
-        if (cb < CB) store_quad<MODE>(act, S, rb * 16 + i16, cb * 16 + 4 * kq, N, acc[t], L.relu, out, violations);
-    }
-    __syncthreads();
+    dense_impl<TILE, Sub<TILE, N>::TPW, MODE, true, NEXT ? Sub<TILE, NEXT ? NEXT : 16>::TPW : 0>(
+        act, S, in_off, L, out, violations, &pre, next, next_pre);
 }
 
 // ---- per-row gather metadata of a tile -------------------------------------------------------
@@ -825,7 +851,7 @@ __device__ __forceinline__ void setconv_tile(const elo_setconv_args &a, const in
 }
 
 template <int TILE, int MODE>
-__global__ __launch_bounds__(FUSED_BLOCK, 5) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK, 6) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
 {
     extern __shared__ float lds[];
     setconv_tile<TILE, MODE>(jobs.job[blockIdx.y], S, lds, blockIdx.x, gridDim.x);
@@ -990,7 +1016,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
 // stage 1: columns [0, w0 + w1 + w2) = the sources; its last layer writes `out` to HBM straight from the accumulators
 // and, with a second stage, to columns [0, N) of the tile; stage 2: [out (N) | before | after] -> layers2 -> out2.
 template <int TILE, int MODE>
-__global__ __launch_bounds__(FUSED_BLOCK, 5) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK, 6) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
 {
     const elo_mlp_args &a = jobs.job[blockIdx.y];
     extern __shared__ float lds[];
@@ -1110,9 +1136,9 @@ __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, flo
         if (grow) geo_store<MODE>(act, tid * S + G, gr, meta.mask[tid], gcell >= 0, bad);           // columns [G, G+16)
         zero_cols<TILE, MODE>(act, S, G + 16, F + cv1_feat_cols(C));
     }
-    Pre<TILE, 128, MODE> p128;
-    Pre<TILE, 64, MODE> p64;
-    prefetch<TILE, 128, MODE>(a.cv0, p128);           // in flight while the barrier drains the gather
+    Pre<Sub<TILE, 128>::TPW> p128;
+    Pre<Sub<TILE, 64>::TPW> p64;
+    prefetch<TILE, Sub<TILE, 128>::TPW, MODE>(a.cv0, p128);           // in flight while the barrier drains the gather
     __syncthreads();
 #if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 2
     if (tid == 0) feat_store(a.out, first_point * 64, act[F] + p128.b[0].x, f16);
@@ -1168,7 +1194,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_setconv_kernel(const elo_c
 // LDS columns: [0,64) grouped cost, [64,128) xyz-encoding, [128,128+C) feat1, [192,208) xyz_cat;
 // sum_cost0 reads [0,128+C) and writes [64,192); sum_cost1 maps [64,192) -> [64,128).
 template <int TILE, int MODE>
-__global__ __launch_bounds__(FUSED_BLOCK, 5) void cv2_kernel(const elo_cv2_args a, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK, 6) void cv2_kernel(const elo_cv2_args a, const int S)
 {
     extern __shared__ float lds[];
     float *act = lds;
@@ -1203,9 +1229,9 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv2_kernel(const elo_cv2_args 
         zero_cols<TILE, MODE>(act, S, 128 + C, 128 + Cp);
         if (grow) geo_store<MODE>(act, tid * S + XYZ, gr, meta.mask[tid], gcell >= 0, bad);   // 10-channel geometry + 6 zeros  :111-120
     }
-    Pre<TILE, 128, MODE> p128;
-    Pre<TILE, 64, MODE> p64;
-    prefetch<TILE, 64, MODE>(a.xyz_enc, p64);
+    Pre<Sub<TILE, 128>::TPW> p128;
+    Pre<Sub<TILE, 64>::TPW> p64;
+    prefetch<TILE, Sub<TILE, 64>::TPW, MODE>(a.xyz_enc, p64);
     __syncthreads();
     dense_pf<TILE, 64, 128, MODE>(act, S, XYZ, to_tile(64), a.xyz_enc, p64, &a.sum_cost0, &p128, bad);   // -> enc at [64,128)       :123-126
     dense_pf<TILE, 128, 64, MODE>(act, S, 0, to_tile(64), a.sum_cost0, p128, &a.sum_cost1, &p64, bad);   // [grouped | enc | feat1] -> [64,192)   :129-135

@@ -83,10 +83,12 @@ def _features(*ts):
 
 
 class PackedDense:
-    """One inference layer y = act(x @ W + b) with BN folded, packed in MFMA B-fragment order.  Each weight is split
-    into fp16 hi + lo (w = hi + lo to 2^-22 relative) for the three-product fp16 MFMA scheme of elo_fused.hip; a lane's
-    16 bytes of a 16-k x 16-n block are [hi k0..k3 | lo k0..k3].  With `half` the lane holds the four weights rounded
-    to fp16 (8 bytes) for the single-product mode."""
+    """One inference layer y = act(x @ W + b) with BN folded, packed in MFMA fragment order (include/elo.h, csrc/elo_fused.hip
+    WFrag).  Each weight is split into fp16 hi + lo (w = hi + lo to 2^-22 relative) for the three-product scheme.  Per
+    column block the K axis is laid out as PAIRS of 32 k -- a lane's eight halves are W[32p + 4kq + j] (j = 0..3) followed
+    by W[32p + 16 + 4kq + j]: 1 KiB of hi8 for all lanes, then 1 KiB of lo8 -- plus, for an odd number of 16-k blocks, a
+    16-k TAIL ([hi4 | lo4] per lane).  With `half` only round-to-nearest halves are kept (single-product mode); a
+    library built with -DELO_DENSE_F32 takes plain fp32 fragments (16-k blocks of four floats per lane)."""
 
     def __init__(self, W, b, relu=True, row_order=None, half=False):
         if row_order is not None:                         # the kernel's LDS column order differs from the concat order
@@ -95,17 +97,33 @@ class PackedDense:
         Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
         Wp = torch.zeros((Kp, Np), dtype=torch.float32, device=W.device)
         Wp[:K, :N] = W
-        # element (cb, ks, lane, s) = Wp[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)], s = 0..3
-        frag = Wp.reshape(Kp // 16, 4, 4, Np // 16, 16).permute(3, 0, 1, 4, 2).contiguous()       # (cb, ks, kq, n, s) fp32
+        CB, KS, NP = Np // 16, Kp // 16, Kp // 32
+        # element (cb, ks, lane = kq*16 + n, s) = Wp[ks*16 + 4*kq + s][cb*16 + n], s = 0..3
+        frag = Wp.reshape(KS, 4, 4, CB, 16).permute(3, 0, 1, 4, 2).reshape(CB, KS, 64, 4).contiguous()
         self.products = PRODUCTS_HALF if half else PRODUCTS_SPLIT
-        if half:
-            self.w = frag.to(torch.float16).contiguous()                                           # (cb, ks, kq, n, 4) fp16
-        elif fp32_mfma():
+
+        def paired(h4):          # (CB, KS, 64, 4) halves -> per column block [pairs of 8 halves per lane ..., tail of 4]
+            parts = []
+            if NP:
+                parts.append(torch.cat([h4[:, 0:2 * NP:2], h4[:, 1:2 * NP:2]], -1))        # (CB, NP, 64, 8)
+            return parts, (h4[:, KS - 1] if KS % 2 else None)                                 # tail (CB, 64, 4)
+
+        if fp32_mfma():
             self.w = frag
+        elif half:
+            pairs, tail = paired(frag.to(torch.float16))
+            flat = [p.reshape(CB, -1) for p in pairs] + ([tail.reshape(CB, -1)] if tail is not None else [])
+            self.w = torch.cat(flat, 1).contiguous()                                          # (CB, KS*256) halves
         else:
             hi = frag.to(torch.float16)
             lo = (frag - hi.to(torch.float32)).to(torch.float16)
-            self.w = torch.stack([hi, lo], dim=-2).contiguous()                                    # (cb, ks, kq, n, 2, 4) fp16
+            (ph, th), (pl, tl) = paired(hi), paired(lo)
+            flat = []
+            if ph:
+                flat.append(torch.stack([ph[0], pl[0]], 2).reshape(CB, -1))                   # per pair: [hi8 x 64 | lo8 x 64]
+            if th is not None:
+                flat.append(torch.cat([th, tl], -1).reshape(CB, -1))                          # per lane [hi4 | lo4]
+            self.w = torch.cat(flat, 1).contiguous()                                          # (CB, KS*512) halves
         self.b = torch.zeros((Np,), dtype=torch.float32, device=W.device)
         self.b[:N] = b
         self.K, self.N, self.relu = K, N, relu
