@@ -7,7 +7,8 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # ELO_DENSE_F32=1: the comparison build (true fp32 MFMA instead of the fp16 hi/lo split products; build.py)
-LIB_PATH = os.path.join(_PKG, "libelo_hip_f32.so" if os.environ.get("ELO_DENSE_F32", "0") == "1" else "libelo_hip.so")
+LIB_PATH = os.environ.get("ELO_LIB_PATH") or os.path.join(      # ELO_LIB_PATH: a debugging build (tools/cv1_clock.sh)
+    _PKG, "libelo_hip_f32.so" if os.environ.get("ELO_DENSE_F32", "0") == "1" else "libelo_hip.so")
 
 _vp = ctypes.c_void_p
 

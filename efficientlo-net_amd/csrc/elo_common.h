@@ -70,6 +70,58 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_max_step(unsigned v)
+{
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+    return o > v ? o : v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_add_step(unsigned v)
+{
+    return v + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// minimum over each aligned group of 8 lanes, in every lane of the group (quad swaps + row_half_mirror)
+__device__ __forceinline__ unsigned group8_min_u32(unsigned v)
+{
+    v = dpp_min_step<0xb1>(v);     // quad_perm:[1,0,3,2]
+    v = dpp_min_step<0x4e>(v);     // quad_perm:[2,3,0,1]
+    v = dpp_min_step<0x141>(v);    // row_half_mirror: the other quad of the 8
+    return v;
+}
+
+// maximum over each aligned group of 8 lanes, in every lane of the group
+__device__ __forceinline__ unsigned group8_max_u32(unsigned v)
+{
+    v = dpp_max_step<0xb1>(v);
+    v = dpp_max_step<0x4e>(v);
+    v = dpp_max_step<0x141>(v);
+    return v;
+}
+
+// wave-wide maximum of a value that is uniform inside every group of 8 lanes
+__device__ __forceinline__ unsigned wave_max_of_group8(unsigned v)
+{
+    v = dpp_max_step<0x140>(v);    // row_mirror: the other half of the row
+    v = dpp_max_step<0x142>(v);    // row_bcast:15
+    v = dpp_max_step<0x143>(v);    // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// wave-wide sum (lane 63 holds it after the standard DPP reduction)
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
+{
+    v = dpp_add_step<0xb1>(v);
+    v = dpp_add_step<0x4e>(v);
+    v = dpp_add_step<0x114>(v);    // row_shr:4
+    v = dpp_add_step<0x118>(v);    // row_shr:8
+    v = dpp_add_step<0x142>(v);    // row_bcast:15
+    v = dpp_add_step<0x143>(v);    // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // lexicographic (hi, lo) minimum over the wave, as one u64 key
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {

@@ -40,6 +40,14 @@ constexpr int MODE_CHECKED = 2;    // MODE_SPLIT + a count of operands outside t
 
 __device__ unsigned long long g_range_violations;      // written by MODE_CHECKED instances only
 
+// -DELO_CV1_CLOCK (a debugging build, tools/cv1_clock.sh): wave 0 of workgroup 0 of cv1_kernel stamps s_memtime at its
+// phase boundaries; elo_debug_cv1_clock() reads the stamps
+#ifdef ELO_CV1_CLOCK
+#define CV1_STAMP(i) do { if (block == 0 && threadIdx.x == 0) g_cv1_clock[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CV1_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ int ceil8(int x) { return (x + 7) & ~7; }
 __device__ __forceinline__ int ceil16(int x) { return (x + 15) & ~15; }
 
@@ -549,6 +557,7 @@ __device__ __forceinline__ void group_tile(const TileMeta &m, int *lds_off, unsi
     const int KT = g.kernel_h * g.kernel_w;
     if (tid < TILE) { m.cell[tid] = -1; m.mask[tid] = 0.0f; }
     stage_offsets(lds_off, g.random_hw, g.kernel_h, g.kernel_w, g.decoded_hw);   // ends with __syncthreads()
+    ELO_GROUP_STAMP(10);
     const float r2 = g.distance * g.distance;
     for (int pi = wave; pi < P; pi += FUSED_WAVES) {
         const long pt = first_point + pi;
@@ -575,10 +584,12 @@ __device__ __forceinline__ void group_tile(const TileMeta &m, int *lds_off, unsi
             const GridBuf gb = grid_buffer(grid2 + (size_t)b * H2 * W2 * 3);      // b is scalar: the resource lives in SGPRs
             if (SELECT)
                 count = wave_select_k(gb, H2, W2, KT, K, lds_off, hc / g.stride_h, wc / g.stride_w, cx, cy, cz, r2,
-                                      scratch + (size_t)wave * 2 * KT, reinterpret_cast<int *>(scratch) + (size_t)wave * 2 * KT + KT, emit);
+                                      scratch + (size_t)wave * select_scratch_words(KT, K),
+                                      reinterpret_cast<int *>(scratch) + (size_t)wave * select_scratch_words(KT, K) + KT, emit);
             else
                 count = wave_random_k(gb, H2, W2, KT, K, lds_off, hc / g.stride_h, wc / g.stride_w, cx, cy, cz, r2, emit);
         }
+        ELO_GROUP_STAMP(16 + (pi >= FUSED_WAVES));
         for (int k = count + lane; k < K; k += 64) {                           // zero-filled slots: index (0,0,0), mask 0
             m.cell[pi * K + k] = 0;
             m.mask[pi * K + k] = 0.0f;
@@ -1107,6 +1118,7 @@ __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, flo
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(block, nblocks) * P;
     if (first_point >= total_points) return;
+    CV1_STAMP(0);
     if (a.group.random_hw) {                          // select-k of frame 2 around every warped frame-1 pixel (:49-51)
         int *lds_off = reinterpret_cast<int *>(meta.cxyz + 96);
         unsigned *scratch = reinterpret_cast<unsigned *>(lds_off + a.group.kernel_h * a.group.kernel_w);
@@ -1120,6 +1132,7 @@ __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, flo
     if (tid == 0) feat_store(a.out, first_point * 64, meta.mask[0], f16);
     return;
 #endif
+    CV1_STAMP(1);
     const int F = 128, G = F + 2 * C;                                                             // :54-66
     {
         auto cell_of = [&](int row) { return (long)meta.cell[row]; };
@@ -1144,17 +1157,25 @@ __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, flo
     if (tid == 0) feat_store(a.out, first_point * 64, act[F] + p128.b[0].x, f16);
     return;
 #endif
+    CV1_STAMP(2);
     dense_pf<TILE, 128, 64, MODE>(act, S, F, to_tile(0), a.cv0, p128, &a.cv1, &p64, bad);          // feat_cat -> 128          :72-76
+    CV1_STAMP(3);
     dense_pf<TILE, 64, 64, MODE>(act, S, 0, to_tile(0), a.cv1, p64, &a.cv2, &p64, bad);            // -> 64 (in place)
+    CV1_STAMP(4);
     dense_pf<TILE, 64, 64, MODE>(act, S, 0, to_tile(0), a.cv2, p64, &a.cv_xyz, &p64, bad);         // -> 64 = x   (values of the pooling)
+    CV1_STAMP(5);
     dense_pf<TILE, 64, 128, MODE>(act, S, G, to_tile(64), a.cv_xyz, p64, &a.sum_cv0, &p128, bad);  // xyz_cat -> enc at [64,128)   :79-82
+    CV1_STAMP(6);
     dense_pf<TILE, 128, 64, MODE>(act, S, 0, to_tile(64), a.sum_cv0, p128, &a.sum_cv1, &p64, bad); // [x | enc] -> 128 at [64,192): over enc, x stays  :84-90
+    CV1_STAMP(7);
     dense_pf<TILE, 64, 0, MODE>(act, S, 64, to_pool(64), a.sum_cv1, p64, nullptr, nullptr, bad);   // -> 64 logits at [64,128) (plain fp32)
+    CV1_STAMP(8);
 #if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 3
     if (tid == 0) feat_store(a.out, first_point * 64, act[F], f16);
     return;
 #endif
     pool_masked_softmax(act, S, 64, 0, meta, P, K, first_point, total_points, a.out, f16);   // :92-98
+    CV1_STAMP(9);
     report_violations<MODE>(bad);
 }
 
@@ -1300,9 +1321,8 @@ int products_mode(const char *who, int *mode, const elo_dense *layers, int n, co
 
 size_t tile_lds_bytes(int rows, int S, int KT = 0, bool select = false, int K = 0)
 {
-    // select-k keeps small-K windows in registers (elo_group_device.h): LDS scratch only for the LDS form
-    const bool scratch = select && !select_in_registers(KT, K);
-    return sizeof(float) * ((size_t)rows * S + 64 + 96 + KT + (scratch ? (size_t)FUSED_WAVES * 2 * KT : 0));
+    // select-k: per wave the two [KT] arrays of its LDS form, or 128 words for the register form's small-K rank path
+    return sizeof(float) * ((size_t)rows * S + 64 + 96 + KT + (select ? (size_t)FUSED_WAVES * select_scratch_words(KT, K) : 0));
 }
 
 // in-kernel grouping: validate the spec the way elo_fused_conv_*_k validates its attributes
@@ -1415,6 +1435,13 @@ extern "C" int elo_dense_f32(void)
     return 0;
 #endif
 }
+
+#ifdef ELO_CV1_CLOCK
+extern "C" int elo_debug_cv1_clock(unsigned long long *out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_cv1_clock), 24 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int elo_range_check(int enable)
 {

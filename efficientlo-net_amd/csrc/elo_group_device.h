@@ -6,6 +6,14 @@
 
 namespace elo {
 
+// -DELO_CV1_CLOCK (debugging build, tools/cv1_clock.sh): s_memtime stamps of wave 0 of workgroup 0
+#ifdef ELO_CV1_CLOCK
+__device__ unsigned long long g_cv1_clock[24];
+#define ELO_GROUP_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cv1_clock[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ELO_GROUP_STAMP(i) do { } while (0)
+#endif
+
 #define ELO_EPS 1e-10f
 #define ELO_FAR 1e10f
 
@@ -146,17 +154,153 @@ __host__ __device__ __forceinline__ bool select_in_registers(int KT, int K)
     return (KT <= 512 && K <= 8) || (KT <= 192 && K <= 32);
 }
 
-// K rounds of the reference's selection sort on a register-resident window of J*64 slots.
+// wave-private LDS words select-k needs per wave: the two [KT] arrays of the LDS form, or the 2 x 64 candidate slots of
+// the register form's small-K rank path
+__host__ __device__ __forceinline__ int select_scratch_words(int KT, int K)
+{
+    return select_in_registers(KT, K) ? 128 : 2 * KT;
+}
+
+// ---- select-k without the K dependent rounds ------------------------------------------------------------------------
+// The reference's selection sort (fused_conv_g.cu:148-204) outputs the K smallest distances in increasing order; WHICH of
+// two EQUAL distances comes first depends on array positions as the swaps left them, and only then.  A round is a
+// ~150-instruction dependent chain (measured: ~1070 cycles per round for the wave that runs it alone: tools/cv1_clock.sh),
+// so K = 6 rounds were 47 % of a cost-volume tile at batch 1 and K = 32 rounds nearly all of the l2_origin one.  The two
+// forms below compute every element's RANK (number of strictly smaller distances) instead -- slot s takes the element
+// of rank s -- and verify that the ranks they hand out are 0 .. count-1, each exactly once: any exact tie that involves
+// a selected element (or the first one left out) breaks that, and only then the swap rounds run (on the same registers).
+// Real scans essentially never tie; the exact-tie lattices of the tests take the fallback and stay bit-exact.
+
+// K <= 7: the maximum over 8 lane-groups of the group minimum bounds the 8th smallest distance from above, so the K + 1
+// smallest are among the (typically 10-20) elements <= that bound; they are compacted into one element per lane
+// (wave-private LDS, 128 words) and ranked among themselves.
+template <int J, class Emit>
+__device__ __forceinline__ bool select_small_k(const unsigned (&d)[J], const int (&pw)[J], int K, unsigned *cand, Emit emit,
+                                               int &count)
+{
+    const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
+    const int lane = threadIdx.x & 63;
+    unsigned lmin = d[0];
+#pragma unroll
+    for (int j = 1; j < J; ++j) lmin = d[j] < lmin ? d[j] : lmin;
+    const unsigned T = wave_max_of_group8(group8_min_u32(lmin));
+    int total = 0, nvalid = 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const bool hit = d[j] < FAR_BITS, c = hit && d[j] <= T;
+        const unsigned long long m = __ballot(c);
+        const int slot = total + __popcll(m & ((1ull << lane) - 1ull));
+        if (c && slot < 64) { cand[slot] = d[j]; cand[64 + slot] = (unsigned)pw[j]; }
+        total += __popcll(m);
+        nvalid += __popcll(__ballot(hit));
+    }
+    count = nvalid < K ? nvalid : K;
+    if (total > 64) return false;                                  // (uniform) does not fit one element per lane
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned dc = lane < total ? cand[lane] : 0xffffffffu;
+    const int pc = (int)cand[64 + (lane < total ? lane : 0)];
+    int rank = 0;
+    for (int i = 0; i < total; ++i) rank += (unsigned)__builtin_amdgcn_readlane((int)dc, i) < dc;
+    const bool sel = lane < total && rank < count;
+    if (__popcll(__ballot(sel)) != count) return false;
+    for (int r = 0; r < count; ++r)                                 // each output slot exactly once (count <= 7)
+        if (__popcll(__ballot(sel && rank == r)) != 1) return false;
+    if (sel) emit(rank, pc);
+    return true;
+}
+
+// K < 64 on a window of more than 128 slots: the same idea with the threshold taken from the 64 PER-LANE minima -- their
+// (K+1)-th smallest bounds the (K+1)-th smallest distance from above -- found by ranking the lane minima (64 steps), after
+// which the candidates (typically K + 10..20; more than 64: give up) are compacted and ranked among themselves.  ~450
+// instructions where ranking all of 175 slots against each other takes ~1200.
+template <int J, class Emit>
+__device__ __forceinline__ bool select_mid_k(const unsigned (&d)[J], const int (&pw)[J], int K, unsigned *cand, Emit emit,
+                                             int &count)
+{
+    const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
+    const int lane = threadIdx.x & 63;
+    unsigned lmin = d[0];
+#pragma unroll
+    for (int j = 1; j < J; ++j) lmin = d[j] < lmin ? d[j] : lmin;
+    int below = 0;                                                  // lane minima strictly below this lane's
+#pragma unroll 8
+    for (int l = 0; l < 64; ++l) below += (unsigned)__builtin_amdgcn_readlane((int)lmin, l) < lmin;
+    const unsigned T = wave_max_of_group8(group8_max_u32(below <= K ? lmin : 0u));     // = the (K+1)-th smallest lane minimum
+    int total = 0, nvalid = 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const bool hit = d[j] < FAR_BITS, c = hit && d[j] <= T;
+        const unsigned long long m = __ballot(c);
+        const int slot = total + __popcll(m & ((1ull << lane) - 1ull));
+        if (c && slot < 64) { cand[slot] = d[j]; cand[64 + slot] = (unsigned)pw[j]; }
+        total += __popcll(m);
+        nvalid += __popcll(__ballot(hit));
+    }
+    count = nvalid < K ? nvalid : K;
+    if (total > 64) return false;                                  // (uniform)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned dc = lane < total ? cand[lane] : 0xffffffffu;
+    const int pc = (int)cand[64 + (lane < total ? lane : 0)];
+    int rank = 0;
+    for (int i = 0; i < total; ++i) rank += (unsigned)__builtin_amdgcn_readlane((int)dc, i) < dc;
+    const bool sel = lane < total && rank < count;
+    if (__popcll(__ballot(sel)) != count) return false;
+    if (wave_sum_u32(sel ? (unsigned)rank : 0u) != (unsigned)(count * (count - 1) / 2)) return false;   // 0 .. count-1, each once
+    if (sel) emit(rank, pc);
+    return true;
+}
+
+// windows of at most 192 slots (J <= 3), any K: every element is ranked against the whole window.
+template <int J, class Emit>
+__device__ __forceinline__ bool select_by_rank(const unsigned (&d)[J], const int (&pw)[J], int KT, int K, Emit emit, int &count)
+{
+    const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
+    int rank[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) rank[j] = 0;
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+        const int n = KT - jj * 64 < 64 ? KT - jj * 64 : 64;        // (uniform) slots held in register jj
+        for (int l = 0; l < n; ++l) {
+            const unsigned di = (unsigned)__builtin_amdgcn_readlane((int)d[jj], l);
+#pragma unroll
+            for (int j = 0; j < J; ++j) rank[j] += di < d[j];
+        }
+    }
+    int nvalid = 0, nsel = 0;
+    unsigned part = 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const bool hit = d[j] < FAR_BITS, sel = hit && rank[j] < K;
+        nvalid += __popcll(__ballot(hit));
+        nsel += __popcll(__ballot(sel));
+        part += sel ? (unsigned)rank[j] : 0u;
+    }
+    count = nvalid < K ? nvalid : K;
+    if (nsel != count) return false;
+    if (wave_sum_u32(part) != (unsigned)(count * (count - 1) / 2)) return false;    // ranks 0 .. count-1, each once
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+        if (d[j] < FAR_BITS && rank[j] < K) emit(rank[j], pw[j]);
+    return true;
+}
+
+// The window of J*64 slots in registers; the rank forms above where they apply, else (or on an exact tie) K rounds of the
+// reference's selection sort.  `cand`: 128 words of wave-private LDS (may be null: no small-K form).
 template <int J, class Grid, class Emit>
 __device__ __forceinline__ int select_rounds_in_registers(const Grid &grid2, int H2, int W2, int KT, int rounds,
                                                           const int *lds_off, int base_h, int base_w, float cx, float cy,
-                                                          float cz, float r2, Emit emit)
+                                                          float cz, float r2, unsigned *cand, Emit emit, int &seen,
+                                                          int &taken)
 {
     const int lane = threadIdx.x & 63;
     const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
     constexpr int BATCH = J < 4 ? J : 4;                   // probes in flight per lane
     unsigned d[J];
     int pw[J];
+    ELO_GROUP_STAMP(12);
 #pragma unroll
     for (int b0 = 0; b0 < J; b0 += BATCH) {
         RawSlot raw[BATCH];
@@ -168,6 +312,8 @@ __device__ __forceinline__ int select_rounds_in_registers(const Grid &grid2, int
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
             const Probe p = judge(raw[u], cx, cy, cz, r2);
+            seen += __popcll(__ballot(p.valid));                         // (dropped by the compiler where the caller ignores them)
+            taken += __popcll(__ballot(p.hit));
             d[b0 + u] = p.hit ? __float_as_uint(p.d) : FAR_BITS;        // d > 0: bit order == float order
             pw[b0 + u] = p.hit ? p.hw : 0;
         }
@@ -177,7 +323,20 @@ __device__ __forceinline__ int select_rounds_in_registers(const Grid &grid2, int
             break;
         }
     }
+    ELO_GROUP_STAMP(13);
+    {
+        int count = 0;
+        bool done = false;
+        if (rounds <= 7 && cand) done = select_small_k<J>(d, pw, rounds, cand, emit, count);
+        else if (J == 3 && rounds < 64 && cand) {
+            done = select_mid_k<J>(d, pw, rounds, cand, emit, count);
+            if (!done) done = select_by_rank<J>(d, pw, KT, rounds, emit, count);       // more than 64 candidates (or a tie)
+        }
+        else if (J <= 3) done = select_by_rank<J>(d, pw, KT, rounds, emit, count);
+        if (done) { ELO_GROUP_STAMP(15); return count; }              // (uniform)
+    }
     for (int s = 0; s < rounds; ++s) {
+        if (s == 1) ELO_GROUP_STAMP(14);
         unsigned best = 0xffffffffu;
         int where = 0x7fffffff;
 #pragma unroll
@@ -201,25 +360,28 @@ __device__ __forceinline__ int select_rounds_in_registers(const Grid &grid2, int
         }
         if (lane == 0) emit(s, pm);
     }
+    ELO_GROUP_STAMP(15);
     return rounds;
 }
 
 // K nearest in-range neighbours, reference tie order (selection sort with swaps): register form (above) where
-// select_in_registers() says so, otherwise the LDS arrays dist/pay ([KT] wave-private each).
+// select_in_registers() says so, otherwise the LDS arrays dist/pay ([KT] wave-private each).  seen / taken: the numbers
+// of existing and of in-range window slots (the reference's valid_idx / valid_in_dis_idx prefix lengths) are ADDED to them.
 template <class Grid, class Emit>
 __device__ __forceinline__ int wave_select_k(const Grid &grid2, int H2, int W2, int KT, int K,
                                              const int *lds_off, int base_h, int base_w, float cx, float cy, float cz,
-                                             float r2, unsigned *dist, int *pay, Emit emit)
+                                             float r2, unsigned *dist, int *pay, Emit emit, int &seen, int &taken)
 {
     const int lane = threadIdx.x & 63;
     const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
     const int rounds = K < KT ? K : KT;
     if (select_in_registers(KT, K)) {
+        unsigned *cand = dist;                          // wave-private scratch of the caller: >= 128 words (or null)
         if (KT <= 128)
-            return select_rounds_in_registers<2>(grid2, H2, W2, KT, rounds, lds_off, base_h, base_w, cx, cy, cz, r2, emit);
+            return select_rounds_in_registers<2>(grid2, H2, W2, KT, rounds, lds_off, base_h, base_w, cx, cy, cz, r2, cand, emit, seen, taken);
         if (KT <= 192)
-            return select_rounds_in_registers<3>(grid2, H2, W2, KT, rounds, lds_off, base_h, base_w, cx, cy, cz, r2, emit);
-        return select_rounds_in_registers<8>(grid2, H2, W2, KT, rounds, lds_off, base_h, base_w, cx, cy, cz, r2, emit);
+            return select_rounds_in_registers<3>(grid2, H2, W2, KT, rounds, lds_off, base_h, base_w, cx, cy, cz, r2, cand, emit, seen, taken);
+        return select_rounds_in_registers<8>(grid2, H2, W2, KT, rounds, lds_off, base_h, base_w, cx, cy, cz, r2, cand, emit, seen, taken);
     }
     for (int base = 0; base < KT; base += ELO_WAVE) {
         const int i = base + lane;
@@ -227,6 +389,8 @@ __device__ __forceinline__ int wave_select_k(const Grid &grid2, int H2, int W2, 
             const Probe p = probe_slot(grid2, H2, W2, lds_off[i], base_h, base_w, cx, cy, cz, r2);
             dist[i] = p.hit ? __float_as_uint(p.d) : FAR_BITS;
             pay[i] = p.hit ? p.hw : 0;
+            seen += __popcll(__ballot(p.valid));
+            taken += __popcll(__ballot(p.hit));
         }
     }
     for (int s = 0; s < rounds; ++s) {
@@ -244,6 +408,15 @@ __device__ __forceinline__ int wave_select_k(const Grid &grid2, int H2, int W2, 
         if (lane == 0) emit(s, pm);
     }
     return rounds;
+}
+
+template <class Grid, class Emit>
+__device__ __forceinline__ int wave_select_k(const Grid &grid2, int H2, int W2, int KT, int K,
+                                             const int *lds_off, int base_h, int base_w, float cx, float cy, float cz,
+                                             float r2, unsigned *dist, int *pay, Emit emit)
+{
+    int seen = 0, taken = 0;
+    return wave_select_k(grid2, H2, W2, KT, K, lds_off, base_h, base_w, cx, cy, cz, r2, dist, pay, emit, seen, taken);
 }
 
 }  // namespace elo

@@ -290,7 +290,8 @@ __global__ __launch_bounds__(ELO_BLOCK) void group_select_k(const elo_group_args
     const int KT = a.kernel_h * a.kernel_w, K = a.K;
     int *lds_off = lds;
     const int wave = threadIdx.x / ELO_WAVE, lane = threadIdx.x % ELO_WAVE;
-    unsigned *dist = (unsigned *)(lds + KT) + (size_t)wave * 2 * KT;
+    const int per_wave = 2 * KT > 128 ? 2 * KT : 128;        // (the register form's rank path keeps 2 x 64 candidates here)
+    unsigned *dist = (unsigned *)(lds + KT) + (size_t)wave * per_wave;
     int *pay = (int *)dist + KT;
     const long u0 = (long)xcd_tile(blockIdx.x, gridDim.x) * waves_per_block + wave;
     const long u = u0 < total ? u0 : total - 1;
@@ -303,22 +304,20 @@ __global__ __launch_bounds__(ELO_BLOCK) void group_select_k(const elo_group_args
     float *o_mask = a.selected_mask + u * K;
     const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
 
-    if (c.ok && a.flag_copy == 0 && !a.valid_idx && !a.valid_in_dis_idx && select_in_registers(KT, K)) {
-        // the model's call shape (flag_copy 0, prefix masks not requested): the register-resident wave form shared with
-        // the fused kernels (elo_group_device.h) -- no LDS scans, probes batched four-deep
+    int taken = 0, seen = 0;
+    if (c.ok && a.flag_copy == 0 && select_in_registers(KT, K)) {
+        // the model's call shape (flag_copy 0): the register-resident wave form shared with the fused kernels
+        // (elo_group_device.h) -- no LDS scans, probes batched four-deep, ranks instead of dependent rounds
         const int count = wave_select_k(grid2, a.H2, a.W2, KT, K, lds_off, c.base_h, c.base_w, c.x, c.y, c.z, r2, dist, pay,
                                         [&](int slot, int hw) {
                                             o_sel[slot * 3 + 0] = c.b; o_sel[slot * 3 + 1] = hw >> 16; o_sel[slot * 3 + 2] = hw & 0xffff;
                                             o_mask[slot] = 1.0f;
-                                        });
+                                        }, seen, taken);
         for (int k = count + lane; k < K; k += ELO_WAVE) {
             o_sel[k * 3 + 0] = 0; o_sel[k * 3 + 1] = 0; o_sel[k * 3 + 2] = 0;
             o_mask[k] = 0.0f;
         }
-        return;
-    }
-    int taken = 0, seen = 0;
-    if (c.ok) {
+    } else if (c.ok) {
         // pass 1: slot position == visiting order (:84,:110,:123,:138)
         for (int base = 0; base < KT; base += ELO_WAVE) {
             const int i = base + lane;
@@ -476,8 +475,9 @@ extern "C" int elo_fused_conv_select_k(const elo_group_args *a, elo_stream_t str
     const int KT = a->kernel_h * a->kernel_w;
     // 4 waves per block while the per-wave window state fits comfortably in LDS
     int wpb = 4;
-    while (wpb > 1 && sizeof(int) * KT * (1 + 2 * (size_t)wpb) > 64 * 1024) wpb >>= 1;
-    const size_t lds = sizeof(int) * KT * (1 + 2 * (size_t)wpb);
+    const size_t per_wave = 2 * (size_t)KT > 128 ? 2 * (size_t)KT : 128;
+    while (wpb > 1 && sizeof(int) * (KT + per_wave * wpb) > 64 * 1024) wpb >>= 1;
+    const size_t lds = sizeof(int) * (KT + per_wave * wpb);
     const unsigned grid = (unsigned)((total + wpb - 1) / wpb);
     hipLaunchKernelGGL(group_select_k, dim3(grid), dim3(wpb * ELO_WAVE), lds, (hipStream_t)stream, *a, total, wpb);
     return check_launch("elo_fused_conv_select_k");

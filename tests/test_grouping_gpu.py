@@ -75,6 +75,32 @@ def test_sweep_against_oracle(seed):
             assert np.array_equal(g, w_), (op, seed)
 
 
+@pytest.mark.parametrize("kH,kW,K", [(5, 15, 6), (7, 25, 6), (11, 41, 6), (5, 15, 32), (5, 35, 32), (5, 35, 16), (3, 60, 63),
+                                     (9, 15, 8), (13, 39, 7)])
+@pytest.mark.parametrize("lattice", [False, True, "sparse"])
+def test_select_k_rank_forms_keep_the_reference_order(kH, kW, K, lattice):
+    """The register form of select-k ranks the window (three forms by window size / K: csrc/elo_group_device.h) instead of
+    running the reference's K swap rounds, and falls back to the rounds on an exact tie that touches the selected set.  On
+    smooth clouds (no ties), on an integer lattice (ties everywhere) and on a 90 %-empty cloud (fewer than K candidates)
+    all four outputs equal the oracle's, valid_idx / valid_in_dis_idx included."""
+    rng = np.random.default_rng(kH * 1000 + kW * 10 + K)
+    B, H, W = 2, 12, 70
+    x = rng.normal(0, 2.0, (2, B, H, W, 3))
+    if lattice is True:
+        x = np.round(x)
+    x[rng.random((2, B, H, W)) < (0.9 if lattice == "sparse" else 0.1)] = 0
+    xyz1, xyz2 = x.astype(np.float32)
+    idx = np.stack([rng.integers(0, H, (B, 200)), rng.integers(0, W, (B, 200))], -1).astype(np.int32)
+    perm = rng.permutation(kH * kW).astype(np.int32)
+    for dist in (1.5, 1000.0):
+        want = G.fused_conv_select_k(xyz1, xyz2, idx, perm, H, W, 200, kH, kW, K, 0, dist, 1, 1)
+        got = _hip("select", xyz1, xyz2, idx, perm, kH, kW, K, 0, dist, 1, 1)
+        for g, w_ in zip(got, want):
+            assert np.array_equal(g, w_)
+        got = _hip("select", xyz1, xyz2, idx, perm, kH, kW, K, 0, dist, 1, 1, want_valid=False)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[3], want[3])
+
+
 def test_edge_cases():
     # all-empty clouds, one centre, K larger than the window, widest legal window
     z = np.zeros((2, 3, 9, 3), np.float32)
