@@ -247,68 +247,82 @@ __device__ __forceinline__ ActPair act_pair(const float *p)
 #endif
 }
 
-template <int MODE, int MAXT>
-__device__ __forceinline__ void mma_pair(f32x4 (&acc)[MAXT], const ActPair a, const WPair (&w)[MAXT])
+// acc[rb][c0 + t] += W_t x A_rb for t < MT column blocks and rb < RB row blocks: one W fragment feeds every row block
+// (products outermost, so consecutive MFMAs go to different accumulators)
+template <int MODE, int MT, int RB, int TPW>
+__device__ __forceinline__ void mma_pair(f32x4 (&acc)[RB][TPW], int c0, const ActPair (&a)[RB], const WPair (&w)[MT])
 {
 #ifdef ELO_DENSE_F32
-    const float4 x0 = __builtin_bit_cast(float4, a.hi), x1 = __builtin_bit_cast(float4, a.lo);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const float4 x = h ? x1 : x0;
-        const float xs[4] = {x.x, x.y, x.z, x.w};
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const float4 wv = __builtin_bit_cast(float4, h ? w[t].lo : w[t].hi);
-                const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[j], xs[j], acc[t], 0, 0, 0);
+            for (int rb = 0; rb < RB; ++rb) {
+                const float4 x = __builtin_bit_cast(float4, h ? a[rb].lo : a[rb].hi);
+                const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const float4 wv = __builtin_bit_cast(float4, h ? w[t].lo : w[t].hi);
+                    const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
+                    acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[j], xs[j], acc[rb][c0 + t], 0, 0, 0);
+                }
             }
-    }
 #else
-    const half8 ahi = __builtin_bit_cast(half8, a.hi);
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w[t].hi), ahi, acc[t], 0, 0, 0);
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w[t].hi), __builtin_bit_cast(half8, a[rb].hi), acc[rb][c0 + t], 0, 0, 0);
     if constexpr (MODE != MODE_HALF) {
-        const half8 alo = __builtin_bit_cast(half8, a.lo);
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w[t].lo), ahi, acc[t], 0, 0, 0);
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w[t].hi), alo, acc[t], 0, 0, 0);
+            for (int t = 0; t < MT; ++t)
+                acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w[t].lo), __builtin_bit_cast(half8, a[rb].hi), acc[rb][c0 + t], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w[t].hi), __builtin_bit_cast(half8, a[rb].lo), acc[rb][c0 + t], 0, 0, 0);
     }
 #endif
 }
 
-template <int MODE, int MAXT>
-__device__ __forceinline__ void mma_tail(f32x4 (&acc)[MAXT], const uint4 a, const uint4 (&w)[MAXT])
+template <int MODE, int MT, int RB, int TPW>
+__device__ __forceinline__ void mma_tail(f32x4 (&acc)[RB][TPW], int c0, const uint4 (&a)[RB], const uint4 (&w)[MT])
 {
 #ifdef ELO_DENSE_F32
-    const float4 x = __builtin_bit_cast(float4, a);
-    const float xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-            const float4 wv = __builtin_bit_cast(float4, w[t]);
-            const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[j], xs[j], acc[t], 0, 0, 0);
+        for (int rb = 0; rb < RB; ++rb) {
+            const float4 x = __builtin_bit_cast(float4, a[rb]);
+            const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const float4 wv = __builtin_bit_cast(float4, w[t]);
+                const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
+                acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[j], xs[j], acc[rb][c0 + t], 0, 0, 0);
+            }
         }
 #else
-    const half4 ahi = __builtin_bit_cast(half4, uint2{a.x, a.y});
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, uint2{w[t].x, w[t].y}), ahi, acc[t], 0, 0, 0);
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, uint2{w[t].x, w[t].y}), __builtin_bit_cast(half4, uint2{a[rb].x, a[rb].y}), acc[rb][c0 + t], 0, 0, 0);
     if constexpr (MODE != MODE_HALF) {
-        const half4 alo = __builtin_bit_cast(half4, uint2{a.z, a.w});
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, uint2{w[t].z, w[t].w}), ahi, acc[t], 0, 0, 0);
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, uint2{w[t].x, w[t].y}), alo, acc[t], 0, 0, 0);
+            for (int t = 0; t < MT; ++t)
+                acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, uint2{w[t].z, w[t].w}), __builtin_bit_cast(half4, uint2{a[rb].x, a[rb].y}), acc[rb][c0 + t], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, uint2{w[t].x, w[t].y}), __builtin_bit_cast(half4, uint2{a[rb].z, a[rb].w}), acc[rb][c0 + t], 0, 0, 0);
     }
 #endif
 }
@@ -361,13 +375,16 @@ __device__ __forceinline__ void store_quad(float *act, int S, int row, int col, 
 }
 
 // ---- one dense layer on the block's tile ---------------------------------------------------
-// D[TILE x Np] = relu?(A[TILE x Kp] * W + bias).  The tile is cut into 16x16 output sub-tiles; wave w owns row block
-// (w % RB) and every (4/RB)-th column block: TPW = 1, 2 or 4 sub-tiles per wave, all accumulators in registers, worked
-// through in PASSES of at most two sub-tiles (the W registers of a 32-k pair are 8 per sub-tile; the A operand is
-// re-read from LDS per pass).  W streams from L2 in packed order (see WFrag), one pair ahead in a second register set;
-// loads are UNCONDITIONAL (indices clamped into the packed array): with per-lane predicates around them the compiler
-// loses track of the outstanding loads and waits vmcnt(0) before every MFMA group.  Layers run IN PLACE on the tile:
-// barrier after the K loops (every wave has finished reading A), write D, barrier.
+// D[TILE x Np] = relu?(A[TILE x Kp] * W + bias).  The tile is cut into 16x16 output sub-tiles; wave w owns column blocks
+// w, w + 4, ... (TPW = 1, 2 or 4 of them) of EVERY row block: a W fragment, once in registers, feeds all TILE / 16 row
+// blocks.  (Round 2 first gave a wave one row block and twice the column blocks: every fragment then crossed the CU's
+// vector L1 once per row block -- 404 KiB per 32-row tile of the cost volume, 2.3 GB per batch-8 launch, ~85 % of what
+// the L1s can deliver during the dense phase; tools/cv1_phases.sh.)  All accumulators live in registers, worked through in
+// PASSES of at most two column blocks (the W registers of a 32-k pair are 8 per block; the A operands are re-read from
+// LDS per pass).  W streams from L2 in packed order (see WFrag), one pair ahead in a second register set; loads are
+// UNCONDITIONAL (indices clamped into the packed array): with per-lane predicates around them the compiler loses track
+// of the outstanding loads and waits vmcnt(0) before every MFMA group.  Layers run IN PLACE on the tile: barrier after
+// the K loops (every wave has finished reading A), write D, barrier.
 //
 // The cost-volume chains have fixed widths, so there the FIRST step of the next layer (its first pair, or its tail when
 // the layer has a single 16-k block) and its bias are fetched into registers (`Pre`) while this layer's epilogue runs:
@@ -380,18 +397,17 @@ struct Pre {
 };
 
 template <int TILE, int N>
-struct Sub {                                          // sub-tiles per wave of a width-N layer: 1, 2 or 4
-    static constexpr int CSTEP = FUSED_WAVES / (TILE / 16);
-    static constexpr int RAW = ((N + 15) / 16 + CSTEP - 1) / CSTEP;
+struct Sub {                                          // column blocks per wave of a width-N layer: 1, 2 or 4
+    static constexpr int RAW = ((N + 15) / 16 + FUSED_WAVES - 1) / FUSED_WAVES;
     static constexpr int TPW = RAW <= 1 ? 1 : RAW <= 2 ? 2 : 4;
 };
 
 template <int TILE, int TPW, int MODE>
 __device__ __forceinline__ void prefetch(const elo_dense &L, Pre<TPW> &pre)
 {
-    constexpr int RB = TILE / 16, CSTEP = FUSED_WAVES / RB, MT = Pre<TPW>::MT;
+    constexpr int CSTEP = FUSED_WAVES, MT = Pre<TPW>::MT;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kq = lane >> 4, cb0 = wave / RB;
+    const int kq = lane >> 4, cb0 = wave;
     const int KS = ceil16(L.K) >> 4, CB = ceil16(L.N) >> 4;
     const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);
 #pragma unroll
@@ -409,36 +425,43 @@ template <int TILE, int TPW, int MODE, bool HAS_PRE, int NEXT_TPW>
 __device__ __forceinline__ void dense_impl(float *act, int S, int in_off, const elo_dense &L, const LayerOut &out,
                                            unsigned &violations, const Pre<TPW> *pre, const elo_dense *next, Pre<(NEXT_TPW ? NEXT_TPW : 1)> *next_pre)
 {
-    constexpr int RB = TILE / 16;                 // row blocks: 1 or 2
-    constexpr int CSTEP = FUSED_WAVES / RB;       // column-block stride between a wave's sub-tiles
+    constexpr int RB = TILE / 16;                 // row blocks: 1 or 2, all of them this wave's
+    constexpr int CSTEP = FUSED_WAVES;            // column-block stride between a wave's sub-tiles
     constexpr int MT = TPW < 2 ? TPW : 2, PASSES = TPW / MT;
-    // the wave index as a SCALAR: row block, column blocks and with them every W / bias base address live in SGPRs,
+    // the wave index as a SCALAR: column blocks and with them every W / bias base address live in SGPRs,
     // so a W load is `buffer_load_dwordx4 v, v_lane_off, s[rsrc], s_off` with no vector address arithmetic
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
-    const int rb = wave % RB, cb0 = wave / RB;
+    const int cb0 = wave;
     const int KS = ceil16(L.K) >> 4, CB = ceil16(L.N) >> 4;
     const int NP = KS >> 1;                        // 32-k pairs; KS & 1: a 16-k tail
     const bool tail = KS & 1;
     constexpr int BB = WFrag<MODE>::BLOCK_BYTES;
-    f32x4 acc[TPW];
+    f32x4 acc[RB][TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const float4 bv = HAS_PRE ? pre->b[t] : *reinterpret_cast<const float4 *>(L.bias + min(cb0 + t * CSTEP, CB - 1) * 16 + 4 * kq);
-        acc[t] = f32x4{bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb][t] = f32x4{bv.x, bv.y, bv.z, bv.w};
     }
-    const float *arow = act + (rb * 16 + i16) * S + in_off + 4 * kq;
+    const float *arow = act + i16 * S + in_off + 4 * kq;              // row block rb: + rb * 16 * S
     const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(L.w_packed);      // buffer addressing: V# + lane offset + scalar offset
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
+        const int c0 = pass * MT;
         int base[MT];                                                  // byte offset of each sub-tile's column block
 #pragma unroll
-        for (int t = 0; t < MT; ++t) base[t] = min(cb0 + (pass * MT + t) * CSTEP, CB - 1) * KS * BB;
+        for (int t = 0; t < MT; ++t) base[t] = min(cb0 + (c0 + t) * CSTEP, CB - 1) * KS * BB;
         auto fetch = [&](int p, WPair (&buf)[MT]) {
 #pragma unroll
             for (int t = 0; t < MT; ++t) buf[t] = pair_load<MODE>(wrsrc, lane, base[t] + min(p, NP - 1) * 2 * BB);
         };
-        f32x4 (&pa)[MT] = *reinterpret_cast<f32x4 (*)[MT]>(&acc[pass * MT]);
+        auto pair_step = [&](int p, const WPair (&buf)[MT]) {
+            ActPair a[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) a[rb] = act_pair(arow + rb * 16 * S + p * 32);
+            mma_pair<MODE, MT, RB, TPW>(acc, c0, a, buf);
+        };
         WPair b0[MT], b1[MT];
         const bool from_pre = HAS_PRE && pass == 0;
         // the tail's fragment travels in the .hi of whichever register set the pair loop has released
@@ -447,10 +470,12 @@ __device__ __forceinline__ void dense_impl(float *act, int S, int in_off, const 
             for (int t = 0; t < MT; ++t) buf[t].hi = tail_load<MODE>(wrsrc, lane, base[t] + (KS - 1) * BB);
         };
         auto tail_step = [&](const WPair (&buf)[MT]) {
-            uint4 wt[MT];
+            uint4 wt[MT], a[RB];
 #pragma unroll
             for (int t = 0; t < MT; ++t) wt[t] = buf[t].hi;
-            mma_tail<MODE, MT>(pa, *reinterpret_cast<const uint4 *>(arow + (KS - 1) * 16), wt);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) a[rb] = *reinterpret_cast<const uint4 *>(arow + rb * 16 * S + (KS - 1) * 16);
+            mma_tail<MODE, MT, RB, TPW>(acc, c0, a, wt);
         };
         if (from_pre) {
 #pragma unroll
@@ -463,14 +488,14 @@ __device__ __forceinline__ void dense_impl(float *act, int S, int in_off, const 
         int p = 0;
         for (; p + 1 < NP; p += 2) {                                         // two pairs per trip: b0, then b1
             fetch(p + 1, b1);
-            mma_pair<MODE, MT>(pa, act_pair(arow + p * 32), b0);
+            pair_step(p, b0);
             if (p + 2 < NP) fetch(p + 2, b0);
             else if (tail) fetch_tail(b0);
-            mma_pair<MODE, MT>(pa, act_pair(arow + (p + 1) * 32), b1);
+            pair_step(p + 1, b1);
         }
         if (p < NP) {                                                        // an odd number of pairs: the last one sits in b0
             if (tail) fetch_tail(b1);
-            mma_pair<MODE, MT>(pa, act_pair(arow + p * 32), b0);
+            pair_step(p, b0);
             if (tail) tail_step(b1);
         } else if (tail) {
             tail_step(b0);
@@ -481,7 +506,9 @@ __device__ __forceinline__ void dense_impl(float *act, int S, int in_off, const 
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int cb = cb0 + t * CSTEP;
-        if (cb < CB) store_quad<MODE>(act, S, rb * 16 + i16, cb * 16 + 4 * kq, L.N, acc[t], L.relu, out, violations);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            if (cb < CB) store_quad<MODE>(act, S, rb * 16 + i16, cb * 16 + 4 * kq, L.N, acc[rb][t], L.relu, out, violations);
     }
     __syncthreads();
 }
@@ -490,12 +517,11 @@ __device__ __forceinline__ void dense_impl(float *act, int S, int in_off, const 
 template <int TILE, int MODE>
 __device__ __forceinline__ void dense(float *act, int S, int in_off, const elo_dense &L, const LayerOut &out, unsigned &violations)
 {
-    constexpr int CSTEP = FUSED_WAVES / (TILE / 16);
-    const int per_wave = ((ceil16(L.N) >> 4) + CSTEP - 1) / CSTEP;      // sub-tiles per wave, <= 4 for N <= 128
+    constexpr int CSTEP = FUSED_WAVES;
+    const int per_wave = ((ceil16(L.N) >> 4) + CSTEP - 1) / CSTEP;      // column blocks per wave: 1 or 2 (N <= 128: check_dense)
     Pre<1> *none = nullptr;
     if (per_wave <= 1) dense_impl<TILE, 1, MODE, false, 0>(act, S, in_off, L, out, violations, (const Pre<1> *)nullptr, nullptr, none);
-    else if (per_wave <= 2) dense_impl<TILE, 2, MODE, false, 0>(act, S, in_off, L, out, violations, (const Pre<2> *)nullptr, nullptr, none);
-    else dense_impl<TILE, 4, MODE, false, 0>(act, S, in_off, L, out, violations, (const Pre<4> *)nullptr, nullptr, none);
+    else dense_impl<TILE, 2, MODE, false, 0>(act, S, in_off, L, out, violations, (const Pre<2> *)nullptr, nullptr, none);
 }
 
 // compile-time width N with the cross-layer prefetch; NEXT = width of the following layer (0 = none)
@@ -512,7 +538,7 @@ __device__ __forceinline__ void dense_pf(float *act, int S, int in_off, const La
 struct TileMeta {
     int *cell;      // [32] flat (b*H2 + h)*W2 + w of the gathered pixel, -1 = row not in use
     float *mask;    // [32]
-    float *cxyz;    // [96] centre xyz of the tile's points
+    float *cxyz;    // [96] centre xyz of the tile's points (+ [32] words behind it: their pixels, in-kernel grouping only)
 };
 
 __device__ __forceinline__ TileMeta tile_meta(float *lds, int rows, int S)
@@ -556,21 +582,37 @@ __device__ __forceinline__ void group_tile(const TileMeta &m, int *lds_off, unsi
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: point index, batch, centre address stay off the vector unit
     const int KT = g.kernel_h * g.kernel_w;
     if (tid < TILE) { m.cell[tid] = -1; m.mask[tid] = 0.0f; }
+    // The tile's centres: thread pi fetches point pi's pixel and xyz (two dependent round trips when the centres come
+    // from an index tensor) NOW, beside the loads that stage the visiting order, and leaves them in LDS -- fetched by
+    // the wave that groups the point they were two serial round trips in front of every point's probes (~3 k of the
+    // ~10 k cycles a point takes: tools/cv1_clock.sh).
+    int *chw = reinterpret_cast<int *>(m.cxyz + 96);                             // [32] (h << 16) | w of the centres
+    {
+        const long pt = first_point + tid;
+        const bool mine = tid < P && pt < total_points;
+        const long pq = mine ? pt : first_point;
+        // (launchers keep batch * npoints below 2^31: 32-bit divisions -- a 64-bit one is a ~100-instruction routine)
+        const int b = (int)((unsigned)pq / (unsigned)npoints), n = (int)((unsigned)pq - (unsigned)b * (unsigned)npoints);
+        const int hc = centre_hw ? centre_hw[pq * 2 + 0] : n / W1, wc = centre_hw ? centre_hw[pq * 2 + 1] : n - (n / W1) * W1;
+        const float *c = centre_grid + (((long)b * H1 + hc) * W1 + wc) * 3;
+        const float cx = c[0], cy = c[1], cz = c[2];
+        if (mine) {
+            chw[tid] = (hc << 16) | wc;
+            m.cxyz[tid * 3 + 0] = cx; m.cxyz[tid * 3 + 1] = cy; m.cxyz[tid * 3 + 2] = cz;
+            if (new_xyz) { new_xyz[pt * 3 + 0] = cx; new_xyz[pt * 3 + 1] = cy; new_xyz[pt * 3 + 2] = cz; }
+        }
+    }
     stage_offsets(lds_off, g.random_hw, g.kernel_h, g.kernel_w, g.decoded_hw);   // ends with __syncthreads()
     ELO_GROUP_STAMP(10);
     const float r2 = g.distance * g.distance;
     for (int pi = wave; pi < P; pi += FUSED_WAVES) {
         const long pt = first_point + pi;
         if (pt >= total_points) continue;
-        const int b = (int)(pt / npoints), n = (int)(pt - (long)b * npoints);
-        const int hc = centre_hw ? centre_hw[pt * 2 + 0] : n / W1, wc = centre_hw ? centre_hw[pt * 2 + 1] : n - (n / W1) * W1;
-        const float *c = centre_grid + (((long)b * H1 + hc) * W1 + wc) * 3;
-        const float cx = c[0], cy = c[1], cz = c[2];
-        if (lane < 3) {
-            const float v = lane == 0 ? cx : lane == 1 ? cy : cz;
-            m.cxyz[pi * 3 + lane] = v;
-            if (new_xyz) new_xyz[pt * 3 + lane] = v;
-        }
+        const int b = (int)((unsigned)pt / (unsigned)npoints);
+        auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };   // back to SGPRs
+        const int hwc = __builtin_amdgcn_readfirstlane(chw[pi]), hc = hwc >> 16, wc = hwc & 0xffff;
+        const float cx = uniform(m.cxyz[pi * 3 + 0]), cy = uniform(m.cxyz[pi * 3 + 1]), cz = uniform(m.cxyz[pi * 3 + 2]);
+        ELO_GROUP_STAMP(11);
         int *o_idx = g.idx_out ? g.idx_out + pt * K * 3 : nullptr;
         float *o_mask = g.mask_out ? g.mask_out + pt * K : nullptr;
         auto emit = [&](int slot, int hw) {
@@ -590,6 +632,7 @@ __device__ __forceinline__ void group_tile(const TileMeta &m, int *lds_off, unsi
                 count = wave_random_k(gb, H2, W2, KT, K, lds_off, hc / g.stride_h, wc / g.stride_w, cx, cy, cz, r2, emit);
         }
         ELO_GROUP_STAMP(16 + (pi >= FUSED_WAVES));
+        if (pi < FUSED_WAVES) ELO_GROUP_STAMP(18);
         for (int k = count + lane; k < K; k += 64) {                           // zero-filled slots: index (0,0,0), mask 0
             m.cell[pi * K + k] = 0;
             m.mask[pi * K + k] = 0.0f;
@@ -799,7 +842,7 @@ __device__ __forceinline__ void setconv_tile(const elo_setconv_args &a, const in
     const long first_point = (long)xcd_tile(block, nblocks) * P;
     if (first_point >= total_points) return;
     if (a.group.random_hw) {
-        int *lds_off = reinterpret_cast<int *>(meta.cxyz + 96);
+        int *lds_off = reinterpret_cast<int *>(meta.cxyz + 128);
         group_tile<TILE, false>(meta, lds_off, nullptr, a.group, first_point, total_points, a.npoints, P, K, a.xyz1_grid,
                                 a.H, a.W, a.centre_hw, a.src_xyz, a.H2, a.W2, a.new_xyz);
     } else {
@@ -1120,8 +1163,8 @@ __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, flo
     if (first_point >= total_points) return;
     CV1_STAMP(0);
     if (a.group.random_hw) {                          // select-k of frame 2 around every warped frame-1 pixel (:49-51)
-        int *lds_off = reinterpret_cast<int *>(meta.cxyz + 96);
-        unsigned *scratch = reinterpret_cast<unsigned *>(lds_off + a.group.kernel_h * a.group.kernel_w);
+        int *lds_off = reinterpret_cast<int *>(meta.cxyz + 128);
+        unsigned *scratch = reinterpret_cast<unsigned *>(lds_off + ((a.group.kernel_h * a.group.kernel_w + 3) & ~3));   // 16-byte aligned
         group_tile<TILE, true>(meta, lds_off, scratch, a.group, first_point, total_points, a.npoints, P, K, a.xyz1, a.H2,
                                a.W2, nullptr, a.xyz2, a.H2, a.W2, nullptr);
     } else {
@@ -1227,7 +1270,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, 6) void cv2_kernel(const elo_cv2_args 
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     if (first_point >= total_points) return;
     if (a.group.random_hw) {                          // random-k of the warped cloud on itself (:106-108)
-        int *lds_off = reinterpret_cast<int *>(meta.cxyz + 96);
+        int *lds_off = reinterpret_cast<int *>(meta.cxyz + 128);
         group_tile<TILE, false>(meta, lds_off, nullptr, a.group, first_point, total_points, a.npoints, P, K, a.xyz1, a.H,
                                 a.W, nullptr, a.xyz1, a.H, a.W, nullptr);
     } else {
@@ -1322,7 +1365,7 @@ int products_mode(const char *who, int *mode, const elo_dense *layers, int n, co
 size_t tile_lds_bytes(int rows, int S, int KT = 0, bool select = false, int K = 0)
 {
     // select-k: per wave the two [KT] arrays of its LDS form, or 128 words for the register form's small-K rank path
-    return sizeof(float) * ((size_t)rows * S + 64 + 96 + KT + (select ? (size_t)FUSED_WAVES * select_scratch_words(KT, K) : 0));
+    return sizeof(float) * ((size_t)rows * S + 64 + 96 + 32 + ((KT + 3) & ~3) + (select ? (size_t)FUSED_WAVES * select_scratch_words(KT, K) : 0));
 }
 
 // in-kernel grouping: validate the spec the way elo_fused_conv_*_k validates its attributes
@@ -1411,6 +1454,7 @@ static bool same_shape(const elo_setconv_args *a, const elo_setconv_args *b)
 static int plan_setconv(const elo_setconv_args *a, const elo_setconv_args *b, TilePlan *p, const char *who)
 {
     const long points = (long)a->batch * a->npoints;
+    if (points >= 0x7fffffffL) return fail(ELO_ERR_LIMIT, "%s: batch * npoints beyond 2^31", who);
     p->S = row_stride(chain_cols(a->layers, a->n_layers, 3 + a->C));
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
     const long u32 = (points + P32 - 1) / P32, u16 = (points + P16 - 1) / P16;
@@ -1473,6 +1517,7 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
         if (!same_shape(a, b)) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must have the same shape", who);
     }
     const long points = (long)a->batch * a->npoints;
+    if (points >= 0x7fffffffL) return fail(ELO_ERR_LIMIT, "%s: batch * npoints beyond 2^31", who);
     if (points == 0) return ELO_OK;
     hipStream_t s = (hipStream_t)stream;
     if (!b && a->group.random_hw && a->K == 32 && a->n_layers == 3 && a->layers[0].w_plain && a->layers[1].w_plain &&
@@ -1617,6 +1662,7 @@ static int plan_cv1(const elo_cv1_args *a, TilePlan *p, const char *who)
     if (int rc = check_dense(a->sum_cv0, 128, 128, who, "sum_CV_0")) return rc;
     if (int rc = check_dense(a->sum_cv1, 128, 64, who, "sum_CV_1")) return rc;
     const long points = (long)a->batch * a->npoints;
+    if (points >= 0x7fffffffL) return fail(ELO_ERR_LIMIT, "%s: batch * npoints beyond 2^31", who);
     const int cols = 128 + cv1_feat_cols(a->C);
     p->S = row_stride(cols > 192 ? cols : 192);
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;
@@ -1705,6 +1751,7 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
     if (int rc = check_dense(a->sum_cost0, 128 + a->C, 128, who, "sum_cost_volume_0")) return rc;
     if (int rc = check_dense(a->sum_cost1, 128, 64, who, "sum_cost_volume_1")) return rc;
     const long points = (long)a->batch * a->npoints;
+    if (points >= 0x7fffffffL) return fail(ELO_ERR_LIMIT, "%s: batch * npoints beyond 2^31", who);
     if (points == 0) return ELO_OK;
     const int S = row_stride(208);
     const int P32 = 32 / a->K, P16 = a->K <= 16 ? 16 / a->K : 1;

@@ -135,13 +135,10 @@ __device__ __forceinline__ RawSlot fetch_slot(const Grid &grid2, int H2, int W2,
 
 __device__ __forceinline__ Probe judge(const RawSlot &r, float cx, float cy, float cz, float r2)
 {
-    Probe p{false, false, ELO_FAR, 0};
-    if (!r.in_grid || sq3(r.x, r.y, r.z) <= ELO_EPS) return p;
-    p.valid = true;
-    p.d = pick_max(sq3(__fsub_rn(cx, r.x), __fsub_rn(cy, r.y), __fsub_rn(cz, r.z)), ELO_EPS);
-    p.hit = !(p.d > r2);
-    p.hw = r.hw;
-    return p;
+    // straight-line: an early return here became a branch per probe (exec save / restore, 17 of them around 8 probes)
+    const bool valid = r.in_grid && !(sq3(r.x, r.y, r.z) <= ELO_EPS);
+    const float d = pick_max(sq3(__fsub_rn(cx, r.x), __fsub_rn(cy, r.y), __fsub_rn(cz, r.z)), ELO_EPS);
+    return Probe{valid, valid && !(d > r2), valid ? d : ELO_FAR, valid ? r.hw : 0};
 }
 
 // The register form keeps the window in J = 2, 3 or 8 registers per lane (position j*64 + lane in register j), so a
@@ -158,7 +155,7 @@ __host__ __device__ __forceinline__ bool select_in_registers(int KT, int K)
 // the register form's small-K rank path
 __host__ __device__ __forceinline__ int select_scratch_words(int KT, int K)
 {
-    return select_in_registers(KT, K) ? 128 : 2 * KT;
+    return select_in_registers(KT, K) ? 128 : (2 * KT + 3) & ~3;            // (multiples of 4 words: 16-byte aligned per wave)
 }
 
 // ---- select-k without the K dependent rounds ------------------------------------------------------------------------
@@ -171,85 +168,97 @@ __host__ __device__ __forceinline__ int select_scratch_words(int KT, int K)
 // a selected element (or the first one left out) breaks that, and only then the swap rounds run (on the same registers).
 // Real scans essentially never tie; the exact-tie lattices of the tests take the fallback and stay bit-exact.
 
-// K <= 7: the maximum over 8 lane-groups of the group minimum bounds the 8th smallest distance from above, so the K + 1
-// smallest are among the (typically 10-20) elements <= that bound; they are compacted into one element per lane
-// (wave-private LDS, 128 words) and ranked among themselves.
+// Shared tail of the two threshold forms.  Candidates = the in-range elements <= T (T' = min(T, FAR - 1): one compare);
+// they are compacted one per lane into cand[0..63] (distance) / cand[64..127] (payload) -- slot = running total +
+// v_mbcnt of the ballot, no bounds check: more than 64 candidates only scribble over slots of an attempt that is given up
+// -- and each is ranked against the candidate list read back as broadcast 16-byte items (the list is padded with
+// 0xffffffff, which is below nothing).  count = min(total, K): fewer than K candidates means T was "no bound" (FAR), i.e.
+// every in-range element is a candidate.
 template <int J, class Emit>
-__device__ __forceinline__ bool select_small_k(const unsigned (&d)[J], const int (&pw)[J], int K, unsigned *cand, Emit emit,
-                                               int &count)
+__device__ __forceinline__ bool rank_candidates(const unsigned (&d)[J], const int (&pw)[J], unsigned T, int K, unsigned *cand,
+                                                Emit emit, int &count)
 {
     const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
     const int lane = threadIdx.x & 63;
-    unsigned lmin = d[0];
-#pragma unroll
-    for (int j = 1; j < J; ++j) lmin = d[j] < lmin ? d[j] : lmin;
-    const unsigned T = wave_max_of_group8(group8_min_u32(lmin));
-    int total = 0, nvalid = 0;
+    const unsigned Tp = T < FAR_BITS ? T : FAR_BITS - 1u;
+    cand[lane] = 0xffffffffu;
+    int total = 0;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const bool hit = d[j] < FAR_BITS, c = hit && d[j] <= T;
+        const bool c = d[j] <= Tp;
         const unsigned long long m = __ballot(c);
-        const int slot = total + __popcll(m & ((1ull << lane) - 1ull));
-        if (c && slot < 64) { cand[slot] = d[j]; cand[64 + slot] = (unsigned)pw[j]; }
+        const int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)total)) & 63;
+        if (c) { cand[slot] = d[j]; cand[64 + slot] = (unsigned)pw[j]; }
         total += __popcll(m);
-        nvalid += __popcll(__ballot(hit));
     }
-    count = nvalid < K ? nvalid : K;
+    count = total < K ? total : K;
     if (total > 64) return false;                                  // (uniform) does not fit one element per lane
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const unsigned dc = lane < total ? cand[lane] : 0xffffffffu;
-    const int pc = (int)cand[64 + (lane < total ? lane : 0)];
+    const unsigned dc = cand[lane];                                 // 0xffffffff beyond `total`
+    const int pc = (int)cand[64 + lane];
+    const uint4 *list = reinterpret_cast<const uint4 *>(cand);      // (callers keep cand 16-byte aligned)
     int rank = 0;
-    for (int i = 0; i < total; ++i) rank += (unsigned)__builtin_amdgcn_readlane((int)dc, i) < dc;
-    const bool sel = lane < total && rank < count;
-    if (__popcll(__ballot(sel)) != count) return false;
-    for (int r = 0; r < count; ++r)                                 // each output slot exactly once (count <= 7)
-        if (__popcll(__ballot(sel && rank == r)) != 1) return false;
-    if (sel) emit(rank, pc);
-    return true;
-}
-
-// K < 64 on a window of more than 128 slots: the same idea with the threshold taken from the 64 PER-LANE minima -- their
-// (K+1)-th smallest bounds the (K+1)-th smallest distance from above -- found by ranking the lane minima (64 steps), after
-// which the candidates (typically K + 10..20; more than 64: give up) are compacted and ranked among themselves.  ~450
-// instructions where ranking all of 175 slots against each other takes ~1200.
-template <int J, class Emit>
-__device__ __forceinline__ bool select_mid_k(const unsigned (&d)[J], const int (&pw)[J], int K, unsigned *cand, Emit emit,
-                                             int &count)
-{
-    const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
-    const int lane = threadIdx.x & 63;
-    unsigned lmin = d[0];
+    {
+        uint4 x[4];
 #pragma unroll
-    for (int j = 1; j < J; ++j) lmin = d[j] < lmin ? d[j] : lmin;
-    int below = 0;                                                  // lane minima strictly below this lane's
-#pragma unroll 8
-    for (int l = 0; l < 64; ++l) below += (unsigned)__builtin_amdgcn_readlane((int)lmin, l) < lmin;
-    const unsigned T = wave_max_of_group8(group8_max_u32(below <= K ? lmin : 0u));     // = the (K+1)-th smallest lane minimum
-    int total = 0, nvalid = 0;
+        for (int i = 0; i < 4; ++i) x[i] = list[i];                 // the first 16 in one go: usually all there are
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const bool hit = d[j] < FAR_BITS, c = hit && d[j] <= T;
-        const unsigned long long m = __ballot(c);
-        const int slot = total + __popcll(m & ((1ull << lane) - 1ull));
-        if (c && slot < 64) { cand[slot] = d[j]; cand[64 + slot] = (unsigned)pw[j]; }
-        total += __popcll(m);
-        nvalid += __popcll(__ballot(hit));
+        for (int i = 0; i < 4; ++i) rank += (x[i].x < dc) + (x[i].y < dc) + (x[i].z < dc) + (x[i].w < dc);
     }
-    count = nvalid < K ? nvalid : K;
-    if (total > 64) return false;                                  // (uniform)
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const unsigned dc = lane < total ? cand[lane] : 0xffffffffu;
-    const int pc = (int)cand[64 + (lane < total ? lane : 0)];
-    int rank = 0;
-    for (int i = 0; i < total; ++i) rank += (unsigned)__builtin_amdgcn_readlane((int)dc, i) < dc;
-    const bool sel = lane < total && rank < count;
+    for (int i = 4; i * 4 < total; ++i) {
+        const uint4 x = list[i];
+        rank += (x.x < dc) + (x.y < dc) + (x.z < dc) + (x.w < dc);
+    }
+    const bool sel = rank < count && dc != 0xffffffffu;
     if (__popcll(__ballot(sel)) != count) return false;
     if (wave_sum_u32(sel ? (unsigned)rank : 0u) != (unsigned)(count * (count - 1) / 2)) return false;   // 0 .. count-1, each once
     if (sel) emit(rank, pc);
     return true;
+}
+
+// K <= 7: the maximum over 8 lane-groups of the group minimum bounds the 8th smallest distance from above, so the K + 1
+// smallest are among the (typically 10-20) elements <= that bound.
+template <int J, class Emit>
+__device__ __forceinline__ bool select_small_k(const unsigned (&d)[J], const int (&pw)[J], int K, unsigned *cand, Emit emit,
+                                               int &count)
+{
+    unsigned lmin = d[0];
+#pragma unroll
+    for (int j = 1; j < J; ++j) lmin = d[j] < lmin ? d[j] : lmin;
+    const unsigned T = wave_max_of_group8(group8_min_u32(lmin));
+    return rank_candidates<J>(d, pw, T, K, cand, emit, count);
+}
+
+// K < 64 on a window of more than 128 slots: the same idea with the threshold taken from the 64 PER-LANE minima -- their
+// (K+1)-th smallest bounds the (K+1)-th smallest distance from above -- found by ranking the lane minima against each
+// other (through the same LDS list), after which the candidates (typically K + 10..20; more than 64: give up) are
+// compacted and ranked.  ~400 instructions where ranking all of 175 slots against each other takes ~1200.
+template <int J, class Emit>
+__device__ __forceinline__ bool select_mid_k(const unsigned (&d)[J], const int (&pw)[J], int K, unsigned *cand, Emit emit,
+                                             int &count)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned lmin = d[0];
+#pragma unroll
+    for (int j = 1; j < J; ++j) lmin = d[j] < lmin ? d[j] : lmin;
+    cand[lane] = lmin;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint4 *list = reinterpret_cast<const uint4 *>(cand);
+    int below = 0;                                                  // lane minima strictly below this lane's
+#pragma unroll
+    for (int i0 = 0; i0 < 16; i0 += 8) {
+        uint4 x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = list[i0 + i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) below += (x[i].x < lmin) + (x[i].y < lmin) + (x[i].z < lmin) + (x[i].w < lmin);
+    }
+    const unsigned T = wave_max_of_group8(group8_max_u32(below <= K ? lmin : 0u));     // = the (K+1)-th smallest lane minimum
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return rank_candidates<J>(d, pw, T, K, cand, emit, count);
 }
 
 // windows of at most 192 slots (J <= 3), any K: every element is ranked against the whole window.
@@ -297,7 +306,7 @@ __device__ __forceinline__ int select_rounds_in_registers(const Grid &grid2, int
 {
     const int lane = threadIdx.x & 63;
     const unsigned FAR_BITS = __float_as_uint(ELO_FAR);
-    constexpr int BATCH = J < 4 ? J : 4;                   // probes in flight per lane
+    constexpr int BATCH = J < 4 ? J : 4;                   // probes in flight per lane (8: measured, no faster)
     unsigned d[J];
     int pw[J];
     ELO_GROUP_STAMP(12);
@@ -328,7 +337,7 @@ __device__ __forceinline__ int select_rounds_in_registers(const Grid &grid2, int
         int count = 0;
         bool done = false;
         if (rounds <= 7 && cand) done = select_small_k<J>(d, pw, rounds, cand, emit, count);
-        else if (J == 3 && rounds < 64 && cand) {
+        else if (J <= 3 && rounds < 64 && cand) {
             done = select_mid_k<J>(d, pw, rounds, cand, emit, count);
             if (!done) done = select_by_rank<J>(d, pw, KT, rounds, emit, count);       // more than 64 candidates (or a tie)
         }

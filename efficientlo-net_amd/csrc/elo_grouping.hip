@@ -283,6 +283,10 @@ __global__ __launch_bounds__(DENSE_ROWS * 64) void group_random_k_dense(const el
 // ---------------------------------------------------------------- select-k
 // One wave per centre. LDS: [KT] decoded offsets (block) + per wave [KT] distance
 // bits and [KT] packed hw.
+// wave-private LDS words of group_select_k: the [KT] distance and payload arrays of its LDS form; at least the 2 x 64
+// candidate slots of the register form's rank paths; whole 16-byte items
+__host__ __device__ inline int select_wave_words(int KT) { return 2 * KT > 128 ? (2 * KT + 3) & ~3 : 128; }
+
 __global__ __launch_bounds__(ELO_BLOCK) void group_select_k(const elo_group_args a, const long total,
                                                             const int waves_per_block)
 {
@@ -290,8 +294,8 @@ __global__ __launch_bounds__(ELO_BLOCK) void group_select_k(const elo_group_args
     const int KT = a.kernel_h * a.kernel_w, K = a.K;
     int *lds_off = lds;
     const int wave = threadIdx.x / ELO_WAVE, lane = threadIdx.x % ELO_WAVE;
-    const int per_wave = 2 * KT > 128 ? 2 * KT : 128;        // (the register form's rank path keeps 2 x 64 candidates here)
-    unsigned *dist = (unsigned *)(lds + KT) + (size_t)wave * per_wave;
+    const int per_wave = select_wave_words(KT);              // (the register form's rank path keeps 2 x 64 candidates here)
+    unsigned *dist = (unsigned *)(lds + ((KT + 3) & ~3)) + (size_t)wave * per_wave;      // 16-byte aligned
     int *pay = (int *)dist + KT;
     const long u0 = (long)xcd_tile(blockIdx.x, gridDim.x) * waves_per_block + wave;
     const long u = u0 < total ? u0 : total - 1;
@@ -475,9 +479,9 @@ extern "C" int elo_fused_conv_select_k(const elo_group_args *a, elo_stream_t str
     const int KT = a->kernel_h * a->kernel_w;
     // 4 waves per block while the per-wave window state fits comfortably in LDS
     int wpb = 4;
-    const size_t per_wave = 2 * (size_t)KT > 128 ? 2 * (size_t)KT : 128;
-    while (wpb > 1 && sizeof(int) * (KT + per_wave * wpb) > 64 * 1024) wpb >>= 1;
-    const size_t lds = sizeof(int) * (KT + per_wave * wpb);
+    const size_t per_wave = (size_t)select_wave_words(KT), order = ((size_t)KT + 3) & ~(size_t)3;
+    while (wpb > 1 && sizeof(int) * (order + per_wave * wpb) > 64 * 1024) wpb >>= 1;
+    const size_t lds = sizeof(int) * (order + per_wave * wpb);
     const unsigned grid = (unsigned)((total + wpb - 1) / wpb);
     hipLaunchKernelGGL(group_select_k, dim3(grid), dim3(wpb * ELO_WAVE), lds, (hipStream_t)stream, *a, total, wpb);
     return check_launch("elo_fused_conv_select_k");

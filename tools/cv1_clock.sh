@@ -21,11 +21,12 @@ fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 assert fn(out) == 0
 names = ["grouping", "gather+encode", "CV_0", "CV_1", "CV_2", "CV_xyz", "sum_CV_0", "sum_CV_1", "pooling"]
 t = list(out)
-print("s_memtime ticks (100 MHz constant clock on gfx950: 1 tick = 10 ns) per phase, wave 0 of workgroup 0:")
+print("s_memtime ticks (shader-clock cycles, ~2.4 GHz) per phase, wave 0 of workgroup 0:")
 for i, n in enumerate(names):
     print("  %-14s %6d ticks" % (n, t[i + 1] - t[i]))
 print("  total          %6d ticks" % (t[9] - t[0]))
-print("inside the grouping (the LAST centre wave 0 handled): offsets staged +%d | its probes %d | round 0 %d | rounds 1.. %d | "
-      "first centre done at +%d, second at +%d, loop end +%d, barrier +%d" % (
-          t[10] - t[0], t[13] - t[12], t[14] - t[13], t[15] - t[14], t[16] - t[0], t[17] - t[0], t[18] - t[0], t[19] - t[0]))
+print("inside the grouping (the LAST centre wave 0 handled): offsets staged +%d | its probes %d | selection %d | "
+      "first centre done at +%d, second at +%d" % (t[10] - t[0], t[13] - t[12], t[15] - t[13], t[16] - t[0], t[17] - t[0]))
+print("  last centre: loop top +%d, probes start +%d, probes end +%d, selection end +%d, centre done +%d" % (
+    t[11] - t[0], t[12] - t[0], t[13] - t[0], t[15] - t[0], t[17] - t[0]))
 PY
