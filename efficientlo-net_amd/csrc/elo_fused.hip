@@ -51,13 +51,20 @@ __device__ unsigned long long g_range_violations;      // written by MODE_CHECKE
 __device__ __forceinline__ int ceil8(int x) { return (x + 7) & ~7; }
 __device__ __forceinline__ int ceil16(int x) { return (x + 15) & ~15; }
 
-// LDS row stride (32-bit words) for `cols` columns: a multiple of 4 with (S/4) odd, so that the 16 rows a
-// ds_read_b128 operand fragment touches fall into 16 different 16-byte bank slots.
+// LDS row stride (32-bit words) for `cols` columns.  An operand read is one ds_read_b128 per lane at word
+// (lane % 16) * S + 4 * (lane / 16) + const; gfx950 serves it in four groups of 16 lanes ({0-3, 12-15, 20-27}, ...) over
+// 64 banks; enumerated against the guide's lane-group table the groups are conflict-free for S % 64 in {4, 8, 24, 40, 56}
+// (4 also keeps the epilogue's ds_write_b128 conflict-free).  Measured on cv1_kernel at batch 8 (SQ_LDS_BANK_CONFLICT):
+// S % 64 = 8, 24, 40 -> 3.4 M conflict cycles per launch, 4, 12, 20, 28, 36 -> 6.2 M, 16 -> 15.4 M -- and the same
+// kernel time for all but 16, so the rule only has to stay away from multiples of 16 (the operand reads as two 8-byte
+// halves, which the compiler emitted before they were made explicit 16-byte reads, cost 11.7 M).
 __host__ __device__ __forceinline__ int row_stride(int cols)
 {
     int s = (cols + 3) & ~3;
-    if (((s >> 2) & 1) == 0) s += 4;
-    return s;
+    for (;; s += 4) {
+        const int m = s & 63;
+        if (m == 4 || m == 8 || m == 24 || m == 40 || m == 56) return s;
+    }
 }
 
 // ---- W fragments through buffer addressing ------------------------------------------------------------------
@@ -241,9 +248,10 @@ __device__ __forceinline__ ActPair act_pair(const float *p)
 #ifdef ELO_DENSE_F32
     return ActPair{*reinterpret_cast<const uint4 *>(p), *reinterpret_cast<const uint4 *>(p + 16)};
 #else
-    const uint2 h0 = *reinterpret_cast<const uint2 *>(p), h1 = *reinterpret_cast<const uint2 *>(p + 16);
-    const uint2 l0 = *reinterpret_cast<const uint2 *>(p + 2), l1 = *reinterpret_cast<const uint2 *>(p + 18);
-    return ActPair{uint4{h0.x, h0.y, h1.x, h1.y}, uint4{l0.x, l0.y, l1.x, l1.y}};
+    // two 16-byte reads (ds_read_b128: the tile, S and every column offset are multiples of 4 words), regrouped in registers
+    const uint4 q0 = *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(p, 16));
+    const uint4 q1 = *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(p + 16, 16));
+    return ActPair{uint4{q0.x, q0.y, q1.x, q1.y}, uint4{q0.z, q0.w, q1.z, q1.w}};
 #endif
 }
 
@@ -474,7 +482,7 @@ __device__ __forceinline__ void dense_impl(float *act, int S, int in_off, const 
 #pragma unroll
             for (int t = 0; t < MT; ++t) wt[t] = buf[t].hi;
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) a[rb] = *reinterpret_cast<const uint4 *>(arow + rb * 16 * S + (KS - 1) * 16);
+            for (int rb = 0; rb < RB; ++rb) a[rb] = *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(arow + rb * 16 * S + (KS - 1) * 16, 16));
             mma_tail<MODE, MT, RB, TPW>(acc, c0, a, wt);
         };
         if (from_pre) {
@@ -907,7 +915,7 @@ __device__ __forceinline__ void setconv_tile(const elo_setconv_args &a, const in
 template <int TILE, int MODE>
 __global__ __launch_bounds__(FUSED_BLOCK, 6) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
 {
-    extern __shared__ float lds[];
+    extern __shared__ __align__(16) float lds[];
     setconv_tile<TILE, MODE>(jobs.job[blockIdx.y], S, lds, blockIdx.x, gridDim.x);
 }
 
@@ -1073,7 +1081,7 @@ template <int TILE, int MODE>
 __global__ __launch_bounds__(FUSED_BLOCK, 6) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
 {
     const elo_mlp_args &a = jobs.job[blockIdx.y];
-    extern __shared__ float lds[];
+    extern __shared__ __align__(16) float lds[];
     float *act = lds;
     const int tid = threadIdx.x, f16 = a.feat_dtype == ELO_F16;
     unsigned bad = 0;
@@ -1225,7 +1233,7 @@ __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, flo
 template <int TILE, int MODE>
 __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_kernel(const elo_cv1_args a, const int S)
 {
-    extern __shared__ float lds[];
+    extern __shared__ __align__(16) float lds[];
     cv1_tile<TILE, MODE>(a, S, lds, blockIdx.x, gridDim.x);
 }
 
@@ -1244,7 +1252,7 @@ template <int TILE_CV, int TILE_SC, int MODE>
 __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_setconv_kernel(const elo_cv1_args a, const int S, const unsigned n_cv,
                                                                      const SideJobs side)
 {
-    extern __shared__ float lds[];
+    extern __shared__ __align__(16) float lds[];
     if (blockIdx.x < n_cv) {
         cv1_tile<TILE_CV, MODE>(a, S, lds, blockIdx.x, n_cv);
     } else {
@@ -1260,7 +1268,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, 5) void cv1_setconv_kernel(const elo_c
 template <int TILE, int MODE>
 __global__ __launch_bounds__(FUSED_BLOCK, 6) void cv2_kernel(const elo_cv2_args a, const int S)
 {
-    extern __shared__ float lds[];
+    extern __shared__ __align__(16) float lds[];
     float *act = lds;
     const TileMeta meta = tile_meta(lds, TILE, S);
     const int tid = threadIdx.x;
