@@ -478,6 +478,12 @@ def main():
 
         def step(i):
             pose_log[i, :, 0] = 1.0
+
+        def begin_repeat():
+            pass
+
+        def end_repeat(n):
+            pass
     else:
         model, synth = pkg("model"), pkg("synth")
         pkg("fused").products(args.products).__enter__()          # for the whole run: packing, capture and the roofline leg
@@ -489,25 +495,37 @@ def main():
         if args.no_graph:
             net.forward(pool[0][:B], pool[0][B:])
         else:
-            net.capture(B, H, W, lanes=lanes)
-        # every step's l0 pose [q | t] is kept (a lane's static outputs are overwritten `lanes` steps later): one (B,7)
-        # row block per step in HBM; with N > 1 ranks the blocks are all-gathered ONCE per repeat, inside the timed
-        # region (7 floats per pair: the only exchange of the inference path, main.py:557-572)
+            # a lane's l0 pose-head kernel writes replay r's [q | t] block into slot r of the lane's ring
+            net.capture(B, H, W, lanes=lanes, pose_ring=max(2, -(-max(args.steps, warmup) // lanes)))
+        # every step's l0 pose [q | t] is kept: one (B,7) row block per step in HBM, collected from the lanes' rings at
+        # the end of each repeat INSIDE the timed region (one strided copy per lane; round 1-2 copied one block out per
+        # step, a launch that sat ~14 us in every lane's serial chain); with N > 1 ranks the blocks are all-gathered ONCE
+        # per repeat, inside the timed region too (7 floats per pair: the only exchange of the inference path,
+        # main.py:557-572)
         pose_log = torch.empty((max(args.steps, warmup), B, 7), device=dev)
 
         def step(i):
             pair = pool[i % len(pool)]
             if args.no_graph:                            # the l0 pose-head kernel writes the log row itself
                 return net.forward(pair[:B], pair[B:], pose_out=pose_log[i])
-            lane = i % lanes                             # step i rides lane i % lanes; lanes overlap on the GPU
-            out = net.submit(lane, pair)                 # one copy in (the stacked pair), graph replay ...
-            with torch.cuda.stream(net.lane_stream(lane)):
-                pose_log[i].copy_(net.lane_pose(lane), non_blocking=True)      # ... one copy out (B,7)
-            return out
+            return net.submit(i % lanes, pair)           # step i rides lane i % lanes: one copy in (the stacked pair), graph replay
+
+        def begin_repeat():
+            if not args.no_graph:
+                for lane in range(lanes):
+                    net.reset_poses(lane)
+
+        def end_repeat(n):
+            if not args.no_graph:
+                for lane in range(min(lanes, n)):
+                    with torch.cuda.stream(net.lane_stream(lane)):
+                        pose_log[lane:n:lanes].copy_(net.lane_poses(lane), non_blocking=True)
     gathered = [torch.empty_like(pose_log[:args.steps]) for _ in range(world)] if world > 1 else None
 
+    begin_repeat()
     for i in range(warmup):
         step(i)
+    end_repeat(warmup)
     sync()
     if world > 1:
         dist.all_gather(gathered, pose_log[:args.steps].contiguous())     # untimed: RCCL sets its channels up on first use
@@ -517,8 +535,10 @@ def main():
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
+        begin_repeat()
         for i in range(args.steps):
             step(i)
+        end_repeat(args.steps)
         sync()
         if world > 1:
             dist.all_gather(gathered, pose_log[:args.steps].contiguous())

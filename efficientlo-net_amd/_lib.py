@@ -56,7 +56,7 @@ PoseHeadArgs = _struct("elo_pose_head_args", [
     ("W_big", _vp), ("b_big", _vp), ("W_q", _vp), ("b_q", _vp), ("W_t", _vp), ("b_t", _vp),
     ("q_coarse", _vp), ("t_coarse", _vp), ("q", _vp), ("t", _vp), ("q_norm", _vp), ("scratch", _vp), ("pose7", _vp),
     ("clear_scratch", _vp), ("clear_xyz", _vp), ("clear_feat", _vp), ("clear_cells", ctypes.c_long), ("clear_C", _i),
-    ("feat_dtype", _i)])
+    ("feat_dtype", _i), ("pose7_slots", _i), ("pose7_cursor", _vp)])
 WarpProjectArgs = _struct("elo_warp_project_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("H", _i), ("W", _i),
     ("az_res", _f), ("vert_res", _f), ("vert_off", _f),
@@ -162,6 +162,9 @@ class EloError(RuntimeError):
     pass
 
 
+ABI_VERSION = 13
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -173,6 +176,9 @@ def lib():
             fn = getattr(handle, name)          # AttributeError if the symbol is missing
             fn.restype = restype
             fn.argtypes = argtypes
+        if handle.elo_abi_version() != ABI_VERSION:      # the ctypes structs below mirror ONE layout of include/elo.h
+            raise EloError("%s has ABI version %d, this host expects %d: rebuild (python -c 'import __graft_entry__ as g; "
+                           "g.build()')" % (LIB_PATH, handle.elo_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 

@@ -305,6 +305,23 @@ class ProjectionBuffers:
         self.result = None          # (warped, out_xyz, out_feat) once a pose head has run the projection itself
 
 
+class PoseRing:
+    """(slots, B, 7) rows [q_norm | t] + a per-batch-element cursor: the pose output of a launch that is REPLAYED from a
+    captured graph.  Replay r writes slot cursor % slots and advances the cursor, so a stream of frame pairs needs no
+    copy-out per pair (elo_pose_head_args.pose7_slots / pose7_cursor); drain with rows() every `slots` replays."""
+
+    def __init__(self, slots, batch, device):
+        if slots < 2:
+            raise ValueError("a pose ring has at least 2 slots")
+        self.rows = torch.zeros((slots, batch, 7), dtype=torch.float32, device=device)
+        self.cursor = torch.zeros((batch,), dtype=torch.int32, device=device)
+        self.slots = slots
+
+    def reset(self):
+        """Cursor back to slot 0 (on the current stream)."""
+        self.cursor.zero_()
+
+
 def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse=None, t_coarse=None, pose7=None,
               clear=None, warp=None):
     """softmax_valid -> conv1d(256) -> q,t heads -> normalise -> compose with the coarse pose, two launches.
@@ -326,12 +343,18 @@ def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t
     q_norm = torch.empty((B, 4), dtype=torch.float32, device=dev)
     scratch = torch.empty((3 * B * L.SV_MAX_PARTS * C,), dtype=torch.float32, device=dev)
     ptr = lambda x: x.data_ptr() if x is not None else None
+    ring = pose7 if isinstance(pose7, PoseRing) else None
+    if ring is not None:
+        if ring.rows.shape[1] != B:
+            raise ValueError("pose ring of batch %d used with batch %d" % (ring.rows.shape[1], B))
+        pose7 = ring.rows
     a = L.PoseHeadArgs(B, N, C, hidden, feature_bnc.data_ptr(), weight_bnc.data_ptr(), xyz_bn3.data_ptr(),
                        W_big.data_ptr(), b_big.data_ptr(), W_q.data_ptr(), b_q.data_ptr(), W_t.data_ptr(), b_t.data_ptr(),
                        ptr(q_coarse), ptr(t_coarse), q.data_ptr(), t.data_ptr(), q_norm.data_ptr(), scratch.data_ptr(),
                        ptr(pose7), *((clear.scratch.data_ptr(), clear.out_xyz.data_ptr(), ptr(clear.out_feat),
                                       clear.shape[0] * clear.shape[2] * clear.shape[3], clear.shape[4])
-                                     if clear is not None else (None, None, None, 0, 0)), fcode)
+                                     if clear is not None else (None, None, None, 0, 0)), fcode,
+                       ring.slots if ring is not None else 0, ring.cursor.data_ptr() if ring is not None else None)
     if clear is not None and clear.out_feat is not None and clear.out_feat.dtype != fdt:
         raise TypeError("the projection buffers and the pose head's features must share one storage dtype")
     if warp is not None:

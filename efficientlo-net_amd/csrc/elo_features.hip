@@ -807,8 +807,14 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
             for (int i = 0; i < 4; ++i) { a.q[b * 4 + i] = q[i]; a.q_norm[b * 4 + i] = qn[i]; }
             for (int i = 0; i < 3; ++i) a.t[b * 3 + i] = t[i];
             if (a.pose7) {
-                for (int i = 0; i < 4; ++i) a.pose7[b * 7 + i] = qn[i];
-                for (int i = 0; i < 3; ++i) a.pose7[b * 7 + 4 + i] = t[i];
+                float *row = a.pose7 + b * 7;
+                if (a.pose7_slots > 1 && a.pose7_cursor) {                     // ring: this replay's slot, then advance
+                    const unsigned at = a.pose7_cursor[b];
+                    a.pose7_cursor[b] = at + 1u;
+                    row += (size_t)(at % (unsigned)a.pose7_slots) * a.batch * 7;
+                }
+                for (int i = 0; i < 4; ++i) row[i] = qn[i];
+                for (int i = 0; i < 3; ++i) row[4 + i] = t[i];
             }
         }
         if (with_warp) {

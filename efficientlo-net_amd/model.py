@@ -12,7 +12,7 @@ import time
 
 import torch
 
-from . import fused, model_util, perm, pwclo_model, tf_util
+from . import _ops, fused, model_util, perm, pwclo_model, tf_util
 
 
 def distinct_queue_streams(device, want, candidates=16, cycles=500_000):
@@ -87,7 +87,7 @@ class PWCLONet:
                                              bn_decay, aug_frame)
 
     # -- HIP graph -----------------------------------------------------------
-    def capture(self, batch_size, H_input, W_input, warmup=3, lanes=1, num_points=None, point_stride=3):
+    def capture(self, batch_size, H_input, W_input, warmup=3, lanes=1, num_points=None, point_stride=3, pose_ring=0):
         """Record the inference forward into `lanes` independent hipGraphs (torch.cuda.CUDAGraph on ROCm).
         With `num_points` the graph starts from RAW clouds: a lane owns a (B, 2*num_points, point_stride) cloud buffer
         and records the input stage (model_util.input_stage: 35 m crop + both projections, no augmentation) in front
@@ -98,7 +98,11 @@ class PWCLONet:
         replays on one of the streams `distinct_queue_streams` found (one per hardware queue; lanes beyond
         the number of queues share streams round-robin, so use a multiple of the queue count, 4: with 6 lanes two
         queues carry twice the work of the others, 5210 instead of 6030 pairs/s); the weights are shared.
-        `lanes=1` is the plain single-stream replay."""
+        `lanes=1` is the plain single-stream replay.
+
+        `pose_ring=R` (>= 2): a lane's pose output is a ring of R rows blocks instead of one (B,7) block -- replay r of the
+        lane writes slot r % R (the l0 pose-head kernel keeps the cursor on the device), so a stream of pairs is not
+        followed by one copy-out launch per pair: `lane_poses(lane)` returns the rows written since `reset_poses(lane)`."""
         dev = self.device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -120,7 +124,8 @@ class PWCLONet:
         for i in range(lanes):
             both = zeros()
             lane = {"stream": streams[i % len(streams)], "pair": both, "in": (both[:batch_size], both[batch_size:]),
-                    "graph": torch.cuda.CUDAGraph(), "pose": torch.zeros((batch_size, 7), device=dev)}
+                    "graph": torch.cuda.CUDAGraph(), "replays": 0,
+                    "pose": _ops.PoseRing(pose_ring, batch_size, dev) if pose_ring else torch.zeros((batch_size, 7), device=dev)}
             if num_points is not None:
                 lane["cloud"] = torch.zeros((batch_size, 2 * num_points, point_stride), device=dev)
             with torch.cuda.graph(lane["graph"]):
@@ -168,6 +173,7 @@ class PWCLONet:
                 lane["in"][0].copy_(xyz_f1_proj, non_blocking=True)
                 lane["in"][1].copy_(xyz_f2_proj, non_blocking=True)
             lane["graph"].replay()
+        lane["replays"] += 1
         return lane["out"]
 
     def submit_points(self, lane_index, point_cloud):
@@ -177,11 +183,33 @@ class PWCLONet:
         with torch.cuda.stream(lane["stream"]):
             lane["cloud"].copy_(point_cloud, non_blocking=True)
             lane["graph"].replay()
+        lane["replays"] += 1
         return lane["out"]
 
     def lane_pose(self, lane_index):
-        """The lane's (B,7) [l0_q_norm | l0_t] block, written by the l0 pose-head kernel of its last replay."""
-        return self._lanes[lane_index]["pose"]
+        """The lane's (B,7) [l0_q_norm | l0_t] block, written by the l0 pose-head kernel of its last replay
+        (capture(..., pose_ring=R): the slot of the last replay)."""
+        lane = self._lanes[lane_index]
+        pose = lane["pose"]
+        if isinstance(pose, _ops.PoseRing):
+            return pose.rows[(lane["replays"] - 1) % pose.slots]
+        return pose
+
+    def reset_poses(self, lane_index):
+        """Pose ring of the lane back to slot 0 (enqueued on the lane's stream)."""
+        lane = self._lanes[lane_index]
+        with torch.cuda.stream(lane["stream"]):
+            lane["pose"].reset()
+        lane["replays"] = 0
+
+    def lane_poses(self, lane_index):
+        """(n,B,7): the rows of the lane's replays since reset_poses (n <= R, oldest first); a view of the ring, valid
+        once the lane's stream has been synchronised or waited on."""
+        lane = self._lanes[lane_index]
+        ring, n = lane["pose"], lane["replays"]
+        if n > ring.slots:
+            raise RuntimeError("%d replays since reset_poses() on a ring of %d slots: rows were overwritten" % (n, ring.slots))
+        return ring.rows[:n]
 
     def lane_stream(self, lane_index):
         return self._lanes[lane_index]["stream"]

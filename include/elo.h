@@ -237,6 +237,12 @@ typedef struct elo_pose_head_args {
     long clear_cells;             /* batch*H*W of that call */
     int clear_C;
     int feat_dtype;               /* ELO_F32 / ELO_F16: storage of feature, weight and of clear_feat (C, clear_C even for fp16) */
+    /* pose7 as a RING, for a launch that is replayed from a captured graph (fixed pointers): with pose7_slots > 1 and
+     * pose7_cursor != NULL, pose7 is (pose7_slots,batch,7); batch element b's row goes to slot pose7_cursor[b] % pose7_slots
+     * and pose7_cursor[b] is incremented (by the one thread that writes the row).  A stream of frame pairs then needs no
+     * copy-out per pair: the caller drains the ring every pose7_slots replays (and may reset the cursors to 0). */
+    int pose7_slots;
+    unsigned *pose7_cursor;       /* (batch) or NULL */
 } elo_pose_head_args;
 int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream);
 

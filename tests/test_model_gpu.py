@@ -255,3 +255,42 @@ def test_stale_graph_refuses_to_replay():
     net.perms.reshuffle()
     with pytest.raises(RuntimeError, match="stale"):
         net.replay()
+
+
+def test_pose_ring_keeps_every_replay_of_a_lane():
+    """capture(..., pose_ring=R): the l0 pose-head kernel writes replay r of a lane into slot r % R of the lane's ring
+    (cursor on the device, include/elo.h pose7_slots / pose7_cursor), so a stream of pairs needs no copy-out launch per
+    pair.  The rows equal the eager forward's [l0_q_norm | l0_t] of the same pairs (1e-5: the per-operator path's
+    atomics do not add in a fixed order), in submission order, on every lane; reset_poses() starts over at slot 0; reading
+    more replays than slots raises."""
+    model, synth = load_pkg("model"), load_pkg("synth")
+    B, H, W, lanes, R = 2, 64, 900, 2, 3
+    pairs = []
+    for i in range(5):
+        f1, f2 = synth.frame_pair(B, H, W, seed=50 + i)
+        pairs.append((torch.from_numpy(f1).to(DEV), torch.from_numpy(f2).to(DEV)))
+    net = model.PWCLONet(DEV, seed=2)
+    want = []
+    for a, b in pairs:
+        out = net.forward(a, b)
+        want.append(torch.cat([out[0], out[1]], -1).clone())
+    net.capture(B, H, W, lanes=lanes, pose_ring=R)
+    for rnd in range(2):                                   # the second round checks reset_poses
+        for lane in range(lanes):
+            net.reset_poses(lane)
+        order = [0, 1, 2, 3, 4]                             # lane = i % lanes: lane 0 gets pairs 0, 2, 4; lane 1 gets 1, 3
+        for i in order:
+            net.submit(i % lanes, *pairs[i])
+        torch.cuda.synchronize()
+        for lane in range(lanes):
+            rows = net.lane_poses(lane)
+            mine = [i for i in order if i % lanes == lane]
+            assert rows.shape == (len(mine), B, 7)
+            for r, i in zip(rows, mine):
+                assert torch.allclose(r, want[i], atol=1e-5, rtol=0)
+            assert torch.allclose(net.lane_pose(lane), want[mine[-1]], atol=1e-5, rtol=0)
+    net.submit(0, *pairs[0])                                # a fourth replay on a ring of 3
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="overwritten"):
+        net.lane_poses(0)
+    assert torch.allclose(net.lane_pose(0), want[0], atol=1e-5, rtol=0)          # ... which wrapped around into slot 0
