@@ -227,7 +227,7 @@ def cost_volume_leg(dev, net, B, H_in, W_in, half, reps=20):
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b), "us": round(tot_s * 1e6, 2),
             "target_us_at_60pct": round(tot_b / (0.6 * HBM_PEAK_GBS * 1e9) * 1e6, 1),
             "mfma": {"executed_TFLOPs": round(tfs, 1), "peak": F16_MFMA_PEAK_TFLOPS,
-                     "frac": round(tfs / F16_MFMA_PEAK_TFLOPS, 5), "issued_as": "v_mfma_f32_16x16x16_f16 x3 per 16-k block"},
+                     "frac": round(tfs / F16_MFMA_PEAK_TFLOPS, 5), "issued_as": "v_mfma_f32_16x16x32_f16 x3 per 32-k pair (v_mfma_f32_16x16x16_f16 x3 on a 16-k tail)"},
             "levels": levels}
 
 
@@ -295,7 +295,8 @@ def roofline_leg(args, dev, net, reps=50):
            "us_per_launch": round(sec * 1e6, 3), "algorithmic_bytes_per_launch": int(nbytes),
            "mfma": {"executed_TFLOPs": round(ex * flops / sec / 1e12, 2), "algorithmic_TFLOPs": round(flops / sec / 1e12, 2),
                     "peak": F16_MFMA_PEAK_TFLOPS, "frac": round(ex * flops / sec / 1e12 / F16_MFMA_PEAK_TFLOPS, 5),
-                    "issued_as": "v_mfma_f32_16x16x16_f16 x%d per 16-k block (%s)" % (
+                    "issued_as": "v_mfma_f32_16x16x32_f16 x%d per 32-k pair, v_mfma_f32_16x16x16_f16 x%d on a 16-k tail (%s)" % (
+                        ex,
                         ex, "fp16 hi+lo split operands, fp32 accumulate" if ex == 3 else "fp16-rounded operands")}}
     if (args.height, args.width) == (64, 1800):
         out["cost_volume_b8_f32"] = cost_volume_leg(dev, net, 8, args.height, args.width, False)

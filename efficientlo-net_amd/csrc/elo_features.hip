@@ -9,6 +9,7 @@
 // along the channel axis, so every gathered feature row is read as one
 // contiguous segment and every output row is written as one.  The dense 1x1
 // convolutions between them are GEMMs and stay with hipBLASLt.
+#include <type_traits>
 #include "elo_common.h"
 #include "elo_project_device.h"
 
@@ -502,17 +503,20 @@ __device__ __forceinline__ void clear_projection(const ProjectionClear &c)
     }
 }
 
-__device__ __forceinline__ float feat_at(const void *p, long i, int f16)
-{
-    return f16 ? (float)reinterpret_cast<const _Float16 *>(p)[i] : reinterpret_cast<const float *>(p)[i];
-}
-
-__global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_partial_kernel(const void *__restrict__ feature,
-                                                                          const void *__restrict__ weight,
+// F16 is a template parameter: with the storage type behind a run-time flag every load sat under a (uniform) branch, and
+// a conditional load costs a full s_waitcnt vmcnt(0) -- the 16 rows a wave has "in flight" became 32 dependent round
+// trips (14 us per launch at batch 8 with fp16 features, whatever the grid size: profiles/r02_c3_summary.json).
+template <bool F16>
+__global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_partial_kernel(const void *__restrict__ feature_,
+                                                                          const void *__restrict__ weight_,
                                                                           const float *__restrict__ xyz, int npoints,
                                                                           int C, int parts, float *scratch,
-                                                                          const ProjectionClear clear, const int f16)
+                                                                          const ProjectionClear clear)
 {
+    typedef typename std::conditional<F16, _Float16, float>::type feat_t;
+    const feat_t *__restrict__ feature = reinterpret_cast<const feat_t *>(feature_);
+    const feat_t *__restrict__ weight = reinterpret_cast<const feat_t *>(weight_);
+    auto ex = [](float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896f); };      // v_exp_f32 (as the poolings)
     __shared__ float part[3][ROWS_PER_BLOCK][ELO_WAVE];
     clear_projection(clear);
     const int slice = blockIdx.x, b = blockIdx.y, lane = threadIdx.x % ELO_WAVE, wave = threadIdx.x / ELO_WAVE;
@@ -535,23 +539,26 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_partial_kernel(const 
             // plain loads, no short-circuit: a conditional load costs a full s_waitcnt vmcnt(0) each (measured: the
             // `a && b && c` form of the zero test serialised three round trips per row)
             const float px = p[nn * 3 + 0], py = p[nn * 3 + 1], pz = p[nn * 3 + 2];
-            l[u] = feat_at(weight, fbase + (long)nn * C + cc, f16);
-            v[u] = feat_at(feature, fbase + (long)nn * C + cc, f16);
+            l[u] = (float)weight[fbase + (long)nn * C + cc];
+            v[u] = (float)feature[fbase + (long)nn * C + cc];
             ok[u] = (n < hi) & live & !((px == 0.0f) & (py == 0.0f) & (pz == 0.0f));
         }
+        // the batch's own softmax first (16 independent exponentials, no branch), then ONE merge into the running triple
+        float bm = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < SV_ROWS; ++u) {
-            if (!ok[u]) continue;
-            if (l[u] > mx) {
-                const float sc = expf(mx - l[u]);      // exp(-inf) = 0 on the first valid point
-                den = den * sc + 1.0f;
-                acc = acc * sc + v[u];
-                mx = l[u];
-            } else {
-                const float e = expf(l[u] - mx);
-                den += e;
-                acc += e * v[u];
+        for (int u = 0; u < SV_ROWS; ++u) bm = ok[u] ? fmaxf(bm, l[u]) : bm;
+        if (bm > -INFINITY) {
+            float d16 = 0.0f, a16 = 0.0f;
+#pragma unroll
+            for (int u = 0; u < SV_ROWS; ++u) {
+                const float e = ok[u] ? ex(l[u] - bm) : 0.0f;
+                d16 += e;
+                a16 += e * v[u];
             }
+            const float m2 = fmaxf(mx, bm), s0 = ex(mx - m2), s1 = ex(bm - m2);     // exp2(-inf) = 0 on the first batch
+            den = den * s0 + d16 * s1;
+            acc = acc * s0 + a16 * s1;
+            mx = m2;
         }
     }
     part[0][wave][lane] = mx; part[1][wave][lane] = den; part[2][wave][lane] = acc;
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_partial_kernel(const 
         float D = 0.0f, A = 0.0f;
         for (int i = 0; i < ROWS_PER_BLOCK; ++i) {
             if (part[1][i][lane] == 0.0f) continue;   // that wave saw no valid point
-            const float sc = expf(part[0][i][lane] - M);
+            const float sc = ex(part[0][i][lane] - M);
             D += part[1][i][lane] * sc;
             A += part[2][i][lane] * sc;
         }
@@ -1076,9 +1083,9 @@ extern "C" int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t s
     ELO_REQUIRE(a->feature && a->weight && a->xyz && a->out && a->scratch, who, "null tensor pointer");
     if (a->batch == 0) return ELO_OK;
     const int parts = sv_parts(a->npoints);
-    hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
+    hipLaunchKernelGGL(softmax_valid_partial_kernel<false>, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
                        dim3(ELO_BLOCK), 0, (hipStream_t)stream, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
-                       a->scratch, ProjectionClear{nullptr, nullptr, nullptr, 0, 0, 0}, 0);
+                       a->scratch, ProjectionClear{nullptr, nullptr, nullptr, 0, 0, 0});
     hipLaunchKernelGGL(softmax_valid_merge_kernel, dim3((a->batch * a->C + ELO_BLOCK - 1) / ELO_BLOCK), dim3(ELO_BLOCK),
                        0, (hipStream_t)stream, a->scratch, a->batch, a->C, parts, a->out);
     return check_launch(who);
@@ -1124,10 +1131,15 @@ static int pose_head_impl(const elo_pose_head_args *a, const elo_warp_project_ar
     if (a->batch == 0) return ELO_OK;
     hipStream_t s = (hipStream_t)stream;
     const int parts = sv_parts(a->npoints);
-    hipLaunchKernelGGL(softmax_valid_partial_kernel, dim3(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE),
-                       dim3(ELO_BLOCK), 0, s, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
-                       a->scratch, ProjectionClear{a->clear_scratch, a->clear_xyz, (unsigned *)a->clear_feat, a->clear_cells,
-                                                   f16 ? a->clear_C / 2 : a->clear_C, a->batch}, f16);
+    const ProjectionClear clear{a->clear_scratch, a->clear_xyz, (unsigned *)a->clear_feat, a->clear_cells,
+                                f16 ? a->clear_C / 2 : a->clear_C, a->batch};
+    const dim3 pgrid(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE);
+    if (f16)
+        hipLaunchKernelGGL(softmax_valid_partial_kernel<true>, pgrid, dim3(ELO_BLOCK), 0, s, a->feature, a->weight, a->xyz,
+                           a->npoints, a->C, parts, a->scratch, clear);
+    else
+        hipLaunchKernelGGL(softmax_valid_partial_kernel<false>, pgrid, dim3(ELO_BLOCK), 0, s, a->feature, a->weight, a->xyz,
+                           a->npoints, a->C, parts, a->scratch, clear);
     const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (ELO_BLOCK / ELO_WAVE) + 3 * 4 * 64);
     const unsigned xb = w ? (unsigned)((w->npoints + ELO_BLOCK - 1) / ELO_BLOCK) : 1u;
     hipLaunchKernelGGL(pose_head_kernel, dim3(xb, a->batch), dim3(ELO_BLOCK), lds, s, *a, parts, wv, w ? 1 : 0);

@@ -412,15 +412,22 @@ int elo_warp_project_backward(const elo_warp_project_bwd_args *a, elo_stream_t s
  * They compute what the unfused kernels above + the hipBLASLt GEMMs compute,
  * for the launch-bound small-batch regime.
  *
- * A layer is  y = act(x[K] @ W[K,N] + b[N]).  `w_packed` is W zero-padded to
- * (Kp = ceil16(K), Np = ceil16(N)) and stored in MFMA fragment order: 16 bytes per (cb, ks, lane),
- *     element s = 0..3  <->  W[ks*16 + 4*(lane>>4) + s][cb*16 + (lane&15)]
- * so that one wave-wide 16-byte load is a contiguous 1 KiB.  The 16 bytes hold the four weights SPLIT into fp16
- * hi + lo, [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] with hi = fp16(w), lo = fp16(w - hi): the kernels compute
- * hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x16_f16 with fp32 accumulation (2^-20 relative per product; fp16 range:
- * |x| < 65504 saturates -- see ELO_RANGE_CHECK below).  Activations are split the same way ONCE, by the layer (or the
- * gather) that produces them, and live in the LDS tile as [hi x4 | lo x4] per four consecutive columns.
- * (A library built with -DELO_DENSE_F32 expects four fp32 weights instead and uses v_mfma_f32_16x16x4_f32.)
+ * A layer is  y = act(x[K] @ W[K,N] + b[N]).  `w_packed` is W zero-padded to (Kp = ceil16(K), Np = ceil16(N)) and stored
+ * in MFMA fragment order, every weight SPLIT into fp16 hi + lo (hi = fp16(w), lo = fp16(w - hi)): the kernels compute
+ * hi*hi + hi*lo + lo*hi on the fp16 matrix cores with fp32 accumulation (2^-20 relative per product; fp16 range:
+ * |x| < 65504 saturates -- see ELO_RANGE_CHECK below).  With KS = Kp / 16 blocks of 16 k and lane = 16*kq + n, the
+ * fragment element (cb, ks, lane, s) is  W[ks*16 + 4*kq + s][cb*16 + n],  s = 0..3.  Per column block cb (contiguous,
+ * KS * 1 KiB) the K axis is laid out as
+ *     KS / 2 PAIRS of 32 k  (v_mfma_f32_16x16x32_f16), pair p = blocks 2p and 2p+1:
+ *         1 KiB of hi8: per lane the eight halves  hi(cb, 2p, lane, 0..3), hi(cb, 2p+1, lane, 0..3)   (16 bytes),
+ *         1 KiB of lo8: the same eight elements' lo halves,
+ *     then, for odd KS, one TAIL of 16 k  (v_mfma_f32_16x16x16_f16), block KS-1:
+ *         1 KiB: per lane  [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3]  (16 bytes),
+ * so that every wave-wide 16-byte load is a contiguous 1 KiB.  ELO_PRODUCTS_HALF keeps only the round-to-nearest
+ * halves: 1 KiB per pair (8 halves per lane), 512 bytes per tail.  Activations are split the same way ONCE, by the
+ * layer (or the gather) that produces them, and live in the LDS tile as [hi x4 | lo x4] per four consecutive columns.
+ * (A library built with -DELO_DENSE_F32 expects KS blocks of four fp32 weights per lane instead -- element order as
+ * above, no pairs -- and uses v_mfma_f32_16x16x4_f32.)
  * `bias` has Np fp32 entries (zero padded).  Packing is done once per parameter update by the host
  * (efficientlo-net_amd/fused.py).
  *
@@ -436,7 +443,7 @@ int elo_warp_project_backward(const elo_warp_project_bwd_args *a, elo_stream_t s
  * ------------------------------------------------------------------------- */
 enum { ELO_PRODUCTS_SPLIT = 0,      /* fp32-class: hi/lo split operands, three fp16 MFMA products (default)     */
        ELO_PRODUCTS_HALF = 1 };     /* fp16 arithmetic: operands rounded to nearest fp16, ONE product, fp32 accumulate;
-                                       `w_packed` then holds 8 bytes per (cb, ks, lane): the four weights as fp16.
+                                       `w_packed` then holds the halves only (pairs / tail as above, half the bytes).
                                        All layers of one launch must use the same mode.  (BASELINE configs[2].)   */
 
 typedef struct elo_dense {

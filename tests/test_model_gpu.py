@@ -42,11 +42,18 @@ def test_full_pyramid_matches_oracle(B, H, W):
     randomise(net.store, seed=7)
     got = net.forward(a, b)
     torch.cuda.synchronize()
-    want = O.get_model_from_projection(export(net.store), shuffle_fn, f1, f2)
-    names = ["l0_q", "l0_t", "l1_q", "l1_t", "l2_q", "l2_t", "l3_q", "l3_t", "l0_xyz_f1"]
-    for n, g, w_ in zip(names, got, want):
+    # protocol of the batch-8 test below (see the comment there): every level against the oracle warped by the SAME coarse
+    # poses at north_star's 1e-4; the coarse level also free-running; the free-running refinement levels only bounded --
+    # one projection cell or neighbour decided the other way (a 1e-7 difference upstream is enough: this case passed
+    # free-running at 1e-4 until softmax_valid moved from expf to the hardware exp2, then showed 3.6e-4 at l0) is not a
+    # parity defect and not bounded by a tolerance
+    params = export(net.store)
+    free = O.get_model_from_projection(params, shuffle_fn, f1, f2)
+    forced = _forced(params, f1, f2, got)
+    for n, g, fr, fo in zip(NAMES, got, free, forced):
         assert torch.isfinite(g).all(), n
-        close(g, w_, atol=1e-4, rtol=1e-4)
+        close(g, fo, atol=1e-4, rtol=1e-4)
+        close(g, fr, atol=1e-4 if n.startswith("l3") or n == "l0_xyz_f1" else FREE_RUNNING_TOL, rtol=1e-4 if n.startswith("l3") else 0)
     # variable names/shapes are those of the shipped checkpoint index
     shapes = net.store.tf_shapes
     assert shapes["sa1/layer0/conv0/weights"] == (1, 1, 6, 8)
