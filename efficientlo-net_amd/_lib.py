@@ -93,6 +93,19 @@ WarpProjectBwdArgs = _struct("elo_warp_project_bwd_args", [
     ("xyz", _vp), ("q", _vp), ("t", _vp), ("scratch", _vp), ("grad_out_xyz", _vp), ("grad_out_feat", _vp),
     ("grad_warped", _vp), ("grad_xyz", _vp), ("grad_feat", _vp), ("grad_q", _vp), ("grad_t", _vp)])
 
+BnStatsArgs = _struct("elo_bn_stats_args", [
+    ("rows", ctypes.c_long), ("C", _i), ("z", _vp), ("scratch", _vp), ("eps", _f), ("momentum", _f), ("mean", _vp), ("invstd", _vp),
+    ("running_mean", _vp), ("running_var", _vp)])
+BnApplyArgs = _struct("elo_bn_apply_args", [
+    ("rows", ctypes.c_long), ("C", _i), ("z", _vp), ("mean", _vp), ("invstd", _vp), ("gamma", _vp), ("beta", _vp), ("relu", _i),
+    ("y", _vp)])
+BnBackwardArgs = _struct("elo_bn_backward_args", [
+    ("rows", ctypes.c_long), ("C", _i), ("dy", _vp), ("z", _vp), ("mean", _vp), ("invstd", _vp), ("gamma", _vp), ("beta", _vp),
+    ("relu", _i), ("scratch", _vp), ("sums", _vp), ("dz", _vp)])
+WeightGradArgs = _struct("elo_weight_grad_args", [
+    ("rows", ctypes.c_long), ("Cin", _i), ("Cout", _i), ("x", _vp), ("g", _vp), ("dW", _vp), ("db", _vp), ("scratch", _vp)])
+BN_MAX_PARTS = 512     # ELO_BN_MAX_PARTS
+
 Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i), ("w_plain", _vp),
                               ("products", _i)])
 _l = ctypes.c_long
@@ -146,6 +159,11 @@ SYMBOLS = [
     ("elo_masked_softmax_pool_backward", ctypes.c_int, [ctypes.POINTER(SoftmaxPoolBwdArgs), _vp]),
     ("elo_softmax_valid_backward", ctypes.c_int, [ctypes.POINTER(SoftmaxValidBwdArgs), _vp]),
     ("elo_warp_project_backward", ctypes.c_int, [ctypes.POINTER(WarpProjectBwdArgs), _vp]),
+    ("elo_bn_stats", ctypes.c_int, [ctypes.POINTER(BnStatsArgs), _vp]),
+    ("elo_bn_apply", ctypes.c_int, [ctypes.POINTER(BnApplyArgs), _vp]),
+    ("elo_bn_backward", ctypes.c_int, [ctypes.POINTER(BnBackwardArgs), _vp]),
+    ("elo_dense_weight_grad", ctypes.c_int, [ctypes.POINTER(WeightGradArgs), _vp]),
+    ("elo_weight_grad_slices", ctypes.c_int, [ctypes.c_long, ctypes.c_int, ctypes.c_int]),
     ("elo_setconv_fused", ctypes.c_int, [ctypes.POINTER(SetconvArgs), _vp]),
     ("elo_mlp_fused", ctypes.c_int, [ctypes.POINTER(MlpArgs), _vp]),
     ("elo_setconv_fused2", ctypes.c_int, [ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
@@ -162,7 +180,7 @@ class EloError(RuntimeError):
     pass
 
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 def lib():

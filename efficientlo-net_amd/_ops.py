@@ -491,3 +491,65 @@ def _warp_project(xyz, feat, q, t, H, W, buffers=None):
     buffers.cleared = False                               # single use: the outputs now hold this call's result
     L.call("elo_warp_project", a, out_xyz)
     return warped, out_xyz, out_feat
+
+
+# ---- training layer: conv2d -> batch norm (batch statistics) -> ReLU (utils/tf_util.py:120-185, :512-563) ----------
+def dense_bn_supported(x2, cout):
+    """The row-reduction kernels of csrc/elo_train.hip take fp32 (rows, C) matrices on the GPU with C a power of two in 4..256."""
+    return x2.is_cuda and x2.dtype == torch.float32 and 4 <= cout <= 256 and cout & (cout - 1) == 0 and x2.shape[0] > 0
+
+
+class _DenseBN(torch.autograd.Function):
+    """y = act(batch_norm(x @ W + b)) with batch statistics.  The two dense products (forward, dx) are library GEMMs; every
+    pass OVER THE ROWS -- the batch moments, the normalisation, the two sums of batch norm's backward, dz, the weight
+    gradient x^T dz and the bias gradient -- is a hand-written kernel (elo_bn_stats / elo_bn_apply / elo_bn_backward /
+    elo_dense_weight_grad).  Saved for backward: x, W, the pre-normalisation z and the (C) moments; the ReLU mask is
+    recomputed from z.  The moving averages are updated in place exactly as F.batch_norm(training=True) does."""
+
+    @staticmethod
+    def forward(ctx, x2, W, b, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        x2 = x2.contiguous()
+        z = torch.addmm(b, x2, W)
+        M, C = z.shape
+        dev = z.device
+        scratch = torch.empty((L.BN_MAX_PARTS * 2 * C,), dtype=torch.float32, device=dev)
+        mean = torch.empty((C,), dtype=torch.float32, device=dev)
+        invstd = torch.empty((C,), dtype=torch.float32, device=dev)
+        g, bt = gamma.detach().contiguous(), beta.detach().contiguous()
+        L.call("elo_bn_stats", L.BnStatsArgs(M, C, z.data_ptr(), scratch.data_ptr(), float(eps), float(momentum), mean.data_ptr(),
+                                             invstd.data_ptr(), running_mean.data_ptr(), running_var.data_ptr()), z)
+        y = torch.empty_like(z)
+        L.call("elo_bn_apply", L.BnApplyArgs(M, C, z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g.data_ptr(), bt.data_ptr(),
+                                             1 if relu else 0, y.data_ptr()), z)
+        ctx.save_for_backward(x2, W, z, mean, invstd, g, bt)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, z, mean, invstd, g, bt = ctx.saved_tensors
+        (dy,) = _f32(dy)
+        M, C = z.shape
+        dev = z.device
+        scratch = torch.empty((L.BN_MAX_PARTS * 2 * C,), dtype=torch.float32, device=dev)
+        sums = torch.empty((2 * C,), dtype=torch.float32, device=dev)
+        dz = torch.empty_like(z)
+        L.call("elo_bn_backward", L.BnBackwardArgs(M, C, dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g.data_ptr(),
+                                                   bt.data_ptr(), 1 if ctx.relu else 0, scratch.data_ptr(), sums.data_ptr(),
+                                                   dz.data_ptr()), z)
+        dbeta, dgamma = sums[:C], sums[C:]
+        dx = dz @ W.t() if ctx.needs_input_grad[0] else None
+        cin = W.shape[0]
+        dW = torch.empty_like(W, memory_format=torch.contiguous_format)
+        db = torch.empty((C,), dtype=torch.float32, device=dev)
+        slices = L.lib().elo_weight_grad_slices(M, cin, C)
+        wscratch = torch.empty((slices * (cin * C + C),), dtype=torch.float32, device=dev)
+        L.call("elo_dense_weight_grad", L.WeightGradArgs(M, cin, C, x2.data_ptr(), dz.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                                                         wscratch.data_ptr()), z)
+        return dx, dW, db, dgamma, dbeta, None, None, None, None, None
+
+
+def dense_bn(x2, W, b, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    """(rows, Cin) -> (rows, Cout): the training layer on the kernels above (dense_bn_supported(x2, Cout) must hold)."""
+    L.require_gpu(x2, W, gamma, running_mean)
+    return _DenseBN.apply(x2, W, b, gamma, beta, running_mean, running_var, momentum, eps, relu)

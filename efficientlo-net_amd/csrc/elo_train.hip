@@ -1,0 +1,443 @@
+// elo_train.hip -- the row reductions of a TRAINING 1x1 convolution + batch norm (+ ReLU), gfx950.
+//
+// A training layer of the reference is conv2d -> batch norm with BATCH statistics -> ReLU (utils/tf_util.py:120-185,
+// :512-563) on a (rows, C) matrix with rows = B*N*K up to ~10^6 and C = 8 ... 256.  Its dense products are small;
+// what costs time are the reductions OVER THE ROWS: the batch moments, the two sums batch norm's backward needs, and the
+// weight gradient X^T dZ -- in the library kernels torch dispatches to for these shapes 4.8 + 5.1 + ~14 ms of a 49 ms
+// training step at batch 8 (tools/train_kernel_stats.py).  All of them stream (rows, C) once; the kernels below do that
+// at HBM speed:
+//   elo_bn_stats            sum, sum of squares per channel (per-block fp32 partials, combined in fp64 in a fixed order),
+//                           then mean / 1/sqrt(var + eps) and the moving-average update of F.batch_norm(training=True)
+//   elo_bn_apply            y = act(gamma * (z - mean) * invstd + beta)
+//   elo_bn_backward_reduce  g = dy * [pre-activation > 0];  sum g, sum g * xhat per channel  (= d beta, d gamma)
+//   elo_bn_backward_apply   dz = gamma * invstd * (g - sum_g / M - xhat * sum_gx / M)
+//   elo_dense_weight_grad   dW = X^T dZ on v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulate), db = column sums of dZ
+// C must be a power of two in 4 .. 256 for the four batch-norm kernels (every batch-normalised width of the model).
+// No atomics anywhere: every reduction is per-block partials + a fixed-order combine, so a training step is
+// reproducible bit for bit (Trainer.save / load resumes exactly), and nothing serialises on one L2 address (the first
+// version added fp64 / fp32 atomics per block: 1800 blocks x 16 same-address atomics made bn_stats 46 us a call and the
+// weight gradient 154 us, no faster than the library kernels they replaced).
+#include <hip/hip_runtime.h>
+
+#include <initializer_list>
+#include "elo_common.h"
+
+namespace elo {
+namespace {
+
+constexpr int TB = 256;                 // threads per block
+constexpr int ROW_UNROLL = 8;           // 16-byte loads in flight per thread and tensor
+
+__device__ __forceinline__ float4 ld4(const float *p, long i) { return reinterpret_cast<const float4 *>(p)[i]; }
+
+// block-wide reduction of per-thread float4 partials that belong to column group (tid % q): the TB / q threads of a
+// column group add up through LDS, the first q threads return the totals
+__device__ __forceinline__ float4 reduce_groups(float4 v, int q, float4 *lds)
+{
+    const int tid = threadIdx.x;
+    __syncthreads();
+    lds[tid] = v;
+    __syncthreads();
+    float4 t{0.f, 0.f, 0.f, 0.f};
+    if (tid < q)
+        for (int i = tid; i < TB; i += q) { const float4 o = lds[i]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+    return t;
+}
+
+// partial sums of block b: part[b][0..C) and part[b][C..2C)
+__device__ __forceinline__ void put4(float *part, int C, int which, int cg, const float4 v)
+{
+    reinterpret_cast<float4 *>(part + ((size_t)blockIdx.x * 2 + which) * C)[cg] = v;
+}
+
+// channel c's two totals over `parts` partial rows, in fp64, by one wave (fixed order): valid in every lane
+__device__ __forceinline__ void combine(const float *part, int parts, int C, int c, double &t0, double &t1)
+{
+    const int lane = threadIdx.x & 63;
+    double a = 0.0, b = 0.0;
+    for (int i = lane; i < parts; i += 64) { a += (double)part[((size_t)i * 2) * C + c]; b += (double)part[((size_t)i * 2 + 1) * C + c]; }
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+    t0 = a; t1 = b;
+}
+
+// rows [r0, r1) of this block, a multiple of the rows one block iteration covers
+__device__ __forceinline__ void block_rows(long M, int rpb, long &r0, long &r1)
+{
+    const long iters = (M + rpb - 1) / rpb, per = (iters + gridDim.x - 1) / gridDim.x;
+    r0 = (long)blockIdx.x * per * rpb;
+    r1 = r0 + per * rpb < M ? r0 + per * rpb : M;
+}
+
+__global__ __launch_bounds__(TB) void bn_stats_kernel(const float *__restrict__ z, long M, int C, float *__restrict__ part)
+{
+    __shared__ float4 lds[TB];
+    const int q = C >> 2, rpb = TB / q, cg = threadIdx.x % q, rr = threadIdx.x / q;
+    long r0, r1;
+    block_rows(M, rpb, r0, r1);
+    float4 s{0.f, 0.f, 0.f, 0.f}, ss{0.f, 0.f, 0.f, 0.f};
+    for (long r = r0 + rr; r < r1; r += (long)rpb * ROW_UNROLL) {
+        float4 v[ROW_UNROLL];
+#pragma unroll
+        for (int u = 0; u < ROW_UNROLL; ++u) {
+            const long ru = r + (long)u * rpb;
+            v[u] = ld4(z, (ru < r1 ? ru : r) * q + cg);
+            if (ru >= r1) v[u] = float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < ROW_UNROLL; ++u) {
+            s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+            ss.x += v[u].x * v[u].x; ss.y += v[u].y * v[u].y; ss.z += v[u].z * v[u].z; ss.w += v[u].w * v[u].w;
+        }
+    }
+    const float4 ts = reduce_groups(s, q, lds), tss = reduce_groups(ss, q, lds);
+    if (threadIdx.x < q) { put4(part, C, 0, cg, ts); put4(part, C, 1, cg, tss); }
+}
+
+// one wave per channel: moments from the partial sums (fp64), F.batch_norm's moving averages (unbiased variance)
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict__ part, int parts, long M, int C, float eps,
+                                                        float momentum, float *__restrict__ mean, float *__restrict__ invstd,
+                                                        float *__restrict__ running_mean, float *__restrict__ running_var)
+{
+    const int c = blockIdx.x;
+    double s, ss;
+    combine(part, parts, C, c, s, ss);
+    if (threadIdx.x != 0) return;
+    const double m = s / (double)M;
+    double var = ss / (double)M - m * m;
+    var = var > 0.0 ? var : 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+}
+
+// one wave per channel: sums[c] = sum g, sums[C + c] = sum g * xhat  (= d beta, d gamma)
+__global__ __launch_bounds__(64) void bn_bwd_combine_kernel(const float *__restrict__ part, int parts, int C, float *__restrict__ sums)
+{
+    const int c = blockIdx.x;
+    double a, b;
+    combine(part, parts, C, c, a, b);
+    if (threadIdx.x == 0) { sums[c] = (float)a; sums[C + c] = (float)b; }
+}
+
+__global__ __launch_bounds__(TB) void bn_apply_kernel(const float *__restrict__ z, long n4, int C, const float *__restrict__ mean,
+                                                      const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, int relu, float *__restrict__ y)
+{
+    const int q = C >> 2;
+    const long stride = (long)gridDim.x * TB;
+    for (long i = (long)blockIdx.x * TB + threadIdx.x; i < n4; i += stride) {
+        const int cg = (int)(i % q);
+        const float4 v = ld4(z, i), m = ld4(mean, cg), s = ld4(invstd, cg), g = ld4(gamma, cg), b = ld4(beta, cg);
+        float4 o{(v.x - m.x) * s.x * g.x + b.x, (v.y - m.y) * s.y * g.y + b.y, (v.z - m.z) * s.z * g.z + b.z,
+                 (v.w - m.w) * s.w * g.w + b.w};
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        reinterpret_cast<float4 *>(y)[i] = o;
+    }
+}
+
+struct BnCol { float4 m, s, g, b; };
+
+__device__ __forceinline__ void bn_back(const float4 dy, const float4 z, const BnCol &p, int relu, float4 &g, float4 &xh)
+{
+    xh = float4{(z.x - p.m.x) * p.s.x, (z.y - p.m.y) * p.s.y, (z.z - p.m.z) * p.s.z, (z.w - p.m.w) * p.s.w};
+    g = dy;
+    if (relu) {
+        g.x = xh.x * p.g.x + p.b.x > 0.f ? dy.x : 0.f; g.y = xh.y * p.g.y + p.b.y > 0.f ? dy.y : 0.f;
+        g.z = xh.z * p.g.z + p.b.z > 0.f ? dy.z : 0.f; g.w = xh.w * p.g.w + p.b.w > 0.f ? dy.w : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(TB) void bn_bwd_reduce_kernel(const float *__restrict__ dy, const float *__restrict__ z, long M, int C,
+                                                           const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           int relu, float *__restrict__ part)
+{
+    __shared__ float4 lds[TB];
+    const int q = C >> 2, rpb = TB / q, cg = threadIdx.x % q, rr = threadIdx.x / q;
+    const BnCol p{ld4(mean, cg), ld4(invstd, cg), ld4(gamma, cg), ld4(beta, cg)};
+    long r0, r1;
+    block_rows(M, rpb, r0, r1);
+    float4 s1{0.f, 0.f, 0.f, 0.f}, s2{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = ROW_UNROLL / 2;
+    for (long r = r0 + rr; r < r1; r += (long)rpb * U) {
+        float4 a[U], b[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long ru = r + (long)u * rpb;
+            live[u] = ru < r1;
+            a[u] = ld4(dy, (live[u] ? ru : r) * q + cg);
+            b[u] = ld4(z, (live[u] ? ru : r) * q + cg);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float4 g, xh;
+            bn_back(a[u], b[u], p, relu, g, xh);
+            if (!live[u]) g = float4{0.f, 0.f, 0.f, 0.f};
+            s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+            s2.x += g.x * xh.x; s2.y += g.y * xh.y; s2.z += g.z * xh.z; s2.w += g.w * xh.w;
+        }
+    }
+    const float4 t1 = reduce_groups(s1, q, lds), t2 = reduce_groups(s2, q, lds);
+    if (threadIdx.x < q) { put4(part, C, 0, cg, t1); put4(part, C, 1, cg, t2); }
+}
+
+__global__ __launch_bounds__(TB) void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ z, long n4, long M,
+                                                          int C, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
+                                                          const float *__restrict__ sums, float *__restrict__ dz)
+{
+    const int q = C >> 2;
+    const long stride = (long)gridDim.x * TB;
+    const float inv_m = 1.0f / (float)M;
+    for (long i = (long)blockIdx.x * TB + threadIdx.x; i < n4; i += stride) {
+        const int cg = (int)(i % q);
+        const BnCol p{ld4(mean, cg), ld4(invstd, cg), ld4(gamma, cg), ld4(beta, cg)};
+        const float4 a1 = ld4(sums, cg), a2 = ld4(sums + C, cg);
+        const float4 k1{a1.x * inv_m, a1.y * inv_m, a1.z * inv_m, a1.w * inv_m}, k2{a2.x * inv_m, a2.y * inv_m, a2.z * inv_m, a2.w * inv_m};
+        float4 g, xh;
+        bn_back(ld4(dy, i), ld4(z, i), p, relu, g, xh);
+        reinterpret_cast<float4 *>(dz)[i] = float4{p.g.x * p.s.x * (g.x - k1.x - xh.x * k2.x), p.g.y * p.s.y * (g.y - k1.y - xh.y * k2.y),
+                                                   p.g.z * p.s.z * (g.z - k1.z - xh.z * k2.z), p.g.w * p.s.w * (g.w - k1.w - xh.w * k2.w)};
+    }
+}
+
+// ---- dW = X^T G ------------------------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32: A[i][k] in lane (i = l % 16, k = l / 16), B[k][j] in lane (j = l % 16, k = l / 16),
+// D[4 * (l / 16) + r][l % 16] in acc[r].  With A = X^T (i: input channel, k: one of 4 rows) and B = G (j: output channel)
+// a step consumes 4 rows.  A workgroup owns a (16 CI x 16 CO) block of dW (blockIdx.y / z) over ONE SLICE of the rows
+// (blockIdx.x); its four waves split the slice, add their accumulators up through LDS and store the slice's partial block
+// to part[slice]; weight_grad_combine_kernel then sums the slices in a fixed order.  Loads are 4 bytes per lane (4 rows x
+// 16 consecutive channels per instruction), U row groups in flight; the kernel is matrix-pipe bound for the wide layers
+// and load-issue bound for the 8-channel ones.
+template <int CI, int CO>
+__global__ __launch_bounds__(TB) void weight_grad_kernel(const float *__restrict__ x, const float *__restrict__ g, long M, int Cin,
+                                                         int Cout, float *__restrict__ part, float *__restrict__ bpart)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ float red[(TB / 64 - 1) * CI * CO * 256];
+    __shared__ float bred[(TB / 64) * CO * 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, k4 = lane >> 4;
+    const int ci0 = blockIdx.y * CI * 16, co0 = blockIdx.z * CO * 16;
+    const long groups = (M + 3) / 4, waves = (long)gridDim.x * (TB / 64), per = (groups + waves - 1) / waves;
+    const long g0 = ((long)blockIdx.x * (TB / 64) + wave) * per, g1 = g0 + per < groups ? g0 + per : groups;
+    f32x4 acc[CI][CO];
+#pragma unroll
+    for (int a = 0; a < CI; ++a)
+#pragma unroll
+        for (int b = 0; b < CO; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[CO];
+#pragma unroll
+    for (int b = 0; b < CO; ++b) bsum[b] = 0.f;
+    int xc[CI], gc[CO];
+    bool xok[CI], gok[CO];
+#pragma unroll
+    for (int a = 0; a < CI; ++a) { xc[a] = ci0 + a * 16 + i16; xok[a] = xc[a] < Cin; xc[a] = xok[a] ? xc[a] : 0; }
+#pragma unroll
+    for (int b = 0; b < CO; ++b) { gc[b] = co0 + b * 16 + i16; gok[b] = gc[b] < Cout; gc[b] = gok[b] ? gc[b] : 0; }
+    constexpr int U = CI * CO >= 8 ? 4 : 8;                        // row groups in flight (narrow layers are load-latency bound)
+    for (long gr = g0; gr < g1; gr += U) {
+        float xv[U][CI], gv[U][CO];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long row = (gr + u) * 4 + k4;
+            const bool live = gr + u < g1 && row < M;
+            const long rc = live ? row : 0;
+#pragma unroll
+            for (int a = 0; a < CI; ++a) { const float v = x[rc * Cin + xc[a]]; xv[u][a] = live && xok[a] ? v : 0.f; }
+#pragma unroll
+            for (int b = 0; b < CO; ++b) { const float v = g[rc * Cout + gc[b]]; gv[u][b] = live && gok[b] ? v : 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int a = 0; a < CI; ++a)
+#pragma unroll
+                for (int b = 0; b < CO; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][a], gv[u][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < CO; ++b) bsum[b] += gv[u][b];
+        }
+    }
+    // waves 1..3 park their accumulators in LDS, wave 0 adds them in wave order and stores the slice's partial block
+    if (wave > 0) {
+#pragma unroll
+        for (int a = 0; a < CI; ++a)
+#pragma unroll
+            for (int b = 0; b < CO; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(((wave - 1) * CI + a) * CO + b) * 256 + r * 64 + lane] = acc[a][b][r];
+    }
+#pragma unroll
+    for (int b = 0; b < CO; ++b) {
+        float v = bsum[b];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (k4 == 0) bred[(wave * CO + b) * 16 + i16] = v;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float *dst = part + (size_t)blockIdx.x * Cin * Cout;
+#pragma unroll
+        for (int a = 0; a < CI; ++a)
+#pragma unroll
+            for (int b = 0; b < CO; ++b) {
+                const int co = co0 + b * 16 + i16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[a][b][r];
+                    for (int w = 0; w < TB / 64 - 1; ++w) v += red[((w * CI + a) * CO + b) * 256 + r * 64 + lane];
+                    const int ci = ci0 + a * 16 + 4 * k4 + r;
+                    if (ci < Cin && co < Cout) dst[(size_t)ci * Cout + co] = v;
+                }
+            }
+        if (bpart && blockIdx.y == 0 && k4 == 0) {
+#pragma unroll
+            for (int b = 0; b < CO; ++b) {
+                const int co = co0 + b * 16 + i16;
+                float v = 0.f;
+                for (int w = 0; w < TB / 64; ++w) v += bred[(w * CO + b) * 16 + i16];
+                if (co < Cout) bpart[(size_t)blockIdx.x * Cout + co] = v;
+            }
+        }
+    }
+}
+
+// out[i] = sum over slices of part[slice][i] (n = Cin*Cout for dW, Cout for db).  A block owns 16 outputs; its 16 thread
+// rows take every 16th slice each (8 loads in flight), then add up through LDS in row order: up to 1024 slices of a
+// narrow layer are 8 round trips instead of 1024 dependent ones.
+__global__ __launch_bounds__(TB) void slices_combine_kernel(const float *__restrict__ part, int slices, long n, float *__restrict__ out)
+{
+    __shared__ float red[16][17];
+    const int j = threadIdx.x & 15, sr = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + j;
+    const long ic = i < n ? i : n - 1;
+    float v = 0.f;
+    for (int s = sr; s < slices; s += 16 * 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int su = s + 16 * u; t[u] = part[(size_t)(su < slices ? su : s) * n + ic]; if (su >= slices) t[u] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    red[sr][j] = v;
+    __syncthreads();
+    if (sr == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][j];
+        out[i] = t;
+    }
+}
+
+bool pow2_width(int C) { return C >= 4 && C <= 256 && (C & (C - 1)) == 0; }
+
+int grid_for(long M, int C)
+{
+    const int rpb = TB / (C >> 2);
+    const long iters = (M + rpb - 1) / rpb;
+    const long want = (iters + ROW_UNROLL - 1) / ROW_UNROLL;        // at least one unrolled trip per block
+    return (int)(want < 1 ? 1 : want > ELO_BN_MAX_PARTS ? ELO_BN_MAX_PARTS : want);
+}
+
+int check_bn(const char *who, long M, int C, std::initializer_list<const void *> ptrs)
+{
+    if (M <= 0) return fail(ELO_ERR_ARG, "%s: no rows", who);
+    if (!pow2_width(C)) return fail(ELO_ERR_LIMIT, "%s: C = %d is not a power of two in 4..256", who, C);
+    for (const void *p : ptrs)
+        if (!p || ((uintptr_t)p & 15)) return fail(ELO_ERR_ARG, "%s: null or unaligned tensor pointer", who);
+    return ELO_OK;
+}
+
+}  // namespace
+}  // namespace elo
+
+using namespace elo;
+
+extern "C" int elo_bn_stats(const elo_bn_stats_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_bn_stats";
+    if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
+    if (int rc = check_bn(who, a->rows, a->C, {a->z, a->scratch, a->mean, a->invstd})) return rc;
+    if ((a->running_mean == nullptr) != (a->running_var == nullptr)) return fail(ELO_ERR_ARG, "%s: running_mean and running_var go together", who);
+    hipStream_t s = (hipStream_t)stream;
+    const int parts = grid_for(a->rows, a->C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(parts), dim3(TB), 0, s, a->z, a->rows, a->C, a->scratch);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a->C), dim3(64), 0, s, a->scratch, parts, a->rows, a->C, a->eps, a->momentum,
+                       a->mean, a->invstd, a->running_mean, a->running_var);
+    return check_launch(who);
+}
+
+extern "C" int elo_bn_apply(const elo_bn_apply_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_bn_apply";
+    if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
+    if (int rc = check_bn(who, a->rows, a->C, {a->z, a->mean, a->invstd, a->gamma, a->beta, a->y})) return rc;
+    const long n4 = a->rows * (a->C >> 2);
+    const long blocks = (n4 + TB * 4 - 1) / (TB * 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(TB), 0, (hipStream_t)stream, a->z, n4, a->C,
+                       a->mean, a->invstd, a->gamma, a->beta, a->relu, a->y);
+    return check_launch(who);
+}
+
+extern "C" int elo_bn_backward(const elo_bn_backward_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_bn_backward";
+    if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
+    if (int rc = check_bn(who, a->rows, a->C, {a->dy, a->z, a->mean, a->invstd, a->gamma, a->beta, a->scratch, a->sums, a->dz})) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int parts = grid_for(a->rows, a->C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(parts), dim3(TB), 0, s, a->dy, a->z, a->rows, a->C, a->mean, a->invstd,
+                       a->gamma, a->beta, a->relu, a->scratch);
+    hipLaunchKernelGGL(bn_bwd_combine_kernel, dim3(a->C), dim3(64), 0, s, a->scratch, parts, a->C, a->sums);
+    const long n4 = a->rows * (a->C >> 2);
+    const long blocks = (n4 + TB * 4 - 1) / (TB * 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(TB), 0, s, a->dy, a->z, n4, a->rows, a->C,
+                       a->mean, a->invstd, a->gamma, a->beta, a->relu, a->sums, a->dz);
+    return check_launch(who);
+}
+
+// row slices of the weight gradient: enough waves to hide the load latency of the narrow layers, few enough that the
+// partial blocks stay small (<= 8 MB) and every wave has >= 32 row groups
+extern "C" int elo_weight_grad_slices(long rows, int Cin, int Cout)
+{
+    const long groups = (rows + 3) / 4;
+    long s = groups / (32 * (TB / 64)) + 1;
+    const long cap = (8l << 20) / ((long)Cin * Cout * 4);
+    s = s > 1024 ? 1024 : s;
+    s = s > cap ? cap : s;
+    return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" int elo_dense_weight_grad(const elo_weight_grad_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_dense_weight_grad";
+    if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
+    if (a->rows <= 0 || a->Cin <= 0 || a->Cout <= 0) return fail(ELO_ERR_ARG, "%s: bad sizes", who);
+    if (!a->x || !a->g || !a->dW || !a->scratch) return fail(ELO_ERR_ARG, "%s: null tensor pointer", who);
+    const int cit = (a->Cin + 15) / 16, cot = (a->Cout + 15) / 16;
+    const int slices = elo_weight_grad_slices(a->rows, a->Cin, a->Cout);
+    float *bpart = a->db ? a->scratch + (size_t)slices * a->Cin * a->Cout : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    // column blocks per workgroup: all of a <= 64-wide output (1, 2 or 4 tiles); row blocks: the count in 1..4 that pads
+    // the input width least (138 channels = 9 tiles: 3 x 3, not 3 x 4)
+    const int CO = cot >= 4 ? 4 : cot >= 2 ? 2 : 1;
+    int CI = 1;
+    for (int c = 2; c <= 4; ++c)
+        if ((cit + c - 1) / c * c <= (cit + CI - 1) / CI * CI) CI = c;
+    const dim3 grid((unsigned)slices, (unsigned)((cit + CI - 1) / CI), (unsigned)((cot + CO - 1) / CO));
+#define ELO_WG(CI_, CO_)                                                                                                      \
+    if (CI == CI_ && CO == CO_)                                                                                               \
+        hipLaunchKernelGGL((weight_grad_kernel<CI_, CO_>), grid, dim3(TB), 0, s, a->x, a->g, a->rows, a->Cin, a->Cout, a->scratch, bpart)
+    ELO_WG(1, 1); ELO_WG(1, 2); ELO_WG(1, 4); ELO_WG(2, 1); ELO_WG(2, 2); ELO_WG(2, 4);
+    ELO_WG(3, 1); ELO_WG(3, 2); ELO_WG(3, 4); ELO_WG(4, 1); ELO_WG(4, 2); ELO_WG(4, 4);
+#undef ELO_WG
+    const long n = (long)a->Cin * a->Cout;
+    hipLaunchKernelGGL(slices_combine_kernel, dim3((unsigned)((n + 15) / 16)), dim3(TB), 0, s, a->scratch, slices, n, a->dW);
+    if (a->db)
+        hipLaunchKernelGGL(slices_combine_kernel, dim3((unsigned)((a->Cout + 15) / 16)), dim3(TB), 0, s, bpart, slices, (long)a->Cout, a->db);
+    return check_launch(who);
+}

@@ -22,10 +22,14 @@ are cached per scope until VariableStore.invalidate().
 """
 import contextlib
 import math
+import os
 
 import torch
 import torch.nn.functional as Fnn
 
+from . import _ops
+
+_TRAIN_KERNELS = os.environ.get("ELO_TRAIN_KERNELS", "1") != "0"     # 0: torch's batch norm + GEMM weight gradients (comparison)
 BN_EPS = 1e-3            # tf.contrib.layers.batch_norm default (utils/tf_util.py:526-531)
 _DEFAULT_BN_DECAY = 0.9  # utils/tf_util.py:525
 
@@ -186,9 +190,15 @@ def _dense(inputs, num_output_channels, scope, tf_kernel_dims, activation_fn, bn
     x2 = inputs.reshape(-1, cin)
     training = bool(is_training) if is_training is not None else False
     if training:                                 # batch statistics, autograd (the caller's is_training decides, not the autograd mode)
+        decay = _DEFAULT_BN_DECAY if bn_decay is None else float(bn_decay)
+        if (bn and _TRAIN_KERNELS and (activation_fn is relu or activation_fn is None)
+                and _ops.dense_bn_supported(x2, num_output_channels)):
+            # the row reductions of conv -> batch norm -> ReLU on hand-written kernels (csrc/elo_train.hip)
+            y = _ops.dense_bn(x2, W, b, bn_vars[0], bn_vars[1], bn_vars[2], bn_vars[3], 1.0 - decay, BN_EPS,
+                              activation_fn is relu)
+            return y.reshape(inputs.shape[:-1] + (num_output_channels,))
         y = torch.addmm(b, x2, W)
         if bn:
-            decay = _DEFAULT_BN_DECAY if bn_decay is None else float(bn_decay)
             y = Fnn.batch_norm(y, bn_vars[2], bn_vars[3], bn_vars[0], bn_vars[1], training=training,
                                momentum=1.0 - decay, eps=BN_EPS)
         if activation_fn is not None:

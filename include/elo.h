@@ -405,6 +405,59 @@ typedef struct elo_warp_project_bwd_args {
 } elo_warp_project_bwd_args;
 int elo_warp_project_backward(const elo_warp_project_bwd_args *a, elo_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Training layer: the ROW REDUCTIONS of conv2d -> batch norm (batch statistics) -> ReLU
+ * (utils/tf_util.py:120-185 conv2d, :512-563 batch_norm_template) on a (rows, C) fp32 matrix, rows = B*N*K.
+ * The dense products themselves (z = x W + b, dx = dz W^T) stay library GEMMs; these entry points are the passes over
+ * the rows around them.  C: a power of two in 4..256 (every batch-normalised width of the model); all tensors fp32,
+ * 16-byte aligned.  Reductions are per-block partial sums in caller-provided scratch, combined in a fixed order (fp64
+ * for the batch-norm sums): no atomics, bit-reproducible.
+ * ------------------------------------------------------------------------- */
+#define ELO_BN_MAX_PARTS 512      /* partial rows of the batch-norm reductions: scratch = 2 * C * ELO_BN_MAX_PARTS floats */
+typedef struct elo_bn_stats_args {
+    long rows; int C;
+    const float *z;               /* (rows,C) */
+    float *scratch;               /* (ELO_BN_MAX_PARTS, 2, C) */
+    float eps, momentum;          /* 1e-3; 1 - bn_decay */
+    float *mean, *invstd;         /* (C) OUT: batch mean, 1/sqrt(biased batch variance + eps) */
+    float *running_mean, *running_var;   /* (C) IN/OUT or both NULL: r <- (1-momentum) r + momentum * (mean | unbiased var) */
+} elo_bn_stats_args;
+int elo_bn_stats(const elo_bn_stats_args *a, elo_stream_t stream);
+
+typedef struct elo_bn_apply_args {
+    long rows; int C;
+    const float *z, *mean, *invstd, *gamma, *beta;
+    int relu;                     /* 1: y = max(., 0) */
+    float *y;                     /* (rows,C) OUT (may alias z) */
+} elo_bn_apply_args;
+int elo_bn_apply(const elo_bn_apply_args *a, elo_stream_t stream);
+
+/* g = dy * [gamma*xhat + beta > 0] (relu = 1) or dy;  sums <- [sum g | sum g*xhat] = [d beta | d gamma];
+ * dz = gamma * invstd * (g - sum g / rows - xhat * sum g*xhat / rows)        (three launches) */
+typedef struct elo_bn_backward_args {
+    long rows; int C;
+    const float *dy, *z, *mean, *invstd, *gamma, *beta;
+    int relu;
+    float *scratch;               /* (ELO_BN_MAX_PARTS, 2, C) */
+    float *sums;                  /* (2*C) OUT [d beta | d gamma] */
+    float *dz;                    /* (rows,C) OUT (may alias dy) */
+} elo_bn_backward_args;
+int elo_bn_backward(const elo_bn_backward_args *a, elo_stream_t stream);
+
+/* dW = x^T g (Cin,Cout row-major), db = column sums of g (or NULL): fp32 operands on v_mfma_f32_16x16x4_f32, fp32
+ * accumulation per row slice, slices summed in order.  Any Cin, Cout.
+ * scratch: elo_weight_grad_slices(rows, Cin, Cout) * (Cin*Cout + Cout) floats. */
+typedef struct elo_weight_grad_args {
+    long rows; int Cin, Cout;
+    const float *x;               /* (rows,Cin)  */
+    const float *g;               /* (rows,Cout) */
+    float *dW;                    /* (Cin,Cout) OUT */
+    float *db;                    /* (Cout) OUT or NULL */
+    float *scratch;
+} elo_weight_grad_args;
+int elo_weight_grad_slices(long rows, int Cin, int Cout);
+int elo_dense_weight_grad(const elo_weight_grad_args *a, elo_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * Fused inference kernels: gather/encode -> chain of 1x1 convolutions (BN and
  * bias folded, ReLU) -> pooling, in ONE launch with the activations of a

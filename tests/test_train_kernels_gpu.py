@@ -1,0 +1,92 @@
+"""GPU: the training layer conv2d -> batch norm (batch statistics) -> ReLU on the row-reduction kernels of
+csrc/elo_train.hip (elo_bn_stats / elo_bn_apply / elo_bn_backward / elo_dense_weight_grad, through tf_util.conv2d with
+is_training=True) against the same layer written with torch in float64: outputs, the moving averages, and the gradients
+of the input, the weights, the bias, gamma and beta.  Reference: utils/tf_util.py:120-185 (conv2d), :512-563
+(batch_norm_template)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _reference(x, W, b, gamma, beta, rm, rv, momentum, eps, relu, gy, mask):
+    """`mask`: the ReLU decisions of the fp32 forward (y > 0).  The float64 reference uses THE SAME decisions: among
+    millions of pre-activations one lies within fp32 rounding of zero now and then, and a reference that decides it the
+    other way differs by that element's whole gradient (seen: 0.08 on a scale of 4.9), which says nothing about the kernels."""
+    x, W, b, gamma, beta = (t.detach().double().requires_grad_(True) for t in (x, W, b, gamma, beta))
+    z = x @ W + b
+    mean, var = z.mean(0), z.var(0, unbiased=False)
+    y = (z - mean) / torch.sqrt(var + eps) * gamma + beta
+    if relu:
+        y = y * mask.double()
+    (y * gy.double()).sum().backward()
+    M = z.shape[0]
+    new_rm = (1 - momentum) * rm.double() + momentum * mean.detach()
+    new_rv = (1 - momentum) * rv.double() + momentum * var.detach() * M / (M - 1)
+    return y.detach(), new_rm, new_rv, [t.grad for t in (x, W, b, gamma, beta)]
+
+
+@pytest.mark.parametrize("rows,cin,cout,relu", [(4096, 6, 8, True), (921, 3, 4, True), (30000, 42, 128, True), (5000, 138, 64, False),
+                                                (777, 272, 256, True), (65536, 16, 16, True), (13, 19, 32, True), (1, 8, 8, True)])
+def test_training_layer_matches_float64(rows, cin, cout, relu):
+    tf_util = load_pkg("tf_util")
+    rng = np.random.default_rng(rows + cin)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    store = tf_util.VariableStore(DEV, seed=3)
+    x = t(rng.normal(0.3, 1.5, (1, rows, 1, cin))).requires_grad_(True)
+    gy = t(rng.normal(0, 1, (rows, cout)))
+    with tf_util.default_store(store):
+        y = tf_util.conv2d(x, cout, [1, 1], scope="layer", bn=True, is_training=True, bn_decay=0.7,
+                           activation_fn=tf_util.relu if relu else None)                       # creates the variables
+        P = store.params
+        with torch.no_grad():                                                                 # non-trivial parameters
+            P["layer/biases"].copy_(t(rng.normal(0, 0.5, (cout,))))
+            P["layer/bn/gamma"].copy_(t(rng.normal(1, 0.3, (cout,))))
+            P["layer/bn/beta"].copy_(t(rng.normal(0, 0.3, (cout,))))
+        rm0, rv0 = store.buffers["layer/bn/moving_mean"].clone(), store.buffers["layer/bn/moving_variance"].clone()
+        y = tf_util.conv2d(x, cout, [1, 1], scope="layer", bn=True, is_training=True, bn_decay=0.7,
+                           activation_fn=tf_util.relu if relu else None)
+    leaves = [x, P["layer/weights"], P["layer/biases"], P["layer/bn/gamma"], P["layer/bn/beta"]]
+    for l in leaves:
+        l.grad = None
+    (y.reshape(rows, cout) * gy).sum().backward()
+    if rows > 1:
+        want_y, want_rm, want_rv, want_g = _reference(x.reshape(rows, cin), leaves[1], leaves[2], leaves[3], leaves[4], rm0, rv0, 0.3,
+                                                      tf_util.BN_EPS, relu, gy, (y.reshape(rows, cout) > 0).detach())
+        scale = lambda w: float(w.abs().max()) + 1e-6
+        assert float((y.detach().reshape(rows, cout).double() - want_y).abs().max()) <= 1e-4 * scale(want_y)
+        assert torch.allclose(store.buffers["layer/bn/moving_mean"].double(), want_rm, atol=1e-5, rtol=1e-5)
+        assert torch.allclose(store.buffers["layer/bn/moving_variance"].double(), want_rv, atol=1e-5, rtol=1e-5)
+        for name, leaf, w in zip(("x", "W", "b", "gamma", "beta"), leaves, want_g):
+            got = leaf.grad.reshape(w.shape).double()
+            tol = 1e-4 * scale(w) if name != "b" else 1e-3 * scale(want_g[4])      # db is a sum that cancels to ~0 under batch norm
+            assert float((got - w).abs().max()) <= tol, (name, float((got - w).abs().max()), scale(w))
+    else:
+        assert torch.isfinite(y).all() and all(torch.isfinite(l.grad).all() for l in leaves)
+
+
+def test_training_layer_is_what_torch_computes():
+    """The kernel path and the torch path of tf_util._dense (ELO_TRAIN_KERNELS=0: addmm + F.batch_norm + relu) agree to fp32
+    rounding on the same variables, moving averages included."""
+    tf_util = load_pkg("tf_util")
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.normal(0, 1, (2, 500, 6, 16)).astype(np.float32)).to(DEV)
+    outs = []
+    for kernels in (True, False):
+        store = tf_util.VariableStore(DEV, seed=9)
+        prev, tf_util._TRAIN_KERNELS = tf_util._TRAIN_KERNELS, kernels
+        try:
+            with tf_util.default_store(store):
+                xi = x.clone().requires_grad_(True)
+                y = tf_util.conv2d(xi, 32, [1, 1], scope="l", bn=True, is_training=True, bn_decay=0.9)
+                y.square().sum().backward()
+        finally:
+            tf_util._TRAIN_KERNELS = prev
+        outs.append((y.detach(), xi.grad, store.params["l/weights"].grad, store.params["l/bn/gamma"].grad,
+                     store.buffers["l/bn/moving_mean"].clone(), store.buffers["l/bn/moving_variance"].clone()))
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, atol=2e-4 * float(b.abs().max()), rtol=0)
