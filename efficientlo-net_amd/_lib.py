@@ -49,7 +49,7 @@ SoftmaxPoolArgs = _struct("elo_softmax_pool_args", [
 ELO_F32, ELO_F16 = 0, 1
 SoftmaxValidArgs = _struct("elo_softmax_valid_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp), ("out", _vp),
-    ("scratch", _vp)])
+    ("scratch", _vp), ("stats", _vp)])
 SV_MAX_PARTS = 64      # ELO_SV_MAX_PARTS
 PoseHeadArgs = _struct("elo_pose_head_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("hidden", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp),
@@ -87,7 +87,7 @@ SoftmaxPoolBwdArgs = _struct("elo_softmax_pool_bwd_args", [
     ("mask", _vp), ("grad_out", _vp), ("grad_logits", _vp), ("grad_values", _vp)])
 SoftmaxValidBwdArgs = _struct("elo_softmax_valid_bwd_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp), ("grad_out", _vp),
-    ("grad_feature", _vp), ("grad_weight", _vp)])
+    ("grad_feature", _vp), ("grad_weight", _vp), ("out", _vp), ("stats", _vp)])
 WarpProjectBwdArgs = _struct("elo_warp_project_bwd_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("H", _i), ("W", _i), ("az_res", _f), ("vert_res", _f), ("vert_off", _f),
     ("xyz", _vp), ("q", _vp), ("t", _vp), ("scratch", _vp), ("grad_out_xyz", _vp), ("grad_out_feat", _vp),

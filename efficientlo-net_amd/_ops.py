@@ -258,17 +258,20 @@ def _masked_softmax_pool(logits, values, mask):
 class _SoftmaxValid(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feature_bnc, weight_bnc, xyz_bn3):
-        ctx.save_for_backward(feature_bnc, weight_bnc, xyz_bn3)
-        return _softmax_valid(feature_bnc, weight_bnc, xyz_bn3)
+        B, N, C = feature_bnc.shape
+        stats = torch.empty((B, 2, C), dtype=torch.float32, device=feature_bnc.device)
+        out = _softmax_valid(feature_bnc, weight_bnc, xyz_bn3, stats)
+        ctx.save_for_backward(feature_bnc, weight_bnc, xyz_bn3, out, stats)
+        return out
 
     @staticmethod
     def backward(ctx, grad):
-        f, w, xyz = ctx.saved_tensors
+        f, w, xyz, out, stats = ctx.saved_tensors
         (grad,) = _f32(grad)
         B, N, C = f.shape
         g_f, g_w = torch.empty_like(f), torch.empty_like(w)
         a = L.SoftmaxValidBwdArgs(B, N, C, f.data_ptr(), w.data_ptr(), xyz.data_ptr(), grad.data_ptr(), g_f.data_ptr(),
-                                  g_w.data_ptr())
+                                  g_w.data_ptr(), out.data_ptr(), stats.data_ptr())
         L.call("elo_softmax_valid_backward", a, grad)
         return g_f, g_w, None
 
@@ -280,14 +283,14 @@ def softmax_valid(feature_bnc, weight_bnc, xyz_bn3):
     return _softmax_valid(feature_bnc, weight_bnc, xyz_bn3)
 
 
-def _softmax_valid(feature_bnc, weight_bnc, xyz_bn3):
+def _softmax_valid(feature_bnc, weight_bnc, xyz_bn3, stats=None):
     L.require_gpu(feature_bnc, weight_bnc, xyz_bn3)
     feature_bnc, weight_bnc, xyz_bn3 = _f32(feature_bnc, weight_bnc, xyz_bn3)
     B, N, C = feature_bnc.shape
     out = torch.empty((B, 1, C), dtype=torch.float32, device=feature_bnc.device)
     scratch = torch.empty((3 * B * L.SV_MAX_PARTS * C,), dtype=torch.float32, device=feature_bnc.device)
     a = L.SoftmaxValidArgs(B, N, C, feature_bnc.data_ptr(), weight_bnc.data_ptr(), xyz_bn3.data_ptr(), out.data_ptr(),
-                           scratch.data_ptr())
+                           scratch.data_ptr(), stats.data_ptr() if stats is not None else None)
     L.call("elo_softmax_valid", a, out)
     return out
 

@@ -242,6 +242,30 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_bwd_kernel(const elo_
     }
 }
 
+// with the forward's (maximum, denominator, out) per channel the adjoint is element-wise: thread per (point, 4 channels)
+__global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_bwd_elementwise_kernel(const elo_softmax_valid_bwd_args a)
+{
+    const int q = a.C >> 2;
+    const long per_b = (long)a.npoints * q, total = per_b * a.batch;
+    for (long i = (long)blockIdx.x * ELO_BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * ELO_BLOCK) {
+        const int b = (int)(i / per_b);
+        const long r = i - (long)b * per_b;
+        const int n = (int)(r / q), cg = (int)(r - (long)n * q);
+        const float *p = a.xyz + ((long)b * a.npoints + n) * 3;
+        const float px = p[0], py = p[1], pz = p[2];
+        const float4 w = reinterpret_cast<const float4 *>(a.weight)[i], f = reinterpret_cast<const float4 *>(a.feature)[i];
+        const float4 M = reinterpret_cast<const float4 *>(a.stats + (size_t)b * 2 * a.C)[cg];
+        const float4 D = reinterpret_cast<const float4 *>(a.stats + ((size_t)b * 2 + 1) * a.C)[cg];
+        const float4 o = reinterpret_cast<const float4 *>(a.out + (size_t)b * a.C)[cg], g = reinterpret_cast<const float4 *>(a.grad_out + (size_t)b * a.C)[cg];
+        const bool ok = !((px == 0.0f) & (py == 0.0f) & (pz == 0.0f));
+        auto soft = [&](float wv, float m, float d) { return ok && d > 0.0f ? expf(wv - m) / d : 0.0f; };
+        const float4 s{soft(w.x, M.x, D.x), soft(w.y, M.y, D.y), soft(w.z, M.z, D.z), soft(w.w, M.w, D.w)};
+        reinterpret_cast<float4 *>(a.grad_feature)[i] = float4{s.x * g.x, s.y * g.y, s.z * g.z, s.w * g.w};
+        reinterpret_cast<float4 *>(a.grad_weight)[i] = float4{s.x * (f.x - o.x) * g.x, s.y * (f.y - o.y) * g.y, s.z * (f.z - o.z) * g.z,
+                                                              s.w * (f.w - o.w) * g.w};
+    }
+}
+
 // ---------------------------------------------------------------- warp + spherical re-projection
 // forward (elo_warp_project): pts = (R(q) x + t) * keep; out_xyz[cell] += pts, out_feat[cell] += feat for the point(s)
 // holding the cell's minimum range.  backward: a winner receives its cell's gradient; then through the warp:
@@ -404,6 +428,14 @@ extern "C" int elo_softmax_valid_backward(const elo_softmax_valid_bwd_args *a, e
     ELO_REQUIRE(a->batch >= 0 && a->npoints > 0 && a->C > 0, who, "bad sizes");
     ELO_REQUIRE(a->feature && a->weight && a->xyz && a->grad_out && a->grad_feature && a->grad_weight, who, "null tensor pointer");
     if (a->batch == 0) return ELO_OK;
+    ELO_REQUIRE((a->out == nullptr) == (a->stats == nullptr), who, "out and stats go together");
+    if (a->stats && a->C % 4 == 0) {
+        const long total = (long)a->batch * a->npoints * (a->C / 4);
+        const long blocks = (total + ELO_BLOCK - 1) / ELO_BLOCK;
+        hipLaunchKernelGGL(softmax_valid_bwd_elementwise_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(ELO_BLOCK), 0,
+                           (hipStream_t)stream, *a);
+        return check_launch(who);
+    }
     hipLaunchKernelGGL(softmax_valid_bwd_kernel, dim3((a->C + ELO_WAVE - 1) / ELO_WAVE, a->batch), dim3(ELO_BLOCK), 0,
                        (hipStream_t)stream, *a);
     return check_launch(who);

@@ -595,11 +595,23 @@ __device__ __forceinline__ float sv_merge(const SvPartials &s, int b, int c, int
     return D > 0.0f ? A / D : 0.0f;
 }
 
-__global__ void softmax_valid_merge_kernel(float *scratch, int batch, int C, int parts, float *out)
+__global__ void softmax_valid_merge_kernel(float *scratch, int batch, int C, int parts, float *out, float *stats)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= batch * C) return;
-    out[i] = sv_merge(sv_partials(scratch, batch, C), i / C, i % C, C, parts);
+    const SvPartials s = sv_partials(scratch, batch, C);
+    const int b = i / C, c = i % C;
+    out[i] = sv_merge(s, b, c, C, parts);
+    if (stats) {                                       // the same merge again, keeping maximum and denominator
+        float M = -INFINITY, D = 0.0f;
+        for (int k = 0; k < parts; ++k) M = fmaxf(M, s.mx[((size_t)b * ELO_SV_MAX_PARTS + k) * C + c]);
+        for (int k = 0; k < parts; ++k) {
+            const size_t at = ((size_t)b * ELO_SV_MAX_PARTS + k) * C + c;
+            if (s.den[at] != 0.0f) D += s.den[at] * expf(s.mx[at] - M);
+        }
+        stats[((size_t)b * 2) * C + c] = M;
+        stats[((size_t)b * 2 + 1) * C + c] = D;
+    }
 }
 
 // Scratch of a projection over `images` range images of H*W cells and `pts` points in total (32-bit words):
@@ -1087,7 +1099,7 @@ extern "C" int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t s
                        dim3(ELO_BLOCK), 0, (hipStream_t)stream, a->feature, a->weight, a->xyz, a->npoints, a->C, parts,
                        a->scratch, ProjectionClear{nullptr, nullptr, nullptr, 0, 0, 0});
     hipLaunchKernelGGL(softmax_valid_merge_kernel, dim3((a->batch * a->C + ELO_BLOCK - 1) / ELO_BLOCK), dim3(ELO_BLOCK),
-                       0, (hipStream_t)stream, a->scratch, a->batch, a->C, parts, a->out);
+                       0, (hipStream_t)stream, a->scratch, a->batch, a->C, parts, a->out, a->stats);
     return check_launch(who);
 }
 

@@ -209,22 +209,24 @@ __global__ __launch_bounds__(TB) void bn_bwd_apply_kernel(const float *__restric
 // ---- dW = X^T G ------------------------------------------------------------------------------------------------------
 // v_mfma_f32_16x16x4_f32: A[i][k] in lane (i = l % 16, k = l / 16), B[k][j] in lane (j = l % 16, k = l / 16),
 // D[4 * (l / 16) + r][l % 16] in acc[r].  With A = X^T (i: input channel, k: one of 4 rows) and B = G (j: output channel)
-// a step consumes 4 rows.  A workgroup owns a (16 CI x 16 CO) block of dW (blockIdx.y / z) over ONE SLICE of the rows
-// (blockIdx.x); its four waves split the slice, add their accumulators up through LDS and store the slice's partial block
-// to part[slice]; weight_grad_combine_kernel then sums the slices in a fixed order.  Loads are 4 bytes per lane (4 rows x
-// 16 consecutive channels per instruction), U row groups in flight; the kernel is matrix-pipe bound for the wide layers
-// and load-issue bound for the 8-channel ones.
+// a step consumes 4 rows.  dW is cut into blocks of (16 CI x 16 CO); a WAVE owns one block over one SLICE of the rows
+// (blockIdx.x), and the (up to four) waves of a workgroup own different blocks over THE SAME slice: they stream the same
+// rows of X and G at the same time, so those come from HBM once and from the CU's L1 afterwards (the first form gave
+// each workgroup one block: X was read once per column block and G once per row block -- 354 MB instead of 177 MB for a
+// 128 -> 128 layer, at 1.8 TB/s the whole 200 us).  No reduction inside the workgroup: a wave stores its block of the
+// slice's partial dW; slices_combine_kernel sums the slices in a fixed order.  Loads are 4 bytes per lane (4 rows x 16
+// consecutive channels per instruction), U row groups in flight.
 template <int CI, int CO>
 __global__ __launch_bounds__(TB) void weight_grad_kernel(const float *__restrict__ x, const float *__restrict__ g, long M, int Cin,
-                                                         int Cout, float *__restrict__ part, float *__restrict__ bpart)
+                                                         int Cout, int gy, int gz, float *__restrict__ part, float *__restrict__ bpart)
 {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    __shared__ float red[(TB / 64 - 1) * CI * CO * 256];
-    __shared__ float bred[(TB / 64) * CO * 16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, k4 = lane >> 4;
-    const int ci0 = blockIdx.y * CI * 16, co0 = blockIdx.z * CO * 16;
-    const long groups = (M + 3) / 4, waves = (long)gridDim.x * (TB / 64), per = (groups + waves - 1) / waves;
-    const long g0 = ((long)blockIdx.x * (TB / 64) + wave) * per, g1 = g0 + per < groups ? g0 + per : groups;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i16 = lane & 15, k4 = lane >> 4;
+    const int tb = blockIdx.y * (blockDim.x >> 6) + wave;            // this wave's block of dW
+    if (tb >= gy * gz) return;
+    const int ci0 = (tb / gz) * CI * 16, co0 = (tb % gz) * CO * 16;
+    const long groups = (M + 3) / 4, per = (groups + gridDim.x - 1) / gridDim.x;
+    const long g0 = (long)blockIdx.x * per, g1 = g0 + per < groups ? g0 + per : groups;
     f32x4 acc[CI][CO];
 #pragma unroll
     for (int a = 0; a < CI; ++a)
@@ -248,10 +250,14 @@ __global__ __launch_bounds__(TB) void weight_grad_kernel(const float *__restrict
             const bool live = gr + u < g1 && row < M;
             const long rc = live ? row : 0;
 #pragma unroll
-            for (int a = 0; a < CI; ++a) { const float v = x[rc * Cin + xc[a]]; xv[u][a] = live && xok[a] ? v : 0.f; }
+            // (a multiply, not a select: behind a select the compiler predicates the LOAD, and every predicated load is a
+            //  branch plus a full s_waitcnt -- 32 dependent round trips per trip instead of one)
+            for (int a = 0; a < CI; ++a) xv[u][a] = x[rc * Cin + xc[a]] * (live && xok[a] ? 1.f : 0.f);
 #pragma unroll
-            for (int b = 0; b < CO; ++b) { const float v = g[rc * Cout + gc[b]]; gv[u][b] = live && gok[b] ? v : 0.f; }
+            for (int b = 0; b < CO; ++b) gv[u][b] = g[rc * Cout + gc[b]] * (live && gok[b] ? 1.f : 0.f);
         }
+        __builtin_amdgcn_sched_barrier(0);         // ALL loads of the trip go out before the first MFMA waits for one (left to
+                                                   // itself the scheduler interleaves them per row group: four round trips)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -261,47 +267,28 @@ __global__ __launch_bounds__(TB) void weight_grad_kernel(const float *__restrict
 #pragma unroll
             for (int b = 0; b < CO; ++b) bsum[b] += gv[u][b];
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // waves 1..3 park their accumulators in LDS, wave 0 adds them in wave order and stores the slice's partial block
-    if (wave > 0) {
+    float *dst = part + (size_t)blockIdx.x * Cin * Cout;
 #pragma unroll
-        for (int a = 0; a < CI; ++a)
+    for (int a = 0; a < CI; ++a)
 #pragma unroll
-            for (int b = 0; b < CO; ++b)
+        for (int b = 0; b < CO; ++b) {
+            const int co = co0 + b * 16 + i16;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[(((wave - 1) * CI + a) * CO + b) * 256 + r * 64 + lane] = acc[a][b][r];
-    }
-#pragma unroll
-    for (int b = 0; b < CO; ++b) {
-        float v = bsum[b];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (k4 == 0) bred[(wave * CO + b) * 16 + i16] = v;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        float *dst = part + (size_t)blockIdx.x * Cin * Cout;
-#pragma unroll
-        for (int a = 0; a < CI; ++a)
-#pragma unroll
-            for (int b = 0; b < CO; ++b) {
-                const int co = co0 + b * 16 + i16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[a][b][r];
-                    for (int w = 0; w < TB / 64 - 1; ++w) v += red[((w * CI + a) * CO + b) * 256 + r * 64 + lane];
-                    const int ci = ci0 + a * 16 + 4 * k4 + r;
-                    if (ci < Cin && co < Cout) dst[(size_t)ci * Cout + co] = v;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + a * 16 + 4 * k4 + r;
+                if (ci < Cin && co < Cout) dst[(size_t)ci * Cout + co] = acc[a][b][r];
             }
-        if (bpart && blockIdx.y == 0 && k4 == 0) {
+        }
+    if (bpart && ci0 == 0) {
 #pragma unroll
-            for (int b = 0; b < CO; ++b) {
-                const int co = co0 + b * 16 + i16;
-                float v = 0.f;
-                for (int w = 0; w < TB / 64; ++w) v += bred[(w * CO + b) * 16 + i16];
-                if (co < Cout) bpart[(size_t)blockIdx.x * Cout + co] = v;
-            }
+        for (int b = 0; b < CO; ++b) {
+            float v = bsum[b];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int co = co0 + b * 16 + i16;
+            if (k4 == 0 && co < Cout) bpart[(size_t)blockIdx.x * Cout + co] = v;
         }
     }
 }
@@ -400,14 +387,15 @@ extern "C" int elo_bn_backward(const elo_bn_backward_args *a, elo_stream_t strea
     return check_launch(who);
 }
 
-// row slices of the weight gradient: enough waves to hide the load latency of the narrow layers, few enough that the
-// partial blocks stay small (<= 8 MB) and every wave has >= 32 row groups
+// row slices of the weight gradient: a slice is one workgroup's rows (its waves own different blocks of dW): enough
+// slices to fill the GPU and hide the load latency of the narrow layers, few enough that the partial blocks stay
+// <= 32 MB and every slice has >= 32 row groups
 extern "C" int elo_weight_grad_slices(long rows, int Cin, int Cout)
 {
     const long groups = (rows + 3) / 4;
-    long s = groups / (32 * (TB / 64)) + 1;
-    const long cap = (8l << 20) / ((long)Cin * Cout * 4);
-    s = s > 1024 ? 1024 : s;
+    long s = groups / 32 + 1;
+    const long cap = (32l << 20) / ((long)Cin * Cout * 4);
+    s = s > 2048 ? 2048 : s;
     s = s > cap ? cap : s;
     return (int)(s < 1 ? 1 : s);
 }
@@ -422,16 +410,20 @@ extern "C" int elo_dense_weight_grad(const elo_weight_grad_args *a, elo_stream_t
     const int slices = elo_weight_grad_slices(a->rows, a->Cin, a->Cout);
     float *bpart = a->db ? a->scratch + (size_t)slices * a->Cin * a->Cout : nullptr;
     hipStream_t s = (hipStream_t)stream;
-    // column blocks per workgroup: all of a <= 64-wide output (1, 2 or 4 tiles); row blocks: the count in 1..4 that pads
-    // the input width least (138 channels = 9 tiles: 3 x 3, not 3 x 4)
+    // blocks of dW: all column tiles of a <= 64-wide output (1, 2 or 4); row tiles: the count in 1..4 that pads the input
+    // width least, larger on a tie or when the padding stays <= 25 % (138 channels = 9 tiles: 3 x 3; 80 = 5 tiles: 2 x 3)
     const int CO = cot >= 4 ? 4 : cot >= 2 ? 2 : 1;
     int CI = 1;
-    for (int c = 2; c <= 4; ++c)
-        if ((cit + c - 1) / c * c <= (cit + CI - 1) / CI * CI) CI = c;
-    const dim3 grid((unsigned)slices, (unsigned)((cit + CI - 1) / CI), (unsigned)((cot + CO - 1) / CO));
+    for (int c = 2; c <= 4; ++c) {
+        const int padded = (cit + c - 1) / c * c;
+        if (padded <= (cit + CI - 1) / CI * CI || padded * 4 <= cit * 5) CI = c;
+    }
+    const int gy = (cit + CI - 1) / CI, gz = (cot + CO - 1) / CO, nb = gy * gz, wpb = nb < TB / 64 ? nb : TB / 64;
+    const dim3 grid((unsigned)slices, (unsigned)((nb + wpb - 1) / wpb));
 #define ELO_WG(CI_, CO_)                                                                                                      \
     if (CI == CI_ && CO == CO_)                                                                                               \
-        hipLaunchKernelGGL((weight_grad_kernel<CI_, CO_>), grid, dim3(TB), 0, s, a->x, a->g, a->rows, a->Cin, a->Cout, a->scratch, bpart)
+        hipLaunchKernelGGL((weight_grad_kernel<CI_, CO_>), grid, dim3(64 * wpb), 0, s, a->x, a->g, a->rows, a->Cin, a->Cout, gy, gz, \
+                           a->scratch, bpart)
     ELO_WG(1, 1); ELO_WG(1, 2); ELO_WG(1, 4); ELO_WG(2, 1); ELO_WG(2, 2); ELO_WG(2, 4);
     ELO_WG(3, 1); ELO_WG(3, 2); ELO_WG(3, 4); ELO_WG(4, 1); ELO_WG(4, 2); ELO_WG(4, 4);
 #undef ELO_WG
