@@ -78,12 +78,33 @@ class FlatGradBucket:
         n = sum(p.numel() for p in self.params)
         self.flat = torch.zeros((n,), dtype=torch.float32, device=self.params[0].device)
         off = 0
+        self.views = []
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self.attach()
+
+    def attach(self):
+        """.grad of every parameter = its view of the bucket (the state the optimiser and the collective work on)."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def zero(self):
         self.flat.zero_()
+
+    def release(self):
+        """.grad = None before a backward pass: autograd then HANDS OVER each gradient instead of launching one
+        `grad += new` kernel per parameter into the views (~870 launches of a few hundred bytes per training step)."""
+        for p in self.params:
+            p.grad = None
+
+    def collect(self):
+        """The gradients autograd produced since release() -> their views (one multi-tensor copy), views attached again.
+        A parameter the loss did not reach keeps the zeros of zero()."""
+        have = [(v, p.grad) for p, v in zip(self.params, self.views) if p.grad is not None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        self.attach()
 
     @staticmethod
     def world_size():

@@ -85,11 +85,13 @@ class Trainer:
     def _gradients(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, decay):
         """zero grads -> forward -> loss -> backward: this rank's gradients, in the flat bucket."""
         self.bucket.zero()
+        self.bucket.release()
         with torch.enable_grad():
             with tf_util.default_store(self.net.store), perm.default_perm_source(self.net.perms):
                 out = pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, True, decay)
             loss = pwclo_model.get_loss(*out[:8], q_gt, t_gt, self.w_x, self.w_q)
             loss.backward()
+        self.bucket.collect()
         return loss.detach()
 
     def _body(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, decay):
