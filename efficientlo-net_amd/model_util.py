@@ -29,7 +29,7 @@ def _hamilton(a, b):
         sign = torch.tensor([1, -1, -1, -1, 1, 1, 1, -1, 1, -1, 1, 1, 1, 1, -1, 1], dtype=torch.float32).to(a.device)
         _HAMILTON[key] = (i, i ^ k, sign)
     ia, ib, sign = _HAMILTON[key]
-    terms = a[..., ia] * (b[..., ib] * sign.to(b.dtype))
+    terms = torch.index_select(a, -1, ia) * (torch.index_select(b, -1, ib) * sign.to(b.dtype))
     return terms.reshape(terms.shape[:-1] + (4, 4)).sum(-1)
 
 
