@@ -70,6 +70,27 @@ def conv(params, scope, x, bn=True, relu=True):
     return y.astype(F)
 
 
+def conv_train(params, scope, x, bn_decay=0.9, relu=True):
+    """The TRAINING form of a batch-normalised layer: 1x1 conv + bias, batch norm with BATCH statistics over every axis
+    but the last, ReLU (utils/tf_util.py:120-185 conv2d with bn=True; :512-531 batch_norm_template =
+    tf.contrib.layers.batch_norm(center, scale, is_training, decay=bn_decay, updates_collections=None): the fused kernel it
+    dispatches to for these NHWC maps normalises with the biased batch variance and feeds the UNBIASED one to the moving
+    average, moving <- decay * moving + (1 - decay) * batch).  Moments are accumulated in float64.
+    Returns (y fp32, new moving_mean, new moving_variance)."""
+    W = params[scope + "/weights"]
+    z = (x.astype(F) @ W + params[scope + "/biases"]).astype(F)
+    flat = z.reshape(-1, z.shape[-1]).astype(np.float64)
+    n = flat.shape[0]
+    mean, var = flat.mean(0), flat.var(0)
+    y = (z - mean.astype(F)) * (1.0 / np.sqrt(var + np.float64(BN_EPS))).astype(F) * params[scope + "/bn/gamma"] + params[scope + "/bn/beta"]
+    if relu:
+        y = np.maximum(y, F(0))
+    d = np.float64(bn_decay)
+    mm = d * params[scope + "/bn/moving_mean"].astype(np.float64) + (1 - d) * mean
+    mv = d * params[scope + "/bn/moving_variance"].astype(np.float64) + (1 - d) * var * (n / max(n - 1, 1))
+    return y.astype(F), mm.astype(F), mv.astype(F)
+
+
 def gather_nd(grid, idx):
     """tf.gather_nd with (...,3) (b,h,w) indices into a (B,H,W,C) tensor."""
     return grid[idx[..., 0], idx[..., 1], idx[..., 2]]

@@ -90,3 +90,26 @@ def test_training_layer_is_what_torch_computes():
                      store.buffers["l/bn/moving_mean"].clone(), store.buffers["l/bn/moving_variance"].clone()))
     for a, b in zip(*outs):
         assert torch.allclose(a, b, atol=2e-4 * float(b.abs().max()), rtol=0)
+
+
+def test_training_layer_matches_the_oracle():
+    """SURVEY a-12, training mode: tf_util.conv2d(is_training=True) -- batch statistics, ReLU, moving-average update --
+    against the numpy restatement oracle/ops_np.conv_train (utils/tf_util.py:120-185, :512-531) at 1e-4."""
+    from oracle import ops_np as O
+    tf_util = load_pkg("tf_util")
+    rng = np.random.default_rng(11)
+    x = rng.normal(0.2, 1.3, (2, 300, 6, 19)).astype(np.float32)
+    store = tf_util.VariableStore(DEV, seed=4)
+    with tf_util.default_store(store):
+        tf_util.conv2d(torch.from_numpy(x).to(DEV), 32, [1, 1], scope="l", bn=True, is_training=True, bn_decay=0.8)   # variables
+        with torch.no_grad():
+            store.params["l/bn/gamma"].copy_(torch.from_numpy(rng.normal(1, 0.2, 32).astype(np.float32)))
+            store.params["l/bn/beta"].copy_(torch.from_numpy(rng.normal(0, 0.2, 32).astype(np.float32)))
+            store.buffers["l/bn/moving_mean"].copy_(torch.from_numpy(rng.normal(0, 0.5, 32).astype(np.float32)))
+            store.buffers["l/bn/moving_variance"].copy_(torch.from_numpy(rng.uniform(0.5, 2, 32).astype(np.float32)))
+        params = {k: v.detach().cpu().numpy() for k, v in store.state_dict().items()}
+        y = tf_util.conv2d(torch.from_numpy(x).to(DEV), 32, [1, 1], scope="l", bn=True, is_training=True, bn_decay=0.8)
+    want_y, want_mm, want_mv = O.conv_train(params, "l", x, bn_decay=0.8)
+    assert np.abs(y.detach().cpu().numpy() - want_y).max() <= 1e-4 * max(1.0, np.abs(want_y).max())
+    assert np.allclose(store.buffers["l/bn/moving_mean"].cpu().numpy(), want_mm, atol=1e-5, rtol=1e-5)
+    assert np.allclose(store.buffers["l/bn/moving_variance"].cpu().numpy(), want_mv, atol=1e-5, rtol=1e-5)
