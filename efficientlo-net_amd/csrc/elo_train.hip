@@ -296,11 +296,18 @@ __global__ __launch_bounds__(TB) void weight_grad_kernel(const float *__restrict
 // out[i] = sum over slices of part[slice][i] (n = Cin*Cout for dW, Cout for db).  A block owns 16 outputs; its 16 thread
 // rows take every 16th slice each (8 loads in flight), then add up through LDS in row order: up to 1024 slices of a
 // narrow layer are 8 round trips instead of 1024 dependent ones.
-__global__ __launch_bounds__(TB) void slices_combine_kernel(const float *__restrict__ part, int slices, long n, float *__restrict__ out)
+// (one launch for both results: the first `blocks_w` blocks sum dW, the rest db)
+__global__ __launch_bounds__(TB) void slices_combine_kernel(const float *__restrict__ part_w, int slices, long n_w, float *__restrict__ out_w,
+                                                            unsigned blocks_w, const float *__restrict__ part_b, long n_b,
+                                                            float *__restrict__ out_b)
 {
     __shared__ float red[16][17];
+    const bool second = blockIdx.x >= blocks_w;
+    const float *__restrict__ part = second ? part_b : part_w;
+    const long n = second ? n_b : n_w;
+    float *__restrict__ out = second ? out_b : out_w;
     const int j = threadIdx.x & 15, sr = threadIdx.x >> 4;
-    const long i = (long)blockIdx.x * 16 + j;
+    const long i = (long)(second ? blockIdx.x - blocks_w : blockIdx.x) * 16 + j;
     const long ic = i < n ? i : n - 1;
     float v = 0.f;
     for (int s = sr; s < slices; s += 16 * 8) {
@@ -428,8 +435,7 @@ extern "C" int elo_dense_weight_grad(const elo_weight_grad_args *a, elo_stream_t
     ELO_WG(3, 1); ELO_WG(3, 2); ELO_WG(3, 4); ELO_WG(4, 1); ELO_WG(4, 2); ELO_WG(4, 4);
 #undef ELO_WG
     const long n = (long)a->Cin * a->Cout;
-    hipLaunchKernelGGL(slices_combine_kernel, dim3((unsigned)((n + 15) / 16)), dim3(TB), 0, s, a->scratch, slices, n, a->dW);
-    if (a->db)
-        hipLaunchKernelGGL(slices_combine_kernel, dim3((unsigned)((a->Cout + 15) / 16)), dim3(TB), 0, s, bpart, slices, (long)a->Cout, a->db);
+    const unsigned bw = (unsigned)((n + 15) / 16), bb = a->db ? (unsigned)((a->Cout + 15) / 16) : 0u;
+    hipLaunchKernelGGL(slices_combine_kernel, dim3(bw + bb), dim3(TB), 0, s, a->scratch, slices, n, a->dW, bw, bpart, (long)a->Cout, a->db);
     return check_launch(who);
 }
