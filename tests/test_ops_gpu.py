@@ -189,6 +189,43 @@ def test_project_spherical_ring(H, W, N, C):
         close(got[1], want[1], atol=1e-5)
 
 
+def test_projection_cells_differ_from_the_oracle_only_on_cell_borders():
+    """The other projection tests keep their points off the cell borders.  Here 150 000 points are drawn with NO such
+    care: the kernel's per-point cell (read from the call's scratch, include/elo.h) equals the oracle's for all but a
+    handful, and every one of those lies on a border -- its continuous column or row coordinate, recomputed in float64, is
+    within 1e-4 of an integer, where one ulp of atan2f / asinf / the division decides the cell (model_util.py:229-242)."""
+    ops = load_pkg("_ops")
+    rng = np.random.default_rng(21)
+    B, N, H, W = 1, 150000, 64, 1800
+    az = rng.uniform(-np.pi, np.pi, (B, N))
+    beta = np.deg2rad(rng.uniform(-26.0, 3.0, (B, N)))          # a little beyond the sensor's -24.8 .. 2 degrees
+    r = rng.uniform(2, 60, (B, N))
+    pc = np.stack([r * np.cos(beta) * np.cos(az), r * np.cos(beta) * np.sin(az), r * np.sin(beta)], -1).astype(np.float32)
+    buf = ops.ProjectionBuffers(B, N, H, W, 0, DEV)
+    ops.warp_project(t(pc), None, None, None, H, W, buffers=buf)
+    torch.cuda.synchronize()
+    cells = B * H * W
+    got = buf.scratch[cells + 4 * B: cells + 4 * B + B * N].cpu().numpy().reshape(B, N)        # cell_of per point
+    az_res, vres, voff = (np.float64(x) for x in O.projection_constants(H, W))
+    x, y, z = (pc[..., i].astype(np.float64) for i in range(3))
+    colf = (np.pi - np.arctan2(y, x)) / az_res
+    rowf = np.arcsin(z / np.sqrt(x * x + y * y + z * z)) / vres + voff
+    # the oracle's cells, from its own fp32 evaluation
+    F = np.float32
+    xs, ys, zs = pc[..., 0], pc[..., 1], pc[..., 2]
+    rr = np.sqrt((pc * pc).sum(-1)).astype(F)
+    ocol = np.trunc(((F(np.pi) - np.arctan2(ys, xs).astype(F)) / F(az_res)).astype(F)).astype(np.int64)
+    orow = H - np.trunc((np.arcsin((zs / rr).astype(F)).astype(F) / F(vres) + F(voff)).astype(F)).astype(np.int64)
+    want = np.clip(orow, 0, H - 1) * W + np.clip(ocol, 0, W - 1)
+    differ = got != want
+    assert differ.mean() < 2e-4, differ.mean()                   # measured: a few points in 150 000
+    near = lambda v: np.abs(v - np.round(v))
+    on_border = (near(colf) < 1e-4) | (near(rowf) < 1e-4)
+    assert on_border[differ].all()
+    # ... and away from the borders the agreement is exact
+    assert (got[~on_border] == want[~on_border]).all()
+
+
 def test_warp_and_project():
     mu = load_pkg("model_util")
     rng = np.random.default_rng(9)
