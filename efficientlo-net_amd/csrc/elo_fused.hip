@@ -659,6 +659,12 @@ __device__ __forceinline__ void group_tile(const TileMeta &m, int *lds_off, unsi
 // segments of a gather are loaded back to back and stored afterwards, so the whole gather is ONE round trip to L2.
 // (The element-per-thread loops this replaces had their load under a condition, which costs a full s_waitcnt vmcnt(0)
 // per iteration: 4...13 dependent round trips per tile.)
+#ifndef ELO_TILE_WAVES
+#define ELO_TILE_WAVES 6                   // waves per SIMD setconv_kernel / mlp_kernel / cv2_kernel are compiled for
+#endif
+#ifndef ELO_CV1_WAVES
+#define ELO_CV1_WAVES 5                    // waves per SIMD the cost-volume stage-1 kernels are compiled for
+#endif
 constexpr int SEG_ITEMS = 4;                        // per thread: TILE(32) * W(128) * 4 bytes / 16 / FUSED_BLOCK
 
 __device__ __forceinline__ bool seg_ok(const void *p, int W, int rows, int f16)
@@ -913,7 +919,7 @@ __device__ __forceinline__ void setconv_tile(const elo_setconv_args &a, const in
 }
 
 template <int TILE, int MODE>
-__global__ __launch_bounds__(FUSED_BLOCK, 6) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK, ELO_TILE_WAVES) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
 {
     extern __shared__ __align__(16) float lds[];
     setconv_tile<TILE, MODE>(jobs.job[blockIdx.y], S, lds, blockIdx.x, gridDim.x);
@@ -1078,7 +1084,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
 // stage 1: columns [0, w0 + w1 + w2) = the sources; its last layer writes `out` to HBM straight from the accumulators
 // and, with a second stage, to columns [0, N) of the tile; stage 2: [out (N) | before | after] -> layers2 -> out2.
 template <int TILE, int MODE>
-__global__ __launch_bounds__(FUSED_BLOCK, 6) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK, ELO_TILE_WAVES) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
 {
     const elo_mlp_args &a = jobs.job[blockIdx.y];
     extern __shared__ __align__(16) float lds[];
@@ -1158,9 +1164,6 @@ __host__ __device__ __forceinline__ int cv1_feat_cols(int C)
     return kp > 2 * C + 16 ? kp : 2 * C + 16;     // and CV_xyz's 16-k block at 2C
 }
 
-#ifndef ELO_CV1_WAVES
-#define ELO_CV1_WAVES 5                    // waves per SIMD the cost-volume stage-1 kernels are compiled for
-#endif
 template <int TILE, int MODE>
 __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, float *lds, unsigned block, unsigned nblocks)
 {
@@ -1271,7 +1274,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, ELO_CV1_WAVES) void cv1_setconv_kernel
 // LDS columns: [0,64) grouped cost, [64,128) xyz-encoding, [128,128+C) feat1, [192,208) xyz_cat;
 // sum_cost0 reads [0,128+C) and writes [64,192); sum_cost1 maps [64,192) -> [64,128).
 template <int TILE, int MODE>
-__global__ __launch_bounds__(FUSED_BLOCK, 6) void cv2_kernel(const elo_cv2_args a, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK, ELO_TILE_WAVES) void cv2_kernel(const elo_cv2_args a, const int S)
 {
     extern __shared__ __align__(16) float lds[];
     float *act = lds;
