@@ -235,7 +235,9 @@ def fused_pairs_available(is_training):
 # Branches that only share inputs ride on ONE heterogeneous launch (fused.cv_stage1(side=...)) while the GPU is
 # underfilled: measured at 64x1800 (8 lanes) batch 1 8770 -> 9290 pairs/s, one lane 2700 -> 3020; at batch 8 the merged
 # grid is slower (15 800 -> 15 200: the set-conv tiles run at the cost-volume kernel's register / LDS footprint), so
-# the merge is taken up to this many centre points per launch (batch x H x W of the level; batch 2: 12 040 -> 12 410, batch 4: 14 620 -> 14 380).
+# the merge is taken -- for ALL levels of a forward or for none -- up to this many centre points at the finest level (batch x
+# H x W of l0).  End of round 2 (pairs/s, 8 lanes; none / levels under the threshold / all): batch 2 13 330 / 13 940 / 14 090,
+# batch 4 16 650 / 15 990 / 16 530, batch 8 18 170 / 18 150 / 17 790: merging SOME levels is the worst choice at batch 4.
 _MERGE_POINTS = int(os.environ.get("ELO_MERGE_POINTS", "8192"))
 
 
