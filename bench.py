@@ -68,7 +68,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="frame pairs per step per GPU (configs[1]: 1)")
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--width", type=int, default=1800)
-    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic pairs kept in HBM")
+    ap.add_argument("--pool", type=int, default=7,
+                    help="distinct synthetic pairs kept in HBM (coprime to --lanes, so a lane sees a different pair on every replay)")
     ap.add_argument("--lanes", type=int, default=8,
                     help="independent forwards in flight (hipGraphs, dealt over the 4 hardware queues: use a multiple of 4)")
     ap.add_argument("--products", choices=("split", "half"), default="split",
@@ -431,6 +432,75 @@ def train_dp_leg(args, dev, rank, world, dist):
                              dist.get_backend() if world > 1 else "none (1 rank)")}
 
 
+# ----------------------------------------------------------------------------- multi-rank evidence (N > 1)
+def pin_to_numa_node(torch, local):
+    """Bind this rank to the CPUs of its GPU's NUMA node (host-side submit latency; best effort: {} when sysfs does not
+    say).  Returns {"numa_node", "cpus"} for the line."""
+    try:
+        p = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return {"numa_node": None}
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        os.sched_setaffinity(0, cpus)
+        return {"numa_node": node, "cpus": len(cpus)}
+    except Exception as e:          # no sysfs entry, a container without the node files, a torch without the pci ids
+        return {"numa_node": None, "why": "%s: %s" % (type(e).__name__, str(e)[:80])}
+
+
+def parse_rccl_log(path):
+    """What RCCL said about itself (NCCL_DEBUG=INFO, subsystems INIT,GRAPH,TUNING) in this rank's log file."""
+    import re
+    out = {"log": path, "nranks": None, "channels": None, "transports": [], "algo_proto": None}
+    try:
+        text = open(path, errors="replace").read()
+    except OSError:
+        return out
+    m = re.search(r"nranks (\d+)", text)
+    out["nranks"] = int(m.group(1)) if m else None
+    m = re.search(r"(\d+) coll channels", text)
+    out["channels"] = int(m.group(1)) if m else None
+    out["transports"] = sorted(set(re.findall(r"via (\S+)", text)))[:8]
+    m = re.findall(r"[Aa]lgo(?:rithm)? (\w+) [Pp]roto(?:col)? (\w+)", text)
+    out["algo_proto"] = sorted(set("%s/%s" % ap for ap in m))[:8] or None
+    return out
+
+
+def rccl_leg(dist, dev, backend, world, rank, pose_block, numa, iters=10):
+    """N > 1: the two collectives of the path under a clock of their own -- one all_reduce(SUM) of the flat gradient bucket
+    (899 134 floats, 3.6 MB: configs[3]'s exchange) and the all_gather of a repeat's pose log -- plus what the backend
+    reported (rank count, channels, transports, algorithm / protocol where the log names them)."""
+    import torch
+    sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
+    bucket = torch.zeros(899134, device=dev)
+    gathered = [torch.empty_like(pose_block) for _ in range(world)]
+
+    def clock(fn):
+        for _ in range(3):
+            fn()
+        sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        sync()
+        el = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return round(float(el.item()) * 1e6, 1)
+
+    ar = clock(lambda: dist.all_reduce(bucket))
+    ag = clock(lambda: dist.all_gather(gathered, pose_block))
+    out = {"world_size": dist.get_world_size(), "backend": backend, "all_reduce_us": ar, "all_reduce_bytes": bucket.numel() * 4,
+           "all_gather_us": ag, "all_gather_bytes": pose_block.numel() * 4 * world, "numa": numa}
+    if backend == "nccl":
+        out.update(parse_rccl_log(os.environ.get("NCCL_DEBUG_FILE", "")))
+    return out
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     args = parse()
@@ -452,17 +522,25 @@ def main():
     if dry:
         dev = torch.device("cpu")
     else:
-        local %= torch.cuda.device_count()           # (only differs when a test runs several ranks on one GPU)
+        have = torch.cuda.device_count()
+        if local >= have:
+            if os.environ.get("ELO_BENCH_SHARE_GPU") != "1":      # (set by the test that rehearses 2 ranks on a 1-GPU box)
+                raise SystemExit("bench.py: rank %d has LOCAL_RANK %d but this node shows %d GPU(s): --gpus %d needs one GPU "
+                                 "per rank (ELO_BENCH_SHARE_GPU=1 lets ranks double up, for rehearsals only)"
+                                 % (rank, local, have, world))
+            local %= have
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
+    numa = pin_to_numa_node(torch, local) if (not dry and world > 1) else {"numa_node": None}
+    backend = None
     sync = (lambda: None) if dry else (lambda: torch.cuda.synchronize(dev))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("ELO_BENCH_BACKEND", "gloo" if dry else "nccl")          # nccl == RCCL on ROCm
         if backend == "nccl":
             os.environ.setdefault("NCCL_DEBUG", "INFO")                                   # ring / tree choice and the transport
-            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
-            os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/elo_bench_rccl_%h_%p.log")     # (RCCL logs to stdout otherwise)
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING")
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/elo_bench_rccl_%d.log" % os.getpid())   # (RCCL logs to stdout otherwise)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -598,6 +676,8 @@ def main():
                               "f16_features_f16_products": batch_rate(dev, 8, H, W, lanes, "half", "f16")}
             if os.environ.get("ELO_DENSE_F32") != "1":
                 line["dense_f32"] = dense_f32_leg(args)
+    if world > 1:                                         # every rank takes part; rank 0 reports
+        line["rccl"] = rccl_leg(dist, dev, backend, world, rank, pose_log[:args.steps].contiguous(), numa)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

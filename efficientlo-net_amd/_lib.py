@@ -142,6 +142,8 @@ SYMBOLS = [
     ("elo_fused_conv_random_k", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
     ("elo_fused_conv_select_k", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
     ("elo_fused_conv_random_k_dense", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
+    ("elo_fused_conv_select_k_dense", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
+    ("elo_debug_select_dense_waves", ctypes.c_int, [ctypes.c_int]),
     ("elo_group_concat", ctypes.c_int, [ctypes.POINTER(GroupConcatArgs), _vp]),
     ("elo_masked_maxpool", ctypes.c_int, [ctypes.POINTER(MaskedMaxpoolArgs), _vp]),
     ("elo_cv_encode1", ctypes.c_int, [ctypes.POINTER(CvEncode1Args), _vp]),
@@ -169,6 +171,7 @@ SYMBOLS = [
     ("elo_setconv_fused2", ctypes.c_int, [ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
     ("elo_mlp_fused2", ctypes.c_int, [ctypes.POINTER(MlpArgs), ctypes.POINTER(MlpArgs), _vp]),
     ("elo_cv_stage1_fused", ctypes.c_int, [ctypes.POINTER(Cv1Args), _vp]),
+    ("elo_debug_cv1_rr", ctypes.c_int, [ctypes.c_int]),
     ("elo_cv_stage2_fused", ctypes.c_int, [ctypes.POINTER(Cv2Args), _vp]),
     ("elo_cv_stage1_setconv_fused", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
 ]

@@ -28,6 +28,20 @@ __device__ __forceinline__ float sq3(float x, float y, float z)
 // the reference's max(a,b) with a NaN first operand returns b
 __device__ __forceinline__ float pick_max(float a, float b) { return a > b ? a : b; }
 
+// e^x to ~2 ulp in 7 instructions on the hardware exp2: x * log2(e) in two pieces (the rounding of the product, up to
+// |x| * 2^-24 in the exponent -- 1e-6 relative at x = -20 --, is carried as a first-order correction).  The argument is
+// clamped at -104 (e^-104 = 2^-150 is 0 in fp32), which also makes exp_acc(-inf) = 0 without a NaN from the correction.
+// Used where a softmax runs over thousands of points (softmax_valid): the plain v_exp_f32(x * 1.4427) form moved a
+// refinement level's pose by enough (1e-7) to flip projection cells on one seed in ~10 ("What's weak" 2).
+__device__ __forceinline__ float exp_acc(float x)
+{
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f;
+    x = fmaxf(x, -104.0f);
+    const float t = __fmul_rn(x, L2E_HI);
+    const float r = __fmaf_rn(x, L2E_LO, __fmaf_rn(x, L2E_HI, -t));
+    return __builtin_amdgcn_exp2f(t) * __fmaf_rn(r, 0.693147180559945f, 1.0f);
+}
+
 // ---- device: XCD-aware tile order ------------------------------------------
 // The dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md, workgroup
 // dispatch).  Give each XCD one contiguous run of tiles so that neighbouring

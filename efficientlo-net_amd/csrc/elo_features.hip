@@ -516,7 +516,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_partial_kernel(const 
     typedef typename std::conditional<F16, _Float16, float>::type feat_t;
     const feat_t *__restrict__ feature = reinterpret_cast<const feat_t *>(feature_);
     const feat_t *__restrict__ weight = reinterpret_cast<const feat_t *>(weight_);
-    auto ex = [](float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896f); };      // v_exp_f32 (as the poolings)
+    auto ex = [](float x) { return exp_acc(x); };      // v_exp_f32 with the argument's rounding corrected (elo_common.h)
     __shared__ float part[3][ROWS_PER_BLOCK][ELO_WAVE];
     clear_projection(clear);
     const int slice = blockIdx.x, b = blockIdx.y, lane = threadIdx.x % ELO_WAVE, wave = threadIdx.x / ELO_WAVE;

@@ -22,6 +22,7 @@
 // Interfaces and the reference lines covered: include/elo.h ("Fused inference kernels").
 #include "elo_group_device.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace elo {
 namespace {
@@ -1164,7 +1165,9 @@ __host__ __device__ __forceinline__ int cv1_feat_cols(int C)
     return kp > 2 * C + 16 ? kp : 2 * C + 16;     // and CV_xyz's 16-k block at 2C
 }
 
-template <int TILE, int MODE>
+// GROUP = false: an instance without the in-kernel select-k (the neighbours come from a.idx / a.mask, written by
+// elo_fused_conv_select_k_dense in front of this launch): the window registers and the grouping's scalars are gone
+template <int TILE, int MODE, bool GROUP = true>
 __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, float *lds, unsigned block, unsigned nblocks)
 {
     float *act = lds;
@@ -1176,7 +1179,7 @@ __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, flo
     const long first_point = (long)xcd_tile(block, nblocks) * P;
     if (first_point >= total_points) return;
     CV1_STAMP(0);
-    if (a.group.random_hw) {                          // select-k of frame 2 around every warped frame-1 pixel (:49-51)
+    if (GROUP && a.group.random_hw) {                 // select-k of frame 2 around every warped frame-1 pixel (:49-51)
         // the visiting order and select-k's scratch live IN the activation tile, which is idle until the gather that
         // follows the grouping's closing barrier: 3.8 KB less LDS per workgroup (a sixth one per CU)
         int *lds_off = reinterpret_cast<int *>(act);
@@ -1245,6 +1248,16 @@ __global__ __launch_bounds__(FUSED_BLOCK, ELO_CV1_WAVES) void cv1_kernel(const e
     cv1_tile<TILE, MODE>(a, S, lds, blockIdx.x, gridDim.x);
 }
 
+#ifndef ELO_CV1_META_WAVES
+#define ELO_CV1_META_WAVES 6
+#endif
+template <int TILE, int MODE>
+__global__ __launch_bounds__(FUSED_BLOCK, ELO_CV1_META_WAVES) void cv1_meta_kernel(const elo_cv1_args a, const int S)
+{
+    extern __shared__ __align__(16) float lds[];
+    cv1_tile<TILE, MODE, false>(a, S, lds, blockIdx.x, gridDim.x);
+}
+
 // ---- heterogeneous launch: cost-volume stage 1 and one or two set-conv jobs in ONE grid ---------------------------------
 // Inside a refinement level the cost volume (stage 1 -> stage 2) and the two set-upconvs only share INPUTS
 // (pwclo_model.py:242-250), and at the head of the pyramid the initial cost volume (:170) does not need the layer-3
@@ -1269,6 +1282,299 @@ __global__ __launch_bounds__(FUSED_BLOCK, ELO_CV1_WAVES) void cv1_setconv_kernel
         setconv_tile<TILE_SC, MODE>(side.job[j], side.S, lds, r - j * side.blocks_per_job, side.blocks_per_job);
     }
 }
+
+// ================================================================ cost volume, stage 1: register-resident chain
+// The tile kernel above runs a layer as "four waves share 32 rows, each owns a quarter of the columns": every layer
+// boundary is an LDS round trip and two workgroup barriers, and EVERY 32-row tile pulls all 172 KB of packed weights
+// through the CU's vector L1 (64 B/clk): at batch 8 that is 3.6 MB per CU and launch -- 56 k cycles of L1 time against
+// 46 k cycles of matrix-core time -- which is what kept that kernel at 17 % matrix utilisation whatever was done to its
+// instruction mix (round 2's phase table; round 3 measured the same wall with a wave that streamed W on its own).
+// Here ONE WAVE owns 16 rows (of the 128 rows = P points x K neighbour slots of its workgroup) and ALL columns, and the chain stays in its registers: the
+// transposed product D^T = W^T A^T leaves lane (i16, kq) with channels cb*16 + 4kq .. +3 of row i16 -- exactly the quad
+// that lane feeds as the B operand of the NEXT layer's k-block cb (the pair layout of WFrag takes quad kq of blocks 2p and
+// 2p+1) -- so a layer's epilogue (bias is the accumulator's initial value, ReLU, hi/lo split) writes the next layer's
+// operands in place: no activation ever touches LDS.  The eight waves of a workgroup walk the SAME weight stream, so W
+// crosses the L1 once per 128 rows: each wave fetches one 1 KB chunk of every 8 KB "superstep" (two k-steps of two column
+// blocks) into a register three supersteps ahead, drops it into a two-slot LDS ring, and all eight read their matrix
+// operands from there (LDS: 256 B/clk); one workgroup barrier per superstep of 12 matrix instructions per wave, waiting on
+// LDS only (the global loads stay in flight across it).  16 rows per wave keep the kernel at <= 128 VGPRs: four waves
+// per SIMD, whose matrix bursts and epilogues interleave.  LDS is used once more, after the chain, to transpose
+// (logits, values) for the softmax pooling over the K rows of a point (the scratch aliases the ring).
+// Neighbours come from a.idx / a.mask.  Same arithmetic in the same order as cv1_tile: the outputs are equal bit for bit
+// (tests/test_ops_gpu.py::test_register_resident_cost_volume_equals_the_tile_kernel).
+#ifndef ELO_DENSE_F32
+constexpr int RR_PITCH = 36;                       // words per row of the pooling scratch (32 channels + 4: the pooling runs in two halves)
+constexpr int RR_WAVES = 8;                        // waves per workgroup: 16 rows each, one W stream for all 128 rows
+constexpr int RR_ROWS = RR_WAVES * 16;
+constexpr int RR_SLOT_U4 = 512;                    // a ring slot: 8 KB = 8 chunks of 64 x 16 bytes, one chunk per wave
+constexpr int RR_NSLOT = 2;                        // ring slots: superstep S is read while S + 1 is being written
+#ifndef ELO_RR_STAGE
+#define ELO_RR_STAGE 3                             // supersteps a wave's global W load runs ahead of its LDS write
+#endif
+constexpr int RR_STAGE = ELO_RR_STAGE;
+constexpr size_t RR_LDS_BYTES = sizeof(float) * (2 * RR_ROWS * RR_PITCH + RR_ROWS);   // pooling scratch (36.5 KB); >= the 16 KB ring it aliases
+
+struct RrW { WPair w[2]; };                        // one k-step of two column blocks (a tail travels in .hi)
+
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. the W loads
+// that are meant to stay in flight across it
+__device__ __forceinline__ void rr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One layer on the wave's 16 rows.  in[p]: operand pairs, tail: the 16-k tail block (TAIL); NCB column blocks, two per
+// pass, a pass = KP pair steps (+ the tail step).  The W stream of the WHOLE kernel is one sequence of steps (layer by
+// layer, pass by pass), two steps = one superstep = one ring slot.  Every step reads its operands from the ring (fetch:
+// the slot is complete since the last barrier); at the end of an odd step the wave moves its chunk of the NEXT superstep
+// from its staging register into the other slot, requests a later one (advance), and joins the barrier.  G0 = this
+// layer's first step.  bias0: the bias quads of pass 0 on entry, of `next_bias`'s pass 0 on exit.
+// emit(pass, t, acc): epilogue of column block 2*pass + t.
+template <int KP, bool TAIL, int NCB, int G0, class Fetch, class Advance, class Emit>
+__device__ __forceinline__ void rr_layer(const ActPair (&in)[KP > 0 ? KP : 1], const uint4 &tail, const elo_dense &L,
+                                         const float *next_bias, float4 (&bias0)[2], Fetch fetch, Advance advance, Emit emit)
+{
+    constexpr int PASSES = NCB / 2, SPP = KP + (TAIL ? 1 : 0);
+    static_assert(G0 % 2 == 0 && (PASSES * SPP) % 2 == 0, "a superstep never straddles two layers");
+    const int kq = (threadIdx.x & 63) >> 4;
+    f32x4 acc[1][2];
+    float4 bnext[2] = {bias0[0], bias0[1]};
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[0][t] = f32x4{bnext[t].x, bnext[t].y, bnext[t].z, bnext[t].w};
+        if (pass + 1 < PASSES) {                                    // the next pass's bias quads, a pass ahead
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bnext[t] = *reinterpret_cast<const float4 *>(L.bias + (2 * (pass + 1) + t) * 16 + 4 * kq);
+        } else if (next_bias) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bnext[t] = *reinterpret_cast<const float4 *>(next_bias + t * 16 + 4 * kq);
+        }
+#pragma unroll
+        for (int k = 0; k < SPP; ++k) {
+            const int g = G0 + pass * SPP + k;
+            RrW cur;
+            fetch(g, cur);                                           // (the other waves of the SIMD cover the LDS round trip)
+            if (k < KP) {
+                const ActPair a1[1] = {in[k < KP ? k : 0]};
+                const WPair w2[2] = {cur.w[0], cur.w[1]};
+                mma_pair<MODE_SPLIT, 2, 1, 2>(acc, 0, a1, w2);
+            } else {
+                const uint4 a1[1] = {tail};
+                const uint4 w2[2] = {cur.w[0].hi, cur.w[1].hi};
+                mma_tail<MODE_SPLIT, 2, 1, 2>(acc, 0, a1, w2);
+            }
+            if (g % 2 == 1) advance(g / 2);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) emit(pass, t, acc[0][t]);
+    }
+    bias0[0] = bnext[0]; bias0[1] = bnext[1];
+}
+
+// max(x, 0) or x as ONE integer instruction and no branch: read as a signed integer every negative float (and -0) is
+// negative, every positive one keeps its order, so ReLU is max(bits, 0); "no ReLU" is max(bits, INT_MIN).  (fmaxf is
+// llvm.maxnum: the compiler puts a canonicalising v_max x, x in front of it -- 256 extra instructions per 32 rows.)
+__device__ __forceinline__ float4 relu4(const f32x4 a, int relu)
+{
+    const int floor = relu ? 0 : (int)0x80000000;
+    auto mx = [&](float x) { return __int_as_float(max(__float_as_int(x), floor)); };
+    return float4{mx(a[0]), mx(a[1]), mx(a[2]), mx(a[3])};
+}
+
+// the quad of column block 2*pass + t goes into half `t` of pair `pass` of the next layer's operands
+__device__ __forceinline__ void put_quad(ActPair &dst, int t, const uint4 q)
+{
+    if (t == 0) { dst.hi.x = q.x; dst.hi.y = q.y; dst.lo.x = q.z; dst.lo.y = q.w; }
+    else { dst.hi.z = q.x; dst.hi.w = q.y; dst.lo.z = q.z; dst.lo.w = q.w; }
+}
+
+// hi + lo of an operand quad as four floats (what act_get reads back in the tile kernel)
+__device__ __forceinline__ float4 quad_value(unsigned h01_, unsigned h23_, unsigned l01_, unsigned l23_)
+{
+    const half2v h01 = __builtin_bit_cast(half2v, h01_), h23 = __builtin_bit_cast(half2v, h23_);
+    const half2v l01 = __builtin_bit_cast(half2v, l01_), l23 = __builtin_bit_cast(half2v, l23_);
+    return float4{(float)h01.x + (float)l01.x, (float)h01.y + (float)l01.y, (float)h23.x + (float)l23.x, (float)h23.y + (float)l23.y};
+}
+
+template <int C, bool F16>
+__global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_args a)
+{
+    extern __shared__ __align__(16) float lds[];
+    constexpr int FP = C / 16;                       // 16-channel blocks per feature tensor; CV_0's pairs: FP (feat1 | feat2 blocks paired up)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    uint4 *ring = reinterpret_cast<uint4 *>(lds);    // [2 slots][8 chunks][64 lanes] x 16 bytes
+    const int K = a.K, P = RR_ROWS / K;              // points per workgroup: rows r = point * K + slot, r < P * K <= 128
+    const long total_points = (long)a.batch * a.npoints;
+    const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
+    unsigned bad = 0;
+    // ---- the W stream.  Steps per layer: CV_0 4*(FP+1), CV_1 2*4, CV_2 2*2, CV_xyz 2*1, sum_CV_0 4*4, sum_CV_1 2*4
+    constexpr int E0 = 4 * (FP + 1), E1 = E0 + 8, E2 = E1 + 4, E3 = E2 + 2, E4 = E3 + 16, E5 = E4 + 8, NSUP = E5 / 2;
+    uint4 st[RR_STAGE];
+    // request this wave's chunk of superstep S: chunk w = (step 2S + (w >> 2), column block (w >> 1) & 1, hi / lo half w & 1)
+    auto issue = [&](int S, uint4 &dst) {                                // (S is a constant after unrolling)
+        if (S >= NSUP) return;
+        const int g = 2 * S;
+        const elo_dense &L = g < E0 ? a.cv0 : g < E1 ? a.cv1 : g < E2 ? a.cv2 : g < E3 ? a.cv_xyz : g < E4 ? a.sum_cv0 : a.sum_cv1;
+        const int kp = g < E0 ? FP : g < E1 ? 4 : g < E2 ? 2 : g < E3 ? 0 : 4;
+        const int tl = (g < E0 || (g >= E2 && g < E3)) ? 1 : 0;
+        const int g0 = g < E0 ? 0 : g < E1 ? E0 : g < E2 ? E1 : g < E3 ? E2 : g < E4 ? E3 : E4;
+        const int spp = kp + tl, KS = 2 * kp + tl;
+        constexpr int BB = WFrag<MODE_SPLIT>::BLOCK_BYTES;
+        const int slA = g - g0, slB = slA + 1;
+        const int passA = slA / spp, kA = slA - passA * spp, passB = slB / spp, kB = slB - passB * spp;
+        const bool tailA = kA >= kp, tailB = kB >= kp;
+        const int offA = 2 * passA * KS * BB + (tailA ? (KS - 1) * BB : kA * 2 * BB);
+        const int offB = 2 * passB * KS * BB + (tailB ? (KS - 1) * BB : kB * 2 * BB);
+        const int second = wave >> 2;                                     // (scalars)
+        const bool is_tail = second ? tailB : tailA;
+        const int off = (second ? offB : offA) + ((wave >> 1) & 1) * KS * BB + ((wave & 1) && !is_tail ? 1024 : 0);
+        dst = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(weight_rsrc(L.w_packed), lane * 16u, off, 0));
+    };
+    auto commit = [&](int S, const uint4 &src) {                         // chunk w of slot S % RR_NSLOT
+        if (S >= NSUP) return;
+        ring[(S % RR_NSLOT) * RR_SLOT_U4 + wave * 64 + lane] = src;
+    };
+    auto fetch = [&](int g, RrW &dst) {                                  // step g's operands: chunks (g % 2) * 4 + 2t (+ 1: lo)
+        if (g >= E5) return;
+        const uint4 *slot = ring + ((g / 2) % RR_NSLOT) * RR_SLOT_U4 + (g % 2) * 256 + lane;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { dst.w[t].hi = slot[t * 128]; dst.w[t].lo = slot[t * 128 + 64]; }
+    };
+    // end of superstep S: superstep S + 1 goes into the slot S - 1 used (every wave read it before the last barrier)
+    auto advance = [&](int S) {
+        commit(S + 1, st[(S + 1) % RR_STAGE]);
+        issue(S + 1 + RR_STAGE, st[(S + 1) % RR_STAGE]);
+        rr_barrier();
+    };
+#pragma unroll
+    for (int S = 0; S < RR_STAGE; ++S) issue(S, st[S]);
+    float4 bias[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const float4 *>(a.cv0.bias + t * 16 + 4 * kq);
+    // ---- row metadata + gather, every load requested before the first use (this lane's row: r = wave * 16 + i16)
+    const int r = wave * 16 + i16, pi = r / K;
+    long pt = first_point + pi;
+    const bool used = pi < P && pt < total_points;
+    if (!used) pt = first_point;
+    const long gr = used ? pt * K + (r - pi * K) : first_point * K;
+    const int id0 = a.idx[gr * 3 + 0], id1 = a.idx[gr * 3 + 1], id2 = a.idx[gr * 3 + 2];
+    float mk = a.mask[gr];
+    const int cell = (id0 * a.H2 + id1) * a.W2 + id2;
+    if (!used) mk = 0.0f;
+    const bool keep2 = used && mk != 0.0f;
+    ActPair in0[FP];                                 // CV_0's input pairs: [feat1 | feat2] blocks, two per pair
+    uint4 geo;                                       // its tail: quad kq of [p, g*m, g*m - p, |g*m - p|, 0 ...]
+    {
+        typedef typename std::conditional<F16, uint2, float4>::type Item;     // 4 channels
+        Item f1[FP], f2[FP];
+        const Item *r1 = reinterpret_cast<const Item *>(a.feat1) + (pt * C >> 2) + kq;
+        const Item *r2 = reinterpret_cast<const Item *>(a.feat2) + ((long)cell * C >> 2) + kq;
+#pragma unroll
+        for (int j = 0; j < FP; ++j) { f1[j] = r1[j * 4]; f2[j] = r2[j * 4]; }
+        const float *c = a.xyz1 + pt * 3, *g = a.xyz2 + (long)cell * 3;
+        const float pc0 = c[0], pc1 = c[1], pc2 = c[2], pg0 = g[0], pg1 = g[1], pg2 = g[2];
+        // superstep 0 into the ring (its load went out first), a later one requested in its place
+        commit(0, st[0]);
+        issue(RR_STAGE, st[0]);
+        auto quad = [&](const Item &v, bool keep) {
+            const uint4 z{0u, 0u, 0u, 0u};
+            if constexpr (F16) return keep ? quad_of_halves(v) : z;
+            else return keep ? pack_quad<MODE_SPLIT>(v, bad) : z;
+        };
+        // CV_0's k-blocks in order: feat1 blocks 0..FP-1, feat2 blocks 0..FP-1, geometry; block b sits in pair b / 2, half b % 2
+#pragma unroll
+        for (int j = 0; j < FP; ++j) put_quad(in0[j / 2], j % 2, quad(f1[j], used));
+#pragma unroll
+        for (int j = 0; j < FP; ++j) put_quad(in0[(FP + j) / 2], (FP + j) % 2, quad(f2[j], keep2));
+        const float g0 = pg0 * mk, g1 = pg1 * mk, g2 = pg2 * mk;
+        const float d0 = g0 - pc0, d1 = g1 - pc1, d2 = g2 - pc2;
+        const float e = sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + 1e-20f);
+        const float4 q4 = kq == 0 ? float4{pc0, pc1, pc2, g0} : kq == 1 ? float4{g1, g2, d0, d1}
+                        : kq == 2 ? float4{d2, e, 0.0f, 0.0f} : float4{0.0f, 0.0f, 0.0f, 0.0f};
+        geo = used ? pack_quad<MODE_SPLIT>(q4, bad) : uint4{0u, 0u, 0u, 0u};
+    }
+    rr_barrier();                                    // superstep 0 is in the ring
+    // ---- the chain
+    const uint4 none{0u, 0u, 0u, 0u};
+    ActPair h128[4];                                 // CV_0's output (128 channels = 4 pairs)
+    rr_layer<FP, true, 8, 0>(in0, geo, a.cv0, a.cv1.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h128[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.cv0.relu), bad));
+    });
+    ActPair h64[2];
+    rr_layer<4, false, 4, E0>(h128, none, a.cv1, a.cv2.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h64[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.cv1.relu), bad));
+    });
+    ActPair xe[4];                                   // [x | enc]: sum_CV_0's input; x stays alive: it is the pooling's value
+    rr_layer<2, false, 4, E1>(h64, none, a.cv2, a.cv_xyz.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(xe[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.cv2.relu), bad));
+    });
+    {
+        ActPair unused[1];
+        rr_layer<0, true, 4, E2>(unused, geo, a.cv_xyz, a.sum_cv0.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+            put_quad(xe[2 + pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.cv_xyz.relu), bad));
+        });
+    }
+    rr_layer<4, false, 8, E3>(xe, none, a.sum_cv0, a.sum_cv1.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h128[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.sum_cv0.relu), bad));
+    });
+    float4 logit[4];                                 // plain fp32, held until the ring is dead
+    rr_layer<4, false, 4, E4>(h128, none, a.sum_cv1, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        logit[2 * pass + t] = relu4(acc, a.sum_cv1.relu);
+    });
+    // (the last superstep's barrier is behind every wave's last ring read: the scratch below may overwrite it)
+    // ---- masked softmax over the K rows of a point, weighted sum of x (:92-98), 32 channels at a time: the rows go through
+    // LDS (logits | values | mask), then a half-wave per point, lane = channel; the same expressions in the same order as
+    // pool_masked_softmax
+    float *lg = lds, *xv = lds + RR_ROWS * RR_PITCH, *mrow = lds + 2 * RR_ROWS * RR_PITCH;
+    if (kq == 0) mrow[r] = mk;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();                   // the first half's reads are done
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int cb = 2 * half + c2;
+            *reinterpret_cast<float4 *>(lg + r * RR_PITCH + c2 * 16 + 4 * kq) = logit[cb];
+            const ActPair &xp = xe[half];            // x's pair `half` = its column blocks 2*half, 2*half + 1
+            *reinterpret_cast<float4 *>(xv + r * RR_PITCH + c2 * 16 + 4 * kq) = c2 == 0 ? quad_value(xp.hi.x, xp.hi.y, xp.lo.x, xp.lo.y)
+                                                                                       : quad_value(xp.hi.z, xp.hi.w, xp.lo.z, xp.lo.w);
+        }
+        __syncthreads();
+        const int ch = lane & 31;
+        for (int pp = wave * 2 + (lane >> 5); pp < P; pp += 2 * RR_WAVES) {
+            const long p = first_point + pp;
+            if (p >= total_points) break;
+            const float *lcol = lg + (pp * K) * RR_PITCH + ch, *vcol = xv + (pp * K) * RR_PITCH + ch;
+            float mx = -INFINITY, den = 0.0f, sum = 0.0f;
+            for (int k0 = 0; k0 < K; k0 += 8) {
+                float l[8], v[8], w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = min(k0 + u, K - 1);
+                    l[u] = lcol[k * RR_PITCH];
+                    v[u] = vcol[k * RR_PITCH];
+                    w[u] = mrow[pp * K + k];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (k0 + u >= K) break;
+                    const float x = w[u] == 1.0f ? l[u] : -1e10f;
+                    if (x > mx) {
+                        const float sc = exp_hw(mx - x);
+                        den = den * sc + 1.0f;
+                        sum = sum * sc + v[u];
+                        mx = x;
+                    } else {
+                        const float e = exp_hw(x - mx);
+                        den += e;
+                        sum += e * v[u];
+                    }
+                }
+            }
+            feat_store(a.out, p * 64 + 32 * half + ch, sum / den, F16);
+        }
+    }
+    report_violations<MODE_SPLIT>(bad);
+}
+#endif   // !ELO_DENSE_F32
 
 // ================================================================ cost volume, stage 2
 // LDS columns: [0,64) grouped cost, [64,128) xyz-encoding, [128,128+C) feat1, [192,208) xyz_cat;
@@ -1693,18 +1999,54 @@ static int plan_cv1(const elo_cv1_args *a, TilePlan *p, const char *who)
     return check_group(a->group, a->H2, a->W2, p->lds, who);
 }
 
+// the register-resident form of cost-volume stage 1 (cv1_rr_kernel) is taken for pre-grouped calls (idx / mask) in the
+// fp32-class products mode; ELO_CV1_RR=0 or elo_debug_cv1_rr(0) keep the tile kernel (comparison, tests)
+static int g_cv1_rr = -1;
+extern "C" int elo_debug_cv1_rr(int on)
+{
+    const int prev = g_cv1_rr;
+    g_cv1_rr = on;
+    return prev;
+}
+static bool cv1_rr_on()
+{
+    static const int from_env = [] { const char *e = getenv("ELO_CV1_RR"); return e ? atoi(e) : 1; }();
+    return (g_cv1_rr >= 0 ? g_cv1_rr : from_env) != 0;
+}
+
 extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
 {
     const char *who = "elo_cv_stage1_fused";
     TilePlan plan;
     if (int rc = plan_cv1(a, &plan, who)) return rc;
     if ((long)a->batch * a->npoints == 0) return ELO_OK;
+#ifndef ELO_DENSE_F32
+    if (!a->group.random_hw && plan.mode == MODE_SPLIT && cv1_rr_on() && (a->C == 16 || a->C == 32 || a->C == 64)) {
+        const int P = RR_ROWS / a->K;                              // points per workgroup (128 rows)
+        const dim3 grid((unsigned)(((long)a->batch * a->npoints + P - 1) / P));
+        const size_t lds = RR_LDS_BYTES;
+        hipStream_t s = (hipStream_t)stream;
+        const bool f16 = a->feat_dtype == ELO_F16;
+        static_assert(RR_LDS_BYTES <= 64 * 1024, "dynamic LDS within the default limit");
+#define RR(CC)                                                                                                      \
+        do {                                                                                                        \
+            if (f16) hipLaunchKernelGGL((cv1_rr_kernel<CC, true>), grid, dim3(RR_WAVES * 64), lds, s, *a);          \
+            else hipLaunchKernelGGL((cv1_rr_kernel<CC, false>), grid, dim3(RR_WAVES * 64), lds, s, *a);             \
+        } while (0)
+        if (a->C == 16) RR(16);
+        else if (a->C == 32) RR(32);
+        else RR(64);
+#undef RR
+        return check_launch(who);
+    }
+#endif
     const dim3 grid((unsigned)plan.units);
     const size_t lds = plan.lds;
     const int S = plan.S;
     hipStream_t s = (hipStream_t)stream;
 #define CALL(k) hipLaunchKernelGGL(k, grid, dim3(FUSED_BLOCK), lds, s, *a, S)
-    ELO_PICK(cv1_kernel, plan.t16, plan.mode, CALL);
+    if (a->group.random_hw) ELO_PICK(cv1_kernel, plan.t16, plan.mode, CALL);
+    else ELO_PICK(cv1_meta_kernel, plan.t16, plan.mode, CALL);
 #undef CALL
     return check_launch(who);
 }

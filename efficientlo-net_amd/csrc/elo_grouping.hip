@@ -386,6 +386,259 @@ __global__ __launch_bounds__(ELO_BLOCK) void group_select_k(const elo_group_args
     }
 }
 
+// ---------------------------------------------------------------- select-k, every pixel a centre: LDS-staged windows
+// The call shape of the refinement cost volumes (utils/pointnet_util.py:49-51: every pixel of the warped frame-1 grid is a
+// centre, K = 6 of a 5x15 / 7x25 / 11x41 window, distance 1000): the wave-per-centre form above spends ~870 instructions
+// per centre, two thirds of them on per-probe address arithmetic (offset decode, wrap, clamp, 12-byte gather) that is
+// the same for neighbouring centres shifted by one pixel.  Here a workgroup owns 64 consecutive centres of one grid
+// row, stages the UNION of their windows once (kH x (64 + kW - 1) points, 16 bytes each: x, y, z and the packed (h, w),
+// an empty pixel or a row outside the grid staged as x = +inf, so that its distance is +inf and no probe tests
+// validity), and A LANE PER CENTRE walks the window: a probe is one conflict-free ds_read_b128 at (lane's origin + a
+// wave-uniform offset) and nine arithmetic instructions for 64 centres at once.  The window's slots are dealt over the
+// P waves of the workgroup (slot s in raster order -> wave s % P), so every wave samples the whole window.
+//
+// What the reference outputs (fused_conv_g.cu:148-204) is the K smallest in-range distances in increasing order; WHICH
+// of two EQUAL distances comes first depends on the visiting order -- and only then (see elo_group_device.h).  So the
+// walk needs no visiting order:
+//   pass 1   every wave keeps the minimum of each of its G slot classes (P * G >= 8 disjoint classes in all): the maximum
+//            of 8 class minima bounds the 8th smallest distance -- hence the (K+1)-th, K <= 7 -- from above: T;
+//   pass 2   the same walk again, appending the in-range slots with d <= T (typically K + 5..15) to the centre's
+//            candidate list in LDS;
+//   select   L = P lanes per centre pull K + 1 minima out of the list (registers + DPP): slots 0..K-1, and the first one
+//            left out.  Two equal minima anywhere among those K + 1 (or a list that overflowed) send the centre through
+//            the exact wave-per-centre form (wave_select_k: reference visiting order, swap rounds) after the tile is done.
+// Real scans essentially never tie; the integer-lattice tests tie on every centre and stay bit-exact through the fallback.
+constexpr int SD_CAP = 32;              // candidate slots per centre
+
+template <int L>
+__device__ __forceinline__ unsigned lanes_min_u32(unsigned v)           // minimum over each aligned group of L lanes
+{
+    v = dpp_min_step<0xb1>(v);                                             // quad_perm:[1,0,3,2]
+    v = dpp_min_step<0x4e>(v);                                             // quad_perm:[2,3,0,1]
+    if (L >= 8) v = dpp_min_step<0x141>(v);                                // row_half_mirror
+    if (L >= 16) v = dpp_min_step<0x140>(v);                               // row_mirror
+    return v;
+}
+
+__host__ __device__ inline size_t select_dense_lds_words(int P, int kH, int kW, int sh, int sw, bool counts)
+{
+    const DenseGeom g = dense_geom(1, kH, kW, sh, sw);
+    const int NG = P >= 8 ? P : 8, KT = kH * kW;
+    return (size_t)4 * g.RH * g.RW + 2 * 64 * SD_CAP + (size_t)NG * 64 + 64 + (counts ? 2 * P * 64 : 0) + 64 +
+           ((KT + 3) & ~3) + (size_t)P * 128;
+}
+
+template <int P, bool COUNTS>
+__global__ __launch_bounds__(P * 64) void group_select_k_dense(const elo_group_args a)
+{
+    extern __shared__ int lds[];
+    constexpr int THREADS = P * 64, G = P >= 8 ? 1 : 8 / P, NG = P * G, L = P, E = SD_CAP / L, CPW = 64 / P;
+    const int KT = a.kernel_h * a.kernel_w, K = a.K, kW = a.kernel_w;
+    const DenseGeom g = dense_geom(1, a.kernel_h, a.kernel_w, a.stride_h, a.stride_w);
+    const int cells = g.RH * g.RW;
+    float4 *region = reinterpret_cast<float4 *>(lds);                       // [RH * RW]
+    uint2 *list = reinterpret_cast<uint2 *>(region + cells);                // [SD_CAP][64] (distance bits, packed hw), slot-major
+    unsigned *gm = reinterpret_cast<unsigned *>(list + 64 * SD_CAP);        // [NG][64] class minima
+    int *cnt = reinterpret_cast<int *>(gm + NG * 64);                       // [64] candidates appended
+    int *part = cnt + 64;                                                   // [2][P][64] seen / in-range counts per wave (COUNTS)
+    int *redo = part + (COUNTS ? 2 * P * 64 : 0);                           // [64] 1: the centre takes the exact wave form
+    int *lds_off = redo + 64;                                               // [KT] decoded visiting order (fallback)
+    unsigned *scratch = reinterpret_cast<unsigned *>(lds_off + ((KT + 3) & ~3));   // [P][128] wave scratch of the fallback
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, hc = blockIdx.y, c0 = blockIdx.x * DENSE_COLS;
+    const int h0 = hc / a.stride_h - a.kernel_h / 2, w0 = c0 / a.stride_w - a.kernel_w / 2;     // region origin (unwrapped)
+    const int wc = c0 + lane;
+    const bool live = wc < a.W;
+    const float *cp = a.xyz1 + (((size_t)b * a.H + hc) * a.W + (live ? wc : a.W - 1)) * 3;
+    const float cx = cp[0], cy = cp[1], cz = cp[2];
+    const float *grid2 = a.xyz2 + (size_t)b * a.H2 * a.W2 * 3;
+    {   // stage the region (all of a thread's loads go out before the first LDS write), the visiting order, the counters
+        constexpr int PER = 4;
+        for (int e0 = 0; e0 < cells; e0 += PER * THREADS) {
+            float x[PER], y[PER], z[PER];
+            int hw[PER];
+            bool in[PER];
+#pragma unroll
+            for (int v = 0; v < PER; ++v) {
+                const int e = min(e0 + v * THREADS + tid, cells - 1);
+                const int rr = e / g.RW, cc = e - rr * g.RW;
+                const int h = h0 + rr;
+                int w = (w0 + cc) % a.W2;
+                if (w < 0) w += a.W2;                                       // the cylindrical wrap (:89-97; kW/2 <= W2: one wrap = modulo)
+                in[v] = h >= 0 && h < a.H2;
+                hw[v] = (h << 16) | w;
+                const float *q = grid2 + ((size_t)(in[v] ? h : 0) * a.W2 + w) * 3;
+                x[v] = q[0]; y[v] = q[1]; z[v] = q[2];
+            }
+#pragma unroll
+            for (int v = 0; v < PER; ++v) {
+                const int e = e0 + v * THREADS + tid;
+                if (e < cells) {
+                    const bool ok = in[v] && !(sq3(x[v], y[v], z[v]) <= ELO_EPS);                 // :106-111
+                    region[e] = ok ? float4{x[v], y[v], z[v], __int_as_float(hw[v])} : float4{INFINITY, 0.0f, 0.0f, __int_as_float(-1)};
+                }
+            }
+        }
+        const int hh = a.kernel_h / 2, hw2 = kW / 2;
+        for (int i = tid; i < KT; i += THREADS) {
+            const int p = a.random_hw[i];
+            lds_off[i] = ((p / kW - hh) << 16) | ((p % kW - hw2) & 0xffff);
+        }
+        if (tid < 64) { cnt[tid] = 0; redo[tid] = 0; }
+    }
+    __syncthreads();
+    const int origin = wc / a.stride_w - c0 / a.stride_w;                  // this centre's window: region[dh * RW + origin + dw]
+    const float r2 = a.distance * a.distance;
+    const bool centre_ok = live && !(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS);              // :62-70
+    constexpr int U = 4;                                                    // probes in flight per lane
+    // the walk of this wave: slots wave, wave + P, ... in raster order; fn(u, q, active) per probe, u = its position in the batch
+    auto walk = [&](auto fn) {
+        int dh = wave / kW, dw = wave - dh * kW;                            // (scalar: derived from the wave index)
+        for (int s0 = wave; s0 < KT; s0 += P * U) {
+            float4 q[U];
+            bool act[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                act[u] = s0 + u * P < KT;
+                q[u] = region[(act[u] ? dh * g.RW + dw : 0) + origin];
+                dw += P;
+                while (dw >= kW) { dw -= kW; ++dh; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) fn(u, q[u], act[u]);
+        }
+    };
+    auto dist_bits = [&](const float4 &q) {                                 // d > 0 (or +inf): bit order == float order
+        return __float_as_uint(pick_max(sq3(__fsub_rn(cx, q.x), __fsub_rn(cy, q.y), __fsub_rn(cz, q.z)), ELO_EPS));
+    };
+    // ---- pass 1: class minima (class = wave, and for P = 4 the probe's parity inside the wave's walk)
+    {
+        unsigned m[G];
+        int seen = 0, taken = 0;
+#pragma unroll
+        for (int j = 0; j < G; ++j) m[j] = 0xffffffffu;
+        walk([&](int u, const float4 &q, bool act) {
+            const unsigned d = dist_bits(q);
+            const unsigned dd = act ? d : 0xffffffffu;
+            m[u % G] = dd < m[u % G] ? dd : m[u % G];
+            if (COUNTS) {
+                const bool valid = centre_ok && act && __float_as_int(q.w) >= 0;        // (a skipped centre's masks stay 0: :62-70)
+                seen += valid;
+                taken += valid && !(__uint_as_float(d) > r2);
+            }
+        });
+#pragma unroll
+        for (int j = 0; j < G; ++j) gm[(wave * G + j) * 64 + lane] = m[j];
+        if (COUNTS) { part[wave * 64 + lane] = seen; part[(P + wave) * 64 + lane] = taken; }
+    }
+    __syncthreads();
+    // ---- the bound T: the maximum of 8 class minima (P = 16: classes merged in pairs first)
+    unsigned T = 0;
+    if (centre_ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned v = gm[j * 64 + lane];
+            if (NG == 16) { const unsigned w2 = gm[(j + 8) * 64 + lane]; v = w2 < v ? w2 : v; }
+            T = v > T ? v : T;
+        }
+    }
+    // ---- pass 2: candidates = in-range slots with d <= T (an invalid centre has T = 0: none)
+    walk([&](int u, const float4 &q, bool act) {
+        const unsigned d = dist_bits(q);
+        const bool c = act && d <= T && !(__uint_as_float(d) > r2) && __float_as_int(q.w) >= 0;
+        if (c) {
+            const int slot = atomicAdd(&cnt[lane], 1);
+            if (slot < SD_CAP) list[slot * 64 + lane] = uint2{d, (unsigned)__float_as_int(q.w)};
+        }
+    });
+    __syncthreads();
+    // ---- selection: L lanes per centre, wave w takes centres w * CPW .. ; lane j of the group holds entries j, j + L, ...
+    {
+        const int c = wave * CPW + lane / L, j = lane % L;
+        const int total = cnt[c], n = total < SD_CAP ? total : SD_CAP;
+        unsigned ed[E];
+        int ep[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int slot = i * L + j;
+            const uint2 v = list[(slot < n ? slot : 0) * 64 + c];
+            ed[i] = slot < n ? v.x : 0xffffffffu;
+            ep[i] = (int)v.y;
+        }
+        const int cw = c0 + c;
+        const bool clive = cw < a.W;
+        const long uo = (((long)b * a.H + hc) * a.W + (clive ? cw : 0)) * K;
+        int *o_sel = a.selected_bhw_idx + uo * 3;
+        float *o_mask = a.selected_mask + uo;
+        bool tie = total > SD_CAP;
+        unsigned prev = 0xffffffffu;
+        for (int s = 0; s <= K; ++s) {
+            unsigned bd = 0xffffffffu;
+            int bi = 0, bp = 0;
+#pragma unroll
+            for (int i = 0; i < E; ++i)
+                if (ed[i] < bd) { bd = ed[i]; bi = i; bp = ep[i]; }
+            const unsigned md = lanes_min_u32<L>(bd);
+            const bool some = md != 0xffffffffu;
+            const bool mine = some && bd == md;
+            const unsigned long long bal = __ballot(mine);
+            const unsigned grp = (unsigned)(bal >> (lane & ~(L - 1))) & ((1u << L) - 1u);
+            tie = tie || (some && (__popc(grp) > 1 || md == prev));
+            prev = md;
+            const bool owner = mine && (grp & ((1u << j) - 1u)) == 0;      // the lowest lane holding the minimum
+            if (owner) {
+#pragma unroll
+                for (int i = 0; i < E; ++i)
+                    if (i == bi) ed[i] = 0xffffffffu;                       // consumed
+            }
+            if (s < K && clive) {
+                if (owner) {
+                    o_sel[s * 3 + 0] = b; o_sel[s * 3 + 1] = bp >> 16; o_sel[s * 3 + 2] = bp & 0xffff;
+                    o_mask[s] = 1.0f;
+                } else if (!some && j == 0) {
+                    o_sel[s * 3 + 0] = 0; o_sel[s * 3 + 1] = 0; o_sel[s * 3 + 2] = 0;
+                    o_mask[s] = 0.0f;
+                }
+            }
+        }
+        if (tie && j == 0 && clive) redo[c] = 1;
+    }
+    __syncthreads();
+    // ---- the prefix masks (:115-117, :132): ones of length num_valid / num_select per centre
+    if (COUNTS && (a.valid_idx || a.valid_in_dis_idx)) {
+        const int ncol = min(DENSE_COLS, a.W - c0);
+        const long u0 = ((long)b * a.H + hc) * a.W + c0;
+        for (int e = tid; e < ncol * KT; e += THREADS) {
+            const int c = e / KT, i = e - c * KT;
+            int seen = 0, taken = 0;
+            for (int w = 0; w < P; ++w) { seen += part[w * 64 + c]; taken += part[(P + w) * 64 + c]; }
+            if (a.valid_idx) a.valid_idx[u0 * KT + e] = i < seen ? 1.0f : 0.0f;
+            if (a.valid_in_dis_idx) a.valid_in_dis_idx[u0 * KT + e] = i < taken ? 1.0f : 0.0f;
+        }
+    }
+    // ---- exact ties / overflowed lists: the reference's own walk, a wave per centre
+    for (int c = wave; c < 64; c += P) {
+        if (!__builtin_amdgcn_readfirstlane(redo[c])) continue;
+        const int cw = c0 + c;
+        const float *pc = a.xyz1 + (((size_t)b * a.H + hc) * a.W + cw) * 3;
+        const float x = pc[0], y = pc[1], z = pc[2];
+        const long uo = (((long)b * a.H + hc) * a.W + cw) * K;
+        int *o_sel = a.selected_bhw_idx + uo * 3;
+        float *o_mask = a.selected_mask + uo;
+        unsigned *dist = scratch + wave * 128;
+        const int count = wave_select_k(grid2, a.H2, a.W2, KT, K, lds_off, hc / a.stride_h, cw / a.stride_w, x, y, z, r2, dist,
+                                        reinterpret_cast<int *>(dist) + 64,
+                                        [&](int slot, int hw) {
+                                            o_sel[slot * 3 + 0] = b; o_sel[slot * 3 + 1] = hw >> 16; o_sel[slot * 3 + 2] = hw & 0xffff;
+                                            o_mask[slot] = 1.0f;
+                                        });
+        for (int k = count + lane; k < K; k += ELO_WAVE) {
+            o_sel[k * 3 + 0] = 0; o_sel[k * 3 + 1] = 0; o_sel[k * 3 + 2] = 0;
+            o_mask[k] = 0.0f;
+        }
+    }
+}
+
 int check_args(const elo_group_args *a, const char *who, bool dense = false)
 {
     if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
@@ -485,4 +738,50 @@ extern "C" int elo_fused_conv_select_k(const elo_group_args *a, elo_stream_t str
     const unsigned grid = (unsigned)((total + wpb - 1) / wpb);
     hipLaunchKernelGGL(group_select_k, dim3(grid), dim3(wpb * ELO_WAVE), lds, (hipStream_t)stream, *a, total, wpb);
     return check_launch("elo_fused_conv_select_k");
+}
+
+static int g_select_dense_waves = 0;
+// debugging hook (tests): force 4, 8 or 16 waves per tile in elo_fused_conv_select_k_dense; 0 = by grid size; returns the
+// previous setting
+extern "C" int elo_debug_select_dense_waves(int waves)
+{
+    const int prev = g_select_dense_waves;
+    g_select_dense_waves = waves;
+    return prev;
+}
+
+// select-k for the call shape "every pixel a centre" (see group_select_k_dense): K <= 7, flag_copy 0, windows up to 512
+// slots whose union over 64 centres fits the LDS tile
+extern "C" int elo_fused_conv_select_k_dense(const elo_group_args *a, elo_stream_t stream)
+{
+    using namespace elo;
+    const char *who = "elo_fused_conv_select_k_dense";
+    if (int rc = check_args(a, who, true)) return rc;
+    if (a->batch == 0) return ELO_OK;
+    const int KT = a->kernel_h * a->kernel_w;
+    if (a->K > 7 || a->flag_copy != 0 || KT > 512)
+        return fail(ELO_ERR_LIMIT, "%s: K = %d, flag_copy = %d, window %dx%d outside the dense form (K <= 7, flag_copy 0, <= 512 slots): "
+                    "use elo_fused_conv_select_k", who, a->K, a->flag_copy, a->kernel_h, a->kernel_w);
+    const bool counts = a->valid_idx || a->valid_in_dis_idx;
+    const long tiles = (long)((a->W + DENSE_COLS - 1) / DENSE_COLS) * a->H * a->batch;
+    // waves per tile: few tiles -> many waves each (latency: a wave's walk is KT / P probes, twice), many tiles -> 4
+    static const int from_env = [] { const char *e = getenv("ELO_SELECT_DENSE_WAVES"); return e ? atoi(e) : 0; }();
+    const int forced = g_select_dense_waves ? g_select_dense_waves : from_env;
+    int P = forced ? forced : tiles >= 1024 ? 4 : tiles >= 256 ? 8 : 16;
+    if (P != 4 && P != 8 && P != 16) return fail(ELO_ERR_ARG, "%s: ELO_SELECT_DENSE_WAVES must be 4, 8 or 16", who);
+    const size_t lds = sizeof(int) * select_dense_lds_words(P, a->kernel_h, a->kernel_w, a->stride_h, a->stride_w, counts);
+    if (lds > 64 * 1024)
+        return fail(ELO_ERR_LIMIT, "%s: window %dx%d does not fit the LDS tile (use elo_fused_conv_select_k)", who, a->kernel_h, a->kernel_w);
+    const dim3 grid((unsigned)((a->W + DENSE_COLS - 1) / DENSE_COLS), (unsigned)a->H, (unsigned)a->batch);
+    hipStream_t s = (hipStream_t)stream;
+#define ELO_SD(PW)                                                                                              \
+    do {                                                                                                        \
+        if (counts) hipLaunchKernelGGL((group_select_k_dense<PW, true>), grid, dim3(PW * 64), lds, s, *a);      \
+        else hipLaunchKernelGGL((group_select_k_dense<PW, false>), grid, dim3(PW * 64), lds, s, *a);            \
+    } while (0)
+    if (P == 4) ELO_SD(4);
+    else if (P == 8) ELO_SD(8);
+    else ELO_SD(16);
+#undef ELO_SD
+    return check_launch(who);
 }

@@ -335,6 +335,55 @@ def mlp2_pair(job_a, job_b):
     return (shape(out_a), shape(out2_a)), (shape(out_b), shape(out2_b))
 
 
+def _prepass_points():
+    """Centre points per launch from which cost-volume stage 1 runs its select-k as a PRE-PASS (a stand-alone grouping
+    launch writes idx / mask) and the REGISTER-RESIDENT kernel (cv1_rr_kernel: one W stream per 128 rows through an LDS
+    ring, activations in registers) starts from them, instead of the tile kernel with in-kernel grouping.  Measured
+    (tools/cv1_variants.py, profiles/r03_cv1_variants.txt): l0 at batch 8 115 -> 88 us, l1 38 -> 29 us; below ~4000
+    points the extra launch costs more than the kernel saves, and at batch 1-2 the tile kernel also carries the
+    set-upconv riders of its level.  ELO_CV1_PREPASS: 0 = never, 1 = always, N = from N points on; unset = 4096."""
+    import os
+    e = os.environ.get("ELO_CV1_PREPASS")
+    return 4096 if e is None else (1 << 60) if e == "0" else 0 if e == "1" else int(e)
+
+
+_HW = {}
+
+
+def _all_pixels(B, H, W, device):
+    """(B, H*W, 2) int32 (h, w) of every pixel, row-major: the centre list of the cost volume's select-k (cached)."""
+    key = (B, H, W, str(device))
+    hit = _HW.get(key)
+    if hit is None:
+        hh = torch.arange(H, dtype=torch.int32, device=device).view(1, H, 1, 1).expand(B, H, W, 1)
+        ww = torch.arange(W, dtype=torch.int32, device=device).view(1, 1, W, 1).expand(B, H, W, 1)
+        hit = torch.cat([hh, ww], -1).reshape(B, H * W, 2).contiguous()
+        if hit.is_cuda and torch.cuda.is_current_stream_capturing():
+            return hit
+        if len(_HW) >= 64:
+            _HW.clear()
+        _HW[key] = hit
+    return hit
+
+
+def select_prepass(xyz1_grid, xyz2_grid, group, K):
+    """The cost volume's select-k (every pixel of xyz1_grid a centre) as its own launch: (idx (B,N,K,3) int32, mask (B,N,K)).
+    Large grids (>= 1024 tiles of 64 centres) take the LDS-tiled elo_fused_conv_select_k_dense (64x1800: 2.5x faster),
+    the pyramid's small levels the wave-per-centre kernel (its fixed cost is a third of the tiled one's)."""
+    B, H, W, _ = xyz1_grid.shape
+    _, H2, W2, _ = xyz2_grid.shape
+    N = H * W
+    idx = torch.empty((B, N, K, 3), dtype=torch.int32, device=xyz1_grid.device)
+    mask = torch.empty((B, N, K), dtype=torch.float32, device=xyz1_grid.device)
+    dense = -(-W // 64) * H * B >= 1024 and K <= 7 and group.kernel_h * group.kernel_w <= 512
+    hw = None if dense else _all_pixels(B, H, W, xyz1_grid.device)
+    a = L.GroupArgs(B, H, W, H2, W2, N, group.kernel_h, group.kernel_w, K, 0, group.distance, group.stride_h, group.stride_w,
+                    xyz1_grid.data_ptr(), xyz2_grid.data_ptr(), None if dense else hw.data_ptr(), group.random_hw.data_ptr(),
+                    idx.data_ptr(), None, None, mask.data_ptr())
+    L.call("elo_fused_conv_select_k_dense" if dense else "elo_fused_conv_select_k", a, idx)
+    return idx, mask
+
+
 def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1, group=None, K=None,
               side=None):
     """Cost-volume stage 1 in one launch.  `side`: one or two set-conv jobs (dicts of setconv() keyword arguments, same
@@ -346,6 +395,11 @@ def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_x
     _, H2, W2, C = feat2_proj.shape
     B, N = xyz1.shape[0], xyz1.shape[1]
     ptr = lambda x: x.data_ptr() if x is not None else None
+    if (group is not None and not side and not group.want_indices and N == H2 * W2 and B * N >= _prepass_points()
+            and group.stride_h == 1 and group.stride_w == 1 and _products == PRODUCTS_SPLIT and not fp32_mfma()
+            and C in (16, 32, 64)):
+        idx, mask = select_prepass(xyz1.reshape(B, H2, W2, 3), xyz2_proj, group, K)
+        group = None
     if group is None:
         idx, mask = idx.contiguous(), _f32c(mask)
         K = idx.shape[2]

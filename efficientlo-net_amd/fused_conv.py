@@ -64,6 +64,14 @@ def register_dense_index(idx_n2):
     return idx_n2
 
 
+def _select_dense_fits(kH, kW, K, flag_copy, stride_h, stride_w):
+    """Bounds of elo_fused_conv_select_k_dense (csrc/elo_grouping.hip): K <= 7, flag_copy 0, <= 512 slots, 64 KB of LDS at
+    its largest form (16 waves per tile, with the two prefix masks)."""
+    RH, RW = kH, 63 // stride_w + kW
+    words = 4 * RH * RW + 2 * 64 * 32 + 16 * 64 + 64 + 2 * 16 * 64 + 64 + ((kH * kW + 3) & ~3) + 16 * 128
+    return K <= 7 and flag_copy == 0 and kH * kW <= 512 and 4 * words <= 64 * 1024
+
+
 def _dense_fits(kH, kW, K, stride_h, stride_w):
     """dense_lds_bytes of csrc/elo_grouping.hip for its smaller (2 x 64) tile: window union + hit lists within 64 KB of LDS."""
     RH, RW = 1 // stride_h + kH, 63 // stride_w + kW
@@ -84,8 +92,15 @@ def _launch(entry, name, xyz1, xyz2, idx_n2, random_hw, H, W, npoints, kernel_si
         known = _DENSE_INDEX.get(idx_n2.data_ptr())
         if dense or (known is idx_n2 and _dense_fits(kernel_size_H, kernel_size_W, K, stride_h, stride_w)):
             entry = "elo_fused_conv_random_k_dense"
+    elif entry == "elo_fused_conv_select_k" and dense is not False and npoints == H * W:
+        known = _DENSE_INDEX.get(idx_n2.data_ptr())
+        fits = _select_dense_fits(kernel_size_H, kernel_size_W, K, flag_copy, stride_h, stride_w)
+        if dense and not fits:
+            raise ValueError("the dense select-k form takes K <= 7, flag_copy = 0 and a window of at most 512 slots")
+        if dense or (known is idx_n2 and fits):
+            entry = "elo_fused_conv_select_k_dense"
     elif dense:
-        raise ValueError("the dense form needs npoints == H*W (every pixel a centre) and random-k")
+        raise ValueError("the dense form needs npoints == H*W (every pixel a centre)")
     sel = torch.empty((B, npoints, K, 3), dtype=torch.int32, device=dev)
     mask = torch.empty((B, npoints, K, 1), dtype=torch.float32, device=dev)
     if want_valid:
@@ -121,8 +136,10 @@ def fused_conv_random_k(xyz1, xyz2, idx_n2, random_hw, H, W, npoints, kernel_siz
 
 
 def fused_conv_select_k(xyz1, xyz2, idx_n2, random_hw, H, W, npoints, kernel_size_H, kernel_size_W, K,
-                        flag_copy, distance, stride_h, stride_w, want_valid=True):
-    """K nearest in-range neighbours of the window (reference tie order)."""
+                        flag_copy, distance, stride_h, stride_w, want_valid=True, dense=None):
+    """K nearest in-range neighbours of the window (reference tie order).
+    dense (extension, as for random-k): the LDS-tiled kernel for "every pixel a centre" with K <= 7 (the refinement cost
+    volumes' call); None = automatically for registered index tensors.  Same outputs bit for bit."""
     return _launch("elo_fused_conv_select_k", "FusedConvSelectK", xyz1, xyz2, idx_n2, random_hw, H, W,
                    npoints, kernel_size_H, kernel_size_W, K, flag_copy, distance, stride_h, stride_w,
-                   want_valid)
+                   want_valid, dense)

@@ -52,6 +52,15 @@ def distinct_queue_streams(device, want, candidates=16, cycles=500_000):
     return chosen
 
 
+def _cached_tensors():
+    """Every tensor the host-side caches hold right now (strided / all-pixel index grids, centre tables, decoded
+    visiting orders): what a graph captured just before may point at."""
+    from . import pointnet_util
+    keep = list(model_util._sel_cache.values()) + list(pointnet_util._hw_cache.values()) + \
+        list(pointnet_util._centre_hw_cache.values()) + list(fused._DECODED.values())
+    return keep
+
+
 class PWCLONet:
     def __init__(self, device="cuda:0", seed=0, perm_source=None, feature_dtype=torch.float32):
         """feature_dtype=torch.float16: fp16 feature STORAGE in HBM between the fused kernels (BASELINE configs[2]);
@@ -134,6 +143,9 @@ class PWCLONet:
                     lane["out"] = self.forward(staged[:batch_size], staged[batch_size:], pose_out=lane["pose"])
                 else:
                     lane["out"] = self.forward(*lane["in"], pose_out=lane["pose"])
+            # the graph holds raw device pointers into the module-level index / decoded-order caches; those caches evict
+            # (clear()) when they grow: the lane keeps the tensors alive for as long as its graph exists
+            lane["keep"] = _cached_tensors()
             self._lanes.append(lane)
         torch.cuda.synchronize(dev)
         self._graph, self._static_in, self._static_out = (self._lanes[0]["graph"], self._lanes[0]["in"],
@@ -158,6 +170,7 @@ class PWCLONet:
     def replay(self):
         self._check_fresh()
         self._graph.replay()
+        self._lanes[0]["replays"] += 1          # lane 0's graph advanced its device-side pose-ring cursor
         return self._static_out
 
     def submit(self, lane_index, xyz_f1_proj, xyz_f2_proj=None):

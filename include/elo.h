@@ -98,6 +98,16 @@ int elo_fused_conv_select_k(const elo_group_args *a, elo_stream_t stream);
  * The window union of a tile of 4 x 64 centres is staged once in LDS and every centre walks its window from there.
  * ELO_ERR_LIMIT when the window / K do not fit the 64 KB tile: call the general entry point. */
 int elo_fused_conv_random_k_dense(const elo_group_args *a, elo_stream_t stream);
+/* elo_fused_conv_select_k for the same call shape (every pixel a centre, row-major; a->idx_n2 ignored) with K <= 7,
+ * flag_copy == 0 and a window of at most 512 slots -- the select-k of the refinement cost volumes
+ * (utils/pointnet_util.py:49-51: K = 6 of 5x15 / 7x25 / 11x41).  The window union of 64 consecutive centres of a grid row
+ * is staged once in LDS; a lane per centre walks it (no visiting order needed: the K smallest distances in increasing
+ * order are unique unless two of them are EQUAL, and exactly then the centre is redone by the wave-per-centre form in
+ * the reference's visiting order).  Same outputs bit for bit.  ELO_ERR_LIMIT outside those bounds. */
+int elo_fused_conv_select_k_dense(const elo_group_args *a, elo_stream_t stream);
+/* debugging hook: force 4, 8 or 16 waves per tile in elo_fused_conv_select_k_dense (0 = chosen by grid size; also
+ * ELO_SELECT_DENSE_WAVES); returns the previous setting */
+int elo_debug_select_dense_waves(int waves);
 
 /* ------------------------------------------------------------------------- *
  * Feature path: fused gather / encode / pool kernels.  These replace chains of
@@ -609,6 +619,10 @@ typedef struct elo_cv1_args {
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
 } elo_cv1_args;
 int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream);
+/* debugging hook: 0 keeps pre-grouped (idx / mask) calls of elo_cv_stage1_fused on the tile kernel, 1 takes the
+ * register-resident form (cv1_rr_kernel; the default, also ELO_CV1_RR), -1 = back to the environment's choice;
+ * returns the previous setting.  Both forms give the same bits. */
+int elo_debug_cv1_rr(int on);
 /* elo_cv_stage1_fused AND one or two set-conv jobs (elo_setconv_fused / elo_setconv_fused2 semantics, tile-kernel form;
  * jb may be NULL) in ONE launch: the first workgroups of the grid run cost-volume tiles, the rest set-conv tiles.
  * For branches that only share inputs -- the cost volume and the two set-upconvs of a refinement level

@@ -56,6 +56,40 @@ def _st(x):
     return x.astype(F) if _STORE[-1] is None else x.astype(_STORE[-1]).astype(F)
 
 
+# DISCRETE decisions of a forward, recorded for the parity statistic (tests/test_parity_flips_gpu.py): every neighbour
+# index / mask tensor the two grouping ops return and every point -> cell assignment (and per-cell winner set) of a
+# projection, in call order, with the level marker get_model_from_projection sets.  Two oracle runs whose traces are equal
+# took the same discrete decisions everywhere; what is left between them is continuous in the inputs.
+_TRACE = [None]
+
+
+class discrete_trace:
+    """`with discrete_trace() as tr:` -- tr.events = [(level, kind, array), ...] in call order."""
+
+    def __init__(self):
+        self.events, self.level = [], None
+
+    def __enter__(self):
+        _TRACE.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _TRACE.pop()
+
+
+def _rec(kind, *arrays):
+    tr = _TRACE[-1]
+    if tr is not None:
+        for a in arrays:
+            tr.events.append((tr.level, kind, np.array(a, copy=True)))
+
+
+def _grouped(out):
+    """Pass a grouping op's 4-tuple through, recording indices and mask."""
+    _rec("group", out[0], out[3])
+    return out
+
+
 # --------------------------------------------------------------------------- layers
 def conv(params, scope, x, bn=True, relu=True):
     """1x1 conv + bias [+ BN(inference)] [+ ReLU]: utils/tf_util.py:120-185 (conv2d), :52-115 (conv1d)."""
@@ -124,8 +158,8 @@ def down_conv(params, shuffle, xyz_proj, points_proj, selected_idx, K_sample, ke
     idx_n2 = selected_idx.reshape(B, -1, 3)
     n = idx_n2.shape[1]
     perm = shuffle(scope, "random_HW", kernel_size[0] * kernel_size[1])
-    sel, _, _, mask = G.fused_conv_random_k(xyz_proj, xyz_proj, idx_n2[:, :, 1:], perm, H, W, n, kernel_size[0],
-                                            kernel_size[1], K_sample, 0, distance, 1, 1)          # :197-199
+    sel, _, _, mask = _grouped(G.fused_conv_random_k(xyz_proj, xyz_proj, idx_n2[:, :, 1:], perm, H, W, n, kernel_size[0],
+                                                     kernel_size[1], K_sample, 0, distance, 1, 1))          # :197-199
     new_xyz_group = gather_nd(xyz_proj, sel) * mask                                               # :203
     new_points_group = gather_nd(points_proj, sel) * mask                                         # :204
     new_xyz_proj = gather_nd(xyz_proj, selected_idx)                                              # :206
@@ -147,8 +181,8 @@ def cost_volume(params, shuffle, warped_xyz1_proj, xyz2_proj, points1_proj, poin
     points1 = points1_proj.reshape(B, H * W, -1)
     perm_q = shuffle(scope, "random_HW_q", kernel_size2[0] * kernel_size2[1])
     idx_hw = get_hw_idx(B, H, W)
-    qi_idx, _, _, valid_mask = G.fused_conv_select_k(warped_xyz1_proj, xyz2_proj, idx_hw, perm_q, H, W, H * W,
-                                                     kernel_size2[0], kernel_size2[1], nsample_q, 0, 1000, 1, 1)  # :49-51
+    qi_idx, _, _, valid_mask = _grouped(G.fused_conv_select_k(warped_xyz1_proj, xyz2_proj, idx_hw, perm_q, H, W, H * W,
+                                                              kernel_size2[0], kernel_size2[1], nsample_q, 0, 1000, 1, 1))  # :49-51
     qi_xyz_grouped = gather_nd(xyz2_proj, qi_idx) * valid_mask                                    # :54
     qi_points_grouped = gather_nd(points2_proj, qi_idx) * valid_mask                              # :55
     pi_xyz = np.broadcast_to(warped_xyz1[:, :, None, :], qi_xyz_grouped.shape)                    # :57
@@ -169,8 +203,8 @@ def cost_volume(params, shuffle, warped_xyz1_proj, xyz2_proj, points1_proj, poin
     pi_feat1_new = _st((WQ * x).sum(2)).reshape(B, H, W, -1)                                      # :97-100
 
     perm_p = shuffle(scope, "random_HW_p", kernel_size1[0] * kernel_size1[1])
-    pc_idx, _, _, valid_mask2 = G.fused_conv_random_k(warped_xyz1_proj, warped_xyz1_proj, idx_hw, perm_p, H, W, H * W,
-                                                      kernel_size1[0], kernel_size1[1], nsample, 0, distance, 1, 1)  # :106-108
+    pc_idx, _, _, valid_mask2 = _grouped(G.fused_conv_random_k(warped_xyz1_proj, warped_xyz1_proj, idx_hw, perm_p, H, W, H * W,
+                                                               kernel_size1[0], kernel_size1[1], nsample, 0, distance, 1, 1))  # :106-108
     pc_points_grouped = gather_nd(pi_feat1_new, pc_idx) * valid_mask2                             # :110
     pc_xyz_grouped = gather_nd(warped_xyz1_proj, pc_idx) * valid_mask2                            # :111
     pc_xyz_new = np.broadcast_to(warped_xyz1[:, :, None, :], pc_xyz_grouped.shape)                # :114
@@ -206,8 +240,8 @@ def up_conv(params, shuffle, xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kerne
     points1 = feat1_proj.reshape(B, H * W, -1)
     idx_hw = get_hw_idx(B, H, W)
     perm = shuffle(scope, "random_HW", kernel_size[0] * kernel_size[1])
-    sel, _, _, mask = G.fused_conv_random_k(xyz1_proj, xyz2_proj, idx_hw, perm, H, W, H * W, kernel_size[0],
-                                            kernel_size[1], nsample, 0, distance, stride_h, stride_w)   # :272-274
+    sel, _, _, mask = _grouped(G.fused_conv_random_k(xyz1_proj, xyz2_proj, idx_hw, perm, H, W, H * W, kernel_size[0],
+                                                     kernel_size[1], nsample, 0, distance, stride_h, stride_w))   # :272-274
     up_grouped = gather_nd(xyz2_proj, sel) * mask                                                 # :277
     up_points_grouped = gather_nd(feat2_proj, sel) * mask                                         # :278
     diff = up_grouped - xyz1[:, :, None, :]                                                       # :283
@@ -316,7 +350,8 @@ def ProjectPC2SphericalRing(PC, Feature, H_input, W_input):
         iRow = np.clip(iRow, 0, H_input - 1)
         iCol = np.clip(iCol, 0, W_input - 1)
         cell = iRow * W_input + iCol
-        _, out_xyz[b] = scatter_min_range(cell, r, cur, H_input * W_input, (H_input, W_input, 3))
+        min_r_pt, out_xyz[b] = scatter_min_range(cell, r, cur, H_input * W_input, (H_input, W_input, 3))
+        _rec("cell", np.stack([cell, (r == min_r_pt).astype(np.int64)]))
         if Feature is not None:
             _, out_feat[b] = scatter_min_range(cell, r, Feature[b].astype(F), H_input * W_input,
                                                (H_input, W_input, Feature.shape[-1]))
@@ -460,6 +495,8 @@ def get_model_from_projection(params, shuffle, xyz_f1_proj, xyz_f2_proj, coarse_
     cv_kernels = {2: [5, 15], 1: [7, 25], 0: [11, 41]}
     q_prev, t_prev = l3_q, l3_t
     for lvl, gi in ((2, 4), (1, 3), (0, 2)):
+        if _TRACE[-1] is not None:
+            _TRACE[-1].level = lvl
         q_coarse, t_coarse = q_prev.reshape(B, 1, -1), t_prev.reshape(B, 1, -1)                            # :211-212
         xyz = f1["x"][lvl].reshape(B, -1, 3)
         warped = warp(xyz, q_coarse, t_coarse)                                                             # :217-227

@@ -21,6 +21,10 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 2
     assert d["value"] is None and d["data"].startswith("dry-run")           # no throughput claim without a GPU
     assert "2 ranks" in out.stderr and "launching 2 ranks" in out.stderr
+    # N > 1: the collectives of the path under their own clock + what the backend reported, in the line the driver parses
+    r = d["rccl"]
+    assert r["world_size"] == 2 and r["backend"] == "gloo" and r["all_reduce_us"] > 0 and r["all_gather_us"] > 0
+    assert r["all_reduce_bytes"] == 899134 * 4 and "numa" in r
 
 
 def test_bench_single_rank_dry_run_needs_no_launcher():

@@ -55,9 +55,11 @@ def test_bench_line_contract():
 def test_bench_gpus_2_launches_two_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["ELO_BENCH_BACKEND"] = "gloo"                    # two ranks on ONE GPU: RCCL would refuse the duplicate device
+    env["ELO_BENCH_SHARE_GPU"] = "1"                     # (without it bench.py refuses --gpus 2 on a 1-GPU box)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "8",
                           "--lanes", "4", "--train-steps", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     d = _line(out)
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
     assert d["train_dp"]["n_gpus"] == 2 and d["train_dp"]["value"] > 0 and "gloo" in d["train_dp"]["collective"]
     assert "roofline" not in d                            # the N = 1 legs stay with N = 1
+    assert d["rccl"]["world_size"] == 2 and d["rccl"]["all_reduce_us"] > 0

@@ -307,3 +307,64 @@ def test_dense_lds_tiled_random_k_is_bit_exact(case):
     pu = load_pkg("pointnet_util")
     auto = elo.fused_conv_random_k(args[0], args[1], pu.get_hw_idx(B, H, W, dev), *args[3:], want_valid=False)
     assert torch.equal(auto[0], got[0]) and torch.equal(auto[3], got[3])
+
+
+@pytest.mark.parametrize("case", [dict(H=16, W=225, win=(11, 41), K=6, d=1000.0, stride=(1, 1), cloud="scan"),     # l0 cost volume
+                                  dict(H=8, W=113, win=(7, 25), K=6, d=1000.0, stride=(1, 1), cloud="scan"),      # l1
+                                  dict(H=4, W=57, win=(5, 15), K=6, d=1000.0, stride=(1, 1), cloud="scan"),       # l2: window union wider than the grid
+                                  dict(H=12, W=70, win=(9, 15), K=7, d=1.5, stride=(1, 1), cloud="lattice"),      # exact ties on every centre: the fallback
+                                  dict(H=12, W=70, win=(5, 15), K=4, d=1000.0, stride=(1, 1), cloud="sparse"),    # fewer than K (and than 8) neighbours
+                                  dict(H=9, W=130, win=(13, 39), K=5, d=2.5, stride=(1, 1), cloud="normal"),      # 507 slots, ragged last tile, small radius
+                                  dict(H=16, W=64, win=(5, 9), K=6, d=1000.0, stride=(2, 2), cloud="normal"),     # strided query grid
+                                  dict(H=32, W=256, win=(11, 41), K=6, d=1000.0, stride=(1, 1), cloud="scan")])   # configs[4]'s l0 grid
+@pytest.mark.parametrize("waves", [4, 8, 16])
+def test_dense_lds_tiled_select_k_is_bit_exact(case, waves):
+    """elo_fused_conv_select_k_dense (every pixel a centre, K <= 7: the window union of 64 centres staged in LDS, a lane per
+    centre walking it twice -- class minima -> bound, then candidates -- and K + 1 minima pulled from the candidate list;
+    exact ties and overflowing lists redone by the wave-per-centre form) against the oracle and the general kernel: all
+    four outputs bit for bit, for 4, 8 and 16 waves per tile."""
+    elo, synth = load_pkg(), load_pkg("synth")
+    H, W, (kH, kW), K, (sh, sw) = case["H"], case["W"], case["win"], case["K"], case["stride"]
+    B = 2
+    rng = np.random.default_rng(kH * kW + K)
+    if case["cloud"] == "scan":
+        f1, f2 = synth.frame_pair(B, H, W, seed=H + W)
+    else:
+        x = rng.normal(0, 2.0, (2, B, H, W, 3))
+        if case["cloud"] == "lattice":
+            x = np.round(x)
+        x[rng.random((2, B, H, W)) < (0.93 if case["cloud"] == "sparse" else 0.1)] = 0
+        f1, f2 = x.astype(np.float32)
+    x2 = np.ascontiguousarray(f2[:, ::sh, ::sw])
+    perm = rng.permutation(kH * kW).astype(np.int32)
+    hw = synth.hw_index(B, H, W)
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = (t(f1), t(x2), t(hw), t(perm), H, W, H * W, kH, kW, K, 0, case["d"], sh, sw)
+    want = G.fused_conv_select_k(f1, x2, hw, perm, H, W, H * W, kH, kW, K, 0, case["d"], sh, sw, threads=8)
+    # (the waves-per-tile choice follows the grid size; the library's debugging hook forces each of the three forms)
+    load_pkg("_lib").lib().elo_debug_select_dense_waves(waves)
+    try:
+        got = elo.fused_conv_select_k(*args, dense=True)
+        lean = elo.fused_conv_select_k(*args, dense=True, want_valid=False)
+    finally:
+        load_pkg("_lib").lib().elo_debug_select_dense_waves(0)
+    gen = elo.fused_conv_select_k(*args, dense=False)
+    for g, o, w_ in zip(got, gen, want):
+        assert np.array_equal(g.cpu().numpy(), w_) and torch.equal(g, o)
+    assert torch.equal(lean[0], got[0]) and torch.equal(lean[3], got[3])
+    if case["cloud"] == "scan":
+        assert want[3].mean() > 0.8                       # populated windows, not a trivially empty case
+    pu = load_pkg("pointnet_util")
+    auto = elo.fused_conv_select_k(args[0], args[1], pu.get_hw_idx(B, H, W, dev), *args[3:], want_valid=False)
+    assert torch.equal(auto[0], got[0]) and torch.equal(auto[3], got[3])
+
+
+def test_dense_select_k_refuses_what_it_cannot_do():
+    elo, synth = load_pkg(), load_pkg("synth")
+    f1, f2 = synth.frame_pair(1, 8, 64, seed=1)
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    perm = np.arange(15, dtype=np.int32)
+    with pytest.raises(ValueError, match="K <= 7"):
+        elo.fused_conv_select_k(t(f1), t(f2), t(synth.hw_index(1, 8, 64)), t(perm), 8, 64, 512, 3, 5, 8, 0, 1.0, 1, 1, dense=True)

@@ -493,3 +493,46 @@ def test_heterogeneous_launch_equals_separate_launches(B, two):
     assert torch.equal(got_cv, want_cv)
     for (g, gx), (w_, wx) in zip(got_side, want_side):
         assert torch.equal(g, w_) and gx is None and wx is None
+
+
+@pytest.mark.parametrize("B,H,W,C,win,features", [(2, 16, 225, 16, (11, 41), "f32"), (1, 8, 113, 32, (7, 25), "f32"), (3, 4, 57, 64, (5, 15), "f32"),
+                                                  (2, 16, 225, 16, (11, 41), "f16"), (1, 4, 57, 64, (5, 15), "f16"), (1, 5, 33, 16, (3, 9), "f32")])
+def test_register_resident_cost_volume_equals_the_tile_kernel(kernel_path, B, H, W, C, win, features):
+    """cv1_rr_kernel (a wave owns 32 rows and all columns; the chain stays in registers) against the tile kernel
+    (cv1_tile: four waves share the rows, activations in LDS) from the same idx / mask: the same products in the same
+    order, so the outputs are equal BIT FOR BIT (fp32 and fp16 feature storage, C = 16 / 32 / 64, ragged last tiles, a
+    cloud with empty pixels and masked slots); the in-kernel-grouping launch gives the same bits again."""
+    if kernel_path != "fused":
+        pytest.skip("fused kernels only")
+    fused, tf_util, synth, elo, lib = load_pkg("fused"), load_pkg("tf_util"), load_pkg("synth"), load_pkg(), load_pkg("_lib")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    f1, f2 = synth.frame_pair(B, H, W, seed=H * W + C)
+    rng = np.random.default_rng(C)
+    dt = np.float16 if features == "f16" else np.float32
+    fa, fb = (rng.normal(0, 1, (B, H, W, C)).astype(dt) for _ in range(2))
+    N, K = H * W, 6
+    perm = rng.permutation(win[0] * win[1]).astype(np.int32)
+    store = tf_util.VariableStore(DEV, seed=3)
+    with tf_util.default_store(store), torch.no_grad():
+        P = fused.packed_layer
+        layers = (P("c0", 10 + 2 * C, 128, row_order=fused.cv0_row_order(C)), P("c1", 128, 64), P("c2", 64, 64),
+                  P("cx", 10, 64), P("s0", 128, 128), P("s1", 128, 64))
+        for p_ in layers:                                          # non-trivial biases
+            p_.b.copy_(torch.from_numpy(rng.normal(0, 0.1, p_.b.shape).astype(np.float32)))
+        hw = t(synth.hw_index(B, H, W))
+        idx, _, _, m = elo.fused_conv_select_k(t(f1), t(f2), hw, t(perm), H, W, N, win[0], win[1], K, 0, 1000.0, 1, 1, want_valid=False)
+        m = m.reshape(B, N, K)
+        run = lambda: fused.cv_stage1(t(f1).reshape(B, N, 3), t(fa).reshape(B, N, C), t(f2), t(fb), idx, m, *layers)
+        try:
+            lib.lib().elo_debug_cv1_rr(0)
+            tile = run()
+            lib.lib().elo_debug_cv1_rr(1)
+            rr = run()
+        finally:
+            lib.lib().elo_debug_cv1_rr(-1)
+        own = fused.cv_stage1(t(f1).reshape(B, N, 3), t(fa).reshape(B, N, C), t(f2), t(fb), None, None, *layers,
+                              group=fused.Grouping(t(perm), list(win), 1000), K=K)
+    torch.cuda.synchronize()
+    assert rr.dtype == tile.dtype and torch.isfinite(rr.float()).all()
+    assert torch.equal(rr, tile) and torch.equal(rr, own)
+    assert m.mean() > 0.5 and m.min() == 0                           # masked slots are in the mix

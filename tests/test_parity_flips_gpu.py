@@ -1,0 +1,105 @@
+"""Free-running parity of the whole pyramid as a MEASURED statement ("Next round" 2).
+
+north_star: "within 1e-4 for fp32 features/pose".  The pyramid takes DISCRETE decisions downstream of a pose (a warped
+point's projection cell, the per-cell winner, the neighbours of a grouping op), so two correct fp32 implementations
+whose coarse poses differ in the 7th digit can take one of them differently and then differ by 1e-3.  This file does not
+hide that behind a loose tolerance; per (seed, pair, level) it demands
+
+  * teacher-forced (the oracle warps a level by the PRODUCT's coarse pose): |product - oracle| <= 1e-4, always;
+  * free-running: |product - oracle| <= 1e-4, OR a counted discrete flip explains the miss: the oracle's own
+    free-running and teacher-forced runs -- same code, same weights, coarse poses that differ by the product's
+    deviation (<= 1e-4 by the first check, ~1e-6 measured) -- took a different discrete decision at that level or a
+    coarser one (oracle/ops_np.discrete_trace: every neighbour index / mask, every point -> cell assignment and cell
+    winner).  A miss with NO flip anywhere upstream would be accumulated arithmetic error: that fails;
+  * the share of (pair, level) outputs within 1e-4 free-running stays above a floor measured on the GPU.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg
+from oracle import ops_np as O
+from util_params import export, randomise, shuffle_fn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+LEVELS = (3, 2, 1, 0)                       # order of computation: coarse to fine
+OUT_OF = {0: (0, 1), 1: (2, 3), 2: (4, 5), 3: (6, 7)}      # level -> positions of (q, t) in the output tuple
+
+
+def _flips(free_tr, forced_tr, B):
+    """{level: int[B]} -- entries that differ between the two traces, per batch element."""
+    assert len(free_tr.events) == len(forced_tr.events)
+    out = {lvl: np.zeros(B, np.int64) for lvl in LEVELS}
+    cell_no = {}
+    for (lvl, kind, a), (lvl2, kind2, b) in zip(free_tr.events, forced_tr.events):
+        assert lvl == lvl2 and kind == kind2 and a.shape == b.shape
+        if lvl is None:
+            assert np.array_equal(a, b)      # upstream of every pose: identical by construction
+            continue
+        if kind == "cell":                   # one event per batch element, in order
+            i = cell_no.get(lvl, 0)
+            cell_no[lvl] = i + 1
+            out[lvl][i % B] += int((a != b).any(0).sum())
+        else:
+            diff = (a != b).reshape(B, -1)
+            out[lvl] += diff.sum(1)
+    return out
+
+
+def statistic(B, seeds, features="f32", H=64, W=1800):
+    """Rows of (seed, pair, level, free error, forced error, flips at this level or coarser)."""
+    model, perm, synth = load_pkg("model"), load_pkg("perm"), load_pkg("synth")
+    f16 = features == "f16"
+    rows = []
+    for seed in seeds:
+        f1, f2 = synth.frame_pair(B, H, W, seed=seed)
+        net = model.PWCLONet(DEV, seed=5, perm_source=perm.PermSource(fn=shuffle_fn),
+                             feature_dtype=torch.float16 if f16 else torch.float32)
+        both = torch.from_numpy(np.concatenate([f1, f2], 0)).to(DEV)
+        net.forward(both[:B], both[B:])
+        randomise(net.store, seed=seed + 100)
+        got = [x.detach().cpu().numpy() for x in net.forward(both[:B], both[B:])]
+        params = export(net.store)
+        with O.feature_storage(np.float16 if f16 else None):
+            with O.discrete_trace() as tr_free:
+                free = O.get_model_from_projection(params, shuffle_fn, f1, f2)
+            with O.discrete_trace() as tr_forced:
+                forced = O.get_model_from_projection(params, shuffle_fn, f1, f2,
+                                                     coarse_pose={3: (got[6], got[7]), 2: (got[4], got[5]), 1: (got[2], got[3])})
+        flips = _flips(tr_free, tr_forced, B)
+        for b in range(B):
+            upstream = 0
+            for lvl in LEVELS:
+                upstream += int(flips[lvl][b])
+                # normalised error |got - ref| / (1 + |ref|): <= TOL is the suite's close(atol=1e-4, rtol=1e-4)
+                err = lambda ref: max(float((np.abs(got[i][b] - ref[i][b]) / (1.0 + np.abs(ref[i][b]))).max()) for i in OUT_OF[lvl])
+                rows.append(dict(seed=seed, pair=b, level=lvl, free=err(free), forced=err(forced), flips=upstream))
+    return rows
+
+
+def summarise(rows):
+    n = len(rows)
+    inside = [r for r in rows if r["free"] <= TOL]
+    missed = [r for r in rows if r["free"] > TOL]
+    return dict(outputs=n, within_tol=len(inside), share=len(inside) / n,
+                misses=len(missed), misses_without_flip=sum(1 for r in missed if r["flips"] == 0),
+                worst_forced=max(r["forced"] for r in rows), worst_free=max(r["free"] for r in rows),
+                worst_free_without_flip=max([r["free"] for r in rows if r["flips"] == 0] or [0.0]),
+                flips_in_misses=sorted(r["flips"] for r in missed))
+
+
+# floors measured on MI355X (tools/parity_flips.py); the assertions that carry the parity claim are the
+# first two -- the share only documents how often a discrete flip happens with random weights
+@pytest.mark.parametrize("B,seeds,features,floor", [(1, range(200, 216), "f32", 0.75), (8, (300, 301), "f32", 0.75),
+                                                    (8, (310,), "f16", 0.6)])
+def test_free_running_misses_are_counted_flips(B, seeds, features, floor):
+    rows = statistic(B, list(seeds), features)
+    s = summarise(rows)
+    print("\nparity statistic B=%d %s: %s" % (B, features, s))
+    for r in rows:
+        assert r["forced"] <= TOL, r
+        if r["flips"] == 0:
+            assert r["free"] <= TOL, r                            # no discrete decision differs: plain fp32 agreement
+    assert s["share"] >= floor, s

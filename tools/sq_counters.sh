@@ -1,10 +1,10 @@
 #!/bin/bash
 # SQ counter passes over one kernel of tools/roofline_micro.py (counters only, one group per run).
-#   bash tools/sq_counters.sh <kernel> <batch> <outdir>
+#   bash tools/sq_counters.sh <kernel> <batch> <outdir> [extra roofline_micro.py arguments, e.g. --pregrouped]
 set -u
-K=$1; B=$2; OUT=$(realpath -m "$3"); REPO=$(pwd)
+K=$1; B=$2; OUT=$(realpath -m "$3"); REPO=$(pwd); shift 3; EXTRA="$*"
 mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
-cmd="python $REPO/tools/roofline_micro.py --kernel $K --batch $B --reps 12"
+cmd="python $REPO/tools/roofline_micro.py --kernel $K --batch $B --reps 12 $EXTRA"
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
