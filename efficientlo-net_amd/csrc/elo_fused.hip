@@ -139,6 +139,24 @@ __device__ __forceinline__ uint4 tail_load(__amdgpu_buffer_rsrc_t rsrc, unsigned
 //   ELO_DENSE_F32 / "plain" layers (the input of a pooling)   four floats
 __device__ __forceinline__ unsigned pk_rtz(float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); }
 
+// x - (float)h, h = half WHICH (0: low, 1: high) of the packed pair `hh`, as ONE v_fma_mix_f32 (the half is converted on
+// the way in): written as fma(h, -1, x) with the -1 in a scalar register the optimiser cannot see through -- with a
+// literal -1 it rewrites the expression as v_cvt_f32_f16 + v_sub_f32 (two instructions; an inline-asm v_fma_mix_f32
+// would be invisible to the matrix-instruction hazard tables).
+__device__ __forceinline__ float opaque_minus_one()
+{
+    float m;
+    asm("s_mov_b32 %0, 0xbf800000" : "=s"(m));
+    return m;
+}
+
+template <int WHICH>
+__device__ __forceinline__ float minus_half(float x, unsigned hh)
+{
+    const half2v h = __builtin_bit_cast(half2v, hh);
+    return __builtin_fmaf((float)(WHICH ? h.y : h.x), opaque_minus_one(), x);
+}
+
 template <int MODE>
 __device__ __forceinline__ uint4 pack_quad(const float4 a, unsigned &violations)
 {
@@ -153,9 +171,11 @@ __device__ __forceinline__ uint4 pack_quad(const float4 a, unsigned &violations)
             const float m = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
             violations += !(m < 65504.0f);                    // also counts NaN
         }
-        const float h0 = __uint_as_float(__float_as_uint(a.x) & 0xffffe000u), h1 = __uint_as_float(__float_as_uint(a.y) & 0xffffe000u);
-        const float h2 = __uint_as_float(__float_as_uint(a.z) & 0xffffe000u), h3 = __uint_as_float(__float_as_uint(a.w) & 0xffffe000u);
-        return uint4{pk_rtz(h0, h1), pk_rtz(h2, h3), pk_rtz(a.x - h0, a.y - h1), pk_rtz(a.z - h2, a.w - h3)};
+        // hi = x rounded toward zero to fp16 (one v_cvt_pkrtz per pair: for |x| >= 2^-14 that is x with its low 13 mantissa
+        // bits cleared; a smaller x gets an fp16 subnormal), lo = x - hi EXACTLY, taken straight from the packed half by
+        // v_fma_mix_f32 (no mask, no unpack: 8 instructions per quad instead of 12), then rounded toward zero as well
+        const unsigned h01 = pk_rtz(a.x, a.y), h23 = pk_rtz(a.z, a.w);
+        return uint4{h01, h23, pk_rtz(minus_half<0>(a.x, h01), minus_half<1>(a.y, h01)), pk_rtz(minus_half<0>(a.z, h23), minus_half<1>(a.w, h23))};
     }
 #endif
 }
@@ -353,8 +373,11 @@ template <int MODE>
 __device__ __forceinline__ void store_quad(float *act, int S, int row, int col, int N, const f32x4 acc, bool relu,
                                            const LayerOut &o, unsigned &violations)
 {
-    float4 v{acc[0], acc[1], acc[2], acc[3]};
-    if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+    // ReLU as max(bits, 0) on the value read as a signed integer (negative floats and -0 are negative integers; "no ReLU" =
+    // max(bits, INT_MIN)): one instruction per value and no branch (fmaxf costs a canonicalising v_max x, x on top)
+    const int floor = relu ? 0 : (int)0x80000000;
+    const float4 v{__int_as_float(max(__float_as_int(acc[0]), floor)), __int_as_float(max(__float_as_int(acc[1]), floor)),
+                   __int_as_float(max(__float_as_int(acc[2]), floor)), __int_as_float(max(__float_as_int(acc[3]), floor))};
     // an output that also goes to HBM as fp16 continues in the tile AS STORED (rounded to fp16): a fused pair of layers
     // then computes exactly what the two separate launches would (and an fp16 value is an exact operand: no split)
     uint2 stored{0u, 0u};
@@ -1320,6 +1343,68 @@ struct RrW { WPair w[2]; };                        // one k-step of two column b
 // that are meant to stay in flight across it
 __device__ __forceinline__ void rr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The W stream of a register-resident chain.  PLAN: NL layers with KP[l] k-pairs (+ TL[l]: a 16-k tail) and NCB[l]
+// column blocks; steps run layer by layer, pass by pass (two column blocks), k-step by k-step; two steps = a superstep =
+// one 8 KB ring slot of 8 chunks, chunk w = (step 2S + (w >> 2), column block (w >> 1) & 1, hi / lo half w & 1) carried
+// by wave w.  Every layer has an even number of steps, so a superstep never straddles two layers.  All arguments named
+// S / g are constants after unrolling: the layer look-ups fold.
+template <class PLAN>
+struct RrStream {
+    const float *w[PLAN::NL];                        // packed weights of the layers
+    uint4 *ring;
+    int wave, lane;
+    uint4 st[RR_STAGE];                              // this wave's chunks on their way from L2 to the ring
+
+    static __device__ __forceinline__ constexpr int steps(int l) { return PLAN::NCB[l] / 2 * (PLAN::KP[l] + PLAN::TL[l]); }
+    static __device__ __forceinline__ constexpr int first(int l) { int g = 0; for (int i = 0; i < l; ++i) g += steps(i); return g; }
+    static constexpr int total() { int g = 0; for (int i = 0; i < PLAN::NL; ++i) g += PLAN::NCB[i] / 2 * (PLAN::KP[i] + PLAN::TL[i]); return g; }
+
+    __device__ __forceinline__ void issue(int S)                          // request this wave's chunk of superstep S
+    {
+        if (2 * S >= total()) return;
+        const int g = 2 * S;
+        int l = 0;
+#pragma unroll
+        for (int i = 1; i < PLAN::NL; ++i) l = g >= first(i) ? i : l;
+        const int kp = PLAN::KP[l], tl = PLAN::TL[l], spp = kp + tl, KS = 2 * kp + tl;
+        constexpr int BB = WFrag<MODE_SPLIT>::BLOCK_BYTES;
+        const int slA = g - first(l), slB = slA + 1;
+        const int passA = slA / spp, kA = slA - passA * spp, passB = slB / spp, kB = slB - passB * spp;
+        const bool tailA = kA >= kp, tailB = kB >= kp;
+        const int offA = 2 * passA * KS * BB + (tailA ? (KS - 1) * BB : kA * 2 * BB);
+        const int offB = 2 * passB * KS * BB + (tailB ? (KS - 1) * BB : kB * 2 * BB);
+        const int second = wave >> 2;                                     // (scalars)
+        const bool is_tail = second ? tailB : tailA;
+        const int off = (second ? offB : offA) + ((wave >> 1) & 1) * KS * BB + ((wave & 1) && !is_tail ? 1024 : 0);
+        st[S % RR_STAGE] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(weight_rsrc(w[l]), lane * 16u, off, 0));
+    }
+    __device__ __forceinline__ void commit(int S)                         // ... into chunk `wave` of slot S % RR_NSLOT
+    {
+        if (2 * S >= total()) return;
+        ring[(S % RR_NSLOT) * RR_SLOT_U4 + wave * 64 + lane] = st[S % RR_STAGE];
+    }
+    __device__ __forceinline__ void fetch(int g, RrW &dst) const          // step g's operands: chunks (g % 2) * 4 + 2t (+ 1: lo)
+    {
+        if (g >= total()) return;
+        const uint4 *slot = ring + ((g / 2) % RR_NSLOT) * RR_SLOT_U4 + (g % 2) * 256 + lane;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { dst.w[t].hi = slot[t * 128]; dst.w[t].lo = slot[t * 128 + 64]; }
+    }
+    // end of superstep S: superstep S + 1 goes into the slot S - 1 used (every wave read it before the last barrier)
+    __device__ __forceinline__ void advance(int S)
+    {
+        commit(S + 1);
+        issue(S + 1 + RR_STAGE);
+        rr_barrier();
+    }
+    __device__ __forceinline__ void start()                               // the first RR_STAGE supersteps requested
+    {
+#pragma unroll
+        for (int S = 0; S < RR_STAGE; ++S) issue(S);
+    }
+    __device__ __forceinline__ void prime() { commit(0); issue(RR_STAGE); }   // superstep 0 into the ring (then: rr_barrier())
+};
+
 // One layer on the wave's 16 rows.  in[p]: operand pairs, tail: the 16-k tail block (TAIL); NCB column blocks, two per
 // pass, a pass = KP pair steps (+ the tail step).  The W stream of the WHOLE kernel is one sequence of steps (layer by
 // layer, pass by pass), two steps = one superstep = one ring slot.  Every step reads its operands from the ring (fetch:
@@ -1394,6 +1479,71 @@ __device__ __forceinline__ float4 quad_value(unsigned h01_, unsigned h23_, unsig
     return float4{(float)h01.x + (float)l01.x, (float)h01.y + (float)l01.y, (float)h23.x + (float)l23.x, (float)h23.y + (float)l23.y};
 }
 
+// The tail of a register-resident chain: masked softmax over the K rows of a point of the 64 logits, weighted sum of the
+// 64 values (two operand pairs: hi + lo is the value, as the tile kernels' act_get reads it), 32 channels at a time: the
+// rows go through LDS (logits | values | mask; the scratch overwrites the W ring, which is dead: the last superstep's
+// barrier is behind every wave's last ring read), then a half-wave per point, lane = channel; the same expressions in
+// the same order as pool_masked_softmax.
+template <bool F16>
+__device__ __forceinline__ void rr_pool(float *lds, const float4 (&logit)[4], const ActPair &v0, const ActPair &v1, float mk, int r,
+                                        int wave, int lane, int K, int P, long first_point, long total_points, void *out)
+{
+    const int kq = lane >> 4;
+    float *lg = lds, *xv = lds + RR_ROWS * RR_PITCH, *mrow = lds + 2 * RR_ROWS * RR_PITCH;
+    if (kq == 0) mrow[r] = mk;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();                   // the first half's reads are done
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int cb = 2 * half + c2;
+            *reinterpret_cast<float4 *>(lg + r * RR_PITCH + c2 * 16 + 4 * kq) = logit[cb];
+            const ActPair &xp = half ? v1 : v0;      // pair `half` = column blocks 2*half, 2*half + 1 of the values
+            *reinterpret_cast<float4 *>(xv + r * RR_PITCH + c2 * 16 + 4 * kq) = c2 == 0 ? quad_value(xp.hi.x, xp.hi.y, xp.lo.x, xp.lo.y)
+                                                                                       : quad_value(xp.hi.z, xp.hi.w, xp.lo.z, xp.lo.w);
+        }
+        __syncthreads();
+        const int ch = lane & 31;
+        for (int pp = wave * 2 + (lane >> 5); pp < P; pp += 2 * RR_WAVES) {
+            const long p = first_point + pp;
+            if (p >= total_points) break;
+            const float *lcol = lg + (pp * K) * RR_PITCH + ch, *vcol = xv + (pp * K) * RR_PITCH + ch;
+            float mx = -INFINITY, den = 0.0f, sum = 0.0f;
+            for (int k0 = 0; k0 < K; k0 += 8) {
+                float l[8], v[8], w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = min(k0 + u, K - 1);
+                    l[u] = lcol[k * RR_PITCH];
+                    v[u] = vcol[k * RR_PITCH];
+                    w[u] = mrow[pp * K + k];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (k0 + u >= K) break;
+                    const float x = w[u] == 1.0f ? l[u] : -1e10f;
+                    if (x > mx) {
+                        const float sc = exp_hw(mx - x);
+                        den = den * sc + 1.0f;
+                        sum = sum * sc + v[u];
+                        mx = x;
+                    } else {
+                        const float e = exp_hw(x - mx);
+                        den += e;
+                        sum += e * v[u];
+                    }
+                }
+            }
+            feat_store(out, p * 64 + 32 * half + ch, sum / den, F16);
+        }
+    }
+}
+
+template <int FP> struct Cv1Plan {                 // CV_0 (FP pairs + geometry tail -> 128), CV_1, CV_2, CV_xyz (tail -> 64), sum_CV_0, sum_CV_1
+    static constexpr int NL = 6;
+    static constexpr int KP[6] = {FP, 4, 2, 0, 4, 4}, TL[6] = {1, 0, 0, 1, 0, 0}, NCB[6] = {8, 4, 4, 4, 8, 4};
+};
+
 template <int C, bool F16>
 __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_args a)
 {
@@ -1407,46 +1557,12 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     unsigned bad = 0;
     // ---- the W stream.  Steps per layer: CV_0 4*(FP+1), CV_1 2*4, CV_2 2*2, CV_xyz 2*1, sum_CV_0 4*4, sum_CV_1 2*4
-    constexpr int E0 = 4 * (FP + 1), E1 = E0 + 8, E2 = E1 + 4, E3 = E2 + 2, E4 = E3 + 16, E5 = E4 + 8, NSUP = E5 / 2;
-    uint4 st[RR_STAGE];
-    // request this wave's chunk of superstep S: chunk w = (step 2S + (w >> 2), column block (w >> 1) & 1, hi / lo half w & 1)
-    auto issue = [&](int S, uint4 &dst) {                                // (S is a constant after unrolling)
-        if (S >= NSUP) return;
-        const int g = 2 * S;
-        const elo_dense &L = g < E0 ? a.cv0 : g < E1 ? a.cv1 : g < E2 ? a.cv2 : g < E3 ? a.cv_xyz : g < E4 ? a.sum_cv0 : a.sum_cv1;
-        const int kp = g < E0 ? FP : g < E1 ? 4 : g < E2 ? 2 : g < E3 ? 0 : 4;
-        const int tl = (g < E0 || (g >= E2 && g < E3)) ? 1 : 0;
-        const int g0 = g < E0 ? 0 : g < E1 ? E0 : g < E2 ? E1 : g < E3 ? E2 : g < E4 ? E3 : E4;
-        const int spp = kp + tl, KS = 2 * kp + tl;
-        constexpr int BB = WFrag<MODE_SPLIT>::BLOCK_BYTES;
-        const int slA = g - g0, slB = slA + 1;
-        const int passA = slA / spp, kA = slA - passA * spp, passB = slB / spp, kB = slB - passB * spp;
-        const bool tailA = kA >= kp, tailB = kB >= kp;
-        const int offA = 2 * passA * KS * BB + (tailA ? (KS - 1) * BB : kA * 2 * BB);
-        const int offB = 2 * passB * KS * BB + (tailB ? (KS - 1) * BB : kB * 2 * BB);
-        const int second = wave >> 2;                                     // (scalars)
-        const bool is_tail = second ? tailB : tailA;
-        const int off = (second ? offB : offA) + ((wave >> 1) & 1) * KS * BB + ((wave & 1) && !is_tail ? 1024 : 0);
-        dst = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(weight_rsrc(L.w_packed), lane * 16u, off, 0));
-    };
-    auto commit = [&](int S, const uint4 &src) {                         // chunk w of slot S % RR_NSLOT
-        if (S >= NSUP) return;
-        ring[(S % RR_NSLOT) * RR_SLOT_U4 + wave * 64 + lane] = src;
-    };
-    auto fetch = [&](int g, RrW &dst) {                                  // step g's operands: chunks (g % 2) * 4 + 2t (+ 1: lo)
-        if (g >= E5) return;
-        const uint4 *slot = ring + ((g / 2) % RR_NSLOT) * RR_SLOT_U4 + (g % 2) * 256 + lane;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) { dst.w[t].hi = slot[t * 128]; dst.w[t].lo = slot[t * 128 + 64]; }
-    };
-    // end of superstep S: superstep S + 1 goes into the slot S - 1 used (every wave read it before the last barrier)
-    auto advance = [&](int S) {
-        commit(S + 1, st[(S + 1) % RR_STAGE]);
-        issue(S + 1 + RR_STAGE, st[(S + 1) % RR_STAGE]);
-        rr_barrier();
-    };
-#pragma unroll
-    for (int S = 0; S < RR_STAGE; ++S) issue(S, st[S]);
+    typedef RrStream<Cv1Plan<FP>> Stream;
+    Stream ws{{a.cv0.w_packed, a.cv1.w_packed, a.cv2.w_packed, a.cv_xyz.w_packed, a.sum_cv0.w_packed, a.sum_cv1.w_packed}, ring, wave, lane, {}};
+    constexpr int E0 = Stream::first(1), E1 = Stream::first(2), E2 = Stream::first(3), E3 = Stream::first(4), E4 = Stream::first(5);
+    auto fetch = [&](int g, RrW &dst) { ws.fetch(g, dst); };
+    auto advance = [&](int S) { ws.advance(S); };
+    ws.start();
     float4 bias[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const float4 *>(a.cv0.bias + t * 16 + 4 * kq);
@@ -1472,9 +1588,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
         for (int j = 0; j < FP; ++j) { f1[j] = r1[j * 4]; f2[j] = r2[j * 4]; }
         const float *c = a.xyz1 + pt * 3, *g = a.xyz2 + (long)cell * 3;
         const float pc0 = c[0], pc1 = c[1], pc2 = c[2], pg0 = g[0], pg1 = g[1], pg2 = g[2];
-        // superstep 0 into the ring (its load went out first), a later one requested in its place
-        commit(0, st[0]);
-        issue(RR_STAGE, st[0]);
+        ws.prime();                                  // superstep 0 into the ring (its load went out first)
         auto quad = [&](const Item &v, bool keep) {
             const uint4 z{0u, 0u, 0u, 0u};
             if constexpr (F16) return keep ? quad_of_halves(v) : z;
@@ -1520,58 +1634,98 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
     rr_layer<4, false, 4, E4>(h128, none, a.sum_cv1, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         logit[2 * pass + t] = relu4(acc, a.sum_cv1.relu);
     });
-    // (the last superstep's barrier is behind every wave's last ring read: the scratch below may overwrite it)
-    // ---- masked softmax over the K rows of a point, weighted sum of x (:92-98), 32 channels at a time: the rows go through
-    // LDS (logits | values | mask), then a half-wave per point, lane = channel; the same expressions in the same order as
-    // pool_masked_softmax
-    float *lg = lds, *xv = lds + RR_ROWS * RR_PITCH, *mrow = lds + 2 * RR_ROWS * RR_PITCH;
-    if (kq == 0) mrow[r] = mk;
+    rr_pool<F16>(lds, logit, xe[0], xe[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
+    report_violations<MODE_SPLIT>(bad);
+}
+// ---- cost volume, stage 2, register-resident (see cv1_rr_kernel): xyz-encoding (geometry tail -> 64), sum_cost_volume_0
+// ([grouped cost (64) | encoding (64) | feat1 (C)] -> 128), sum_cost_volume_1 (-> 64 logits), masked softmax over the K
+// rows of a point weighting the grouped cost (utils/pointnet_util.py:110-146).  Neighbours from a.idx / a.mask.
+template <int C> struct Cv2Plan {
+    static constexpr int NL = 3;
+    static constexpr int KP[3] = {0, 4 + C / 32, 4}, TL[3] = {1, C == 16 ? 1 : 0, 0}, NCB[3] = {4, 8, 4};
+};
+
+template <int C, bool F16>
+__global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_args a)
+{
+    extern __shared__ __align__(16) float lds[];
+    constexpr int FP = C / 16, KP1 = 4 + C / 32;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int K = a.K, P = RR_ROWS / K;
+    const long total_points = (long)a.batch * a.npoints;
+    const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
+    unsigned bad = 0;
+    typedef RrStream<Cv2Plan<C>> Stream;
+    Stream ws{{a.xyz_enc.w_packed, a.sum_cost0.w_packed, a.sum_cost1.w_packed}, reinterpret_cast<uint4 *>(lds), wave, lane, {}};
+    constexpr int E0 = Stream::first(1), E1 = Stream::first(2);
+    auto fetch = [&](int g, RrW &dst) { ws.fetch(g, dst); };
+    auto advance = [&](int S) { ws.advance(S); };
+    ws.start();
+    float4 bias[2];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (half) __syncthreads();                   // the first half's reads are done
+    for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const float4 *>(a.xyz_enc.bias + t * 16 + 4 * kq);
+    // ---- row metadata + gather (this lane's row: r = wave * 16 + i16 = point * K + slot)
+    const int r = wave * 16 + i16, pi = r / K;
+    long pt = first_point + pi;
+    const bool used = pi < P && pt < total_points;
+    if (!used) pt = first_point;
+    const long gr = used ? pt * K + (r - pi * K) : first_point * K;
+    const int id0 = a.idx[gr * 3 + 0], id1 = a.idx[gr * 3 + 1], id2 = a.idx[gr * 3 + 2];
+    float mk = a.mask[gr];
+    const int cell = (id0 * a.H + id1) * a.W + id2;
+    if (!used) mk = 0.0f;
+    const bool keep2 = used && mk != 0.0f;
+    ActPair in1[KP1];                                // sum_cost_volume_0's pairs: [grouped cost | encoding | feat1]
+    uint4 geo, ftail = uint4{0u, 0u, 0u, 0u};        // the geometry quad (xyz-encoding's input); feat1's quad when C == 16 (a tail block)
+    {
+        typedef typename std::conditional<F16, uint2, float4>::type Item;     // 4 channels
+        Item fc[4], f1[FP];
+        const Item *rc = reinterpret_cast<const Item *>(a.cost) + ((long)cell * 64 >> 2) + kq;
+        const Item *r1 = reinterpret_cast<const Item *>(a.feat1) + (pt * C >> 2) + kq;
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            const int cb = 2 * half + c2;
-            *reinterpret_cast<float4 *>(lg + r * RR_PITCH + c2 * 16 + 4 * kq) = logit[cb];
-            const ActPair &xp = xe[half];            // x's pair `half` = its column blocks 2*half, 2*half + 1
-            *reinterpret_cast<float4 *>(xv + r * RR_PITCH + c2 * 16 + 4 * kq) = c2 == 0 ? quad_value(xp.hi.x, xp.hi.y, xp.lo.x, xp.lo.y)
-                                                                                       : quad_value(xp.hi.z, xp.hi.w, xp.lo.z, xp.lo.w);
+        for (int j = 0; j < 4; ++j) fc[j] = rc[j * 4];
+#pragma unroll
+        for (int j = 0; j < FP; ++j) f1[j] = r1[j * 4];
+        const float *c = a.xyz1 + pt * 3, *g = a.xyz1 + (long)cell * 3;
+        const float pc0 = c[0], pc1 = c[1], pc2 = c[2], pg0 = g[0], pg1 = g[1], pg2 = g[2];
+        ws.prime();
+        auto quad = [&](const Item &v, bool keep) {
+            const uint4 z{0u, 0u, 0u, 0u};
+            if constexpr (F16) return keep ? quad_of_halves(v) : z;
+            else return keep ? pack_quad<MODE_SPLIT>(v, bad) : z;
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) put_quad(in1[j / 2], j % 2, quad(fc[j], keep2));           // cost[idx] * mask   :110
+        if constexpr (C == 16) ftail = quad(f1[0], used);
+        else {
+#pragma unroll
+            for (int j = 0; j < FP; ++j) put_quad(in1[4 + j / 2], j % 2, quad(f1[j], used));   // centre features    :115
         }
-        __syncthreads();
-        const int ch = lane & 31;
-        for (int pp = wave * 2 + (lane >> 5); pp < P; pp += 2 * RR_WAVES) {
-            const long p = first_point + pp;
-            if (p >= total_points) break;
-            const float *lcol = lg + (pp * K) * RR_PITCH + ch, *vcol = xv + (pp * K) * RR_PITCH + ch;
-            float mx = -INFINITY, den = 0.0f, sum = 0.0f;
-            for (int k0 = 0; k0 < K; k0 += 8) {
-                float l[8], v[8], w[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int k = min(k0 + u, K - 1);
-                    l[u] = lcol[k * RR_PITCH];
-                    v[u] = vcol[k * RR_PITCH];
-                    w[u] = mrow[pp * K + k];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (k0 + u >= K) break;
-                    const float x = w[u] == 1.0f ? l[u] : -1e10f;
-                    if (x > mx) {
-                        const float sc = exp_hw(mx - x);
-                        den = den * sc + 1.0f;
-                        sum = sum * sc + v[u];
-                        mx = x;
-                    } else {
-                        const float e = exp_hw(x - mx);
-                        den += e;
-                        sum += e * v[u];
-                    }
-                }
-            }
-            feat_store(a.out, p * 64 + 32 * half + ch, sum / den, F16);
-        }
+        const float g0 = pg0 * mk, g1 = pg1 * mk, g2 = pg2 * mk;
+        const float d0 = g0 - pc0, d1 = g1 - pc1, d2 = g2 - pc2;
+        const float e = sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + 1e-20f);
+        const float4 q4 = kq == 0 ? float4{pc0, pc1, pc2, g0} : kq == 1 ? float4{g1, g2, d0, d1}
+                        : kq == 2 ? float4{d2, e, 0.0f, 0.0f} : float4{0.0f, 0.0f, 0.0f, 0.0f};
+        geo = used ? pack_quad<MODE_SPLIT>(q4, bad) : uint4{0u, 0u, 0u, 0u};
     }
+    rr_barrier();
+    const uint4 none{0u, 0u, 0u, 0u};
+    {
+        ActPair unused[1];
+        rr_layer<0, true, 4, 0>(unused, geo, a.xyz_enc, a.sum_cost0.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+            put_quad(in1[2 + pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.xyz_enc.relu), bad));      // encoding: pairs 2, 3
+        });
+    }
+    ActPair h128[4];
+    rr_layer<KP1, C == 16, 8, E0>(in1, ftail, a.sum_cost0, a.sum_cost1.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h128[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.sum_cost0.relu), bad));
+    });
+    float4 logit[4];
+    rr_layer<4, false, 4, E1>(h128, none, a.sum_cost1, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        logit[2 * pass + t] = relu4(acc, a.sum_cost1.relu);
+    });
+    rr_pool<F16>(lds, logit, in1[0], in1[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
     report_violations<MODE_SPLIT>(bad);
 }
 #endif   // !ELO_DENSE_F32
@@ -2122,8 +2276,25 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
     const int KT = a->group.random_hw ? a->group.kernel_h * a->group.kernel_w : 0;
     const size_t lds = tile_lds_bytes(t16 ? 16 : 32, S, KT, false);
     if (int rc = check_group(a->group, a->H, a->W, lds, who)) return rc;
-    const dim3 grid((unsigned)(t16 ? u16 : u32));
     hipStream_t s = (hipStream_t)stream;
+#ifndef ELO_DENSE_F32
+    if (!a->group.random_hw && mode == MODE_SPLIT && cv1_rr_on() && (a->C == 16 || a->C == 32 || a->C == 64)) {
+        const int P = RR_ROWS / a->K;                              // points per workgroup (128 rows)
+        const dim3 rgrid((unsigned)((points + P - 1) / P));
+        const bool f16 = a->feat_dtype == ELO_F16;
+#define RR(CC)                                                                                                           \
+        do {                                                                                                             \
+            if (f16) hipLaunchKernelGGL((cv2_rr_kernel<CC, true>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);     \
+            else hipLaunchKernelGGL((cv2_rr_kernel<CC, false>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);        \
+        } while (0)
+        if (a->C == 16) RR(16);
+        else if (a->C == 32) RR(32);
+        else RR(64);
+#undef RR
+        return check_launch(who);
+    }
+#endif
+    const dim3 grid((unsigned)(t16 ? u16 : u32));
 #define CALL(k) hipLaunchKernelGGL(k, grid, dim3(FUSED_BLOCK), lds, s, *a, S)
     ELO_PICK(cv2_kernel, t16, mode, CALL);
 #undef CALL

@@ -335,16 +335,17 @@ def mlp2_pair(job_a, job_b):
     return (shape(out_a), shape(out2_a)), (shape(out_b), shape(out2_b))
 
 
-def _prepass_points():
-    """Centre points per launch from which cost-volume stage 1 runs its select-k as a PRE-PASS (a stand-alone grouping
-    launch writes idx / mask) and the REGISTER-RESIDENT kernel (cv1_rr_kernel: one W stream per 128 rows through an LDS
-    ring, activations in registers) starts from them, instead of the tile kernel with in-kernel grouping.  Measured
-    (tools/cv1_variants.py, profiles/r03_cv1_variants.txt): l0 at batch 8 115 -> 88 us, l1 38 -> 29 us; below ~4000
-    points the extra launch costs more than the kernel saves, and at batch 1-2 the tile kernel also carries the
-    set-upconv riders of its level.  ELO_CV1_PREPASS: 0 = never, 1 = always, N = from N points on; unset = 4096."""
+def _prepass_rows(stage=1):
+    """Rows (centre points x K) per launch from which a cost-volume stage runs its grouping as a PRE-PASS (a stand-alone
+    grouping launch writes idx / mask) and the REGISTER-RESIDENT kernel (cv1_rr_kernel / cv2_rr_kernel: one W stream per
+    128 rows through an LDS ring, activations in registers) starts from them, instead of the tile kernel with in-kernel
+    grouping.  Measured (tools/cv1_variants.py, profiles/r03_cv1_variants.txt): stage 1 at l0, batch 8, 115 -> 87 us, l1
+    38 -> 30 us; stage 2 at l0 46 -> 39 us; below ~25 k rows (stage 2, a third of the work per row: ~64 k) the extra launch
+    costs more than the kernel saves, and at batch 1-2 the stage-1 tile kernel also carries the set-upconv riders of its
+    level.  ELO_CV_PREPASS: 0 = never, 1 = always, N = from N rows on (both stages)."""
     import os
-    e = os.environ.get("ELO_CV1_PREPASS")
-    return 4096 if e is None else (1 << 60) if e == "0" else 0 if e == "1" else int(e)
+    e = os.environ.get("ELO_CV_PREPASS")
+    return (24576 if stage == 1 else 65536) if e is None else (1 << 60) if e == "0" else 0 if e == "1" else int(e)
 
 
 _HW = {}
@@ -366,22 +367,37 @@ def _all_pixels(B, H, W, device):
     return hit
 
 
-def select_prepass(xyz1_grid, xyz2_grid, group, K):
-    """The cost volume's select-k (every pixel of xyz1_grid a centre) as its own launch: (idx (B,N,K,3) int32, mask (B,N,K)).
-    Large grids (>= 1024 tiles of 64 centres) take the LDS-tiled elo_fused_conv_select_k_dense (64x1800: 2.5x faster),
-    the pyramid's small levels the wave-per-centre kernel (its fixed cost is a third of the tiled one's)."""
+def group_prepass(kind, xyz1_grid, xyz2_grid, group, K):
+    """A cost volume's grouping (every pixel of xyz1_grid a centre; kind "select" = stage 1's select-k, "random" = stage
+    2's random-k) as its own launch: (idx (B,N,K,3) int32, mask (B,N,K)).  Forms: random-k takes the LDS-tiled
+    elo_fused_conv_random_k_dense when its tile fits; select-k the LDS-tiled elo_fused_conv_select_k_dense on large grids
+    (>= 1024 tiles of 64 centres: 64x1800 is 2.5x faster there) and the wave-per-centre kernel on the pyramid's small
+    levels (its fixed cost is a third of the tiled one's)."""
     B, H, W, _ = xyz1_grid.shape
     _, H2, W2, _ = xyz2_grid.shape
-    N = H * W
+    N, kH, kW = H * W, group.kernel_h, group.kernel_w
     idx = torch.empty((B, N, K, 3), dtype=torch.int32, device=xyz1_grid.device)
     mask = torch.empty((B, N, K), dtype=torch.float32, device=xyz1_grid.device)
-    dense = -(-W // 64) * H * B >= 1024 and K <= 7 and group.kernel_h * group.kernel_w <= 512
+    if kind == "select":
+        dense = -(-W // 64) * H * B >= 1024 and K <= 7 and kH * kW <= 512
+        entry = "elo_fused_conv_select_k_dense" if dense else "elo_fused_conv_select_k"
+    else:
+        RH, RW = 1 // group.stride_h + kH, 63 // group.stride_w + kW           # (fused_conv._dense_fits)
+        dense = 4 * ((kH * kW + 7) & ~7) + 16 * RH * RW + 4 * (129 * K + 256) <= 64 * 1024
+        entry = "elo_fused_conv_random_k_dense" if dense else "elo_fused_conv_random_k"
     hw = None if dense else _all_pixels(B, H, W, xyz1_grid.device)
-    a = L.GroupArgs(B, H, W, H2, W2, N, group.kernel_h, group.kernel_w, K, 0, group.distance, group.stride_h, group.stride_w,
+    a = L.GroupArgs(B, H, W, H2, W2, N, kH, kW, K, 0, group.distance, group.stride_h, group.stride_w,
                     xyz1_grid.data_ptr(), xyz2_grid.data_ptr(), None if dense else hw.data_ptr(), group.random_hw.data_ptr(),
                     idx.data_ptr(), None, None, mask.data_ptr())
-    L.call("elo_fused_conv_select_k_dense" if dense else "elo_fused_conv_select_k", a, idx)
+    L.call(entry, a, idx)
     return idx, mask
+
+
+def _rr_path(group, B, N, K, C, stage=1):
+    """True when a cost-volume stage with in-kernel grouping should take the pre-pass + register-resident kernel."""
+    return (group is not None and not group.want_indices and K <= 32 and B * N * K >= _prepass_rows(stage)
+            and group.stride_h == 1 and group.stride_w == 1 and _products == PRODUCTS_SPLIT and not fp32_mfma()
+            and C in (16, 32, 64))
 
 
 def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1, group=None, K=None,
@@ -395,10 +411,8 @@ def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_x
     _, H2, W2, C = feat2_proj.shape
     B, N = xyz1.shape[0], xyz1.shape[1]
     ptr = lambda x: x.data_ptr() if x is not None else None
-    if (group is not None and not side and not group.want_indices and N == H2 * W2 and B * N >= _prepass_points()
-            and group.stride_h == 1 and group.stride_w == 1 and _products == PRODUCTS_SPLIT and not fp32_mfma()
-            and C in (16, 32, 64)):
-        idx, mask = select_prepass(xyz1.reshape(B, H2, W2, 3), xyz2_proj, group, K)
+    if not side and N == H2 * W2 and _rr_path(group, B, N, K, C):
+        idx, mask = group_prepass("select", xyz1.reshape(B, H2, W2, 3), xyz2_proj, group, K)
         group = None
     if group is None:
         idx, mask = idx.contiguous(), _f32c(mask)
@@ -423,6 +437,9 @@ def cv_stage2(xyz1_proj, feat1_proj, cost_proj, idx, mask, xyz_enc, sum_cost0, s
     B, H, W, C = feat1_proj.shape
     N = H * W
     ptr = lambda x: x.data_ptr() if x is not None else None
+    if _rr_path(group, B, N, K, C, stage=2):
+        idx, mask = group_prepass("random", xyz1_proj, xyz1_proj, group, K)
+        group = None
     if group is None:
         idx, mask = idx.contiguous(), _f32c(mask)
         K = idx.shape[2]

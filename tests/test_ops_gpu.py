@@ -536,3 +536,45 @@ def test_register_resident_cost_volume_equals_the_tile_kernel(kernel_path, B, H,
     assert rr.dtype == tile.dtype and torch.isfinite(rr.float()).all()
     assert torch.equal(rr, tile) and torch.equal(rr, own)
     assert m.mean() > 0.5 and m.min() == 0                           # masked slots are in the mix
+
+
+@pytest.mark.parametrize("B,H,W,C,features", [(2, 16, 225, 16, "f32"), (1, 8, 113, 32, "f32"), (3, 4, 57, 64, "f32"), (2, 16, 225, 16, "f16"),
+                                              (1, 4, 57, 64, "f16"), (1, 5, 33, 32, "f16")])
+def test_register_resident_cost_volume_stage2_equals_the_tile_kernel(kernel_path, B, H, W, C, features):
+    """cv2_rr_kernel against cv2_kernel from the same idx / mask (random-k 3x5, K = 4 of the warped cloud on itself), and
+    against the launch that groups in-kernel: bit for bit, fp32 and fp16 storage, C = 16 (feat1 is a 16-k tail block) /
+    32 / 64."""
+    if kernel_path != "fused":
+        pytest.skip("fused kernels only")
+    fused, tf_util, synth, elo, lib = load_pkg("fused"), load_pkg("tf_util"), load_pkg("synth"), load_pkg(), load_pkg("_lib")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    f1, _ = synth.frame_pair(B, H, W, seed=H * W + C + 1)
+    rng = np.random.default_rng(C + 1)
+    dt = np.float16 if features == "f16" else np.float32
+    fa = rng.normal(0, 1, (B, H, W, C)).astype(dt)
+    cost = rng.normal(0, 1, (B, H, W, 64)).astype(dt)
+    N, K = H * W, 4
+    perm = rng.permutation(15).astype(np.int32)
+    store = tf_util.VariableStore(DEV, seed=4)
+    with tf_util.default_store(store), torch.no_grad():
+        P = fused.packed_layer
+        order = list(range(64 + C, 128 + C)) + list(range(64)) + list(range(64, 64 + C))
+        layers = (P("xe", 10, 64), P("s0", 128 + C, 128, row_order=order), P("s1", 128, 64))
+        for p_ in layers:
+            p_.b.copy_(torch.from_numpy(rng.normal(0, 0.1, p_.b.shape).astype(np.float32)))
+        hw = t(synth.hw_index(B, H, W))
+        idx, _, _, m = elo.fused_conv_random_k(t(f1), t(f1), hw, t(perm), H, W, N, 3, 5, K, 0, 2.0, 1, 1, want_valid=False)
+        m = m.reshape(B, N, K)
+        run = lambda: fused.cv_stage2(t(f1), t(fa), t(cost), idx, m, *layers)
+        try:
+            lib.lib().elo_debug_cv1_rr(0)
+            tile = run()
+            lib.lib().elo_debug_cv1_rr(1)
+            rr = run()
+        finally:
+            lib.lib().elo_debug_cv1_rr(-1)
+        own = fused.cv_stage2(t(f1), t(fa), t(cost), None, None, *layers, group=fused.Grouping(t(perm), [3, 5], 2.0), K=K)
+    torch.cuda.synchronize()
+    assert rr.dtype == tile.dtype and torch.isfinite(rr.float()).all()
+    assert torch.equal(rr, tile) and torch.equal(rr, own)
+    assert 0.3 < m.mean() and m.min() == 0
