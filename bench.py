@@ -77,6 +77,10 @@ def parse():
                          "half = ONE fp16 product (fp16 arithmetic; not the fp32 parity path)")
     ap.add_argument("--features", choices=("f32", "f16"), default="f32",
                     help="storage of the feature tensors in HBM (f16: BASELINE configs[2]); arithmetic is unchanged")
+    ap.add_argument("--fresh-orders", type=int, default=16,
+                    help="pre-drawn window visiting orders per lane: every replay walks the next set (tf.random_shuffle per "
+                         "sess.run, utils/pointnet_util.py:45,104,193,270: one tiny launch at the head of each replay); 0 = one "
+                         "fixed draw for the life of the graph")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true",
@@ -165,65 +169,58 @@ def _pmc_traffic(kernel, batch, features="f32"):
     return None if hit is None else hit.get("traffic_bytes")
 
 
-class CostVolumeLevel:
-    """The two fused cost-volume launches of one pyramid level (pwclo_model.py:170, :242, :316, :390) on synthetic inputs
-    of that level's shape: run1() = stage 1 (select-k + encode + six convolutions + softmax pooling), run2() = stage 2."""
-    SHAPES = {"l0": (2, 16, 6, (11, 41)), "l1": (3, 32, 6, (7, 25)), "l2": (4, 64, 6, (5, 15)), "l2_origin": (4, 64, 32, (5, 35))}
-
-    def __init__(self, level, B, H_in, W_in, dev, net, half):
-        import torch
-        fused, tf_util, pm, synth = pkg("fused"), pkg("tf_util"), pkg("pwclo_model"), pkg("synth")
-        oh, ow = pm.pyramid_sizes(H_in, W_in)
-        gi, C, Kq, win = self.SHAPES[level]
-        H, W = oh[gi], ow[gi]
-        self.level, self.B, self.N, self.C, self.Kq, self.Kp = level, B, H * W, C, Kq, 4
-        g = torch.Generator(device="cpu").manual_seed(11)
-        f1, f2 = synth.frame_pair(B, H, W, seed=5)
-        x1, x2 = torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev)
-        cast = (lambda t: t.half()) if half else (lambda t: t)
-        ft1, ft2 = (cast(torch.randn((B, H, W, C), generator=g).to(dev)) for _ in range(2))
-        cost = cast(torch.randn((B, H, W, 64), generator=g).to(dev))
-        oq = torch.randperm(win[0] * win[1], generator=g).to(torch.int32).to(dev)
-        op = torch.randperm(15, generator=g).to(torch.int32).to(dev)
-        scope = "flow_embedding_" + level
-        with tf_util.default_store(net.store), torch.no_grad(), tf_util.variable_scope(scope):
-            P = fused.packed_layer
-            l1 = (P('CV_0', 10 + 2 * C, 128, row_order=fused.cv0_row_order(C)), P('CV_1', 128, 64), P('CV_2', 64, 64),
-                  P('CV_xyz', 10, 64), P('sum_CV_0', 128, 128, row_order=list(range(64, 128)) + list(range(64))),
-                  P('sum_CV_1', 128, 64))
-            order = list(range(64 + C, 128 + C)) + list(range(64)) + list(range(64, 64 + C))
-            l2 = (P('sum_xyz_encoding', 10, 64), P('sum_cost_volume_0', 128 + C, 128, row_order=order),
-                  P('sum_cost_volume_1', 128, 64))
-        g1, g2 = fused.Grouping(oq, win, 1000), fused.Grouping(op, [3, 5], {"l0": 1.0, "l1": 2.0}.get(level, 4.0))
-        N = self.N
-        self.run1 = lambda: fused.cv_stage1(x1.reshape(B, N, 3), ft1.reshape(B, N, C), x2, ft2, None, None, *l1, group=g1, K=Kq)
-        self.run2 = lambda: fused.cv_stage2(x1, ft1, cost, None, None, *l2, group=g2, K=4)
-
-    def bytes(self, s):
-        return cost_volume_bytes(self.N, self.C, self.Kq, self.Kp, s)
+LEVELS = ("l2_origin", "l2", "l1", "l0")          # the order in which a forward issues its four cost volumes
 
 
-def cost_volume_leg(dev, net, B, H_in, W_in, half, reps=20):
-    """SURVEY 8(d)'s cost-volume figure ON THE PATH THE VALUE RUNS: the eight fused launches (stage 1 + stage 2 at l0,
-    l1, l2, l2_origin) of one forward at batch B, each timed with HIP events; achieved = the operator-boundary bytes
-    (A1+P1 / A2+P2, s = 4 or 2) of all of them x B / the sum of the kernel times, against 8 TB/s.  The fused kernels
-    never materialise those tensors (their HBM traffic is the compulsory bytes only, `traffic`), so this is the
-    section-8(d) accounting figure, not a bandwidth they could reach: what bounds them is the matrix + vector work,
-    `mfma` (executed fp16 products against the 2.5 PFLOP/s fp16 peak)."""
+def recorded_cost_volume(dev, B, H_in, W_in, half, seed=5):
+    """The eight cost-volume launches of ONE REAL FORWARD at batch B (pwclo_model.py:170, :242, :316, :390), on the tensors
+    that forward fed them: an eager forward of a fresh net (random-init weights, seed 0: the timed workload's) on a
+    synthetic pair is recorded (fused.recording clones every argument), and each level's stage 1 / stage 2 call can be
+    re-issued as often as a timing needs.  {level: dict(run1, run2, N, C, Kq, Kp, riders)}; `riders`: stage 1 carried
+    set-upconv jobs in the forward (batch 1-2) -- run1 re-issues the cost volume alone."""
+    import torch
+    model, synth, fused = pkg("model"), pkg("synth"), pkg("fused")
+    net = model.PWCLONet(dev, seed=0, feature_dtype=torch.float16 if half else torch.float32)
+    f1, f2 = synth.frame_pair(B, H_in, W_in, seed=seed)
+    both = torch.cat([torch.from_numpy(f1), torch.from_numpy(f2)], 0).to(dev)
+    net.forward(both[:B], both[B:])                      # variables, packed weights, caches
+    with fused.recording() as calls:
+        net.forward(both[:B], both[B:])
+    torch.cuda.synchronize(dev)
+    s1 = [c for c in calls if c[0] == 1]
+    s2 = [c for c in calls if c[0] == 2]
+    assert len(s1) == 4 and len(s2) == 4, (len(s1), len(s2))
+    out = {}
+    for name, c1, c2 in zip(LEVELS, s1, s2):
+        xyz1, feat1 = c1[1][0], c1[1][1]
+        out[name] = dict(run1=(lambda c=c1: fused.cv_stage1(*c[1], **c[2])), run2=(lambda c=c2: fused.cv_stage2(*c[1], **c[2])),
+                         N=xyz1.shape[1], C=feat1.shape[-1], Kq=c1[2]["K"], Kp=c2[2]["K"], riders=c1[3])
+    return out
+
+
+def cost_volume_leg(dev, B, H_in, W_in, half, reps=20):
+    """SURVEY 8(d)'s cost-volume figure ON THE PATH THE VALUE RUNS: the eight fused launches (stage 1 + stage 2 at
+    l2_origin, l2, l1, l0; from 24.6 k rows on a stage is a grouping pre-pass + the register-resident kernel, timed
+    together) of one forward at batch B ON THAT FORWARD'S OWN TENSORS (recorded_cost_volume), each timed with HIP events;
+    achieved = the operator-boundary bytes (A1+P1 / A2+P2, s = 4 or 2) of all of them x B / the sum of the times,
+    against 8 TB/s.  The fused kernels never materialise those tensors (their HBM traffic is the compulsory bytes only),
+    so this is the section-8(d) accounting figure, not a bandwidth they could reach: what bounds them is the matrix +
+    vector work, `mfma` (executed fp16 products against the 2.5 PFLOP/s fp16 peak)."""
     s = 2 if half else 4
+    rec = recorded_cost_volume(dev, B, H_in, W_in, half)
     levels, tot_b, tot_s, tot_f = {}, 0, 0.0, 0
-    for lv in CostVolumeLevel.SHAPES:
-        L = CostVolumeLevel(lv, B, H_in, W_in, dev, net, half)
-        t1, t2 = _time_launches(L.run1, dev, reps), _time_launches(L.run2, dev, reps)
-        cb = L.bytes(s)
+    for lv in ("l0", "l1", "l2", "l2_origin"):
+        L = rec[lv]
+        t1, t2 = _time_launches(L["run1"], dev, reps), _time_launches(L["run2"], dev, reps)
+        cb = cost_volume_bytes(L["N"], L["C"], L["Kq"], L["Kp"], s)
         b1, b2 = (cb["A1"] + cb["P1"]) * B, (cb["A2"] + cb["P2"]) * B
-        fl = (cv1_flops(L.N, L.C, L.Kq) + cv2_flops(L.N, L.C, L.Kp)) * B
+        fl = (cv1_flops(L["N"], L["C"], L["Kq"]) + cv2_flops(L["N"], L["C"], L["Kp"])) * B
         levels[lv] = {"cv1_us": round(t1 * 1e6, 2), "cv2_us": round(t2 * 1e6, 2), "bytes": int(b1 + b2),
                       "GBps": round((b1 + b2) / (t1 + t2) / 1e9, 1), "frac": round((b1 + b2) / (t1 + t2) / 1e9 / HBM_PEAK_GBS, 4)}
         tot_b, tot_s, tot_f = tot_b + b1 + b2, tot_s + t1 + t2, tot_f + fl
     gbs = tot_b / tot_s / 1e9
     tfs = MFMA_PRODUCTS * tot_f / tot_s / 1e12
-    return {"kernel": "cv1_kernel + cv2_kernel at l0, l1, l2, l2_origin (the 8 cost-volume launches of a forward)",
+    return {"kernel": "cost-volume stage 1 + stage 2 at l0, l1, l2, l2_origin (the launches of one forward, on its own tensors)",
             "batch": B, "features": "f16" if half else "f32", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b), "us": round(tot_s * 1e6, 2),
             "target_us_at_60pct": round(tot_b / (0.6 * HBM_PEAK_GBS * 1e9) * 1e6, 1),
@@ -280,28 +277,29 @@ def roofline_leg(args, dev, net, reps=50):
     2.5 PFLOP/s)."""
     B = args.batch
     half = args.features == "f16"
-    L = CostVolumeLevel("l0", B, args.height, args.width, dev, net, half)
-    sec = _time_launches(L.run1, dev, reps)
-    cb = L.bytes(2 if half else 4)
+    L = recorded_cost_volume(dev, B, args.height, args.width, half)["l0"]
+    sec = _time_launches(L["run1"], dev, reps)
+    cb = cost_volume_bytes(L["N"], L["C"], L["Kq"], L["Kp"], 2 if half else 4)
     nbytes = (cb["A1"] + cb["P1"]) * B
-    flops = cv1_flops(L.N, L.C, L.Kq) * B
+    flops = cv1_flops(L["N"], L["C"], L["Kq"]) * B
     gbs = nbytes / sec / 1e9
     ex = MFMA_PRODUCTS if args.products == "split" else 1
-    out = {"bound": "hbm", "kernel": "cv1_kernel (fused cost-volume stage 1 at l0: %d points, K=%d, batch %d, %s features)"
-                                     % (L.N, L.Kq, B, args.features),
+    out = {"bound": "hbm", "kernel": "cv1_kernel (fused cost-volume stage 1 at l0 on the tensors of a real forward: %d points, K=%d, batch %d, %s features)"
+                                     % (L["N"], L["Kq"], B, args.features),
            "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
            "traffic": _pmc_traffic("cv1_kernel", B, args.features),
            "traffic_source": os.path.relpath(PMC_SUMMARY, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                              "not measured in this run)",
            "us_per_launch": round(sec * 1e6, 3), "algorithmic_bytes_per_launch": int(nbytes),
+           "carries_riders_in_the_forward": L["riders"],      # batch 1-2: the forward's launch also runs the level's two set-upconv jobs
            "mfma": {"executed_TFLOPs": round(ex * flops / sec / 1e12, 2), "algorithmic_TFLOPs": round(flops / sec / 1e12, 2),
                     "peak": F16_MFMA_PEAK_TFLOPS, "frac": round(ex * flops / sec / 1e12 / F16_MFMA_PEAK_TFLOPS, 5),
                     "issued_as": "v_mfma_f32_16x16x32_f16 x%d per 32-k pair, v_mfma_f32_16x16x16_f16 x%d on a 16-k tail (%s)" % (
                         ex,
                         ex, "fp16 hi+lo split operands, fp32 accumulate" if ex == 3 else "fp16-rounded operands")}}
     if (args.height, args.width) == (64, 1800):
-        out["cost_volume_b8_f32"] = cost_volume_leg(dev, net, 8, args.height, args.width, False)
-        out["cost_volume_b8_f16"] = cost_volume_leg(dev, net, 8, args.height, args.width, True)
+        out["cost_volume_b8_f32"] = cost_volume_leg(dev, 8, args.height, args.width, False)
+        out["cost_volume_b8_f16"] = cost_volume_leg(dev, 8, args.height, args.width, True)
         out["per_operator_b8_f32"] = per_operator_leg(dev, 8, False)
         out["per_operator_b8_f16"] = per_operator_leg(dev, 8, True)
         out["per_operator_b64_f32"] = per_operator_leg(dev, 64, False)
@@ -374,6 +372,25 @@ def raw_cloud_rate(dev, B, H, W, lanes, points=150000, steps=400):
         net.submit_points(i % lanes, clouds[i % 4])
     torch.cuda.synchronize(dev)
     return round(B * steps / (time.perf_counter() - t0), 1)
+
+
+def hires_leg(dev, lanes):
+    """BASELINE configs[4]'s scans: 128x2048 range images (levels 32x256 / 16x128 / 8x64 / 8x32).  Pairs/s at batch 1 and
+    batch 8 through `lanes` captured graphs, the cost-volume launches of a batch-8 forward on its own tensors, and the
+    LDS footprint of the kernels that stage neighbour windows / W rings there (bytes per workgroup -> workgroups per CU of
+    160 KB; the register-resident kernels are held to 2 by their 116-122 VGPRs)."""
+    H, W = 128, 2048
+    cv = cost_volume_leg(dev, 8, H, W, True, reps=10)
+    sel_words = lambda P, kH, kW: 4 * kH * (63 + kW) + 2 * 64 * 32 + max(P, 8) * 64 + 64 + 64 + ((kH * kW + 3) & ~3) + P * 128
+    lds = {"select_k_dense_11x41 (16 waves per tile)": 4 * sel_words(16, 11, 41), "select_k_dense_11x41 (4 waves per tile)": 4 * sel_words(4, 11, 41),
+           "random_k_dense_3x5_K4 (2 x 64 centres)": 4 * ((15 + 7) & ~7) + 16 * (1 + 3) * (63 + 5) + 4 * (129 * 4 + 256),
+           "cv1_rr / cv2_rr (W ring 16 KB, aliased by the pooling scratch)": 4 * (2 * 128 * 36 + 128)}
+    return {"grid": "%dx%d" % (H, W), "unit": "frame-pairs/s", "lanes": lanes,
+            "batch1": batch_rate(dev, 1, H, W, lanes, "split", "f32", steps=160),
+            "batch8_f32": batch_rate(dev, 8, H, W, lanes, "split", "f32", steps=48),
+            "batch8_f16_features": batch_rate(dev, 8, H, W, lanes, "split", "f16", steps=48),
+            "cost_volume_b8_f16": {k: cv[k] for k in ("us", "bytes", "frac", "levels", "mfma")},
+            "lds_bytes_per_workgroup": lds, "workgroups_per_cu_by_lds": {k: min(160 * 1024 // v, 32) for k, v in lds.items()}}
 
 
 def dense_f32_leg(args):
@@ -575,7 +592,8 @@ def main():
             net.forward(pool[0][:B], pool[0][B:])
         else:
             # a lane's l0 pose-head kernel writes replay r's [q | t] block into slot r of the lane's ring
-            net.capture(B, H, W, lanes=lanes, pose_ring=max(2, -(-max(args.steps, warmup) // lanes)))
+            net.capture(B, H, W, lanes=lanes, pose_ring=max(2, -(-max(args.steps, warmup) // lanes)), sample=pool[0],
+                        fresh_orders=args.fresh_orders)
         # every step's l0 pose [q | t] is kept: one (B,7) row block per step in HBM, collected from the lanes' rings at
         # the end of each repeat INSIDE the timed region (one strided copy per lane; round 1-2 copied one block out per
         # step, a launch that sat ~14 us in every lane's serial chain); with N > 1 ranks the blocks are all-gathered ONCE
@@ -654,7 +672,9 @@ def main():
                                "set-upconv), %dx%d range-image pairs, batch %d per GPU, %s feature storage, "
                                "random-init weights, %s" % (H, W, B, "fp16" if args.features == "f16" else "fp32",
                                                            "eager launches" if args.no_graph else
-                                                           "hipGraph replay, %d forwards in flight" % lanes),
+                                                           "hipGraph replay, %d forwards in flight%s" % (
+                                                               lanes, ", fresh visiting orders per replay (pool of %d)" % args.fresh_orders
+                                                               if args.fresh_orders else ", one fixed draw of the visiting orders")),
                    "global_batch": B * world, "parallelism": "dp%d" % world},
     }
     legs = not args.no_legs and not dry
@@ -674,6 +694,7 @@ def main():
                               "f32": batch_rate(dev, 8, H, W, lanes, "split", "f32"),
                               "f16_features": batch_rate(dev, 8, H, W, lanes, "split", "f16"),
                               "f16_features_f16_products": batch_rate(dev, 8, H, W, lanes, "half", "f16")}
+            line["hires"] = hires_leg(dev, lanes)
             if os.environ.get("ELO_DENSE_F32") != "1":
                 line["dense_f32"] = dense_f32_leg(args)
     if world > 1:                                         # every rank takes part; rank 0 reports

@@ -106,6 +106,9 @@ WeightGradArgs = _struct("elo_weight_grad_args", [
     ("rows", ctypes.c_long), ("Cin", _i), ("Cout", _i), ("x", _vp), ("g", _vp), ("dW", _vp), ("db", _vp), ("scratch", _vp)])
 BN_MAX_PARTS = 512     # ELO_BN_MAX_PARTS
 
+PermRefreshArgs = _struct("elo_perm_refresh_args", [
+    ("pool", _vp), ("versions", _i), ("total", _i), ("cursor", _vp), ("flat", _vp), ("decoded", _vp), ("entry_of", _vp),
+    ("table", _vp), ("n_entries", _i)])
 Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i), ("w_plain", _vp),
                               ("products", _i)])
 _l = ctypes.c_long
@@ -144,6 +147,7 @@ SYMBOLS = [
     ("elo_fused_conv_random_k_dense", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
     ("elo_fused_conv_select_k_dense", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
     ("elo_debug_select_dense_waves", ctypes.c_int, [ctypes.c_int]),
+    ("elo_perm_refresh", ctypes.c_int, [ctypes.POINTER(PermRefreshArgs), _vp]),
     ("elo_group_concat", ctypes.c_int, [ctypes.POINTER(GroupConcatArgs), _vp]),
     ("elo_masked_maxpool", ctypes.c_int, [ctypes.POINTER(MaskedMaxpoolArgs), _vp]),
     ("elo_cv_encode1", ctypes.c_int, [ctypes.POINTER(CvEncode1Args), _vp]),

@@ -785,3 +785,37 @@ extern "C" int elo_fused_conv_select_k_dense(const elo_group_args *a, elo_stream
 #undef ELO_SD
     return check_launch(who);
 }
+
+// ---------------------------------------------------------------- visiting orders of a captured forward
+// The reference draws tf.random_shuffle(tf.range(KT)) inside every operator on every sess.run
+// (utils/pointnet_util.py:45,104,193,270).  A captured hipGraph bakes the ADDRESSES of the order tensors (and of their
+// decoded (dh, dw) forms) into its kernel arguments, so fresh orders per replay mean fresh CONTENTS at fixed addresses:
+// all orders of a forward live in one flat buffer, `pool` holds R pre-drawn versions of it, and this one-workgroup
+// kernel -- captured at the head of the graph -- copies version (cursor % R) in, decodes it, and advances the cursor,
+// which lives on the device.  table[e] = (offset, KT, kH, kW) of entry e, entry_of[i] = the entry slot i belongs to.
+__global__ void perm_refresh_kernel(const elo_perm_refresh_args a)
+{
+    const int r = *a.cursor % a.versions;
+    const int *src = a.pool + (size_t)r * a.total;
+    for (int i = threadIdx.x; i < a.total; i += blockDim.x) {
+        const int p = src[i];
+        const int *e = a.table + 4 * a.entry_of[i];
+        const int kH = e[2], kW = e[3];
+        a.flat[i] = p;
+        a.decoded[i] = ((p / kW - kH / 2) << 16) | ((p % kW - kW / 2) & 0xffff);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *a.cursor = *a.cursor + 1;
+}
+
+extern "C" int elo_perm_refresh(const elo_perm_refresh_args *a, elo_stream_t stream)
+{
+    using namespace elo;
+    const char *who = "elo_perm_refresh";
+    if (!a || !a->pool || !a->cursor || !a->flat || !a->decoded || !a->entry_of || !a->table)
+        return fail(ELO_ERR_ARG, "%s: null pointer", who);
+    if (a->versions <= 0 || a->total < 0) return fail(ELO_ERR_ARG, "%s: bad sizes", who);
+    if (a->total == 0) return ELO_OK;
+    hipLaunchKernelGGL(perm_refresh_kernel, dim3(1), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a);
+    return check_launch(who);
+}

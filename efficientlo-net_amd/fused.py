@@ -94,6 +94,14 @@ class PackedDense:
         if row_order is not None:                         # the kernel's LDS column order differs from the concat order
             W = W[row_order]
         K, N = W.shape
+        if not fp32_mfma():
+            # the hi/lo halves are fp16: a folded weight at or beyond the fp16 range would become inf (and lo = w - inf)
+            # at pack time.  Real checkpoints fold BN gains of up to ~31x (eps 1e-3) into weights of O(1): far away, but not
+            # by construction -- so it is checked where it would happen (one host sync per packed layer, at pack time only)
+            peak = float(W.abs().max()) if W.numel() else 0.0
+            if not peak < 65504.0:
+                raise ValueError("a folded weight of magnitude %g does not fit the fp16 hi/lo split of the fused kernels "
+                                 "(|w| < 65504): rescale the layer or run the fp32-MFMA build (ELO_DENSE_F32=1)" % peak)
         Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
         Wp = torch.zeros((Kp, Np), dtype=torch.float32, device=W.device)
         Wp[:K, :N] = W
@@ -212,6 +220,10 @@ def _decoded_order(random_hw, kH, kW):
     the order tensor (keyed by storage and in-place version counter: PermSource.reshuffle() invalidates it) instead of
     two integer divisions per slot in every tile.  Never computed while a graph is being captured (the few torch
     kernels would be recorded into it): the capture's warm-up forwards have filled the cache by then."""
+    from . import perm
+    pooled = perm.pooled_decoded(random_hw)              # fresh orders per replay: decoded on the device by the refresh launch
+    if pooled is not None:
+        return pooled.data_ptr()
     key = (random_hw.data_ptr(), kH, kW)
     hit = _DECODED.get(key)
     if hit is not None and hit[0] is random_hw and hit[1] == random_hw._version:
@@ -400,12 +412,41 @@ def _rr_path(group, B, N, K, C, stage=1):
             and C in (16, 32, 64))
 
 
+_RECORD = None          # a list while `recording()` is active: the cost-volume calls of a forward, arguments cloned
+
+
+class recording:
+    """`with fused.recording() as calls:` -- keep (stage, args, kwargs) of every cv_stage1 / cv_stage2 call made inside,
+    with tensor arguments CLONED (a forward recycles its intermediates): bench.py times the cost-volume launches on the
+    tensors a real forward feeds them instead of on synthesised ones."""
+
+    def __enter__(self):
+        global _RECORD
+        self.prev, _RECORD = _RECORD, []
+        return _RECORD
+
+    def __exit__(self, *exc):
+        global _RECORD
+        _RECORD = self.prev
+
+
+def _record(stage, args, kwargs):
+    keep = lambda v: v.detach().clone() if torch.is_tensor(v) else v
+    kw = {k: keep(v) for k, v in kwargs.items() if k != "side"}
+    if kwargs.get("group") is not None:
+        g = kwargs["group"]
+        kw["group"] = Grouping(g.random_hw.clone(), [g.kernel_h, g.kernel_w], g.distance, g.stride_h, g.stride_w)
+    _RECORD.append((stage, tuple(keep(v) for v in args), kw, bool(kwargs.get("side"))))
+
+
 def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1, group=None, K=None,
               side=None):
     """Cost-volume stage 1 in one launch.  `side`: one or two set-conv jobs (dicts of setconv() keyword arguments, same
     shape) that only share inputs with the cost volume -- run INSIDE this launch (elo_cv_stage1_setconv_fused); the call
     then returns (out, [(out_a, new_xyz_a), ...])."""
     L.require_gpu(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask)
+    if _RECORD is not None:
+        _record(1, (xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1), dict(group=group, K=K, side=side))
     xyz1, xyz2_proj = _f32c(xyz1), _f32c(xyz2_proj)
     (feat1, feat2_proj), dt, code = _features(feat1, feat2_proj)
     _, H2, W2, C = feat2_proj.shape
@@ -432,6 +473,8 @@ def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_x
 
 def cv_stage2(xyz1_proj, feat1_proj, cost_proj, idx, mask, xyz_enc, sum_cost0, sum_cost1, group=None, K=None):
     L.require_gpu(xyz1_proj, feat1_proj, cost_proj, idx, mask)
+    if _RECORD is not None:
+        _record(2, (xyz1_proj, feat1_proj, cost_proj, idx, mask, xyz_enc, sum_cost0, sum_cost1), dict(group=group, K=K))
     xyz1_proj = _f32c(xyz1_proj)
     (feat1_proj, cost_proj), dt, code = _features(feat1_proj, cost_proj)
     B, H, W, C = feat1_proj.shape

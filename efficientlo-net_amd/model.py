@@ -95,8 +95,23 @@ class PWCLONet:
                 return pwclo_model.get_model(point_cloud, H_input, W_input, T_gt, T_trans, T_trans_inv, is_training,
                                              bn_decay, aug_frame)
 
+    def check_range(self, xyz_f1_proj, xyz_f2_proj):
+        """One eager forward on the CHECKED instances of the fused kernels (include/elo.h elo_range_check): the number of
+        matrix-core operands -- gathered inputs and layer outputs -- at or beyond the fp16 range (|x| >= 65504, or NaN),
+        where the hi/lo split saturates instead of representing the value.  0 for any sane checkpoint and scan; capture()
+        runs it on its `sample` so that a captured graph (which replays the unchecked kernels) was vetted on real data."""
+        from . import _lib
+        prev = _lib.range_check(True)
+        try:
+            _lib.range_violations(xyz_f1_proj)                       # reset the counter
+            self.forward(xyz_f1_proj, xyz_f2_proj)
+            return _lib.range_violations(xyz_f1_proj)
+        finally:
+            _lib.range_check(bool(prev))
+
     # -- HIP graph -----------------------------------------------------------
-    def capture(self, batch_size, H_input, W_input, warmup=3, lanes=1, num_points=None, point_stride=3, pose_ring=0):
+    def capture(self, batch_size, H_input, W_input, warmup=3, lanes=1, num_points=None, point_stride=3, pose_ring=0, sample=None,
+                fresh_orders=0):
         """Record the inference forward into `lanes` independent hipGraphs (torch.cuda.CUDAGraph on ROCm).
         With `num_points` the graph starts from RAW clouds: a lane owns a (B, 2*num_points, point_stride) cloud buffer
         and records the input stage (model_util.input_stage: 35 m crop + both projections, no augmentation) in front
@@ -109,10 +124,25 @@ class PWCLONet:
         queues carry twice the work of the others, 5210 instead of 6030 pairs/s); the weights are shared.
         `lanes=1` is the plain single-stream replay.
 
+        `sample`: a stacked (2B,H,W,3) pair of real range images: check_range() runs on it first and capture refuses weights
+        / inputs whose operands leave the fp16 range of the hi/lo split (the replayed kernels do not check).
+
+        `fresh_orders=R` (>= 2): every REPLAY walks its own window visiting orders, as every sess.run of the reference does
+        (tf.random_shuffle inside each operator, utils/pointnet_util.py:45,104,193,270): the order tensors become slices of
+        one flat buffer per lane, R versions are pre-drawn, and one tiny launch at the head of the lane's graph copies the
+        next version in and decodes it (perm.PermSource.enable_pool / refresh; elo_perm_refresh).  Replay n of a lane
+        (n = 1, 2, ...) uses version n % R: `perms.pooled_version(n)`.  0: one fixed draw for the life of the graph.
+
         `pose_ring=R` (>= 2): a lane's pose output is a ring of R rows blocks instead of one (B,7) block -- replay r of the
         lane writes slot r % R (the l0 pose-head kernel keeps the cursor on the device), so a stream of pairs is not
         followed by one copy-out launch per pair: `lane_poses(lane)` returns the rows written since `reset_poses(lane)`."""
         dev = self.device
+        if sample is not None:                       # a representative (2B,H,W,3) pair: vet the operand ranges on it
+            bad = self.check_range(sample[:batch_size], sample[batch_size:])
+            if bad:
+                raise RuntimeError("%d matrix-core operands of this forward lie at or beyond the fp16 range (|x| >= 65504): the "
+                                   "fused kernels' hi/lo split would saturate them -- rescale the inputs / weights or run the "
+                                   "fp32-MFMA build (ELO_DENSE_F32=1)" % bad)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         def zeros():          # both frames in one allocation: the Siamese pyramid then runs as one 2B batch
@@ -124,6 +154,8 @@ class PWCLONet:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self._lanes = []
+        if fresh_orders:
+            self.perms.enable_pool(int(fresh_orders), lanes, dev)       # (the warm-up forwards above created every order tensor)
         streams = distinct_queue_streams(dev, lanes)
         if num_points is not None:                   # warm the input stage's allocations up as well
             with torch.cuda.stream(side):
@@ -137,7 +169,14 @@ class PWCLONet:
                     "pose": _ops.PoseRing(pose_ring, batch_size, dev) if pose_ring else torch.zeros((batch_size, 7), device=dev)}
             if num_points is not None:
                 lane["cloud"] = torch.zeros((batch_size, 2 * num_points, point_stride), device=dev)
+            if fresh_orders:                          # this lane's order buffers; caches keyed on them filled before the capture
+                self.perms.active_lane = i
+                with torch.cuda.stream(side):
+                    self.forward(both[:batch_size], both[batch_size:])
+                torch.cuda.synchronize(dev)
             with torch.cuda.graph(lane["graph"]):
+                if fresh_orders:
+                    self.perms.refresh(i)             # head of the graph: the next pooled version, decoded, at fixed addresses
                 if num_points is not None:
                     _pts, staged = model_util.input_stage(lane["cloud"], None, None, H_input, W_input)
                     lane["out"] = self.forward(staged[:batch_size], staged[batch_size:], pose_out=lane["pose"])
@@ -147,6 +186,7 @@ class PWCLONet:
             # (clear()) when they grow: the lane keeps the tensors alive for as long as its graph exists
             lane["keep"] = _cached_tensors()
             self._lanes.append(lane)
+        self.perms.active_lane = 0
         torch.cuda.synchronize(dev)
         self._graph, self._static_in, self._static_out = (self._lanes[0]["graph"], self._lanes[0]["in"],
                                                           self._lanes[0]["out"])

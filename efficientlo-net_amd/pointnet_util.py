@@ -120,8 +120,8 @@ def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_
         dev = warped_xyz1_proj.device
 
         C = points1.shape[-1]
-        random_HW_q = random_shuffle(tf_util.scope_name(), "random_HW_q", kernel_size2[0] * kernel_size2[1], dev)
-        random_HW_p = random_shuffle(tf_util.scope_name(), "random_HW_p", kernel_size1[0] * kernel_size1[1], dev)
+        random_HW_q = random_shuffle(tf_util.scope_name(), "random_HW_q", kernel_size2[0] * kernel_size2[1], dev, kernel_size2)
+        random_HW_p = random_shuffle(tf_util.scope_name(), "random_HW_p", kernel_size1[0] * kernel_size1[1], dev, kernel_size1)
         if _fused_path(is_training) and nsample_q <= 32 and nsample <= 32:
             # two launches for the whole operator: each fused kernel does its own grouping (select-k / random-k),
             # gather + encoding, the conv chain on the matrix cores and the masked softmax pooling
@@ -268,7 +268,7 @@ def up_conv_pair(call_a, call_b):
             xyz1_proj, feat1_proj, feat2_proj = c["xyz1_proj"], c["feat1_proj"], c["feat2_proj"]
             B, H, W, _ = xyz1_proj.shape
             ks, mlp, mlp2 = c["kernel_size"], c["mlp"], c["mlp2"]
-            random_HW = random_shuffle(tf_util.scope_name(), "random_HW", ks[0] * ks[1], xyz1_proj.device)
+            random_HW = random_shuffle(tf_util.scope_name(), "random_HW", ks[0] * ks[1], xyz1_proj.device, ks)
             P = fused.packed_layer
             w1 = [3 + feat2_proj.shape[-1]] + list(mlp)
             jobs.append(dict(src_xyz=c["xyz2_proj"], src_feat=feat2_proj, idx=None, mask=None,
@@ -304,7 +304,7 @@ def up_conv_stage1_jobs(up_a, up_b):
         P = fused.packed_layer
         with tf_util.variable_scope(up["scope"]):
             feat2_proj, ks, mlp = up["feat2_proj"], up["kernel_size"], up["mlp"]
-            random_HW = random_shuffle(tf_util.scope_name(), "random_HW", ks[0] * ks[1], up["xyz1_proj"].device)
+            random_HW = random_shuffle(tf_util.scope_name(), "random_HW", ks[0] * ks[1], up["xyz1_proj"].device, ks)
             w1 = [3 + feat2_proj.shape[-1]] + list(mlp)
             jobs.append(dict(src_xyz=up["xyz2_proj"], src_feat=feat2_proj, idx=None, mask=None,
                              layers=[P('up_1_%d' % j, w1[j], w1[j + 1],
@@ -344,7 +344,7 @@ def down_conv_job(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, di
     -- to run on its own or as a `side_jobs` entry of a cost volume that only shares inputs with it -- and
     finish(out, new_xyz) gives down_conv's return value."""
     with tf_util.variable_scope(scope):
-        random_HW = random_shuffle(tf_util.scope_name(), "random_HW", kernel_size[0] * kernel_size[1], xyz_proj.device)
+        random_HW = random_shuffle(tf_util.scope_name(), "random_HW", kernel_size[0] * kernel_size[1], xyz_proj.device, kernel_size)
         widths = [3 + points_proj.shape[-1]] + list(mlp)
         layers = [fused.packed_layer('conv%d' % i, widths[i], widths[i + 1], bn=bn,
                                      row_order=fused.setconv_row_order(widths[0] - 3) if i == 0 else None)
@@ -364,7 +364,7 @@ def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distan
         idx_n2 = selected_idx.reshape(B, -1, 3)
         n_sampled = idx_n2.shape[1]
         dev = xyz_proj.device
-        random_HW = random_shuffle(tf_util.scope_name(), "random_HW", kernel_size[0] * kernel_size[1], dev)
+        random_HW = random_shuffle(tf_util.scope_name(), "random_HW", kernel_size[0] * kernel_size[1], dev, kernel_size)
         centre_hw = _centre_hw(selected_idx)
         if _fused_path(is_training) and len(mlp) <= 3 and K_sample <= 32:
             # ONE launch: random-k grouping, gather, centre-subtract, MLP on the matrix cores, masked max-pool.
@@ -401,7 +401,7 @@ def up_conv(xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kernel_size, stride_h,
         dev = xyz1_proj.device
         xyz1 = xyz1_proj.reshape(B, N, 3)
         points1 = feat1_proj.reshape(B, N, -1)
-        random_HW = random_shuffle(tf_util.scope_name(), "random_HW", kernel_size[0] * kernel_size[1], dev)
+        random_HW = random_shuffle(tf_util.scope_name(), "random_HW", kernel_size[0] * kernel_size[1], dev, kernel_size)
         if _fused_path(is_training) and len(mlp) <= 3 and len(mlp2) <= 3 and nsample <= 32:
             P = fused.packed_layer
             w1 = [3 + feat2_proj.shape[-1]] + list(mlp)

@@ -109,6 +109,23 @@ int elo_fused_conv_select_k_dense(const elo_group_args *a, elo_stream_t stream);
  * ELO_SELECT_DENSE_WAVES); returns the previous setting */
 int elo_debug_select_dense_waves(int waves);
 
+/* Fresh visiting orders per replay of a captured forward (tf.random_shuffle inside every operator on every sess.run:
+ * utils/pointnet_util.py:45,104,193,270).  All order tensors of a forward are slices of `flat` (their decoded (dh, dw)
+ * forms, elo_group_spec.decoded_hw, slices of `decoded`); `pool` holds `versions` pre-drawn contents of `flat`.  One
+ * launch copies version (*cursor % versions) into flat, decodes it and advances the device-side cursor -- captured at the
+ * head of a hipGraph it gives every replay its own orders at unchanged addresses.
+ *   table (n_entries,4) i32: (offset, KT, kernel_h, kernel_w) per order tensor; entry_of (total) i32: slot -> entry. */
+typedef struct elo_perm_refresh_args {
+    const int *pool;            /* (versions, total) */
+    int versions, total;
+    int *cursor;                /* (1) device counter */
+    int *flat, *decoded;        /* (total) each */
+    const int *entry_of;        /* (total) */
+    const int *table;           /* (n_entries, 4) */
+    int n_entries;
+} elo_perm_refresh_args;
+int elo_perm_refresh(const elo_perm_refresh_args *a, elo_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * Feature path: fused gather / encode / pool kernels.  These replace chains of
  * stock TF ops (tf.gather_nd, tf.tile, tf.concat, tf.where, tf.nn.softmax,

@@ -90,14 +90,17 @@ def summarise(rows):
                 flips_in_misses=sorted(r["flips"] for r in missed))
 
 
-# floors measured on MI355X (tools/parity_flips.py); the assertions that carry the parity claim are the
-# first two -- the share only documents how often a discrete flip happens with random weights
-@pytest.mark.parametrize("B,seeds,features,floor", [(1, range(200, 216), "f32", 0.75), (8, (300, 301), "f32", 0.75),
-                                                    (8, (310,), "f16", 0.6)])
-def test_free_running_misses_are_counted_flips(B, seeds, features, floor):
-    rows = statistic(B, list(seeds), features)
+# floors below the shares measured on MI355X; the assertions that carry the parity claim are the first two -- the share
+# only documents how often a discrete flip happens with random weights
+# measured (tools/parity_flips.py, profiles/r03_parity_flips.txt): fp32 62/64 and 63/64 outputs within 1e-4 free-running,
+# fp16 storage 20/32; every miss carries 1..14 k flipped decisions; worst teacher-forced error 4.8e-5 (fp16: 8.3e-5)
+@pytest.mark.parametrize("B,seeds,features,floor,H,W", [(1, range(200, 216), "f32", 0.85, 64, 1800), (8, (300, 301), "f32", 0.85, 64, 1800),
+                                                        (8, (310,), "f16", 0.45, 64, 1800),
+                                                        (8, (320,), "f32", 0.75, 128, 2048), (8, (321,), "f16", 0.35, 128, 2048)])   # configs[4] at batch 8
+def test_free_running_misses_are_counted_flips(B, seeds, features, floor, H, W):
+    rows = statistic(B, list(seeds), features, H, W)
     s = summarise(rows)
-    print("\nparity statistic B=%d %s: %s" % (B, features, s))
+    print("\nparity statistic B=%d %dx%d %s: %s" % (B, H, W, features, s))
     for r in rows:
         assert r["forced"] <= TOL, r
         if r["flips"] == 0:

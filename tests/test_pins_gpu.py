@@ -121,7 +121,7 @@ def test_range_check_flags_operands_beyond_fp16():
         big[7, 3] = 1e5                                                        # one input operand out of range
         fused.mlp([t(big)], layers)
         assert L.range_violations(t(x)) >= 1
-        scaled = [fused.PackedDense(t(W * 1e5), t(np.zeros(N, np.float32)), relu=False), layers[1]]
+        scaled = [fused.PackedDense(t(W * 4e4), t(np.zeros(N, np.float32)), relu=False), layers[1]]      # (|w| < 65504: packable)
         fused.mlp([t(x)], scaled)                                              # inputs fine, the first layer's OUTPUT is not
         assert L.range_violations(t(x)) > rows
         y = fused.mlp([t(x)], layers).cpu().numpy()                            # the checked instance computes the same numbers
@@ -140,3 +140,25 @@ def test_full_pyramid_parity_on_the_fp32_mfma_build():
                          text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "2 passed" in out.stdout, out.stdout[-500:]
+
+
+def test_capture_vets_the_operand_range_and_packing_refuses_huge_weights():
+    """capture(sample=pair) runs one checked forward first (PWCLONet.check_range) and refuses inputs whose matrix-core
+    operands leave the fp16 range of the hi/lo split; packing a layer whose folded weight is >= 65504 raises instead of
+    writing inf halves."""
+    model, synth, fused, tf_util = load_pkg("model"), load_pkg("synth"), load_pkg("fused"), load_pkg("tf_util")
+    f1, f2 = synth.frame_pair(1, 64, 900, seed=8)
+    pair = torch.from_numpy(np.concatenate([f1, f2], 0)).to(DEV)
+    net = model.PWCLONet(DEV, seed=2)
+    assert net.check_range(pair[:1], pair[1:]) == 0
+    net.capture(1, 64, 900, sample=pair)                                       # a sane scan: captured
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        net.capture(1, 64, 900, sample=pair * 3e4)                             # coordinates of ~1e6 m
+    store = tf_util.VariableStore(DEV, seed=0)
+    with tf_util.default_store(store), torch.no_grad():
+        name, W, b, bn = tf_util.dense_variables("huge", 16, 16, (1, 1), False)
+        W.mul_(1e6)
+        store.invalidate()
+        if not fused.fp32_mfma():
+            with pytest.raises(ValueError, match="fp16 hi/lo split"):
+                fused.packed_layer("huge", 16, 16, bn=False)

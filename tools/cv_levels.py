@@ -6,9 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device("cuda:0")
-net = importlib.import_module("efficientlo-net_amd.model").PWCLONet(dev, seed=0)
 for half in (False, True):
-    r = bench.cost_volume_leg(dev, net, B, 64, 1800, half)
+    r = bench.cost_volume_leg(dev, B, 64, 1800, half)
     print("batch %d %s: %.1f us, %.1f GB/s (%.3f of HBM), mfma %.3f of fp16 peak | %s" % (
         B, r["features"], r["us"], r["achieved"], r["frac"], r["mfma"]["frac"],
         " ".join("%s %.1f+%.1f" % (k, v["cv1_us"], v["cv2_us"]) for k, v in r["levels"].items())))
