@@ -51,12 +51,15 @@ SoftmaxValidArgs = _struct("elo_softmax_valid_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp), ("out", _vp),
     ("scratch", _vp), ("stats", _vp)])
 SV_MAX_PARTS = 64      # ELO_SV_MAX_PARTS
+PermRefreshArgs = _struct("elo_perm_refresh_args", [
+    ("pool", _vp), ("versions", _i), ("total", _i), ("cursor", _vp), ("flat", _vp), ("decoded", _vp), ("entry_of", _vp),
+    ("table", _vp), ("n_entries", _i)])
 PoseHeadArgs = _struct("elo_pose_head_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("hidden", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp),
     ("W_big", _vp), ("b_big", _vp), ("W_q", _vp), ("b_q", _vp), ("W_t", _vp), ("b_t", _vp),
     ("q_coarse", _vp), ("t_coarse", _vp), ("q", _vp), ("t", _vp), ("q_norm", _vp), ("scratch", _vp), ("pose7", _vp),
     ("clear_scratch", _vp), ("clear_xyz", _vp), ("clear_feat", _vp), ("clear_cells", ctypes.c_long), ("clear_C", _i),
-    ("feat_dtype", _i), ("pose7_slots", _i), ("pose7_cursor", _vp)])
+    ("feat_dtype", _i), ("pose7_slots", _i), ("pose7_cursor", _vp), ("next_orders", PermRefreshArgs)])
 WarpProjectArgs = _struct("elo_warp_project_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("H", _i), ("W", _i),
     ("az_res", _f), ("vert_res", _f), ("vert_off", _f),
@@ -106,9 +109,6 @@ WeightGradArgs = _struct("elo_weight_grad_args", [
     ("rows", ctypes.c_long), ("Cin", _i), ("Cout", _i), ("x", _vp), ("g", _vp), ("dW", _vp), ("db", _vp), ("scratch", _vp)])
 BN_MAX_PARTS = 512     # ELO_BN_MAX_PARTS
 
-PermRefreshArgs = _struct("elo_perm_refresh_args", [
-    ("pool", _vp), ("versions", _i), ("total", _i), ("cursor", _vp), ("flat", _vp), ("decoded", _vp), ("entry_of", _vp),
-    ("table", _vp), ("n_entries", _i)])
 Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i), ("w_plain", _vp),
                               ("products", _i)])
 _l = ctypes.c_long
@@ -187,7 +187,7 @@ class EloError(RuntimeError):
     pass
 
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 def lib():

@@ -326,9 +326,11 @@ class PoseRing:
 
 
 def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse=None, t_coarse=None, pose7=None,
-              clear=None, warp=None):
+              clear=None, warp=None, next_orders=None):
     """softmax_valid -> conv1d(256) -> q,t heads -> normalise -> compose with the coarse pose, two launches.
     pwclo_model.py:194-208 / :262-280.  Returns (q (B,4), t (B,3), q_norm (B,4)); `pose7` (B,7), if given, also receives [q_norm | t].
+    `next_orders`: an elo_perm_refresh_args (perm.PermSource.refresh_args): the next pooled set of visiting orders is
+    loaded by this launch once the pose is written (the last launch of a captured forward).
     `clear`: ProjectionBuffers of the projection that will consume this pose (cleared on the side).
     `warp` = (xyz (B,N,3), feat (B,N,C) or None) with `clear`: that projection itself -- warp by this pose, spherical
     re-projection -- is run by this call (elo_pose_head_warp: 3 launches instead of 2 + 2); its result is left in
@@ -357,7 +359,8 @@ def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t
                        ptr(pose7), *((clear.scratch.data_ptr(), clear.out_xyz.data_ptr(), ptr(clear.out_feat),
                                       clear.shape[0] * clear.shape[2] * clear.shape[3], clear.shape[4])
                                      if clear is not None else (None, None, None, 0, 0)), fcode,
-                       ring.slots if ring is not None else 0, ring.cursor.data_ptr() if ring is not None else None)
+                       ring.slots if ring is not None else 0, ring.cursor.data_ptr() if ring is not None else None,
+                       next_orders if next_orders is not None else L.PermRefreshArgs())
     if clear is not None and clear.out_feat is not None and clear.out_feat.dtype != fdt:
         raise TypeError("the projection buffers and the pose head's features must share one storage dtype")
     if warp is not None:

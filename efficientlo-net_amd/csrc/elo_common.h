@@ -42,6 +42,23 @@ __device__ __forceinline__ float exp_acc(float x)
     return __builtin_amdgcn_exp2f(t) * __fmaf_rn(r, 0.693147180559945f, 1.0f);
 }
 
+// ---- device: the next pooled set of window visiting orders into a forward's order buffers (include/elo.h
+// elo_perm_refresh_args): one workgroup; copies version (*cursor % versions), decodes it, advances the cursor
+__device__ __forceinline__ void perm_refresh_block(const elo_perm_refresh_args &a)
+{
+    const int r = *a.cursor % a.versions;
+    const int *src = a.pool + (size_t)r * a.total;
+    for (int i = threadIdx.x; i < a.total; i += blockDim.x) {
+        const int p = src[i];
+        const int *e = a.table + 4 * a.entry_of[i];
+        const int kH = e[2], kW = e[3];
+        a.flat[i] = p;
+        a.decoded[i] = ((p / kW - kH / 2) << 16) | ((p % kW - kW / 2) & 0xffff);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *a.cursor = *a.cursor + 1;
+}
+
 // ---- device: XCD-aware tile order ------------------------------------------
 // The dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md, workgroup
 // dispatch).  Give each XCD one contiguous run of tiles so that neighbouring

@@ -841,6 +841,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
             for (int i = 0; i < 3; ++i) head[12 + i] = t[i];
         }
     }
+    if (a.next_orders.pool && blockIdx.x == 0 && blockIdx.y == 0) perm_refresh_block(a.next_orders);   // (uniform per workgroup)
     if (!with_warp) return;
     __syncthreads();
     const long n = (long)blockIdx.x * blockDim.x + tid;

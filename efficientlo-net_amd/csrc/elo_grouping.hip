@@ -790,23 +790,11 @@ extern "C" int elo_fused_conv_select_k_dense(const elo_group_args *a, elo_stream
 // The reference draws tf.random_shuffle(tf.range(KT)) inside every operator on every sess.run
 // (utils/pointnet_util.py:45,104,193,270).  A captured hipGraph bakes the ADDRESSES of the order tensors (and of their
 // decoded (dh, dw) forms) into its kernel arguments, so fresh orders per replay mean fresh CONTENTS at fixed addresses:
-// all orders of a forward live in one flat buffer, `pool` holds R pre-drawn versions of it, and this one-workgroup
-// kernel -- captured at the head of the graph -- copies version (cursor % R) in, decodes it, and advances the cursor,
-// which lives on the device.  table[e] = (offset, KT, kH, kW) of entry e, entry_of[i] = the entry slot i belongs to.
-__global__ void perm_refresh_kernel(const elo_perm_refresh_args a)
-{
-    const int r = *a.cursor % a.versions;
-    const int *src = a.pool + (size_t)r * a.total;
-    for (int i = threadIdx.x; i < a.total; i += blockDim.x) {
-        const int p = src[i];
-        const int *e = a.table + 4 * a.entry_of[i];
-        const int kH = e[2], kW = e[3];
-        a.flat[i] = p;
-        a.decoded[i] = ((p / kW - kH / 2) << 16) | ((p % kW - kW / 2) & 0xffff);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) *a.cursor = *a.cursor + 1;
-}
+// all orders of a forward live in one flat buffer, `pool` holds R pre-drawn versions of it, and one workgroup copies
+// version (cursor % R) in, decodes it, and advances the cursor, which lives on the device -- as this kernel,
+// or riding on the last launch of a forward (elo_pose_head_args.next_orders: the orders of the NEXT replay, no launch
+// of its own).  table[e] = (offset, KT, kH, kW) of entry e, entry_of[i] = the entry slot i belongs to.
+__global__ void perm_refresh_kernel(const elo_perm_refresh_args a) { elo::perm_refresh_block(a); }
 
 extern "C" int elo_perm_refresh(const elo_perm_refresh_args *a, elo_stream_t stream)
 {

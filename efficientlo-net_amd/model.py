@@ -129,9 +129,10 @@ class PWCLONet:
 
         `fresh_orders=R` (>= 2): every REPLAY walks its own window visiting orders, as every sess.run of the reference does
         (tf.random_shuffle inside each operator, utils/pointnet_util.py:45,104,193,270): the order tensors become slices of
-        one flat buffer per lane, R versions are pre-drawn, and one tiny launch at the head of the lane's graph copies the
-        next version in and decodes it (perm.PermSource.enable_pool / refresh; elo_perm_refresh).  Replay n of a lane
-        (n = 1, 2, ...) uses version n % R: `perms.pooled_version(n)`.  0: one fixed draw for the life of the graph.
+        one flat buffer per lane, R versions are pre-drawn, and the LAST launch of the lane's graph (the l0 pose head)
+        copies the next version in and decodes it for the replay that follows (perm.PermSource.enable_pool;
+        elo_pose_head_args.next_orders): no launch of its own.  Replay n of a lane (n = 1, 2, ...) walks version
+        (n - 1) % R: `perms.pooled_version(n - 1)`.  0: one fixed draw for the life of the graph.
 
         `pose_ring=R` (>= 2): a lane's pose output is a ring of R rows blocks instead of one (B,7) block -- replay r of the
         lane writes slot r % R (the l0 pose-head kernel keeps the cursor on the device), so a stream of pairs is not
@@ -170,13 +171,12 @@ class PWCLONet:
             if num_points is not None:
                 lane["cloud"] = torch.zeros((batch_size, 2 * num_points, point_stride), device=dev)
             if fresh_orders:                          # this lane's order buffers; caches keyed on them filled before the capture
-                self.perms.active_lane = i
+                self.perms.active_lane, self.perms.tail_armed = i, False
                 with torch.cuda.stream(side):
                     self.forward(both[:batch_size], both[batch_size:])
                 torch.cuda.synchronize(dev)
+            self.perms.tail_armed = bool(fresh_orders)    # the recorded forward's last launch loads the NEXT replay's orders
             with torch.cuda.graph(lane["graph"]):
-                if fresh_orders:
-                    self.perms.refresh(i)             # head of the graph: the next pooled version, decoded, at fixed addresses
                 if num_points is not None:
                     _pts, staged = model_util.input_stage(lane["cloud"], None, None, H_input, W_input)
                     lane["out"] = self.forward(staged[:batch_size], staged[batch_size:], pose_out=lane["pose"])
@@ -186,7 +186,7 @@ class PWCLONet:
             # (clear()) when they grow: the lane keeps the tensors alive for as long as its graph exists
             lane["keep"] = _cached_tensors()
             self._lanes.append(lane)
-        self.perms.active_lane = 0
+        self.perms.active_lane, self.perms.tail_armed = 0, False
         torch.cuda.synchronize(dev)
         self._graph, self._static_in, self._static_out = (self._lanes[0]["graph"], self._lanes[0]["in"],
                                                           self._lanes[0]["out"])

@@ -29,6 +29,7 @@ class PermSource:
         self._kernel = {}         # key -> (kernel_h, kernel_w): what the pooled refresh needs to decode an order
         self._pool = None
         self.active_lane = 0      # which lane's buffers get() hands out in pooled mode (model.capture sets it per lane)
+        self.tail_armed = False   # model.capture: the forward being recorded ends with "load the next replay's orders"
         self._draws = 0
         self.generation = 0       # bumped by reshuffle(): the decoded orders a captured inference graph points at are dropped
 
@@ -85,15 +86,19 @@ class PermSource:
         for lane in range(lanes):                      # every lane starts on version 0 (its cursor then points at 1)
             self.refresh(lane)
 
-    def refresh(self, lane=None):
-        """The next pooled version into lane's buffers (one launch on the current stream; capturable)."""
+    def refresh_args(self, lane=None):
+        """elo_perm_refresh_args of a lane's buffers."""
         from . import _lib as L
         P = self._pool
         lane = self.active_lane if lane is None else lane
-        a = L.PermRefreshArgs(P["rows"].data_ptr(), P["versions"], P["total"], P["cursor"][lane].data_ptr(),
-                              P["flat"][lane].data_ptr(), P["decoded"][lane].data_ptr(), P["entry_of"].data_ptr(),
-                              P["table"].data_ptr(), P["n"])
-        L.call("elo_perm_refresh", a, P["rows"])
+        return L.PermRefreshArgs(P["rows"].data_ptr(), P["versions"], P["total"], P["cursor"][lane].data_ptr(),
+                                 P["flat"][lane].data_ptr(), P["decoded"][lane].data_ptr(), P["entry_of"].data_ptr(),
+                                 P["table"].data_ptr(), P["n"])
+
+    def refresh(self, lane=None):
+        """The next pooled version into lane's buffers (one launch on the current stream; capturable)."""
+        from . import _lib as L
+        L.call("elo_perm_refresh", self.refresh_args(lane), self._pool["rows"])
 
     def pooled_decoded(self, order):
         """The decoded (dh, dw) form of a pooled order tensor (a slice of the lane's decoded buffer), or None."""
@@ -137,3 +142,10 @@ def random_shuffle(scope, tag, KT, device, kernel_size=None):
 
 def pooled_decoded(order):
     return _current[-1].pooled_decoded(order)
+
+
+def tail_refresh_args():
+    """The side job of a captured forward's last launch (the l0 pose head): elo_perm_refresh_args of the active lane while
+    model.capture records a graph with fresh_orders, else None."""
+    src = _current[-1]
+    return src.refresh_args() if (src._pool is not None and src.tail_armed) else None

@@ -181,7 +181,10 @@ def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training,
         W_big, b_big = tf_util.folded_variables('l%d_big' % level, predict.shape[-1], 256, (1,), bn=False)
         W_q, b_q = tf_util.folded_variables(qn % level, 256, 4, (1,), bn=False)
         W_t, b_t = tf_util.folded_variables(tn % level, 256, 3, (1,), bn=False)
-        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7, clear, warp)
+        # the l0 head is the last launch of a forward: in a graph captured with fresh_orders it also loads the NEXT replay's orders
+        from . import perm
+        nxt = perm.tail_refresh_args() if level == 0 else None
+        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7, clear, warp, nxt)
     summed = softmax_valid(feature_bnc=predict, weight_bnc=weight, mask_valid=xyz)                  # :194 / :262
     q_det, t_det = _pose_head(summed, level, coarse, is_training)                                   # :197-208 / :264-273
     if coarse:

@@ -109,23 +109,6 @@ int elo_fused_conv_select_k_dense(const elo_group_args *a, elo_stream_t stream);
  * ELO_SELECT_DENSE_WAVES); returns the previous setting */
 int elo_debug_select_dense_waves(int waves);
 
-/* Fresh visiting orders per replay of a captured forward (tf.random_shuffle inside every operator on every sess.run:
- * utils/pointnet_util.py:45,104,193,270).  All order tensors of a forward are slices of `flat` (their decoded (dh, dw)
- * forms, elo_group_spec.decoded_hw, slices of `decoded`); `pool` holds `versions` pre-drawn contents of `flat`.  One
- * launch copies version (*cursor % versions) into flat, decodes it and advances the device-side cursor -- captured at the
- * head of a hipGraph it gives every replay its own orders at unchanged addresses.
- *   table (n_entries,4) i32: (offset, KT, kernel_h, kernel_w) per order tensor; entry_of (total) i32: slot -> entry. */
-typedef struct elo_perm_refresh_args {
-    const int *pool;            /* (versions, total) */
-    int versions, total;
-    int *cursor;                /* (1) device counter */
-    int *flat, *decoded;        /* (total) each */
-    const int *entry_of;        /* (total) */
-    const int *table;           /* (n_entries, 4) */
-    int n_entries;
-} elo_perm_refresh_args;
-int elo_perm_refresh(const elo_perm_refresh_args *a, elo_stream_t stream);
-
 /* ------------------------------------------------------------------------- *
  * Feature path: fused gather / encode / pool kernels.  These replace chains of
  * stock TF ops (tf.gather_nd, tf.tile, tf.concat, tf.where, tf.nn.softmax,
@@ -216,6 +199,23 @@ typedef struct elo_softmax_pool_args {
 } elo_softmax_pool_args;
 int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_stream_t stream);
 
+/* Fresh visiting orders per replay of a captured forward (tf.random_shuffle inside every operator on every sess.run:
+ * utils/pointnet_util.py:45,104,193,270).  All order tensors of a forward are slices of `flat` (their decoded (dh, dw)
+ * forms, elo_group_spec.decoded_hw, slices of `decoded`); `pool` holds `versions` pre-drawn contents of `flat`.  One
+ * launch copies version (*cursor % versions) into flat, decodes it and advances the device-side cursor -- captured at the
+ * head of a hipGraph it gives every replay its own orders at unchanged addresses.
+ *   table (n_entries,4) i32: (offset, KT, kernel_h, kernel_w) per order tensor; entry_of (total) i32: slot -> entry. */
+typedef struct elo_perm_refresh_args {
+    const int *pool;            /* (versions, total) */
+    int versions, total;
+    int *cursor;                /* (1) device counter */
+    int *flat, *decoded;        /* (total) each */
+    const int *entry_of;        /* (total) */
+    const int *table;           /* (n_entries, 4) */
+    int n_entries;
+} elo_perm_refresh_args;
+int elo_perm_refresh(const elo_perm_refresh_args *a, elo_stream_t stream);
+
 /* model_util.py:319-343 softmax_valid: per batch element, softmax over the
  * VALID points (xyz != (0,0,0)) per channel, out[b,0,c] = sum_n softmax*feature.
  * Two launches: `parts` blocks per batch element reduce slices of the point axis
@@ -272,6 +272,10 @@ typedef struct elo_pose_head_args {
      * copy-out per pair: the caller drains the ring every pose7_slots replays (and may reset the cursors to 0). */
     int pose7_slots;
     unsigned *pose7_cursor;       /* (batch) or NULL */
+    /* Optional side job for the LAST launch of a captured forward (the l0 pose head): load the next pooled set of window
+     * visiting orders (elo_perm_refresh semantics) once this pose is written -- the NEXT replay of the graph then walks
+     * fresh orders without a launch of its own.  next_orders.pool == NULL: no side job. */
+    elo_perm_refresh_args next_orders;
 } elo_pose_head_args;
 int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream);
 

@@ -304,7 +304,7 @@ def test_pose_ring_keeps_every_replay_of_a_lane():
 
 
 def test_fresh_visiting_orders_per_replay():
-    """capture(fresh_orders=R): replay n of a lane walks pooled version n % R of every window visiting order (the reference
+    """capture(fresh_orders=R): replay n of a lane walks pooled version (n - 1) % R of every window visiting order (the reference
     draws tf.random_shuffle inside every operator on every sess.run) -- without recapture.  Two replays on the SAME pair
     differ; each equals, bit for bit, the eager forward of a twin net (same weights) handed exactly that version's orders;
     version R wraps around to version 0; lanes keep their own buffers."""
@@ -320,14 +320,14 @@ def test_fresh_visiting_orders_per_replay():
         net.lane_stream(0).synchronize()
         outs.append([x.clone() for x in o])
     assert not torch.equal(outs[0][0], outs[1][0]) or not torch.equal(outs[0][1], outs[1][1])     # different orders, different poses
-    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[R]))                                # version R + 1 == version 1
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[R]))                                # replay R + 1 walks version 0 again
     for n in (1, 2):
-        table = net.perms.pooled_version(n)
+        table = net.perms.pooled_version(n - 1)
         twin = model.PWCLONet(DEV, seed=3, perm_source=perm.PermSource(fn=lambda s, t, kt: table[(s, t, kt)]))
         want = twin.forward(pair[:B], pair[B:])
         torch.cuda.synchronize()
         for g, w_ in zip(outs[n - 1], want):
             assert torch.equal(g, w_), n
-    o1 = net.submit(1, pair)                                   # lane 1's first replay: version 1 on its own buffers
+    o1 = net.submit(1, pair)                                   # lane 1's first replay: version 0 on its own buffers
     net.lane_stream(1).synchronize()
     assert all(torch.equal(a, b) for a, b in zip(o1, outs[0]))
