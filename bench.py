@@ -319,10 +319,13 @@ def cpu_baseline_leg(args, net):
     per_worker = 3
     r = cpu_bench.run(params, f1, f2, args.cpu_pairs, per_worker, cores)
     return {"value": round(r["all_cores"], 3), "unit": "frame-pairs/s", "cores": cores, "cores_available": cores, "kind": "port",
-            "one_core": round(r["one_core"], 4),
+            "one_core": round(r["one_core"], 4), "one_process_all_threads": round(r["one_process_all_threads"], 4),
             "sample": "oracle/ops_np.get_model_from_projection (numpy fp32 + C grouping oracle) on one %dx%d pair: "
-                      "one core %d pairs in %.1f s; all cores = %d single-threaded worker processes x %d pairs in %.1f s"
-                      % (args.height, args.width, args.cpu_pairs, r["seconds"][0], cores, per_worker, r["seconds"][1])}
+                      "one core %d pairs in %.1f s; all cores (`value`) = %d single-threaded worker processes x %d pairs in %.1f s "
+                      "(frame pairs are independent: the split the GPUs use); one_process_all_threads = SURVEY 8(d)'s literal "
+                      "recipe, C grouping with a thread per core + threaded BLAS in ONE process, %d pairs in %.1f s"
+                      % (args.height, args.width, args.cpu_pairs, r["seconds"][0], cores, per_worker, r["seconds"][1],
+                         args.cpu_pairs, r["seconds"][2])}
 
 
 def batch_rate(dev, B, H, W, lanes, products, features, steps=240):

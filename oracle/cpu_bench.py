@@ -4,10 +4,14 @@ The reference has no CPU implementation (fused_conv.cpp:176 registers a GPU kern
 TensorFlow): "the reference CPU path" is the reference ALGORITHM on host cores, i.e. this package's restatement
 (oracle/ops_np.get_model_from_projection: numpy fp32 + the C grouping oracle), kind "port".
 
-Two legs on the same bounded sample:
+Three legs on the same bounded sample:
   * one core: a single process, BLAS limited to one thread;
   * all cores: one single-threaded worker PROCESS per host core, each running whole frame pairs (frame pairs are
-    independent, so this is the same data-parallel split the GPUs use) -- spawned workers that import numpy only.
+    independent, so this is the same data-parallel split the GPUs use) -- spawned workers that import numpy only;
+  * one process, all threads: SURVEY 8(d)'s literal recipe -- ONE process, the C grouping oracle with a thread per
+    core over the centres (ELO_ORACLE_THREADS) and the dense layers on the BLAS's thread pool -- which is the weaker of
+    the two all-core readings (a pair is ~0.2 s of small operators: threads per operator scale worse than pairs per
+    core), reported beside it for completeness.
 Inputs (weights, one frame pair) travel through an .npz file so that the workers never import torch.
 """
 import os
@@ -32,10 +36,15 @@ def _shuffle_table():
     return shuffle
 
 
-def worker(npz_path, pairs, start_at):
+def worker(npz_path, pairs, start_at, threads=1):
     """Run `pairs` forwards; returns (first start, last end) wall-clock stamps.  Spins until `start_at` so that all
-    workers of the all-cores leg run their pairs at the same time."""
-    _limit_threads()
+    workers of the all-cores leg run their pairs at the same time.  threads > 1: the threaded leg (set before numpy loads)."""
+    if threads > 1:
+        for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+            os.environ[v] = str(min(threads, 64))              # (BLAS thread pools above 64 only add contention on 42-row GEMMs)
+        os.environ["ELO_ORACLE_THREADS"] = str(threads)
+    else:
+        _limit_threads()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
         sys.path.insert(0, root)
@@ -72,5 +81,8 @@ def run(params, f1, f2, pairs_one_core, pairs_per_worker, workers=None):
             start_at = time.time() + 6.0 + 0.25 * workers              # interpreter start + the untimed warm-up forward
             spans = pool.starmap(worker, [(path, pairs_per_worker, start_at)] * workers)
         t_all = max(e for _, e in spans) - min(s for s, _ in spans)
+        with ctx.Pool(1) as pool:                                    # SURVEY 8(d)'s recipe: one process, threads inside the operators
+            a, b = pool.apply(worker, (path, pairs_one_core, 0.0, workers))
+        t_thr = b - a
     return {"one_core": pairs_one_core / t_one, "all_cores": workers * pairs_per_worker / t_all, "cores": workers,
-            "seconds": (t_one, t_all)}
+            "one_process_all_threads": pairs_one_core / t_thr, "seconds": (t_one, t_all, t_thr)}

@@ -98,13 +98,20 @@ def _run(op, impl, xyz1, xyz2, idx_n2, random_hw, npoints, kH, kW, K, flag_copy,
     return sel, valid, indis, mask
 
 
+def _threads(threads):
+    """threads=None: ELO_ORACLE_THREADS (the threaded CPU-baseline leg of bench.py sets it), else 1."""
+    return int(os.environ.get("ELO_ORACLE_THREADS", "1")) if threads is None else threads
+
+
 def fused_conv_random_k(xyz1, xyz2, idx_n2, random_hw, H, W, npoints, kernel_size_H, kernel_size_W,
-                        K, flag_copy, distance, stride_h, stride_w, impl="oracle", threads=1):
+                        K, flag_copy, distance, stride_h, stride_w, impl="oracle", threads=None):
+    threads = _threads(threads)
     return _run("random", impl, xyz1, xyz2, idx_n2, random_hw, npoints, kernel_size_H,
                 kernel_size_W, K, flag_copy, distance, stride_h, stride_w, threads)
 
 
 def fused_conv_select_k(xyz1, xyz2, idx_n2, random_hw, H, W, npoints, kernel_size_H, kernel_size_W,
-                        K, flag_copy, distance, stride_h, stride_w, impl="oracle", threads=1):
+                        K, flag_copy, distance, stride_h, stride_w, impl="oracle", threads=None):
+    threads = _threads(threads)
     return _run("select", impl, xyz1, xyz2, idx_n2, random_hw, npoints, kernel_size_H,
                 kernel_size_W, K, flag_copy, distance, stride_h, stride_w, threads)

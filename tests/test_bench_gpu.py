@@ -41,13 +41,17 @@ def test_bench_line_contract():
         assert r[leg]["bound"] == "hbm" and 0 < r[leg]["frac"] < 1, leg
     assert set(r["cost_volume_b8_f16"]["levels"]) == {"l0", "l1", "l2", "l2_origin"}
     c = d["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample", "one_core", "cores_available"):
+    for key in ("value", "unit", "cores", "kind", "sample", "one_core", "cores_available", "one_process_all_threads"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["cores"] == os.cpu_count() and c["value"] > 0 and c["one_core"] > 0
     assert d["from_raw_clouds"]["value"] > 0
     b8 = d["batch8"]
     assert b8["f32"] > 0 and b8["f16_features"] > 0 and b8["f16_features_f16_products"] > 0
     assert d["dense_f32"]["value"] and d["dense_f32"]["value"] > 0
+    h = d["hires"]                                        # BASELINE configs[4]: 128x2048
+    assert h["grid"] == "128x2048" and h["batch1"] > 0 and h["batch8_f32"] > 0 and h["batch8_f16_features"] > 0
+    assert h["cost_volume_b8_f16"]["us"] > 0 and all(v >= 1 for v in h["workgroups_per_cu_by_lds"].values())
+    assert d["roofline"]["carries_riders_in_the_forward"] in (True, False)
     t = d["train_dp"]
     assert t["n_gpus"] == 1 and t["value"] > 0 and t["batch_per_gpu"] == 8
 
