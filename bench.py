@@ -53,7 +53,7 @@ F16_MFMA_PEAK_TFLOPS = 2500.0  # ibid.: BF16/FP16 MFMA ~2.5 PFLOP/s dense -- the
 F32_MFMA_PEAK_TFLOPS = 157.3   # ibid.: v_mfma_f32_16x16x4_f32 dense peak -- only for the -DELO_DENSE_F32 comparison build
 MFMA_PRODUCTS = 3              # fp16 matrix-core products per fp32-class product: hi*hi + hi*lo + lo*hi (elo_fused.hip)
 MIN_TIMED_S = 0.25
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc", "summary.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc", "summary.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 
 
 def pkg(sub=None):

@@ -689,6 +689,9 @@ __device__ __forceinline__ void group_tile(const TileMeta &m, int *lds_off, unsi
 #ifndef ELO_CV1_WAVES
 #define ELO_CV1_WAVES 5                    // waves per SIMD the cost-volume stage-1 kernels are compiled for
 #endif
+#ifndef ELO_TILE32_WAVES
+#define ELO_TILE32_WAVES 5                 // ... and the 32-row instances of setconv_kernel / mlp_kernel: at 6 (80 VGPRs) they spill
+#endif                                     // 6-8 registers to scratch (round 2's ISA metadata: private_segment_fixed_size 20-28)
 constexpr int SEG_ITEMS = 4;                        // per thread: TILE(32) * W(128) * 4 bytes / 16 / FUSED_BLOCK
 
 __device__ __forceinline__ bool seg_ok(const void *p, int W, int rows, int f16)
@@ -943,7 +946,7 @@ __device__ __forceinline__ void setconv_tile(const elo_setconv_args &a, const in
 }
 
 template <int TILE, int MODE>
-__global__ __launch_bounds__(FUSED_BLOCK, ELO_TILE_WAVES) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK, TILE == 32 ? ELO_TILE32_WAVES : ELO_TILE_WAVES) void setconv_kernel(const JobPair<elo_setconv_args> jobs, const int S)
 {
     extern __shared__ __align__(16) float lds[];
     setconv_tile<TILE, MODE>(jobs.job[blockIdx.y], S, lds, blockIdx.x, gridDim.x);
@@ -1108,7 +1111,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
 // stage 1: columns [0, w0 + w1 + w2) = the sources; its last layer writes `out` to HBM straight from the accumulators
 // and, with a second stage, to columns [0, N) of the tile; stage 2: [out (N) | before | after] -> layers2 -> out2.
 template <int TILE, int MODE>
-__global__ __launch_bounds__(FUSED_BLOCK, ELO_TILE_WAVES) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK, TILE == 32 ? ELO_TILE32_WAVES : ELO_TILE_WAVES) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
 {
     const elo_mlp_args &a = jobs.job[blockIdx.y];
     extern __shared__ __align__(16) float lds[];
@@ -1272,7 +1275,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, ELO_CV1_WAVES) void cv1_kernel(const e
 }
 
 #ifndef ELO_CV1_META_WAVES
-#define ELO_CV1_META_WAVES 6
+#define ELO_CV1_META_WAVES 5               // (6 spills 24 registers in the 32-row instance)
 #endif
 template <int TILE, int MODE>
 __global__ __launch_bounds__(FUSED_BLOCK, ELO_CV1_META_WAVES) void cv1_meta_kernel(const elo_cv1_args a, const int S)

@@ -16,8 +16,10 @@ def main(src, dst):
         meta = json.load(open(info))
         kname = KNAME[meta["kernel"]]
         meta.setdefault("half", False)
-        durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-                for r in csv.DictReader(open(os.path.join(src, tag + ".trace", "t_kernel_trace.csv"))) if kname in r["Kernel_Name"]][5:]
+        rows = list(csv.DictReader(open(os.path.join(src, tag + ".trace", "t_kernel_trace.csv"))))
+        if kname == "cv1_kernel" and not any(kname in r["Kernel_Name"] for r in rows):
+            kname = "cv1_rr_kernel"            # from 24.6 k rows on stage 1 is a select-k launch + the register-resident kernel
+        durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if kname in r["Kernel_Name"]][5:]
         avg = sum(durs) / len(durs)
 
         def counter(sub, f, name):
