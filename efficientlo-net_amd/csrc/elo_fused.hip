@@ -1731,6 +1731,176 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
     rr_pool<F16>(lds, logit, in1[0], in1[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
     report_violations<MODE_SPLIT>(bad);
 }
+// ---- set-conv / set-upconv stage 1, register-resident (see cv1_rr_kernel): in-kernel random-k grouping (a wave groups
+// the points its 16 rows belong to), gather [features (16 FPB) | xyz difference], two or three layers of compile-time
+// widths, masked max over the K rows of a point (utils/pointnet_util.py:197-230, :272-298).  Instantiated for the
+// model's shapes whose layers all have an even number of k-steps: the set-upconvs (64 + 3 -> 128 -> 64), sa1/layer3
+// (64 + 3 -> 64 -> 64 -> 128) and new_layer3 (64 + 3 -> 128 -> 64 -> 64); blockIdx.y selects one of two jobs.
+template <int FPB, int N1, int N2, int N3> struct ScPlan {
+    static constexpr int NL = N3 ? 3 : 2;
+    static constexpr int KP[3] = {FPB / 2, N1 / 32, N2 / 32}, TL[3] = {1, 0, 0}, NCB[3] = {N1 / 16, N2 / 16, (N3 ? N3 : 32) / 16};
+};
+
+// masked max over the K rows of a point of the NOUT channels the lane quads hold (`last[cb]`: channels cb*16 + 4kq ..),
+// 32 channels at a time through LDS (the scratch overwrites the dead W ring): pool_masked_max's expressions
+template <int NOUT, bool F16>
+__device__ __forceinline__ void rr_pool_max(float *lds, const float4 (&last)[NOUT / 16], float mk, int r, int wave, int lane, int K,
+                                            int P, long first_point, long total_points, void *out)
+{
+    const int kq = lane >> 4;
+    float *vv = lds, *mrow = lds + RR_ROWS * RR_PITCH;
+    if (kq == 0) mrow[r] = mk;
+#pragma unroll
+    for (int part = 0; part < NOUT / 32; ++part) {
+        if (part) __syncthreads();
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) *reinterpret_cast<float4 *>(vv + r * RR_PITCH + c2 * 16 + 4 * kq) = last[2 * part + c2];
+        __syncthreads();
+        const int ch = lane & 31;
+        for (int pp = wave * 2 + (lane >> 5); pp < P; pp += 2 * RR_WAVES) {
+            const long p = first_point + pp;
+            if (p >= total_points) break;
+            const float *col = vv + (pp * K) * RR_PITCH + ch, *mkp = mrow + pp * K;
+            float best = -INFINITY;
+            for (int k0 = 0; k0 < K; k0 += 8) {
+                float v[8], w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = min(k0 + u, K - 1);
+                    v[u] = col[k * RR_PITCH];
+                    w[u] = mkp[k];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) best = fmaxf(best, v[u] * w[u]);
+            }
+            feat_store(out, p * NOUT + 32 * part + ch, best, F16);
+        }
+    }
+}
+
+template <int FPB, int N1, int N2, int N3, bool F16>
+__global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobPair<elo_setconv_args> jobs)
+{
+    extern __shared__ __align__(16) float lds[];
+    const elo_setconv_args &a = jobs.job[blockIdx.y];
+    constexpr int C = 16 * FPB, NOUT = N3 ? N3 : N2;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, kq = lane >> 4, tid = threadIdx.x;
+    const int K = a.K, P = RR_ROWS / K;
+    const long total_points = (long)a.batch * a.npoints;
+    const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
+    unsigned bad = 0;
+    typedef RrStream<ScPlan<FPB, N1, N2, N3>> Stream;
+    Stream ws{};
+    ws.w[0] = a.layers[0].w_packed; ws.w[1] = a.layers[1].w_packed;
+    if constexpr (N3 != 0) ws.w[2] = a.layers[2].w_packed;
+    ws.ring = reinterpret_cast<uint4 *>(lds); ws.wave = wave; ws.lane = lane;
+    constexpr int E0 = Stream::first(1), E1 = N3 ? Stream::first(N3 ? 2 : 1) : 0;
+    auto fetch = [&](int g, RrW &dst) { ws.fetch(g, dst); };
+    auto advance = [&](int S) { ws.advance(S); };
+    ws.start();
+    float4 bias[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const float4 *>(a.layers[0].bias + t * 16 + 4 * kq);
+    // ---- grouping.  Scratch behind the 16 KB ring: [KT] visiting order | [128] cell | [128] mask | [P] centres (hw, xyz)
+    int *lds_off = reinterpret_cast<int *>(lds + 4096);
+    const int KT = a.group.kernel_h * a.group.kernel_w;
+    int *cell_row = lds_off + ((KT + 3) & ~3);
+    float *mask_row = reinterpret_cast<float *>(cell_row + RR_ROWS);
+    int *chw = reinterpret_cast<int *>(mask_row + RR_ROWS);                  // [128] (h << 16) | w of the centres
+    float *cxyz = reinterpret_cast<float *>(chw + RR_ROWS);                  // [128 * 3]
+    {
+        const long ptq = first_point + tid;
+        const bool mine = tid < P && ptq < total_points;
+        const long pq = mine ? ptq : first_point;
+        const int b = (int)((unsigned)pq / (unsigned)a.npoints), n = (int)((unsigned)pq - (unsigned)b * (unsigned)a.npoints);
+        const int hc = a.centre_hw ? a.centre_hw[pq * 2 + 0] : n / a.W, wc = a.centre_hw ? a.centre_hw[pq * 2 + 1] : n - (n / a.W) * a.W;
+        const float *c = a.xyz1_grid + (((long)b * a.H + hc) * a.W + wc) * 3;
+        const float cx = c[0], cy = c[1], cz = c[2];
+        if (tid < RR_ROWS) { cell_row[tid] = -1; mask_row[tid] = 0.0f; }
+        if (mine) {
+            chw[tid] = (hc << 16) | wc;
+            cxyz[tid * 3 + 0] = cx; cxyz[tid * 3 + 1] = cy; cxyz[tid * 3 + 2] = cz;
+            if (a.new_xyz) { a.new_xyz[ptq * 3 + 0] = cx; a.new_xyz[ptq * 3 + 1] = cy; a.new_xyz[ptq * 3 + 2] = cz; }     // :206
+        }
+    }
+    stage_offsets(lds_off, a.group.random_hw, a.group.kernel_h, a.group.kernel_w, a.group.decoded_hw);      // ends with __syncthreads()
+    {
+        const float r2 = a.group.distance * a.group.distance;
+        const int per_wave = 16 / K > 0 ? 16 / K : 1;                        // whole points in this wave's 16 rows (K = 8: 2, K = 16: 1)
+        for (int j = 0; j < per_wave; ++j) {
+            const int pp = (wave * 16) / K + j;                              // (K divides 16 here: see the launcher)
+            const long ptw = first_point + pp;
+            if (pp >= P || ptw >= total_points) continue;                    // (uniform)
+            const int b = (int)((unsigned)ptw / (unsigned)a.npoints);
+            auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+            const int hwc = __builtin_amdgcn_readfirstlane(chw[pp]), hc = hwc >> 16, wc = hwc & 0xffff;
+            const float cx = uniform(cxyz[pp * 3 + 0]), cy = uniform(cxyz[pp * 3 + 1]), cz = uniform(cxyz[pp * 3 + 2]);
+            auto emit = [&](int slot, int hw) {
+                cell_row[pp * K + slot] = (b * a.H2 + (hw >> 16)) * a.W2 + (hw & 0xffff);
+                mask_row[pp * K + slot] = 1.0f;
+            };
+            int count = 0;
+            if (!(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS)) {          // valid centre (:62-70)
+                const GridBuf gb = grid_buffer(a.src_xyz + (size_t)b * a.H2 * a.W2 * 3);
+                count = wave_random_k(gb, a.H2, a.W2, KT, K, lds_off, hc / a.group.stride_h, wc / a.group.stride_w, cx, cy, cz, r2, emit);
+            }
+            for (int k = count + lane; k < K; k += 64) { cell_row[pp * K + k] = 0; mask_row[pp * K + k] = 0.0f; }   // index (0,0,0), mask 0
+        }
+    }
+    __syncthreads();
+    // ---- this lane's row: gather [features | xyz difference]
+    const int r = wave * 16 + i16, pi = r / K;
+    const int cell = cell_row[r];
+    const bool used = cell >= 0;                     // (rows of points beyond the end keep -1)
+    const float mk = mask_row[r];
+    const float c0 = cxyz[(pi < P ? pi : 0) * 3 + 0], c1 = cxyz[(pi < P ? pi : 0) * 3 + 1], c2 = cxyz[(pi < P ? pi : 0) * 3 + 2];
+    ActPair in0[FPB / 2];
+    uint4 dxyz;
+    {
+        typedef typename std::conditional<F16, uint2, float4>::type Item;
+        Item f[FPB];
+        const long cc = used ? cell : 0;
+        const Item *rf = reinterpret_cast<const Item *>(a.src_feat) + (cc * C >> 2) + kq;
+#pragma unroll
+        for (int j = 0; j < FPB; ++j) f[j] = rf[j * 4];
+        const float *g = a.src_xyz + cc * 3;
+        const float x = g[0], y = g[1], z = g[2];
+        ws.prime();
+        const bool keep = used && mk != 0.0f;
+        auto quad = [&](const Item &v) {
+            const uint4 zq{0u, 0u, 0u, 0u};
+            if constexpr (F16) return keep ? quad_of_halves(v) : zq;
+            else return keep ? pack_quad<MODE_SPLIT>(v, bad) : zq;
+        };
+#pragma unroll
+        for (int j = 0; j < FPB; ++j) put_quad(in0[j / 2], j % 2, quad(f[j]));
+        const float4 d = kq == 0 ? float4{x * mk - c0, y * mk - c1, z * mk - c2, 0.0f} : float4{0.0f, 0.0f, 0.0f, 0.0f};
+        dxyz = used ? pack_quad<MODE_SPLIT>(d, bad) : uint4{0u, 0u, 0u, 0u};
+    }
+    rr_barrier();
+    const uint4 none{0u, 0u, 0u, 0u};
+    ActPair h1[N1 / 32];
+    rr_layer<FPB / 2, true, N1 / 16, 0>(in0, dxyz, a.layers[0], a.layers[1].bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h1[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.layers[0].relu), bad));
+    });
+    float4 last[NOUT / 16];
+    if constexpr (N3 == 0) {
+        rr_layer<N1 / 32, false, N2 / 16, E0>(h1, none, a.layers[1], nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+            last[2 * pass + t] = relu4(acc, a.layers[1].relu);
+        });
+    } else {
+        ActPair h2[N2 / 32];
+        rr_layer<N1 / 32, false, N2 / 16, E0>(h1, none, a.layers[1], a.layers[2].bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+            put_quad(h2[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.layers[1].relu), bad));
+        });
+        rr_layer<N2 / 32, false, NOUT / 16, E1>(h2, none, a.layers[2], nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+            last[2 * pass + t] = relu4(acc, a.layers[2].relu);
+        });
+    }
+    rr_pool_max<NOUT, F16>(lds, last, mk, r, wave, lane, K, P, first_point, total_points, a.out);
+    report_violations<MODE_SPLIT>(bad);
+}
 #endif   // !ELO_DENSE_F32
 
 // ================================================================ cost volume, stage 2
@@ -1987,6 +2157,21 @@ extern "C" int elo_range_violations(unsigned long long *count, elo_stream_t stre
     return ELO_OK;
 }
 
+// the register-resident form of cost-volume stage 1 (cv1_rr_kernel) is taken for pre-grouped calls (idx / mask) in the
+// fp32-class products mode; ELO_CV1_RR=0 or elo_debug_cv1_rr(0) keep the tile kernel (comparison, tests)
+static int g_cv1_rr = -1;
+extern "C" int elo_debug_cv1_rr(int on)
+{
+    const int prev = g_cv1_rr;
+    g_cv1_rr = on;
+    return prev;
+}
+static bool cv1_rr_on()
+{
+    static const int from_env = [] { const char *e = getenv("ELO_CV1_RR"); return e ? atoi(e) : 1; }();
+    return (g_cv1_rr >= 0 ? g_cv1_rr : from_env) != 0;
+}
+
 extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_args *b, elo_stream_t stream)
 {
     const char *who = "elo_setconv_fused";
@@ -2018,6 +2203,32 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
     JobPair<elo_setconv_args> pair;
     pair.job[0] = *a;
     pair.job[1] = b ? *b : *a;
+#ifndef ELO_DENSE_F32
+    {   // the register-resident form (setconv_rr_kernel) for the model's wide shapes, from ELO_SETCONV_RR_ROWS rows on
+        const char *env_rows = getenv("ELO_SETCONV_RR_ROWS");          // (read per call: tests switch it)
+        const long min_rows = env_rows ? atol(env_rows) : 100000L;
+        const int nl = a->n_layers, n1 = a->layers[0].N, n2 = a->layers[1].N, n3 = nl == 3 ? a->layers[2].N : 0;
+        const int shape = (nl == 2 && n1 == 128 && n2 == 64) ? 1 : (nl == 3 && n1 == 64 && n2 == 64 && n3 == 128) ? 2
+                        : (nl == 3 && n1 == 128 && n2 == 64 && n3 == 64) ? 3 : 0;
+        const int KT = a->group.kernel_h * a->group.kernel_w;
+        if (shape && a->group.random_hw && plan.mode == MODE_SPLIT && cv1_rr_on() && a->C == 64 && (a->K == 8 || a->K == 16 || a->K == 32) &&
+            KT <= 512 && !a->group.idx_out && !a->group.mask_out && points * a->K * (b ? 2 : 1) >= min_rows) {
+            const int P = RR_ROWS / a->K;
+            const dim3 rgrid((unsigned)((points + P - 1) / P), b ? 2u : 1u);
+            const bool f16 = a->feat_dtype == ELO_F16;
+#define RRS(N1_, N2_, N3_)                                                                                                              \
+            do {                                                                                                                        \
+                if (f16) hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, true>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);  \
+                else hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, false>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);     \
+            } while (0)
+            if (shape == 1) RRS(128, 64, 0);
+            else if (shape == 2) RRS(64, 64, 128);
+            else RRS(128, 64, 64);
+#undef RRS
+            return check_launch(who);
+        }
+    }
+#endif
     const dim3 grid((unsigned)plan.units, b ? 2u : 1u);
     const size_t lds = plan.lds;
     const int S = plan.S;
@@ -2154,21 +2365,6 @@ static int plan_cv1(const elo_cv1_args *a, TilePlan *p, const char *who)
     if (sizeof(float) * (((size_t)KT + 3) / 4 * 4 + (size_t)FUSED_WAVES * select_scratch_words(KT, a->K)) > sizeof(float) * (p->t16 ? 16 : 32) * p->S)
         return fail(ELO_ERR_LIMIT, "%s: window %dx%d does not fit the tile for in-kernel grouping", who, a->group.kernel_h, a->group.kernel_w);
     return check_group(a->group, a->H2, a->W2, p->lds, who);
-}
-
-// the register-resident form of cost-volume stage 1 (cv1_rr_kernel) is taken for pre-grouped calls (idx / mask) in the
-// fp32-class products mode; ELO_CV1_RR=0 or elo_debug_cv1_rr(0) keep the tile kernel (comparison, tests)
-static int g_cv1_rr = -1;
-extern "C" int elo_debug_cv1_rr(int on)
-{
-    const int prev = g_cv1_rr;
-    g_cv1_rr = on;
-    return prev;
-}
-static bool cv1_rr_on()
-{
-    static const int from_env = [] { const char *e = getenv("ELO_CV1_RR"); return e ? atoi(e) : 1; }();
-    return (g_cv1_rr >= 0 ? g_cv1_rr : from_env) != 0;
 }
 
 extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)

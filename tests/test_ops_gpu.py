@@ -578,3 +578,69 @@ def test_register_resident_cost_volume_stage2_equals_the_tile_kernel(kernel_path
     assert rr.dtype == tile.dtype and torch.isfinite(rr.float()).all()
     assert torch.equal(rr, tile) and torch.equal(rr, own)
     assert 0.3 < m.mean() and m.min() == 0
+
+
+@pytest.mark.parametrize("case", [dict(B=2, H=16, W=225, sh=2, sw=2, K=8, mlp=[128, 64], win=(7, 15), d=3.0, feat="f32", pair=True),    # set-upconv l0 <- l1
+                                  dict(B=3, H=8, W=113, sh=2, sw=2, K=8, mlp=[128, 64], win=(7, 15), d=6.0, feat="f16", pair=True),
+                                  dict(B=2, H=4, W=57, sh=1, sw=2, K=8, mlp=[128, 64], win=(7, 15), d=9.0, feat="f32", pair=False),
+                                  dict(B=4, H=4, W=57, sh=1, sw=2, K=16, mlp=[64, 64, 128], win=(5, 9), d=12.0, feat="f32", pair=False, down=True),   # sa1/layer3
+                                  dict(B=2, H=4, W=57, sh=1, sw=2, K=16, mlp=[128, 64, 64], win=(5, 9), d=12.0, feat="f16", pair=False, down=True)])  # new_layer3
+def test_register_resident_setconv_equals_the_tile_kernel(kernel_path, case, monkeypatch):
+    """setconv_rr_kernel (in-kernel random-k by the wave that owns the rows, chain in registers, masked max through LDS)
+    against setconv_kernel on the same call: bit for bit -- set-upconv shapes (every dense pixel a centre, strided sparse
+    grid, K = 8, single and paired launches) and the two wide down_conv shapes (strided centre list, K = 16), fp32 and
+    fp16 feature storage."""
+    if kernel_path != "fused":
+        pytest.skip("fused kernels only")
+    fused, tf_util, synth, lib, mu = load_pkg("fused"), load_pkg("tf_util"), load_pkg("synth"), load_pkg("_lib"), load_pkg("model_util")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    B, H, W, sh, sw, K = case["B"], case["H"], case["W"], case["sh"], case["sw"], case["K"]
+    f1, _ = synth.frame_pair(B, H, W, seed=H + W + K)
+    rng = np.random.default_rng(K + H)
+    dt = np.float16 if case["feat"] == "f16" else np.float32
+    kH, kW = case["win"]
+    perm = [rng.permutation(kH * kW).astype(np.int32) for _ in range(2)]
+    store = tf_util.VariableStore(DEV, seed=6)
+    if case.get("down"):                                        # down_conv: strided centres on the grid itself
+        src_xyz = f1
+        H2, W2 = H, W
+        oh, ow = -(-H // sh), -(-W // sw)
+        sel = mu.get_selected_idx(t(f1), sh, sw, oh, ow)
+        centre_hw = sel.reshape(B, -1, 3)[:, :, 1:].contiguous()
+        stride = (1, 1)
+    else:                                                       # up_conv: dense centres, sparse source grid
+        src_xyz = np.ascontiguousarray(f1[:, ::sh, ::sw])
+        H2, W2 = src_xyz.shape[1:3]
+        centre_hw = None
+        stride = (sh, sw)
+    feats = [rng.normal(0, 1, (B, H2, W2, 64)).astype(dt) for _ in range(2)]
+    with tf_util.default_store(store), torch.no_grad():
+        P = fused.packed_layer
+        chains = []
+        for j in range(2):
+            widths = [67] + case["mlp"]
+            layers = [P("j%d_l%d" % (j, i), widths[i], widths[i + 1], row_order=fused.setconv_row_order(64) if i == 0 else None)
+                      for i in range(len(case["mlp"]))]
+            for p_ in layers:
+                p_.b.copy_(torch.from_numpy(rng.normal(0, 0.1, p_.b.shape).astype(np.float32)))
+            chains.append(layers)
+        job = lambda j: dict(src_xyz=t(src_xyz), src_feat=t(feats[j]), idx=None, mask=None, layers=chains[j], xyz1_grid=t(f1),
+                             centre_hw=centre_hw, group=fused.Grouping(t(perm[j]), [kH, kW], case["d"], *stride), K=K)
+        def run():
+            if case["pair"]:
+                (oa, _), (ob, _) = fused.setconv_pair(job(0), job(1))
+                return [oa, ob]
+            o, nx = fused.setconv(**job(0))
+            return [o] + ([nx] if nx is not None else [])
+        try:
+            lib.lib().elo_debug_cv1_rr(0)
+            tile = run()
+            lib.lib().elo_debug_cv1_rr(1)
+            monkeypatch.setenv("ELO_SETCONV_RR_ROWS", "0")
+            rr = run()
+        finally:
+            lib.lib().elo_debug_cv1_rr(-1)
+    torch.cuda.synchronize()
+    for a_, b_ in zip(rr, tile):
+        assert a_.dtype == b_.dtype and torch.equal(a_, b_)
+    assert float(rr[0].float().abs().max()) > 0
