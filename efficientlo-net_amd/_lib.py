@@ -51,6 +51,7 @@ SoftmaxValidArgs = _struct("elo_softmax_valid_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp), ("out", _vp),
     ("scratch", _vp), ("stats", _vp)])
 SV_MAX_PARTS = 64      # ELO_SV_MAX_PARTS
+POSE_DIRECT_MAX = 1024 # ELO_POSE_DIRECT_MAX
 PermRefreshArgs = _struct("elo_perm_refresh_args", [
     ("pool", _vp), ("versions", _i), ("total", _i), ("cursor", _vp), ("flat", _vp), ("decoded", _vp), ("entry_of", _vp),
     ("table", _vp), ("n_entries", _i)])
@@ -59,7 +60,7 @@ PoseHeadArgs = _struct("elo_pose_head_args", [
     ("W_big", _vp), ("b_big", _vp), ("W_q", _vp), ("b_q", _vp), ("W_t", _vp), ("b_t", _vp),
     ("q_coarse", _vp), ("t_coarse", _vp), ("q", _vp), ("t", _vp), ("q_norm", _vp), ("scratch", _vp), ("pose7", _vp),
     ("clear_scratch", _vp), ("clear_xyz", _vp), ("clear_feat", _vp), ("clear_cells", ctypes.c_long), ("clear_C", _i),
-    ("feat_dtype", _i), ("pose7_slots", _i), ("pose7_cursor", _vp), ("next_orders", PermRefreshArgs)])
+    ("feat_dtype", _i), ("pose7_slots", _i), ("pose7_cursor", _vp), ("next_orders", PermRefreshArgs), ("direct", _i)])
 WarpProjectArgs = _struct("elo_warp_project_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("H", _i), ("W", _i),
     ("az_res", _f), ("vert_res", _f), ("vert_off", _f),
@@ -124,7 +125,8 @@ MlpArgs = _struct("elo_mlp_args", [
     ("rows", _l), ("n_sources", _i), ("src", _vp * 3), ("src_width", _i * 3), ("n_layers", _i),
     ("layers", Dense * 3), ("out", _vp),
     ("n_layers2", _i), ("layers2", Dense * 3), ("before", _vp), ("w_before", _i), ("after", _vp), ("w_after", _i),
-    ("out2", _vp), ("feat_dtype", _i)])
+    ("out2", _vp), ("feat_dtype", _i),
+    ("clear_scratch", _vp), ("clear_xyz", _vp), ("clear_feat", _vp), ("clear_cells", _l), ("clear_C", _i), ("clear_images", _i)])
 Cv1Args = _struct("elo_cv1_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("xyz2", _vp), ("feat2", _vp), ("idx", _vp), ("mask", _vp),
@@ -187,7 +189,7 @@ class EloError(RuntimeError):
     pass
 
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 def lib():

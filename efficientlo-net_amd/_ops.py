@@ -326,8 +326,10 @@ class PoseRing:
 
 
 def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse=None, t_coarse=None, pose7=None,
-              clear=None, warp=None, next_orders=None):
+              clear=None, warp=None, next_orders=None, direct=False):
     """softmax_valid -> conv1d(256) -> q,t heads -> normalise -> compose with the coarse pose, two launches.
+    `direct` (N <= L.POSE_DIRECT_MAX, C = 64, hidden = 256): ONE launch -- the head's workgroups reduce the rows themselves
+    (elo_pose_head_args.direct); `clear` must then already have been cleared by an earlier launch (fused.mlp(clear=...)).
     pwclo_model.py:194-208 / :262-280.  Returns (q (B,4), t (B,3), q_norm (B,4)); `pose7` (B,7), if given, also receives [q_norm | t].
     `next_orders`: an elo_perm_refresh_args (perm.PermSource.refresh_args): the next pooled set of visiting orders is
     loaded by this launch once the pose is written (the last launch of a captured forward).
@@ -360,7 +362,9 @@ def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t
                                       clear.shape[0] * clear.shape[2] * clear.shape[3], clear.shape[4])
                                      if clear is not None else (None, None, None, 0, 0)), fcode,
                        ring.slots if ring is not None else 0, ring.cursor.data_ptr() if ring is not None else None,
-                       next_orders if next_orders is not None else L.PermRefreshArgs())
+                       next_orders if next_orders is not None else L.PermRefreshArgs(), 1 if direct else 0)
+    if direct and clear is not None and not clear.cleared:
+        raise ValueError("direct=True: the ProjectionBuffers must have been cleared by an earlier launch (fused.mlp(clear=...))")
     if clear is not None and clear.out_feat is not None and clear.out_feat.dtype != fdt:
         raise TypeError("the projection buffers and the pose head's features must share one storage dtype")
     if warp is not None:

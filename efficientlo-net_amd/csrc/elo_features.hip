@@ -484,25 +484,6 @@ __device__ __forceinline__ SvPartials sv_partials(float *scratch, int batch, int
     return SvPartials{scratch, scratch + n, scratch + 2 * n};
 }
 
-// Side job of the partial kernel (elo_pose_head_args.clear_*): its workgroups also clear the buffers of the
-// projection that follows the pose head, which saves that call's init launch (three per forward).
-constexpr int ZFLAGS = 4;                          // projection scratch, per image: one flag per cell a zero point can fall in (3 used)
-struct ProjectionClear { unsigned *minr; float *xyz; unsigned *feat; long cells; int C; int images; };   // minr: cells + images words; C: 32-bit words of features per cell
-
-__device__ __forceinline__ void clear_projection(const ProjectionClear &c)
-{
-    if (!c.minr) return;
-    const long n_xyz = c.cells * 3, total = c.cells + n_xyz + c.cells * c.C;
-    const long nthreads = (long)gridDim.x * gridDim.y * gridDim.z * blockDim.x;
-    const long me = (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-    for (long i = me; i < (long)c.images * ZFLAGS; i += nthreads) c.minr[c.cells + i] = 0x7f7f7f7fu;   // the zero-point flags
-    for (long i = me; i < total; i += nthreads) {
-        if (i < c.cells) c.minr[i] = 0x7f7f7f7fu;
-        else if (i < c.cells + n_xyz) c.xyz[i - c.cells] = 0.0f;
-        else c.feat[i - c.cells - n_xyz] = 0u;
-    }
-}
-
 // F16 is a template parameter: with the storage type behind a run-time flag every load sat under a (uniform) branch, and
 // a conditional load costs a full s_waitcnt vmcnt(0) -- the 16 rows a wave has "in flight" became 32 dependent round
 // trips (14 us per launch at batch 8 with fp16 features, whatever the grid size: profiles/r02_c3_summary.json).
@@ -699,8 +680,13 @@ __device__ __forceinline__ void normalise_q(const float *q, float *o)
 // same head redundantly -- identical instructions on identical inputs, a few microseconds -- block 0 stores it, and
 // then each block warps its 256 points of the NEXT level's cloud by that pose and does pass A of the projection:
 // the warp no longer waits for a kernel boundary after the pose head.
-__global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_head_args a, const int parts,
-                                                              const elo_warp_project_args w, const int with_warp)
+// DIRECT (elo_pose_head_args.direct; 1: fp32 storage, 2: fp16): BLOCK = 1024 and the workgroup computes softmax_valid
+// itself -- wave g walks rows g, g+16, ... with 16 rows in flight, lane = channel -- instead of merging the slices of a
+// partial-sums launch: for clouds of <= 1024 points that launch (8.5 us + a launch boundary, three per forward) is all
+// latency.  Only the first 256 threads own a unit of the hidden layer.
+template <int BLOCK, int DIRECT>
+__global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_args a, const int parts,
+                                                          const elo_warp_project_args w, const int with_warp)
 {
     extern __shared__ float sm[];                      // [C] pooled feature, [hidden] big, [8] heads
     float *feat = sm, *big = sm + a.C, *head = big + a.hidden;
@@ -709,20 +695,78 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
     // The model's head (C = 64, hidden = 256 = one unit per thread): this thread's column of W_big and its rows of
     // W_q / W_t do not depend on anything computed here -- requested now, they arrive while the slices are merged
     // (otherwise four dependent batches of 16 loads sit between the merge and the heads).
-    constexpr int HEAD_C = 64;
-    const bool model_head = a.C == HEAD_C && a.hidden == (int)blockDim.x;
+    constexpr int HEAD_C = 64, HEAD_HIDDEN = 256;
+    const bool model_head = DIRECT ? true : (a.C == HEAD_C && a.hidden == BLOCK);
+    const bool unit = !DIRECT || tid < HEAD_HIDDEN;    // this thread owns hidden unit `tid`
     float wb[HEAD_C], wq[4], wt[3], bias_big = 0.0f;
-    if (model_head) {
+    auto request_weights = [&]() {
+        const int j = unit ? tid : 0;
 #pragma unroll
-        for (int c = 0; c < HEAD_C; ++c) wb[c] = a.W_big[(size_t)c * a.hidden + tid];
+        for (int c = 0; c < HEAD_C; ++c) wb[c] = a.W_big[(size_t)c * a.hidden + j];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) wq[o] = a.W_q[(size_t)tid * 4 + o];
+        for (int o = 0; o < 4; ++o) wq[o] = a.W_q[(size_t)j * 4 + o];
 #pragma unroll
-        for (int o = 0; o < 3; ++o) wt[o] = a.W_t[(size_t)tid * 3 + o];
-        bias_big = a.b_big[tid];
-    }
-    {   // merge the slices: 4 threads per channel (C <= 64), each over every 4th slice, then a 4-way combine
-        float *mpart = head + 8 + 8 * (ELO_BLOCK / ELO_WAVE);          // [3][4][64]
+        for (int o = 0; o < 3; ++o) wt[o] = a.W_t[(size_t)j * 3 + o];
+        bias_big = a.b_big[j];
+    };
+    float *mpart = head + 8 + 8 * (BLOCK / ELO_WAVE);                  // [3][G][64], G = 4 (merge) or BLOCK / 64 (direct)
+    if constexpr (DIRECT != 0) {
+        typedef typename std::conditional<DIRECT == 2, _Float16, float>::type feat_t;
+        const feat_t *__restrict__ feature = reinterpret_cast<const feat_t *>(a.feature) + (size_t)b * a.npoints * HEAD_C;
+        const feat_t *__restrict__ weight = reinterpret_cast<const feat_t *>(a.weight) + (size_t)b * a.npoints * HEAD_C;
+        const float *__restrict__ p = a.xyz + (size_t)b * a.npoints * 3;
+        constexpr int G = BLOCK / ELO_WAVE, U = 16;
+        // (g stays a vector value: as a scalar the validity test becomes s_load + s_waitcnt lgkmcnt(0) per row, and the 16
+        // rows of a step turn into 16 dependent round trips -- 7 us per step, measured)
+        const int c = tid & 63, g = tid >> 6, N = a.npoints;
+        float mx = -INFINITY, den = 0.0f, acc = 0.0f;
+        for (int n0 = g; n0 < N; n0 += G * U) {
+            // which of the step's 16 rows are valid points: lane u < 16 tests row n0 + u*G, one ballot (three registers
+            // instead of 48 for the coordinates); straight-line code below -- a branch around the second half of the
+            // loads or around an exponential splits the step into dependent round trips
+            const int nv = n0 + (c & 15) * G, nvc = nv < N ? nv : N - 1;
+            const float px = p[nvc * 3 + 0], py = p[nvc * 3 + 1], pz = p[nvc * 3 + 2];
+            float l[U], v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int n = n0 + u * G, nn = n < N ? n : N - 1;
+                l[u] = (float)weight[nn * HEAD_C + c];
+                v[u] = (float)feature[nn * HEAD_C + c];
+            }
+            const unsigned okm = (unsigned)__ballot((c < U) & (nv < N) & !((px == 0.0f) & (py == 0.0f) & (pz == 0.0f)));
+            float bm = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < U; ++u) bm = (okm >> u & 1u) ? fmaxf(bm, l[u]) : bm;
+            const float bz = bm > -INFINITY ? bm : 0.0f;
+            float d16 = 0.0f, a16 = 0.0f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float e = (okm >> u & 1u) ? exp_acc(l[u] - bz) : 0.0f;
+                d16 += e;
+                a16 += e * v[u];
+            }
+            const float m2 = fmaxf(mx, bm);
+            const float s0 = mx > -INFINITY ? exp_acc(mx - m2) : 0.0f, s1 = bm > -INFINITY ? exp_acc(bm - m2) : 0.0f;
+            den = den * s0 + d16 * s1;
+            acc = acc * s0 + a16 * s1;
+            mx = m2;
+        }
+        request_weights();                             // (after the loop: its 32 values per step and these 72 do not fit 128 registers together)
+        mpart[(0 * G + g) * 64 + c] = mx; mpart[(1 * G + g) * 64 + c] = den; mpart[(2 * G + g) * 64 + c] = acc;
+        __syncthreads();
+        if (tid < 64) {
+            float MM = -INFINITY;
+            for (int i = 0; i < G; ++i) MM = fmaxf(MM, mpart[(0 * G + i) * 64 + tid]);
+            float DD = 0.0f, AA = 0.0f;
+            for (int i = 0; i < G; ++i) {
+                if (mpart[(1 * G + i) * 64 + tid] == 0.0f) continue;
+                const float sc = exp_acc(mpart[(0 * G + i) * 64 + tid] - MM);
+                DD += mpart[(1 * G + i) * 64 + tid] * sc; AA += mpart[(2 * G + i) * 64 + tid] * sc;
+            }
+            feat[tid] = DD > 0.0f ? AA / DD : 0.0f;
+        }
+    } else {   // merge the slices: 4 threads per channel (C <= 64), each over every 4th slice, then a 4-way combine
+        if (model_head) request_weights();
         const int c = tid & 63, q = tid >> 6;
         float M = -INFINITY, D = 0.0f, A = 0.0f;
         if (c < a.C) {
@@ -762,7 +806,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
         float v = bias_big;
 #pragma unroll
         for (int c = 0; c < HEAD_C; ++c) v += feat[c] * wb[c];
-        big[tid] = v;
+        if (unit) big[tid] = v;
     } else {
         for (int j = tid; j < a.hidden; j += blockDim.x) {
             float v = a.b_big[j];
@@ -775,7 +819,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void pose_head_kernel(const elo_pose_hea
     {   // conv1d hidden -> 4 (q) and hidden -> 3 (t): 7 dot products over `hidden`, reduced wave-wide then across waves
         float part[7] = {0, 0, 0, 0, 0, 0, 0};
         if (model_head) {
-            const float bj = big[tid];
+            const float bj = unit ? big[tid] : 0.0f;
 #pragma unroll
             for (int o = 0; o < 4; ++o) part[o] += bj * wq[o];
 #pragma unroll
@@ -1141,21 +1185,31 @@ static int pose_head_impl(const elo_pose_head_args *a, const elo_warp_project_ar
         wv.q = a->q;                                  // pass B only asks whether a warp happened (reads `warped`)
         wv.t = a->t;
     }
+    ELO_REQUIRE(!a->direct || (a->npoints <= ELO_POSE_DIRECT_MAX && a->C == 64 && a->hidden == 256), who,
+                "direct takes npoints <= ELO_POSE_DIRECT_MAX, C == 64, hidden == 256");
     if (a->batch == 0) return ELO_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int parts = sv_parts(a->npoints);
-    const ProjectionClear clear{a->clear_scratch, a->clear_xyz, (unsigned *)a->clear_feat, a->clear_cells,
-                                f16 ? a->clear_C / 2 : a->clear_C, a->batch};
-    const dim3 pgrid(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE);
-    if (f16)
-        hipLaunchKernelGGL(softmax_valid_partial_kernel<true>, pgrid, dim3(ELO_BLOCK), 0, s, a->feature, a->weight, a->xyz,
-                           a->npoints, a->C, parts, a->scratch, clear);
-    else
-        hipLaunchKernelGGL(softmax_valid_partial_kernel<false>, pgrid, dim3(ELO_BLOCK), 0, s, a->feature, a->weight, a->xyz,
-                           a->npoints, a->C, parts, a->scratch, clear);
-    const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (ELO_BLOCK / ELO_WAVE) + 3 * 4 * 64);
-    const unsigned xb = w ? (unsigned)((w->npoints + ELO_BLOCK - 1) / ELO_BLOCK) : 1u;
-    hipLaunchKernelGGL(pose_head_kernel, dim3(xb, a->batch), dim3(ELO_BLOCK), lds, s, *a, parts, wv, w ? 1 : 0);
+    if (a->direct) {                                  // one launch: the head's workgroups reduce the rows themselves
+        constexpr int DB = 1024;
+        const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (DB / ELO_WAVE) + 3 * (DB / ELO_WAVE) * 64);
+        const unsigned xb = w ? (unsigned)((w->npoints + DB - 1) / DB) : 1u;
+        if (f16) hipLaunchKernelGGL((pose_head_kernel<DB, 2>), dim3(xb, a->batch), dim3(DB), lds, s, *a, 0, wv, w ? 1 : 0);
+        else hipLaunchKernelGGL((pose_head_kernel<DB, 1>), dim3(xb, a->batch), dim3(DB), lds, s, *a, 0, wv, w ? 1 : 0);
+    } else {
+        const int parts = sv_parts(a->npoints);
+        const ProjectionClear clear{a->clear_scratch, a->clear_xyz, (unsigned *)a->clear_feat, a->clear_cells,
+                                    f16 ? a->clear_C / 2 : a->clear_C, a->batch};
+        const dim3 pgrid(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE);
+        if (f16)
+            hipLaunchKernelGGL(softmax_valid_partial_kernel<true>, pgrid, dim3(ELO_BLOCK), 0, s, a->feature, a->weight, a->xyz,
+                               a->npoints, a->C, parts, a->scratch, clear);
+        else
+            hipLaunchKernelGGL(softmax_valid_partial_kernel<false>, pgrid, dim3(ELO_BLOCK), 0, s, a->feature, a->weight, a->xyz,
+                               a->npoints, a->C, parts, a->scratch, clear);
+        const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (ELO_BLOCK / ELO_WAVE) + 3 * 4 * 64);
+        const unsigned xb = w ? (unsigned)((w->npoints + ELO_BLOCK - 1) / ELO_BLOCK) : 1u;
+        hipLaunchKernelGGL((pose_head_kernel<ELO_BLOCK, 0>), dim3(xb, a->batch), dim3(ELO_BLOCK), lds, s, *a, parts, wv, w ? 1 : 0);
+    }
     if (w) {
         const size_t cells = (size_t)w->batch * w->H * w->W, pts = (size_t)w->batch * w->npoints;
         const size_t elems = pts * (3 + (f16 ? w->C / 2 : w->C));

@@ -21,6 +21,7 @@
 //
 // Interfaces and the reference lines covered: include/elo.h ("Fused inference kernels").
 #include "elo_group_device.h"
+#include "elo_project_device.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -1118,6 +1119,11 @@ __global__ __launch_bounds__(FUSED_BLOCK, TILE == 32 ? ELO_TILE32_WAVES : ELO_TI
     float *act = lds;
     const int tid = threadIdx.x, f16 = a.feat_dtype == ELO_F16;
     unsigned bad = 0;
+    {   // side job (elo_mlp_args.clear_*, job 0's): every workgroup of the launch clears its share of a later projection's buffers
+        const elo_mlp_args &j0 = jobs.job[0];
+        clear_projection(ProjectionClear{j0.clear_scratch, j0.clear_xyz, (unsigned *)j0.clear_feat, j0.clear_cells,
+                                         j0.feat_dtype == ELO_F16 ? j0.clear_C / 2 : j0.clear_C, j0.clear_images});
+    }
     const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * TILE;
     if (first >= a.rows) return;
     auto row_of = [&](int row) { return first + row < a.rows ? first + row : -1L; };
@@ -2259,6 +2265,9 @@ static int check_mlp(const elo_mlp_args *a, const char *who, int *in_width)
         if (int rc = check_dense(a->layers[l], width, 0, who, "mlp")) return rc;
         width = a->layers[l].N;
     }
+    ELO_REQUIRE(!a->clear_scratch || (a->clear_xyz && a->clear_cells > 0 && a->clear_images > 0 && a->clear_C >= 0 &&
+                                      (a->clear_feat || a->clear_C == 0) && (a->feat_dtype != ELO_F16 || a->clear_C % 2 == 0)),
+                who, "incomplete clear_* side job");
     ELO_REQUIRE(a->n_layers2 >= 0 && a->n_layers2 <= ELO_MAX_CHAIN, who, "0..3 second-stage layers");
     if (a->n_layers2 > 0) {
         ELO_REQUIRE(a->out2 && a->w_before >= 0 && a->w_after >= 0 && (a->before || a->w_before == 0) &&
@@ -2299,7 +2308,9 @@ extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_
         for (int l = 0; same && l < a->n_layers2; ++l) same = a->layers2[l].N == b->layers2[l].N;
         if (!same) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must have the same shape", who);
     }
-    if (a->rows == 0) return ELO_OK;
+    if (b && b->clear_scratch) return fail(ELO_ERR_ARG, "%s: the clear_* side job belongs to the first job of a pair", who);
+    if (a->rows == 0)
+        return a->clear_scratch ? fail(ELO_ERR_ARG, "%s: a clear_* side job needs rows to ride on", who) : ELO_OK;
     const int S = row_stride(mlp_cols(a, in_width));
     const long u32 = (a->rows + 31) / 32, u16 = (a->rows + 15) / 16;
     int mode = 0, mode_b = 0;

@@ -32,4 +32,24 @@ __device__ __forceinline__ void zero_cells(int H, int W, float az_res, float ver
     zc[2] = cell_of_point(atan2f(-0.0f, -0.0f), 0.0f, 0.0f, H, W, az_res, vert_res, vert_off);
 }
 
+// Side job of a launch in front of a projection (elo_pose_head_args.clear_* on the softmax partial-sums kernel,
+// elo_mlp_args.clear_* on the row-wise MLP): its workgroups also clear the projection's buffers, which saves that
+// call's init launch (three per forward).
+constexpr int ZFLAGS = 4;                          // projection scratch, per image: one flag per cell a zero point can fall in (3 used)
+struct ProjectionClear { unsigned *minr; float *xyz; unsigned *feat; long cells; int C; int images; };   // minr: cells + images words; C: 32-bit words of features per cell
+
+__device__ __forceinline__ void clear_projection(const ProjectionClear &c)
+{
+    if (!c.minr) return;
+    const long n_xyz = c.cells * 3, total = c.cells + n_xyz + c.cells * c.C;
+    const long nthreads = (long)gridDim.x * gridDim.y * gridDim.z * blockDim.x;
+    const long me = (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    for (long i = me; i < (long)c.images * ZFLAGS; i += nthreads) c.minr[c.cells + i] = 0x7f7f7f7fu;   // the zero-point flags
+    for (long i = me; i < total; i += nthreads) {
+        if (i < c.cells) c.minr[i] = 0x7f7f7f7fu;
+        else if (i < c.cells + n_xyz) c.xyz[i - c.cells] = 0.0f;
+        else c.feat[i - c.cells - n_xyz] = 0u;
+    }
+}
+
 }  // namespace elo

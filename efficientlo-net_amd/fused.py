@@ -305,9 +305,24 @@ def _mlp_args(sources, layers):
     return a, out, (srcs, layers)
 
 
-def mlp(sources, layers):
-    """Row-wise MLP over concat(sources, -1) without building the concat.  sources: (..., C_i) tensors."""
+def _ride_clear(a, clear, dt):
+    """elo_mlp_args.clear_*: the launch's workgroups also clear `clear` (an _ops.ProjectionBuffers)."""
+    if clear is None:
+        return
+    if clear.out_feat is not None and clear.out_feat.dtype != dt:
+        raise TypeError("the projection buffers and the MLP's features must share one storage dtype")
+    B, _N, H, W, C = clear.shape
+    a.clear_scratch, a.clear_xyz = clear.scratch.data_ptr(), clear.out_xyz.data_ptr()
+    a.clear_feat = clear.out_feat.data_ptr() if clear.out_feat is not None else None
+    a.clear_cells, a.clear_C, a.clear_images = B * H * W, C, B
+    clear.cleared = True
+
+
+def mlp(sources, layers, clear=None):
+    """Row-wise MLP over concat(sources, -1) without building the concat.  sources: (..., C_i) tensors.
+    `clear`: ProjectionBuffers of a later projection, cleared on the side (for a pose head run with direct=True)."""
     a, out, _keep = _mlp_args(sources, layers)
+    _ride_clear(a, clear, out.dtype)
     L.call("elo_mlp_fused", a, out)
     return out.reshape(sources[0].shape[:-1] + (layers[-1].N,))
 
@@ -334,13 +349,14 @@ def _mlp2_args(sources, layers, before, after, layers2):
     return a, out, out2, (keep, before, after, layers2)
 
 
-def mlp2_pair(job_a, job_b):
+def mlp2_pair(job_a, job_b, clear=None):
     """Two jobs of identical shape, each TWO chained row-wise MLPs, in ONE launch:
     out = layers(concat(sources)); out2 = layers2(concat(before, out, after)).  job: dict(sources, layers, before,
     after, layers2); layers2[0] is packed with `row_order=stage2_row_order(w_before, N, w_after)` (the kernel's columns
     are [out | before | after]).  Returns ((out_a, out2_a), (out_b, out2_b))."""
     a, out_a, out2_a, _ka = _mlp2_args(**job_a)
     b, out_b, out2_b, _kb = _mlp2_args(**job_b)
+    _ride_clear(a, clear, out_a.dtype)                            # (clear: as for mlp)
     L.call2("elo_mlp_fused2", a, b, out_a)
     lead = job_a["sources"][0].shape[:-1]
     shape = lambda t: t.reshape(lead + (t.shape[-1],))

@@ -203,7 +203,7 @@ def _cost_volume_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, ma
     return _ops.masked_softmax_pool(pc_cat, pc_points_grouped, mask2)                             # :137-146
 
 
-def flow_predictor(points_f1, upsampled_feat, cost_volume, mlp, is_training, bn_decay, scope, bn=True):
+def flow_predictor(points_f1, upsampled_feat, cost_volume, mlp, is_training, bn_decay, scope, bn=True, clear=None):
     """utils/pointnet_util.py:153-175: MLP over concat[points_f1, upsampled_feat?, cost_volume?] -> (B,N,mlp[-1])."""
     with tf_util.variable_scope(scope):
         parts = [points_f1]
@@ -215,7 +215,7 @@ def flow_predictor(points_f1, upsampled_feat, cost_volume, mlp, is_training, bn_
             widths = [sum(p.shape[-1] for p in parts)] + list(mlp)
             layers = [fused.packed_layer('conv_predictor%d' % i, widths[i], widths[i + 1], bn=bn)
                       for i in range(len(mlp))]
-            return fused.mlp(parts, layers)                                                       # one launch
+            return fused.mlp(parts, layers, clear=clear)                                          # one launch (clear: a side job)
         parts = [p.unsqueeze(2) for p in parts]                                                   # :166
         x = None
         for i, num_out_channel in enumerate(mlp):
@@ -315,7 +315,7 @@ def up_conv_stage1_jobs(up_a, up_b):
     return jobs
 
 
-def up_conv_predict_finish(up_a, up_b, fp_a, fp_b, up_a_pooled, up_b_pooled):
+def up_conv_predict_finish(up_a, up_b, fp_a, fp_b, up_a_pooled, up_b_pooled, clear=None):
     """Stage 2 of both set-upconvs and the two flow predictors they feed, in ONE launch (see up_conv_predict_pair)."""
     stage2 = []
     for up, fp, pooled in ((up_a, fp_a, up_a_pooled), (up_b, fp_b, up_b_pooled)):
@@ -335,7 +335,7 @@ def up_conv_predict_finish(up_a, up_b, fp_a, fp_b, up_a_pooled, up_b_pooled):
                          row_order=fused.stage2_row_order(w_before, mlp2[-1], w_after) if i == 0 else None)
                        for i in range(len(fp["mlp"]))]
         stage2.append(dict(sources=[pooled, points1], layers=layers, before=before, after=after, layers2=layers2))
-    (out_a, pred_a), (out_b, pred_b) = fused.mlp2_pair(stage2[0], stage2[1])
+    (out_a, pred_a), (out_b, pred_b) = fused.mlp2_pair(stage2[0], stage2[1], clear=clear)
     return out_a, pred_a, out_b, pred_b
 
 

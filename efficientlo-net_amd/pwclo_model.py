@@ -12,6 +12,7 @@ Differences from the reference, all documented in DESIGN.md:
     projection first (:54-67).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -170,7 +171,7 @@ def _pose_head(feat_b1c, level, coarse, is_training):
     return q, t
 
 
-def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training, pose7=None, clear=None, warp=None):
+def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training, pose7=None, clear=None, warp=None, direct=False):
     """softmax_valid + pose head + composition with the coarse pose (q_coarse None at l3).
     Returns (q (B,4), t (B,3), q_norm (B,4)): the level's pose and its final normalisation (:427-430).
     Inference: two fused HIP launches (_ops.pose_head).  Training: the literal operator chain."""
@@ -184,7 +185,7 @@ def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training,
         # the l0 head is the last launch of a forward: in a graph captured with fresh_orders it also loads the NEXT replay's orders
         from . import perm
         nxt = perm.tail_refresh_args() if level == 0 else None
-        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7, clear, warp, nxt)
+        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7, clear, warp, nxt, direct)
     summed = softmax_valid(feature_bnc=predict, weight_bnc=weight, mask_valid=xyz)                  # :194 / :262
     q_det, t_det = _pose_head(summed, level, coarse, is_training)                                   # :197-208 / :264-273
     if coarse:
@@ -299,9 +300,6 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
     # coarse pose at l3 (:183-208)
     l3_points_predict = l3_points_f1_cost_volume
     l3_points_predict_proj = l3_points_predict.reshape(batch_size, out_h_list[5], out_w_list[5], -1)
-    l3_cost_volume_w = flow_predictor(pts_f1[3], None, l3_points_predict, mlp=[128, 64], is_training=is_training,
-                                      bn_decay=bn_decay, scope='l3_costvolume_predict_ww')
-    l3_cost_volume_w_proj = l3_cost_volume_w.reshape(batch_size, out_h_list[5], out_w_list[5], -1)
     l3_xyz_f1 = xyz_proj_f1[3].reshape(batch_size, -1, 3)
     # inference: the pose head of level L+1 also clears the projection buffers of level L's warp (one launch less)
     inference = not is_training
@@ -311,11 +309,24 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
             return None
         return _ops.ProjectionBuffers(batch_size, xyz_proj_f1[level].shape[1] * xyz_proj_f1[level].shape[2],
                                       out_h_list[g], out_w_list[g], pts_f1[level].shape[-1], dev, pts_f1[level].dtype)
+    def direct_head(xyz_bn3):
+        # ELO_POSE_DIRECT=1: for small clouds (l3, l2, l1 of the 64 x 1800 input) the pose head reduces softmax_valid itself
+        # (one launch less per level; the projection buffers are then cleared by the launch that produces the head's
+        # inputs).  OFF by default -- measured slower: the 1024-thread head takes 13.8 / 16.2 / 24.3 us where the
+        # partial-sums launch + head take 17.0 / 18.3 / 20.8 us, and a workgroup that needs a whole CU waits for one when
+        # eight lanes are in flight (10 200 -> 9 640 frame-pairs/s; one lane 3 290 -> 3 230).  DESIGN.md, round 3.
+        return (inference and fused_pairs_available(is_training) and xyz_bn3.shape[1] <= _ops.L.POSE_DIRECT_MAX and
+                os.environ.get("ELO_POSE_DIRECT", "0") == "1")
     def next_warp(level):          # the cloud + features the NEXT warp moves: run by the pose head's own launches
         return (xyz_proj_f1[level].reshape(batch_size, -1, 3), pts_f1[level]) if inference else None
     next_buffers = projection_buffers(2, 4)
+    l3_cost_volume_w = flow_predictor(pts_f1[3], None, l3_points_predict, mlp=[128, 64], is_training=is_training,
+                                      bn_decay=bn_decay, scope='l3_costvolume_predict_ww',
+                                      clear=next_buffers if direct_head(l3_xyz_f1) else None)
+    l3_cost_volume_w_proj = l3_cost_volume_w.reshape(batch_size, out_h_list[5], out_w_list[5], -1)
     l3_q, l3_t, l3_q_norm = _estimate_pose(l3_points_predict, l3_cost_volume_w, l3_xyz_f1, 3, None, None,
-                                           is_training, clear=next_buffers, warp=next_warp(2))     # :194-208
+                                           is_training, clear=next_buffers, warp=next_warp(2),
+                                           direct=direct_head(l3_xyz_f1))                           # :194-208
 
     # three warp-refinement levels (:211-425); one loop instead of three pasted blocks
     cv_kernel2 = {2: [5, 15], 1: [7, 25], 0: [11, 41]}                                              # :243,:317,:391
@@ -368,7 +379,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
             # set-upconv stage 2 and the predictor it feeds share a launch
             w_up_sample, weight, cost_up_sample, predict = up_conv_predict_finish(
                 up_w, up_c, dict(fp, scope='l%d_w_predict' % level), dict(fp, scope='l%d_costvolume_predict' % level),
-                up_w_pooled, up_c_pooled)
+                up_w_pooled, up_c_pooled, clear=next_buffers if direct_head(xyz_warp_f1) else None)
         else:
             # the cost volume and the two set-upconvs only share inputs: optional concurrent branches
             cost, w_up_sample, cost_up_sample = _parallel([branch_cost, lambda: branch_up('w', coarse_w_proj),
@@ -381,7 +392,8 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
         q_prev, t_prev, q_norm = _estimate_pose(predict, weight, xyz_warp_f1, level, q_coarse, t_coarse,
                                                 is_training, pose_out if level == 0 else None,
                                                 clear=next_buffers,
-                                                warp=next_warp(level - 1) if level > 0 else None)  # :262-280
+                                                warp=next_warp(level - 1) if level > 0 else None,
+                                                direct=direct_head(xyz_warp_f1))  # :262-280
         poses[level] = (q_norm, t_prev)
 
         coarse_w_proj = weight.reshape(batch_size, out_h_list[g], out_w_list[g], -1)                # :256-257

@@ -276,7 +276,14 @@ typedef struct elo_pose_head_args {
      * visiting orders (elo_perm_refresh semantics) once this pose is written -- the NEXT replay of the graph then walks
      * fresh orders without a launch of its own.  next_orders.pool == NULL: no side job. */
     elo_perm_refresh_args next_orders;
+    /* direct != 0: ONE launch less.  softmax_valid is computed by the head launch itself (every workgroup reduces the
+     * npoints rows on its own: 1024 threads, 16 rows of 64 channels per step) instead of by a partial-sums launch in
+     * front of it: for npoints <= ELO_POSE_DIRECT_MAX, C == 64, hidden == 256.  The clear_* buffers are then NOT cleared
+     * by this call -- the caller has had an earlier launch do it (elo_mlp_args.clear_*: the launch that produces
+     * `feature` / `weight`); with elo_pose_head_warp they still name the warp's buffers. */
+    int direct;
 } elo_pose_head_args;
+#define ELO_POSE_DIRECT_MAX 1024
 int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream);
 
 /* Pose warp + spherical re-projection.
@@ -616,6 +623,15 @@ typedef struct elo_mlp_args {
     int w_after;
     void *out2;                   /* (rows, layers2[last].N) feat_dtype */
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
+    /* Optional side job (job 0 of a paired launch only): the launch's workgroups also clear the buffers of an
+     * elo_warp_project / elo_pose_head_warp call further down the stream -- elo_pose_head_args.clear_* semantics, for a
+     * pose head run with `direct` (which has no launch of its own left to do it).  clear_scratch == NULL: no side job. */
+    unsigned *clear_scratch;      /* first clear_cells + 4*clear_images words <- 0x7f7f7f7f */
+    float *clear_xyz;             /* clear_cells*3 floats <- 0 */
+    void *clear_feat;             /* clear_cells*clear_C elements of feat_dtype <- 0, NULL when clear_C == 0 */
+    long clear_cells;             /* images*H*W of the projection */
+    int clear_C;
+    int clear_images;
 } elo_mlp_args;
 int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream);
 int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_stream_t stream);   /* paired launch, as above */
