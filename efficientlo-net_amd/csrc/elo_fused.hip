@@ -46,8 +46,24 @@ __device__ unsigned long long g_range_violations;      // written by MODE_CHECKE
 // phase boundaries; elo_debug_cv1_clock() reads the stamps
 #ifdef ELO_CV1_CLOCK
 #define CV1_STAMP(i) do { if (block == 0 && threadIdx.x == 0) g_cv1_clock[i] = __builtin_readcyclecounter(); } while (0)
+#ifndef ELO_RR_CLOCK_BLOCK
+#define ELO_RR_CLOCK_BLOCK 0
+#endif
+// cv1_rr_kernel (tools/rr_clock.sh): wave 0 of workgroup ELO_RR_CLOCK_BLOCK, and the same workgroup's wave 7 twelve slots on
+#define RR_STAMP(i) do { if (blockIdx.x == ELO_RR_CLOCK_BLOCK && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) % 7 == 0) \
+                             g_cv1_clock[(i) + 12 * (threadIdx.x >> 9 | (threadIdx.x >> 6) / 7)] = __builtin_readcyclecounter(); } while (0)
+#ifdef ELO_RR_CLOCK_POOL                           // the stamps go to the inside of the pooling tail instead of the layers
+#define RR_POOL_STAMP(i) RR_STAMP(i)
+#define RR_LAYER_STAMP(i) do { } while (0)
+#else
+#define RR_POOL_STAMP(i) do { } while (0)
+#define RR_LAYER_STAMP(i) RR_STAMP(i)
+#endif
 #else
 #define CV1_STAMP(i) do { } while (0)
+#define RR_STAMP(i) do { } while (0)
+#define RR_POOL_STAMP(i) do { } while (0)
+#define RR_LAYER_STAMP(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ int ceil8(int x) { return (x + 7) & ~7; }
@@ -813,11 +829,38 @@ __device__ __forceinline__ void pool_masked_max(const float *act, int S, int off
     }
 }
 
-// out = sum_k softmax_k(mask == 1 ? logit : -1e10) * value      (64 channels), one pass (online softmax)
+// out = sum_k softmax_k(mask == 1 ? logit : -1e10) * value      (64 channels)
 // e^x on the hardware exp2 (v_exp_f32: ~1 ulp), a fifth of the instructions of expf's range-reduced polynomial; the
 // pooled softmax weights feed a convex combination, far inside the 1e-4 parity tolerance.
 // logits: a PLAIN fp32 region; values: an OPERAND-format region (they were a layer's input).
 __device__ __forceinline__ float exp_hw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896f); }
+
+// One chunk of up to 8 rows (n of them real) merged into the running (maximum, denominator, weighted sum): the chunk's own
+// maximum first, then its 8 exponentials side by side, then ONE merge -- no branch.  (Until round 3 this was the textbook
+// online form, a data-dependent branch and two dependent exponentials per row: 370 cycles per row, a THIRD of the
+// register-resident kernel's time at K = 6: tools/rr_clock.sh.)  A single chunk (K <= 8) merges into (-inf, 0, 0) exactly:
+// exp2(-inf) = 0, exp2(0) = 1.  All rows masked: every x is -1e10, the weights are uniform, as in the reference.
+__device__ __forceinline__ void softmax_chunk8(const float (&l)[8], const float (&v)[8], const float (&w)[8], int n,
+                                               float &mx, float &den, float &acc)
+{
+    float x[8], cm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        x[u] = w[u] == 1.0f ? l[u] : -1e10f;
+        cm = u < n ? fmaxf(cm, x[u]) : cm;
+    }
+    float cd = 0.0f, ca = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const float e = u < n ? exp_hw(x[u] - cm) : 0.0f;
+        cd += e;
+        ca += e * v[u];
+    }
+    const float m2 = fmaxf(mx, cm), s0 = exp_hw(mx - m2), s1 = exp_hw(cm - m2);
+    den = den * s0 + cd * s1;
+    acc = acc * s0 + ca * s1;
+    mx = m2;
+}
 
 __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int logit_off, int value_off,
                                                     const TileMeta &m, int P, int K, long first_point,
@@ -840,21 +883,7 @@ __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int
                 v[u] = act_get(act, vword + k * S);
                 w[u] = mk[k];
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (k0 + u >= K) break;
-                const float x = w[u] == 1.0f ? l[u] : -1e10f;
-                if (x > mx) {
-                    const float sc = exp_hw(mx - x);
-                    den = den * sc + 1.0f;
-                    acc = acc * sc + v[u];
-                    mx = x;
-                } else {
-                    const float e = exp_hw(x - mx);
-                    den += e;
-                    acc += e * v[u];
-                }
-            }
+            softmax_chunk8(l, v, w, K - k0, mx, den, acc);
         }
         feat_store(out, pt * 64 + c, acc / den, f16);
     }
@@ -966,6 +995,26 @@ __device__ __forceinline__ float dpp_max_step(float v)
     const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(v), CTRL,
                                                                ROW_MASK, 0xf, false));
     return fmaxf(o, v);
+}
+
+// the same on the BIT PATTERNS of non-negative floats (a ReLU output times a 0 / 1 mask): integer order = float order there,
+// and the compiler folds update_dpp + max into ONE v_max_i32_dpp -- fmaxf is llvm.maxnum, which costs a canonicalising
+// v_max x, x per operand that came out of a DPP move (3 instructions per step instead of 1: 240 of the 1225 vector
+// instructions of the 6 -> 8 -> 8 -> 16 kernel)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_imax_step(int v)
+{
+    return max(__builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, ROW_MASK, 0xf, false), v);
+}
+__device__ __forceinline__ float half_wave_max_nonneg(float f)
+{
+    int v = __float_as_int(f);
+    v = dpp_imax_step<0xb1, 0xf>(v);
+    v = dpp_imax_step<0x4e, 0xf>(v);
+    v = dpp_imax_step<0x114, 0xf>(v);
+    v = dpp_imax_step<0x118, 0xf>(v);
+    v = dpp_imax_step<0x142, 0xa>(v);
+    return __int_as_float(v);
 }
 
 // max over each 32-lane half; valid in lane 31 / 63
@@ -1100,8 +1149,9 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
     small_layer<N1, N2>(y, x, wsm + W2, wsm + B2, a.layers[1].relu);
     small_layer<N2, N3>(x, y, wsm + W3, wsm + B3, a.layers[2].relu);
     // ---- masked max over the 32 rows (:224-230); lane 31 of the half-wave holds it
+    // (the launcher takes this kernel only when the last layer has a ReLU: outputs >= 0, the integer form of the reduction)
 #pragma unroll
-    for (int c = 0; c < N3; ++c) y[c] = half_wave_max(y[c] * m);
+    for (int c = 0; c < N3; ++c) y[c] = half_wave_max_nonneg(y[c] * m);
     if (live && lane == G - 1) {
 #pragma unroll
         for (int c = 0; c < N3; c += 4) feat_store4(a.out, pt * N3 + c, float4{y[c], y[c + 1], y[c + 2], y[c + 3]}, f16);
@@ -1419,11 +1469,15 @@ struct RrStream {
 // layer, pass by pass), two steps = one superstep = one ring slot.  Every step reads its operands from the ring (fetch:
 // the slot is complete since the last barrier); at the end of an odd step the wave moves its chunk of the NEXT superstep
 // from its staging register into the other slot, requests a later one (advance), and joins the barrier.  G0 = this
-// layer's first step.  bias0: the bias quads of pass 0 on entry, of `next_bias`'s pass 0 on exit.
+// layer's first step.  bias0: the bias quads of pass 0 on entry, of `next_bias`'s pass 0 on exit.  The biases of later passes
+// come from the workgroup's LDS table (rr_stage_biases): as global loads one pass ahead they were a dependent L2 round trip
+// PER PASS -- a pass is 100-1000 cycles of work, the round trip ~700 under load: tools/rr_clock.sh showed ~500 + 250 k cycles
+// for a pass of k steps whatever the MFMA count, and a build without any MFMA ran as long.
 // emit(pass, t, acc): epilogue of column block 2*pass + t.
 template <int KP, bool TAIL, int NCB, int G0, class Fetch, class Advance, class Emit>
-__device__ __forceinline__ void rr_layer(const ActPair (&in)[KP > 0 ? KP : 1], const uint4 &tail, const elo_dense &L,
+__device__ __forceinline__ void rr_layer(const ActPair (&in)[KP > 0 ? KP : 1], const uint4 &tail, const float *bias,
                                          const float *next_bias, float4 (&bias0)[2], Fetch fetch, Advance advance, Emit emit)
+// (L.bias / next_bias: this layer's and the next one's biases IN THE LDS TABLE, see rr_stage_biases)
 {
     constexpr int PASSES = NCB / 2, SPP = KP + (TAIL ? 1 : 0);
     static_assert(G0 % 2 == 0 && (PASSES * SPP) % 2 == 0, "a superstep never straddles two layers");
@@ -1436,7 +1490,7 @@ __device__ __forceinline__ void rr_layer(const ActPair (&in)[KP > 0 ? KP : 1], c
         for (int t = 0; t < 2; ++t) acc[0][t] = f32x4{bnext[t].x, bnext[t].y, bnext[t].z, bnext[t].w};
         if (pass + 1 < PASSES) {                                    // the next pass's bias quads, a pass ahead
 #pragma unroll
-            for (int t = 0; t < 2; ++t) bnext[t] = *reinterpret_cast<const float4 *>(L.bias + (2 * (pass + 1) + t) * 16 + 4 * kq);
+            for (int t = 0; t < 2; ++t) bnext[t] = *reinterpret_cast<const float4 *>(bias + (2 * (pass + 1) + t) * 16 + 4 * kq);
         } else if (next_bias) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) bnext[t] = *reinterpret_cast<const float4 *>(next_bias + t * 16 + 4 * kq);
@@ -1500,9 +1554,11 @@ __device__ __forceinline__ void rr_pool(float *lds, const float4 (&logit)[4], co
     const int kq = lane >> 4;
     float *lg = lds, *xv = lds + RR_ROWS * RR_PITCH, *mrow = lds + 2 * RR_ROWS * RR_PITCH;
     if (kq == 0) mrow[r] = mk;
+    RR_POOL_STAMP(2);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        if (half) __syncthreads();                   // the first half's reads are done
+        if (half) rr_barrier();                      // the first half's reads are done (rr_barrier: LDS traffic only -- __syncthreads would
+                                                     // also wait for the first half's global stores, ~1-2 us)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
             const int cb = 2 * half + c2;
@@ -1511,7 +1567,9 @@ __device__ __forceinline__ void rr_pool(float *lds, const float4 (&logit)[4], co
             *reinterpret_cast<float4 *>(xv + r * RR_PITCH + c2 * 16 + 4 * kq) = c2 == 0 ? quad_value(xp.hi.x, xp.hi.y, xp.lo.x, xp.lo.y)
                                                                                        : quad_value(xp.hi.z, xp.hi.w, xp.lo.z, xp.lo.w);
         }
-        __syncthreads();
+        if (!half) RR_POOL_STAMP(3); else RR_POOL_STAMP(6);
+        rr_barrier();
+        if (!half) RR_POOL_STAMP(4); else RR_POOL_STAMP(7);
         const int ch = lane & 31;
         for (int pp = wave * 2 + (lane >> 5); pp < P; pp += 2 * RR_WAVES) {
             const long p = first_point + pp;
@@ -1527,26 +1585,32 @@ __device__ __forceinline__ void rr_pool(float *lds, const float4 (&logit)[4], co
                     v[u] = vcol[k * RR_PITCH];
                     w[u] = mrow[pp * K + k];
                 }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (k0 + u >= K) break;
-                    const float x = w[u] == 1.0f ? l[u] : -1e10f;
-                    if (x > mx) {
-                        const float sc = exp_hw(mx - x);
-                        den = den * sc + 1.0f;
-                        sum = sum * sc + v[u];
-                        mx = x;
-                    } else {
-                        const float e = exp_hw(x - mx);
-                        den += e;
-                        sum += e * v[u];
-                    }
-                }
+                softmax_chunk8(l, v, w, K - k0, mx, den, sum);
             }
             feat_store(out, p * 64 + 32 * half + ch, sum / den, F16);
         }
+        if (!half) RR_POOL_STAMP(5);
     }
 }
+
+// The biases of a chain's layers, concatenated, into the workgroup's LDS table (words RR_BIAS_OFF ...: behind the ring and the
+// set-conv grouping scratch, inside the pooling scratch -- dead, like the ring, by the time the pooling writes).  One float
+// per thread (<= 512 in all), requested at kernel start and written before the first rr_barrier().
+constexpr int RR_BIAS_OFF = 8192;
+template <int NL>
+__device__ __forceinline__ float rr_bias_request(const float *const (&b)[NL], const int (&n)[NL], int tid)
+{
+    int at = tid;
+    const float *src = b[0];                        // (clamped: every thread loads something)
+    bool found = false;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        if (!found && at < n[l]) { src = b[l] + at; found = true; }
+        at -= n[l];
+    }
+    return *src;
+}
+__device__ __forceinline__ void rr_bias_store(float *lds, int tid, int total, float v) { if (tid < total) lds[RR_BIAS_OFF + tid] = v; }
 
 template <int FP> struct Cv1Plan {                 // CV_0 (FP pairs + geometry tail -> 128), CV_1, CV_2, CV_xyz (tail -> 64), sum_CV_0, sum_CV_1
     static constexpr int NL = 6;
@@ -1565,6 +1629,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     unsigned bad = 0;
+    RR_STAMP(0);
     // ---- the W stream.  Steps per layer: CV_0 4*(FP+1), CV_1 2*4, CV_2 2*2, CV_xyz 2*1, sum_CV_0 4*4, sum_CV_1 2*4
     typedef RrStream<Cv1Plan<FP>> Stream;
     Stream ws{{a.cv0.w_packed, a.cv1.w_packed, a.cv2.w_packed, a.cv_xyz.w_packed, a.sum_cv0.w_packed, a.sum_cv1.w_packed}, ring, wave, lane, {}};
@@ -1575,6 +1640,10 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
     float4 bias[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const float4 *>(a.cv0.bias + t * 16 + 4 * kq);
+    const float *const bsrc[6] = {a.cv0.bias, a.cv1.bias, a.cv2.bias, a.cv_xyz.bias, a.sum_cv0.bias, a.sum_cv1.bias};
+    constexpr int BN[6] = {128, 64, 64, 64, 128, 64}, B1 = 128, B2 = 192, B3 = 256, B4 = 320, B5 = 448;     // table offsets
+    const float bias_word = rr_bias_request(bsrc, BN, (int)threadIdx.x);
+    const float *bt = lds + RR_BIAS_OFF;
     // ---- row metadata + gather, every load requested before the first use (this lane's row: r = wave * 16 + i16)
     const int r = wave * 16 + i16, pi = r / K;
     long pt = first_point + pi;
@@ -1615,35 +1684,45 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
                         : kq == 2 ? float4{d2, e, 0.0f, 0.0f} : float4{0.0f, 0.0f, 0.0f, 0.0f};
         geo = used ? pack_quad<MODE_SPLIT>(q4, bad) : uint4{0u, 0u, 0u, 0u};
     }
+    rr_bias_store(lds, (int)threadIdx.x, 512, bias_word);
+    RR_STAMP(1);
     rr_barrier();                                    // superstep 0 is in the ring
+    RR_LAYER_STAMP(2);
     // ---- the chain
     const uint4 none{0u, 0u, 0u, 0u};
     ActPair h128[4];                                 // CV_0's output (128 channels = 4 pairs)
-    rr_layer<FP, true, 8, 0>(in0, geo, a.cv0, a.cv1.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<FP, true, 8, 0>(in0, geo, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         put_quad(h128[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.cv0.relu), bad));
     });
+    RR_LAYER_STAMP(3);
     ActPair h64[2];
-    rr_layer<4, false, 4, E0>(h128, none, a.cv1, a.cv2.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<4, false, 4, E0>(h128, none, bt + B1, bt + B2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         put_quad(h64[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.cv1.relu), bad));
     });
+    RR_LAYER_STAMP(4);
     ActPair xe[4];                                   // [x | enc]: sum_CV_0's input; x stays alive: it is the pooling's value
-    rr_layer<2, false, 4, E1>(h64, none, a.cv2, a.cv_xyz.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<2, false, 4, E1>(h64, none, bt + B2, bt + B3, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         put_quad(xe[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.cv2.relu), bad));
     });
+    RR_LAYER_STAMP(5);
     {
         ActPair unused[1];
-        rr_layer<0, true, 4, E2>(unused, geo, a.cv_xyz, a.sum_cv0.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        rr_layer<0, true, 4, E2>(unused, geo, bt + B3, bt + B4, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
             put_quad(xe[2 + pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.cv_xyz.relu), bad));
         });
     }
-    rr_layer<4, false, 8, E3>(xe, none, a.sum_cv0, a.sum_cv1.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    RR_LAYER_STAMP(6);
+    rr_layer<4, false, 8, E3>(xe, none, bt + B4, bt + B5, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         put_quad(h128[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.sum_cv0.relu), bad));
     });
+    RR_LAYER_STAMP(7);
     float4 logit[4];                                 // plain fp32, held until the ring is dead
-    rr_layer<4, false, 4, E4>(h128, none, a.sum_cv1, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<4, false, 4, E4>(h128, none, bt + B5, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         logit[2 * pass + t] = relu4(acc, a.sum_cv1.relu);
     });
+    RR_STAMP(8);
     rr_pool<F16>(lds, logit, xe[0], xe[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
+    RR_STAMP(9);
     report_violations<MODE_SPLIT>(bad);
 }
 // ---- cost volume, stage 2, register-resident (see cv1_rr_kernel): xyz-encoding (geometry tail -> 64), sum_cost_volume_0
@@ -1674,6 +1753,10 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
     float4 bias[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const float4 *>(a.xyz_enc.bias + t * 16 + 4 * kq);
+    const float *const bsrc[3] = {a.xyz_enc.bias, a.sum_cost0.bias, a.sum_cost1.bias};
+    constexpr int BN[3] = {64, 128, 64}, B1 = 64, B2 = 192;
+    const float bias_word = rr_bias_request(bsrc, BN, (int)threadIdx.x);
+    const float *bt = lds + RR_BIAS_OFF;
     // ---- row metadata + gather (this lane's row: r = wave * 16 + i16 = point * K + slot)
     const int r = wave * 16 + i16, pi = r / K;
     long pt = first_point + pi;
@@ -1718,20 +1801,21 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
                         : kq == 2 ? float4{d2, e, 0.0f, 0.0f} : float4{0.0f, 0.0f, 0.0f, 0.0f};
         geo = used ? pack_quad<MODE_SPLIT>(q4, bad) : uint4{0u, 0u, 0u, 0u};
     }
+    rr_bias_store(lds, (int)threadIdx.x, 256, bias_word);
     rr_barrier();
     const uint4 none{0u, 0u, 0u, 0u};
     {
         ActPair unused[1];
-        rr_layer<0, true, 4, 0>(unused, geo, a.xyz_enc, a.sum_cost0.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        rr_layer<0, true, 4, 0>(unused, geo, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
             put_quad(in1[2 + pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.xyz_enc.relu), bad));      // encoding: pairs 2, 3
         });
     }
     ActPair h128[4];
-    rr_layer<KP1, C == 16, 8, E0>(in1, ftail, a.sum_cost0, a.sum_cost1.bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<KP1, C == 16, 8, E0>(in1, ftail, bt + B1, bt + B2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         put_quad(h128[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.sum_cost0.relu), bad));
     });
     float4 logit[4];
-    rr_layer<4, false, 4, E1>(h128, none, a.sum_cost1, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<4, false, 4, E1>(h128, none, bt + B2, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         logit[2 * pass + t] = relu4(acc, a.sum_cost1.relu);
     });
     rr_pool<F16>(lds, logit, in1[0], in1[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
@@ -1758,10 +1842,10 @@ __device__ __forceinline__ void rr_pool_max(float *lds, const float4 (&last)[NOU
     if (kq == 0) mrow[r] = mk;
 #pragma unroll
     for (int part = 0; part < NOUT / 32; ++part) {
-        if (part) __syncthreads();
+        if (part) rr_barrier();
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) *reinterpret_cast<float4 *>(vv + r * RR_PITCH + c2 * 16 + 4 * kq) = last[2 * part + c2];
-        __syncthreads();
+        rr_barrier();
         const int ch = lane & 31;
         for (int pp = wave * 2 + (lane >> 5); pp < P; pp += 2 * RR_WAVES) {
             const long p = first_point + pp;
@@ -1808,6 +1892,10 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
     float4 bias[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const float4 *>(a.layers[0].bias + t * 16 + 4 * kq);
+    const float *const bsrc[3] = {a.layers[0].bias, a.layers[1].bias, N3 ? a.layers[2].bias : a.layers[1].bias};
+    constexpr int BN[3] = {N1, N2, N3}, B1 = N1, B2 = N1 + N2;
+    const float bias_word = rr_bias_request(bsrc, BN, tid);
+    const float *bt = lds + RR_BIAS_OFF;
     // ---- grouping.  Scratch behind the 16 KB ring: [KT] visiting order | [128] cell | [128] mask | [P] centres (hw, xyz)
     int *lds_off = reinterpret_cast<int *>(lds + 4096);
     const int KT = a.group.kernel_h * a.group.kernel_w;
@@ -1884,23 +1972,24 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
         const float4 d = kq == 0 ? float4{x * mk - c0, y * mk - c1, z * mk - c2, 0.0f} : float4{0.0f, 0.0f, 0.0f, 0.0f};
         dxyz = used ? pack_quad<MODE_SPLIT>(d, bad) : uint4{0u, 0u, 0u, 0u};
     }
+    rr_bias_store(lds, tid, N1 + N2 + N3, bias_word);
     rr_barrier();
     const uint4 none{0u, 0u, 0u, 0u};
     ActPair h1[N1 / 32];
-    rr_layer<FPB / 2, true, N1 / 16, 0>(in0, dxyz, a.layers[0], a.layers[1].bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<FPB / 2, true, N1 / 16, 0>(in0, dxyz, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         put_quad(h1[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.layers[0].relu), bad));
     });
     float4 last[NOUT / 16];
     if constexpr (N3 == 0) {
-        rr_layer<N1 / 32, false, N2 / 16, E0>(h1, none, a.layers[1], nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        rr_layer<N1 / 32, false, N2 / 16, E0>(h1, none, bt + B1, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
             last[2 * pass + t] = relu4(acc, a.layers[1].relu);
         });
     } else {
         ActPair h2[N2 / 32];
-        rr_layer<N1 / 32, false, N2 / 16, E0>(h1, none, a.layers[1], a.layers[2].bias, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        rr_layer<N1 / 32, false, N2 / 16, E0>(h1, none, bt + B1, bt + B2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
             put_quad(h2[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.layers[1].relu), bad));
         });
-        rr_layer<N2 / 32, false, NOUT / 16, E1>(h2, none, a.layers[2], nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        rr_layer<N2 / 32, false, NOUT / 16, E1>(h2, none, bt + B2, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
             last[2 * pass + t] = relu4(acc, a.layers[2].relu);
         });
     }
@@ -2191,7 +2280,7 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
     if (points == 0) return ELO_OK;
     hipStream_t s = (hipStream_t)stream;
     if (!b && a->group.random_hw && a->K == 32 && a->n_layers == 3 && a->layers[0].w_plain && a->layers[1].w_plain &&
-        a->layers[2].w_plain && a->group.kernel_h * a->group.kernel_w <= SMALL_STEPS * 32) {                     // narrow chains: wave-per-point VALU kernel
+        a->layers[2].w_plain && a->layers[2].relu && a->group.kernel_h * a->group.kernel_w <= SMALL_STEPS * 32) {   // narrow chains: wave-per-point VALU kernel
         const int cin = 3 + a->C, n1 = a->layers[0].N, n2 = a->layers[1].N, n3 = a->layers[2].N;
         const unsigned grid = (unsigned)((points + 7) / 8);
         if (int rc = check_group(a->group, a->H2, a->W2, 0, who)) return rc;
