@@ -229,12 +229,33 @@ def cost_volume_leg(dev, B, H_in, W_in, half, reps=20):
             "levels": levels}
 
 
-def per_operator_leg(dev, batch, half, reps=20):
-    """The four HBM-bound kernels of the ELO_FUSED=0 cost volume at l0 (SURVEY 8(d) terms A1, P1, A2, P2: gather/encode
-    and masked softmax pooling with the GEMMs between them left to hipBLASLt), each against its own algorithmic bytes."""
+# the four cost volumes of a 64 x 1800 forward: grid, feature channels, stage-1 neighbours, stage-1 window (pwclo_model.py:170,
+# :242, :316, :390)
+PER_OPERATOR_LEVELS = {"l0": (16, 225, 16, 6, (11, 41)), "l1": (8, 113, 32, 6, (7, 25)), "l2": (4, 57, 64, 6, (5, 15)),
+                       "l2_origin": (4, 57, 64, 32, (5, 35))}
+
+
+def per_operator_all_levels_leg(dev, batch, half):
+    """The 16 per-operator cost-volume launches of a forward (A1, P1, A2, P2 at l0, l1, l2, l2_origin) against the sum of
+    their algorithmic bytes (216 MB at batch 8 with fp16 features), as separate launches."""
+    levels = {lv: per_operator_leg(dev, batch, half, level=lv) for lv in PER_OPERATOR_LEVELS}
+    tot_b, tot_us = sum(r["bytes"] for r in levels.values()), sum(r["us"] for r in levels.values())
+    gbs = tot_b / tot_us / 1e3
+    return {"kernel": "ELO_FUSED=0 cost volume, all four levels: 4 x (cv_encode1 + softmax_pool + cv_encode2 + softmax_pool)",
+            "batch": batch, "features": "f16" if half else "f32", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b), "us": round(tot_us, 2),
+            "target_us_at_60pct": round(tot_b / (0.6 * HBM_PEAK_GBS * 1e3), 1),
+            "levels": {lv: {"us": r["us"], "bytes": r["bytes"], "frac": r["frac"]} for lv, r in levels.items()}}
+
+
+def per_operator_leg(dev, batch, half, reps=20, level="l0"):
+    """The four HBM-bound kernels of the ELO_FUSED=0 cost volume at one level (default l0) (SURVEY 8(d) terms A1, P1, A2, P2:
+    gather/encode and masked softmax pooling with the GEMMs between them left to hipBLASLt), each against its own
+    algorithmic bytes."""
     import torch
     ops, synth, elo = pkg("_ops"), pkg("synth"), pkg()
-    H, W, C, Kq, Kp, win = 16, 225, 16, 6, 4, (11, 41)
+    H, W, C, Kq, win = PER_OPERATOR_LEVELS[level]
+    Kp = 4
     N = H * W
     g = torch.Generator(device="cpu").manual_seed(3)
     cvb = cost_volume_bytes(N, C, Kq, Kp, 2 if half else 4)
@@ -262,7 +283,7 @@ def per_operator_leg(dev, batch, half, reps=20):
         terms[term] = {"bytes": int(nbytes), "us": round(sec * 1e6, 2), "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4)}
         tot_b, tot_s = tot_b + nbytes, tot_s + sec
     gbs = tot_b / tot_s / 1e9
-    return {"kernel": "ELO_FUSED=0 cost volume at l0: cv_encode1 + softmax_pool + cv_encode2 + softmax_pool", "batch": batch,
+    return {"kernel": "ELO_FUSED=0 cost volume at %s: cv_encode1 + softmax_pool + cv_encode2 + softmax_pool" % level, "batch": batch,
             "features": "f16" if half else "f32", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b), "us": round(tot_s * 1e6, 2), "terms": terms}
 
@@ -304,6 +325,7 @@ def roofline_leg(args, dev, net, reps=50):
         out["per_operator_b8_f16"] = per_operator_leg(dev, 8, True)
         out["per_operator_b64_f32"] = per_operator_leg(dev, 64, False)
         out["per_operator_b64_f16"] = per_operator_leg(dev, 64, True)
+        out["per_operator_all_levels_b8_f16"] = per_operator_all_levels_leg(dev, 8, True)
     return out
 
 

@@ -1593,6 +1593,72 @@ __device__ __forceinline__ void rr_pool(float *lds, const float4 (&logit)[4], co
     }
 }
 
+// ---- pooling INSIDE the wave, for K | 16: the K rows of a point are K adjacent lanes of one 16-lane DPP row (row r = wave*16
+// + i16), so the reduction over K needs no LDS and no barrier -- where the LDS form is a fifth of a workgroup's time
+// (tools/rr_clock.sh: ~6.7 k of ~32 k cycles: two write / barrier / half-wave-per-point rounds, with the waves' skew in the
+// barriers).  Both forms give the same bits: a maximum does not depend on the order, and the softmax sums are scanned in
+// the order softmax_chunk8 adds them.  Values must be >= 0 (a ReLU in front: the launchers check), so that the maxima can be
+// taken on the bit patterns (dpp_imax_step: one v_max_i32_dpp per step).
+template <int CTRL>
+__device__ __forceinline__ int dpp_imax_all(int v) { return max(__builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false), v); }
+
+template <int NOUT, bool F16>
+__device__ __forceinline__ void rr_pool_max_inwave(const float4 (&last)[NOUT / 16], float mk, int r, int lane, int K, long first_point,
+                                                   long total_points, void *out)
+{
+    const int kq = lane >> 4, i16 = lane & 15;
+    const long p = first_point + (K == 16 ? r >> 4 : r >> 3);
+    const bool writer = (i16 & (K - 1)) == 0 && p < total_points;
+#pragma unroll
+    for (int cb = 0; cb < NOUT / 16; ++cb) {
+        const float q[4] = {last[cb].x * mk, last[cb].y * mk, last[cb].z * mk, last[cb].w * mk};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int v = __float_as_int(q[e]);
+            v = dpp_imax_all<0xb1>(v);               // quad_perm:[1,0,3,2]
+            v = dpp_imax_all<0x4e>(v);               // quad_perm:[2,3,0,1]
+            v = dpp_imax_all<0x141>(v);              // row_half_mirror: 8 lanes
+            if (K == 16) v = dpp_imax_all<0x140>(v); // row_mirror: 16 lanes
+            o[e] = __int_as_float(v);
+        }
+        if (writer) feat_store4(out, p * NOUT + cb * 16 + 4 * kq, float4{o[0], o[1], o[2], o[3]}, F16);
+    }
+}
+
+// masked softmax over K = 4 rows of the 64 logits, weighted sum of the 64 values (rr_pool's arguments): lane 3 of each quad
+// of lanes ends up with softmax_chunk8's sums in softmax_chunk8's order (a left fold over the rows: row_shr:1 three times)
+template <bool F16>
+__device__ __forceinline__ void rr_pool_softmax4_inwave(const float4 (&logit)[4], const ActPair &v0, const ActPair &v1, float mk, int r,
+                                                        int lane, long first_point, long total_points, void *out)
+{
+    const int kq = lane >> 4, i16 = lane & 15;
+    const long p = first_point + (r >> 2);
+    const bool writer = (i16 & 3) == 3 && p < total_points;
+    auto shr1 = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, false)); };
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const ActPair &xp = cb < 2 ? v0 : v1;
+        const float4 val = cb % 2 == 0 ? quad_value(xp.hi.x, xp.hi.y, xp.lo.x, xp.lo.y) : quad_value(xp.hi.z, xp.hi.w, xp.lo.z, xp.lo.w);
+        const float l[4] = {logit[cb].x, logit[cb].y, logit[cb].z, logit[cb].w}, v[4] = {val.x, val.y, val.z, val.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = mk == 1.0f ? l[e] : -1e10f;
+            int m = __float_as_int(x);               // (logits >= 0 or exactly -1e10: integer order = float order)
+            m = dpp_imax_all<0xb1>(m);
+            m = dpp_imax_all<0x4e>(m);
+            const float ex = exp_hw(x - __int_as_float(m)), ev = ex * v[e];
+            float cd = ex, ca = ev;
+#pragma unroll
+            for (int step = 0; step < 3; ++step) { cd = shr1(cd) + ex; ca = shr1(ca) + ev; }
+            // (softmax_chunk8's merge into (-inf, 0, 0): den = 0 * 0 + cd * 1, acc = 0 * 0 + ca * 1)
+            o[e] = ca / cd;
+        }
+        if (writer) feat_store4(out, p * 64 + cb * 16 + 4 * kq, float4{o[0], o[1], o[2], o[3]}, F16);
+    }
+}
+
 // The biases of a chain's layers, concatenated, into the workgroup's LDS table (words RR_BIAS_OFF ...: behind the ring and the
 // set-conv grouping scratch, inside the pooling scratch -- dead, like the ring, by the time the pooling writes).  One float
 // per thread (<= 512 in all), requested at kernel start and written before the first rr_barrier().
@@ -1818,7 +1884,8 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
     rr_layer<4, false, 4, E1>(h128, none, bt + B2, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         logit[2 * pass + t] = relu4(acc, a.sum_cost1.relu);
     });
-    rr_pool<F16>(lds, logit, in1[0], in1[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
+    if (K == 4 && a.sum_cost1.relu) rr_pool_softmax4_inwave<F16>(logit, in1[0], in1[1], mk, r, lane, first_point, total_points, a.out);
+    else rr_pool<F16>(lds, logit, in1[0], in1[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
     report_violations<MODE_SPLIT>(bad);
 }
 // ---- set-conv / set-upconv stage 1, register-resident (see cv1_rr_kernel): in-kernel random-k grouping (a wave groups
@@ -1993,7 +2060,8 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
             last[2 * pass + t] = relu4(acc, a.layers[2].relu);
         });
     }
-    rr_pool_max<NOUT, F16>(lds, last, mk, r, wave, lane, K, P, first_point, total_points, a.out);
+    if ((K == 8 || K == 16) && a.layers[N3 ? 2 : 1].relu) rr_pool_max_inwave<NOUT, F16>(last, mk, r, lane, K, first_point, total_points, a.out);
+    else rr_pool_max<NOUT, F16>(lds, last, mk, r, wave, lane, K, P, first_point, total_points, a.out);
     report_violations<MODE_SPLIT>(bad);
 }
 #endif   // !ELO_DENSE_F32
