@@ -1888,6 +1888,123 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
     else rr_pool<F16>(lds, logit, in1[0], in1[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
     report_violations<MODE_SPLIT>(bad);
 }
+// ---- two chained row-wise MLPs, register-resident (see cv1_rr_kernel): set-upconv stage 2 and the flow predictor it feeds
+// (mlp_kernel's two-stage form: utils/pointnet_util.py:303-311, :161-175) on the model's widths -- stage 1 [pooled (64) |
+// points (C)] -> 128 -> 64 = `out` (stored), stage 2 [out (64) | before (C) | after (64)] -> 128 -> 64 = `out2`.  No grouping
+// and no pooling: a lane's row is a global row.  blockIdx.y selects one of two jobs.  With fp16 storage `out` continues AS
+// STORED (store_quad's rule), so the chain computes exactly what mlp_kernel does.
+template <int C> struct Mlp2Plan {
+    static constexpr int NL = 4, B1 = 4 + C / 16, B3 = 8 + C / 16;     // 16-k blocks of the two first layers
+    static constexpr int KP[4] = {B1 / 2, 4, B3 / 2, 4}, TL[4] = {B1 % 2, 0, B3 % 2, 0}, NCB[4] = {8, 4, 8, 4};
+};
+
+template <int C, bool F16>
+__global__ __launch_bounds__(RR_WAVES * 64, 4) void mlp2_rr_kernel(const JobPair<elo_mlp_args> jobs)
+{
+    extern __shared__ __align__(16) float lds[];
+    {   // side job (elo_mlp_args.clear_*, job 0's), as in mlp_kernel
+        const elo_mlp_args &j0 = jobs.job[0];
+        clear_projection(ProjectionClear{j0.clear_scratch, j0.clear_xyz, (unsigned *)j0.clear_feat, j0.clear_cells,
+                                         j0.feat_dtype == ELO_F16 ? j0.clear_C / 2 : j0.clear_C, j0.clear_images});
+    }
+    const elo_mlp_args &a = jobs.job[blockIdx.y];
+    typedef Mlp2Plan<C> PL;
+    constexpr int FP = C / 16, KP1 = PL::KP[0], KP3 = PL::KP[2];
+    constexpr bool T1 = PL::TL[0] != 0, T3 = PL::TL[2] != 0;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * RR_ROWS;
+    unsigned bad = 0;
+    typedef RrStream<PL> Stream;
+    Stream ws{{a.layers[0].w_packed, a.layers[1].w_packed, a.layers2[0].w_packed, a.layers2[1].w_packed}, reinterpret_cast<uint4 *>(lds), wave, lane, {}};
+    constexpr int E0 = Stream::first(1), E1 = Stream::first(2), E2 = Stream::first(3);
+    auto fetch = [&](int g, RrW &dst) { ws.fetch(g, dst); };
+    auto advance = [&](int S) { ws.advance(S); };
+    ws.start();
+    float4 bias[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const float4 *>(a.layers[0].bias + t * 16 + 4 * kq);
+    const float *const bsrc[4] = {a.layers[0].bias, a.layers[1].bias, a.layers2[0].bias, a.layers2[1].bias};
+    constexpr int BN[4] = {128, 64, 128, 64}, O1 = 128, O2 = 192, O3 = 320;
+    const float bias_word = rr_bias_request(bsrc, BN, (int)threadIdx.x);
+    const float *bt = lds + RR_BIAS_OFF;
+    // ---- this lane's row
+    const int r = wave * 16 + i16;
+    const bool used = first + r < a.rows;
+    const long gr = used ? first + r : a.rows - 1;
+    typedef typename std::conditional<F16, uint2, float4>::type Item;         // 4 channels
+    auto quad = [&](const Item &v) {
+        const uint4 z{0u, 0u, 0u, 0u};
+        if constexpr (F16) return used ? quad_of_halves(v) : z;
+        else return used ? pack_quad<MODE_SPLIT>(v, bad) : z;
+    };
+    // block b of a concatenation goes to half b % 2 of pair b / 2, the last block of an odd count to the tail
+    ActPair in1[KP1];
+    uint4 tail1{0u, 0u, 0u, 0u};
+    {
+        Item s0[4], s1[FP];
+        const Item *p0 = reinterpret_cast<const Item *>(a.src[0]) + (gr * 64 >> 2) + kq, *p1 = reinterpret_cast<const Item *>(a.src[1]) + (gr * C >> 2) + kq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s0[j] = p0[j * 4];
+#pragma unroll
+        for (int j = 0; j < FP; ++j) s1[j] = p1[j * 4];
+        ws.prime();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) put_quad(in1[j / 2], j % 2, quad(s0[j]));
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            if (T1 && j == FP - 1) tail1 = quad(s1[j]);
+            else put_quad(in1[(4 + j) / 2], (4 + j) % 2, quad(s1[j]));
+        }
+    }
+    rr_bias_store(lds, (int)threadIdx.x, 384, bias_word);
+    rr_barrier();
+    const uint4 none{0u, 0u, 0u, 0u};
+    ActPair h128[4];
+    rr_layer<KP1, T1, 8, 0>(in1, tail1, bt, bt + O1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h128[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.layers[0].relu), bad));
+    });
+    // the second stage's other inputs: requested now, a layer ahead of their first use
+    Item sb[FP], sa[4];
+    {
+        const Item *pb = reinterpret_cast<const Item *>(a.before) + (gr * C >> 2) + kq, *pa = reinterpret_cast<const Item *>(a.after) + (gr * 64 >> 2) + kq;
+#pragma unroll
+        for (int j = 0; j < FP; ++j) sb[j] = pb[j * 4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sa[j] = pa[j * 4];
+    }
+    ActPair in3[KP3];
+    uint4 tail3{0u, 0u, 0u, 0u};
+    rr_layer<4, false, 4, E0>(h128, none, bt + O1, bt + O2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        const float4 v = relu4(acc, a.layers[1].relu);
+        const long at = (first + r) * 64 + (2 * pass + t) * 16 + 4 * kq;
+        if constexpr (F16) {
+            const half2v h0 = half2v{(_Float16)v.x, (_Float16)v.y}, h1 = half2v{(_Float16)v.z, (_Float16)v.w};
+            const uint2 stored{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+            if (used) *reinterpret_cast<uint2 *>(reinterpret_cast<_Float16 *>(a.out) + at) = stored;
+            put_quad(in3[pass], t, quad_of_halves(stored));
+        } else {
+            if (used) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(a.out) + at) = v;
+            put_quad(in3[pass], t, pack_quad<MODE_SPLIT>(v, bad));
+        }
+    });
+    // [out (blocks 0..3) | before (FP blocks) | after (4 blocks)]
+#pragma unroll
+    for (int j = 0; j < FP; ++j) put_quad(in3[(4 + j) / 2], (4 + j) % 2, quad(sb[j]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        constexpr int B0 = 4 + FP;
+        if (T3 && j == 3) tail3 = quad(sa[j]);
+        else put_quad(in3[(B0 + j) / 2], (B0 + j) % 2, quad(sa[j]));
+    }
+    rr_layer<KP3, T3, 8, E1>(in3, tail3, bt + O2, bt + O3, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h128[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.layers2[0].relu), bad));
+    });
+    rr_layer<4, false, 4, E2>(h128, none, bt + O3, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        if (used) feat_store4(a.out2, (first + r) * 64 + (2 * pass + t) * 16 + 4 * kq, relu4(acc, a.layers2[1].relu), F16);
+    });
+    report_violations<MODE_SPLIT>(bad);
+}
 // ---- set-conv / set-upconv stage 1, register-resident (see cv1_rr_kernel): in-kernel random-k grouping (a wave groups
 // the points its 16 rows belong to), gather [features (16 FPB) | xyz difference], two or three layers of compile-time
 // widths, masked max over the K rows of a point (utils/pointnet_util.py:197-230, :272-298).  Instantiated for the
@@ -2481,6 +2598,34 @@ extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_
     JobPair<elo_mlp_args> pair;
     pair.job[0] = *a;
     pair.job[1] = b ? *b : *a;
+#ifndef ELO_DENSE_F32
+    {   // the register-resident form (mlp2_rr_kernel) for the model's two-stage shape, from ELO_MLP_RR_ROWS rows per launch on
+        const char *env_rows = getenv("ELO_MLP_RR_ROWS");              // (read per call: tests switch it)
+        const long min_rows = env_rows ? atol(env_rows) : 8192L;          // batch 8: 23.1 k -> 23.9 k pairs/s (24.1 k with every level); at batch 1 (7200 rows at l0) the tile kernel is faster: 10.2 k vs 9.8 k
+        const int C = a->n_sources == 2 ? a->src_width[1] : 0;
+        const bool aligned = ((uintptr_t)a->src[0] | (uintptr_t)a->src[1] | (uintptr_t)a->before | (uintptr_t)a->after | (uintptr_t)a->out |
+                              (uintptr_t)a->out2) % 16 == 0 &&
+                             (!b || ((uintptr_t)b->src[0] | (uintptr_t)b->src[1] | (uintptr_t)b->before | (uintptr_t)b->after | (uintptr_t)b->out |
+                                     (uintptr_t)b->out2) % 16 == 0);
+        if (mode == MODE_SPLIT && cv1_rr_on() && a->n_sources == 2 && a->src_width[0] == 64 && (C == 16 || C == 32 || C == 64) &&
+            a->n_layers == 2 && a->layers[0].N == 128 && a->layers[1].N == 64 && a->n_layers2 == 2 && a->layers2[0].N == 128 &&
+            a->layers2[1].N == 64 && a->w_before == C && a->w_after == 64 && aligned && a->rows * (b ? 2 : 1) >= min_rows) {
+            const dim3 rgrid((unsigned)((a->rows + RR_ROWS - 1) / RR_ROWS), b ? 2u : 1u);
+            const bool f16 = a->feat_dtype == ELO_F16;
+            hipStream_t rs = (hipStream_t)stream;
+#define RRM(C_)                                                                                                                      \
+            do {                                                                                                                    \
+                if (f16) hipLaunchKernelGGL((mlp2_rr_kernel<C_, true>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);             \
+                else hipLaunchKernelGGL((mlp2_rr_kernel<C_, false>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);                \
+            } while (0)
+            if (C == 16) RRM(16);
+            else if (C == 32) RRM(32);
+            else RRM(64);
+#undef RRM
+            return check_launch(who);
+        }
+    }
+#endif
     const dim3 grid((unsigned)(t16 ? u16 : u32), b ? 2u : 1u);
     hipStream_t s = (hipStream_t)stream;
 #define CALL(k) hipLaunchKernelGGL(k, grid, dim3(FUSED_BLOCK), lds, s, pair, S)

@@ -364,6 +364,45 @@ def test_two_stage_mlp_equals_two_launches(rows, w_src, w_before, w_after):
         assert torch.allclose(o2, want2, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("C,dt,rows,pair", [(16, "f32", 700, True), (16, "f16", 1000, True), (32, "f32", 257, False), (64, "f16", 384, True)])
+def test_register_resident_two_stage_mlp_equals_the_tile_kernel(C, dt, rows, pair, monkeypatch):
+    """mlp2_rr_kernel (set-upconv stage 2 + flow predictor on the register-resident chain, taken from ELO_MLP_RR_ROWS rows
+    on) gives mlp_kernel's outputs bit for bit -- both stages, fp32 and fp16 storage, ragged last tile, single and paired."""
+    fused, tf_util, lib = load_pkg("fused"), load_pkg("tf_util"), load_pkg("_lib")
+    if fused.fp32_mfma():
+        pytest.skip("the fp32-MFMA comparison build has no register-resident kernels")
+    rng = np.random.default_rng(C + rows)
+    store = tf_util.VariableStore(DEV, seed=rows)
+    tdt = torch.float16 if dt == "f16" else torch.float32
+    r = lambda *s: t(rng.normal(0, 1, s).astype(np.float32)).to(tdt)
+
+    def job(tag):
+        with tf_util.default_store(store), torch.no_grad(), tf_util.variable_scope("rr_two_stage_%s" % tag):
+            P = fused.packed_layer
+            layers = [P("a0", 64 + C, 128), P("a1", 128, 64)]
+            layers2 = [P("b0", C + 64 + 64, 128, row_order=fused.stage2_row_order(C, 64, 64)), P("b1", 128, 64)]
+            for p_ in layers + layers2:
+                p_.b.copy_(torch.from_numpy(rng.normal(0, 0.1, p_.b.shape).astype(np.float32)))
+        return dict(sources=[r(rows, 64), r(rows, C)], layers=layers, before=r(rows, C), after=r(rows, 64), layers2=layers2)
+    ja, jb = job("a"), job("b")
+
+    def run():
+        if pair:
+            (o1a, o2a), (o1b, o2b) = fused.mlp2_pair(ja, jb)
+            return [o1a, o2a, o1b, o2b]
+        a_, out, out2, _keep = fused._mlp2_args(**ja)
+        lib.call("elo_mlp_fused", a_, out)
+        return [out, out2]
+    monkeypatch.setenv("ELO_MLP_RR_ROWS", str(1 << 40))
+    tile = run()
+    monkeypatch.setenv("ELO_MLP_RR_ROWS", "0")
+    rr = run()
+    torch.cuda.synchronize()
+    for a_, b_ in zip(rr, tile):
+        assert a_.dtype == b_.dtype == tdt and torch.equal(a_, b_)
+    assert float(rr[1].float().abs().max()) > 0
+
+
 def test_dense_layers_keep_fp32_class_accuracy_across_magnitudes():
     """The fused 1x1 convolutions run as hi*hi + hi*lo + lo*hi of fp16-split operands on the fp16 matrix cores: the
     result must stay at fp32-class accuracy (not fp16's 1e-3) for inputs from 1e-6 (below fp16's normal range) to 1e3,
