@@ -2106,14 +2106,31 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
     {
         const float r2 = a.group.distance * a.group.distance;
         const int per_wave = 16 / K > 0 ? 16 / K : 1;                        // whole points in this wave's 16 rows (K = 8: 2, K = 16: 1)
-        for (int j = 0; j < per_wave; ++j) {
+        // the first window step of BOTH points is requested before either is judged: two round trips in flight, not in sequence
+        auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+        int pb[2], ph[2], pw[2];
+        float pc[2][3];
+        bool live[2];
+        RawSlot first[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
             const int pp = (wave * 16) / K + j;                              // (K divides 16 here: see the launcher)
             const long ptw = first_point + pp;
-            if (pp >= P || ptw >= total_points) continue;                    // (uniform)
-            const int b = (int)((unsigned)ptw / (unsigned)a.npoints);
-            auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-            const int hwc = __builtin_amdgcn_readfirstlane(chw[pp]), hc = hwc >> 16, wc = hwc & 0xffff;
-            const float cx = uniform(cxyz[pp * 3 + 0]), cy = uniform(cxyz[pp * 3 + 1]), cz = uniform(cxyz[pp * 3 + 2]);
+            live[j] = j < per_wave && pp < P && ptw < total_points;          // (uniform)
+            const int ppc = live[j] ? pp : 0;
+            pb[j] = (int)((unsigned)(live[j] ? ptw : first_point) / (unsigned)a.npoints);
+            const int hwc = __builtin_amdgcn_readfirstlane(chw[ppc]);
+            ph[j] = (hwc >> 16) / a.group.stride_h; pw[j] = (hwc & 0xffff) / a.group.stride_w;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) pc[j][e] = uniform(cxyz[ppc * 3 + e]);
+            first[j] = fetch_slot(grid_buffer(a.src_xyz + (size_t)pb[j] * a.H2 * a.W2 * 3), a.H2, a.W2, lds_off[lane < KT ? lane : 0], ph[j], pw[j],
+                                  lane < KT);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!live[j]) continue;
+            const int pp = (wave * 16) / K + j, b = pb[j];
+            const float cx = pc[j][0], cy = pc[j][1], cz = pc[j][2];
             auto emit = [&](int slot, int hw) {
                 cell_row[pp * K + slot] = (b * a.H2 + (hw >> 16)) * a.W2 + (hw & 0xffff);
                 mask_row[pp * K + slot] = 1.0f;
@@ -2121,7 +2138,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
             int count = 0;
             if (!(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS)) {          // valid centre (:62-70)
                 const GridBuf gb = grid_buffer(a.src_xyz + (size_t)b * a.H2 * a.W2 * 3);
-                count = wave_random_k(gb, a.H2, a.W2, KT, K, lds_off, hc / a.group.stride_h, wc / a.group.stride_w, cx, cy, cz, r2, emit);
+                count = wave_random_k_prefetched(gb, a.H2, a.W2, KT, K, lds_off, ph[j], pw[j], cx, cy, cz, r2, first[j], emit);
             }
             for (int k = count + lane; k < K; k += 64) { cell_row[pp * K + k] = 0; mask_row[pp * K + k] = 0.0f; }   // index (0,0,0), mask 0
         }

@@ -373,6 +373,37 @@ __device__ __forceinline__ int select_rounds_in_registers(const Grid &grid2, int
     return rounds;
 }
 
+// wave_random_k whose first window step (slots 0..63) was fetched by the caller (fetch_slot: a plain load, so that the first
+// steps of SEVERAL centres can be in flight together -- the walk of a centre is otherwise one L2 round trip per step, and
+// most centres are done after the first)
+template <class Grid, class Emit>
+__device__ __forceinline__ int wave_random_k_prefetched(const Grid &grid2, int H2, int W2, int KT, int K, const int *lds_off, int base_h,
+                                                        int base_w, float cx, float cy, float cz, float r2, const RawSlot &first, Emit emit)
+{
+    const int lane = threadIdx.x & 63;
+    int taken = 0;
+    {
+        const Probe p = judge(first, cx, cy, cz, r2);
+        const unsigned long long mh = __ballot(p.hit);
+        const int slot = __popcll(mh & ((1ull << lane) - 1ull));
+        if (p.hit && slot < K) emit(slot, p.hw);
+        taken = __popcll(mh);
+        if (taken >= K) return K;
+    }
+    for (int base = ELO_WAVE; base < KT; base += ELO_WAVE) {
+        const int i = base + lane;
+        Probe p{false, false, ELO_FAR, 0};
+        if (i < KT) p = probe_slot(grid2, H2, W2, lds_off[i], base_h, base_w, cx, cy, cz, r2);
+        const unsigned long long mh = __ballot(p.hit);
+        if (mh == 0) continue;
+        const int slot = taken + __popcll(mh & ((1ull << lane) - 1ull));
+        if (p.hit && slot < K) emit(slot, p.hw);
+        taken += __popcll(mh);
+        if (taken >= K) return K;
+    }
+    return taken;
+}
+
 // K nearest in-range neighbours, reference tie order (selection sort with swaps): register form (above) where
 // select_in_registers() says so, otherwise the LDS arrays dist/pay ([KT] wave-private each).  seen / taken: the numbers
 // of existing and of in-range window slots (the reference's valid_idx / valid_in_dis_idx prefix lengths) are ADDED to them.
