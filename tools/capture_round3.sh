@@ -3,7 +3,8 @@
 # -> gpurun_out/r03/: the driver's bench line, kernel stats at 8 lanes / 1 lane, the launch sequence of one forward,
 #    configs[2] (batch 8, fp16 features) trace + FETCH_SIZE / WRITE_SIZE passes, SQ counters of cost-volume stage 1 at batch 8
 #    (register-resident kernel from idx / mask, and the tile kernel with in-kernel grouping), PMC traffic of the timed
-#    kernel, the cost-volume variants table, the free-running parity statistic.
+#    kernel, the cost-volume variants table, the free-running parity statistic, the phase clock of the register-resident
+#    kernel (tools/rr_clock.sh) and the MFMA / VALU co-execution microbenchmark (tools/micro/coexec.hip).
 set -u
 REPO=$(pwd); OUT=$REPO/gpurun_out/r03; mkdir -p $OUT
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.log
@@ -19,5 +20,8 @@ ELO_PMC_SPECS="cv1:1 cv1:8 cv1_f16:8" bash tools/pmc_collect.sh $OUT/pmc > $OUT/
 bash tools/sq_counters.sh cv1 8 $OUT/sq_rr --pregrouped > $OUT/sq_cv1_rr_b8.txt 2>&1
 ELO_CV_PREPASS=0 bash tools/sq_counters.sh cv1 8 $OUT/sq_tile > $OUT/sq_cv1_tile_b8.txt 2>&1
 bash tools/c3_capture.sh $OUT/c3 > $OUT/c3.log 2>&1
+bash tools/rr_clock.sh 8 0 700 2>&1 | grep workgroup > $OUT/rr_clock_b8.txt
+ELO_RR_FLAGS=-DELO_RR_CLOCK_POOL bash tools/rr_clock.sh 8 700 2>&1 | grep workgroup >> $OUT/rr_clock_b8.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tools/micro/coexec.hip -o /tmp/coexec > /dev/null 2>&1 && /tmp/coexec > $OUT/coexec.txt 2>&1
 find $OUT -name "*.db" -delete; find $OUT -size +3M -delete
 ls $OUT
