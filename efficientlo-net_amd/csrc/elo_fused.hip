@@ -2064,6 +2064,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     unsigned bad = 0;
+    RR_STAMP(0);
     typedef RrStream<ScPlan<FPB, N1, N2, N3>> Stream;
     Stream ws{};
     ws.w[0] = a.layers[0].w_packed; ws.w[1] = a.layers[1].w_packed;
@@ -2103,6 +2104,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
         }
     }
     stage_offsets(lds_off, a.group.random_hw, a.group.kernel_h, a.group.kernel_w, a.group.decoded_hw);      // ends with __syncthreads()
+    RR_STAMP(1);
     {
         const float r2 = a.group.distance * a.group.distance;
         const int per_wave = 16 / K > 0 ? 16 / K : 1;                        // whole points in this wave's 16 rows (K = 8: 2, K = 16: 1)
@@ -2143,7 +2145,9 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
             for (int k = count + lane; k < K; k += 64) { cell_row[pp * K + k] = 0; mask_row[pp * K + k] = 0.0f; }   // index (0,0,0), mask 0
         }
     }
+    RR_STAMP(2);
     __syncthreads();
+    RR_STAMP(3);
     // ---- this lane's row: gather [features | xyz difference]
     const int r = wave * 16 + i16, pi = r / K;
     const int cell = cell_row[r];
@@ -2174,12 +2178,15 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
         dxyz = used ? pack_quad<MODE_SPLIT>(d, bad) : uint4{0u, 0u, 0u, 0u};
     }
     rr_bias_store(lds, tid, N1 + N2 + N3, bias_word);
+    RR_STAMP(4);
     rr_barrier();
+    RR_STAMP(5);
     const uint4 none{0u, 0u, 0u, 0u};
     ActPair h1[N1 / 32];
     rr_layer<FPB / 2, true, N1 / 16, 0>(in0, dxyz, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         put_quad(h1[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.layers[0].relu), bad));
     });
+    RR_STAMP(6);
     float4 last[NOUT / 16];
     if constexpr (N3 == 0) {
         rr_layer<N1 / 32, false, N2 / 16, E0>(h1, none, bt + B1, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
@@ -2194,8 +2201,10 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
             last[2 * pass + t] = relu4(acc, a.layers[2].relu);
         });
     }
+    RR_STAMP(7);
     if ((K == 8 || K == 16) && a.layers[N3 ? 2 : 1].relu) rr_pool_max_inwave<NOUT, F16>(last, mk, r, lane, K, first_point, total_points, a.out);
     else rr_pool_max<NOUT, F16>(lds, last, mk, r, wave, lane, K, P, first_point, total_points, a.out);
+    RR_STAMP(8);
     report_violations<MODE_SPLIT>(bad);
 }
 #endif   // !ELO_DENSE_F32
