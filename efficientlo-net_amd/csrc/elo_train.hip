@@ -13,8 +13,9 @@
 //   elo_bn_backward_apply   dz = gamma * invstd * (g - sum_g / M - xhat * sum_gx / M)
 //   elo_dense_weight_grad   dW = X^T dZ on v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulate), db = column sums of dZ
 // C must be a power of two in 4 .. 256 for the four batch-norm kernels (every batch-normalised width of the model).
-// No atomics anywhere: every reduction is per-block partials + a fixed-order combine, so a training step is
-// reproducible bit for bit (Trainer.save / load resumes exactly), and nothing serialises on one L2 address (the first
+// No atomics in THIS file: every reduction is per-block partials + a fixed-order combine, so these kernels give the same
+// bits on every run (a whole training step does not: the scatter adjoints of elo_backward.hip -- group_concat, cv_encode1/2,
+// warp_project -- add with float atomics in run-dependent order), and nothing serialises on one L2 address (the first
 // version added fp64 / fp32 atomics per block: 1800 blocks x 16 same-address atomics made bn_stats 46 us a call and the
 // weight gradient 154 us, no faster than the library kernels they replaced).
 #include <hip/hip_runtime.h>

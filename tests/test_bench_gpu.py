@@ -37,7 +37,7 @@ def test_bench_line_contract():
         assert key in r, key
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["mfma"]["peak"] == 2500.0 and 0 < r["mfma"]["frac"] < 1                          # the dtype ISSUED: fp16
-    for leg in ("cost_volume_b8_f32", "cost_volume_b8_f16", "per_operator_b8_f32", "per_operator_b64_f16"):
+    for leg in ("cost_volume_b8_f32", "cost_volume_b8_f16", "per_operator_b8_f32", "per_operator_b64_f16", "per_operator_all_levels_b8_f16"):
         assert r[leg]["bound"] == "hbm" and 0 < r[leg]["frac"] < 1, leg
     assert set(r["cost_volume_b8_f16"]["levels"]) == {"l0", "l1", "l2", "l2_origin"}
     c = d["cpu_baseline"]

@@ -623,7 +623,8 @@ def test_register_resident_cost_volume_stage2_equals_the_tile_kernel(kernel_path
                                   dict(B=3, H=8, W=113, sh=2, sw=2, K=8, mlp=[128, 64], win=(7, 15), d=6.0, feat="f16", pair=True),
                                   dict(B=2, H=4, W=57, sh=1, sw=2, K=8, mlp=[128, 64], win=(7, 15), d=9.0, feat="f32", pair=False),
                                   dict(B=4, H=4, W=57, sh=1, sw=2, K=16, mlp=[64, 64, 128], win=(5, 9), d=12.0, feat="f32", pair=False, down=True),   # sa1/layer3
-                                  dict(B=2, H=4, W=57, sh=1, sw=2, K=16, mlp=[128, 64, 64], win=(5, 9), d=12.0, feat="f16", pair=False, down=True)])  # new_layer3
+                                  dict(B=2, H=4, W=57, sh=1, sw=2, K=16, mlp=[128, 64, 64], win=(5, 9), d=12.0, feat="f16", pair=False, down=True),   # new_layer3
+                                  dict(B=2, H=8, W=113, sh=2, sw=2, K=32, mlp=[128, 64], win=(7, 15), d=20.0, feat="f32", pair=True)])   # K = 32: a point spans two waves, the pooling goes through LDS
 def test_register_resident_setconv_equals_the_tile_kernel(kernel_path, case, monkeypatch):
     """setconv_rr_kernel (in-kernel random-k by the wave that owns the rows, chain in registers, masked max through LDS)
     against setconv_kernel on the same call: bit for bit -- set-upconv shapes (every dense pixel a centre, strided sparse
