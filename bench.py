@@ -338,7 +338,7 @@ def cpu_baseline_leg(args, net):
     params = {k: v.detach().cpu().numpy() for k, v in net.store.state_dict().items()}
     f1, f2 = synth.frame_pair(1, args.height, args.width, seed=900)
     cores = os.cpu_count() or 1
-    per_worker = 3
+    per_worker = 2
     r = cpu_bench.run(params, f1, f2, args.cpu_pairs, per_worker, cores)
     return {"value": round(r["all_cores"], 3), "unit": "frame-pairs/s", "cores": cores, "cores_available": cores, "kind": "port",
             "one_core": round(r["one_core"], 4), "one_process_all_threads": round(r["one_process_all_threads"], 4),
@@ -347,7 +347,7 @@ def cpu_baseline_leg(args, net):
                       "(frame pairs are independent: the split the GPUs use); one_process_all_threads = SURVEY 8(d)'s literal "
                       "recipe, C grouping with a thread per core + threaded BLAS in ONE process, %d pairs in %.1f s"
                       % (args.height, args.width, args.cpu_pairs, r["seconds"][0], cores, per_worker, r["seconds"][1],
-                         args.cpu_pairs, r["seconds"][2])}
+                         r["pairs_threaded"], r["seconds"][2])}
 
 
 def batch_rate(dev, B, H, W, lanes, products, features, steps=240):

@@ -78,11 +78,13 @@ def run(params, f1, f2, pairs_one_core, pairs_per_worker, workers=None):
             a, b = pool.apply(worker, (path, pairs_one_core, 0.0))
         t_one = b - a
         with ctx.Pool(workers) as pool:
-            start_at = time.time() + 6.0 + 0.25 * workers              # interpreter start + the untimed warm-up forward
+            start_at = time.time() + 4.0 + 0.1 * workers               # interpreter start + the untimed warm-up forward (a late
+                                                                       # worker starts late: the span below still covers it)
             spans = pool.starmap(worker, [(path, pairs_per_worker, start_at)] * workers)
         t_all = max(e for _, e in spans) - min(s for s, _ in spans)
         with ctx.Pool(1) as pool:                                    # SURVEY 8(d)'s recipe: one process, threads inside the operators
-            a, b = pool.apply(worker, (path, pairs_one_core, 0.0, workers))
+            pairs_threaded = max(4, pairs_one_core // 4)
+            a, b = pool.apply(worker, (path, pairs_threaded, 0.0, workers))
         t_thr = b - a
     return {"one_core": pairs_one_core / t_one, "all_cores": workers * pairs_per_worker / t_all, "cores": workers,
-            "one_process_all_threads": pairs_one_core / t_thr, "seconds": (t_one, t_all, t_thr)}
+            "one_process_all_threads": pairs_threaded / t_thr, "seconds": (t_one, t_all, t_thr), "pairs_threaded": pairs_threaded}
