@@ -126,7 +126,8 @@ MlpArgs = _struct("elo_mlp_args", [
     ("layers", Dense * 3), ("out", _vp),
     ("n_layers2", _i), ("layers2", Dense * 3), ("before", _vp), ("w_before", _i), ("after", _vp), ("w_after", _i),
     ("out2", _vp), ("feat_dtype", _i),
-    ("clear_scratch", _vp), ("clear_xyz", _vp), ("clear_feat", _vp), ("clear_cells", _l), ("clear_C", _i), ("clear_images", _i)])
+    ("clear_scratch", _vp), ("clear_xyz", _vp), ("clear_feat", _vp), ("clear_cells", _l), ("clear_C", _i), ("clear_images", _i),
+    ("batch_hint", _i)])
 Cv1Args = _struct("elo_cv1_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("xyz2", _vp), ("feat2", _vp), ("idx", _vp), ("mask", _vp),
@@ -189,7 +190,7 @@ class EloError(RuntimeError):
     pass
 
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 def lib():

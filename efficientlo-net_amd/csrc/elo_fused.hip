@@ -2512,7 +2512,7 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
 #ifndef ELO_DENSE_F32
     {   // the register-resident form (setconv_rr_kernel) for the model's wide shapes, from ELO_SETCONV_RR_ROWS rows on
         const char *env_rows = getenv("ELO_SETCONV_RR_ROWS");          // (read per call: tests switch it)
-        const long min_rows = env_rows ? atol(env_rows) : 100000L;
+        const long min_rows = env_rows ? atol(env_rows) : a->batch >= ELO_THROUGHPUT_BATCH ? 20000L : 100000L;     // (regimes: elo_mlp_fused2)
         const int nl = a->n_layers, n1 = a->layers[0].N, n2 = a->layers[1].N, n3 = nl == 3 ? a->layers[2].N : 0;
         const int shape = (nl == 2 && n1 == 128 && n2 == 64) ? 1 : (nl == 3 && n1 == 64 && n2 == 64 && n3 == 128) ? 2
                         : (nl == 3 && n1 == 128 && n2 == 64 && n3 == 64) ? 3 : 0;
@@ -2627,7 +2627,9 @@ extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_
 #ifndef ELO_DENSE_F32
     {   // the register-resident form (mlp2_rr_kernel) for the model's two-stage shape, from ELO_MLP_RR_ROWS rows per launch on
         const char *env_rows = getenv("ELO_MLP_RR_ROWS");              // (read per call: tests switch it)
-        const long min_rows = env_rows ? atol(env_rows) : 8192L;          // batch 8: 23.1 k -> 23.9 k pairs/s (24.1 k with every level); at batch 1 (7200 rows at l0) the tile kernel is faster: 10.2 k vs 9.8 k
+        // two regimes (fused._prepass_rows): batch >= 4 keeps the GPU full -- 24.0 k -> 25.5 k pairs/s at batch 8 with the chain at
+        // every level; at batch 1 (7200 rows at l0) the tile kernel is faster: 10.2 k vs 9.8 k
+        const long min_rows = env_rows ? atol(env_rows) : a->batch_hint >= ELO_THROUGHPUT_BATCH ? 2048L : 8192L;
         const int C = a->n_sources == 2 ? a->src_width[1] : 0;
         const bool aligned = ((uintptr_t)a->src[0] | (uintptr_t)a->src[1] | (uintptr_t)a->before | (uintptr_t)a->after | (uintptr_t)a->out |
                               (uintptr_t)a->out2) % 16 == 0 &&

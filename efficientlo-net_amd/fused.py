@@ -293,13 +293,14 @@ def setconv_pair(job_a, job_b):
 
 def _mlp_args(sources, layers):
     L.require_gpu(*sources)
+    batch_hint = sources[0].shape[0] if sources[0].dim() >= 3 else 0      # (B, N, C) inputs: the launcher's regime switch
     srcs, dt, code = _features(*sources)
     srcs = [s.reshape(-1, s.shape[-1]) for s in srcs]
     rows = srcs[0].shape[0]
     out = torch.empty((rows, layers[-1].N), dtype=dt, device=srcs[0].device)
     a = L.MlpArgs()
     a.rows, a.n_sources, a.n_layers, a.layers, a.out = rows, len(srcs), len(layers), _chain(layers), out.data_ptr()
-    a.feat_dtype = code
+    a.feat_dtype, a.batch_hint = code, batch_hint
     for i, s in enumerate(srcs):
         a.src[i], a.src_width[i] = s.data_ptr(), s.shape[1]
     return a, out, (srcs, layers)
@@ -363,17 +364,24 @@ def mlp2_pair(job_a, job_b, clear=None):
     return (shape(out_a), shape(out2_a)), (shape(out_b), shape(out2_b))
 
 
-def _prepass_rows(stage=1):
+THROUGHPUT_BATCH = 4    # from this batch on a forward keeps the GPU busy by itself and the chain kernels win at every level
+
+
+def _prepass_rows(stage=1, batch=1):
     """Rows (centre points x K) per launch from which a cost-volume stage runs its grouping as a PRE-PASS (a stand-alone
     grouping launch writes idx / mask) and the REGISTER-RESIDENT kernel (cv1_rr_kernel / cv2_rr_kernel: one W stream per
     128 rows through an LDS ring, activations in registers) starts from them, instead of the tile kernel with in-kernel
-    grouping.  Measured (tools/cv1_variants.py, profiles/r03_cv1_variants.txt): stage 1 at l0, batch 8, 115 -> 87 us, l1
-    38 -> 30 us; stage 2 at l0 46 -> 39 us; below ~25 k rows (stage 2, a third of the work per row: ~64 k) the extra launch
-    costs more than the kernel saves, and at batch 1-2 the stage-1 tile kernel also carries the set-upconv riders of its
-    level.  ELO_CV_PREPASS: 0 = never, 1 = always, N = from N rows on (both stages)."""
+    grouping.  Two regimes, measured with 8 lanes and fp16 features (pairs/s, tile-kernel thresholds against chain-kernel
+    thresholds): batch 1 10 320 / 9 760 and batch 2 14 520 / 14 310 -- a forward is a latency chain, the tile kernels (with
+    the set-upconv riders of their level, and no extra launch) are faster, so only the largest launches take the chain
+    (stage 1 from 24 576 rows, stage 2 from 65 536); batch 4 19 520 / 21 330 and batch 8 24 040 / 25 450 -- the GPU is full, a
+    kernel costs its CU-time, and every level takes the chain (from 8192 rows; the same switch sits in elo_setconv_fused2 and
+    elo_mlp_fused2).  ELO_CV_PREPASS: 0 = never, 1 = always, N = from N rows on (both stages, any batch)."""
     import os
     e = os.environ.get("ELO_CV_PREPASS")
-    return (24576 if stage == 1 else 65536) if e is None else (1 << 60) if e == "0" else 0 if e == "1" else int(e)
+    if e is None:
+        return 8192 if batch >= THROUGHPUT_BATCH else (24576 if stage == 1 else 65536)
+    return (1 << 60) if e == "0" else 0 if e == "1" else int(e)
 
 
 _HW = {}
@@ -423,7 +431,7 @@ def group_prepass(kind, xyz1_grid, xyz2_grid, group, K):
 
 def _rr_path(group, B, N, K, C, stage=1):
     """True when a cost-volume stage with in-kernel grouping should take the pre-pass + register-resident kernel."""
-    return (group is not None and not group.want_indices and K <= 32 and B * N * K >= _prepass_rows(stage)
+    return (group is not None and not group.want_indices and K <= 32 and B * N * K >= _prepass_rows(stage, B)
             and group.stride_h == 1 and group.stride_w == 1 and _products == PRODUCTS_SPLIT and not fp32_mfma()
             and C in (16, 32, 64))
 

@@ -632,7 +632,12 @@ typedef struct elo_mlp_args {
     long clear_cells;             /* images*H*W of the projection */
     int clear_C;
     int clear_images;
+    /* Batch size the rows came from (rows = batch x points), 0 = unknown: from ELO_THROUGHPUT_BATCH on the launcher takes the
+     * register-resident kernel for every launch of 2048 rows or more (the GPU is full: a kernel costs its CU-time), below
+     * that only from 8192 rows (a forward is a latency chain there and the tile kernel is faster). */
+    int batch_hint;
 } elo_mlp_args;
+#define ELO_THROUGHPUT_BATCH 4
 int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream);
 int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_stream_t stream);   /* paired launch, as above */
 
