@@ -1407,7 +1407,7 @@ __device__ __forceinline__ void rr_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // one 8 KB ring slot of 8 chunks, chunk w = (step 2S + (w >> 2), column block (w >> 1) & 1, hi / lo half w & 1) carried
 // by wave w.  Every layer has an even number of steps, so a superstep never straddles two layers.  All arguments named
 // S / g are constants after unrolling: the layer look-ups fold.
-template <class PLAN>
+template <class PLAN, int MODE = MODE_SPLIT>
 struct RrStream {
     const float *w[PLAN::NL];                        // packed weights of the layers
     uint4 *ring;
@@ -1426,7 +1426,14 @@ struct RrStream {
 #pragma unroll
         for (int i = 1; i < PLAN::NL; ++i) l = g >= first(i) ? i : l;
         const int kp = PLAN::KP[l], tl = PLAN::TL[l], spp = kp + tl, KS = 2 * kp + tl;
-        constexpr int BB = WFrag<MODE_SPLIT>::BLOCK_BYTES;
+        constexpr int BB = WFrag<MODE>::BLOCK_BYTES;
+        constexpr int LO = MODE == MODE_HALF ? 0 : 1024;                  // the lo8 half of a pair chunk (MODE_HALF: there is none)
+        // MODE_HALF: the lo waves have nothing to carry, but they issue their partner's load all the same (LO = 0: the same
+        // kilobyte, an L1 hit) and only skip the LDS write.  With NO load on their path the kernel gave wrong rows in a few
+        // waves per launch (C = 16 at 16 x 225, every run; found by the bit-for-bit test against the tile kernel): the
+        // counted s_waitcnt vmcnt(N) the compiler places after the merge of the two wave-uniform paths was one short for the
+        // path with one load less (the mask of a row was consumed before it had arrived).  Equal load counts on every path
+        // make every count right.
         const int slA = g - first(l), slB = slA + 1;
         const int passA = slA / spp, kA = slA - passA * spp, passB = slB / spp, kB = slB - passB * spp;
         const bool tailA = kA >= kp, tailB = kB >= kp;
@@ -1434,12 +1441,17 @@ struct RrStream {
         const int offB = 2 * passB * KS * BB + (tailB ? (KS - 1) * BB : kB * 2 * BB);
         const int second = wave >> 2;                                     // (scalars)
         const bool is_tail = second ? tailB : tailA;
-        const int off = (second ? offB : offA) + ((wave >> 1) & 1) * KS * BB + ((wave & 1) && !is_tail ? 1024 : 0);
+        const int off = (second ? offB : offA) + ((wave >> 1) & 1) * KS * BB + ((wave & 1) && !is_tail ? LO : 0);
+        if (MODE == MODE_HALF && is_tail) {                                // a 16-k tail is 8 bytes per lane there
+            const uint2 v = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(weight_rsrc(w[l]), lane * 8u, off, 0));
+            st[S % RR_STAGE] = uint4{v.x, v.y, 0u, 0u};
+            return;
+        }
         st[S % RR_STAGE] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(weight_rsrc(w[l]), lane * 16u, off, 0));
     }
     __device__ __forceinline__ void commit(int S)                         // ... into chunk `wave` of slot S % RR_NSLOT
     {
-        if (2 * S >= total()) return;
+        if (2 * S >= total() || (MODE == MODE_HALF && (wave & 1))) return;
         ring[(S % RR_NSLOT) * RR_SLOT_U4 + wave * 64 + lane] = st[S % RR_STAGE];
     }
     __device__ __forceinline__ void fetch(int g, RrW &dst) const          // step g's operands: chunks (g % 2) * 4 + 2t (+ 1: lo)
@@ -1447,7 +1459,11 @@ struct RrStream {
         if (g >= total()) return;
         const uint4 *slot = ring + ((g / 2) % RR_NSLOT) * RR_SLOT_U4 + (g % 2) * 256 + lane;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { dst.w[t].hi = slot[t * 128]; dst.w[t].lo = slot[t * 128 + 64]; }
+        for (int t = 0; t < 2; ++t) {
+            dst.w[t].hi = slot[t * 128];
+            if constexpr (MODE != MODE_HALF) dst.w[t].lo = slot[t * 128 + 64];
+            else dst.w[t].lo = uint4{0u, 0u, 0u, 0u};
+        }
     }
     // end of superstep S: superstep S + 1 goes into the slot S - 1 used (every wave read it before the last barrier)
     __device__ __forceinline__ void advance(int S)
@@ -1474,7 +1490,7 @@ struct RrStream {
 // PER PASS -- a pass is 100-1000 cycles of work, the round trip ~700 under load: tools/rr_clock.sh showed ~500 + 250 k cycles
 // for a pass of k steps whatever the MFMA count, and a build without any MFMA ran as long.
 // emit(pass, t, acc): epilogue of column block 2*pass + t.
-template <int KP, bool TAIL, int NCB, int G0, class Fetch, class Advance, class Emit>
+template <int KP, bool TAIL, int NCB, int G0, int MODE = MODE_SPLIT, class Fetch, class Advance, class Emit>
 __device__ __forceinline__ void rr_layer(const ActPair (&in)[KP > 0 ? KP : 1], const uint4 &tail, const float *bias,
                                          const float *next_bias, float4 (&bias0)[2], Fetch fetch, Advance advance, Emit emit)
 // (L.bias / next_bias: this layer's and the next one's biases IN THE LDS TABLE, see rr_stage_biases)
@@ -1503,11 +1519,11 @@ __device__ __forceinline__ void rr_layer(const ActPair (&in)[KP > 0 ? KP : 1], c
             if (k < KP) {
                 const ActPair a1[1] = {in[k < KP ? k : 0]};
                 const WPair w2[2] = {cur.w[0], cur.w[1]};
-                mma_pair<MODE_SPLIT, 2, 1, 2>(acc, 0, a1, w2);
+                mma_pair<MODE, 2, 1, 2>(acc, 0, a1, w2);
             } else {
                 const uint4 a1[1] = {tail};
                 const uint4 w2[2] = {cur.w[0].hi, cur.w[1].hi};
-                mma_tail<MODE_SPLIT, 2, 1, 2>(acc, 0, a1, w2);
+                mma_tail<MODE, 2, 1, 2>(acc, 0, a1, w2);
             }
             if (g % 2 == 1) advance(g / 2);
         }
@@ -1683,7 +1699,7 @@ template <int FP> struct Cv1Plan {                 // CV_0 (FP pairs + geometry 
     static constexpr int KP[6] = {FP, 4, 2, 0, 4, 4}, TL[6] = {1, 0, 0, 1, 0, 0}, NCB[6] = {8, 4, 4, 4, 8, 4};
 };
 
-template <int C, bool F16>
+template <int C, bool F16, int MODE = MODE_SPLIT>
 __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_args a)
 {
     extern __shared__ __align__(16) float lds[];
@@ -1697,7 +1713,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
     unsigned bad = 0;
     RR_STAMP(0);
     // ---- the W stream.  Steps per layer: CV_0 4*(FP+1), CV_1 2*4, CV_2 2*2, CV_xyz 2*1, sum_CV_0 4*4, sum_CV_1 2*4
-    typedef RrStream<Cv1Plan<FP>> Stream;
+    typedef RrStream<Cv1Plan<FP>, MODE> Stream;
     Stream ws{{a.cv0.w_packed, a.cv1.w_packed, a.cv2.w_packed, a.cv_xyz.w_packed, a.sum_cv0.w_packed, a.sum_cv1.w_packed}, ring, wave, lane, {}};
     constexpr int E0 = Stream::first(1), E1 = Stream::first(2), E2 = Stream::first(3), E3 = Stream::first(4), E4 = Stream::first(5);
     auto fetch = [&](int g, RrW &dst) { ws.fetch(g, dst); };
@@ -1736,7 +1752,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
         auto quad = [&](const Item &v, bool keep) {
             const uint4 z{0u, 0u, 0u, 0u};
             if constexpr (F16) return keep ? quad_of_halves(v) : z;
-            else return keep ? pack_quad<MODE_SPLIT>(v, bad) : z;
+            else return keep ? pack_quad<MODE>(v, bad) : z;
         };
         // CV_0's k-blocks in order: feat1 blocks 0..FP-1, feat2 blocks 0..FP-1, geometry; block b sits in pair b / 2, half b % 2
 #pragma unroll
@@ -1748,7 +1764,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
         const float e = sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + 1e-20f);
         const float4 q4 = kq == 0 ? float4{pc0, pc1, pc2, g0} : kq == 1 ? float4{g1, g2, d0, d1}
                         : kq == 2 ? float4{d2, e, 0.0f, 0.0f} : float4{0.0f, 0.0f, 0.0f, 0.0f};
-        geo = used ? pack_quad<MODE_SPLIT>(q4, bad) : uint4{0u, 0u, 0u, 0u};
+        geo = used ? pack_quad<MODE>(q4, bad) : uint4{0u, 0u, 0u, 0u};
     }
     rr_bias_store(lds, (int)threadIdx.x, 512, bias_word);
     RR_STAMP(1);
@@ -1757,39 +1773,39 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
     // ---- the chain
     const uint4 none{0u, 0u, 0u, 0u};
     ActPair h128[4];                                 // CV_0's output (128 channels = 4 pairs)
-    rr_layer<FP, true, 8, 0>(in0, geo, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
-        put_quad(h128[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.cv0.relu), bad));
+    rr_layer<FP, true, 8, 0, MODE>(in0, geo, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h128[pass], t, pack_quad<MODE>(relu4(acc, a.cv0.relu), bad));
     });
     RR_LAYER_STAMP(3);
     ActPair h64[2];
-    rr_layer<4, false, 4, E0>(h128, none, bt + B1, bt + B2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
-        put_quad(h64[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.cv1.relu), bad));
+    rr_layer<4, false, 4, E0, MODE>(h128, none, bt + B1, bt + B2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h64[pass], t, pack_quad<MODE>(relu4(acc, a.cv1.relu), bad));
     });
     RR_LAYER_STAMP(4);
     ActPair xe[4];                                   // [x | enc]: sum_CV_0's input; x stays alive: it is the pooling's value
-    rr_layer<2, false, 4, E1>(h64, none, bt + B2, bt + B3, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
-        put_quad(xe[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.cv2.relu), bad));
+    rr_layer<2, false, 4, E1, MODE>(h64, none, bt + B2, bt + B3, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(xe[pass], t, pack_quad<MODE>(relu4(acc, a.cv2.relu), bad));
     });
     RR_LAYER_STAMP(5);
     {
         ActPair unused[1];
-        rr_layer<0, true, 4, E2>(unused, geo, bt + B3, bt + B4, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
-            put_quad(xe[2 + pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.cv_xyz.relu), bad));
+        rr_layer<0, true, 4, E2, MODE>(unused, geo, bt + B3, bt + B4, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+            put_quad(xe[2 + pass], t, pack_quad<MODE>(relu4(acc, a.cv_xyz.relu), bad));
         });
     }
     RR_LAYER_STAMP(6);
-    rr_layer<4, false, 8, E3>(xe, none, bt + B4, bt + B5, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
-        put_quad(h128[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.sum_cv0.relu), bad));
+    rr_layer<4, false, 8, E3, MODE>(xe, none, bt + B4, bt + B5, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h128[pass], t, pack_quad<MODE>(relu4(acc, a.sum_cv0.relu), bad));
     });
     RR_LAYER_STAMP(7);
     float4 logit[4];                                 // plain fp32, held until the ring is dead
-    rr_layer<4, false, 4, E4>(h128, none, bt + B5, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<4, false, 4, E4, MODE>(h128, none, bt + B5, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         logit[2 * pass + t] = relu4(acc, a.sum_cv1.relu);
     });
     RR_STAMP(8);
     rr_pool<F16>(lds, logit, xe[0], xe[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
     RR_STAMP(9);
-    report_violations<MODE_SPLIT>(bad);
+    report_violations<MODE>(bad);
 }
 // ---- cost volume, stage 2, register-resident (see cv1_rr_kernel): xyz-encoding (geometry tail -> 64), sum_cost_volume_0
 // ([grouped cost (64) | encoding (64) | feat1 (C)] -> 128), sum_cost_volume_1 (-> 64 logits), masked softmax over the K
@@ -1799,7 +1815,7 @@ template <int C> struct Cv2Plan {
     static constexpr int KP[3] = {0, 4 + C / 32, 4}, TL[3] = {1, C == 16 ? 1 : 0, 0}, NCB[3] = {4, 8, 4};
 };
 
-template <int C, bool F16>
+template <int C, bool F16, int MODE = MODE_SPLIT>
 __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_args a)
 {
     extern __shared__ __align__(16) float lds[];
@@ -1810,7 +1826,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     unsigned bad = 0;
-    typedef RrStream<Cv2Plan<C>> Stream;
+    typedef RrStream<Cv2Plan<C>, MODE> Stream;
     Stream ws{{a.xyz_enc.w_packed, a.sum_cost0.w_packed, a.sum_cost1.w_packed}, reinterpret_cast<uint4 *>(lds), wave, lane, {}};
     constexpr int E0 = Stream::first(1), E1 = Stream::first(2);
     auto fetch = [&](int g, RrW &dst) { ws.fetch(g, dst); };
@@ -1851,7 +1867,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
         auto quad = [&](const Item &v, bool keep) {
             const uint4 z{0u, 0u, 0u, 0u};
             if constexpr (F16) return keep ? quad_of_halves(v) : z;
-            else return keep ? pack_quad<MODE_SPLIT>(v, bad) : z;
+            else return keep ? pack_quad<MODE>(v, bad) : z;
         };
 #pragma unroll
         for (int j = 0; j < 4; ++j) put_quad(in1[j / 2], j % 2, quad(fc[j], keep2));           // cost[idx] * mask   :110
@@ -1865,28 +1881,28 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
         const float e = sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + 1e-20f);
         const float4 q4 = kq == 0 ? float4{pc0, pc1, pc2, g0} : kq == 1 ? float4{g1, g2, d0, d1}
                         : kq == 2 ? float4{d2, e, 0.0f, 0.0f} : float4{0.0f, 0.0f, 0.0f, 0.0f};
-        geo = used ? pack_quad<MODE_SPLIT>(q4, bad) : uint4{0u, 0u, 0u, 0u};
+        geo = used ? pack_quad<MODE>(q4, bad) : uint4{0u, 0u, 0u, 0u};
     }
     rr_bias_store(lds, (int)threadIdx.x, 256, bias_word);
     rr_barrier();
     const uint4 none{0u, 0u, 0u, 0u};
     {
         ActPair unused[1];
-        rr_layer<0, true, 4, 0>(unused, geo, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
-            put_quad(in1[2 + pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.xyz_enc.relu), bad));      // encoding: pairs 2, 3
+        rr_layer<0, true, 4, 0, MODE>(unused, geo, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+            put_quad(in1[2 + pass], t, pack_quad<MODE>(relu4(acc, a.xyz_enc.relu), bad));      // encoding: pairs 2, 3
         });
     }
     ActPair h128[4];
-    rr_layer<KP1, C == 16, 8, E0>(in1, ftail, bt + B1, bt + B2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
-        put_quad(h128[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.sum_cost0.relu), bad));
+    rr_layer<KP1, C == 16, 8, E0, MODE>(in1, ftail, bt + B1, bt + B2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h128[pass], t, pack_quad<MODE>(relu4(acc, a.sum_cost0.relu), bad));
     });
     float4 logit[4];
-    rr_layer<4, false, 4, E1>(h128, none, bt + B2, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<4, false, 4, E1, MODE>(h128, none, bt + B2, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         logit[2 * pass + t] = relu4(acc, a.sum_cost1.relu);
     });
     if (K == 4 && a.sum_cost1.relu) rr_pool_softmax4_inwave<F16>(logit, in1[0], in1[1], mk, r, lane, first_point, total_points, a.out);
     else rr_pool<F16>(lds, logit, in1[0], in1[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
-    report_violations<MODE_SPLIT>(bad);
+    report_violations<MODE>(bad);
 }
 // ---- two chained row-wise MLPs, register-resident (see cv1_rr_kernel): set-upconv stage 2 and the flow predictor it feeds
 // (mlp_kernel's two-stage form: utils/pointnet_util.py:303-311, :161-175) on the model's widths -- stage 1 [pooled (64) |
@@ -1898,7 +1914,7 @@ template <int C> struct Mlp2Plan {
     static constexpr int KP[4] = {B1 / 2, 4, B3 / 2, 4}, TL[4] = {B1 % 2, 0, B3 % 2, 0}, NCB[4] = {8, 4, 8, 4};
 };
 
-template <int C, bool F16>
+template <int C, bool F16, int MODE = MODE_SPLIT>
 __global__ __launch_bounds__(RR_WAVES * 64, 4) void mlp2_rr_kernel(const JobPair<elo_mlp_args> jobs)
 {
     extern __shared__ __align__(16) float lds[];
@@ -1915,7 +1931,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void mlp2_rr_kernel(const JobPair
     const int i16 = lane & 15, kq = lane >> 4;
     const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * RR_ROWS;
     unsigned bad = 0;
-    typedef RrStream<PL> Stream;
+    typedef RrStream<PL, MODE> Stream;
     Stream ws{{a.layers[0].w_packed, a.layers[1].w_packed, a.layers2[0].w_packed, a.layers2[1].w_packed}, reinterpret_cast<uint4 *>(lds), wave, lane, {}};
     constexpr int E0 = Stream::first(1), E1 = Stream::first(2), E2 = Stream::first(3);
     auto fetch = [&](int g, RrW &dst) { ws.fetch(g, dst); };
@@ -1936,7 +1952,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void mlp2_rr_kernel(const JobPair
     auto quad = [&](const Item &v) {
         const uint4 z{0u, 0u, 0u, 0u};
         if constexpr (F16) return used ? quad_of_halves(v) : z;
-        else return used ? pack_quad<MODE_SPLIT>(v, bad) : z;
+        else return used ? pack_quad<MODE>(v, bad) : z;
     };
     // block b of a concatenation goes to half b % 2 of pair b / 2, the last block of an odd count to the tail
     ActPair in1[KP1];
@@ -1961,8 +1977,8 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void mlp2_rr_kernel(const JobPair
     rr_barrier();
     const uint4 none{0u, 0u, 0u, 0u};
     ActPair h128[4];
-    rr_layer<KP1, T1, 8, 0>(in1, tail1, bt, bt + O1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
-        put_quad(h128[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.layers[0].relu), bad));
+    rr_layer<KP1, T1, 8, 0, MODE>(in1, tail1, bt, bt + O1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h128[pass], t, pack_quad<MODE>(relu4(acc, a.layers[0].relu), bad));
     });
     // the second stage's other inputs: requested now, a layer ahead of their first use
     Item sb[FP], sa[4];
@@ -1975,7 +1991,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void mlp2_rr_kernel(const JobPair
     }
     ActPair in3[KP3];
     uint4 tail3{0u, 0u, 0u, 0u};
-    rr_layer<4, false, 4, E0>(h128, none, bt + O1, bt + O2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<4, false, 4, E0, MODE>(h128, none, bt + O1, bt + O2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         const float4 v = relu4(acc, a.layers[1].relu);
         const long at = (first + r) * 64 + (2 * pass + t) * 16 + 4 * kq;
         if constexpr (F16) {
@@ -1985,7 +2001,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void mlp2_rr_kernel(const JobPair
             put_quad(in3[pass], t, quad_of_halves(stored));
         } else {
             if (used) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(a.out) + at) = v;
-            put_quad(in3[pass], t, pack_quad<MODE_SPLIT>(v, bad));
+            put_quad(in3[pass], t, pack_quad<MODE>(v, bad));
         }
     });
     // [out (blocks 0..3) | before (FP blocks) | after (4 blocks)]
@@ -1997,13 +2013,13 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void mlp2_rr_kernel(const JobPair
         if (T3 && j == 3) tail3 = quad(sa[j]);
         else put_quad(in3[(B0 + j) / 2], (B0 + j) % 2, quad(sa[j]));
     }
-    rr_layer<KP3, T3, 8, E1>(in3, tail3, bt + O2, bt + O3, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
-        put_quad(h128[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.layers2[0].relu), bad));
+    rr_layer<KP3, T3, 8, E1, MODE>(in3, tail3, bt + O2, bt + O3, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h128[pass], t, pack_quad<MODE>(relu4(acc, a.layers2[0].relu), bad));
     });
-    rr_layer<4, false, 4, E2>(h128, none, bt + O3, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<4, false, 4, E2, MODE>(h128, none, bt + O3, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         if (used) feat_store4(a.out2, (first + r) * 64 + (2 * pass + t) * 16 + 4 * kq, relu4(acc, a.layers2[1].relu), F16);
     });
-    report_violations<MODE_SPLIT>(bad);
+    report_violations<MODE>(bad);
 }
 // ---- set-conv / set-upconv stage 1, register-resident (see cv1_rr_kernel): in-kernel random-k grouping (a wave groups
 // the points its 16 rows belong to), gather [features (16 FPB) | xyz difference], two or three layers of compile-time
@@ -2052,7 +2068,7 @@ __device__ __forceinline__ void rr_pool_max(float *lds, const float4 (&last)[NOU
     }
 }
 
-template <int FPB, int N1, int N2, int N3, bool F16>
+template <int FPB, int N1, int N2, int N3, bool F16, int MODE = MODE_SPLIT>
 __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobPair<elo_setconv_args> jobs)
 {
     extern __shared__ __align__(16) float lds[];
@@ -2065,7 +2081,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     unsigned bad = 0;
     RR_STAMP(0);
-    typedef RrStream<ScPlan<FPB, N1, N2, N3>> Stream;
+    typedef RrStream<ScPlan<FPB, N1, N2, N3>, MODE> Stream;
     Stream ws{};
     ws.w[0] = a.layers[0].w_packed; ws.w[1] = a.layers[1].w_packed;
     if constexpr (N3 != 0) ws.w[2] = a.layers[2].w_packed;
@@ -2170,12 +2186,12 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
         auto quad = [&](const Item &v) {
             const uint4 zq{0u, 0u, 0u, 0u};
             if constexpr (F16) return keep ? quad_of_halves(v) : zq;
-            else return keep ? pack_quad<MODE_SPLIT>(v, bad) : zq;
+            else return keep ? pack_quad<MODE>(v, bad) : zq;
         };
 #pragma unroll
         for (int j = 0; j < FPB; ++j) put_quad(in0[j / 2], j % 2, quad(f[j]));
         const float4 d = kq == 0 ? float4{x * mk - c0, y * mk - c1, z * mk - c2, 0.0f} : float4{0.0f, 0.0f, 0.0f, 0.0f};
-        dxyz = used ? pack_quad<MODE_SPLIT>(d, bad) : uint4{0u, 0u, 0u, 0u};
+        dxyz = used ? pack_quad<MODE>(d, bad) : uint4{0u, 0u, 0u, 0u};
     }
     rr_bias_store(lds, tid, N1 + N2 + N3, bias_word);
     RR_STAMP(4);
@@ -2183,21 +2199,21 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
     RR_STAMP(5);
     const uint4 none{0u, 0u, 0u, 0u};
     ActPair h1[N1 / 32];
-    rr_layer<FPB / 2, true, N1 / 16, 0>(in0, dxyz, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
-        put_quad(h1[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.layers[0].relu), bad));
+    rr_layer<FPB / 2, true, N1 / 16, 0, MODE>(in0, dxyz, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        put_quad(h1[pass], t, pack_quad<MODE>(relu4(acc, a.layers[0].relu), bad));
     });
     RR_STAMP(6);
     float4 last[NOUT / 16];
     if constexpr (N3 == 0) {
-        rr_layer<N1 / 32, false, N2 / 16, E0>(h1, none, bt + B1, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        rr_layer<N1 / 32, false, N2 / 16, E0, MODE>(h1, none, bt + B1, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
             last[2 * pass + t] = relu4(acc, a.layers[1].relu);
         });
     } else {
         ActPair h2[N2 / 32];
-        rr_layer<N1 / 32, false, N2 / 16, E0>(h1, none, bt + B1, bt + B2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
-            put_quad(h2[pass], t, pack_quad<MODE_SPLIT>(relu4(acc, a.layers[1].relu), bad));
+        rr_layer<N1 / 32, false, N2 / 16, E0, MODE>(h1, none, bt + B1, bt + B2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+            put_quad(h2[pass], t, pack_quad<MODE>(relu4(acc, a.layers[1].relu), bad));
         });
-        rr_layer<N2 / 32, false, NOUT / 16, E1>(h2, none, bt + B2, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+        rr_layer<N2 / 32, false, NOUT / 16, E1, MODE>(h2, none, bt + B2, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
             last[2 * pass + t] = relu4(acc, a.layers[2].relu);
         });
     }
@@ -2205,7 +2221,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
     if ((K == 8 || K == 16) && a.layers[N3 ? 2 : 1].relu) rr_pool_max_inwave<NOUT, F16>(last, mk, r, lane, K, first_point, total_points, a.out);
     else rr_pool_max<NOUT, F16>(lds, last, mk, r, wave, lane, K, P, first_point, total_points, a.out);
     RR_STAMP(8);
-    report_violations<MODE_SPLIT>(bad);
+    report_violations<MODE>(bad);
 }
 #endif   // !ELO_DENSE_F32
 
@@ -2517,15 +2533,17 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
         const int shape = (nl == 2 && n1 == 128 && n2 == 64) ? 1 : (nl == 3 && n1 == 64 && n2 == 64 && n3 == 128) ? 2
                         : (nl == 3 && n1 == 128 && n2 == 64 && n3 == 64) ? 3 : 0;
         const int KT = a->group.kernel_h * a->group.kernel_w;
-        if (shape && a->group.random_hw && plan.mode == MODE_SPLIT && cv1_rr_on() && a->C == 64 && (a->K == 8 || a->K == 16 || a->K == 32) &&
+        if (shape && a->group.random_hw && (plan.mode == MODE_SPLIT || plan.mode == MODE_HALF) && cv1_rr_on() && a->C == 64 && (a->K == 8 || a->K == 16 || a->K == 32) &&
             KT <= 512 && !a->group.idx_out && !a->group.mask_out && points * a->K * (b ? 2 : 1) >= min_rows) {
             const int P = RR_ROWS / a->K;
             const dim3 rgrid((unsigned)((points + P - 1) / P), b ? 2u : 1u);
             const bool f16 = a->feat_dtype == ELO_F16;
 #define RRS(N1_, N2_, N3_)                                                                                                              \
             do {                                                                                                                        \
-                if (f16) hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, true>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);  \
-                else hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, false>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);     \
+                if (f16 && plan.mode == MODE_HALF) hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, true, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);  \
+                else if (f16) hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, true, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);  \
+                else if (plan.mode == MODE_HALF) hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, false, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);     \
+                else hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, false, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);     \
             } while (0)
             if (shape == 1) RRS(128, 64, 0);
             else if (shape == 2) RRS(64, 64, 128);
@@ -2635,7 +2653,7 @@ extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_
                               (uintptr_t)a->out2) % 16 == 0 &&
                              (!b || ((uintptr_t)b->src[0] | (uintptr_t)b->src[1] | (uintptr_t)b->before | (uintptr_t)b->after | (uintptr_t)b->out |
                                      (uintptr_t)b->out2) % 16 == 0);
-        if (mode == MODE_SPLIT && cv1_rr_on() && a->n_sources == 2 && a->src_width[0] == 64 && (C == 16 || C == 32 || C == 64) &&
+        if ((mode == MODE_SPLIT || mode == MODE_HALF) && cv1_rr_on() && a->n_sources == 2 && a->src_width[0] == 64 && (C == 16 || C == 32 || C == 64) &&
             a->n_layers == 2 && a->layers[0].N == 128 && a->layers[1].N == 64 && a->n_layers2 == 2 && a->layers2[0].N == 128 &&
             a->layers2[1].N == 64 && a->w_before == C && a->w_after == 64 && aligned && a->rows * (b ? 2 : 1) >= min_rows) {
             const dim3 rgrid((unsigned)((a->rows + RR_ROWS - 1) / RR_ROWS), b ? 2u : 1u);
@@ -2643,8 +2661,10 @@ extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_
             hipStream_t rs = (hipStream_t)stream;
 #define RRM(C_)                                                                                                                      \
             do {                                                                                                                    \
-                if (f16) hipLaunchKernelGGL((mlp2_rr_kernel<C_, true>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);             \
-                else hipLaunchKernelGGL((mlp2_rr_kernel<C_, false>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);                \
+                if (f16 && mode == MODE_HALF) hipLaunchKernelGGL((mlp2_rr_kernel<C_, true, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);             \
+                else if (f16) hipLaunchKernelGGL((mlp2_rr_kernel<C_, true, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);             \
+                else if (mode == MODE_HALF) hipLaunchKernelGGL((mlp2_rr_kernel<C_, false, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);                \
+                else hipLaunchKernelGGL((mlp2_rr_kernel<C_, false, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);                \
             } while (0)
             if (C == 16) RRM(16);
             else if (C == 32) RRM(32);
@@ -2715,7 +2735,7 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
     if (int rc = plan_cv1(a, &plan, who)) return rc;
     if ((long)a->batch * a->npoints == 0) return ELO_OK;
 #ifndef ELO_DENSE_F32
-    if (!a->group.random_hw && plan.mode == MODE_SPLIT && cv1_rr_on() && (a->C == 16 || a->C == 32 || a->C == 64)) {
+    if (!a->group.random_hw && (plan.mode == MODE_SPLIT || plan.mode == MODE_HALF) && cv1_rr_on() && (a->C == 16 || a->C == 32 || a->C == 64)) {
         const int P = RR_ROWS / a->K;                              // points per workgroup (128 rows)
         const dim3 grid((unsigned)(((long)a->batch * a->npoints + P - 1) / P));
         const size_t lds = RR_LDS_BYTES;
@@ -2724,8 +2744,10 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
         static_assert(RR_LDS_BYTES <= 64 * 1024, "dynamic LDS within the default limit");
 #define RR(CC)                                                                                                      \
         do {                                                                                                        \
-            if (f16) hipLaunchKernelGGL((cv1_rr_kernel<CC, true>), grid, dim3(RR_WAVES * 64), lds, s, *a);          \
-            else hipLaunchKernelGGL((cv1_rr_kernel<CC, false>), grid, dim3(RR_WAVES * 64), lds, s, *a);             \
+            if (f16 && plan.mode == MODE_HALF) hipLaunchKernelGGL((cv1_rr_kernel<CC, true, MODE_HALF>), grid, dim3(RR_WAVES * 64), lds, s, *a);          \
+            else if (f16) hipLaunchKernelGGL((cv1_rr_kernel<CC, true, MODE_SPLIT>), grid, dim3(RR_WAVES * 64), lds, s, *a);          \
+            else if (plan.mode == MODE_HALF) hipLaunchKernelGGL((cv1_rr_kernel<CC, false, MODE_HALF>), grid, dim3(RR_WAVES * 64), lds, s, *a);             \
+            else hipLaunchKernelGGL((cv1_rr_kernel<CC, false, MODE_SPLIT>), grid, dim3(RR_WAVES * 64), lds, s, *a);             \
         } while (0)
         if (a->C == 16) RR(16);
         else if (a->C == 32) RR(32);
@@ -2818,14 +2840,16 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
     if (int rc = check_group(a->group, a->H, a->W, lds, who)) return rc;
     hipStream_t s = (hipStream_t)stream;
 #ifndef ELO_DENSE_F32
-    if (!a->group.random_hw && mode == MODE_SPLIT && cv1_rr_on() && (a->C == 16 || a->C == 32 || a->C == 64)) {
+    if (!a->group.random_hw && (mode == MODE_SPLIT || mode == MODE_HALF) && cv1_rr_on() && (a->C == 16 || a->C == 32 || a->C == 64)) {
         const int P = RR_ROWS / a->K;                              // points per workgroup (128 rows)
         const dim3 rgrid((unsigned)((points + P - 1) / P));
         const bool f16 = a->feat_dtype == ELO_F16;
 #define RR(CC)                                                                                                           \
         do {                                                                                                             \
-            if (f16) hipLaunchKernelGGL((cv2_rr_kernel<CC, true>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);     \
-            else hipLaunchKernelGGL((cv2_rr_kernel<CC, false>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);        \
+            if (f16 && mode == MODE_HALF) hipLaunchKernelGGL((cv2_rr_kernel<CC, true, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);     \
+            else if (f16) hipLaunchKernelGGL((cv2_rr_kernel<CC, true, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);     \
+            else if (mode == MODE_HALF) hipLaunchKernelGGL((cv2_rr_kernel<CC, false, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);        \
+            else hipLaunchKernelGGL((cv2_rr_kernel<CC, false, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);        \
         } while (0)
         if (a->C == 16) RR(16);
         else if (a->C == 32) RR(32);

@@ -432,7 +432,7 @@ def group_prepass(kind, xyz1_grid, xyz2_grid, group, K):
 def _rr_path(group, B, N, K, C, stage=1):
     """True when a cost-volume stage with in-kernel grouping should take the pre-pass + register-resident kernel."""
     return (group is not None and not group.want_indices and K <= 32 and B * N * K >= _prepass_rows(stage, B)
-            and group.stride_h == 1 and group.stride_w == 1 and _products == PRODUCTS_SPLIT and not fp32_mfma()
+            and group.stride_h == 1 and group.stride_w == 1 and not fp32_mfma()
             and C in (16, 32, 64))
 
 

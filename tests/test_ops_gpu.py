@@ -364,8 +364,19 @@ def test_two_stage_mlp_equals_two_launches(rows, w_src, w_before, w_after):
         assert torch.allclose(o2, want2, rtol=1e-5, atol=1e-5)
 
 
+@pytest.fixture(params=["split", "half"])
+def chain_products(request):
+    """The register-resident kernels exist for both products modes (fp32-class hi / lo split, and ONE fp16 product per
+    block: `fused.products("half")`): the tests below run under each."""
+    fused = load_pkg("fused")
+    if fused.fp32_mfma():
+        pytest.skip("the fp32-MFMA comparison build has no register-resident kernels")
+    with fused.products(request.param):
+        yield request.param
+
+
 @pytest.mark.parametrize("C,dt,rows,pair", [(16, "f32", 700, True), (16, "f16", 1000, True), (32, "f32", 257, False), (64, "f16", 384, True)])
-def test_register_resident_two_stage_mlp_equals_the_tile_kernel(C, dt, rows, pair, monkeypatch):
+def test_register_resident_two_stage_mlp_equals_the_tile_kernel(C, dt, rows, pair, monkeypatch, chain_products):
     """mlp2_rr_kernel (set-upconv stage 2 + flow predictor on the register-resident chain, taken from ELO_MLP_RR_ROWS rows
     on) gives mlp_kernel's outputs bit for bit -- both stages, fp32 and fp16 storage, ragged last tile, single and paired."""
     fused, tf_util, lib = load_pkg("fused"), load_pkg("tf_util"), load_pkg("_lib")
@@ -536,7 +547,7 @@ def test_heterogeneous_launch_equals_separate_launches(B, two):
 
 @pytest.mark.parametrize("B,H,W,C,win,features", [(2, 16, 225, 16, (11, 41), "f32"), (1, 8, 113, 32, (7, 25), "f32"), (3, 4, 57, 64, (5, 15), "f32"),
                                                   (2, 16, 225, 16, (11, 41), "f16"), (1, 4, 57, 64, (5, 15), "f16"), (1, 5, 33, 16, (3, 9), "f32")])
-def test_register_resident_cost_volume_equals_the_tile_kernel(kernel_path, B, H, W, C, win, features):
+def test_register_resident_cost_volume_equals_the_tile_kernel(kernel_path, B, H, W, C, win, features, chain_products):
     """cv1_rr_kernel (a wave owns 32 rows and all columns; the chain stays in registers) against the tile kernel
     (cv1_tile: four waves share the rows, activations in LDS) from the same idx / mask: the same products in the same
     order, so the outputs are equal BIT FOR BIT (fp32 and fp16 feature storage, C = 16 / 32 / 64, ragged last tiles, a
@@ -579,7 +590,7 @@ def test_register_resident_cost_volume_equals_the_tile_kernel(kernel_path, B, H,
 
 @pytest.mark.parametrize("B,H,W,C,features", [(2, 16, 225, 16, "f32"), (1, 8, 113, 32, "f32"), (3, 4, 57, 64, "f32"), (2, 16, 225, 16, "f16"),
                                               (1, 4, 57, 64, "f16"), (1, 5, 33, 32, "f16")])
-def test_register_resident_cost_volume_stage2_equals_the_tile_kernel(kernel_path, B, H, W, C, features):
+def test_register_resident_cost_volume_stage2_equals_the_tile_kernel(kernel_path, B, H, W, C, features, chain_products):
     """cv2_rr_kernel against cv2_kernel from the same idx / mask (random-k 3x5, K = 4 of the warped cloud on itself), and
     against the launch that groups in-kernel: bit for bit, fp32 and fp16 storage, C = 16 (feat1 is a 16-k tail block) /
     32 / 64."""
@@ -625,7 +636,7 @@ def test_register_resident_cost_volume_stage2_equals_the_tile_kernel(kernel_path
                                   dict(B=4, H=4, W=57, sh=1, sw=2, K=16, mlp=[64, 64, 128], win=(5, 9), d=12.0, feat="f32", pair=False, down=True),   # sa1/layer3
                                   dict(B=2, H=4, W=57, sh=1, sw=2, K=16, mlp=[128, 64, 64], win=(5, 9), d=12.0, feat="f16", pair=False, down=True),   # new_layer3
                                   dict(B=2, H=8, W=113, sh=2, sw=2, K=32, mlp=[128, 64], win=(7, 15), d=20.0, feat="f32", pair=True)])   # K = 32: a point spans two waves, the pooling goes through LDS
-def test_register_resident_setconv_equals_the_tile_kernel(kernel_path, case, monkeypatch):
+def test_register_resident_setconv_equals_the_tile_kernel(kernel_path, case, monkeypatch, chain_products):
     """setconv_rr_kernel (in-kernel random-k by the wave that owns the rows, chain in registers, masked max through LDS)
     against setconv_kernel on the same call: bit for bit -- set-upconv shapes (every dense pixel a centre, strided sparse
     grid, K = 8, single and paired launches) and the two wide down_conv shapes (strided centre list, K = 16), fp32 and
