@@ -1429,11 +1429,9 @@ struct RrStream {
         constexpr int BB = WFrag<MODE>::BLOCK_BYTES;
         constexpr int LO = MODE == MODE_HALF ? 0 : 1024;                  // the lo8 half of a pair chunk (MODE_HALF: there is none)
         // MODE_HALF: the lo waves have nothing to carry, but they issue their partner's load all the same (LO = 0: the same
-        // kilobyte, an L1 hit) and only skip the LDS write.  With NO load on their path the kernel gave wrong rows in a few
-        // waves per launch (C = 16 at 16 x 225, every run; found by the bit-for-bit test against the tile kernel): the
-        // counted s_waitcnt vmcnt(N) the compiler places after the merge of the two wave-uniform paths was one short for the
-        // path with one load less (the mask of a row was consumed before it had arrived).  Equal load counts on every path
-        // make every count right.
+        // kilobyte, an L1 hit) and only skip the LDS write.  With NO load on their path the kernel gave wrong rows in one or two
+        // waves of a few workgroups per launch (C = 16 at 16 x 225, every run; found by the bit-for-bit test against the tile
+        // kernel).  Cause not identified (finding 4): every wave issues the same loads in both modes.
         const int slA = g - first(l), slB = slA + 1;
         const int passA = slA / spp, kA = slA - passA * spp, passB = slB / spp, kB = slB - passB * spp;
         const bool tailA = kA >= kp, tailB = kB >= kp;

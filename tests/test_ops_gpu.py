@@ -1,6 +1,8 @@
 """GPU parity of the operator library (set-conv, cost volume, set-upconv, flow predictor,
 softmax_valid, quaternion warp + re-projection) against the numpy restatement in oracle/ops_np.py.
 Tolerance (north_star): 1e-4 for fp32 features; neighbour indices are compared bit-exact elsewhere."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -412,6 +414,22 @@ def test_register_resident_two_stage_mlp_equals_the_tile_kernel(C, dt, rows, pai
     for a_, b_ in zip(rr, tile):
         assert a_.dtype == b_.dtype == tdt and torch.equal(a_, b_)
     assert float(rr[1].float().abs().max()) > 0
+
+
+def test_register_resident_kernels_are_stable_under_repetition(kernel_path):
+    """tools/rr_stress.py: cost-volume stage 1 on the chain kernel, repeated on shapes with more workgroups than CUs, in both
+    products modes: every run equals the tile kernel bit for bit (a race between the waves of a workgroup shows up as a
+    run that differs: DESIGN.md section 3b, finding 4)."""
+    if kernel_path != "fused":
+        pytest.skip("fused kernels only")
+    if load_pkg("fused").fp32_mfma():
+        pytest.skip("the fp32-MFMA comparison build has no register-resident kernels")
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rr_stress.py"), "12"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if "runs differing" in l]
+    assert len(lines) == 8 and all(": 0 of 12" in l for l in lines), out.stdout
 
 
 def test_dense_layers_keep_fp32_class_accuracy_across_magnitudes():
