@@ -218,6 +218,34 @@ def test_half_products_forward(kernel_path):
     assert (ref[0] - out[0]).abs().max() < 0.2                               # l0 q: same motion, fp16-class + regrouping
 
 
+@pytest.mark.parametrize("products,features", [("split", "f32"), ("split", "f16"), ("half", "f16")])
+def test_chain_kernels_leave_a_batch8_forward_unchanged(kernel_path, products, features):
+    """From batch 4 on every level of a forward runs on the register-resident chain kernels (cost-volume stages 1 and 2,
+    set-conv / set-upconv stage 1, set-upconv stage 2 + flow predictor).  Each equals its tile kernel bit for bit, so the WHOLE
+    forward must: all eight pose outputs of a batch-8 forward with the chain kernels switched off (elo_debug_cv1_rr(0): the
+    same launches fall back to the tile kernels) are identical -- in both products modes and both storage types."""
+    if kernel_path != "fused":
+        pytest.skip("fused kernels only")
+    synth, fused, model, perm, lib = load_pkg("synth"), load_pkg("fused"), load_pkg("model"), load_pkg("perm"), load_pkg("_lib")
+    if fused.fp32_mfma():
+        pytest.skip("the fp32-MFMA comparison build has no register-resident kernels")
+    f1, f2 = synth.frame_pair(8, 64, 1800, seed=43)
+    a, b = torch.from_numpy(f1).to(DEV), torch.from_numpy(f2).to(DEV)
+    dt = torch.float16 if features == "f16" else torch.float32
+    with fused.products(products):
+        net = model.PWCLONet(DEV, seed=5, perm_source=perm.PermSource(fn=shuffle_fn), feature_dtype=dt)
+        with fused.recording() as rec:
+            chain = [x.clone() for x in net.forward(a, b)[:8]]
+        try:
+            lib.lib().elo_debug_cv1_rr(0)
+            tile = [x.clone() for x in net.forward(a, b)[:8]]
+        finally:
+            lib.lib().elo_debug_cv1_rr(-1)
+    assert all(torch.isfinite(x).all() for x in chain)
+    assert all(torch.equal(x, y) for x, y in zip(chain, tile))
+    assert len(rec) == 8                                                      # (four cost volumes x two stages went through)
+
+
 def test_graph_from_raw_clouds_equals_forward_points(kernel_path):
     """capture(num_points=N): the input stage (crop + both projections) is recorded in front of the pyramid; a replay
     fed with raw clouds gives what the eager get_model gives for the same clouds (identity augmentation)."""
