@@ -179,6 +179,8 @@ SYMBOLS = [
     ("elo_mlp_fused2", ctypes.c_int, [ctypes.POINTER(MlpArgs), ctypes.POINTER(MlpArgs), _vp]),
     ("elo_cv_stage1_fused", ctypes.c_int, [ctypes.POINTER(Cv1Args), _vp]),
     ("elo_debug_cv1_rr", ctypes.c_int, [ctypes.c_int]),
+    ("elo_debug_rr_rows", ctypes.c_int, [ctypes.c_long, ctypes.c_long]),
+    ("elo_debug_rr_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_cv_stage2_fused", ctypes.c_int, [ctypes.POINTER(Cv2Args), _vp]),
     ("elo_cv_stage1_setconv_fused", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
 ]
@@ -190,7 +192,7 @@ class EloError(RuntimeError):
     pass
 
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 def lib():

@@ -22,6 +22,7 @@
 // Interfaces and the reference lines covered: include/elo.h ("Fused inference kernels").
 #include "elo_group_device.h"
 #include "elo_project_device.h"
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -335,9 +336,40 @@ __device__ __forceinline__ void mma_pair(f32x4 (&acc)[RB][TPW], int c0, const Ac
 #endif
 }
 
-template <int MODE, int MT, int RB, int TPW>
+// ---- gfx950: a 16x16x16 MFMA must not read a 16x16x32 MFMA's result as SrcC within 5 wait states -----------------
+// Measured (tools/micro/mfma_srcc_hazard.hip, profiles/r04_mfma_srcc_hazard.txt): v_mfma_f32_16x16x16_f16 issued 0-4 wait
+// states after a v_mfma_f32_16x16x32_f16 whose vDst is its SrcC reads the accumulator as it was BEFORE that instruction's
+// update, in every lane; from 5 wait states on it is right.  Two MFMAs of the same shape, or 16x16x16 followed by
+// 16x16x32, are interlocked by the hardware.  hipcc (ROCm 7.2, clang 22) treats "SrcC is exactly the previous MFMA's
+// vDst" as needing no wait state whatever the two shapes are, so the 16-k tail step of a layer, which continues the
+// accumulators of its pair steps, was right only while the scheduler happened to leave other instructions in between --
+// the chain kernels' "waves without a W load give wrong rows" (finding 4) was this pair, two wait
+// states apart, behind an s_waitcnt that usually stalled long enough.  The guard: ONE asm statement that takes every
+// accumulator of the tail step in and out -- the pair MFMAs that write them are ordered before it and the tail MFMAs
+// that read them after it by data dependence, whatever the scheduler does -- and holds six wait states (LLVM's figure for
+// the not-forwardable case on gfx950: passes + 2).  tools/isa_mfma_hazard.py checks the built library for any such pair.
+#ifndef ELO_DENSE_F32
+template <int RB, int TPW, int MT>
+__device__ __forceinline__ void mfma_shape_guard(f32x4 (&acc)[RB][TPW], int c0)
+{
+#ifndef ELO_NO_MFMA_SHAPE_GUARD                     // (tools/rr_bisect.sh builds the unguarded form to show the failure)
+    static_assert(RB * MT == 1 || RB * MT == 2 || RB * MT == 4, "accumulators of one tail step");
+    if constexpr (RB * MT == 1) asm volatile("s_nop 5" : "+v"(acc[0][c0]));
+    else if constexpr (RB == 1 && MT == 2) asm volatile("s_nop 5" : "+v"(acc[0][c0]), "+v"(acc[0][c0 + 1]));
+    else if constexpr (RB == 2 && MT == 1) asm volatile("s_nop 5" : "+v"(acc[0][c0]), "+v"(acc[1][c0]));
+    else if constexpr (RB == 1 && MT == 4) asm volatile("s_nop 5" : "+v"(acc[0][c0]), "+v"(acc[0][c0 + 1]), "+v"(acc[0][c0 + 2]), "+v"(acc[0][c0 + 3]));
+    else asm volatile("s_nop 5" : "+v"(acc[0][c0]), "+v"(acc[0][c0 + 1]), "+v"(acc[1][c0]), "+v"(acc[1][c0 + 1]));
+#endif
+}
+#endif
+
+// AFTER_PAIR: the accumulators were last written by mma_pair (false: by the bias initialisation only)
+template <int MODE, int MT, int RB, int TPW, bool AFTER_PAIR = true>
 __device__ __forceinline__ void mma_tail(f32x4 (&acc)[RB][TPW], int c0, const uint4 (&a)[RB], const uint4 (&w)[MT])
 {
+#ifndef ELO_DENSE_F32
+    if constexpr (AFTER_PAIR) mfma_shape_guard<RB, TPW, MT>(acc, c0);
+#endif
 #ifdef ELO_DENSE_F32
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1400,7 +1432,18 @@ struct RrW { WPair w[2]; };                        // one k-step of two column b
 
 // workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. the W loads
 // that are meant to stay in flight across it
+#if defined(ELO_RR_BARRIER) && ELO_RR_BARRIER == 1        // bisect builds (tools/rr_bisect.sh): the full barrier ...
+__device__ __forceinline__ void rr_barrier() { __syncthreads(); }
+#elif defined(ELO_RR_BARRIER) && ELO_RR_BARRIER == 2      // ... or the compiler's own workgroup fences around the barrier builtin
+__device__ __forceinline__ void rr_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#else
 __device__ __forceinline__ void rr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // The W stream of a register-resident chain.  PLAN: NL layers with KP[l] k-pairs (+ TL[l]: a 16-k tail) and NCB[l]
 // column blocks; steps run layer by layer, pass by pass (two column blocks), k-step by k-step; two steps = a superstep =
@@ -1421,6 +1464,14 @@ struct RrStream {
     __device__ __forceinline__ void issue(int S)                          // request this wave's chunk of superstep S
     {
         if (2 * S >= total()) return;
+#ifndef ELO_RR_EQUAL_LOADS
+        // MODE_HALF: a pair chunk has no lo half, the odd waves have nothing to stage and issue no load.  (Round 3 shipped
+        // them fetching their partner's kilobyte and dropping it, because without a load on their path "one or two waves of a
+        // few workgroups gave wrong rows".  The loads were never the cause: that build's schedule put a 16-k tail MFMA two
+        // wait states behind the pair MFMA whose accumulator it continues -- mfma_shape_guard, above mma_tail.
+        // -DELO_RR_EQUAL_LOADS restores round 3's form for tools/rr_bisect.sh.)
+        if (MODE == MODE_HALF && (wave & 1)) return;
+#endif
         const int g = 2 * S;
         int l = 0;
 #pragma unroll
@@ -1428,10 +1479,6 @@ struct RrStream {
         const int kp = PLAN::KP[l], tl = PLAN::TL[l], spp = kp + tl, KS = 2 * kp + tl;
         constexpr int BB = WFrag<MODE>::BLOCK_BYTES;
         constexpr int LO = MODE == MODE_HALF ? 0 : 1024;                  // the lo8 half of a pair chunk (MODE_HALF: there is none)
-        // MODE_HALF: the lo waves have nothing to carry, but they issue their partner's load all the same (LO = 0: the same
-        // kilobyte, an L1 hit) and only skip the LDS write.  With NO load on their path the kernel gave wrong rows in one or two
-        // waves of a few workgroups per launch (C = 16 at 16 x 225, every run; found by the bit-for-bit test against the tile
-        // kernel).  Cause not identified (finding 4): every wave issues the same loads in both modes.
         const int slA = g - first(l), slB = slA + 1;
         const int passA = slA / spp, kA = slA - passA * spp, passB = slB / spp, kB = slB - passB * spp;
         const bool tailA = kA >= kp, tailB = kB >= kp;
@@ -1521,7 +1568,7 @@ __device__ __forceinline__ void rr_layer(const ActPair (&in)[KP > 0 ? KP : 1], c
             } else {
                 const uint4 a1[1] = {tail};
                 const uint4 w2[2] = {cur.w[0].hi, cur.w[1].hi};
-                mma_tail<MODE, 2, 1, 2>(acc, 0, a1, w2);
+                mma_tail<MODE, 2, 1, 2, (KP > 0)>(acc, 0, a1, w2);
             }
             if (g % 2 == 1) advance(g / 2);
         }
@@ -2480,7 +2527,7 @@ extern "C" int elo_range_violations(unsigned long long *count, elo_stream_t stre
 // the register-resident form of cost-volume stage 1 (cv1_rr_kernel) is taken for pre-grouped calls (idx / mask) in the
 // fp32-class products mode; ELO_CV1_RR=0 or elo_debug_cv1_rr(0) keep the tile kernel (comparison, tests)
 static int g_cv1_rr = -1;
-extern "C" int elo_debug_cv1_rr(int on)
+extern "C" int elo_debug_cv1_rr(int on)           // (the name is round 3's: the switch covers all four register-resident kernels)
 {
     const int prev = g_cv1_rr;
     g_cv1_rr = on;
@@ -2490,6 +2537,41 @@ static bool cv1_rr_on()
 {
     static const int from_env = [] { const char *e = getenv("ELO_CV1_RR"); return e ? atoi(e) : 1; }();
     return (g_cv1_rr >= 0 ? g_cv1_rr : from_env) != 0;
+}
+// row thresholds of the register-resident set-conv / two-stage MLP kernels: the environment is read ONCE (a form baked into a
+// captured graph must not depend on when the variable was set); elo_debug_rr_rows() overrides them for tests, -1 = back
+static long g_setconv_rr_rows = -1, g_mlp_rr_rows = -1;
+extern "C" int elo_debug_rr_rows(long setconv_rows, long mlp_rows)
+{
+    g_setconv_rr_rows = setconv_rows;
+    g_mlp_rr_rows = mlp_rows;
+    return ELO_OK;
+}
+static long env_rows(const char *name)
+{
+    const char *e = getenv(name);
+    return e ? atol(e) : -1;
+}
+static long setconv_rr_rows(int batch)
+{
+    static const long from_env = env_rows("ELO_SETCONV_RR_ROWS");
+    return g_setconv_rr_rows >= 0 ? g_setconv_rr_rows : from_env >= 0 ? from_env : batch >= ELO_THROUGHPUT_BATCH ? 20000L : 100000L;
+}
+static long mlp_rr_rows(int batch_hint)
+{
+    static const long from_env = env_rows("ELO_MLP_RR_ROWS");
+    return g_mlp_rr_rows >= 0 ? g_mlp_rr_rows : from_env >= 0 ? from_env : batch_hint >= ELO_THROUGHPUT_BATCH ? 2048L : 8192L;
+}
+// launches of the register-resident kernels since the last reset: [cv1_rr, cv2_rr, setconv_rr, mlp2_rr].  The parity tests
+// of the chain regime assert through it that the kernel under test is the one that ran.
+static std::atomic<unsigned long long> g_rr_launches[4];
+extern "C" int elo_debug_rr_launches(unsigned long long *counts4, int reset)
+{
+    for (int i = 0; i < 4; ++i) {
+        if (counts4) counts4[i] = g_rr_launches[i].load();
+        if (reset) g_rr_launches[i].store(0);
+    }
+    return ELO_OK;
 }
 
 extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_args *b, elo_stream_t stream)
@@ -2525,8 +2607,7 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
     pair.job[1] = b ? *b : *a;
 #ifndef ELO_DENSE_F32
     {   // the register-resident form (setconv_rr_kernel) for the model's wide shapes, from ELO_SETCONV_RR_ROWS rows on
-        const char *env_rows = getenv("ELO_SETCONV_RR_ROWS");          // (read per call: tests switch it)
-        const long min_rows = env_rows ? atol(env_rows) : a->batch >= ELO_THROUGHPUT_BATCH ? 20000L : 100000L;     // (regimes: elo_mlp_fused2)
+        const long min_rows = setconv_rr_rows(a->batch);               // (regimes: elo_mlp_fused2)
         const int nl = a->n_layers, n1 = a->layers[0].N, n2 = a->layers[1].N, n3 = nl == 3 ? a->layers[2].N : 0;
         const int shape = (nl == 2 && n1 == 128 && n2 == 64) ? 1 : (nl == 3 && n1 == 64 && n2 == 64 && n3 == 128) ? 2
                         : (nl == 3 && n1 == 128 && n2 == 64 && n3 == 64) ? 3 : 0;
@@ -2547,6 +2628,7 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
             else if (shape == 2) RRS(64, 64, 128);
             else RRS(128, 64, 64);
 #undef RRS
+            ++g_rr_launches[2];
             return check_launch(who);
         }
     }
@@ -2642,10 +2724,9 @@ extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_
     pair.job[1] = b ? *b : *a;
 #ifndef ELO_DENSE_F32
     {   // the register-resident form (mlp2_rr_kernel) for the model's two-stage shape, from ELO_MLP_RR_ROWS rows per launch on
-        const char *env_rows = getenv("ELO_MLP_RR_ROWS");              // (read per call: tests switch it)
         // two regimes (fused._prepass_rows): batch >= 4 keeps the GPU full -- 24.0 k -> 25.5 k pairs/s at batch 8 with the chain at
         // every level; at batch 1 (7200 rows at l0) the tile kernel is faster: 10.2 k vs 9.8 k
-        const long min_rows = env_rows ? atol(env_rows) : a->batch_hint >= ELO_THROUGHPUT_BATCH ? 2048L : 8192L;
+        const long min_rows = mlp_rr_rows(a->batch_hint);
         const int C = a->n_sources == 2 ? a->src_width[1] : 0;
         const bool aligned = ((uintptr_t)a->src[0] | (uintptr_t)a->src[1] | (uintptr_t)a->before | (uintptr_t)a->after | (uintptr_t)a->out |
                               (uintptr_t)a->out2) % 16 == 0 &&
@@ -2668,6 +2749,7 @@ extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_
             else if (C == 32) RRM(32);
             else RRM(64);
 #undef RRM
+            ++g_rr_launches[3];
             return check_launch(who);
         }
     }
@@ -2751,6 +2833,7 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
         else if (a->C == 32) RR(32);
         else RR(64);
 #undef RR
+        ++g_rr_launches[0];
         return check_launch(who);
     }
 #endif
@@ -2853,6 +2936,7 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
         else if (a->C == 32) RR(32);
         else RR(64);
 #undef RR
+        ++g_rr_launches[1];
         return check_launch(who);
     }
 #endif

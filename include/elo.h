@@ -661,10 +661,18 @@ typedef struct elo_cv1_args {
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
 } elo_cv1_args;
 int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream);
-/* debugging hook: 0 keeps pre-grouped (idx / mask) calls of elo_cv_stage1_fused on the tile kernel, 1 takes the
- * register-resident form (cv1_rr_kernel; the default, also ELO_CV1_RR), -1 = back to the environment's choice;
- * returns the previous setting.  Both forms give the same bits. */
+/* debugging hooks of the register-resident ("chain") kernel forms -- cv1_rr_kernel, cv2_rr_kernel, setconv_rr_kernel,
+ * mlp2_rr_kernel: the forms elo_cv_stage1_fused / elo_cv_stage2_fused (pre-grouped calls), elo_setconv_fused2 and
+ * elo_mlp_fused2 take from their row thresholds on.  Both forms of an entry point give the same bits.
+ * elo_debug_cv1_rr(0) keeps ALL FOUR entry points on their tile kernels, 1 allows the chain forms (the default, also
+ * ELO_CV1_RR), -1 = back to the environment's choice; returns the previous setting.  (The name is round 3's, when the
+ * switch covered cost-volume stage 1 only.)
+ * elo_debug_rr_rows(setconv_rows, mlp_rows): rows per launch from which elo_setconv_fused2 / elo_mlp_fused2 take the chain
+ * form; -1 = the built-in regimes (or ELO_SETCONV_RR_ROWS / ELO_MLP_RR_ROWS, read once per process).
+ * elo_debug_rr_launches(counts4, reset): launches of [cv1_rr, cv2_rr, setconv_rr, mlp2_rr] since the last reset. */
 int elo_debug_cv1_rr(int on);
+int elo_debug_rr_rows(long setconv_rows, long mlp_rows);
+int elo_debug_rr_launches(unsigned long long *counts4, int reset);
 /* elo_cv_stage1_fused AND one or two set-conv jobs (elo_setconv_fused / elo_setconv_fused2 semantics, tile-kernel form;
  * jb may be NULL) in ONE launch: the first workgroups of the grid run cost-volume tiles, the rest set-conv tiles.
  * For branches that only share inputs -- the cost volume and the two set-upconvs of a refinement level

@@ -174,8 +174,11 @@ def down_conv(params, shuffle, xyz_proj, points_proj, selected_idx, K_sample, ke
 
 # --------------------------------------------------------------------------- cost volume
 def cost_volume(params, shuffle, warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_size1, kernel_size2,
-                nsample, nsample_q, distance, mlp1, mlp2, scope):
-    """utils/pointnet_util.py:33-149."""
+                nsample, nsample_q, distance, mlp1, mlp2, scope, stage1=None, taps=None):
+    """utils/pointnet_util.py:33-149.  Test hooks (not reference arguments): `taps` (a dict) receives the stage-1 tensor
+    (B,H,W,64) under "stage1"; `stage1` replaces it for stage 2 -- with fp16 feature storage the product keeps that tensor
+    in HBM as fp16, and an element-wise comparison of the FINAL tensor is made with the product's own stored intermediate
+    (one fp16 ulp of difference there is allowed and moves the final value by more than 1e-4)."""
     B, H, W, _ = warped_xyz1_proj.shape
     warped_xyz1 = warped_xyz1_proj.reshape(B, H * W, -1)
     points1 = points1_proj.reshape(B, H * W, -1)
@@ -201,6 +204,10 @@ def cost_volume(params, shuffle, warped_xyz1_proj, xyz2_proj, points1_proj, poin
     logits = np.where(valid_mask == 1.0, cat, F(-1e10)).astype(F)                                 # :92-94
     WQ = softmax(logits, 2)                                                                       # :96
     pi_feat1_new = _st((WQ * x).sum(2)).reshape(B, H, W, -1)                                      # :97-100
+    if taps is not None:
+        taps["stage1"] = pi_feat1_new
+    if stage1 is not None:
+        pi_feat1_new = np.asarray(stage1, F).reshape(pi_feat1_new.shape)
 
     perm_p = shuffle(scope, "random_HW_p", kernel_size1[0] * kernel_size1[1])
     pc_idx, _, _, valid_mask2 = _grouped(G.fused_conv_random_k(warped_xyz1_proj, warped_xyz1_proj, idx_hw, perm_p, H, W, H * W,
@@ -233,8 +240,9 @@ def flow_predictor(params, points_f1, upsampled_feat, cost_vol, mlp, scope):
 
 
 def up_conv(params, shuffle, xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kernel_size, stride_h, stride_w, nsample,
-            distance, mlp, mlp2, scope):
-    """utils/pointnet_util.py:254-316."""
+            distance, mlp, mlp2, scope, pooled=None, taps=None):
+    """utils/pointnet_util.py:254-316.  Test hooks as in cost_volume: `taps["pooled"]` receives the max-pooled stage-1
+    tensor (B,N,mlp[-1]), `pooled` replaces it for stage 2."""
     B, H, W, _ = xyz1_proj.shape
     xyz1 = xyz1_proj.reshape(B, H * W, -1)
     points1 = feat1_proj.reshape(B, H * W, -1)
@@ -250,6 +258,10 @@ def up_conv(params, shuffle, xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kerne
         x = conv(params, "%s/up_1_%d" % (scope, j), x)                                            # :289-293
     x = x * mask                                                                                  # :295
     up_feat = _st(x.max(axis=2))                                                                  # :298
+    if taps is not None:
+        taps["pooled"] = up_feat
+    if pooled is not None:
+        up_feat = np.asarray(pooled, F).reshape(up_feat.shape)
     y = np.concatenate([up_feat, points1], -1)[:, :, None, :]                                     # :303-305
     for i, _c in enumerate(mlp2):
         y = conv(params, "%s/up_2_%d" % (scope, i), y)                                            # :307-311

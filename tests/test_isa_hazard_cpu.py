@@ -1,0 +1,62 @@
+"""The shipped libraries hold no 16x16x16 MFMA that accumulates onto a 16x16x32 MFMA's result within the 5 wait states
+gfx950 needs and hipcc does not insert (finding 4; measured by tools/micro/mfma_srcc_hazard.hip;
+guard: mfma_shape_guard in csrc/elo_fused.hip).  The check is static (disassembly of the built code objects), so it
+runs without a GPU -- a rebuild whose scheduling puts such a pair back fails here, not as a wrong row on some input."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("isa_mfma_hazard", os.path.join(ROOT, "tools", "isa_mfma_hazard.py"))
+H = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(H)
+
+PAIR = """
+0000000000001000 <kernel_a>:
+	v_mfma_f32_16x16x32_f16 v[22:25], v[30:33], v[34:37], v[22:25]
+	ds_read_b128 v[30:33], v73 offset:10240
+	s_waitcnt lgkmcnt(1)
+	v_mfma_f32_16x16x16_f16 v[38:41], v[40:41], v[62:63], v[22:25]
+	s_endpgm
+"""
+
+
+def test_the_checker_flags_the_pair_the_bisect_ended_at():
+    hits = H.check_text(PAIR)
+    assert len(hits) == 1 and hits[0][0] == "kernel_a" and hits[0][3] == 2
+
+
+@pytest.mark.parametrize("between,flagged", [("s_nop 3", True), ("s_nop 4", False), ("s_nop 5", False),
+                                             ("v_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[8:11], v[0:3]", False),
+                                             ("v_mov_b32 v1, v2\n\tv_mov_b32 v1, v2\n\tv_mov_b32 v1, v2\n\tv_mov_b32 v1, v2", True),
+                                             ("v_mov_b32 v22, 0", False)])
+def test_what_counts_as_distance(between, flagged):
+    """s_nop n is n + 1 wait states, another MFMA in between clears the hazard, an overwrite of the accumulator ends it."""
+    text = PAIR.replace("\tds_read_b128 v[30:33], v73 offset:10240\n\ts_waitcnt lgkmcnt(1)", "\t" + between)
+    assert bool(H.check_text(text)) == flagged
+
+
+def test_the_hazard_is_followed_across_branches():
+    text = """
+0000000000001000 <kernel_b>:
+	v_mfma_f32_16x16x32_f16 v[22:25], v[30:33], v[34:37], v[22:25]
+	s_cbranch_vccnz 12 <L1>
+	s_nop 7
+0000000000001010 <L1>:
+	v_mfma_f32_16x16x16_f16 v[22:25], v[40:41], v[62:63], v[22:25]
+	s_endpgm
+"""
+    hits = H.check_text(text)
+    assert len(hits) == 1 and hits[0][3] == 1
+
+
+@pytest.mark.parametrize("lib", ["libelo_hip.so", "libelo_hip_f32.so"])
+def test_shipped_libraries_are_free_of_the_pair(lib):
+    path = os.path.join(ROOT, "efficientlo-net_amd", lib)
+    if not os.path.exists(path):
+        pytest.skip("library not built")
+    objs = H.code_objects(path)
+    assert objs and all("gfx950" in triple for triple, _ in objs)
+    hits = H.check_library(path)
+    assert not hits, hits[:5]

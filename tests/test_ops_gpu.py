@@ -1,6 +1,7 @@
 """GPU parity of the operator library (set-conv, cost volume, set-upconv, flow predictor,
 softmax_valid, quaternion warp + re-projection) against the numpy restatement in oracle/ops_np.py.
 Tolerance (north_star): 1e-4 for fp32 features; neighbour indices are compared bit-exact elsewhere."""
+import ctypes
 import os
 
 import numpy as np
@@ -406,10 +407,17 @@ def test_register_resident_two_stage_mlp_equals_the_tile_kernel(C, dt, rows, pai
         a_, out, out2, _keep = fused._mlp2_args(**ja)
         lib.call("elo_mlp_fused", a_, out)
         return [out, out2]
-    monkeypatch.setenv("ELO_MLP_RR_ROWS", str(1 << 40))
-    tile = run()
-    monkeypatch.setenv("ELO_MLP_RR_ROWS", "0")
-    rr = run()
+    try:
+        lib.lib().elo_debug_rr_rows(-1, 1 << 40)
+        tile = run()
+        lib.lib().elo_debug_rr_rows(-1, 0)
+        lib.lib().elo_debug_rr_launches(None, 1)
+        rr = run()
+        counts = (ctypes.c_ulonglong * 4)()
+        lib.lib().elo_debug_rr_launches(counts, 1)
+        assert counts[3] == 1, "the chain kernel is the one under test"
+    finally:
+        lib.lib().elo_debug_rr_rows(-1, -1)
     torch.cuda.synchronize()
     for a_, b_ in zip(rr, tile):
         assert a_.dtype == b_.dtype == tdt and torch.equal(a_, b_)
@@ -705,10 +713,15 @@ def test_register_resident_setconv_equals_the_tile_kernel(kernel_path, case, mon
             lib.lib().elo_debug_cv1_rr(0)
             tile = run()
             lib.lib().elo_debug_cv1_rr(1)
-            monkeypatch.setenv("ELO_SETCONV_RR_ROWS", "0")
+            lib.lib().elo_debug_rr_rows(0, -1)
+            lib.lib().elo_debug_rr_launches(None, 1)
             rr = run()
+            counts = (ctypes.c_ulonglong * 4)()
+            lib.lib().elo_debug_rr_launches(counts, 1)
+            assert counts[2] == 1, "the chain kernel is the one under test"
         finally:
             lib.lib().elo_debug_cv1_rr(-1)
+            lib.lib().elo_debug_rr_rows(-1, -1)
     torch.cuda.synchronize()
     for a_, b_ in zip(rr, tile):
         assert a_.dtype == b_.dtype and torch.equal(a_, b_)
