@@ -494,10 +494,19 @@ def pin_to_numa_node(torch, local):
         return {"numa_node": None, "why": "%s: %s" % (type(e).__name__, str(e)[:80])}
 
 
+RCCL_ALGO = {"0": "Tree", "1": "Ring", "2": "CollNetDirect", "3": "CollNetChain", "4": "NVLS", "5": "NVLSTree"}   # NCCL_ALGO_* (nccl devcomm.h)
+RCCL_PROTO = {"0": "LL", "1": "LL128", "2": "Simple"}                                                                    # NCCL_PROTO_*
+
+
 def parse_rccl_log(path):
-    """What RCCL said about itself (NCCL_DEBUG=INFO, subsystems INIT,GRAPH,TUNING) in this rank's log file."""
+    """What RCCL said about itself (NCCL_DEBUG=INFO, subsystems INIT,GRAPH,TUNING) in this rank's log file: the rank count
+    of the communicator ("... rank 0 nranks 8 cudaDev 0 ... Init COMPLETE"), the channel count ("16 coll channels, ..."),
+    the transports of the ring / tree links ("Channel 00 : 0[..] -> 1[..] via P2P/IPC"), whether rings and trees were
+    connected, and the algorithm / protocol the tuner picked per collective ("AllReduce: 3596536 Bytes -> Algo 1 proto 2
+    time 52.3": numbers are NCCL_ALGO_* / NCCL_PROTO_*; newer logs spell them out).  tests/test_bench_cpu.py feeds it canned
+    excerpts of both spellings; it has not met a live RCCL log on this pool yet (no multi-GPU node)."""
     import re
-    out = {"log": path, "nranks": None, "channels": None, "transports": [], "algo_proto": None}
+    out = {"log": path, "nranks": None, "channels": None, "transports": [], "algo_proto": None, "rings": None, "trees": None}
     try:
         text = open(path, errors="replace").read()
     except OSError:
@@ -507,8 +516,15 @@ def parse_rccl_log(path):
     m = re.search(r"(\d+) coll channels", text)
     out["channels"] = int(m.group(1)) if m else None
     out["transports"] = sorted(set(re.findall(r"via (\S+)", text)))[:8]
-    m = re.findall(r"[Aa]lgo(?:rithm)? (\w+) [Pp]roto(?:col)? (\w+)", text)
-    out["algo_proto"] = sorted(set("%s/%s" % ap for ap in m))[:8] or None
+    out["rings"] = bool(re.search(r"Connected all rings", text)) or (True if re.search(r"Channel \d+/\d+ *:", text) else None)
+    out["trees"] = bool(re.search(r"Connected all trees", text)) or (True if re.search(r"\bTrees \[", text) else None)
+    picks = set()
+    for coll, algo, proto in re.findall(r"(\w+): \d+ Bytes -> [Aa]lgo(?:rithm)? (\w+) [Pp]roto(?:col)? (\w+)", text):
+        picks.add("%s:%s/%s" % (coll, RCCL_ALGO.get(algo, algo), RCCL_PROTO.get(proto, proto)))
+    if not picks:
+        for algo, proto in re.findall(r"[Aa]lgo(?:rithm)? (\w+) [Pp]roto(?:col)? (\w+)", text):
+            picks.add("%s/%s" % (RCCL_ALGO.get(algo, algo), RCCL_PROTO.get(proto, proto)))
+    out["algo_proto"] = sorted(picks)[:8] or None
     return out
 
 

@@ -46,7 +46,8 @@ __device__ __forceinline__ float exp_acc(float x)
 // elo_perm_refresh_args): one workgroup; copies version (*cursor % versions), decodes it, advances the cursor
 __device__ __forceinline__ void perm_refresh_block(const elo_perm_refresh_args &a)
 {
-    const int r = *a.cursor % a.versions;
+    const unsigned cur = (unsigned)*a.cursor;           // the stored cursor is kept in [0, versions): no overflow however long a lane replays
+    const int r = (int)(cur % (unsigned)a.versions);
     const int *src = a.pool + (size_t)r * a.total;
     for (int i = threadIdx.x; i < a.total; i += blockDim.x) {
         const int p = src[i];
@@ -56,7 +57,7 @@ __device__ __forceinline__ void perm_refresh_block(const elo_perm_refresh_args &
         a.decoded[i] = ((p / kW - kH / 2) << 16) | ((p % kW - kW / 2) & 0xffff);
     }
     __syncthreads();
-    if (threadIdx.x == 0) *a.cursor = *a.cursor + 1;
+    if (threadIdx.x == 0) *a.cursor = (r + 1) % a.versions;
 }
 
 // ---- device: XCD-aware tile order ------------------------------------------

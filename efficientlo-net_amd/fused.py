@@ -415,7 +415,8 @@ def group_prepass(kind, xyz1_grid, xyz2_grid, group, K):
     idx = torch.empty((B, N, K, 3), dtype=torch.int32, device=xyz1_grid.device)
     mask = torch.empty((B, N, K), dtype=torch.float32, device=xyz1_grid.device)
     if kind == "select":
-        dense = -(-W // 64) * H * B >= 1024 and K <= 7 and kH * kW <= 512
+        from .fused_conv import _select_dense_fits                # the launcher's own bounds (K <= 7, <= 512 slots, 64 KB of LDS)
+        dense = -(-W // 64) * H * B >= 1024 and _select_dense_fits(kH, kW, K, 0, group.stride_h, group.stride_w)
         entry = "elo_fused_conv_select_k_dense" if dense else "elo_fused_conv_select_k"
     else:
         RH, RW = 1 // group.stride_h + kH, 63 // group.stride_w + kW           # (fused_conv._dense_fits)

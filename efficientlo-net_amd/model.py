@@ -57,7 +57,7 @@ def _cached_tensors():
     visiting orders): what a graph captured just before may point at."""
     from . import pointnet_util
     keep = list(model_util._sel_cache.values()) + list(pointnet_util._hw_cache.values()) + \
-        list(pointnet_util._centre_hw_cache.values()) + list(fused._DECODED.values())
+        list(pointnet_util._centre_hw_cache.values()) + list(fused._DECODED.values()) + list(fused._HW.values())
     return keep
 
 

@@ -34,3 +34,50 @@ def test_bench_single_rank_dry_run_needs_no_launcher():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and "launching" not in out.stderr
+
+
+RING_LOG = """\
+node0:4242:4242 [0] NCCL INFO cudaDriverVersion 12000
+node0:4242:4242 [0] NCCL INFO RCCL version 2.22.3+hip7.0 HEAD:abcdef0
+node0:4242:4300 [0] NCCL INFO comm 0x55d0c8a0 rank 0 nranks 8 cudaDev 0 busId c000 commId 0x9d1c2f3e4a5b6c7d - Init START
+node0:4242:4300 [0] NCCL INFO Channel 00/16 :    0   1   2   3   4   5   6   7
+node0:4242:4300 [0] NCCL INFO Channel 01/16 :    0   2   4   6   7   5   3   1
+node0:4242:4300 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1 [1] 2/-1/-1->0->-1
+node0:4242:4300 [0] NCCL INFO Channel 00 : 0[c000] -> 1[d000] via P2P/IPC
+node0:4242:4300 [0] NCCL INFO Channel 01 : 0[c000] -> 2[e000] via P2P/IPC
+node0:4242:4300 [0] NCCL INFO Connected all rings
+node0:4242:4300 [0] NCCL INFO Connected all trees
+node0:4242:4300 [0] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 16 p2p channels, 2 p2p channels per peer
+node0:4242:4300 [0] NCCL INFO comm 0x55d0c8a0 rank 0 nranks 8 cudaDev 0 busId c000 commId 0x9d1c2f3e4a5b6c7d - Init COMPLETE
+node0:4242:4242 [0] NCCL INFO AllReduce: 3596536 Bytes -> Algo 1 proto 2 time 61.250000
+node0:4242:4242 [0] NCCL INFO AllGather: 224 Bytes -> Algo 1 proto 0 time 9.500000
+"""
+
+TREE_LOG = """\
+gpu-box:77:77 [3] NCCL INFO comm 0x1 rank 3 nranks 4 cudaDev 3 busId 2f000 commId 0xfeed - Init START
+gpu-box:77:91 [3] NCCL INFO Trees [0] -1/-1/-1->3->2 [1] -1/-1/-1->3->2
+gpu-box:77:91 [3] NCCL INFO Channel 00/0 : 3[2f000] -> 2[2e000] via SHM/direct/direct
+gpu-box:77:91 [3] NCCL INFO 8 coll channels, 0 collnet channels, 0 nvls channels, 8 p2p channels, 2 p2p channels per peer
+gpu-box:77:91 [3] NCCL INFO Connected all trees
+gpu-box:77:77 [3] NCCL INFO AllReduce: 3596536 Bytes -> Algorithm Tree Protocol LL128 time 40.1
+"""
+
+
+def test_parse_rccl_log_on_canned_excerpts(tmp_path):
+    """bench.py's reading of an RCCL init / tuning log (NCCL_DEBUG=INFO, INIT,GRAPH,TUNING): rank count, channels, transports,
+    ring / tree, algorithm / protocol -- on the ring spelling (numeric algo / proto) and the tree spelling (names)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ring, tree = tmp_path / "ring.log", tmp_path / "tree.log"
+    ring.write_text(RING_LOG)
+    tree.write_text(TREE_LOG)
+    r = bench.parse_rccl_log(str(ring))
+    assert r["nranks"] == 8 and r["channels"] == 16 and r["transports"] == ["P2P/IPC"] and r["rings"] and r["trees"]
+    assert r["algo_proto"] == ["AllGather:Ring/LL", "AllReduce:Ring/Simple"]
+    q = bench.parse_rccl_log(str(tree))
+    assert q["nranks"] == 4 and q["channels"] == 8 and q["transports"] == ["SHM/direct/direct"] and q["trees"]
+    assert q["algo_proto"] == ["AllReduce:Tree/LL128"]
+    missing = bench.parse_rccl_log(str(tmp_path / "absent.log"))
+    assert missing["nranks"] is None and missing["algo_proto"] is None
