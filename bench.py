@@ -81,6 +81,9 @@ def parse():
                     help="pre-drawn window visiting orders per lane: every replay walks the next set (tf.random_shuffle per "
                          "sess.run, utils/pointnet_util.py:45,104,193,270: one tiny launch at the head of each replay); 0 = one "
                          "fixed draw for the life of the graph")
+    ap.add_argument("--check-every", type=int, default=64,
+                    help="every N-th replay of a lane runs the graph recorded on the range-checked kernels (the fp16 split's "
+                         "production guard, PWCLONet.capture(check_every=N)); 0: off")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true",
@@ -634,7 +637,7 @@ def main():
         else:
             # a lane's l0 pose-head kernel writes replay r's [q | t] block into slot r of the lane's ring
             net.capture(B, H, W, lanes=lanes, pose_ring=max(2, -(-max(args.steps, warmup) // lanes)), sample=pool[0],
-                        fresh_orders=args.fresh_orders)
+                        fresh_orders=args.fresh_orders, check_every=0 if args.products == "half" else args.check_every)
         # every step's l0 pose [q | t] is kept: one (B,7) row block per step in HBM, collected from the lanes' rings at
         # the end of each repeat INSIDE the timed region (one strided copy per lane; round 1-2 copied one block out per
         # step, a launch that sat ~14 us in every lane's serial chain); with N > 1 ranks the blocks are all-gathered ONCE
@@ -718,6 +721,10 @@ def main():
                                                                if args.fresh_orders else ", one fixed draw of the visiting orders")),
                    "global_batch": B * world, "parallelism": "dp%d" % world},
     }
+    if not dry and not args.no_graph and args.products != "half" and args.check_every:
+        # the fp16 split's production guard: every N-th replay of a lane ran on the range-checked kernels INSIDE the timed loop
+        line["range_check"] = {"every_nth_replay": args.check_every, "violations": net.range_violations()}
+        assert line["range_check"]["violations"] == 0
     legs = not args.no_legs and not dry
     if legs and args.train_steps > 0 and (H, W) == (64, 1800):
         train = train_dp_leg(args, dev, rank, world, dist)          # every rank takes part (one collective per step)

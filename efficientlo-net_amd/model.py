@@ -111,7 +111,7 @@ class PWCLONet:
 
     # -- HIP graph -----------------------------------------------------------
     def capture(self, batch_size, H_input, W_input, warmup=3, lanes=1, num_points=None, point_stride=3, pose_ring=0, sample=None,
-                fresh_orders=0):
+                fresh_orders=0, check_every=0):
         """Record the inference forward into `lanes` independent hipGraphs (torch.cuda.CUDAGraph on ROCm).
         With `num_points` the graph starts from RAW clouds: a lane owns a (B, 2*num_points, point_stride) cloud buffer
         and records the input stage (model_util.input_stage: 35 m crop + both projections, no augmentation) in front
@@ -133,6 +133,13 @@ class PWCLONet:
         copies the next version in and decodes it for the replay that follows (perm.PermSource.enable_pool;
         elo_pose_head_args.next_orders): no launch of its own.  Replay n of a lane (n = 1, 2, ...) walks version
         (n - 1) % R: `perms.pooled_version(n - 1)`.  0: one fixed draw for the life of the graph.
+
+        `check_every=N` (>= 1): the production guard of the fp16 hi/lo split.  Every lane records a SECOND graph of the same
+        forward on the CHECKED kernel instances (elo_range_check: every matrix-core operand -- gathered inputs and every
+        layer output -- is compared with the fp16 range on its way into a quad; the tile kernels, bit-identical results) and
+        every N-th replay of a lane takes that graph; `range_violations()` / `collect()` read the device counter and raise.
+        A stream of scans is therefore vetted continuously at 1/N of the checked kernels' extra cost (N = 1: every replay)
+        instead of once on the capture `sample`; a single out-of-range scan between two checked replays can go unseen.
 
         `pose_ring=R` (>= 2): a lane's pose output is a ring of R rows blocks instead of one (B,7) block -- replay r of the
         lane writes slot r % R (the l0 pose-head kernel keeps the cursor on the device), so a stream of pairs is not
@@ -182,12 +189,33 @@ class PWCLONet:
                     lane["out"] = self.forward(staged[:batch_size], staged[batch_size:], pose_out=lane["pose"])
                 else:
                     lane["out"] = self.forward(*lane["in"], pose_out=lane["pose"])
+            if check_every:                           # the same forward on the checked kernel instances, same buffers
+                from . import _lib
+                lane["graph_checked"], lane["check_every"] = torch.cuda.CUDAGraph(), int(check_every)
+                prev = _lib.range_check(True)
+                try:
+                    self.perms.tail_armed = False     # (the warm-up below must not advance the lane's order cursor)
+                    with torch.cuda.stream(side):     # the checked path's own allocations / caches, before its capture
+                        self.forward(*lane["in"])
+                    torch.cuda.synchronize(dev)
+                    self.perms.tail_armed = bool(fresh_orders)
+                    with torch.cuda.graph(lane["graph_checked"]):
+                        if num_points is not None:
+                            _pts, staged = model_util.input_stage(lane["cloud"], None, None, H_input, W_input)
+                            lane["out_checked"] = self.forward(staged[:batch_size], staged[batch_size:], pose_out=lane["pose"])
+                        else:
+                            lane["out_checked"] = self.forward(*lane["in"], pose_out=lane["pose"])
+                finally:
+                    _lib.range_check(bool(prev))
             # the graph holds raw device pointers into the module-level index / decoded-order caches; those caches evict
             # (clear()) when they grow: the lane keeps the tensors alive for as long as its graph exists
             lane["keep"] = _cached_tensors()
             self._lanes.append(lane)
         self.perms.active_lane, self.perms.tail_armed = 0, False
         torch.cuda.synchronize(dev)
+        if check_every:
+            from . import _lib
+            _lib.range_violations(self._lanes[0]["pair"])            # the counter starts at zero
         self._graph, self._static_in, self._static_out = (self._lanes[0]["graph"], self._lanes[0]["in"],
                                                           self._lanes[0]["out"])
         self._captured_at = (self.store.generation, self.perms.generation)
@@ -209,9 +237,36 @@ class PWCLONet:
 
     def replay(self):
         self._check_fresh()
-        self._graph.replay()
-        self._lanes[0]["replays"] += 1          # lane 0's graph advanced its device-side pose-ring cursor
-        return self._static_out
+        return self._replay_lane(self._lanes[0])   # (lane 0's graph advances its device-side pose-ring cursor)
+
+    def _replay_lane(self, lane):
+        """Replay the lane's graph -- every `check_every`-th time the one recorded on the range-checked kernels."""
+        n = lane.get("check_every", 0)
+        lane["total"] = lane.get("total", 0) + 1
+        checked = n and lane["total"] % n == 0
+        (lane["graph_checked"] if checked else lane["graph"]).replay()
+        lane["replays"] += 1
+        return lane["out_checked"] if checked else lane["out"]
+
+    def range_violations(self):
+        """Matrix-core operands at or beyond the fp16 range (|x| >= 65504, or NaN) seen by the checked replays since the
+        last call (capture(..., check_every=N)); reads and resets the device counter on the current stream -- call it once
+        the lanes' streams have been synchronised or waited on."""
+        from . import _lib
+        return _lib.range_violations(self._lanes[0]["pair"])
+
+    def collect(self, lane_index):
+        """lane_poses(lane_index) for a lane whose work is DONE: synchronises the lane's stream, and raises if a checked
+        replay saw an operand outside the fp16 range (the poses since the last collection are then not to be trusted)."""
+        lane = self._lanes[lane_index]
+        lane["stream"].synchronize()
+        if lane.get("check_every"):
+            bad = self.range_violations()
+            if bad:
+                raise RuntimeError("%d matrix-core operands at or beyond the fp16 range (|x| >= 65504 or NaN) since the last "
+                                   "collection: the hi/lo split of the fused kernels saturated them -- rescale the inputs / "
+                                   "weights or run the fp32-MFMA build (ELO_DENSE_F32=1)" % bad)
+        return self.lane_poses(lane_index) if isinstance(lane["pose"], _ops.PoseRing) else self.lane_pose(lane_index)
 
     def submit(self, lane_index, xyz_f1_proj, xyz_f2_proj=None):
         """Enqueue one forward on lane `lane_index` (its own stream); returns the lane's static outputs,
@@ -225,9 +280,8 @@ class PWCLONet:
             else:
                 lane["in"][0].copy_(xyz_f1_proj, non_blocking=True)
                 lane["in"][1].copy_(xyz_f2_proj, non_blocking=True)
-            lane["graph"].replay()
-        lane["replays"] += 1
-        return lane["out"]
+            out = self._replay_lane(lane)
+        return out
 
     def submit_points(self, lane_index, point_cloud):
         """Enqueue one forward from raw clouds (B, 2N, stride) on a lane captured with `num_points`."""
@@ -235,9 +289,8 @@ class PWCLONet:
         lane = self._lanes[lane_index]
         with torch.cuda.stream(lane["stream"]):
             lane["cloud"].copy_(point_cloud, non_blocking=True)
-            lane["graph"].replay()
-        lane["replays"] += 1
-        return lane["out"]
+            out = self._replay_lane(lane)
+        return out
 
     def lane_pose(self, lane_index):
         """The lane's (B,7) [l0_q_norm | l0_t] block, written by the l0 pose-head kernel of its last replay

@@ -43,6 +43,46 @@ def _fused_path(is_training):
     return _FUSED and not is_training
 
 
+# ---- fp16 feature STORAGE on the per-operator path (BASELINE configs[2] with ELO_FUSED=0) ---------------------------
+# The storage contract (fused.storage, oracle/ops_np.feature_storage): every feature tensor an operator hands to the next
+# one through HBM is fp16 -- the outputs of down_conv and flow_predictor and both halves of cost_volume and up_conv --,
+# everything inside an operator is fp32.  The fused kernels read and write fp16 themselves; the per-operator kernels +
+# hipBLASLt GEMMs keep their fp32 tensors INSIDE an operator, so here the boundary is explicit: fp16 feature arguments are
+# widened on entry (exact), the result is rounded to fp16 on exit, and the stage-1 tensor of the two two-stage operators
+# is rounded where the fused path stores it.  Same numbers as the oracle's storage mode, two elementwise launches per
+# operator more than the fp32 run: this path is the HBM-roofline / training path, not the throughput one.
+def _store_round(x):
+    """x rounded to the storage dtype and widened again (the value the next stage would read back from HBM)."""
+    return x.half().float() if fused.storage_dtype() == torch.float16 else x
+
+
+def _storage_boundary(*feature_args, tuple_out=False):
+    import functools
+    import inspect
+
+    def deco(fn):
+        sig = inspect.signature(fn)
+
+        @functools.wraps(fn)
+        def wrapped(*args, **kw):
+            b = sig.bind(*args, **kw)
+            b.apply_defaults()
+            if _fused_path(b.arguments["is_training"]):
+                return fn(*args, **kw)
+            halves = [n for n in feature_args if torch.is_tensor(b.arguments.get(n)) and b.arguments[n].dtype == torch.float16]
+            if not halves:
+                return fn(*args, **kw)
+            if b.arguments["is_training"]:
+                raise NotImplementedError("training stores its features in fp32")
+            for n in halves:
+                b.arguments[n] = b.arguments[n].float()
+            with fused.storage(torch.float16):
+                out = fn(*b.args, **b.kwargs)
+            return ((out[0].half(),) + tuple(out[1:])) if tuple_out else out.half()
+        return wrapped
+    return deco
+
+
 def warping_layers(xyz1, upsampled_flow):
     """utils/pointnet_util.py:18-20."""
     return xyz1 + upsampled_flow
@@ -106,6 +146,7 @@ def _split_conv(parts, num_output_channels, scope, is_training, bn_decay, bn=Tru
     return y.reshape(lead + (num_output_channels,))
 
 
+@_storage_boundary("points1_proj", "points2_proj")
 def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_size1, kernel_size2, nsample,
                 nsample_q, distance, mlp1, mlp2, is_training, bn_decay, scope, bn=True, pooling='max', knn=True,
                 corr_func='elementwise_product', side_jobs=None):
@@ -152,8 +193,8 @@ def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_
             warped_xyz1_proj, xyz2_proj, idx_hw, random_HW_q, H, W, N, kernel_size2[0], kernel_size2[1], nsample_q,
             flag_copy=0, distance=1000, stride_h=1, stride_w=1, want_valid=False)            # :49-51 (1000 is literal)
         mask = valid_mask.reshape(B, N, nsample_q)
-        pi_feat1_new = _cost_volume_stage1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask, mlp1, mlp2,
-                                           is_training, bn_decay).reshape(B, H, W, -1)
+        pi_feat1_new = _store_round(_cost_volume_stage1(warped_xyz1, points1, xyz2_proj, points2_proj, qi_idx, mask, mlp1, mlp2,
+                                                        is_training, bn_decay)).reshape(B, H, W, -1)
 
         # ---- stage 2: patch -> patch inside frame 1 (:104-146)
         pc_idx, _, _, valid_mask2 = fused_conv_random_k(
@@ -203,6 +244,7 @@ def _cost_volume_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, ma
     return _ops.masked_softmax_pool(pc_cat, pc_points_grouped, mask2)                             # :137-146
 
 
+@_storage_boundary("points_f1", "upsampled_feat", "cost_volume")
 def flow_predictor(points_f1, upsampled_feat, cost_volume, mlp, is_training, bn_decay, scope, bn=True, clear=None):
     """utils/pointnet_util.py:153-175: MLP over concat[points_f1, upsampled_feat?, cost_volume?] -> (B,N,mlp[-1])."""
     with tf_util.variable_scope(scope):
@@ -354,6 +396,7 @@ def down_conv_job(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, di
     return job, lambda out, new_xyz: (out, new_xyz.reshape(selected_idx.shape[:-1] + (3,)))
 
 
+@_storage_boundary("points_proj", tuple_out=True)
 def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distance, mlp, mlp2, flag_add, is_training,
               bn_decay, scope, bn=True, pooling='max', knn=False, use_xyz=True, use_nchw=False):
     """Set-conv, utils/pointnet_util.py:179-250.  Returns ((B, n, mlp[-1]), new_xyz_proj (B,H',W',3))."""
@@ -392,6 +435,7 @@ def down_conv(xyz_proj, points_proj, selected_idx, K_sample, kernel_size, distan
         return _ops.masked_maxpool(x, mask), new_xyz_proj                                         # :224-230
 
 
+@_storage_boundary("feat1_proj", "feat2_proj")
 def up_conv(xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kernel_size, stride_h, stride_w, nsample, distance, mlp,
             mlp2, is_training, scope, bn_decay=None, bn=True, pooling='max', radius=None, knn=True):
     """Set-upconv (embedding and embedding-mask up-convolution), utils/pointnet_util.py:254-316."""
@@ -422,7 +466,7 @@ def up_conv(xyz1_proj, xyz2_proj, feat1_proj, feat2_proj, kernel_size, stride_h,
         for j, num_out_channel in enumerate(mlp):
             x = tf_util.conv2d(x, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=True,
                                is_training=is_training, scope='up_1_%d' % j, bn_decay=bn_decay)   # :289-293
-        up_feat = _ops.masked_maxpool(x, mask)                                                    # :295-298
+        up_feat = _store_round(_ops.masked_maxpool(x, mask))                                      # :295-298
         y = None
         for i, num_out_channel in enumerate(mlp2):                                                # :303-311
             if i == 0:

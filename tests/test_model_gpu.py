@@ -90,8 +90,6 @@ def test_batch8_matches_oracle_level_by_level(kernel_path, features):
     """configs[2] end to end: PWCLONet(feature_dtype=half) at (8, 64, 1800) -- all 8 poses of all four levels against the
     oracle fed the same fp16-rounded feature tensors (and the fp32 run of the same batch beside it); graph replay ==
     eager bit for bit."""
-    if kernel_path != "fused" and features == "f16":
-        pytest.skip("fp16 feature storage is plumbed through the fused inference path")
     model, perm, synth = load_pkg("model"), load_pkg("perm"), load_pkg("synth")
     B, H, W = 8, 64, 1800
     f1, f2 = synth.frame_pair(B, H, W, seed=52)

@@ -159,6 +159,51 @@ def test_range_check_flags_operands_beyond_fp16():
     assert L.range_violations(t(x)) == 0                                       # off: nothing is counted
 
 
+def test_range_check_guards_a_captured_graph():
+    """capture(..., check_every=N): every N-th REPLAY of a lane runs the graph recorded on the checked kernel instances, so a
+    scan whose coordinates leave the fp16 range of the hi/lo split is caught in production (round 3 vetted the capture
+    sample only).  A healthy stream counts nothing and gives the same poses as an unchecked capture bit for bit; an
+    out-of-range pair makes collect() raise; with N = 2 only every second replay is a checked one."""
+    model, synth, fused = load_pkg("model"), load_pkg("synth"), load_pkg("fused")
+    if fused.fp32_mfma():
+        pytest.skip("the fp32-MFMA comparison build has no split operands")
+    B, H, W = 1, 64, 900
+    pairs = []
+    for seed in (5, 6, 7, 8):
+        a, b = synth.frame_pair(B, H, W, seed=seed)
+        pairs.append(torch.cat([t(a), t(b)], 0))
+    bad = pairs[1].clone()
+    bad[0, 24:40, 380:460] *= 1.0e4                                            # a patch of points at ~2e5 m (pyramid centres among them)
+    plain = model.PWCLONet(DEV, seed=1)
+    plain.capture(B, H, W, lanes=1, pose_ring=8)
+    guarded = model.PWCLONet(DEV, seed=1)
+    guarded.capture(B, H, W, lanes=1, pose_ring=8, check_every=1)
+    for net in (plain, guarded):
+        net.reset_poses(0)
+        for p_ in pairs:
+            net.submit(0, p_)
+    want = plain.collect(0).clone()
+    got = guarded.collect(0).clone()                                          # healthy stream: no violation, same bits
+    assert torch.equal(got, want) and float(got.abs().max()) > 0
+    guarded.reset_poses(0)
+    guarded.submit(0, pairs[0])
+    guarded.submit(0, bad)
+    with pytest.raises(RuntimeError, match="beyond the fp16 range"):
+        guarded.collect(0)
+    assert guarded.range_violations() == 0                                     # the counter was read and reset
+    sampled = model.PWCLONet(DEV, seed=1)
+    sampled.capture(B, H, W, lanes=1, pose_ring=8, check_every=2)
+    sampled.reset_poses(0)
+    sampled.submit(0, bad)                                                     # replay 1: the unchecked graph -- goes unseen
+    sampled.submit(0, pairs[0])                                                # replay 2: checked, healthy
+    assert sampled.collect(0).shape[0] == 2
+    sampled.reset_poses(0)
+    sampled.submit(0, pairs[0])
+    sampled.submit(0, bad)                                                     # replay 4: checked
+    with pytest.raises(RuntimeError, match="beyond the fp16 range"):
+        sampled.collect(0)
+
+
 def test_full_pyramid_parity_on_the_fp32_mfma_build():
     """The same full-pyramid parity test on libelo_hip_f32.so (-DELO_DENSE_F32: every product on
     v_mfma_f32_16x16x4_f32), in a child process (the library is chosen at import time)."""
