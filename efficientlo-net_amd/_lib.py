@@ -181,6 +181,7 @@ SYMBOLS = [
     ("elo_debug_cv1_rr", ctypes.c_int, [ctypes.c_int]),
     ("elo_debug_rr_rows", ctypes.c_int, [ctypes.c_long, ctypes.c_long]),
     ("elo_debug_rr_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
+    ("elo_debug_narrow_mfma", ctypes.c_int, [ctypes.c_int]),
     ("elo_cv_stage2_fused", ctypes.c_int, [ctypes.POINTER(Cv2Args), _vp]),
     ("elo_cv_stage1_setconv_fused", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
 ]

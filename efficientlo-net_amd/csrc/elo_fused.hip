@@ -2268,6 +2268,209 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
     RR_STAMP(8);
     report_violations<MODE>(bad);
 }
+// ================================================================ the same narrow set-conv, MLP on the matrix cores (round 4)
+// setconv_small_kernel spends 1507 (6 -> 8 -> 8 -> 16) / 2756 (19 -> 16 -> 16 -> 32) vector instructions per wave, three
+// quarters of them the row-per-lane FMAs of the MLP, and is issue-bound once the GPU is full (batch 8: 37 + 27 us, the two
+// largest VALU kernels of a forward).  Here the grouping is unchanged -- half a wave per centre, a lane per window slot,
+// ballot + popcount -- and leaves the 32 neighbour slots of the workgroup's 8 centres in LDS; then the wave's 64 rows
+// (2 centres x 32 neighbours) run the MLP as FOUR 16-row blocks in the chain kernels' transposed form, D^T = W^T X^T:
+// lane (j, kq) of a block gathers the channel quad kq of row j itself (a float4 / four halves of the neighbour's feature
+// row; the geometry quad is [dx dy dz 0] in lane group 0), which IS the matrix cores' B operand; the layer's accumulator
+// leaves the lane with four consecutive output channels of its row -- the next layer's operand after bias (the
+// accumulator's initial value), ReLU and the hi / lo split -- and the masked max over the 32 rows of a centre is four DPP
+// steps inside a 16-lane row plus one elementwise maximum of the centre's two row blocks.  No LDS tile, no barrier after
+// the grouping, no W stream: the three layers' weights are <= 1.6 K floats, each lane builds its W^T fragments (<= 20
+// registers) ONCE from the plain row-major weights (elo_dense.w_plain, already in [features | xyz difference] row order) and
+// keeps them.  12 (6 -> 8 -> 8 -> 16: 9) matrix instructions per row block instead of ~270 (60) FMAs per row.
+// fp32-class products whatever the launch's products mode (three products of hi / lo operands; the VALU kernel was plain
+// fp32 in either mode).  The fp32-MFMA comparison build keeps setconv_small_kernel.
+template <int CIN, int N1, int N2, int N3, int MODE>
+__global__ __launch_bounds__(ELO_BLOCK) void setconv_narrow_kernel(const elo_setconv_args a)
+{
+    constexpr int G = 32, PER_BLOCK = ELO_BLOCK / G, C = CIN - 3, CB3 = N3 / 16;
+    static_assert((C == 16 || C == 3) && N1 <= 16 && N2 <= 16 && (N3 == 16 || N3 == 32), "the pyramid's two narrow set-conv layers");
+    __shared__ int slot_hw[PER_BLOCK][G];
+    const int tid = threadIdx.x;
+    const int l64 = tid & 63, i16 = l64 & 15, kq = l64 >> 4;
+    unsigned bad = 0, wbad = 0;
+    // ---- (1) W^T fragments and bias quads, requested first (consumed after the grouping): lane (i16, kq) of a fragment holds
+    // W[4kq + e][cb * 16 + i16], e = 0..3 (and, for the 32-k pair of the 19-channel input, W[16 + 4kq + e][..] as well)
+    auto wq = [&](const elo_dense &L, int k0, int n) {                   // rows k0 .. k0 + 3 of column n; 0 beyond (K, N); unconditional loads
+        const int nc = n < L.N ? n : L.N - 1;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + e < L.K ? k0 + e : L.K - 1;
+            v[e] = L.w_plain[k * L.N + nc];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (k0 + e < L.K && n < L.N) ? v[e] : 0.0f;
+        return float4{v[0], v[1], v[2], v[3]};
+    };
+    auto bq = [&](const elo_dense &L, int n0) {                          // bias[n0 .. n0 + 3]
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = L.bias[n0 + e < L.N ? n0 + e : L.N - 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = n0 + e < L.N ? v[e] : 0.0f;
+        return float4{v[0], v[1], v[2], v[3]};
+    };
+    const float4 w1a = wq(a.layers[0], 4 * kq, i16), w1b = C == 16 ? wq(a.layers[0], 16 + 4 * kq, i16) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+    const float4 w2f = wq(a.layers[1], 4 * kq, i16);
+    float4 w3f[CB3];
+#pragma unroll
+    for (int cb = 0; cb < CB3; ++cb) w3f[cb] = wq(a.layers[2], 4 * kq, cb * 16 + i16);
+    const float4 b1 = bq(a.layers[0], 4 * kq), b2 = bq(a.layers[1], 4 * kq);
+    float4 b3[CB3];
+#pragma unroll
+    for (int cb = 0; cb < CB3; ++cb) b3[cb] = bq(a.layers[2], cb * 16 + 4 * kq);
+
+    // ---- (2) grouping: half a wave per centre, as setconv_small_kernel
+    const int g = tid / G, lane = tid % G, shift = (tid & 63) / G * G;
+    const elo_group_spec &gs = a.group;
+    const int KT = gs.kernel_h * gs.kernel_w, kW = gs.kernel_w, hh = gs.kernel_h / 2, hw2 = gs.kernel_w / 2;
+    int off[SMALL_STEPS];
+    const int *order = gs.decoded_hw ? gs.decoded_hw : gs.random_hw;
+#pragma unroll
+    for (int st = 0; st < SMALL_STEPS; ++st) off[st] = order[st * G + lane < KT ? st * G + lane : 0];
+    const long total = (long)a.batch * a.npoints;
+    const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * PER_BLOCK;
+    const long pt = first + g;
+    const bool live = pt < total;
+    const long ptc = live ? pt : total - 1;                 // dead groups shadow the last point and store nothing
+    const int b = (int)(ptc / a.npoints), n = (int)(ptc - (long)b * a.npoints);
+    int hc = n / a.W, wc = n - (n / a.W) * a.W;
+    if (a.centre_hw) {
+        const int2 c2 = reinterpret_cast<const int2 *>(a.centre_hw)[ptc];
+        hc = c2.x; wc = c2.y;
+    }
+    if (!gs.decoded_hw) {
+#pragma unroll
+        for (int st = 0; st < SMALL_STEPS; ++st) off[st] = ((off[st] / kW - hh) << 16) | ((off[st] % kW - hw2) & 0xffff);
+    }
+    const float *cp = a.xyz1_grid + (((long)b * a.H + hc) * a.W + wc) * 3;
+    const float cx = cp[0], cy = cp[1], cz = cp[2];
+    const float *grid2 = a.src_xyz + (size_t)b * a.H2 * a.W2 * 3;
+    const int base_h = hc / gs.stride_h, base_w = wc / gs.stride_w;
+    RawSlot raw[SMALL_STEPS];
+#pragma unroll
+    for (int st = 0; st < SMALL_STEPS; ++st) raw[st] = fetch_slot(grid2, a.H2, a.W2, off[st], base_h, base_w, st * G + lane < KT);
+    if (live && lane < 3 && a.new_xyz) a.new_xyz[pt * 3 + lane] = lane == 0 ? cx : lane == 1 ? cy : cz;
+    const float r2 = gs.distance * gs.distance;
+    slot_hw[g][lane] = -1;
+    int taken = 0;
+    const bool centre_ok = !(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS);
+#pragma unroll
+    for (int st = 0; st < SMALL_STEPS; ++st) {
+        const Probe pr = judge(raw[st], cx, cy, cz, r2);
+        const bool hit = pr.hit && centre_ok && taken < G;
+        const unsigned long long mh = group_ballot<G>(hit, shift);
+        const int slot = taken + __popcll(mh & ((1ull << lane) - 1ull));
+        if (hit && slot < G) slot_hw[g][slot] = pr.hw;
+        taken += __popcll(mh);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (gs.idx_out || gs.mask_out) {                         // (parity tests: the op's index / mask outputs)
+        const int hw = slot_hw[g][lane];
+        if (live && gs.idx_out) {
+            int *o = gs.idx_out + (pt * G + lane) * 3;
+            o[0] = hw >= 0 ? b : 0; o[1] = hw >= 0 ? hw >> 16 : 0; o[2] = hw >= 0 ? hw & 0xffff : 0;
+        }
+        if (live && gs.mask_out) gs.mask_out[pt * G + lane] = hw >= 0 ? 1.0f : 0.0f;
+    }
+
+    // ---- (3) the wave's four row blocks: rows (rb & 1) * 16 + i16 of centre 2 * wave + (rb >> 1); every gather goes out first
+    const int wv = tid >> 6, f16 = a.feat_dtype == ELO_F16;
+    auto uni = [](float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+    float mrow[4], sx[4][3];
+    uint4 ff[4];                                             // bits of the gathered features: the quad kq (C = 16: four floats, or four halves in .x / .y) or channels 0..2 (C = 3, as floats)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        const int hw = slot_hw[wv * 2 + (rb >> 1)][(rb & 1) * 16 + i16];
+        const int bb = __builtin_amdgcn_readlane(b, (rb >> 1) * 32);
+        mrow[rb] = hw >= 0 ? 1.0f : 0.0f;
+        const long cell = hw >= 0 ? ((long)bb * a.H2 + (hw >> 16)) * a.W2 + (hw & 0xffff) : 0;       // empty slot: index (0,0,0)
+        const float *sp = a.src_xyz + cell * 3;
+        sx[rb][0] = sp[0]; sx[rb][1] = sp[1]; sx[rb][2] = sp[2];
+        if constexpr (C == 16) {
+            if (f16) {
+                const uint2 h = reinterpret_cast<const uint2 *>(a.src_feat)[cell * 4 + kq];
+                ff[rb] = uint4{h.x, h.y, 0u, 0u};
+            } else ff[rb] = reinterpret_cast<const uint4 *>(a.src_feat)[cell * 4 + kq];
+        } else {
+            float v[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = feat_load(a.src_feat, cell * 3 + c, f16);
+            ff[rb] = uint4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), 0u};
+        }
+    }
+    // the fragments as matrix-core operands (weights were vetted when they were packed: no range count for them)
+    const uint4 q1a = pack_quad<MODE_SPLIT>(w1a, wbad), q1b = pack_quad<MODE_SPLIT>(w1b, wbad), w2t = pack_quad<MODE_SPLIT>(w2f, wbad);
+    const WPair w1p{uint4{q1a.x, q1a.y, q1b.x, q1b.y}, uint4{q1a.z, q1a.w, q1b.z, q1b.w}};
+    uint4 w3t[CB3];
+#pragma unroll
+    for (int cb = 0; cb < CB3; ++cb) w3t[cb] = pack_quad<MODE_SPLIT>(w3f[cb], wbad);
+    float4 best[CB3];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        const float m = mrow[rb];
+        const float ccx = uni(cx, (rb >> 1) * 32), ccy = uni(cy, (rb >> 1) * 32), ccz = uni(cz, (rb >> 1) * 32);
+        const float dx = sx[rb][0] * m - ccx, dy = sx[rb][1] * m - ccy, dz = sx[rb][2] * m - ccz;
+        f32x4 acc1[1][1] = {{f32x4{b1.x, b1.y, b1.z, b1.w}}};
+        if constexpr (C == 16) {
+            // k-blocks [features 0..15 | dx dy dz 0 ...]: one 32-k pair
+            uint4 fq;
+            const float4 fv = __builtin_bit_cast(float4, ff[rb]);
+            if (f16) fq = m != 0.0f ? quad_of_halves(uint2{ff[rb].x, ff[rb].y}) : uint4{0u, 0u, 0u, 0u};
+            else fq = pack_quad<MODE>(float4{fv.x * m, fv.y * m, fv.z * m, fv.w * m}, bad);
+            const uint4 gq = pack_quad<MODE>(kq == 0 ? float4{dx, dy, dz, 0.0f} : float4{0.0f, 0.0f, 0.0f, 0.0f}, bad);
+            const ActPair in[1] = {ActPair{uint4{fq.x, fq.y, gq.x, gq.y}, uint4{fq.z, fq.w, gq.z, gq.w}}};
+            const WPair w[1] = {w1p};
+            mma_pair<MODE, 1, 1, 1>(acc1, 0, in, w);
+        } else {
+            // one 16-k block: [f0 f1 f2 dx | dy dz 0 0 | 0 ...]
+            const float4 fv = __builtin_bit_cast(float4, ff[rb]);
+            const float4 v = kq == 0 ? float4{fv.x * m, fv.y * m, fv.z * m, dx} : kq == 1 ? float4{dy, dz, 0.0f, 0.0f}
+                                                                                            : float4{0.0f, 0.0f, 0.0f, 0.0f};
+            const uint4 in[1] = {pack_quad<MODE>(v, bad)}, w[1] = {q1a};
+            mma_tail<MODE, 1, 1, 1, false>(acc1, 0, in, w);
+        }
+        f32x4 acc2[1][1] = {{f32x4{b2.x, b2.y, b2.z, b2.w}}};
+        {
+            const uint4 in[1] = {pack_quad<MODE>(relu4(acc1[0][0], a.layers[0].relu), bad)}, w[1] = {w2t};
+            mma_tail<MODE, 1, 1, 1, false>(acc2, 0, in, w);
+        }
+        const uint4 h2[1] = {pack_quad<MODE>(relu4(acc2[0][0], a.layers[1].relu), bad)};
+#pragma unroll
+        for (int cb = 0; cb < CB3; ++cb) {
+            f32x4 acc3[1][1] = {{f32x4{b3[cb].x, b3[cb].y, b3[cb].z, b3[cb].w}}};
+            const uint4 w[1] = {w3t[cb]};
+            mma_tail<MODE, 1, 1, 1, false>(acc3, 0, h2, w);
+            // masked max over the block's 16 rows (:224-230): the last layer has a ReLU (launcher), so values >= 0 and the
+            // maximum can be taken on the bit patterns; every lane of the 16-lane row ends up with it
+            const float4 y = relu4(acc3[0][0], a.layers[2].relu);
+            const float q[4] = {y.x * m, y.y * m, y.z * m, y.w * m};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int v = __float_as_int(q[e]);
+                v = dpp_imax_all<0xb1>(v);
+                v = dpp_imax_all<0x4e>(v);
+                v = dpp_imax_all<0x141>(v);
+                v = dpp_imax_all<0x140>(v);
+                o[e] = __int_as_float(v);
+            }
+            if (rb & 1) {                                    // the centre's second half: combine and store (lane group kq: channels cb*16 + 4kq ..)
+                const long ptg = first + wv * 2 + (rb >> 1);
+                const float4 r4{fmaxf(best[cb].x, o[0]), fmaxf(best[cb].y, o[1]), fmaxf(best[cb].z, o[2]), fmaxf(best[cb].w, o[3])};
+                if (i16 == 0 && ptg < total) feat_store4(a.out, ptg * N3 + cb * 16 + 4 * kq, r4, f16);
+            } else best[cb] = float4{o[0], o[1], o[2], o[3]};
+        }
+    }
+    report_violations<MODE>(bad);
+}
+
 #endif   // !ELO_DENSE_F32
 
 // ================================================================ cost volume, stage 2
@@ -2562,6 +2765,21 @@ static long mlp_rr_rows(int batch_hint)
     static const long from_env = env_rows("ELO_MLP_RR_ROWS");
     return g_mlp_rr_rows >= 0 ? g_mlp_rr_rows : from_env >= 0 ? from_env : batch_hint >= ELO_THROUGHPUT_BATCH ? 2048L : 8192L;
 }
+// the narrow set-conv layers: setconv_narrow_kernel (MLP on the matrix cores; the default) or setconv_small_kernel (VALU;
+// ELO_SETCONV_NARROW_MFMA=0 or elo_debug_narrow_mfma(0): comparison, tests); -1 = back to the environment's choice
+static int g_narrow_mfma = -1;
+extern "C" int elo_debug_narrow_mfma(int on)
+{
+    const int prev = g_narrow_mfma;
+    g_narrow_mfma = on;
+    return prev;
+}
+static int narrow_mfma_level()
+{
+    static const int from_env = [] { const char *e = getenv("ELO_SETCONV_NARROW_MFMA"); return e ? atoi(e) : 1; }();
+    return g_narrow_mfma >= 0 ? g_narrow_mfma : from_env;
+}
+static bool narrow_mfma_on() { return narrow_mfma_level() != 0; }
 // launches of the register-resident kernels since the last reset: [cv1_rr, cv2_rr, setconv_rr, mlp2_rr].  The parity tests
 // of the chain regime assert through it that the kernel under test is the one that ran.
 static std::atomic<unsigned long long> g_rr_launches[4];
@@ -2591,6 +2809,24 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
         const int cin = 3 + a->C, n1 = a->layers[0].N, n2 = a->layers[1].N, n3 = a->layers[2].N;
         const unsigned grid = (unsigned)((points + 7) / 8);
         if (int rc = check_group(a->group, a->H2, a->W2, 0, who)) return rc;
+#ifndef ELO_DENSE_F32
+        if (narrow_mfma_on()) {                              // round 4: the same kernel with its MLP on the matrix cores
+            const bool checked = range_check_flag();
+            // (6 -> 8 -> 8 -> 16, the layer on the 64x1800 input: measured SLOWER on the matrix cores -- 64 us against 36.5 us at
+            // batch 8: its MLP is 240 FMAs per row, the kernel is the latency chain of its grouping times its occupancy, and the
+            // MFMA form's 88 registers cost three of the eight waves per SIMD.  ELO_SETCONV_NARROW_MFMA=2 forces it, for the test.)
+            if (cin == 6 && n1 == 8 && n2 == 8 && n3 == 16 && narrow_mfma_level() >= 2) {
+                if (checked) hipLaunchKernelGGL((setconv_narrow_kernel<6, 8, 8, 16, MODE_CHECKED>), dim3(grid), dim3(ELO_BLOCK), 0, s, *a);
+                else hipLaunchKernelGGL((setconv_narrow_kernel<6, 8, 8, 16, MODE_SPLIT>), dim3(grid), dim3(ELO_BLOCK), 0, s, *a);
+                return check_launch(who);
+            }
+            if (cin == 19 && n1 == 16 && n2 == 16 && n3 == 32) {
+                if (checked) hipLaunchKernelGGL((setconv_narrow_kernel<19, 16, 16, 32, MODE_CHECKED>), dim3(grid), dim3(ELO_BLOCK), 0, s, *a);
+                else hipLaunchKernelGGL((setconv_narrow_kernel<19, 16, 16, 32, MODE_SPLIT>), dim3(grid), dim3(ELO_BLOCK), 0, s, *a);
+                return check_launch(who);
+            }
+        }
+#endif
         if (cin == 6 && n1 == 8 && n2 == 8 && n3 == 16) {
             hipLaunchKernelGGL((setconv_small_kernel<6, 8, 8, 16>), dim3(grid), dim3(ELO_BLOCK), 0, s, *a);
             return check_launch(who);

@@ -673,6 +673,12 @@ int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream);
 int elo_debug_cv1_rr(int on);
 int elo_debug_rr_rows(long setconv_rows, long mlp_rows);
 int elo_debug_rr_launches(unsigned long long *counts4, int reset);
+/* the two narrow set-conv layers of the pyramid (6 -> 8 -> 8 -> 16 and 19 -> 16 -> 16 -> 32, K = 32; elo_setconv_fused with
+ * elo_dense.w_plain given): 1 = setconv_narrow_kernel, the MLP on the matrix cores, for the 19-channel layer (the default;
+ * also ELO_SETCONV_NARROW_MFMA), 2 = for both layers (the 6-channel one is slower that way: measured), 0 =
+ * setconv_small_kernel, the fp32 VALU form, for both (the only one in the fp32-MFMA build), -1 = back to the environment's
+ * choice; returns the previous setting.  Results agree to fp32-class rounding. */
+int elo_debug_narrow_mfma(int on);
 /* elo_cv_stage1_fused AND one or two set-conv jobs (elo_setconv_fused / elo_setconv_fused2 semantics, tile-kernel form;
  * jb may be NULL) in ONE launch: the first workgroups of the grid run cost-volume tiles, the rest set-conv tiles.
  * For branches that only share inputs -- the cost volume and the two set-upconvs of a refinement level

@@ -726,3 +726,42 @@ def test_register_resident_setconv_equals_the_tile_kernel(kernel_path, case, mon
     for a_, b_ in zip(rr, tile):
         assert a_.dtype == b_.dtype and torch.equal(a_, b_)
     assert float(rr[0].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,H,W,C,ks,dist,mlp,feat", [(1, 64, 450, 3, [9, 15], 0.5, [8, 8, 16], "f32"), (3, 16, 225, 16, [7, 11], 3.0, [16, 16, 32], "f32"),
+                                                      (2, 16, 113, 16, [7, 11], 3.0, [16, 16, 32], "f16"), (5, 6, 21, 3, [9, 15], 2.0, [8, 8, 16], "f16")])
+def test_narrow_setconv_on_the_matrix_cores_equals_the_valu_kernel(kernel_path, B, H, W, C, ks, dist, mlp, feat):
+    """setconv_narrow_kernel (round 4: the MLP of the two narrow set-conv layers as 16-row MFMA blocks, weights built into
+    fragments in-kernel) against setconv_small_kernel (fp32 FMAs, a lane per row): the same grouping (new_xyz equal bit for
+    bit), the pooled features equal to fp32-class rounding (2e-6 of the value scale; in fp16 storage the same stored half
+    but for rounding boundaries), ragged centre counts (not a multiple of the 8 centres of a workgroup), fp32 / fp16 storage."""
+    if kernel_path != "fused":
+        pytest.skip("fused kernels only")
+    pu, mu, fused, lib = load_pkg("pointnet_util"), load_pkg("model_util"), load_pkg("fused"), load_pkg("_lib")
+    if fused.fp32_mfma():
+        pytest.skip("the fp32-MFMA comparison build keeps the VALU kernel")
+    _, _, store, perms = _ctx()
+    f1, _, feats = _scene(B, H, W, 13, C)
+    oh, ow = (H + 1) // 2, (W + 1) // 2
+    xyz = t(f1)
+    pts = t(feats[0]).half() if feat == "f16" else t(feats[0])
+    sel = mu.get_selected_idx(xyz, 2, 2, oh, ow)
+    run = lambda: pu.down_conv(xyz, pts, sel, K_sample=32, kernel_size=ks, distance=dist, mlp=mlp, mlp2=None, flag_add=False,
+                               is_training=False, bn_decay=None, scope='layerN')
+    try:
+        lib.lib().elo_debug_narrow_mfma(0)
+        valu = _run(run, store, perms)
+        lib.lib().elo_debug_narrow_mfma(2)
+        with load_pkg("tf_util").default_store(store), load_pkg("perm").default_perm_source(perms), torch.no_grad():
+            mfma = run()
+    finally:
+        lib.lib().elo_debug_narrow_mfma(-1)
+    torch.cuda.synchronize()
+    assert torch.equal(mfma[1], valu[1]) and mfma[0].dtype == valu[0].dtype == pts.dtype
+    a_, b_ = mfma[0].float(), valu[0].float()
+    scale = float(b_.abs().max())
+    assert scale > 0 and torch.isfinite(a_).all()
+    if feat == "f32":
+        assert float((a_ - b_).abs().max()) <= 2e-6 * scale
+    else:
+        assert float((a_ - b_).abs().max()) <= 2.0 ** -10 * scale and float((a_ != b_).float().mean()) < 0.01
