@@ -106,6 +106,16 @@ BnApplyArgs = _struct("elo_bn_apply_args", [
 BnBackwardArgs = _struct("elo_bn_backward_args", [
     ("rows", ctypes.c_long), ("C", _i), ("dy", _vp), ("z", _vp), ("mean", _vp), ("invstd", _vp), ("gamma", _vp), ("beta", _vp),
     ("relu", _i), ("scratch", _vp), ("sums", _vp), ("dz", _vp)])
+AdamFlatArgs = _struct("elo_adam_flat_args", [
+    ("n", ctypes.c_long), ("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("hyper", _vp),
+    ("beta1", _f), ("beta2", _f)])
+PoseComposeArgs = _struct("elo_pose_compose_args", [
+    ("batch", _i), ("q_raw", _vp), ("t_det", _vp), ("q_coarse", _vp), ("t_coarse", _vp), ("q", _vp), ("t", _vp), ("q_norm", _vp),
+    ("grad_q", _vp), ("grad_t", _vp), ("grad_q_norm", _vp), ("grad_q_raw", _vp), ("grad_t_det", _vp), ("grad_q_coarse", _vp),
+    ("grad_t_coarse", _vp)])
+PoseLossArgs = _struct("elo_pose_loss_args", [
+    ("batch", _i), ("q", _vp * 4), ("t", _vp * 4), ("q_gt", _vp), ("t_gt", _vp), ("w_x", _vp), ("w_q", _vp), ("loss", _vp),
+    ("grad_out", _vp), ("grad_q", _vp * 4), ("grad_t", _vp * 4), ("grad_w_x", _vp), ("grad_w_q", _vp)])
 WeightGradArgs = _struct("elo_weight_grad_args", [
     ("rows", ctypes.c_long), ("Cin", _i), ("Cout", _i), ("x", _vp), ("g", _vp), ("dW", _vp), ("db", _vp), ("scratch", _vp)])
 BN_MAX_PARTS = 512     # ELO_BN_MAX_PARTS
@@ -172,6 +182,9 @@ SYMBOLS = [
     ("elo_bn_apply", ctypes.c_int, [ctypes.POINTER(BnApplyArgs), _vp]),
     ("elo_bn_backward", ctypes.c_int, [ctypes.POINTER(BnBackwardArgs), _vp]),
     ("elo_dense_weight_grad", ctypes.c_int, [ctypes.POINTER(WeightGradArgs), _vp]),
+    ("elo_adam_flat", ctypes.c_int, [ctypes.POINTER(AdamFlatArgs), _vp]),
+    ("elo_pose_compose", ctypes.c_int, [ctypes.POINTER(PoseComposeArgs), _vp]),
+    ("elo_pose_loss", ctypes.c_int, [ctypes.POINTER(PoseLossArgs), _vp]),
     ("elo_weight_grad_slices", ctypes.c_int, [ctypes.c_long, ctypes.c_int, ctypes.c_int]),
     ("elo_setconv_fused", ctypes.c_int, [ctypes.POINTER(SetconvArgs), _vp]),
     ("elo_mlp_fused", ctypes.c_int, [ctypes.POINTER(MlpArgs), _vp]),
@@ -193,7 +206,7 @@ class EloError(RuntimeError):
     pass
 
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 def lib():

@@ -7,6 +7,8 @@ import math
 
 import numpy as np
 
+import ctypes
+
 import torch
 
 from . import _lib as L
@@ -293,6 +295,84 @@ def _softmax_valid(feature_bnc, weight_bnc, xyz_bn3, stats=None):
                            scratch.data_ptr(), stats.data_ptr() if stats is not None else None)
     L.call("elo_softmax_valid", a, out)
     return out
+
+
+class _PoseCompose(torch.autograd.Function):
+    """normalise -> compose with the coarse pose -> normalise (pwclo_model.py:197-208, :262-280) as ONE launch forward and ONE
+    backward (elo_pose_compose); torch ran the same chain as ~60 + ~120 kernels of eight elements per level."""
+
+    @staticmethod
+    def forward(ctx, q_raw, t_det, q_coarse, t_coarse):
+        B = q_raw.shape[0]
+        q, t, q_norm = torch.empty_like(q_raw), torch.empty_like(t_det), torch.empty_like(q_raw)
+        ptr = lambda x: x.data_ptr() if x is not None else None
+        a = L.PoseComposeArgs(B, q_raw.data_ptr(), t_det.data_ptr(), ptr(q_coarse), ptr(t_coarse), q.data_ptr(), t.data_ptr(),
+                              q_norm.data_ptr(), None, None, None, None, None, None, None)
+        L.call("elo_pose_compose", a, q_raw)
+        ctx.save_for_backward(q_raw, t_det, q_coarse, t_coarse)
+        return q, t, q_norm
+
+    @staticmethod
+    def backward(ctx, gq, gt, gqn):
+        q_raw, t_det, q_coarse, t_coarse = ctx.saved_tensors
+        B = q_raw.shape[0]
+        z = lambda g, like: torch.zeros_like(like) if g is None else g.contiguous()
+        gq, gt, gqn = z(gq, q_raw), z(gt, t_det), z(gqn, q_raw)
+        g_qr, g_td = torch.empty_like(q_raw), torch.empty_like(t_det)
+        g_qc = torch.empty_like(q_coarse) if q_coarse is not None else None
+        g_tc = torch.empty_like(t_coarse) if t_coarse is not None else None
+        ptr = lambda x: x.data_ptr() if x is not None else None
+        a = L.PoseComposeArgs(B, q_raw.data_ptr(), t_det.data_ptr(), ptr(q_coarse), ptr(t_coarse), None, None, None,
+                              gq.data_ptr(), gt.data_ptr(), gqn.data_ptr(), g_qr.data_ptr(), g_td.data_ptr(), ptr(g_qc), ptr(g_tc))
+        L.call("elo_pose_compose", a, q_raw)
+        return g_qr, g_td, g_qc, g_tc
+
+
+def pose_compose(q_raw, t_det, q_coarse=None, t_coarse=None):
+    """(q (B,4), t (B,3), q_norm (B,4)) of a level from the head's raw quaternion and translation and the coarse pose
+    (None at the coarsest level); differentiable (the training path's pose algebra in one launch each way)."""
+    L.require_gpu(q_raw, t_det, q_coarse, t_coarse)
+    B = q_raw.shape[0]
+    f = lambda x, n: None if x is None else _f32(x.reshape(B, n))[0]
+    return _PoseCompose.apply(f(q_raw, 4), f(t_det, 3), f(q_coarse, 4), f(t_coarse, 3))
+
+
+class _PoseLoss(torch.autograd.Function):
+    """get_loss (pwclo_model.py:437-481) over the four levels: one launch forward, one backward (elo_pose_loss)."""
+
+    @staticmethod
+    def forward(ctx, w_x, w_q, q_gt, t_gt, *poses):                # poses: l0_q, l0_t, l1_q, l1_t, l2_q, l2_t, l3_q, l3_t
+        B = q_gt.shape[0]
+        loss = torch.empty((), dtype=torch.float32, device=q_gt.device)
+        P4 = ctypes.c_void_p * 4
+        a = L.PoseLossArgs(B, P4(*[poses[2 * i].data_ptr() for i in range(4)]), P4(*[poses[2 * i + 1].data_ptr() for i in range(4)]),
+                           q_gt.data_ptr(), t_gt.data_ptr(), w_x.data_ptr(), w_q.data_ptr(), loss.data_ptr(), None, P4(), P4(), None, None)
+        L.call("elo_pose_loss", a, q_gt)
+        ctx.save_for_backward(w_x, w_q, q_gt, t_gt, *poses)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        w_x, w_q, q_gt, t_gt, *poses = ctx.saved_tensors
+        B = q_gt.shape[0]
+        grads = [torch.empty_like(x) for x in poses]
+        g_wx, g_wq = torch.empty_like(w_x), torch.empty_like(w_q)
+        go = grad_out.contiguous().float()
+        P4 = ctypes.c_void_p * 4
+        a = L.PoseLossArgs(B, P4(*[poses[2 * i].data_ptr() for i in range(4)]), P4(*[poses[2 * i + 1].data_ptr() for i in range(4)]),
+                           q_gt.data_ptr(), t_gt.data_ptr(), w_x.data_ptr(), w_q.data_ptr(), None, go.data_ptr(),
+                           P4(*[grads[2 * i].data_ptr() for i in range(4)]), P4(*[grads[2 * i + 1].data_ptr() for i in range(4)]),
+                           g_wx.data_ptr(), g_wq.data_ptr())
+        L.call("elo_pose_loss", a, q_gt)
+        return (g_wx, g_wq, None, None) + tuple(grads)
+
+
+def pose_loss(l0_q, l0_t, l1_q, l1_t, l2_q, l2_t, l3_q, l3_t, q_gt, t_gt, w_x, w_q):
+    """get_loss's arithmetic on the device in one launch (arguments in get_loss's order)."""
+    L.require_gpu(l0_q, q_gt, w_x)
+    B = q_gt.shape[0]
+    poses = [_f32(x.reshape(B, n))[0] for x, n in ((l0_q, 4), (l0_t, 3), (l1_q, 4), (l1_t, 3), (l2_q, 4), (l2_t, 3), (l3_q, 4), (l3_t, 3))]
+    return _PoseLoss.apply(w_x, w_q, _f32(q_gt.reshape(B, 4))[0], _f32(t_gt.reshape(B, 3))[0], *poses)
 
 
 class ProjectionBuffers:

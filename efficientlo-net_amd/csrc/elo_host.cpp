@@ -27,5 +27,5 @@ int check_launch(const char *what)
 
 }  // namespace elo
 
-extern "C" int elo_abi_version(void) { return 18; }
+extern "C" int elo_abi_version(void) { return 19; }
 extern "C" const char *elo_last_error(void) { return elo::err_buf(); }

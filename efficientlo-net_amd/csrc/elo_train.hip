@@ -440,3 +440,275 @@ extern "C" int elo_dense_weight_grad(const elo_weight_grad_args *a, elo_stream_t
     hipLaunchKernelGGL(slices_combine_kernel, dim3(bw + bb), dim3(TB), 0, s, a->scratch, slices, n, a->dW, bw, bpart, (long)a->Cout, a->db);
     return check_launch(who);
 }
+
+// ================================================================ Adam over ONE flat parameter buffer
+// main.py:171-176 (tf.train.AdamOptimizer): all 382 variables of the model are views of one contiguous fp32 buffer (and so
+// are their gradients -- distributed.FlatGradBucket -- and the two moment buffers), so an optimiser step is ONE elementwise
+// launch over 899 134 floats instead of torch's ~46 multi-tensor launches.  The step's scalars (learning rate over the
+// first-moment bias correction, the second-moment bias correction, epsilon) are computed by the host in double precision
+// and handed over in a 4-float device buffer the captured graph reads (one async copy per step; it also replaces the
+// learning-rate fill).  The arithmetic is torch.optim.Adam's (amsgrad off, no weight decay):
+//     m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                        float *__restrict__ v, long n, const float *__restrict__ hyper, float b1, float b2)
+{
+    const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1], eps = hyper[2];
+    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 4 <= n) {
+        const float4 gv = *reinterpret_cast<const float4 *>(g + i4);
+        float4 mv = *reinterpret_cast<float4 *>(m + i4), vv = *reinterpret_cast<float4 *>(v + i4), pv = *reinterpret_cast<float4 *>(p + i4);
+        auto upd = [&](float &pp, float gg, float &mm, float &vq) {
+            mm = b1 * mm + (1.0f - b1) * gg;
+            vq = b2 * vq + (1.0f - b2) * gg * gg;
+            pp -= step_size * (mm / (sqrtf(vq) * inv_sqrt_bc2 + eps));
+        };
+        upd(pv.x, gv.x, mv.x, vv.x); upd(pv.y, gv.y, mv.y, vv.y); upd(pv.z, gv.z, mv.z, vv.z); upd(pv.w, gv.w, mv.w, vv.w);
+        *reinterpret_cast<float4 *>(m + i4) = mv; *reinterpret_cast<float4 *>(v + i4) = vv; *reinterpret_cast<float4 *>(p + i4) = pv;
+    } else {
+        for (long i = i4; i < n; ++i) {
+            const float gg = g[i];
+            const float mm = b1 * m[i] + (1.0f - b1) * gg, vq = b2 * v[i] + (1.0f - b2) * gg * gg;
+            m[i] = mm; v[i] = vq;
+            p[i] -= step_size * (mm / (sqrtf(vq) * inv_sqrt_bc2 + eps));
+        }
+    }
+}
+
+extern "C" int elo_adam_flat(const elo_adam_flat_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_adam_flat";
+    if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
+    if (a->n < 0) return fail(ELO_ERR_ARG, "%s: bad size", who);
+    if (a->n == 0) return ELO_OK;
+    if (!a->param || !a->grad || !a->exp_avg || !a->exp_avg_sq || !a->hyper) return fail(ELO_ERR_ARG, "%s: null tensor pointer", who);
+    if (((uintptr_t)a->param | (uintptr_t)a->grad | (uintptr_t)a->exp_avg | (uintptr_t)a->exp_avg_sq) % 16)
+        return fail(ELO_ERR_ARG, "%s: the flat buffers must be 16-byte aligned", who);
+    const long quads = (a->n + 3) / 4;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a->param, a->grad, a->exp_avg,
+                       a->exp_avg_sq, a->n, a->hyper, a->beta1, a->beta2);
+    return check_launch(who);
+}
+
+// ================================================================ the per-pair pose algebra of a training step
+// pwclo_model.py:197-208, :262-280 (pose head -> normalise -> compose with the coarse pose) and :437-481 (get_loss) are a
+// few dozen scalars per frame pair, which torch runs as ~60 eight-element kernels per level forward and twice that
+// backward: ~800 of a training step's ~2000 launches (tools/train_op_counts.py).  Here: one thread per batch element, the
+// whole chain in registers, one launch forward and one backward (the adjoints are written out by hand, operator by operator,
+// and checked against torch.autograd in float64: tests/test_train_kernels_gpu.py).
+namespace {
+struct Q4 { float v[4]; };
+__device__ __forceinline__ float ham_sign(int k, int i)
+{
+    // component k of a (x) b = sum_i sign[k][i] * a_i * b_(i ^ k)   (model_util._hamilton)
+    const unsigned neg = 0x428eu;            // bit (4k + i) set: the term is negative  [k=0: i=1,2,3 | k=1: i=3 | k=2: i=1 | k=3: i=2]
+    return (neg >> (4 * k + i)) & 1u ? -1.0f : 1.0f;
+}
+__device__ __forceinline__ Q4 ham(const Q4 &a, const Q4 &b)
+{
+    Q4 c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += ham_sign(k, i) * a.v[i] * b.v[i ^ k];
+        c.v[k] = s;
+    }
+    return c;
+}
+// adjoint of c = a (x) b: ga += dL/da, gb += dL/db for the incoming gc
+__device__ __forceinline__ void ham_bwd(const Q4 &a, const Q4 &b, const Q4 &gc, Q4 &ga, Q4 &gb)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float w = ham_sign(k, i) * gc.v[k];
+            ga.v[i] += w * b.v[i ^ k];
+            gb.v[i ^ k] += w * a.v[i];
+        }
+}
+// y = q / (sqrt(sum q^2 + 1e-10) + 1e-10)   (pwclo_model.py:206)
+__device__ __forceinline__ Q4 normalise(const Q4 &q)
+{
+    const float n = sqrtf(q.v[0] * q.v[0] + q.v[1] * q.v[1] + q.v[2] * q.v[2] + q.v[3] * q.v[3] + 1e-10f), d = n + 1e-10f;
+    return Q4{{q.v[0] / d, q.v[1] / d, q.v[2] / d, q.v[3] / d}};
+}
+__device__ __forceinline__ void normalise_bwd(const Q4 &q, const Q4 &gy, Q4 &gq)
+{
+    const float n = sqrtf(q.v[0] * q.v[0] + q.v[1] * q.v[1] + q.v[2] * q.v[2] + q.v[3] * q.v[3] + 1e-10f), d = n + 1e-10f;
+    const float dot = gy.v[0] * q.v[0] + gy.v[1] * q.v[1] + gy.v[2] * q.v[2] + gy.v[3] * q.v[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gq.v[i] += gy.v[i] / d - dot / (d * d) * (q.v[i] / n);
+}
+// y = conj(q) / (sum q^2 + 1e-10)   (model_util.py:61-69)
+__device__ __forceinline__ Q4 inverse(const Q4 &q)
+{
+    const float s = q.v[0] * q.v[0] + q.v[1] * q.v[1] + q.v[2] * q.v[2] + q.v[3] * q.v[3] + 1e-10f;
+    return Q4{{q.v[0] / s, -q.v[1] / s, -q.v[2] / s, -q.v[3] / s}};
+}
+__device__ __forceinline__ void inverse_bwd(const Q4 &q, const Q4 &gy, Q4 &gq)
+{
+    const float s = q.v[0] * q.v[0] + q.v[1] * q.v[1] + q.v[2] * q.v[2] + q.v[3] * q.v[3] + 1e-10f;
+    const float c[4] = {q.v[0], -q.v[1], -q.v[2], -q.v[3]};
+    const float dot = gy.v[0] * c[0] + gy.v[1] * c[1] + gy.v[2] * c[2] + gy.v[3] * c[3];
+    const float gs = -dot / (s * s);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gq.v[i] += (i == 0 ? 1.0f : -1.0f) * gy.v[i] / s + gs * 2.0f * q.v[i];
+}
+
+// forward of one batch element; `coarse`: the l3 head (no composition: q = normalise(q_raw), t = t_det)
+struct PoseFwd { Q4 q_det, qi, p1, q, q_norm; float t[3]; };
+__device__ __forceinline__ PoseFwd pose_forward(const Q4 &qr, const float (&td)[3], const Q4 &qc, const float (&tc)[3], bool coarse)
+{
+    PoseFwd f;
+    f.q_det = normalise(qr);
+    if (coarse) {
+        f.q = f.q_det;
+        f.t[0] = td[0]; f.t[1] = td[1]; f.t[2] = td[2];
+    } else {
+        f.qi = inverse(f.q_det);
+        const Q4 P{{0.0f, tc[0], tc[1], tc[2]}};
+        f.p1 = ham(f.q_det, P);                            // :275-277: t_coarse rotated by q_det
+        const Q4 p2 = ham(f.p1, f.qi);
+        f.q = ham(f.q_det, qc);                            // :279
+        f.t[0] = p2.v[1] + td[0]; f.t[1] = p2.v[2] + td[1]; f.t[2] = p2.v[3] + td[2];     // :280
+    }
+    f.q_norm = normalise(f.q);
+    return f;
+}
+}  // namespace
+
+__global__ void pose_compose_kernel(const elo_pose_compose_args a)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.batch) return;
+    const bool coarse = a.q_coarse == nullptr;
+    Q4 qr, qc{{1.0f, 0.0f, 0.0f, 0.0f}};
+    float td[3], tc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qr.v[i] = a.q_raw[b * 4 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) td[i] = a.t_det[b * 3 + i];
+    if (!coarse) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qc.v[i] = a.q_coarse[b * 4 + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tc[i] = a.t_coarse[b * 3 + i];
+    }
+    const PoseFwd f = pose_forward(qr, td, qc, tc, coarse);
+    if (!a.grad_q) {                                           // ---- forward
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a.q[b * 4 + i] = f.q.v[i]; a.q_norm[b * 4 + i] = f.q_norm.v[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a.t[b * 3 + i] = f.t[i];
+        return;
+    }
+    // ---- backward: incoming (grad_q, grad_t, grad_q_norm) -> (grad_q_raw, grad_t_det, grad_q_coarse, grad_t_coarse)
+    Q4 gq, gqn, gq_det{{0, 0, 0, 0}}, gqc{{0, 0, 0, 0}}, gqr{{0, 0, 0, 0}};
+    float gt[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { gq.v[i] = a.grad_q[b * 4 + i]; gqn.v[i] = a.grad_q_norm[b * 4 + i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gt[i] = a.grad_t[b * 3 + i];
+    normalise_bwd(f.q, gqn, gq);                               // q_norm = normalise(q)
+    if (coarse) {
+        gq_det = gq;                                           // q = q_det
+    } else {
+        Q4 gP{{0, 0, 0, 0}}, gp1{{0, 0, 0, 0}}, gqi{{0, 0, 0, 0}};
+        ham_bwd(f.q_det, qc, gq, gq_det, gqc);                 // q = q_det (x) q_coarse
+        const Q4 gp2{{0.0f, gt[0], gt[1], gt[2]}};             // t = p2[1:] + t_det
+        ham_bwd(f.p1, f.qi, gp2, gp1, gqi);                    // p2 = p1 (x) qi
+        const Q4 P{{0.0f, tc[0], tc[1], tc[2]}};
+        ham_bwd(f.q_det, P, gp1, gq_det, gP);                  // p1 = q_det (x) P
+        inverse_bwd(f.q_det, gqi, gq_det);                     // qi = inverse(q_det)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a.grad_q_coarse[b * 4 + i] = gqc.v[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a.grad_t_coarse[b * 3 + i] = gP.v[1 + i];
+    }
+    normalise_bwd(qr, gq_det, gqr);                            // q_det = normalise(q_raw)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.grad_q_raw[b * 4 + i] = gqr.v[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.grad_t_det[b * 3 + i] = gt[i];
+}
+
+extern "C" int elo_pose_compose(const elo_pose_compose_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_pose_compose";
+    if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
+    if (a->batch <= 0) return a->batch == 0 ? ELO_OK : fail(ELO_ERR_ARG, "%s: bad batch", who);
+    if (!a->q_raw || !a->t_det || (!a->q_coarse != !a->t_coarse)) return fail(ELO_ERR_ARG, "%s: null tensor pointer", who);
+    if (a->grad_q) {
+        if (!a->grad_t || !a->grad_q_norm || !a->grad_q_raw || !a->grad_t_det || (a->q_coarse && (!a->grad_q_coarse || !a->grad_t_coarse)))
+            return fail(ELO_ERR_ARG, "%s: backward needs every gradient pointer", who);
+    } else if (!a->q || !a->t || !a->q_norm) return fail(ELO_ERR_ARG, "%s: null output pointer", who);
+    hipLaunchKernelGGL(pose_compose_kernel, dim3((unsigned)((a->batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, *a);
+    return check_launch(who);
+}
+
+// get_loss (pwclo_model.py:437-481) over the four levels in one workgroup; backward (grad_out given): the same kernel
+// writes the gradients of the eight pose tensors and of (w_x, w_q), scaled by the incoming scalar gradient.
+__global__ __launch_bounds__(64) void pose_loss_kernel(const elo_pose_loss_args a)
+{
+    const int b = threadIdx.x, B = a.batch;
+    const float wx = *a.w_x, wq = *a.w_q, ex = expf(-wx), eq = expf(-wq);
+    const float weight[4] = {0.2f, 0.4f, 0.8f, 1.6f};         // l0 .. l3  (:478-481)
+    const float go = a.grad_out ? *a.grad_out : 0.0f;
+    float loss = 0.0f, gwx = 0.0f, gwq = 0.0f;                 // (per thread: its batch elements' share)
+    for (int lv = 0; lv < 4; ++lv) {
+        float lq = 0.0f, lx = 0.0f;
+        for (int e = b; e < B; e += 64) {
+            Q4 q, gt4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { q.v[i] = a.q[lv][e * 4 + i]; gt4.v[i] = a.q_gt[e * 4 + i]; }
+            const Q4 qn = normalise(q);                        // :443 (the model's output is normalised once more)
+            float d[4], s = 1e-10f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { d[i] = gt4.v[i] - qn.v[i]; s += d[i] * d[i]; }
+            const float nq = sqrtf(s);
+            lq += nq;
+            float dx[3], rx[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { dx[i] = a.t[lv][e * 3 + i] - a.t_gt[e * 3 + i]; rx[i] = sqrtf(dx[i] * dx[i] + 1e-10f); lx += rx[i]; }
+            if (a.grad_out) {
+                // d level / d loss_q = exp(-w_q) / B; loss_q element = sqrt(sum d^2 + 1e-10), d = q_gt - normalise(q)
+                const float cq = go * weight[lv] * eq / B;
+                Q4 gqn, gq{{0, 0, 0, 0}};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gqn.v[i] = -cq * d[i] / nq;
+                normalise_bwd(q, gqn, gq);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a.grad_q[lv][e * 4 + i] = gq.v[i];
+                const float cx = go * weight[lv] * ex / (3.0f * B);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) a.grad_t[lv][e * 3 + i] = cx * dx[i] / rx[i];
+            }
+        }
+        // sums over the batch: a 64-lane butterfly (one wave)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lq += __shfl_xor(lq, o); lx += __shfl_xor(lx, o); }
+        const float loss_q = lq / B, loss_x = lx / (3.0f * B);
+        loss += weight[lv] * (loss_x * ex + wx + loss_q * eq + wq);
+        gwx += weight[lv] * (1.0f - loss_x * ex);
+        gwq += weight[lv] * (1.0f - loss_q * eq);
+    }
+    if (b == 0) {
+        if (a.grad_out) { *a.grad_w_x = go * gwx; *a.grad_w_q = go * gwq; }
+        else *a.loss = loss;
+    }
+}
+
+extern "C" int elo_pose_loss(const elo_pose_loss_args *a, elo_stream_t stream)
+{
+    const char *who = "elo_pose_loss";
+    if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
+    if (a->batch <= 0) return fail(ELO_ERR_ARG, "%s: bad batch", who);
+    for (int lv = 0; lv < 4; ++lv)
+        if (!a->q[lv] || !a->t[lv] || (a->grad_out && (!a->grad_q[lv] || !a->grad_t[lv]))) return fail(ELO_ERR_ARG, "%s: null tensor pointer", who);
+    if (!a->q_gt || !a->t_gt || !a->w_x || !a->w_q || (a->grad_out ? (!a->grad_w_x || !a->grad_w_q) : !a->loss))
+        return fail(ELO_ERR_ARG, "%s: null tensor pointer", who);
+    hipLaunchKernelGGL(pose_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a);
+    return check_launch(who);
+}

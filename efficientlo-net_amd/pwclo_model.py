@@ -159,16 +159,16 @@ def _normalise_q(q):
     return q / (torch.sqrt((q * q).sum(-1, keepdim=True) + 1e-10) + 1e-10)
 
 
-def _pose_head(feat_b1c, level, coarse, is_training):
+def _pose_head(feat_b1c, level, coarse, is_training, raw=False):
     """pwclo_model.py:197-208 (l3) and :264-273 / :340-349 / :408-417 (refinement levels)."""
     # (the reference leaves is_training at its default for these BN-free layers; here it also selects the autograd path)
     big = tf_util.conv1d(feat_b1c, 256, 1, padding='VALID', activation_fn=None, scope='l%d_big' % level, is_training=is_training)
     if is_training:
         big = torch.nn.functional.dropout(big, p=0.5, training=True)                                # :199
     qn, tn = ('l%d_q_coarse', 'l%d_t_coarse') if coarse else ('l%d_q_det', 'l%d_t_det')
-    q = _normalise_q(tf_util.conv1d(big, 4, 1, padding='VALID', activation_fn=None, scope=qn % level, is_training=is_training))
+    q = tf_util.conv1d(big, 4, 1, padding='VALID', activation_fn=None, scope=qn % level, is_training=is_training)
     t = tf_util.conv1d(big, 3, 1, padding='VALID', activation_fn=None, scope=tn % level, is_training=is_training)
-    return q, t
+    return (q if raw else _normalise_q(q)), t
 
 
 def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training, pose7=None, clear=None, warp=None, direct=False):
@@ -187,6 +187,11 @@ def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training,
         nxt = perm.tail_refresh_args() if level == 0 else None
         return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7, clear, warp, nxt, direct)
     summed = softmax_valid(feature_bnc=predict, weight_bnc=weight, mask_valid=xyz)                  # :194 / :262
+    if predict.is_cuda and pose7 is None:
+        # the pose algebra of :206-208 / :271-280 in ONE launch forward and one backward (_ops.pose_compose; the literal chain
+        # below is ~60 + ~120 eight-element torch kernels per level)
+        q_raw, t_det = _pose_head(summed, level, coarse, is_training, raw=True)                     # :197-205 / :264-270
+        return _ops.pose_compose(q_raw, t_det, q_coarse, t_coarse)
     q_det, t_det = _pose_head(summed, level, coarse, is_training)                                   # :197-208 / :264-273
     if coarse:
         q = q_det.squeeze(1)
@@ -422,6 +427,8 @@ def get_model(point_cloud, H_input, W_input, T_gt, T_trans, T_trans_inv, is_trai
 
 def get_loss(l0_q, l0_t, l1_q, l1_t, l2_q, l2_t, l3_q, l3_t, q_gt, t_gt, w_x, w_q):
     """pwclo_model.py:437-481."""
+    if l0_q.is_cuda and w_x.is_cuda and w_x.dim() == 0:
+        return _ops.pose_loss(l0_q, l0_t, l1_q, l1_t, l2_q, l2_t, l3_q, l3_t, q_gt, t_gt, w_x, w_q)   # one launch each way
     t_gt = t_gt.squeeze(-1)
 
     def level(q, t):

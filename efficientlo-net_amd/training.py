@@ -50,6 +50,69 @@ def data_augmentation(rng=None):
     return T
 
 
+class FlatAdam:
+    """Adam (torch.optim.Adam's arithmetic, betas 0.9 / 0.999, eps 1e-8; main.py:171-176) as ONE launch per step: the
+    parameters are re-seated as views of one flat fp32 buffer (as FlatGradBucket does for the gradients), the two moment
+    buffers are flat as well, and `elo_adam_flat` walks all 899 134 floats at once -- torch's foreach Adam is ~46 launches
+    for the 382 tensors.  The step's scalars go to the device in ONE small async copy (`hyper`), which also makes the
+    optimiser capturable: a hipGraph reads them, the host rewrites them before every replay."""
+
+    def __init__(self, params, bucket, lr=BASE_LEARNING_RATE, betas=(0.9, 0.999), eps=1e-8):
+        from . import _lib
+        self._lib = _lib
+        self.params, self.bucket, self.lr, self.betas, self.eps = [p for p in params if p.requires_grad], bucket, lr, betas, eps
+        dev = self.params[0].device
+        n = bucket.flat.numel()
+        self.flat = torch.empty((n,), dtype=torch.float32, device=dev)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.views_m, self.views_v = [], []
+        off = 0
+        with torch.no_grad():
+            for p in self.params:                              # the variables move into the flat buffer (same values, same objects)
+                k = p.numel()
+                view = self.flat[off:off + k].view_as(p)
+                view.copy_(p)
+                p.data = view
+                self.views_m.append(self.exp_avg[off:off + k].view_as(p))
+                self.views_v.append(self.exp_avg_sq[off:off + k].view_as(p))
+                off += k
+        self.t = 0                                             # steps taken (the bias corrections' exponent)
+        self.hyper = torch.zeros((4,), dtype=torch.float32, device=dev)
+        self._host = torch.zeros((4,), dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros((4,))
+        self._args = _lib.AdamFlatArgs(n, self.flat.data_ptr(), bucket.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                       self.exp_avg_sq.data_ptr(), self.hyper.data_ptr(), betas[0], betas[1])
+
+    def set_hyper(self):
+        """The scalars of step t + 1 to the device (call before step(), or before replaying a graph that recorded it)."""
+        t = self.t + 1
+        self._host[0] = self.lr / (1.0 - self.betas[0] ** t)
+        self._host[1] = 1.0 / math.sqrt(1.0 - self.betas[1] ** t)
+        self._host[2] = self.eps
+        self.hyper.copy_(self._host, non_blocking=True)
+        self.t = t
+
+    def launch(self):
+        """The update itself (the launch a captured training step records)."""
+        self._lib.call("elo_adam_flat", self._args, self.flat)
+
+    def step(self):
+        self.set_hyper()
+        self.launch()
+
+    def state_dict(self):
+        """{"state": {i: {"step", "exp_avg", "exp_avg_sq"}}} as torch.optim's, the moments as views of the flat buffers."""
+        return {"state": {i: {"step": torch.tensor(float(self.t)), "exp_avg": m, "exp_avg_sq": v}
+                          for i, (m, v) in enumerate(zip(self.views_m, self.views_v))}}
+
+    def load_state(self, moments_m, moments_v, t):
+        with torch.no_grad():
+            for i, (m, v) in enumerate(zip(self.views_m, self.views_v)):
+                if i in moments_m:
+                    m.copy_(torch.as_tensor(moments_m[i]).reshape(m.shape))
+                    v.copy_(torch.as_tensor(moments_v[i]).reshape(v.shape))
+        self.t = int(t)
+
+
 class Trainer:
     def __init__(self, net, capturable=False):
         """`capturable`: Adam keeps its step counts and learning rate on the device, so that a whole optimisation step
@@ -63,11 +126,7 @@ class Trainer:
         self.w_q = torch.nn.Parameter(torch.tensor(-2.5, device=dev))    # main.py:152
         self.params = net.store.parameters() + [self.w_x, self.w_q]      # 382 tensors, 899 134 values
         self.bucket = FlatGradBucket(self.params)
-        if capturable:
-            self._lr = torch.tensor(BASE_LEARNING_RATE, device=dev)
-            self.opt = torch.optim.Adam(self.params, lr=self._lr, capturable=True)
-        else:
-            self.opt = torch.optim.Adam(self.params, lr=BASE_LEARNING_RATE)  # main.py:174
+        self.opt = FlatAdam(self.params, self.bucket, lr=BASE_LEARNING_RATE)   # main.py:174; one launch per step, capturable as it is
         self.step_count = 0
 
     def _global_batch(self, B):
@@ -75,12 +134,7 @@ class Trainer:
         return B * self.bucket.world_size()
 
     def _set_lr(self, B):
-        lr = learning_rate(self.step_count, self._global_batch(B))
-        if self.capturable:
-            self._lr.fill_(lr)
-        else:
-            for g in self.opt.param_groups:
-                g["lr"] = lr
+        self.opt.lr = learning_rate(self.step_count, self._global_batch(B))     # (reaches the device with the step's other scalars)
 
     def _gradients(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, decay):
         """zero grads -> forward -> loss -> backward: this rank's gradients, in the flat bucket."""
@@ -98,13 +152,14 @@ class Trainer:
         """gradients -> all-reduce -> Adam: everything of a step that runs on the GPU."""
         loss = self._gradients(xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, decay)
         self.bucket.all_reduce_mean()                                    # the one collective of a training step
-        self.opt.step()
+        self.opt.launch()                                                # (its scalars: opt.set_hyper(), outside a captured graph)
         return loss
 
     def step(self, xyz_f1_proj, xyz_f2_proj, q_gt, t_gt):
         """One optimisation step on this rank's batch; returns the (local) loss."""
         B = xyz_f1_proj.shape[0]
         self._set_lr(B)
+        self.opt.set_hyper()
         self.net.perms.reshuffle()                                       # tf.random_shuffle draws per step
         loss = self._body(xyz_f1_proj, xyz_f2_proj, q_gt, t_gt, bn_decay(self.step_count, self._global_batch(B)))
         self.net.store.invalidate()                                      # folded / packed inference weights are stale
@@ -145,13 +200,18 @@ class Trainer:
         if self._split:
             self._graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_opt):
-                self.opt.step()
+                self.opt.launch()
+        # the graphs hold raw device pointers into the module-level index / decoded-order caches, which evict when they grow:
+        # keep what they point at alive for as long as the graphs exist (model._cached_tensors, as the inference lanes do)
+        from . import model
+        self._keep = model._cached_tensors()
         self.net.store.invalidate()
         self.step_count += 1                                             # the capture itself does not run the step...
         self._replay()                                                   # ... this replay does
         return self
 
     def _replay(self):
+        self.opt.set_hyper()
         self._graph.replay()
         if self._split:
             self.bucket.all_reduce_mean()
@@ -183,11 +243,10 @@ class Trainer:
             shapes = self.net.store.tf_shapes
             return tf_checkpoint.save_checkpoint(path, {k: v.reshape(shapes.get(k, v.shape)) for k, v in state.items()})
         opt = self.opt.state_dict()["state"]
-        for i, p in enumerate(self.params):
-            if i in opt:
-                state["adam_m/%d" % i] = opt[i]["exp_avg"].cpu().numpy()
-                state["adam_v/%d" % i] = opt[i]["exp_avg_sq"].cpu().numpy()
-                state["adam_t/%d" % i] = np.asarray(float(opt[i]["step"]))
+        for i, p in enumerate(self.opt.params):
+            state["adam_m/%d" % i] = opt[i]["exp_avg"].cpu().numpy()
+            state["adam_v/%d" % i] = opt[i]["exp_avg_sq"].cpu().numpy()
+            state["adam_t/%d" % i] = np.asarray(float(opt[i]["step"]))
         state["step_count"] = np.asarray(self.step_count)
         np.savez(path, **state)
         return sorted(state)
@@ -205,15 +264,9 @@ class Trainer:
             adam = {k: state.pop(k) for k in list(state) if k.startswith("adam_")}
             self.step_count = int(state.pop("step_count", 0))
             self.net.store.load_state_dict(state)
-            dev = self.net.device
-            opt_state = self.opt.state_dict()
-            for i, p in enumerate(self.params):
-                if "adam_m/%d" % i in adam:
-                    opt_state["state"][i] = {"step": torch.tensor(float(adam["adam_t/%d" % i]),
-                                                                  device=dev if self.capturable else "cpu"),
-                                             "exp_avg": torch.from_numpy(adam["adam_m/%d" % i]).to(dev),
-                                             "exp_avg_sq": torch.from_numpy(adam["adam_v/%d" % i]).to(dev)}
-            self.opt.load_state_dict(opt_state)
+            idx = [i for i in range(len(self.opt.params)) if "adam_m/%d" % i in adam]
+            self.opt.load_state({i: adam["adam_m/%d" % i] for i in idx}, {i: adam["adam_v/%d" % i] for i in idx},
+                                max([float(adam["adam_t/%d" % i]) for i in idx], default=0.0))
         with torch.no_grad():
             if "w_x" in extra:
                 self.w_x.copy_(torch.as_tensor(extra["w_x"]).reshape(()))

@@ -501,6 +501,50 @@ typedef struct elo_weight_grad_args {
 int elo_weight_grad_slices(long rows, int Cin, int Cout);
 int elo_dense_weight_grad(const elo_weight_grad_args *a, elo_stream_t stream);
 
+/* Adam (torch.optim.Adam's arithmetic; the reference trains with tf.train.AdamOptimizer, main.py:171-176) over ONE flat
+ * fp32 parameter buffer in one launch: every variable, its gradient and its two moments are views of four buffers of n
+ * floats.  hyper (device, 4 floats, written by the host before the step): [lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), eps, -]. */
+typedef struct elo_adam_flat_args {
+    long n;
+    float *param;                 /* (n) IN/OUT */
+    const float *grad;            /* (n)        */
+    float *exp_avg;               /* (n) IN/OUT */
+    float *exp_avg_sq;            /* (n) IN/OUT */
+    const float *hyper;           /* (4) device */
+    float beta1, beta2;
+} elo_adam_flat_args;
+int elo_adam_flat(const elo_adam_flat_args *a, elo_stream_t stream);
+
+/* The per-pair pose algebra of a TRAINING step in one launch each way (inference has it inside pose_head_kernel):
+ * q_det = normalise(q_raw); coarse level (q_coarse == NULL): q = q_det, t = t_det; refinement level: q = q_det (x) q_coarse,
+ * t = (q_det (x) [0, t_coarse] (x) q_det^-1)[1:] + t_det; q_norm = normalise(q)   (pwclo_model.py:197-208, :262-280;
+ * model_util.py:17-69).  Forward: grad_q == NULL, writes q, t, q_norm.  Backward: grad_q / grad_t / grad_q_norm given (all
+ * three), writes grad_q_raw, grad_t_det and (refinement level) grad_q_coarse, grad_t_coarse.  All tensors (batch,4) / (batch,3) fp32. */
+typedef struct elo_pose_compose_args {
+    int batch;
+    const float *q_raw, *t_det, *q_coarse, *t_coarse;
+    float *q, *t, *q_norm;
+    const float *grad_q, *grad_t, *grad_q_norm;
+    float *grad_q_raw, *grad_t_det, *grad_q_coarse, *grad_t_coarse;
+} elo_pose_compose_args;
+int elo_pose_compose(const elo_pose_compose_args *a, elo_stream_t stream);
+
+/* get_loss (pwclo_model.py:437-481): per level L_q = mean_b |q_gt - normalise(q)|_2 (+1e-10 under the root), L_x = mean
+ * sqrt((t - t_gt)^2 + 1e-10), level = L_x e^-w_x + w_x + L_q e^-w_q + w_q; loss = 0.2 l0 + 0.4 l1 + 0.8 l2 + 1.6 l3.
+ * q[lv] / t[lv]: level lv = 0..3 (batch,4) / (batch,3).  Forward: grad_out == NULL, writes *loss.  Backward: grad_out (the
+ * incoming scalar gradient, device) given, writes grad_q[lv], grad_t[lv], *grad_w_x, *grad_w_q. */
+typedef struct elo_pose_loss_args {
+    int batch;
+    const float *q[4], *t[4];
+    const float *q_gt, *t_gt;     /* (batch,4), (batch,3) */
+    const float *w_x, *w_q;       /* scalars (device) */
+    float *loss;
+    const float *grad_out;
+    float *grad_q[4], *grad_t[4];
+    float *grad_w_x, *grad_w_q;
+} elo_pose_loss_args;
+int elo_pose_loss(const elo_pose_loss_args *a, elo_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * Fused inference kernels: gather/encode -> chain of 1x1 convolutions (BN and
  * bias folded, ReLU) -> pooling, in ONE launch with the activations of a

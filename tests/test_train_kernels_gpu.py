@@ -113,3 +113,66 @@ def test_training_layer_matches_the_oracle():
     assert np.abs(y.detach().cpu().numpy() - want_y).max() <= 1e-4 * max(1.0, np.abs(want_y).max())
     assert np.allclose(store.buffers["l/bn/moving_mean"].cpu().numpy(), want_mm, atol=1e-5, rtol=1e-5)
     assert np.allclose(store.buffers["l/bn/moving_variance"].cpu().numpy(), want_mv, atol=1e-5, rtol=1e-5)
+
+
+def _literal_pose(q_raw, t_det, q_coarse, t_coarse):
+    """The reference's operator chain (pwclo_model.py:206-208, :271-280 on model_util.py:17-69) in torch, any dtype."""
+    pm, mu = load_pkg("pwclo_model"), load_pkg("model_util")
+    B = q_raw.shape[0]
+    q_det = pm._normalise_q(q_raw.reshape(B, 1, 4))
+    if q_coarse is None:
+        q = q_det.squeeze(1)
+        return q, t_det, pm._normalise_q(q)
+    tc = torch.cat([torch.zeros((B, 1, 1), dtype=q_raw.dtype), t_coarse.reshape(B, 1, 3)], -1)
+    tc = mu.mul_q_point(q_det, tc, B)
+    tc = mu.mul_point_q(tc, mu.inv_q(q_det, B), B)[:, :, 1:]
+    q = mu.mul_point_q(q_det, q_coarse.reshape(B, 1, 4), B).squeeze(1)
+    t = (tc + t_det.reshape(B, 1, 3)).squeeze(1)
+    return q, t, pm._normalise_q(q)
+
+
+@pytest.mark.parametrize("coarse", [True, False])
+def test_pose_compose_matches_the_literal_chain_and_its_gradients(coarse):
+    """_ops.pose_compose (elo_pose_compose: the pose algebra of a training step in one launch each way, adjoints written by
+    hand) against the reference's operator chain under torch.autograd in float64: values to 2e-6, every input gradient to 1e-5
+    of its scale, for arbitrary incoming gradients on all three outputs."""
+    ops = load_pkg("_ops")
+    rng = np.random.default_rng(11)
+    B = 9
+    mk = lambda *s: rng.normal(0, 1, s)
+    q_raw, t_det, q_c, t_c = mk(B, 4) * 2.0, mk(B, 3), mk(B, 4), mk(B, 3) * 3.0
+    gq, gt, gqn = mk(B, 4), mk(B, 3), mk(B, 4)
+    ins64 = [torch.tensor(x, dtype=torch.float64, requires_grad=True) for x in ((q_raw, t_det) if coarse else (q_raw, t_det, q_c, t_c))]
+    want = _literal_pose(ins64[0], ins64[1], None if coarse else ins64[2], None if coarse else ins64[3])
+    (want[0] * torch.tensor(gq) + 0).sum().add((want[1] * torch.tensor(gt)).sum()).add((want[2] * torch.tensor(gqn)).sum()).backward()
+    ins = [torch.tensor(x, dtype=torch.float32, device=DEV, requires_grad=True) for x in ((q_raw, t_det) if coarse else (q_raw, t_det, q_c, t_c))]
+    got = ops.pose_compose(ins[0], ins[1], None if coarse else ins[2], None if coarse else ins[3])
+    dev = lambda x: torch.tensor(x, dtype=torch.float32, device=DEV)
+    ((got[0] * dev(gq)).sum() + (got[1] * dev(gt)).sum() + (got[2] * dev(gqn)).sum()).backward()
+    for g, w in zip(got, want):
+        assert float((g.detach().cpu().double() - w.detach()).abs().max()) <= 2e-6 * max(1.0, float(w.detach().abs().max()))
+    for a, b in zip(ins, ins64):
+        scale = max(1e-3, float(b.grad.abs().max()))
+        assert float((a.grad.cpu().double() - b.grad).abs().max()) <= 1e-5 * scale, (coarse, a.shape)
+
+
+def test_pose_loss_matches_get_loss_and_its_gradients():
+    """_ops.pose_loss (elo_pose_loss) against get_loss's literal torch chain in float64: the value, and the gradients of all
+    eight pose tensors and of the two learnable loss weights (pwclo_model.py:437-481)."""
+    ops, pm = load_pkg("_ops"), load_pkg("pwclo_model")
+    rng = np.random.default_rng(12)
+    B = 8
+    poses = [rng.normal(0, 1, (B, 4 if i % 2 == 0 else 3)) for i in range(8)]
+    q_gt, t_gt = rng.normal(0, 1, (B, 4)), rng.normal(0, 1, (B, 3, 1))
+    p64 = [torch.tensor(x, dtype=torch.float64, requires_grad=True) for x in poses]
+    w64 = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (0.3, -2.5)]
+    want = pm.get_loss(*p64, torch.tensor(q_gt), torch.tensor(t_gt), *w64)       # (CPU tensors: the literal chain)
+    (want * 1.7).backward()
+    p32 = [torch.tensor(x, dtype=torch.float32, device=DEV, requires_grad=True) for x in poses]
+    w32 = [torch.tensor(v, dtype=torch.float32, device=DEV, requires_grad=True) for v in (0.3, -2.5)]
+    got = pm.get_loss(*p32, torch.tensor(q_gt, dtype=torch.float32, device=DEV), torch.tensor(t_gt, dtype=torch.float32, device=DEV), *w32)
+    (got * 1.7).backward()
+    assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want))
+    for a, b in zip(p32 + w32, p64 + w64):
+        scale = max(1e-4, float(b.grad.abs().max()))
+        assert float((a.grad.cpu().double() - b.grad).abs().max()) <= 1e-5 * scale

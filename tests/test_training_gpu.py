@@ -212,7 +212,9 @@ def test_captured_training_step_trains():
     start = tr.step_count
     losses = [float(tr.step_graph(a, b, q_gt, t_gt)) for _ in range(8)]
     assert tr.step_count == start + 8 and all(np.isfinite(losses)) and min(losses[4:]) < losses[0], losses
-    assert abs(float(tr._lr) - training.learning_rate(tr.step_count - 1, 2)) < 1e-9
+    lr = training.learning_rate(tr.step_count - 1, 2)
+    assert abs(tr.opt.lr - lr) < 1e-12 and tr.opt.t == tr.step_count           # the schedule; one Adam step per optimisation step
+    assert abs(float(tr.opt.hyper[0]) - lr / (1 - 0.9 ** tr.opt.t)) < 1e-9       # ... and what the captured launch reads
     g1, g2 = synth.frame_pair(2, 64, 900, seed=21)
     other = float(tr.step_graph(t(g1), t(g2), q_gt, t_gt))
     assert np.isfinite(other) and other != losses[-1]
