@@ -81,6 +81,10 @@ def parse():
                     help="pre-drawn window visiting orders per lane: every replay walks the next set (tf.random_shuffle per "
                          "sess.run, utils/pointnet_util.py:45,104,193,270: one tiny launch at the head of each replay); 0 = one "
                          "fixed draw for the life of the graph")
+    ap.add_argument("--submit-threads", type=int, default=1,
+                    help="host threads that enqueue the steps of a repeat (step i goes to thread i %% N).  Measured at the driver's "
+                         "--steps 20: 1 thread 9.65 k pairs/s, 2 threads 9.4-9.8 k, 4 threads 9.3 k, 8 threads 8.7 k -- the "
+                         "interpreter lock costs more than the staggered start of the four queues; default 1")
     ap.add_argument("--check-every", type=int, default=64,
                     help="every N-th replay of a lane runs the graph recorded on the range-checked kernels (the fp16 split's "
                          "production guard, PWCLONet.capture(check_every=N)); 0: off")
@@ -619,7 +623,7 @@ def main():
         def step(i):
             pose_log[i, :, 0] = 1.0
 
-        def begin_repeat():
+        def begin_repeat(reset=False):
             pass
 
         def end_repeat(n):
@@ -636,7 +640,8 @@ def main():
             net.forward(pool[0][:B], pool[0][B:])
         else:
             # a lane's l0 pose-head kernel writes replay r's [q | t] block into slot r of the lane's ring
-            net.capture(B, H, W, lanes=lanes, pose_ring=max(2, -(-max(args.steps, warmup) // lanes)), sample=pool[0],
+            per_lane = -(-args.steps // lanes)            # replays of a lane per repeat: this or one less -> slots a multiple of both
+            net.capture(B, H, W, lanes=lanes, pose_ring=max(2, -(-warmup // lanes), per_lane * max(1, per_lane - 1) * 2), sample=pool[0],
                         fresh_orders=args.fresh_orders, check_every=0 if args.products == "half" else args.check_every)
         # every step's l0 pose [q | t] is kept: one (B,7) row block per step in HBM, collected from the lanes' rings at
         # the end of each repeat INSIDE the timed region (one strided copy per lane; round 1-2 copied one block out per
@@ -651,10 +656,10 @@ def main():
                 return net.forward(pair[:B], pair[B:], pose_out=pose_log[i])
             return net.submit(i % lanes, pair)           # step i rides lane i % lanes: one copy in (the stacked pair), graph replay
 
-        def begin_repeat():
+        def begin_repeat(reset=False):
             if not args.no_graph:
-                for lane in range(lanes):
-                    net.reset_poses(lane)
+                for lane in range(lanes):                # (mark: host bookkeeping only -- no launch inside the timed region)
+                    net.reset_poses(lane) if reset else net.mark_poses(lane)
 
         def end_repeat(n):
             if not args.no_graph:
@@ -663,10 +668,53 @@ def main():
                         pose_log[lane:n:lanes].copy_(net.lane_poses(lane), non_blocking=True)
     gathered = [torch.empty_like(pose_log[:args.steps]) for _ in range(world)] if world > 1 else None
 
-    begin_repeat()
-    for i in range(warmup):
-        step(i)
+    # Host submission.  A step costs the host ~50 us (one copy + one graph launch), so with one submitting thread the four
+    # hardware queues receive their first forward of a repeat 50 us apart -- at the driver's 20 steps per repeat (2 ms) the
+    # last queue idles 150 us, 7 % of the repeat.  --submit-threads N (step i -> thread i % N; lane = i % lanes, queue =
+    # lane % 4: with N = 4 a thread feeds one queue, in order) was built to enqueue side by side and measured SLOWER (the
+    # Python part of a submit holds the interpreter lock: 9.65 k pairs/s with one thread, 9.3 k with four); kept as an option.
+    nthreads = 1 if (dry or args.no_graph) else max(1, min(args.submit_threads, lanes))
+    if lanes % nthreads:
+        nthreads = 1                                       # (a lane is fed by ONE thread: its host-side counters are not shared)
+    if nthreads > 1:
+        import threading
+        go, done = threading.Barrier(nthreads), threading.Barrier(nthreads)
+        job = {"n": 0, "stop": False, "err": None}
+
+        def worker(w):
+            torch.cuda.set_device(dev)
+            while True:
+                go.wait()
+                if job["stop"]:
+                    return
+                try:
+                    for i in range(w, job["n"], nthreads):
+                        step(i)
+                except Exception as e:                     # noqa: BLE001 -- reported by the main thread
+                    job["err"] = e
+                done.wait()
+        pool_threads = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(1, nthreads)]
+        for th in pool_threads:
+            th.start()
+
+        def submit_all(n):
+            job["n"] = n
+            go.wait()
+            for i in range(0, n, nthreads):
+                step(i)
+            done.wait()
+            if job["err"] is not None:
+                raise job["err"]
+    else:
+        def submit_all(n):
+            for i in range(n):
+                step(i)
+
+    begin_repeat(reset=True)
+    submit_all(warmup)
     end_repeat(warmup)
+    sync()
+    begin_repeat(reset=True)                              # (untimed: the rings start the timed repeats at slot 0)
     sync()
     if world > 1:
         dist.all_gather(gathered, pose_log[:args.steps].contiguous())     # untimed: RCCL sets its channels up on first use
@@ -677,8 +725,7 @@ def main():
             dist.barrier()
         t0 = time.perf_counter()
         begin_repeat()
-        for i in range(args.steps):
-            step(i)
+        submit_all(args.steps)
         end_repeat(args.steps)
         sync()
         if world > 1:
@@ -716,8 +763,8 @@ def main():
                                "set-upconv), %dx%d range-image pairs, batch %d per GPU, %s feature storage, "
                                "random-init weights, %s" % (H, W, B, "fp16" if args.features == "f16" else "fp32",
                                                            "eager launches" if args.no_graph else
-                                                           "hipGraph replay, %d forwards in flight%s" % (
-                                                               lanes, ", fresh visiting orders per replay (pool of %d)" % args.fresh_orders
+                                                           "hipGraph replay, %d forwards in flight fed by %d host thread%s%s" % (
+                                                               lanes, nthreads, "s" if nthreads > 1 else "", ", fresh visiting orders per replay (pool of %d)" % args.fresh_orders
                                                                if args.fresh_orders else ", one fixed draw of the visiting orders")),
                    "global_batch": B * world, "parallelism": "dp%d" % world},
     }

@@ -298,24 +298,35 @@ class PWCLONet:
         lane = self._lanes[lane_index]
         pose = lane["pose"]
         if isinstance(pose, _ops.PoseRing):
-            return pose.rows[(lane["replays"] - 1) % pose.slots]
+            return pose.rows[(lane.get("base", 0) + lane["replays"] - 1) % pose.slots]
         return pose
 
     def reset_poses(self, lane_index):
-        """Pose ring of the lane back to slot 0 (enqueued on the lane's stream)."""
+        """Pose ring of the lane back to slot 0 (one small launch, enqueued on the lane's stream)."""
         lane = self._lanes[lane_index]
         with torch.cuda.stream(lane["stream"]):
             lane["pose"].reset()
+        lane["replays"], lane["base"] = 0, 0
+
+    def mark_poses(self, lane_index):
+        """Start a new collection WITHOUT touching the device: lane_poses() then returns the rows of the replays from here
+        on (the device-side cursor keeps running; the host remembers which slot the next replay writes).  No launch -- a
+        stream of short collections (bench.py's 20-step repeats) paid one reset launch per lane and collection before."""
+        lane = self._lanes[lane_index]
+        ring = lane["pose"]
+        lane["base"] = (lane.get("base", 0) + lane["replays"]) % ring.slots
         lane["replays"] = 0
 
     def lane_poses(self, lane_index):
         """(n,B,7): the rows of the lane's replays since reset_poses (n <= R, oldest first); a view of the ring, valid
         once the lane's stream has been synchronised or waited on."""
         lane = self._lanes[lane_index]
-        ring, n = lane["pose"], lane["replays"]
+        ring, n, base = lane["pose"], lane["replays"], lane.get("base", 0)
         if n > ring.slots:
             raise RuntimeError("%d replays since reset_poses() on a ring of %d slots: rows were overwritten" % (n, ring.slots))
-        return ring.rows[:n]
+        if base + n <= ring.slots:
+            return ring.rows[base:base + n]
+        return torch.cat([ring.rows[base:], ring.rows[:base + n - ring.slots]], 0)        # (wrapped: a copy, on the current stream)
 
     def lane_stream(self, lane_index):
         return self._lanes[lane_index]["stream"]
