@@ -140,6 +140,12 @@ def _adjacent_frames(a, b):
     return None
 
 
+# Test hook: a list here receives (level, scratch, B, N, H, W, projected xyz grid) of every warp-refinement projection of an
+# eager inference forward -- `scratch` is elo_warp_project_args.scratch, whose words [B*H*W + 4B, B*H*W + 4B + B*N) are the
+# projection cell of every warped point: the product's own DISCRETE decisions (which cell, and through the grid which point
+# won it), for tests/test_parity_flips_gpu.py to compare with the oracle's.
+PROJECTION_TAP = None
+
 _ZEROS = {}
 
 
@@ -345,6 +351,8 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
         # warp by the coarse pose, zero invalid points, re-project with the level's features (:217-236)
         _warped, xyz_warp_proj_f1, points_warp_proj_f1 = warp_and_project(
             xyz_f1, pts_f1[level], q_coarse, t_coarse, out_h_list[g], out_w_list[g], next_buffers)
+        if PROJECTION_TAP is not None and next_buffers is not None:      # (parity tests: the cell every warped point landed in)
+            PROJECTION_TAP.append((level, next_buffers.scratch, batch_size, xyz_f1.shape[1], out_h_list[g], out_w_list[g], xyz_warp_proj_f1))
         next_buffers = projection_buffers(level - 1, g - 1) if level > 0 else None
         xyz_warp_f1 = xyz_warp_proj_f1.reshape(batch_size, -1, 3)
         points_warp_f1 = points_warp_proj_f1.reshape(batch_size, out_h_list[g] * out_w_list[g], -1)

@@ -53,12 +53,20 @@ class feature_storage:
 
 
 def _st(x):
-    return x.astype(F) if _STORE[-1] is None else x.astype(_STORE[-1]).astype(F)
+    if _STORE[-1] is None:
+        return x.astype(F)
+    stored = x.astype(_STORE[-1])
+    # the ROUNDING of a stored feature is a discrete decision too (one fp16 ulp is 5e-4 relative: a value that lands on the
+    # other side of a rounding boundary moves everything downstream by more than the parity tolerance): the trace keeps the
+    # stored bit patterns, so the parity statistic can count them
+    _rec("store", stored.view(np.uint16) if stored.dtype == np.float16 else stored)
+    return stored.astype(F)
 
 
 # DISCRETE decisions of a forward, recorded for the parity statistic (tests/test_parity_flips_gpu.py): every neighbour
-# index / mask tensor the two grouping ops return and every point -> cell assignment (and per-cell winner set) of a
-# projection, in call order, with the level marker get_model_from_projection sets.  Two oracle runs whose traces are equal
+# index / mask tensor the two grouping ops return, every point -> cell assignment (and per-cell winner set) of a
+# projection and -- with fp16 feature storage -- the bit pattern of every stored feature, in call order, with the level
+# marker get_model_from_projection sets.  Two oracle runs whose traces are equal
 # took the same discrete decisions everywhere; what is left between them is continuous in the inputs.
 _TRACE = [None]
 
@@ -363,10 +371,11 @@ def ProjectPC2SphericalRing(PC, Feature, H_input, W_input):
         iCol = np.clip(iCol, 0, W_input - 1)
         cell = iRow * W_input + iCol
         min_r_pt, out_xyz[b] = scatter_min_range(cell, r, cur, H_input * W_input, (H_input, W_input, 3))
-        _rec("cell", np.stack([cell, (r == min_r_pt).astype(np.int64)]))
+        _rec("cell", np.stack([cell, (r == min_r_pt).astype(np.int64), (r > 0).astype(np.int64)]))
         if Feature is not None:
             _, out_feat[b] = scatter_min_range(cell, r, Feature[b].astype(F), H_input * W_input,
                                                (H_input, W_input, Feature.shape[-1]))
+    _rec("grid", out_xyz)                                    # (continuous: compared with the product's grid by the parity statistic, not counted as decisions)
     return out_xyz, (_st(out_feat) if Feature is not None else out_xyz)
 
 

@@ -10,9 +10,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_parity_flips_gpu as T  # noqa: E402
 
-for B, seeds, features in ((1, range(200, 232), "f32"), (8, (300, 301, 302, 303), "f32"), (8, (310, 311), "f16")):
-    rows = T.statistic(B, list(seeds), features)
-    print(json.dumps({"batch": B, "features": features, "seeds": len(list(seeds)), **T.summarise(rows)}))
+for B, seeds, features, H, W in ((1, range(200, 232), "f32", 64, 1800), (8, (300, 301, 302, 303), "f32", 64, 1800), (8, (310, 311), "f16", 64, 1800),
+                                 (8, (320, 322), "f32", 128, 2048), (8, (321,), "f16", 128, 2048)):
+    rows = T.statistic(B, list(seeds), features, H, W)
+    print(json.dumps({"batch": B, "features": features, "grid": "%dx%d" % (H, W), "seeds": len(list(seeds)), **T.summarise(rows)}))
     for lvl in T.LEVELS:
         sub = [r for r in rows if r["level"] == lvl]
         print("   l%d: %d outputs, %d within 1e-4 free-running, worst forced %.2e, worst free %.2e" % (
