@@ -108,7 +108,7 @@ BnBackwardArgs = _struct("elo_bn_backward_args", [
     ("relu", _i), ("scratch", _vp), ("sums", _vp), ("dz", _vp)])
 AdamFlatArgs = _struct("elo_adam_flat_args", [
     ("n", ctypes.c_long), ("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("hyper", _vp),
-    ("beta1", _f), ("beta2", _f)])
+    ("beta1", _f), ("beta2", _f), ("one_minus_beta1", _f), ("one_minus_beta2", _f)])
 PoseComposeArgs = _struct("elo_pose_compose_args", [
     ("batch", _i), ("q_raw", _vp), ("t_det", _vp), ("q_coarse", _vp), ("t_coarse", _vp), ("q", _vp), ("t", _vp), ("q_norm", _vp),
     ("grad_q", _vp), ("grad_t", _vp), ("grad_q_norm", _vp), ("grad_q_raw", _vp), ("grad_t_det", _vp), ("grad_q_coarse", _vp),

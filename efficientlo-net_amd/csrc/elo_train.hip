@@ -450,7 +450,8 @@ extern "C" int elo_dense_weight_grad(const elo_weight_grad_args *a, elo_stream_t
 // learning-rate fill).  The arithmetic is torch.optim.Adam's (amsgrad off, no weight decay):
 //     m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-                                                        float *__restrict__ v, long n, const float *__restrict__ hyper, float b1, float b2)
+                                                        float *__restrict__ v, long n, const float *__restrict__ hyper, float b1, float b2,
+                                                        float c1, float c2)      // c = 1 - b, rounded from the host's double (1.0f - 0.999f is 4.7e-5 off)
 {
     const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1], eps = hyper[2];
     const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -459,8 +460,8 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, c
         const float4 gv = *reinterpret_cast<const float4 *>(g + i4);
         float4 mv = *reinterpret_cast<float4 *>(m + i4), vv = *reinterpret_cast<float4 *>(v + i4), pv = *reinterpret_cast<float4 *>(p + i4);
         auto upd = [&](float &pp, float gg, float &mm, float &vq) {
-            mm = b1 * mm + (1.0f - b1) * gg;
-            vq = b2 * vq + (1.0f - b2) * gg * gg;
+            mm = b1 * mm + c1 * gg;
+            vq = b2 * vq + c2 * gg * gg;
             pp -= step_size * (mm / (sqrtf(vq) * inv_sqrt_bc2 + eps));
         };
         upd(pv.x, gv.x, mv.x, vv.x); upd(pv.y, gv.y, mv.y, vv.y); upd(pv.z, gv.z, mv.z, vv.z); upd(pv.w, gv.w, mv.w, vv.w);
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, c
     } else {
         for (long i = i4; i < n; ++i) {
             const float gg = g[i];
-            const float mm = b1 * m[i] + (1.0f - b1) * gg, vq = b2 * v[i] + (1.0f - b2) * gg * gg;
+            const float mm = b1 * m[i] + c1 * gg, vq = b2 * v[i] + c2 * gg * gg;
             m[i] = mm; v[i] = vq;
             p[i] -= step_size * (mm / (sqrtf(vq) * inv_sqrt_bc2 + eps));
         }
@@ -486,7 +487,7 @@ extern "C" int elo_adam_flat(const elo_adam_flat_args *a, elo_stream_t stream)
         return fail(ELO_ERR_ARG, "%s: the flat buffers must be 16-byte aligned", who);
     const long quads = (a->n + 3) / 4;
     hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a->param, a->grad, a->exp_avg,
-                       a->exp_avg_sq, a->n, a->hyper, a->beta1, a->beta2);
+                       a->exp_avg_sq, a->n, a->hyper, a->beta1, a->beta2, a->one_minus_beta1, a->one_minus_beta2);
     return check_launch(who);
 }
 

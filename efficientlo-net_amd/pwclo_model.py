@@ -105,10 +105,23 @@ def set_concurrent_branches(flag):
     _CONCURRENT = bool(flag)
 
 
+# The same fork in TRAINING (ELO_TRAIN_BRANCHES=1 / set_training_branches): there a level's three branches (cost volume,
+# embedding and embedding-mask set-upconv) and its two predictors are ~35 conv + batch-norm layers of ten launch-bound
+# kernels each, with their own variables and moving statistics -- nothing shared but inputs; autograd runs each branch's
+# backward on the stream its forward ran on.
+_CONCURRENT_TRAIN = os.environ.get("ELO_TRAIN_BRANCHES", "0") == "1"
+
+
+def set_training_branches(flag):
+    global _CONCURRENT_TRAIN
+    _CONCURRENT_TRAIN = bool(flag)
+
+
 def _parallel(branches, is_training=False):
-    """Run independent closures on forked streams and join; results in order.  Sequential in training, on CPU
-    tensors, or when switched off."""
-    if not _CONCURRENT or is_training or len(branches) < 2 or not torch.cuda.is_available():
+    """Run independent closures on forked streams and join; results in order.  Sequential on CPU tensors or when switched
+    off (inference: set_concurrent_branches; training: set_training_branches)."""
+    on = _CONCURRENT_TRAIN if is_training else _CONCURRENT
+    if not on or len(branches) < 2 or not torch.cuda.is_available():
         return [b() for b in branches]
     dev = torch.cuda.current_device()
     cur = torch.cuda.current_stream(dev)

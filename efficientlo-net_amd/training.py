@@ -80,7 +80,7 @@ class FlatAdam:
         self.hyper = torch.zeros((4,), dtype=torch.float32, device=dev)
         self._host = torch.zeros((4,), dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros((4,))
         self._args = _lib.AdamFlatArgs(n, self.flat.data_ptr(), bucket.flat.data_ptr(), self.exp_avg.data_ptr(),
-                                       self.exp_avg_sq.data_ptr(), self.hyper.data_ptr(), betas[0], betas[1])
+                                       self.exp_avg_sq.data_ptr(), self.hyper.data_ptr(), betas[0], betas[1], 1.0 - betas[0], 1.0 - betas[1])
 
     def set_hyper(self):
         """The scalars of step t + 1 to the device (call before step(), or before replaying a graph that recorded it)."""

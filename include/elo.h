@@ -512,6 +512,7 @@ typedef struct elo_adam_flat_args {
     float *exp_avg_sq;            /* (n) IN/OUT */
     const float *hyper;           /* (4) device */
     float beta1, beta2;
+    float one_minus_beta1, one_minus_beta2;   /* (float)(1.0 - beta) from the caller's doubles */
 } elo_adam_flat_args;
 int elo_adam_flat(const elo_adam_flat_args *a, elo_stream_t stream);
 

@@ -93,11 +93,11 @@ def compare(got, want, storage, what):
 
 
 LEVELS = [(8, 16, 225, 16, 6, [11, 41], 1.0), (8, 8, 113, 32, 6, [7, 25], 2.0), (8, 4, 57, 64, 6, [5, 15], 4.0),
-          (8, 4, 57, 64, 32, [5, 35], 4.0)]
+          (8, 4, 57, 64, 32, [5, 35], 4.0), (4, 32, 256, 16, 6, [11, 41], 1.0)]       # the last: l0 of BASELINE configs[4]'s 128x2048 scans
 
 
 @pytest.mark.parametrize("storage", ["f32", "f16"])
-@pytest.mark.parametrize("B,H,W,C,Kq,ks2,dist", LEVELS, ids=["l0", "l1", "l2", "l2_origin"])
+@pytest.mark.parametrize("B,H,W,C,Kq,ks2,dist", LEVELS, ids=["l0", "l1", "l2", "l2_origin", "hires_l0"])
 def test_cost_volume_on_the_chain_kernels_matches_the_oracle(B, H, W, C, Kq, ks2, dist, storage):
     """cost_volume (utils/pointnet_util.py:33-149): select-k pre-pass + cv1_rr_kernel, random-k pre-pass + cv2_rr_kernel."""
     pu, synth = load_pkg("pointnet_util"), load_pkg("synth")

@@ -176,3 +176,37 @@ def test_pose_loss_matches_get_loss_and_its_gradients():
     for a, b in zip(p32 + w32, p64 + w64):
         scale = max(1e-4, float(b.grad.abs().max()))
         assert float((a.grad.cpu().double() - b.grad).abs().max()) <= 1e-5 * scale
+
+
+def test_flat_adam_is_torch_adam():
+    """training.FlatAdam (elo_adam_flat: one launch over the flat parameter buffer, the step's scalars computed by the host)
+    against torch.optim.Adam on the same tensors and gradients over several steps with a changing learning rate: the
+    variables and the moments stay equal to fp32 rounding (torch forms the moments with lerp / addcmul and the bias corrections
+    in fp32, the kernel with plain multiply-adds and host doubles); and the variables ARE views of the flat buffer afterwards."""
+    training, dist_mod = load_pkg("training"), load_pkg("distributed")
+    rng = np.random.default_rng(5)
+    shapes = [(1, 1, 6, 8), (8,), (1, 1, 138, 128), (128,), (), (3, 5)]
+    mine = [torch.nn.Parameter(torch.tensor(rng.normal(0, 1, s_), dtype=torch.float32, device=DEV)) for s_ in shapes]
+    ref = [torch.nn.Parameter(p_.detach().clone()) for p_ in mine]
+    bucket = dist_mod.FlatGradBucket(mine)
+    opt = training.FlatAdam(mine, bucket, lr=1e-3)
+    topt = torch.optim.Adam(ref, lr=1e-3)
+    for step in range(6):
+        lr = 1e-3 * 0.7 ** step
+        opt.lr = lr
+        for g_ in topt.param_groups:
+            g_["lr"] = lr
+        for p_, r_ in zip(mine, ref):
+            g = torch.tensor(rng.normal(0, 1, p_.shape), dtype=torch.float32, device=DEV)
+            p_.grad.copy_(g)                              # (.grad is the bucket's view)
+            r_.grad = g.clone()
+        opt.step()
+        topt.step()
+    torch.cuda.synchronize()
+    state = opt.state_dict()["state"]
+    for i, (p_, r_) in enumerate(zip(mine, ref)):
+        assert float((p_.detach() - r_.detach()).abs().max()) <= 2e-6 * max(1.0, float(r_.detach().abs().max())), i
+        for mine_m, ref_m in ((state[i]["exp_avg"], topt.state[r_]["exp_avg"]), (state[i]["exp_avg_sq"], topt.state[r_]["exp_avg_sq"])):
+            assert float((mine_m - ref_m).abs().max()) <= 1e-6 * max(1e-3, float(ref_m.abs().max())), i   # (torch: lerp / addcmul)
+        assert p_.data_ptr() >= opt.flat.data_ptr() and p_.data_ptr() < opt.flat.data_ptr() + opt.flat.numel() * 4
+    assert opt.t == 6
