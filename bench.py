@@ -53,7 +53,7 @@ F16_MFMA_PEAK_TFLOPS = 2500.0  # ibid.: BF16/FP16 MFMA ~2.5 PFLOP/s dense -- the
 F32_MFMA_PEAK_TFLOPS = 157.3   # ibid.: v_mfma_f32_16x16x4_f32 dense peak -- only for the -DELO_DENSE_F32 comparison build
 MFMA_PRODUCTS = 3              # fp16 matrix-core products per fp32-class product: hi*hi + hi*lo + lo*hi (elo_fused.hip)
 MIN_TIMED_S = 0.25
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc", "summary.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc", "summary.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 
 
 def pkg(sub=None):
@@ -162,6 +162,14 @@ def _time_launches(fn, dev, reps):
     sec = start.elapsed_time(stop) / 1e3 / reps
     del graph
     return sec
+
+
+def _pmc_commit():
+    """' @ <commit>' the committed counter passes were taken at (written into the summary when it was copied to profiles/)."""
+    try:
+        return " @ commit " + json.load(open(PMC_SUMMARY))["captured_at_commit"]
+    except (OSError, KeyError, ValueError):
+        return ""
 
 
 def _pmc_traffic(kernel, batch, features="f32"):
@@ -316,7 +324,7 @@ def roofline_leg(args, dev, net, reps=50):
                                      % (L["N"], L["Kq"], B, args.features),
            "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
            "traffic": _pmc_traffic("cv1_kernel", B, args.features),
-           "traffic_source": os.path.relpath(PMC_SUMMARY, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+           "traffic_source": os.path.relpath(PMC_SUMMARY, ROOT) + _pmc_commit() + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                              "not measured in this run)",
            "us_per_launch": round(sec * 1e6, 3), "algorithmic_bytes_per_launch": int(nbytes),
            "carries_riders_in_the_forward": L["riders"],      # batch 1-2: the forward's launch also runs the level's two set-upconv jobs
