@@ -1281,6 +1281,29 @@ __host__ __device__ __forceinline__ int cv1_feat_cols(int C)
 
 // GROUP = false: an instance without the in-kernel select-k (the neighbours come from a.idx / a.mask, written by
 // elo_fused_conv_select_k_dense in front of this launch): the window registers and the grouping's scalars are gone
+// A layer descriptor read from the kernel-argument segment AT THE LAYER, through a pointer the compiler cannot see
+// through: with the by-value argument block it hoists the s_loads of all six descriptors (72 scalar registers) to the
+// kernel's entry and keeps them live across the in-kernel grouping, whose own scalars then do not fit (67-68 SGPRs
+// spilled to VGPR lanes in cv1_kernel / cv1_setconv_kernel).  Valid where the elo_cv1_args block is the kernel's FIRST
+// parameter (all three kernels below).
+__device__ __forceinline__ elo_dense kernarg_dense(size_t byte_offset)
+{
+    static_assert(sizeof(elo_dense) == 48, "three 16-byte scalar loads");
+    typedef const __attribute__((address_space(4))) char *KernargBytes;
+    typedef unsigned int Quad __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) Quad *KernargQuads;
+    KernargBytes p = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + byte_offset;
+    asm volatile("" : "+s"(p));
+    KernargQuads q = reinterpret_cast<KernargQuads>(p);
+    struct Raw { Quad a, b, c; } raw = {q[0], q[1], q[2]};
+    return __builtin_bit_cast(elo_dense, raw);
+}
+#ifdef ELO_CV1_EARLY_DESCRIPTORS
+#define CV1_LAYER(field) (a.field)
+#else
+#define CV1_LAYER(field) kernarg_dense(offsetof(elo_cv1_args, field))
+#endif
+
 template <int TILE, int MODE, bool GROUP = true>
 __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, float *lds, unsigned block, unsigned nblocks)
 {
@@ -1327,24 +1350,30 @@ __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, flo
     }
     Pre<Sub<TILE, 128>::TPW> p128;
     Pre<Sub<TILE, 64>::TPW> p64;
-    prefetch<TILE, Sub<TILE, 128>::TPW, MODE>(a.cv0, p128);           // in flight while the barrier drains the gather
+    const elo_dense cv0 = CV1_LAYER(cv0);
+    prefetch<TILE, Sub<TILE, 128>::TPW, MODE>(cv0, p128);           // in flight while the barrier drains the gather
     __syncthreads();
 #if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 2
     if (tid == 0) feat_store(a.out, first_point * 64, act[F] + p128.b[0].x, f16);
     return;
 #endif
     CV1_STAMP(2);
-    dense_pf<TILE, 128, 64, MODE>(act, S, F, to_tile(0), a.cv0, p128, &a.cv1, &p64, bad);          // feat_cat -> 128          :72-76
+    const elo_dense cv1 = CV1_LAYER(cv1);
+    dense_pf<TILE, 128, 64, MODE>(act, S, F, to_tile(0), cv0, p128, &cv1, &p64, bad);          // feat_cat -> 128          :72-76
     CV1_STAMP(3);
-    dense_pf<TILE, 64, 64, MODE>(act, S, 0, to_tile(0), a.cv1, p64, &a.cv2, &p64, bad);            // -> 64 (in place)
+    const elo_dense cv2 = CV1_LAYER(cv2);
+    dense_pf<TILE, 64, 64, MODE>(act, S, 0, to_tile(0), cv1, p64, &cv2, &p64, bad);            // -> 64 (in place)
     CV1_STAMP(4);
-    dense_pf<TILE, 64, 64, MODE>(act, S, 0, to_tile(0), a.cv2, p64, &a.cv_xyz, &p64, bad);         // -> 64 = x   (values of the pooling)
+    const elo_dense cv_xyz = CV1_LAYER(cv_xyz);
+    dense_pf<TILE, 64, 64, MODE>(act, S, 0, to_tile(0), cv2, p64, &cv_xyz, &p64, bad);         // -> 64 = x   (values of the pooling)
     CV1_STAMP(5);
-    dense_pf<TILE, 64, 128, MODE>(act, S, G, to_tile(64), a.cv_xyz, p64, &a.sum_cv0, &p128, bad);  // xyz_cat -> enc at [64,128)   :79-82
+    const elo_dense sum_cv0 = CV1_LAYER(sum_cv0);
+    dense_pf<TILE, 64, 128, MODE>(act, S, G, to_tile(64), cv_xyz, p64, &sum_cv0, &p128, bad);  // xyz_cat -> enc at [64,128)   :79-82
     CV1_STAMP(6);
-    dense_pf<TILE, 128, 64, MODE>(act, S, 0, to_tile(64), a.sum_cv0, p128, &a.sum_cv1, &p64, bad); // [x | enc] -> 128 at [64,192): over enc, x stays  :84-90
+    const elo_dense sum_cv1 = CV1_LAYER(sum_cv1);
+    dense_pf<TILE, 128, 64, MODE>(act, S, 0, to_tile(64), sum_cv0, p128, &sum_cv1, &p64, bad); // [x | enc] -> 128 at [64,192): over enc, x stays  :84-90
     CV1_STAMP(7);
-    dense_pf<TILE, 64, 0, MODE>(act, S, 64, to_pool(64), a.sum_cv1, p64, nullptr, nullptr, bad);   // -> 64 logits at [64,128) (plain fp32)
+    dense_pf<TILE, 64, 0, MODE>(act, S, 64, to_pool(64), sum_cv1, p64, nullptr, nullptr, bad);   // -> 64 logits at [64,128) (plain fp32)
     CV1_STAMP(8);
 #if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 3
     if (tid == 0) feat_store(a.out, first_point * 64, act[F], f16);
