@@ -92,6 +92,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true",
                     help="only the timed loop: no roofline / cpu_baseline / from_raw_clouds / batch8 / dense_f32 / train_dp legs")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed counter passes instead of two rocprofv3 --pmc child runs (~30 s)")
     ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs in the one-core CPU sample (all cores: 3 per core)")
     ap.add_argument("--train-steps", type=int, default=8, help="timed steps of the train_dp leg (0: skip)")
     ap.add_argument("--dry-run", action="store_true",
@@ -182,6 +184,45 @@ def _pmc_traffic(kernel, batch, features="f32"):
         return None
     hit = table.get("%s/b%d/%s" % (kernel, batch, features))
     return None if hit is None else hit.get("traffic_bytes")
+
+
+def _live_traffic(batch, features, timeout=150):
+    """HBM bytes per launch of the fused cost-volume stage 1 at l0 MEASURED DURING THIS RUN: two child processes, each
+    `rocprofv3 --pmc <counter>` (FETCH_SIZE, then WRITE_SIZE: separate passes, no trace domain beside them) around
+    tools/roofline_micro.py --kernel cv1_recorded (the launch roofline_leg times: stage 1 at l0 of a real forward on its own
+    tensors), averaged over the last 20 of its 25 launches; FETCH_SIZE x2 (the gfx950 correction of MI355X_MICROARCH.md's HBM section), both in KB.
+    (bytes, note) -- (None, why) when rocprofv3 is missing, a pass fails or times out: the caller then falls back to the
+    committed passes.  The parent is idle meanwhile (called between the timed region and the other legs)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    micro = os.path.join(ROOT, "tools", "roofline_micro.py")
+    cmd = [sys.executable, micro, "--kernel", "cv1_recorded", "--batch", str(batch), "--reps", "25"] + (["--half"] if features == "f16" else [])
+    got = {}
+    work = tempfile.mkdtemp(prefix="elo_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "c", "--"] + cmd, cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            except (subprocess.SubprocessError, OSError) as e:
+                return None, "%s pass failed: %s" % (counter, type(e).__name__)
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                vals += [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+                         if r.get("Counter_Name") == counter and ("cv1_kernel" in r.get("Kernel_Name", "") or "cv1_rr_kernel" in r.get("Kernel_Name", ""))]
+            if len(vals) < 20:
+                return None, "%s pass: no cv1 launches in the counter file" % counter
+            got[counter] = sum(vals[-20:]) / 20                    # the last 20 of the 25 repeats (the recording forwards come first)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return int((2 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024), (
+        "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around tools/roofline_micro.py "
+        "--kernel cv1_recorded --batch %d%s; 2 x FETCH_SIZE + WRITE_SIZE, KB (FETCH_SIZE %.0f, WRITE_SIZE %.0f per launch)"
+        % (batch, " --half" if features == "f16" else "", got["FETCH_SIZE"], got["WRITE_SIZE"]))
 
 
 LEVELS = ("l2_origin", "l2", "l1", "l0")          # the order in which a forward issues its four cost volumes
@@ -320,12 +361,16 @@ def roofline_leg(args, dev, net, reps=50):
     flops = cv1_flops(L["N"], L["C"], L["Kq"]) * B
     gbs = nbytes / sec / 1e9
     ex = MFMA_PRODUCTS if args.products == "split" else 1
+    traffic, traffic_source = (None, "--no-live-traffic") if args.no_live_traffic else _live_traffic(B, args.features)
+    if traffic is None:                                 # the committed passes of the same kernel and shape
+        why = traffic_source
+        traffic = _pmc_traffic("cv1_kernel", B, args.features)
+        traffic_source = (os.path.relpath(PMC_SUMMARY, ROOT) + _pmc_commit() + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                          "not measured in this run: %s)" % why)
     out = {"bound": "hbm", "kernel": "cv1_kernel (fused cost-volume stage 1 at l0 on the tensors of a real forward: %d points, K=%d, batch %d, %s features)"
                                      % (L["N"], L["Kq"], B, args.features),
            "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
-           "traffic": _pmc_traffic("cv1_kernel", B, args.features),
-           "traffic_source": os.path.relpath(PMC_SUMMARY, ROOT) + _pmc_commit() + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
-                             "not measured in this run)",
+           "traffic": traffic, "traffic_source": traffic_source,
            "us_per_launch": round(sec * 1e6, 3), "algorithmic_bytes_per_launch": int(nbytes),
            "carries_riders_in_the_forward": L["riders"],      # batch 1-2: the forward's launch also runs the level's two set-upconv jobs
            "mfma": {"executed_TFLOPs": round(ex * flops / sec / 1e12, 2), "algorithmic_TFLOPs": round(flops / sec / 1e12, 2),

@@ -81,3 +81,16 @@ def test_parse_rccl_log_on_canned_excerpts(tmp_path):
     assert q["algo_proto"] == ["AllReduce:Tree/LL128"]
     missing = bench.parse_rccl_log(str(tmp_path / "absent.log"))
     assert missing["nranks"] is None and missing["algo_proto"] is None
+
+
+def test_live_traffic_falls_back_with_a_reason(monkeypatch):
+    """No GPU here: the counter pass cannot run, and bench._live_traffic must say why instead of raising (roofline_leg
+    then reports the committed passes and puts the reason into traffic_source)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench.shutil if hasattr(bench, "shutil") else __import__("shutil"), "which", lambda name: "/bin/false")
+    got, why = bench._live_traffic(1, "f32", timeout=60)
+    assert got is None and "FETCH_SIZE pass failed" in why
+    import json as _json
+    table = _json.load(open(bench.PMC_SUMMARY))
+    assert bench._pmc_traffic("cv1_kernel", 1, "f32") == table["cv1_kernel/b1/f32"]["traffic_bytes"] > 0

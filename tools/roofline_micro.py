@@ -2,6 +2,7 @@
 
     python tools/roofline_micro.py --kernel cv1|pool|pool2|encode1|encode2|select32|select32_l2|random16 --batch B [--reps N]
 cv1     = fused stage 1 at l0 (16x225, K=6, C=16)          -> cv1_kernel
+cv1_recorded = the same launch of a real 64x1800 forward, on its own tensors (bench.py's roofline object; its live counter passes)
 pool    = per-operator masked softmax pool, K=6 (P1 term)  -> softmax_pool_vec_kernel
 pool2   = the same with K=4 (P2 term)
 encode1 = per-operator gather + geometry encode (A1 term)  -> cv_encode1_col_kernel (C = 16), cv_encode1_vec_kernel otherwise
@@ -30,7 +31,12 @@ feat1 = torch.randn((B, H, W, C), generator=g).to(dev); feat2 = torch.randn((B, 
 order = torch.randperm(11 * 41, generator=g).to(torch.int32).to(dev)
 cvb = bench.cost_volume_bytes(N, C, Kq, 4, 2 if a.half else 4)
 cast = (lambda x: x.half()) if a.half else (lambda x: x)
-if a.kernel == "cv1":
+if a.kernel == "cv1_recorded":            # stage 1 at l0 of a REAL forward, on that forward's tensors: what bench.py's roofline object times
+    L = bench.recorded_cost_volume(dev, B, 64, 1800, a.half)["l0"]
+    run = L["run1"]
+    cb = bench.cost_volume_bytes(L["N"], L["C"], L["Kq"], L["Kp"], 2 if a.half else 4)
+    info = {"flops": bench.cv1_flops(L["N"], L["C"], L["Kq"]) * B, "algorithmic_bytes": (cb["A1"] + cb["P1"]) * B}
+elif a.kernel == "cv1":
     store = tf_util.VariableStore(dev, seed=0)
     with tf_util.default_store(store), torch.no_grad():
         P = fused.packed_layer
