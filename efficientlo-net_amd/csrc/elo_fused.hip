@@ -1470,6 +1470,8 @@ __device__ __forceinline__ void rr_barrier()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+#elif defined(ELO_RR_BARRIER) && ELO_RR_BARRIER == 3      // timing experiment (wrong results): the waves run free
+__device__ __forceinline__ void rr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #else
 __device__ __forceinline__ void rr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
@@ -1535,8 +1537,12 @@ struct RrStream {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             dst.w[t].hi = slot[t * 128];
+#ifdef ELO_RR_WHATIF_HALF_READS                                            // timing experiment (wrong results): half the ring reads
+            dst.w[t].lo = dst.w[t].hi;
+#else
             if constexpr (MODE != MODE_HALF) dst.w[t].lo = slot[t * 128 + 64];
             else dst.w[t].lo = uint4{0u, 0u, 0u, 0u};
+#endif
         }
     }
     // end of superstep S: superstep S + 1 goes into the slot S - 1 used (every wave read it before the last barrier)
