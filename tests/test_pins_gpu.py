@@ -235,3 +235,18 @@ def test_capture_vets_the_operand_range_and_packing_refuses_huge_weights():
         if not fused.fp32_mfma():
             with pytest.raises(ValueError, match="fp16 hi/lo split"):
                 fused.packed_layer("huge", 16, 16, bn=False)
+
+
+def test_bench_measures_the_roofline_traffic_itself():
+    """bench.py's roofline.traffic: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) around the launch the leg times;
+    the result is within a factor of the committed passes of the same kernel (profiles/r04_pmc) and far below the
+    algorithmic bytes (the fused kernel never materialises the operator-boundary tensors)."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    got, why = bench._live_traffic(1, "f32")
+    assert got is not None, why
+    committed = bench._pmc_traffic("cv1_kernel", 1, "f32")
+    assert 0.5 * committed <= got <= 2.0 * committed, (got, committed, why)
+    assert got < 16588800 // 2
