@@ -1,12 +1,12 @@
 """One eager training step at batch B under the torch profiler: GPU time per kernel (top 30) and the launch count.
-    python tools/train_kernel_stats.py [B]"""
+    python tools/train_kernel_stats.py [B] [--by-count]"""
 import importlib, sys, collections
 import torch
 from torch.profiler import profile, ProfilerActivity
 sys.path.insert(0, ".")
 pkg = lambda m: importlib.import_module("efficientlo-net_amd." + m)
 model, training, synth = pkg("model"), pkg("training"), pkg("synth")
-dev = "cuda:0"; B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dev = "cuda:0"; B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
 net = model.PWCLONet(dev, seed=0); tr = training.Trainer(net)
 f1, f2 = synth.frame_pair(B, 64, 1800, seed=1)
 a, b = torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev)
@@ -21,5 +21,6 @@ for e in prof.events():
         agg[e.name[:90]][0] += 1; agg[e.name[:90]][1] += e.device_time
 tot = sum(v[1] for v in agg.values()); n = sum(v[0] for v in agg.values())
 print("batch %d: %d launches, %.2f ms of GPU time" % (B, n, tot / 1e3))
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
+by_count = "--by-count" in sys.argv
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0 if by_count else 1])[:200 if by_count else 30]:
     print("%6.2f ms %5.1f%% x%-5d %s" % (v[1] / 1e3, 100 * v[1] / tot, v[0], k))
