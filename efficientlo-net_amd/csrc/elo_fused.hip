@@ -1138,6 +1138,9 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
     const bool centre_ok = !(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS);
 #pragma unroll
     for (int st = 0; st < SMALL_STEPS; ++st) {
+        // (uniform) nothing left to decide: the window has no slot here, or both points of the wave have their 32 hits --
+        // the slots were fetched ahead in one batch; what is skipped is their judging (dense scans fill up in 2 steps of 5)
+        if (st > 0 && (st * G >= KT || __builtin_amdgcn_ballot_w64(taken < G) == 0)) break;
         const Probe pr = judge(raw[st], cx, cy, cz, r2);
         const bool hit = pr.hit && centre_ok && taken < G;          // (st * G < KT is in raw[st].in_grid)
         const unsigned long long mh = group_ballot<G>(hit, shift);
@@ -2397,6 +2400,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_narrow_kernel(const elo_set
     const bool centre_ok = !(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS);
 #pragma unroll
     for (int st = 0; st < SMALL_STEPS; ++st) {
+        if (st > 0 && (st * G >= KT || __builtin_amdgcn_ballot_w64(taken < G) == 0)) break;     // as in setconv_small_kernel
         const Probe pr = judge(raw[st], cx, cy, cz, r2);
         const bool hit = pr.hit && centre_ok && taken < G;
         const unsigned long long mh = group_ballot<G>(hit, shift);
