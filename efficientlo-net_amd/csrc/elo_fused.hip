@@ -1699,7 +1699,10 @@ __device__ __forceinline__ void rr_pool(float *lds, const float4 (&logit)[4], co
 // the order softmax_chunk8 adds them.  Values must be >= 0 (a ReLU in front: the launchers check), so that the maxima can be
 // taken on the bit patterns (dpp_imax_step: one v_max_i32_dpp per step).
 template <int CTRL>
-__device__ __forceinline__ int dpp_imax_all(int v) { return max(__builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false), v); }
+// (`old` = the maximum's identity, as in dpp_imax_step: these controls read a valid lane everywhere, and with the identity there
+//  the compiler folds move + max into ONE v_max_i32_dpp; with old = v it emitted v_mov_b32_dpp + v_max_i32: 128 of the 1.6 k vector
+//  instructions of a setconv_narrow wave, 64 of the 600 of a setconv_rr wave)
+__device__ __forceinline__ int dpp_imax_all(int v) { return max(__builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, 0xf, 0xf, false), v); }
 
 template <int NOUT, bool F16>
 __device__ __forceinline__ void rr_pool_max_inwave(const float4 (&last)[NOUT / 16], float mk, int r, int lane, int K, long first_point,
@@ -2323,7 +2326,10 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
 // fp32-class products whatever the launch's products mode (three products of hi / lo operands; the VALU kernel was plain
 // fp32 in either mode).  The fp32-MFMA comparison build keeps setconv_small_kernel.
 template <int CIN, int N1, int N2, int N3, int MODE>
-__global__ __launch_bounds__(ELO_BLOCK) void setconv_narrow_kernel(const elo_setconv_args a)
+// (the second launch bound caps the kernel at 256 registers: allowed 512 -- VGPRs + AGPRs -- the compiler selects the AGPR form
+//  of the matrix instructions and pays 4 v_accvgpr_write + 4 v_accvgpr_read around every short chain: 128 of 1.66 k vector
+//  instructions per wave here.  The kernel needs 103.)
+__global__ __launch_bounds__(ELO_BLOCK, 2) void setconv_narrow_kernel(const elo_setconv_args a)
 {
     constexpr int G = 32, PER_BLOCK = ELO_BLOCK / G, C = CIN - 3, CB3 = N3 / 16;
     static_assert((C == 16 || C == 3) && N1 <= 16 && N2 <= 16 && (N3 == 16 || N3 == 32), "the pyramid's two narrow set-conv layers");

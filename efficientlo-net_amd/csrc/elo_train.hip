@@ -218,7 +218,7 @@ __global__ __launch_bounds__(TB) void bn_bwd_apply_kernel(const float *__restric
 // slice's partial dW; slices_combine_kernel sums the slices in a fixed order.  Loads are 4 bytes per lane (4 rows x 16
 // consecutive channels per instruction), U row groups in flight.
 template <int CI, int CO>
-__global__ __launch_bounds__(TB) void weight_grad_kernel(const float *__restrict__ x, const float *__restrict__ g, long M, int Cin,
+__global__ __launch_bounds__(TB, 2) void weight_grad_kernel(const float *__restrict__ x, const float *__restrict__ g, long M, int Cin,
                                                          int Cout, int gy, int gz, float *__restrict__ part, float *__restrict__ bpart)
 {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
