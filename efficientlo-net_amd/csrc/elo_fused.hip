@@ -1282,8 +1282,6 @@ __host__ __device__ __forceinline__ int cv1_feat_cols(int C)
     return kp > 2 * C + 16 ? kp : 2 * C + 16;     // and CV_xyz's 16-k block at 2C
 }
 
-// GROUP = false: an instance without the in-kernel select-k (the neighbours come from a.idx / a.mask, written by
-// elo_fused_conv_select_k_dense in front of this launch): the window registers and the grouping's scalars are gone
 // A layer descriptor read from the kernel-argument segment AT THE LAYER, through a pointer the compiler cannot see
 // through: with the by-value argument block it hoists the s_loads of all six descriptors (72 scalar registers) to the
 // kernel's entry and keeps them live across the in-kernel grouping, whose own scalars then do not fit (67-68 SGPRs
@@ -1307,6 +1305,8 @@ __device__ __forceinline__ elo_dense kernarg_dense(size_t byte_offset)
 #define CV1_LAYER(field) kernarg_dense(offsetof(elo_cv1_args, field))
 #endif
 
+// GROUP = false: an instance without the in-kernel select-k (the neighbours come from a.idx / a.mask, written by
+// elo_fused_conv_select_k_dense in front of this launch): the window registers and the grouping's scalars are gone
 template <int TILE, int MODE, bool GROUP = true>
 __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, float *lds, unsigned block, unsigned nblocks)
 {
