@@ -15,8 +15,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
     X(6, "v_mov_b32 %0, %1") X(7, "v_exp_f32 %0, %0") X(8, "v_max_f32 %0, %0, %1") X(9, "v_pk_add_f32 %3, %3, %3") \
     X(10, "v_cndmask_b32 %0, %0, %1, vcc") X(11, "v_cvt_f32_f16 %0, %0") X(12, "v_pk_fma_f32 %3, %3, %3, %3") \
     X(13, "v_xor_b32 %0, %0, %1") X(14, "v_pk_mul_f32 %3, %3, %3") X(15, "v_perm_b32 %0, %0, %1, %2") X(16, "v_pk_max_f16 %0, %0, %1") \
-    X(17, "v_lshl_add_u32 %0, %0, 1, %1") X(18, "v_and_or_b32 %0, %0, %1, %2") X(19, "v_pk_add_f16 %0, %0, %1") X(20, "v_mad_u32_u24 %0, %0, %1, %2")
-constexpr int NOPS = 21;
+    X(17, "v_lshl_add_u32 %0, %0, 1, %1") X(18, "v_and_or_b32 %0, %0, %1, %2") X(19, "v_pk_add_f16 %0, %0, %1") X(20, "v_mad_u32_u24 %0, %0, %1, %2") \
+    X(21, "v_mul_lo_u32 %0, %0, %1") X(22, "v_mul_hi_u32 %0, %0, %1") X(23, "v_mul_u32_u24 %0, %0, %1") X(24, "v_mad_u64_u32 %3, vcc, %0, %1, %3")
+constexpr int NOPS = 25;
 
 template <int OP> __device__ __forceinline__ void op16(float (&v)[16], float2 (&p)[16], float a, float b)
 {
