@@ -60,3 +60,28 @@ def test_shipped_libraries_are_free_of_the_pair(lib):
     assert objs and all("gfx950" in triple for triple, _ in objs)
     hits = H.check_library(path)
     assert not hits, hits[:5]
+
+
+def test_inference_kernels_keep_their_accumulators_in_vgprs_and_their_dpp_maxima_in_one_instruction():
+    """Two compiler choices round 4 found by counting instructions (profiles/r04_instruction_diet.txt), pinned statically:
+    (1) a kernel allowed 512 registers gets the AGPR form of the matrix instructions and pays v_accvgpr_write / _read around
+    every short accumulator chain -- every kernel of csrc/elo_fused.hip carries a launch bound that keeps it on the VGPR form;
+    (2) an in-wave maximum step is ONE v_max_i32_dpp when update_dpp's `old` is the identity: the pooling of setconv_rr has no
+    v_mov_b32_dpp left, the narrow kernels only the 16 / 32 of their row_bcast step (partial row mask: not foldable)."""
+    path = os.path.join(ROOT, "efficientlo-net_amd", "libelo_hip.so")
+    if not os.path.exists(path):
+        pytest.skip("library not built")
+    seen = 0
+    for _triple, blob in H.code_objects(path):
+        for name, ins in H.functions(H.disassemble(blob)).items():
+            ops = [op for _, op, _, _ in ins]
+            if not any(o.startswith("v_mfma") for o in ops) or "weight_grad" in name:
+                continue                                     # (the training kernel's 64 accumulator registers may live anywhere)
+            seen += 1
+            assert not any(o.startswith("v_accvgpr") for o in ops), name
+            moves = sum(o.startswith("v_mov_b32_dpp") for o in ops)
+            if "setconv_rr_kernel" in name:
+                assert moves == 0, (name, moves)
+            if "setconv_narrow_kernel" in name:
+                assert moves <= 32, (name, moves)
+    assert seen > 50
