@@ -1076,6 +1076,22 @@ __device__ __forceinline__ void small_layer(const float (&x)[32], float (&y)[32]
     }
 }
 
+// ---- integer divisions of the per-point prologues.  A 64-bit `pt / npoints` is an ~80-instruction routine (+ 75 scalar
+// ones), `h / stride` a 24-instruction one; tools/isa_by_line.py showed them as 130 of the ~720 vector instructions a
+// setconv_small wave executes.  The launchers bound batch * npoints by 2^31: the point split is a 32-bit unsigned division;
+// strides are 1, 2, 4 or 8 in this model: a shift behind a uniform branch (a division can trap in the abstract machine, so
+// the compiler keeps the branch instead of computing both and selecting).
+__device__ __forceinline__ void split_point(long pt, int npoints, int &b, int &n)
+{
+    const unsigned p = (unsigned)pt, q = p / (unsigned)npoints;
+    b = (int)q; n = (int)(p - q * (unsigned)npoints);
+}
+__device__ __forceinline__ int div_stride(int v, int stride)
+{
+    if ((stride & (stride - 1)) == 0) return v >> (31 - __builtin_clz(stride));
+    return v / stride;
+}
+
 constexpr int SMALL_STEPS = 5;                    // window steps of 32 slots held in flight: windows up to 160 slots
 
 template <int CIN, int N1, int N2, int N3>
@@ -1112,12 +1128,12 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
     const long pt = (long)xcd_tile(blockIdx.x, gridDim.x) * PER_BLOCK + g;
     const bool live = pt < total;
     const long ptc = live ? pt : total - 1;                 // dead groups shadow the last point and store nothing
-    const int b = (int)(ptc / a.npoints), n = (int)(ptc - (long)b * a.npoints);
-    int hc = n / a.W, wc = n - (n / a.W) * a.W;
+    int b, n, hc, wc;
+    split_point(ptc, a.npoints, b, n);
     if (a.centre_hw) {                                       // one 8-byte load, in the first batch
         const int2 c2 = reinterpret_cast<const int2 *>(a.centre_hw)[ptc];
         hc = c2.x; wc = c2.y;
-    }
+    } else { hc = n / a.W; wc = n - hc * a.W; }
     if (!gs.decoded_hw) {
 #pragma unroll
         for (int st = 0; st < SMALL_STEPS; ++st) off[st] = ((off[st] / kW - hh) << 16) | ((off[st] % kW - hw2) & 0xffff);
@@ -1125,7 +1141,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
     const float *cp = a.xyz1_grid + (((long)b * a.H + hc) * a.W + wc) * 3;
     const float cx = cp[0], cy = cp[1], cz = cp[2];
     const float *grid2 = a.src_xyz + (size_t)b * a.H2 * a.W2 * 3;
-    const int base_h = hc / gs.stride_h, base_w = wc / gs.stride_w;
+    const int base_h = div_stride(hc, gs.stride_h), base_w = div_stride(wc, gs.stride_w);
     RawSlot raw[SMALL_STEPS];
 #pragma unroll
     for (int st = 0; st < SMALL_STEPS; ++st) raw[st] = fetch_slot(grid2, a.H2, a.W2, off[st], base_h, base_w, st * G + lane < KT);
@@ -2195,7 +2211,9 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
         const bool mine = tid < P && ptq < total_points;
         const long pq = mine ? ptq : first_point;
         const int b = (int)((unsigned)pq / (unsigned)a.npoints), n = (int)((unsigned)pq - (unsigned)b * (unsigned)a.npoints);
-        const int hc = a.centre_hw ? a.centre_hw[pq * 2 + 0] : n / a.W, wc = a.centre_hw ? a.centre_hw[pq * 2 + 1] : n - (n / a.W) * a.W;
+        int hc, wc;
+        if (a.centre_hw) { hc = a.centre_hw[pq * 2 + 0]; wc = a.centre_hw[pq * 2 + 1]; }
+        else { hc = n / a.W; wc = n - hc * a.W; }
         const float *c = a.xyz1_grid + (((long)b * a.H + hc) * a.W + wc) * 3;
         const float cx = c[0], cy = c[1], cz = c[2];
         if (tid < RR_ROWS) { cell_row[tid] = -1; mask_row[tid] = 0.0f; }
@@ -2224,7 +2242,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
             const int ppc = live[j] ? pp : 0;
             pb[j] = (int)((unsigned)(live[j] ? ptw : first_point) / (unsigned)a.npoints);
             const int hwc = __builtin_amdgcn_readfirstlane(chw[ppc]);
-            ph[j] = (hwc >> 16) / a.group.stride_h; pw[j] = (hwc & 0xffff) / a.group.stride_w;
+            ph[j] = div_stride(hwc >> 16, a.group.stride_h); pw[j] = div_stride(hwc & 0xffff, a.group.stride_w);
 #pragma unroll
             for (int e = 0; e < 3; ++e) pc[j][e] = uniform(cxyz[ppc * 3 + e]);
             first[j] = fetch_slot(grid_buffer(a.src_xyz + (size_t)pb[j] * a.H2 * a.W2 * 3), a.H2, a.W2, lds_off[lane < KT ? lane : 0], ph[j], pw[j],
@@ -2244,7 +2262,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
                 const GridBuf gb = grid_buffer(a.src_xyz + (size_t)b * a.H2 * a.W2 * 3);
                 count = wave_random_k_prefetched(gb, a.H2, a.W2, KT, K, lds_off, ph[j], pw[j], cx, cy, cz, r2, first[j], emit);
             }
-            for (int k = count + lane; k < K; k += 64) { cell_row[pp * K + k] = 0; mask_row[pp * K + k] = 0.0f; }   // index (0,0,0), mask 0
+            if (count + lane < K) { cell_row[pp * K + count + lane] = 0; mask_row[pp * K + count + lane] = 0.0f; }   // index (0,0,0), mask 0 (K <= 32: one trip)
         }
     }
     RR_STAMP(2);
@@ -2382,12 +2400,12 @@ __global__ __launch_bounds__(ELO_BLOCK, 2) void setconv_narrow_kernel(const elo_
     const long pt = first + g;
     const bool live = pt < total;
     const long ptc = live ? pt : total - 1;                 // dead groups shadow the last point and store nothing
-    const int b = (int)(ptc / a.npoints), n = (int)(ptc - (long)b * a.npoints);
-    int hc = n / a.W, wc = n - (n / a.W) * a.W;
+    int b, n, hc, wc;
+    split_point(ptc, a.npoints, b, n);
     if (a.centre_hw) {
         const int2 c2 = reinterpret_cast<const int2 *>(a.centre_hw)[ptc];
         hc = c2.x; wc = c2.y;
-    }
+    } else { hc = n / a.W; wc = n - hc * a.W; }
     if (!gs.decoded_hw) {
 #pragma unroll
         for (int st = 0; st < SMALL_STEPS; ++st) off[st] = ((off[st] / kW - hh) << 16) | ((off[st] % kW - hw2) & 0xffff);
@@ -2395,7 +2413,7 @@ __global__ __launch_bounds__(ELO_BLOCK, 2) void setconv_narrow_kernel(const elo_
     const float *cp = a.xyz1_grid + (((long)b * a.H + hc) * a.W + wc) * 3;
     const float cx = cp[0], cy = cp[1], cz = cp[2];
     const float *grid2 = a.src_xyz + (size_t)b * a.H2 * a.W2 * 3;
-    const int base_h = hc / gs.stride_h, base_w = wc / gs.stride_w;
+    const int base_h = div_stride(hc, gs.stride_h), base_w = div_stride(wc, gs.stride_w);
     RawSlot raw[SMALL_STEPS];
 #pragma unroll
     for (int st = 0; st < SMALL_STEPS; ++st) raw[st] = fetch_slot(grid2, a.H2, a.W2, off[st], base_h, base_w, st * G + lane < KT);
