@@ -1070,9 +1070,9 @@ __device__ __forceinline__ void small_layer(const float (&x)[32], float (&y)[32]
 #pragma unroll
         for (int n = 0; n < NOUT; ++n) y[n] = fmaf(x[k], w[k * NOUT + n], y[n]);
     }
-    if (relu) {
-#pragma unroll
-        for (int n = 0; n < NOUT; ++n) y[n] = fmaxf(y[n], 0.0f);
+    if (relu) {                                    // on the bit patterns (relu4's form): fmaxf is llvm.maxnum and costs a canonicalising
+#pragma unroll                                     // v_max x, x per value on top of the maximum itself
+        for (int n = 0; n < NOUT; ++n) y[n] = __int_as_float(max(__float_as_int(y[n]), 0));
     }
 }
 
@@ -1753,13 +1753,19 @@ __device__ __forceinline__ void rr_pool_softmax4_inwave(const float4 (&logit)[4]
     const int kq = lane >> 4, i16 = lane & 15;
     const long p = first_point + (r >> 2);
     const bool writer = (i16 & 3) == 3 && p < total_points;
-    auto shr1 = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, false)); };
+    // row_shr:1 with bound_ctrl: lane 0 of a row reads 0 -- and the compiler folds move + add into ONE v_add_f32_dpp (with
+    // old = 0 and no bound_ctrl it kept them apart: 96 of the wave's instructions)
+    auto shr1 = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true)); };
+    auto quad_lane = [](float x, auto sel) {          // lane `sel` of this lane's quad, in every lane of the quad
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(sel)::value * 0x55, 0xf, 0xf, true));
+    };
+    const int j = i16 & 3;
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
         const ActPair &xp = cb < 2 ? v0 : v1;
         const float4 val = cb % 2 == 0 ? quad_value(xp.hi.x, xp.hi.y, xp.lo.x, xp.lo.y) : quad_value(xp.hi.z, xp.hi.w, xp.lo.z, xp.lo.w);
         const float l[4] = {logit[cb].x, logit[cb].y, logit[cb].z, logit[cb].w}, v[4] = {val.x, val.y, val.z, val.w};
-        float o[4];
+        float den[4], acc[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float x = mk == 1.0f ? l[e] : -1e10f;
@@ -1771,9 +1777,19 @@ __device__ __forceinline__ void rr_pool_softmax4_inwave(const float4 (&logit)[4]
 #pragma unroll
             for (int step = 0; step < 3; ++step) { cd = shr1(cd) + ex; ca = shr1(ca) + ev; }
             // (softmax_chunk8's merge into (-inf, 0, 0): den = 0 * 0 + cd * 1, acc = 0 * 0 + ca * 1)
-            o[e] = ca / cd;
+            den[e] = cd; acc[e] = ca;
         }
-        if (writer) feat_store4(out, p * 64 + cb * 16 + 4 * kq, float4{o[0], o[1], o[2], o[3]}, F16);
+        // lane 3 of the quad holds the four (acc, den) pairs; a division is ~11 instructions in every lane whoever needs it, so
+        // the quad shares them: lane j divides pair j (read from lane 3), lane 3 collects the quotients (same division, same bits)
+        typedef std::integral_constant<int, 3> L3;
+        float a4[4], d4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a4[e] = quad_lane(acc[e], L3{}); d4[e] = quad_lane(den[e], L3{}); }
+        const float aj = j == 0 ? a4[0] : j == 1 ? a4[1] : j == 2 ? a4[2] : a4[3], dj = j == 0 ? d4[0] : j == 1 ? d4[1] : j == 2 ? d4[2] : d4[3];
+        const float qj = aj / dj;
+        const float4 o{quad_lane(qj, std::integral_constant<int, 0>{}), quad_lane(qj, std::integral_constant<int, 1>{}),
+                       quad_lane(qj, std::integral_constant<int, 2>{}), quad_lane(qj, L3{})};
+        if (writer) feat_store4(out, p * 64 + cb * 16 + 4 * kq, o, F16);
     }
 }
 
@@ -2357,35 +2373,37 @@ __global__ __launch_bounds__(ELO_BLOCK, 2) void setconv_narrow_kernel(const elo_
     unsigned bad = 0, wbad = 0;
     // ---- (1) W^T fragments and bias quads, requested first (consumed after the grouping): lane (i16, kq) of a fragment holds
     // W[4kq + e][cb * 16 + i16], e = 0..3 (and, for the 32-k pair of the 19-channel input, W[16 + 4kq + e][..] as well)
-    auto wq = [&](const elo_dense &L, int k0, int n) {                   // rows k0 .. k0 + 3 of column n; 0 beyond (K, N); unconditional loads
-        const int nc = n < L.N ? n : L.N - 1;
+    // (LK, LN: the layer's K and N, the template's widths -- the launcher picked the instance by them --, so the clamps and the
+    //  zero tests fold wherever a whole quad is inside or outside)
+    auto wq = [&](const elo_dense &L, const int LK, const int LN, int k0, int n) {   // rows k0 .. k0 + 3 of column n; 0 beyond (K, N); unconditional loads
+        const int nc = n < LN ? n : LN - 1;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int k = k0 + e < L.K ? k0 + e : L.K - 1;
-            v[e] = L.w_plain[k * L.N + nc];
+            const int k = k0 + e < LK ? k0 + e : LK - 1;
+            v[e] = L.w_plain[k * LN + nc];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (k0 + e < L.K && n < L.N) ? v[e] : 0.0f;
+        for (int e = 0; e < 4; ++e) v[e] = (k0 + e < LK && n < LN) ? v[e] : 0.0f;
         return float4{v[0], v[1], v[2], v[3]};
     };
-    auto bq = [&](const elo_dense &L, int n0) {                          // bias[n0 .. n0 + 3]
+    auto bq = [&](const elo_dense &L, const int LN, int n0) {            // bias[n0 .. n0 + 3]
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = L.bias[n0 + e < L.N ? n0 + e : L.N - 1];
+        for (int e = 0; e < 4; ++e) v[e] = L.bias[n0 + e < LN ? n0 + e : LN - 1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = n0 + e < L.N ? v[e] : 0.0f;
+        for (int e = 0; e < 4; ++e) v[e] = n0 + e < LN ? v[e] : 0.0f;
         return float4{v[0], v[1], v[2], v[3]};
     };
-    const float4 w1a = wq(a.layers[0], 4 * kq, i16), w1b = C == 16 ? wq(a.layers[0], 16 + 4 * kq, i16) : float4{0.0f, 0.0f, 0.0f, 0.0f};
-    const float4 w2f = wq(a.layers[1], 4 * kq, i16);
+    const float4 w1a = wq(a.layers[0], CIN, N1, 4 * kq, i16), w1b = C == 16 ? wq(a.layers[0], CIN, N1, 16 + 4 * kq, i16) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+    const float4 w2f = wq(a.layers[1], N1, N2, 4 * kq, i16);
     float4 w3f[CB3];
 #pragma unroll
-    for (int cb = 0; cb < CB3; ++cb) w3f[cb] = wq(a.layers[2], 4 * kq, cb * 16 + i16);
-    const float4 b1 = bq(a.layers[0], 4 * kq), b2 = bq(a.layers[1], 4 * kq);
+    for (int cb = 0; cb < CB3; ++cb) w3f[cb] = wq(a.layers[2], N2, N3, 4 * kq, cb * 16 + i16);
+    const float4 b1 = bq(a.layers[0], N1, 4 * kq), b2 = bq(a.layers[1], N2, 4 * kq);
     float4 b3[CB3];
 #pragma unroll
-    for (int cb = 0; cb < CB3; ++cb) b3[cb] = bq(a.layers[2], cb * 16 + 4 * kq);
+    for (int cb = 0; cb < CB3; ++cb) b3[cb] = bq(a.layers[2], N3, cb * 16 + 4 * kq);
 
     // ---- (2) grouping: half a wave per centre, as setconv_small_kernel
     const int g = tid / G, lane = tid % G, shift = (tid & 63) / G * G;
