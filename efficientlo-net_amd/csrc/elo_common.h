@@ -25,7 +25,28 @@ __device__ __forceinline__ float sq3(float x, float y, float z)
 {
     return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
 }
-// the reference's max(a,b) with a NaN first operand returns b
+// ---- integer divisions of the per-point prologues.  A 64-bit `pt / npoints` is an ~80-instruction routine (+ 75 scalar
+// ones), `h / stride` a 24-instruction one; tools/isa_by_line.py showed them as 130 of the ~720 vector instructions a
+// setconv_small wave executes, 126 of the 294 of a select-k wave.  The fused launchers bound batch * npoints by 2^31: there the
+// point split is a 32-bit unsigned division (split_point); elsewhere the 32-bit form sits on a branch (point_batch).  Strides
+// are 1, 2, 4 or 8 in this model: a shift behind a uniform branch (a division can trap in the abstract machine, so the
+// compiler keeps the branch instead of computing both and selecting).
+__device__ __forceinline__ void split_point(long pt, int npoints, int &b, int &n)
+{
+    const unsigned p = (unsigned)pt, q = p / (unsigned)npoints;
+    b = (int)q; n = (int)(p - q * (unsigned)npoints);
+}
+__device__ __forceinline__ int div_stride(int v, int stride)
+{
+    if ((stride & (stride - 1)) == 0) return v >> (31 - __builtin_clz(stride));
+    return v / stride;
+}
+__device__ __forceinline__ int point_batch(long pt, int npoints)      // pt / npoints for any pt
+{
+    if ((unsigned long)pt >> 31 == 0) return (int)((unsigned)pt / (unsigned)npoints);
+    return (int)(pt / npoints);
+}
+
 __device__ __forceinline__ float pick_max(float a, float b) { return a > b ? a : b; }
 
 // e^x to ~2 ulp in 7 instructions on the hardware exp2: x * log2(e) in two pieces (the rounding of the product, up to

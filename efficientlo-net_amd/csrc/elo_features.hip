@@ -85,7 +85,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void group_concat_kernel(const elo_group
         const long cell = m.cell[lr];
         if (cell < 0) continue;
         const float mk = m.mask[lr];
-        const long bn = (first + lr) / a.K;
+        const long bn = point_batch(first + lr, a.K);
         tile[e] = ch < 3 ? a.src_xyz[cell * 3 + ch] * mk - a.centre_xyz[bn * 3 + ch] : a.src_feat[cell * a.C + (ch - 3)] * mk;
     }
     __syncthreads();
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_kernel(const elo_cv_enco
         const long cell = m.cell[lr];
         if (cell < 0) continue;
         const float mk = m.mask[lr];
-        const long bn = (first + lr) / a.K;
+        const long bn = point_batch(first + lr, a.K);
         tile[e] = ch < 10 ? geo_value(a.xyz1 + bn * 3, a.xyz2 + cell * 3, mk, ch)
                 : ch < 10 + C ? static_cast<const float *>(a.feat1)[bn * C + (ch - 10)]
                               : static_cast<const float *>(a.feat2)[cell * C + (ch - 10 - C)] * mk;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_kernel(const elo_cv_enco
         const long cell = m.cell[lr];
         if (cell < 0) continue;
         const float mk = m.mask[lr];
-        const long bn = (first + lr) / a.K;
+        const long bn = point_batch(first + lr, a.K);
         if (ch < 10) geo[lr * 10 + ch] = geo_value(a.xyz1 + bn * 3, a.xyz1 + cell * 3, mk, ch);
         else if (ch < 10 + a.C) rest[lr * CT + (ch - 10)] = static_cast<const float *>(a.feat1)[bn * a.C + (ch - 10)];
         else rest[lr * CT + (ch - 10)] = static_cast<const float *>(a.cost)[cell * a.Cc + (ch - 10 - a.C)] * mk;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_vec_kernel(const elo_cv_
     if (first >= rows) return;
     const int C = a.C, HC = C >> 1, HP = 5 + C;      // two-element slots per row: 5 geometry, C/2 + C/2 features
     const int nrows = (int)(rows - first < ENC_ROWS ? rows - first : ENC_ROWS), nslots = nrows * HP;
-    const long bn0 = first / a.K;
+    const long bn0 = point_batch(first, a.K);
     const unsigned rem0 = (unsigned)(first - bn0 * a.K);
     resolve_rows(rf, first, nrows, bn0, rem0, by_K, a.idx, a.mask, a.xyz1, a.xyz2, a.H2, a.W2);
     const T *feat1 = static_cast<const T *>(a.feat1), *feat2 = static_cast<const T *>(a.feat2);
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_col_kernel(const elo_cv_
     if (first >= rows) return;
     const int C = a.C, HC = C >> 1, HP = 5 + C;
     const int nrows = (int)(rows - first < span ? rows - first : span);
-    const long bn0 = first / a.K;
+    const long bn0 = point_batch(first, a.K);
     const unsigned rem0 = (unsigned)(first - bn0 * a.K);
     resolve_rows(rf, first, nrows, bn0, rem0, by_K, a.idx, a.mask, a.xyz1, a.xyz2, a.H2, a.W2);
     const int r0 = (int)by_slots(threadIdx.x), j = (int)threadIdx.x - r0 * HP;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_vec_kernel(const elo_cv_
     if (first >= rows) return;
     const int C = a.C, Cc = a.Cc, QC = C / E, QP = (C + Cc) / E;
     const int nrows = (int)(rows - first < ENC_ROWS ? rows - first : ENC_ROWS), nslots = nrows * QP;
-    const long bn0 = first / a.K;
+    const long bn0 = point_batch(first, a.K);
     const unsigned rem0 = (unsigned)(first - bn0 * a.K);
     resolve_rows(rf, first, nrows, bn0, rem0, by_K, a.idx, a.mask, a.xyz1, a.xyz1, a.H, a.W);
     const T *feat1 = static_cast<const T *>(a.feat1), *cost = static_cast<const T *>(a.cost);

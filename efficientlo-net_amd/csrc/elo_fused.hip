@@ -706,11 +706,11 @@ __device__ __forceinline__ void group_tile(const TileMeta &m, int *lds_off, unsi
         if (!(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS)) {                // valid centre (:62-70)
             const GridBuf gb = grid_buffer(grid2 + (size_t)b * H2 * W2 * 3);      // b is scalar: the resource lives in SGPRs
             if (SELECT)
-                count = wave_select_k(gb, H2, W2, KT, K, lds_off, hc / g.stride_h, wc / g.stride_w, cx, cy, cz, r2,
+                count = wave_select_k(gb, H2, W2, KT, K, lds_off, div_stride(hc, g.stride_h), div_stride(wc, g.stride_w), cx, cy, cz, r2,
                                       scratch + (size_t)wave * select_scratch_words(KT, K),
                                       reinterpret_cast<int *>(scratch) + (size_t)wave * select_scratch_words(KT, K) + KT, emit);
             else
-                count = wave_random_k(gb, H2, W2, KT, K, lds_off, hc / g.stride_h, wc / g.stride_w, cx, cy, cz, r2, emit);
+                count = wave_random_k(gb, H2, W2, KT, K, lds_off, div_stride(hc, g.stride_h), div_stride(wc, g.stride_w), cx, cy, cz, r2, emit);
         }
         ELO_GROUP_STAMP(16 + (pi >= FUSED_WAVES));
         if (pi < FUSED_WAVES) ELO_GROUP_STAMP(18);
@@ -956,7 +956,7 @@ __device__ __forceinline__ void setconv_tile(const elo_setconv_args &a, const in
             float v = 0.0f;
             if (pt < total_points) {
                 if (a.centre_hw) {
-                    const int b = (int)(pt / a.npoints);
+                    const int b = point_batch(pt, a.npoints);
                     const int h = a.centre_hw[pt * 2 + 0], w = a.centre_hw[pt * 2 + 1];
                     v = a.xyz1_grid[(((long)b * a.H + h) * a.W + w) * 3 + c];
                     if (a.new_xyz) a.new_xyz[pt * 3 + c] = v;                   // :206
@@ -1074,22 +1074,6 @@ __device__ __forceinline__ void small_layer(const float (&x)[32], float (&y)[32]
 #pragma unroll                                     // v_max x, x per value on top of the maximum itself
         for (int n = 0; n < NOUT; ++n) y[n] = __int_as_float(max(__float_as_int(y[n]), 0));
     }
-}
-
-// ---- integer divisions of the per-point prologues.  A 64-bit `pt / npoints` is an ~80-instruction routine (+ 75 scalar
-// ones), `h / stride` a 24-instruction one; tools/isa_by_line.py showed them as 130 of the ~720 vector instructions a
-// setconv_small wave executes.  The launchers bound batch * npoints by 2^31: the point split is a 32-bit unsigned division;
-// strides are 1, 2, 4 or 8 in this model: a shift behind a uniform branch (a division can trap in the abstract machine, so
-// the compiler keeps the branch instead of computing both and selecting).
-__device__ __forceinline__ void split_point(long pt, int npoints, int &b, int &n)
-{
-    const unsigned p = (unsigned)pt, q = p / (unsigned)npoints;
-    b = (int)q; n = (int)(p - q * (unsigned)npoints);
-}
-__device__ __forceinline__ int div_stride(int v, int stride)
-{
-    if ((stride & (stride - 1)) == 0) return v >> (31 - __builtin_clz(stride));
-    return v / stride;
 }
 
 constexpr int SMALL_STEPS = 5;                    // window steps of 32 slots held in flight: windows up to 160 slots

@@ -34,13 +34,13 @@ struct Centre {
 __device__ __forceinline__ Centre load_centre(const elo_group_args &a, long u)
 {
     Centre c;
-    c.b = (int)(u / a.npoints);
+    c.b = point_batch(u, a.npoints);
     const int hc = a.idx_n2[u * 2 + 0], wc = a.idx_n2[u * 2 + 1];
     const float *p = a.xyz1 + (((size_t)c.b * a.H + hc) * a.W + wc) * 3;
     c.x = p[0]; c.y = p[1]; c.z = p[2];
     c.ok = !(pick_max(sq3(c.x, c.y, c.z), ELO_EPS) <= ELO_EPS);      // :62-70
-    c.base_h = hc / a.stride_h;
-    c.base_w = wc / a.stride_w;
+    c.base_h = div_stride(hc, a.stride_h);
+    c.base_w = div_stride(wc, a.stride_w);
     return c;
 }
 
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(DENSE_ROWS * 64) void group_random_k_dense(const el
     int *count = sel + K * DENSE_SEL_PITCH;                          // [2][THREADS] num_valid, num_select of every centre
     const int tid = threadIdx.x, lane = tid & 63, wrow = tid >> 6;
     const int b = blockIdx.z, r0 = blockIdx.y * DENSE_ROWS, c0 = blockIdx.x * DENSE_COLS;
-    const int h0 = r0 / a.stride_h - a.kernel_h / 2, w0 = c0 / a.stride_w - a.kernel_w / 2;    // region origin (unwrapped)
+    const int h0 = div_stride(r0, a.stride_h) - a.kernel_h / 2, w0 = div_stride(c0, a.stride_w) - a.kernel_w / 2;    // region origin (unwrapped)
     // centre of this thread (requested first: overlaps the staging)
     const int hc = r0 + wrow, wc = c0 + lane;
     const bool live = hc < a.H && wc < a.W;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(DENSE_ROWS * 64) void group_random_k_dense(const el
     __syncthreads();
     // this thread's window origin inside the region: slot (dh, dw) of the window is region[(bh + dh) * RW + bw + dw] with
     // dh, dw counted from the window's top-left corner (the -kH/2, -kW/2 of :80-81 is in h0, w0)
-    const int bh = hc / a.stride_h - (r0 / a.stride_h), bw = wc / a.stride_w - (c0 / a.stride_w);
+    const int bh = div_stride(hc, a.stride_h) - (div_stride(r0, a.stride_h)), bw = div_stride(wc, a.stride_w) - (div_stride(c0, a.stride_w));
     const int origin = bh * g.RW + bw;
     const float r2 = a.distance * a.distance;
     const bool centre_ok = live && !(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS);           // :62-70
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(P * 64) void group_select_k_dense(const elo_group_a
     unsigned *scratch = reinterpret_cast<unsigned *>(lds_off + ((KT + 3) & ~3));   // [P][128] wave scratch of the fallback
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, hc = blockIdx.y, c0 = blockIdx.x * DENSE_COLS;
-    const int h0 = hc / a.stride_h - a.kernel_h / 2, w0 = c0 / a.stride_w - a.kernel_w / 2;     // region origin (unwrapped)
+    const int h0 = div_stride(hc, a.stride_h) - a.kernel_h / 2, w0 = div_stride(c0, a.stride_w) - a.kernel_w / 2;     // region origin (unwrapped)
     const int wc = c0 + lane;
     const bool live = wc < a.W;
     const float *cp = a.xyz1 + (((size_t)b * a.H + hc) * a.W + (live ? wc : a.W - 1)) * 3;
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(P * 64) void group_select_k_dense(const elo_group_a
         int *o_sel = a.selected_bhw_idx + uo * 3;
         float *o_mask = a.selected_mask + uo;
         unsigned *dist = scratch + wave * 128;
-        const int count = wave_select_k(grid2, a.H2, a.W2, KT, K, lds_off, hc / a.stride_h, cw / a.stride_w, x, y, z, r2, dist,
+        const int count = wave_select_k(grid2, a.H2, a.W2, KT, K, lds_off, div_stride(hc, a.stride_h), div_stride(cw, a.stride_w), x, y, z, r2, dist,
                                         reinterpret_cast<int *>(dist) + 64,
                                         [&](int slot, int hw) {
                                             o_sel[slot * 3 + 0] = b; o_sel[slot * 3 + 1] = hw >> 16; o_sel[slot * 3 + 2] = hw & 0xffff;
