@@ -915,7 +915,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void warp_cell_kernel(const elo_warp_pro
 {
     const long total = (long)a.batch * a.npoints;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int b = (int)(i / a.npoints);
+        const int b = point_batch(i, a.npoints);
         warp_cell_point(a, i, b, a.q ? a.q + b * 4 : nullptr, a.q ? a.t + b * 3 : nullptr, ps);
     }
 }
@@ -928,7 +928,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void input_cell_kernel(const elo_input_s
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int f = i >= per_frame;                                     // 0: frame 1, 1: frame 2
         const long j = i - f * per_frame;
-        const int b = (int)(j / a.npoints);
+        const int b = point_batch(j, a.npoints);
         const long n = j - (long)b * a.npoints;
         const float *p = a.cloud + ((long)b * 2 * a.npoints + (long)f * a.npoints + n) * a.point_stride;
         float x = p[0], y = p[1], z = p[2], w = 1.0f;
@@ -960,9 +960,11 @@ __global__ __launch_bounds__(ELO_BLOCK) void scatter_min_kernel(const elo_warp_p
     const int zc1 = cell_of_point(atan2f(0.0f, -0.0f), 0.0f, 0.0f, a.H, a.W, a.az_res, a.vert_res, a.vert_off);
     const int zc2 = cell_of_point(atan2f(-0.0f, -0.0f), 0.0f, 0.0f, a.H, a.W, a.az_res, a.vert_res, a.vert_off);
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long i = e / CT;
+        // (e < 2^31 in every call of the model: the 32-bit forms of point_batch -- a 64-bit division is ~80 instructions, and this
+        //  kernel is ~5 us of a batch-1 forward's critical path, three times)
+        const long i = point_batch(e, CT);
         const int ch = (int)(e - i * CT);
-        const int b = (int)(i / a.npoints);
+        const int b = point_batch(i, a.npoints);
         const int c = ps.cell_of[i];
         const long cell = (long)b * a.H * a.W + c;
         // an image's zero points (range 0) win their cell: only they add there (zeros to xyz, their features to feat)

@@ -635,7 +635,7 @@ __device__ __forceinline__ void load_meta(const TileMeta &m, long first_point, l
 {
     const int r = threadIdx.x;
     if (r < TILE) {
-        const int pi = r / K;
+        const int pi = small_div(r, K);
         const long pt = first_point + pi;
         int cell = -1;
         float mk = 0.0f;
@@ -674,7 +674,9 @@ __device__ __forceinline__ void group_tile(const TileMeta &m, int *lds_off, unsi
         const long pq = mine ? pt : first_point;
         // (launchers keep batch * npoints below 2^31: 32-bit divisions -- a 64-bit one is a ~100-instruction routine)
         const int b = (int)((unsigned)pq / (unsigned)npoints), n = (int)((unsigned)pq - (unsigned)b * (unsigned)npoints);
-        const int hc = centre_hw ? centre_hw[pq * 2 + 0] : n / W1, wc = centre_hw ? centre_hw[pq * 2 + 1] : n - (n / W1) * W1;
+        int hc, wc;                                          // (a branch: behind a select the division is computed either way)
+        if (centre_hw) { hc = centre_hw[pq * 2 + 0]; wc = centre_hw[pq * 2 + 1]; }
+        else { hc = n / W1; wc = n - hc * W1; }
         const float *c = centre_grid + (((long)b * H1 + hc) * W1 + wc) * 3;
         const float cx = c[0], cy = c[1], cz = c[2];
         if (mine) {
@@ -752,7 +754,7 @@ __device__ __forceinline__ bool seg_ok(const void *p, int W, int rows, int f16)
 __device__ __forceinline__ void seg_split(int it, int q, int &row, int &c4)
 {
     if ((q & (q - 1)) == 0) { const int sh = __builtin_ctz(q); row = it >> sh; c4 = it & (q - 1); }   // uniform branch
-    else { row = it / q; c4 = it - row * q; }
+    else { row = small_div(it, q); c4 = it - row * q; }
 }
 
 // rowof(row) -> source row (long), negative = row not in use (the load then reads source row 0 and is dropped)
@@ -801,11 +803,11 @@ __device__ __forceinline__ void zero_cols(float *act, int S, int from, int to)
 {
     if (((from | to) & 3) == 0) {
         const int w = (to - from) >> 2;
-        for (int e = threadIdx.x; e < TILE * w; e += FUSED_BLOCK) quad_store(act, (e / w) * S + from + 4 * (e % w), uint4{0u, 0u, 0u, 0u});
+        for (int e = threadIdx.x; e < TILE * w; e += FUSED_BLOCK) { const int er = small_div(e, w); quad_store(act, er * S + from + 4 * (e - er * w), uint4{0u, 0u, 0u, 0u}); }
     } else {
         const int w = to - from;
         unsigned none = 0;
-        for (int e = threadIdx.x; e < TILE * w; e += FUSED_BLOCK) act_put<MODE>(act, (e / w) * S + from + e % w, 0.0f, none);
+        for (int e = threadIdx.x; e < TILE * w; e += FUSED_BLOCK) { const int er = small_div(e, w); act_put<MODE>(act, er * S + from + (e - er * w), 0.0f, none); }
     }
 }
 
@@ -982,20 +984,20 @@ __device__ __forceinline__ void setconv_tile(const elo_setconv_args &a, const in
         seg_store<TILE, MODE>(act, S, 0, C, f16, rf, cell_of, [&](int row) { return meta.mask[row] != 0.0f; }, bad);
         if (tid < TILE) {
             const float m = meta.mask[tid];
-            const float *c = meta.cxyz + (tid / K) * 3;
+            const float *c = meta.cxyz + small_div(tid, K) * 3;
             const float4 d{x * m - c[0], y * m - c[1], z * m - c[2], 0.0f};
             quad_store(act, tid * S + C, meta.cell[tid] >= 0 ? pack_quad<MODE>(d, bad) : uint4{0u, 0u, 0u, 0u});
         }
         zero_cols<TILE, MODE>(act, S, C + 4, CTp);
     } else {
         for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {
-            const int row = e / CTp, ch = e - row * CTp;
+            const int row = small_div(e, CTp), ch = e - row * CTp;
             const int cell = meta.cell[row];
             float v = 0.0f;
             if (cell >= 0 && ch < CT) {
                 const float m = meta.mask[row];
                 v = ch < C ? feat_load(a.src_feat, (long)cell * C + ch, f16) * m
-                           : a.src_xyz[(long)cell * 3 + (ch - C)] * m - meta.cxyz[(row / K) * 3 + (ch - C)];
+                           : a.src_xyz[(long)cell * 3 + (ch - C)] * m - meta.cxyz[small_div(row, K) * 3 + (ch - C)];
             }
             act_put<MODE>(act, row * S + ch, v, bad);
         }
@@ -1226,7 +1228,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, TILE == 32 ? ELO_TILE32_WAVES : ELO_TI
         zero_cols<TILE, MODE>(act, S, CT, CTp);
     } else {
         for (int e = tid; e < TILE * CTp; e += FUSED_BLOCK) {
-            const int row = e / CTp, ch = e - row * CTp;
+            const int row = small_div(e, CTp), ch = e - row * CTp;
             const long gr = first + row;
             float v = 0.0f;
             if (gr < a.rows && ch < CT) {
@@ -1254,7 +1256,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, TILE == 32 ? ELO_TILE32_WAVES : ELO_TI
         if (wa) seg_store<TILE, MODE>(act, S, N + wb, wa, f16, ra, row_of, all, bad);
     } else {
         for (int e = tid; e < TILE * (wb + wa); e += FUSED_BLOCK) {
-            const int row = e / (wb + wa), ch = e - row * (wb + wa);
+            const int row = small_div(e, wb + wa), ch = e - row * (wb + wa);
             const long gr = first + row;
             const long grc = gr < a.rows ? gr : a.rows - 1;
             const float v = ch < wb ? feat_load(a.before, grc * wb + ch, f16) : feat_load(a.after, grc * wa + (ch - wb), f16);
@@ -1338,14 +1340,14 @@ __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, flo
     const int F = 128, G = F + 2 * C;                                                             // :54-66
     {
         auto cell_of = [&](int row) { return (long)meta.cell[row]; };
-        auto centre_of = [&](int row) { return meta.cell[row] >= 0 ? first_point + row / K : -1L; };
+        auto centre_of = [&](int row) { return meta.cell[row] >= 0 ? first_point + small_div(row, K) : -1L; };
         uint4 r1[SEG_ITEMS], r2[SEG_ITEMS];
         seg_load<TILE>(r1, a.feat1, C, f16, centre_of);
         seg_load<TILE>(r2, a.feat2, C, f16, cell_of);
         GeoRow gr;
         const bool grow = tid < TILE;
         const int gcell = grow ? meta.cell[tid] : -1;
-        if (grow) gr = geo_load(a.xyz1 + (gcell >= 0 ? first_point + tid / K : 0) * 3, a.xyz2 + (long)(gcell >= 0 ? gcell : 0) * 3);
+        if (grow) gr = geo_load(a.xyz1 + (gcell >= 0 ? first_point + small_div(tid, K) : 0) * 3, a.xyz2 + (long)(gcell >= 0 ? gcell : 0) * 3);
         seg_store<TILE, MODE>(act, S, F, C, f16, r1, centre_of, [](int) { return true; }, bad);
         seg_store<TILE, MODE>(act, S, F + C, C, f16, r2, cell_of, [&](int row) { return meta.mask[row] != 0.0f; }, bad);
         if (grow) geo_store<MODE>(act, tid * S + G, gr, meta.mask[tid], gcell >= 0, bad);           // columns [G, G+16)
@@ -1829,7 +1831,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
     const float bias_word = rr_bias_request(bsrc, BN, (int)threadIdx.x);
     const float *bt = lds + RR_BIAS_OFF;
     // ---- row metadata + gather, every load requested before the first use (this lane's row: r = wave * 16 + i16)
-    const int r = wave * 16 + i16, pi = r / K;
+    const int r = wave * 16 + i16, pi = small_div(r, K);
     long pt = first_point + pi;
     const bool used = pi < P && pt < total_points;
     if (!used) pt = first_point;
@@ -1942,7 +1944,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
     const float bias_word = rr_bias_request(bsrc, BN, (int)threadIdx.x);
     const float *bt = lds + RR_BIAS_OFF;
     // ---- row metadata + gather (this lane's row: r = wave * 16 + i16 = point * K + slot)
-    const int r = wave * 16 + i16, pi = r / K;
+    const int r = wave * 16 + i16, pi = small_div(r, K);
     long pt = first_point + pi;
     const bool used = pi < P && pt < total_points;
     if (!used) pt = first_point;
@@ -2269,7 +2271,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
     __syncthreads();
     RR_STAMP(3);
     // ---- this lane's row: gather [features | xyz difference]
-    const int r = wave * 16 + i16, pi = r / K;
+    const int r = wave * 16 + i16, pi = small_div(r, K);
     const int cell = cell_row[r];
     const bool used = cell >= 0;                     // (rows of points beyond the end keep -1)
     const float mk = mask_row[r];
@@ -2564,14 +2566,14 @@ __global__ __launch_bounds__(FUSED_BLOCK, ELO_TILE_WAVES) void cv2_kernel(const 
     const int Cp = ceil16(C), XYZ = 192;
     {
         auto cell_of = [&](int row) { return (long)meta.cell[row]; };
-        auto centre_of = [&](int row) { return meta.cell[row] >= 0 ? first_point + row / K : -1L; };
+        auto centre_of = [&](int row) { return meta.cell[row] >= 0 ? first_point + small_div(row, K) : -1L; };
         uint4 rc[SEG_ITEMS], rf[SEG_ITEMS];
         seg_load<TILE>(rc, a.cost, 64, f16, cell_of);                                 // grouped cost * mask  :110
         seg_load<TILE>(rf, a.feat1, C, f16, centre_of);                               // centre features      :115
         GeoRow gr;
         const bool grow = tid < TILE;
         const int gcell = grow ? meta.cell[tid] : -1;
-        if (grow) gr = geo_load(a.xyz1 + (gcell >= 0 ? first_point + tid / K : 0) * 3, a.xyz1 + (long)(gcell >= 0 ? gcell : 0) * 3);
+        if (grow) gr = geo_load(a.xyz1 + (gcell >= 0 ? first_point + small_div(tid, K) : 0) * 3, a.xyz1 + (long)(gcell >= 0 ? gcell : 0) * 3);
         seg_store<TILE, MODE>(act, S, 0, 64, f16, rc, cell_of, [&](int row) { return meta.mask[row] != 0.0f; }, bad);
         seg_store<TILE, MODE>(act, S, 128, C, f16, rf, centre_of, [](int) { return true; }, bad);
         zero_cols<TILE, MODE>(act, S, 128 + C, 128 + Cp);
