@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1800)
     ap.add_argument("--pool", type=int, default=7,
                     help="distinct synthetic pairs kept in HBM (coprime to --lanes, so a lane sees a different pair on every replay)")
+    ap.add_argument("--inputs", choices=("copied", "in-place"), default="copied",
+                    help="copied: every step copies a pooled pair into its lane's input buffer (a launch in the lane's chain); "
+                         "in-place: the lanes' buffers are filled once, before the timed region (a producer writing in place)")
     ap.add_argument("--lanes", type=int, default=8,
                     help="independent forwards in flight (hipGraphs, dealt over the 4 hardware queues: use a multiple of 4)")
     ap.add_argument("--products", choices=("split", "half"), default="split",
@@ -702,11 +705,17 @@ def main():
         # per repeat, inside the timed region too (7 floats per pair: the only exchange of the inference path,
         # main.py:557-572)
         pose_log = torch.empty((max(args.steps, warmup), B, 7), device=dev)
+        if not args.no_graph and args.inputs == "in-place":
+            for lane in range(lanes):                    # untimed: every lane's input buffer gets its own synthetic pair
+                net.lane_input(lane).copy_(pool[lane % len(pool)])
+            sync()
 
         def step(i):
             pair = pool[i % len(pool)]
             if args.no_graph:                            # the l0 pose-head kernel writes the log row itself
                 return net.forward(pair[:B], pair[B:], pose_out=pose_log[i])
+            if args.inputs == "in-place":                # the lane's buffer holds its pair (filled before the timed region)
+                return net.submit(i % lanes)
             return net.submit(i % lanes, pair)           # step i rides lane i % lanes: one copy in (the stacked pair), graph replay
 
         def begin_repeat(reset=False):

@@ -268,14 +268,24 @@ class PWCLONet:
                                    "weights or run the fp32-MFMA build (ELO_DENSE_F32=1)" % bad)
         return self.lane_poses(lane_index) if isinstance(lane["pose"], _ops.PoseRing) else self.lane_pose(lane_index)
 
-    def submit(self, lane_index, xyz_f1_proj, xyz_f2_proj=None):
+    def lane_input(self, lane_index):
+        """The lane's input buffer, (2B,H,W,3) = [frame 1 | frame 2]: a producer (a data loader, elo_input_stage, the previous
+        stage of a pipeline) that writes its range images HERE -- on the lane's stream, or ordered before the submit -- needs no
+        copy: submit(lane_index) then replays on what the buffer holds."""
+        self._check_fresh()
+        return self._lanes[lane_index]["pair"]
+
+    def submit(self, lane_index, xyz_f1_proj=None, xyz_f2_proj=None):
         """Enqueue one forward on lane `lane_index` (its own stream); returns the lane's static outputs,
         valid once that stream has been synchronised (or waited on).  With `xyz_f2_proj` None the first
-        argument is the stacked pair (2B,H,W,3) = [frame 1 | frame 2]: one copy instead of two."""
+        argument is the stacked pair (2B,H,W,3) = [frame 1 | frame 2]: one copy instead of two; with both None the lane's
+        input buffer was written in place (lane_input): no copy."""
         self._check_fresh()
         lane = self._lanes[lane_index]
         with torch.cuda.stream(lane["stream"]):
-            if xyz_f2_proj is None:
+            if xyz_f1_proj is None:
+                pass
+            elif xyz_f2_proj is None:
                 lane["pair"].copy_(xyz_f1_proj, non_blocking=True)
             else:
                 lane["in"][0].copy_(xyz_f1_proj, non_blocking=True)
