@@ -192,6 +192,14 @@ def test_lanes_take_a_stacked_pair_and_log_the_pose_row():
         for e, o in zip(eager, out):
             assert torch.equal(e, o)
         assert torch.equal(net.lane_pose(lane), row)
+    # a producer that writes the lane's input buffer in place: submit(lane) replays without a copy
+    net.lane_input(1).zero_()
+    with torch.cuda.stream(net.lane_stream(1)):
+        net.lane_input(1).copy_(pair)
+    out = net.submit(1)
+    net.lane_stream(1).synchronize()
+    for e, o in zip(eager, out):
+        assert torch.equal(e, o)
 
 
 def test_half_products_forward(kernel_path):
