@@ -124,20 +124,33 @@ __global__ __launch_bounds__(64) void bn_bwd_combine_kernel(const float *__restr
     if (threadIdx.x == 0) { sums[c] = (float)a; sums[C + c] = (float)b; }
 }
 
+// (C is a power of two <= 256 (check_bn), so q = C / 4 divides the block and the grid stride: a thread keeps ONE channel quad for
+//  its whole life.  The first form took `i % q` -- a 64-bit modulo, ~150 instructions -- and re-read the four per-channel
+//  constants for every 16-byte element, one element in flight per thread: tools/isa_by_line.py.  Same arithmetic.)
+constexpr int BN_APPLY_UNROLL = 4;                  // elements in flight per thread
+
 __global__ __launch_bounds__(TB) void bn_apply_kernel(const float *__restrict__ z, long n4, int C, const float *__restrict__ mean,
                                                       const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                       const float *__restrict__ beta, int relu, float *__restrict__ y)
 {
-    const int q = C >> 2;
+    const int cg = threadIdx.x & ((C >> 2) - 1);
+    const float4 m = ld4(mean, cg), s = ld4(invstd, cg), g = ld4(gamma, cg), b = ld4(beta, cg);
     const long stride = (long)gridDim.x * TB;
-    for (long i = (long)blockIdx.x * TB + threadIdx.x; i < n4; i += stride) {
-        const int cg = (int)(i % q);
-        const float4 v = ld4(z, i), m = ld4(mean, cg), s = ld4(invstd, cg), g = ld4(gamma, cg), b = ld4(beta, cg);
+    auto one = [&](const float4 v) {
         float4 o{(v.x - m.x) * s.x * g.x + b.x, (v.y - m.y) * s.y * g.y + b.y, (v.z - m.z) * s.z * g.z + b.z,
                  (v.w - m.w) * s.w * g.w + b.w};
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        reinterpret_cast<float4 *>(y)[i] = o;
+        return o;
+    };
+    long i = (long)blockIdx.x * TB + threadIdx.x;
+    for (; i + (BN_APPLY_UNROLL - 1) * stride < n4; i += BN_APPLY_UNROLL * stride) {
+        float4 v[BN_APPLY_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BN_APPLY_UNROLL; ++u) v[u] = ld4(z, i + u * stride);
+#pragma unroll
+        for (int u = 0; u < BN_APPLY_UNROLL; ++u) reinterpret_cast<float4 *>(y)[i + u * stride] = one(v[u]);
     }
+    for (; i < n4; i += stride) reinterpret_cast<float4 *>(y)[i] = one(ld4(z, i));
 }
 
 struct BnCol { float4 m, s, g, b; };
@@ -192,19 +205,27 @@ __global__ __launch_bounds__(TB) void bn_bwd_apply_kernel(const float *__restric
                                                           const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
                                                           const float *__restrict__ sums, float *__restrict__ dz)
 {
-    const int q = C >> 2;
+    const int cg = threadIdx.x & ((C >> 2) - 1);     // (one channel quad per thread: see bn_apply_kernel)
     const long stride = (long)gridDim.x * TB;
     const float inv_m = 1.0f / (float)M;
-    for (long i = (long)blockIdx.x * TB + threadIdx.x; i < n4; i += stride) {
-        const int cg = (int)(i % q);
-        const BnCol p{ld4(mean, cg), ld4(invstd, cg), ld4(gamma, cg), ld4(beta, cg)};
-        const float4 a1 = ld4(sums, cg), a2 = ld4(sums + C, cg);
-        const float4 k1{a1.x * inv_m, a1.y * inv_m, a1.z * inv_m, a1.w * inv_m}, k2{a2.x * inv_m, a2.y * inv_m, a2.z * inv_m, a2.w * inv_m};
+    const BnCol p{ld4(mean, cg), ld4(invstd, cg), ld4(gamma, cg), ld4(beta, cg)};
+    const float4 a1 = ld4(sums, cg), a2 = ld4(sums + C, cg);
+    const float4 k1{a1.x * inv_m, a1.y * inv_m, a1.z * inv_m, a1.w * inv_m}, k2{a2.x * inv_m, a2.y * inv_m, a2.z * inv_m, a2.w * inv_m};
+    auto one = [&](const float4 dyv, const float4 zv) {
         float4 g, xh;
-        bn_back(ld4(dy, i), ld4(z, i), p, relu, g, xh);
-        reinterpret_cast<float4 *>(dz)[i] = float4{p.g.x * p.s.x * (g.x - k1.x - xh.x * k2.x), p.g.y * p.s.y * (g.y - k1.y - xh.y * k2.y),
-                                                   p.g.z * p.s.z * (g.z - k1.z - xh.z * k2.z), p.g.w * p.s.w * (g.w - k1.w - xh.w * k2.w)};
+        bn_back(dyv, zv, p, relu, g, xh);
+        return float4{p.g.x * p.s.x * (g.x - k1.x - xh.x * k2.x), p.g.y * p.s.y * (g.y - k1.y - xh.y * k2.y),
+                      p.g.z * p.s.z * (g.z - k1.z - xh.z * k2.z), p.g.w * p.s.w * (g.w - k1.w - xh.w * k2.w)};
+    };
+    long i = (long)blockIdx.x * TB + threadIdx.x;
+    for (; i + (BN_APPLY_UNROLL - 1) * stride < n4; i += BN_APPLY_UNROLL * stride) {
+        float4 a[BN_APPLY_UNROLL], b[BN_APPLY_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BN_APPLY_UNROLL; ++u) { a[u] = ld4(dy, i + u * stride); b[u] = ld4(z, i + u * stride); }
+#pragma unroll
+        for (int u = 0; u < BN_APPLY_UNROLL; ++u) reinterpret_cast<float4 *>(dz)[i + u * stride] = one(a[u], b[u]);
     }
+    for (; i < n4; i += stride) reinterpret_cast<float4 *>(dz)[i] = one(ld4(dy, i), ld4(z, i));
 }
 
 // ---- dW = X^T G ------------------------------------------------------------------------------------------------------
