@@ -42,7 +42,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void group_concat_bwd_kernel(const elo_g
         }
     }
     for (long e = me; e < rows * CT; e += stride) {
-        const long row = e / CT;
+        const long row = point_batch(e, CT);
         const int c = (int)(e - row * CT);
         if (a.mask[row] == 0.0f) continue;
         const float g = a.grad_out[e];
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void masked_maxpool_bwd_kernel(const elo
 {
     const long total = (long)a.batch * a.npoints * a.C;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long pt = e / a.C;
+        const long pt = point_batch(e, a.C);
         const int c = (int)(e - pt * a.C);
         const float *x = a.x + pt * a.K * a.C + c;
         const float *m = a.mask + pt * a.K;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_bwd_kernel(const elo_cv_
     }
     if (a.grad_feat1) {
         for (long e = me; e < points * a.C; e += stride) {           // feat1 is tiled over K: its gradient is the sum
-            const long pt = e / a.C;
+            const long pt = point_batch(e, a.C);
             const int c = (int)(e - pt * a.C);
             float s = 0.0f;
             for (int k = 0; k < a.K; ++k) s += a.grad_out[(pt * a.K + k) * CT + 10 + c];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_bwd_kernel(const elo_cv_
     }
     if (a.grad_feat2) {
         for (long e = me; e < points * a.K * a.C; e += stride) {
-            const long row = e / a.C;
+            const long row = point_batch(e, a.C);
             const int c = (int)(e - row * a.C);
             if (a.mask[row] == 0.0f) continue;
             const float g = a.grad_out[row * CT + 10 + a.C + c];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_bwd_kernel(const elo_cv_
     }
     if (a.grad_feat1) {
         for (long e = me; e < points * a.C; e += stride) {
-            const long pt = e / a.C;
+            const long pt = point_batch(e, a.C);
             const int c = (int)(e - pt * a.C);
             float s = 0.0f;
             for (int k = 0; k < a.K; ++k) s += a.grad_rest[(pt * a.K + k) * CR + c];
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_bwd_kernel(const elo_cv_
     }
     if (a.grad_cost) {
         for (long e = me; e < points * a.K * a.Cc; e += stride) {
-            const long row = e / a.Cc;
+            const long row = point_batch(e, a.Cc);
             const int c = (int)(e - row * a.Cc);
             if (a.mask[row] == 0.0f) continue;
             const float g = a.grad_rest[row * CR + a.C + c];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_bwd_kernel(const elo_s
 {
     const long total = (long)a.batch * a.npoints * a.C;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long pt = e / a.C;
+        const long pt = point_batch(e, a.C);
         const int c = (int)(e - pt * a.C);
         const float *l = a.logits + pt * a.K * a.C + c;
         const float *v = a.values + pt * a.K * (long)a.values_stride + c;
@@ -248,9 +248,9 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_bwd_elementwise_kerne
     const int q = a.C >> 2;
     const long per_b = (long)a.npoints * q, total = per_b * a.batch;
     for (long i = (long)blockIdx.x * ELO_BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * ELO_BLOCK) {
-        const int b = (int)(i / per_b);
+        const int b = per_b < 0x7fffffffL ? point_batch(i, (int)per_b) : (int)(i / per_b);     // (32-bit divisions: elo_common.h)
         const long r = i - (long)b * per_b;
-        const int n = (int)(r / q), cg = (int)(r - (long)n * q);
+        const int n = point_batch(r, q), cg = (int)(r - (long)n * q);
         const float *p = a.xyz + ((long)b * a.npoints + n) * 3;
         const float px = p[0], py = p[1], pz = p[2];
         const float4 w = reinterpret_cast<const float4 *>(a.weight)[i], f = reinterpret_cast<const float4 *>(a.feature)[i];
