@@ -782,8 +782,8 @@ __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_ar
 #pragma unroll
             for (int u = 0; u < MINE; ++u) {
                 if (d_[u] == 0.0f) continue;
-                if (m_[u] > M) { const float sc = expf(M - m_[u]); D = D * sc + d_[u]; A = A * sc + a_[u]; M = m_[u]; }
-                else { const float sc = expf(m_[u] - M); D += d_[u] * sc; A += a_[u] * sc; }
+                if (m_[u] > M) { const float sc = exp_acc(M - m_[u]); D = D * sc + d_[u]; A = A * sc + a_[u]; M = m_[u]; }
+                else { const float sc = exp_acc(m_[u] - M); D += d_[u] * sc; A += a_[u] * sc; }
             }
         }
         mpart[(0 * 4 + q) * 64 + c] = M; mpart[(1 * 4 + q) * 64 + c] = D; mpart[(2 * 4 + q) * 64 + c] = A;
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_ar
             float DD = 0.0f, AA = 0.0f;
             for (int i = 0; i < 4; ++i) {
                 if (mpart[(1 * 4 + i) * 64 + tid] == 0.0f) continue;
-                const float sc = expf(mpart[(0 * 4 + i) * 64 + tid] - MM);
+                const float sc = exp_acc(mpart[(0 * 4 + i) * 64 + tid] - MM);
                 DD += mpart[(1 * 4 + i) * 64 + tid] * sc; AA += mpart[(2 * 4 + i) * 64 + tid] * sc;
             }
             if (tid < a.C) feat[tid] = DD > 0.0f ? AA / DD : 0.0f;
