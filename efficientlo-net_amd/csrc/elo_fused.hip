@@ -296,7 +296,9 @@ __device__ __forceinline__ ActPair act_pair(const float *p)
 
 // acc[rb][c0 + t] += W_t x A_rb for t < MT column blocks and rb < RB row blocks: one W fragment feeds every row block
 // (products outermost, so consecutive MFMAs go to different accumulators)
-template <int MODE, int MT, int RB, int TPW>
+// A_EXACT: the activations are exact fp16 values (read from fp16 feature storage: lo == 0), so the w_hi x a_lo product adds
+// exact zeros and is not issued (2 matrix instructions per pair instead of 3)
+template <int MODE, int MT, int RB, int TPW, bool A_EXACT = false>
 __device__ __forceinline__ void mma_pair(f32x4 (&acc)[RB][TPW], int c0, const ActPair (&a)[RB], const WPair (&w)[MT])
 {
 #ifdef ELO_DENSE_F32
@@ -327,11 +329,13 @@ __device__ __forceinline__ void mma_pair(f32x4 (&acc)[RB][TPW], int c0, const Ac
 #pragma unroll
             for (int t = 0; t < MT; ++t)
                 acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w[t].lo), __builtin_bit_cast(half8, a[rb].hi), acc[rb][c0 + t], 0, 0, 0);
+        if constexpr (!A_EXACT) {
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
-                acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w[t].hi), __builtin_bit_cast(half8, a[rb].lo), acc[rb][c0 + t], 0, 0, 0);
+                for (int t = 0; t < MT; ++t)
+                    acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, w[t].hi), __builtin_bit_cast(half8, a[rb].lo), acc[rb][c0 + t], 0, 0, 0);
+        }
     }
 #endif
 }
@@ -364,7 +368,7 @@ __device__ __forceinline__ void mfma_shape_guard(f32x4 (&acc)[RB][TPW], int c0)
 #endif
 
 // AFTER_PAIR: the accumulators were last written by mma_pair (false: by the bias initialisation only)
-template <int MODE, int MT, int RB, int TPW, bool AFTER_PAIR = true>
+template <int MODE, int MT, int RB, int TPW, bool AFTER_PAIR = true, bool A_EXACT = false>
 __device__ __forceinline__ void mma_tail(f32x4 (&acc)[RB][TPW], int c0, const uint4 (&a)[RB], const uint4 (&w)[MT])
 {
 #ifndef ELO_DENSE_F32
@@ -396,11 +400,13 @@ __device__ __forceinline__ void mma_tail(f32x4 (&acc)[RB][TPW], int c0, const ui
 #pragma unroll
             for (int t = 0; t < MT; ++t)
                 acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, uint2{w[t].z, w[t].w}), __builtin_bit_cast(half4, uint2{a[rb].x, a[rb].y}), acc[rb][c0 + t], 0, 0, 0);
+        if constexpr (!A_EXACT) {
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
-                acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, uint2{w[t].x, w[t].y}), __builtin_bit_cast(half4, uint2{a[rb].z, a[rb].w}), acc[rb][c0 + t], 0, 0, 0);
+                for (int t = 0; t < MT; ++t)
+                    acc[rb][c0 + t] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, uint2{w[t].x, w[t].y}), __builtin_bit_cast(half4, uint2{a[rb].z, a[rb].w}), acc[rb][c0 + t], 0, 0, 0);
+        }
     }
 #endif
 }
@@ -1575,7 +1581,8 @@ struct RrStream {
 // PER PASS -- a pass is 100-1000 cycles of work, the round trip ~700 under load: tools/rr_clock.sh showed ~500 + 250 k cycles
 // for a pass of k steps whatever the MFMA count, and a build without any MFMA ran as long.
 // emit(pass, t, acc): epilogue of column block 2*pass + t.
-template <int KP, bool TAIL, int NCB, int G0, int MODE = MODE_SPLIT, class Fetch, class Advance, class Emit>
+// XMASK bit k: pair k of `in` holds exact fp16 values (lo == 0); XTAIL: so does the tail block -- see mma_pair's A_EXACT
+template <int KP, bool TAIL, int NCB, int G0, int MODE = MODE_SPLIT, unsigned XMASK = 0u, bool XTAIL = false, class Fetch, class Advance, class Emit>
 __device__ __forceinline__ void rr_layer(const ActPair (&in)[KP > 0 ? KP : 1], const uint4 &tail, const float *bias,
                                          const float *next_bias, float4 (&bias0)[2], Fetch fetch, Advance advance, Emit emit)
 // (L.bias / next_bias: this layer's and the next one's biases IN THE LDS TABLE, see rr_stage_biases)
@@ -1604,11 +1611,12 @@ __device__ __forceinline__ void rr_layer(const ActPair (&in)[KP > 0 ? KP : 1], c
             if (k < KP) {
                 const ActPair a1[1] = {in[k < KP ? k : 0]};
                 const WPair w2[2] = {cur.w[0], cur.w[1]};
-                mma_pair<MODE, 2, 1, 2>(acc, 0, a1, w2);
+                if ((XMASK >> (k & 31)) & 1u) mma_pair<MODE, 2, 1, 2, true>(acc, 0, a1, w2);     // (k is a constant after unrolling)
+                else mma_pair<MODE, 2, 1, 2>(acc, 0, a1, w2);
             } else {
                 const uint4 a1[1] = {tail};
                 const uint4 w2[2] = {cur.w[0].hi, cur.w[1].hi};
-                mma_tail<MODE, 2, 1, 2, (KP > 0)>(acc, 0, a1, w2);
+                mma_tail<MODE, 2, 1, 2, (KP > 0), XTAIL>(acc, 0, a1, w2);
             }
             if (g % 2 == 1) advance(g / 2);
         }
@@ -1877,7 +1885,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
     // ---- the chain
     const uint4 none{0u, 0u, 0u, 0u};
     ActPair h128[4];                                 // CV_0's output (128 channels = 4 pairs)
-    rr_layer<FP, true, 8, 0, MODE>(in0, geo, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<FP, true, 8, 0, MODE, (F16 ? ~0u : 0u)>(in0, geo, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         put_quad(h128[pass], t, pack_quad<MODE>(relu4(acc, a.cv0.relu), bad));
     });
     RR_LAYER_STAMP(3);
@@ -1997,7 +2005,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
         });
     }
     ActPair h128[4];
-    rr_layer<KP1, C == 16, 8, E0, MODE>(in1, ftail, bt + B1, bt + B2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<KP1, C == 16, 8, E0, MODE, (F16 ? ~0xcu : 0u), F16>(in1, ftail, bt + B1, bt + B2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         put_quad(h128[pass], t, pack_quad<MODE>(relu4(acc, a.sum_cost0.relu), bad));
     });
     float4 logit[4];
@@ -2081,7 +2089,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void mlp2_rr_kernel(const JobPair
     rr_barrier();
     const uint4 none{0u, 0u, 0u, 0u};
     ActPair h128[4];
-    rr_layer<KP1, T1, 8, 0, MODE>(in1, tail1, bt, bt + O1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<KP1, T1, 8, 0, MODE, (F16 ? ~0u : 0u), F16>(in1, tail1, bt, bt + O1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         put_quad(h128[pass], t, pack_quad<MODE>(relu4(acc, a.layers[0].relu), bad));
     });
     // the second stage's other inputs: requested now, a layer ahead of their first use
@@ -2117,7 +2125,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void mlp2_rr_kernel(const JobPair
         if (T3 && j == 3) tail3 = quad(sa[j]);
         else put_quad(in3[(B0 + j) / 2], (B0 + j) % 2, quad(sa[j]));
     }
-    rr_layer<KP3, T3, 8, E1, MODE>(in3, tail3, bt + O2, bt + O3, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<KP3, T3, 8, E1, MODE, (F16 ? ~0u : 0u), F16>(in3, tail3, bt + O2, bt + O3, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         put_quad(h128[pass], t, pack_quad<MODE>(relu4(acc, a.layers2[0].relu), bad));
     });
     rr_layer<4, false, 4, E2, MODE>(h128, none, bt + O3, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
@@ -2305,7 +2313,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
     RR_STAMP(5);
     const uint4 none{0u, 0u, 0u, 0u};
     ActPair h1[N1 / 32];
-    rr_layer<FPB / 2, true, N1 / 16, 0, MODE>(in0, dxyz, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
+    rr_layer<FPB / 2, true, N1 / 16, 0, MODE, (F16 ? ~0u : 0u)>(in0, dxyz, bt, bt + B1, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         put_quad(h1[pass], t, pack_quad<MODE>(relu4(acc, a.layers[0].relu), bad));
     });
     RR_STAMP(6);
