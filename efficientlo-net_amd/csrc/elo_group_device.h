@@ -127,8 +127,8 @@ __device__ __forceinline__ RawSlot fetch_slot(const Grid &grid2, int H2, int W2,
     const bool in_grid = active && h >= 0 && h < H2;
     h = h < 0 ? 0 : h >= H2 ? H2 - 1 : h;
     if (w < 0) w += W2;
-    if (w >= W2) w -= W2;
-    w = w < 0 ? 0 : w >= W2 ? W2 - 1 : w;               // only reachable for inactive lanes
+    if (w >= W2) w -= W2;                              // in [0, W2): |dw| <= kernel_w / 2 <= W2 (launchers), and inactive lanes are
+                                                        // handed a real slot's offset by every caller -- no clamp needed behind the wrap
     const Xyz q = pixel3(grid2, h * W2 + w);
     return RawSlot{q.x, q.y, q.z, (h << 16) | w, in_grid};
 }
