@@ -880,18 +880,21 @@ __device__ __forceinline__ float exp_hw(float x) { return __builtin_amdgcn_exp2f
 // online form, a data-dependent branch and two dependent exponentials per row: 370 cycles per row, a THIRD of the
 // register-resident kernel's time at K = 6: tools/rr_clock.sh.)  A single chunk (K <= 8) merges into (-inf, 0, 0) exactly:
 // exp2(-inf) = 0, exp2(0) = 1.  All rows masked: every x is -1e10, the weights are uniform, as in the reference.
-__device__ __forceinline__ void softmax_chunk8(const float (&l)[8], const float (&v)[8], const float (&w)[8], int n,
+// NMAX = 6: the cost volumes' K = 6 as ONE chunk of six slots -- the eight-slot form computed two dead slots (a quarter of the
+// ~100 instructions per point and channel; dead slots add exact zeros, so the sums are the same).
+template <int NMAX = 8>
+__device__ __forceinline__ void softmax_chunk8(const float (&l)[NMAX], const float (&v)[NMAX], const float (&w)[NMAX], int n,
                                                float &mx, float &den, float &acc)
 {
-    float x[8], cm = -INFINITY;
+    float x[NMAX], cm = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NMAX; ++u) {
         x[u] = w[u] == 1.0f ? l[u] : -1e10f;
         cm = u < n ? fmaxf(cm, x[u]) : cm;
     }
     float cd = 0.0f, ca = 0.0f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NMAX; ++u) {
         const float e = u < n ? exp_hw(x[u] - cm) : 0.0f;
         cd += e;
         ca += e * v[u];
@@ -914,6 +917,12 @@ __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int
         const int vword = (pi * K) * S + value_off + c;
         const float *mk = m.mask + pi * K;
         float mx = -INFINITY, den = 0.0f, acc = 0.0f;
+        if (K == 6) {                                     // (uniform)
+            float l[6], v[6], w[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { l[u] = lcol[u * S]; v[u] = act_get(act, vword + u * S); w[u] = mk[u]; }
+            softmax_chunk8<6>(l, v, w, 6, mx, den, acc);
+        } else
         for (int k0 = 0; k0 < K; k0 += 8) {
             float l[8], v[8], w[8];
 #pragma unroll
@@ -1685,6 +1694,12 @@ __device__ __forceinline__ void rr_pool(float *lds, const float4 (&logit)[4], co
             if (p >= total_points) break;
             const float *lcol = lg + (pp * K) * RR_PITCH + ch, *vcol = xv + (pp * K) * RR_PITCH + ch;
             float mx = -INFINITY, den = 0.0f, sum = 0.0f;
+            if (K == 6) {                                 // (uniform)
+                float l[6], v[6], w[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) { l[u] = lcol[u * RR_PITCH]; v[u] = vcol[u * RR_PITCH]; w[u] = mrow[pp * 6 + u]; }
+                softmax_chunk8<6>(l, v, w, 6, mx, den, sum);
+            } else
             for (int k0 = 0; k0 < K; k0 += 8) {
                 float l[8], v[8], w[8];
 #pragma unroll
@@ -1708,10 +1723,10 @@ __device__ __forceinline__ void rr_pool(float *lds, const float4 (&logit)[4], co
 // barriers).  Both forms give the same bits: a maximum does not depend on the order, and the softmax sums are scanned in
 // the order softmax_chunk8 adds them.  Values must be >= 0 (a ReLU in front: the launchers check), so that the maxima can be
 // taken on the bit patterns (dpp_imax_step: one v_max_i32_dpp per step).
-template <int CTRL>
 // (`old` = the maximum's identity, as in dpp_imax_step: these controls read a valid lane everywhere, and with the identity there
 //  the compiler folds move + max into ONE v_max_i32_dpp; with old = v it emitted v_mov_b32_dpp + v_max_i32: 128 of the 1.6 k vector
 //  instructions of a setconv_narrow wave, 64 of the 600 of a setconv_rr wave)
+template <int CTRL>
 __device__ __forceinline__ int dpp_imax_all(int v) { return max(__builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, 0xf, 0xf, false), v); }
 
 template <int NOUT, bool F16>
