@@ -882,7 +882,9 @@ __device__ __forceinline__ float exp_hw(float x) { return __builtin_amdgcn_exp2f
 // exp2(-inf) = 0, exp2(0) = 1.  All rows masked: every x is -1e10, the weights are uniform, as in the reference.
 // NMAX = 6: the cost volumes' K = 6 as ONE chunk of six slots -- the eight-slot form computed two dead slots (a quarter of the
 // ~100 instructions per point and channel; dead slots add exact zeros, so the sums are the same).
-template <int NMAX = 8>
+// FIRST: the chunk opens the running triple (it merges into (-inf, 0, 0): the merge's factors are exactly 0 and 1, so the triple IS
+// the chunk's -- two exponentials and eight more instructions per point and channel not issued)
+template <int NMAX = 8, bool FIRST = false>
 __device__ __forceinline__ void softmax_chunk8(const float (&l)[NMAX], const float (&v)[NMAX], const float (&w)[NMAX], int n,
                                                float &mx, float &den, float &acc)
 {
@@ -899,6 +901,7 @@ __device__ __forceinline__ void softmax_chunk8(const float (&l)[NMAX], const flo
         cd += e;
         ca += e * v[u];
     }
+    if constexpr (FIRST) { mx = cm; den = cd; acc = ca; return; }
     const float m2 = fmaxf(mx, cm), s0 = exp_hw(mx - m2), s1 = exp_hw(cm - m2);
     den = den * s0 + cd * s1;
     acc = acc * s0 + ca * s1;
@@ -921,7 +924,7 @@ __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int
             float l[6], v[6], w[6];
 #pragma unroll
             for (int u = 0; u < 6; ++u) { l[u] = lcol[u * S]; v[u] = act_get(act, vword + u * S); w[u] = mk[u]; }
-            softmax_chunk8<6>(l, v, w, 6, mx, den, acc);
+            softmax_chunk8<6, true>(l, v, w, 6, mx, den, acc);
         } else
         for (int k0 = 0; k0 < K; k0 += 8) {
             float l[8], v[8], w[8];
@@ -1698,7 +1701,7 @@ __device__ __forceinline__ void rr_pool(float *lds, const float4 (&logit)[4], co
                 float l[6], v[6], w[6];
 #pragma unroll
                 for (int u = 0; u < 6; ++u) { l[u] = lcol[u * RR_PITCH]; v[u] = vcol[u * RR_PITCH]; w[u] = mrow[pp * 6 + u]; }
-                softmax_chunk8<6>(l, v, w, 6, mx, den, sum);
+                softmax_chunk8<6, true>(l, v, w, 6, mx, den, sum);
             } else
             for (int k0 = 0; k0 < K; k0 += 8) {
                 float l[8], v[8], w[8];
