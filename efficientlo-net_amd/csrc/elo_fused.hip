@@ -925,6 +925,11 @@ __device__ __forceinline__ void pool_masked_softmax(const float *act, int S, int
 #pragma unroll
             for (int u = 0; u < 6; ++u) { l[u] = lcol[u * S]; v[u] = act_get(act, vword + u * S); w[u] = mk[u]; }
             softmax_chunk8<6, true>(l, v, w, 6, mx, den, acc);
+        } else if (K == 4) {                              // stage 2 of the cost volume
+            float l[4], v[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { l[u] = lcol[u * S]; v[u] = act_get(act, vword + u * S); w[u] = mk[u]; }
+            softmax_chunk8<4, true>(l, v, w, 4, mx, den, acc);
         } else
         for (int k0 = 0; k0 < K; k0 += 8) {
             float l[8], v[8], w[8];

@@ -3,6 +3,8 @@ kernels"): weight packing into MFMA B-fragment order and torch-tensor front-ends
 
 A packed layer is cached in the VariableStore next to the folded weights and dropped by
 VariableStore.invalidate(); packing costs a few small torch ops once per parameter update."""
+import os
+
 import torch
 
 from . import _lib as L
@@ -403,6 +405,9 @@ def _all_pixels(B, H, W, device):
     return hit
 
 
+_SELECT_DENSE_TILES = int(os.environ.get("ELO_SELECT_DENSE_TILES", "1024"))      # read once (a captured graph bakes the form in)
+
+
 def group_prepass(kind, xyz1_grid, xyz2_grid, group, K):
     """A cost volume's grouping (every pixel of xyz1_grid a centre; kind "select" = stage 1's select-k, "random" = stage
     2's random-k) as its own launch: (idx (B,N,K,3) int32, mask (B,N,K)).  Forms: random-k takes the LDS-tiled
@@ -416,7 +421,7 @@ def group_prepass(kind, xyz1_grid, xyz2_grid, group, K):
     mask = torch.empty((B, N, K), dtype=torch.float32, device=xyz1_grid.device)
     if kind == "select":
         from .fused_conv import _select_dense_fits                # the launcher's own bounds (K <= 7, <= 512 slots, 64 KB of LDS)
-        dense = -(-W // 64) * H * B >= 1024 and _select_dense_fits(kH, kW, K, 0, group.stride_h, group.stride_w)
+        dense = -(-W // 64) * H * B >= _SELECT_DENSE_TILES and _select_dense_fits(kH, kW, K, 0, group.stride_h, group.stride_w)
         entry = "elo_fused_conv_select_k_dense" if dense else "elo_fused_conv_select_k"
     else:
         RH, RW = 1 // group.stride_h + kH, 63 // group.stride_w + kW           # (fused_conv._dense_fits)
