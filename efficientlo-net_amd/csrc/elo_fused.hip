@@ -2239,7 +2239,9 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
     float *mask_row = reinterpret_cast<float *>(cell_row + RR_ROWS);
     int *chw = reinterpret_cast<int *>(mask_row + RR_ROWS);                  // [128] (h << 16) | w of the centres
     float *cxyz = reinterpret_cast<float *>(chw + RR_ROWS);                  // [128 * 3]
-    {
+    if (tid < RR_ROWS) { cell_row[tid] = -1; mask_row[tid] = 0.0f; }
+    if (wave == 0) {            // (uniform) the P <= 64 centres of the workgroup are the first wave's lanes: the other seven waves
+                                // used to run the same ~60 instructions (division, clamped loads) for nothing
         const long ptq = first_point + tid;
         const bool mine = tid < P && ptq < total_points;
         const long pq = mine ? ptq : first_point;
@@ -2249,7 +2251,6 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
         else { hc = n / a.W; wc = n - hc * a.W; }
         const float *c = a.xyz1_grid + (((long)b * a.H + hc) * a.W + wc) * 3;
         const float cx = c[0], cy = c[1], cz = c[2];
-        if (tid < RR_ROWS) { cell_row[tid] = -1; mask_row[tid] = 0.0f; }
         if (mine) {
             chw[tid] = (hc << 16) | wc;
             cxyz[tid * 3 + 0] = cx; cxyz[tid * 3 + 1] = cy; cxyz[tid * 3 + 2] = cz;
@@ -2272,12 +2273,12 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
             const int pp = (wave * 16) / K + j;                              // (K divides 16 here: see the launcher)
             const long ptw = first_point + pp;
             live[j] = j < per_wave && pp < P && ptw < total_points;          // (uniform)
-            const int ppc = live[j] ? pp : 0;
-            pb[j] = (int)((unsigned)(live[j] ? ptw : first_point) / (unsigned)a.npoints);
-            const int hwc = __builtin_amdgcn_readfirstlane(chw[ppc]);
+            if (!live[j]) continue;                                          // (K = 16: the wave has ONE point -- no dead second fetch)
+            pb[j] = (int)((unsigned)ptw / (unsigned)a.npoints);
+            const int hwc = __builtin_amdgcn_readfirstlane(chw[pp]);
             ph[j] = div_stride(hwc >> 16, a.group.stride_h); pw[j] = div_stride(hwc & 0xffff, a.group.stride_w);
 #pragma unroll
-            for (int e = 0; e < 3; ++e) pc[j][e] = uniform(cxyz[ppc * 3 + e]);
+            for (int e = 0; e < 3; ++e) pc[j][e] = uniform(cxyz[pp * 3 + e]);
             first[j] = fetch_slot(grid_buffer(a.src_xyz + (size_t)pb[j] * a.H2 * a.W2 * 3), a.H2, a.W2, lds_off[lane < KT ? lane : 0], ph[j], pw[j],
                                   lane < KT);
         }
