@@ -54,6 +54,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # ibid.: v_mfma_f32_16x16x4_f32 dense peak -- onl
 MFMA_PRODUCTS = 3              # fp16 matrix-core products per fp32-class product: hi*hi + hi*lo + lo*hi (elo_fused.hip)
 MIN_TIMED_S = 0.25
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc", "summary.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_HIRES_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_hires", "summary.json")   # the per-operator kernels at the 128 x 2048 l0 shape
 
 
 def pkg(sub=None):
@@ -228,6 +229,24 @@ def _live_traffic(batch, features, timeout=150):
         % (batch, " --half" if features == "f16" else "", got["FETCH_SIZE"], got["WRITE_SIZE"]))
 
 
+def _hires_traffic(features):
+    """HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, KB) of the four per-operator kernels at the 128 x 2048 l0 shape, batch
+    8, from the committed counter passes (profiles/r05_pmc_hires/summary.json: tools/pmc_collect.sh with ELO_PMC_GRID=32x256);
+    None per term when that pass is not in the file."""
+    try:
+        table = json.load(open(PMC_HIRES_SUMMARY))
+    except (OSError, ValueError):
+        return None
+    out = {}
+    for term, kernel, tag in (("A1", "cv_encode1", "encode1"), ("P1", "softmax_pool", "pool"), ("A2", "cv_encode2", "encode2"),
+                              ("P2", "softmax_pool", "pool2")):
+        row = next((r for r in table.get("rows", []) if r["tag"] == "%s%s_b8" % (tag, "_f16" if features == "f16" else "")), None)
+        out[term] = None if row is None else {"traffic_bytes": int(row["hbm_MB_fetch_x2"] * 1e6), "algorithmic_bytes": int(row["algorithmic_MB"] * 1e6),
+                                              "trace_us": row["avg_us"]}
+    out["source"] = os.path.relpath(PMC_HIRES_SUMMARY, ROOT)
+    return out
+
+
 LEVELS = ("l2_origin", "l2", "l1", "l0")          # the order in which a forward issues its four cost volumes
 
 
@@ -292,12 +311,17 @@ def cost_volume_leg(dev, B, H_in, W_in, half, reps=20):
 # :242, :316, :390)
 PER_OPERATOR_LEVELS = {"l0": (16, 225, 16, 6, (11, 41)), "l1": (8, 113, 32, 6, (7, 25)), "l2": (4, 57, 64, 6, (5, 15)),
                        "l2_origin": (4, 57, 64, 32, (5, 35))}
+# ... and of a 128 x 2048 forward (BASELINE configs[4]'s scans: levels 32x256 / 16x128 / 8x64; same channels, K and windows)
+PER_OPERATOR_LEVELS_HIRES = {"l0": (32, 256, 16, 6, (11, 41)), "l1": (16, 128, 32, 6, (7, 25)), "l2": (8, 64, 64, 6, (5, 15)),
+                             "l2_origin": (8, 64, 64, 32, (5, 35))}
 
 
-def per_operator_all_levels_leg(dev, batch, half):
+def per_operator_all_levels_leg(dev, batch, half, table=None):
     """The 16 per-operator cost-volume launches of a forward (A1, P1, A2, P2 at l0, l1, l2, l2_origin) against the sum of
-    their algorithmic bytes (216 MB at batch 8 with fp16 features), as separate launches."""
-    levels = {lv: per_operator_leg(dev, batch, half, level=lv) for lv in PER_OPERATOR_LEVELS}
+    their algorithmic bytes (216 MB at batch 8 with fp16 features), as separate launches.  `table`: the
+    level shapes (default: the 64 x 1800 forward's; PER_OPERATOR_LEVELS_HIRES: the 128 x 2048 forward's)."""
+    table = table or PER_OPERATOR_LEVELS
+    levels = {lv: per_operator_leg(dev, batch, half, level=lv, table=table) for lv in table}
     tot_b, tot_us = sum(r["bytes"] for r in levels.values()), sum(r["us"] for r in levels.values())
     gbs = tot_b / tot_us / 1e3
     return {"kernel": "ELO_FUSED=0 cost volume, all four levels: 4 x (cv_encode1 + softmax_pool + cv_encode2 + softmax_pool)",
@@ -307,13 +331,13 @@ def per_operator_all_levels_leg(dev, batch, half):
             "levels": {lv: {"us": r["us"], "bytes": r["bytes"], "frac": r["frac"]} for lv, r in levels.items()}}
 
 
-def per_operator_leg(dev, batch, half, reps=20, level="l0"):
+def per_operator_leg(dev, batch, half, reps=20, level="l0", table=None):
     """The four HBM-bound kernels of the ELO_FUSED=0 cost volume at one level (default l0) (SURVEY 8(d) terms A1, P1, A2, P2:
     gather/encode and masked softmax pooling with the GEMMs between them left to hipBLASLt), each against its own
-    algorithmic bytes."""
+    algorithmic bytes.  `table`: the level shapes (PER_OPERATOR_LEVELS, or PER_OPERATOR_LEVELS_HIRES for configs[4]'s scans)."""
     import torch
     ops, synth, elo = pkg("_ops"), pkg("synth"), pkg()
-    H, W, C, Kq, win = PER_OPERATOR_LEVELS[level]
+    H, W, C, Kq, win = (table or PER_OPERATOR_LEVELS)[level]
     Kp = 4
     N = H * W
     g = torch.Generator(device="cpu").manual_seed(3)
@@ -342,7 +366,7 @@ def per_operator_leg(dev, batch, half, reps=20, level="l0"):
         terms[term] = {"bytes": int(nbytes), "us": round(sec * 1e6, 2), "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4)}
         tot_b, tot_s = tot_b + nbytes, tot_s + sec
     gbs = tot_b / tot_s / 1e9
-    return {"kernel": "ELO_FUSED=0 cost volume at %s: cv_encode1 + softmax_pool + cv_encode2 + softmax_pool" % level, "batch": batch,
+    return {"kernel": "ELO_FUSED=0 cost volume at %s (%dx%d grid): cv_encode1 + softmax_pool + cv_encode2 + softmax_pool" % (level, H, W), "batch": batch,
             "features": "f16" if half else "f32", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b), "us": round(tot_s * 1e6, 2), "terms": terms}
 
@@ -389,6 +413,14 @@ def roofline_leg(args, dev, net, reps=50):
         out["per_operator_b64_f32"] = per_operator_leg(dev, 64, False)
         out["per_operator_b64_f16"] = per_operator_leg(dev, 64, True)
         out["per_operator_all_levels_b8_f16"] = per_operator_all_levels_leg(dev, 8, True)
+        # "take the roofline reading at C3 / C5 batch sizes" -- configs[4]'s workload (128 x 2048 scans: l0 is
+        # 32 x 256 = 8192 points) at batch 8 on the per-operator (HBM-bound) kernels, fp16 (configs[2]'s storage) and fp32
+        out["per_operator_hires_b8_f16"] = per_operator_leg(dev, 8, True, table=PER_OPERATOR_LEVELS_HIRES)
+        out["per_operator_hires_b8_f32"] = per_operator_leg(dev, 8, False, table=PER_OPERATOR_LEVELS_HIRES)
+        out["per_operator_hires_all_levels_b8_f16"] = per_operator_all_levels_leg(dev, 8, True, table=PER_OPERATOR_LEVELS_HIRES)
+        out["per_operator_hires_all_levels_b8_f32"] = per_operator_all_levels_leg(dev, 8, False, table=PER_OPERATOR_LEVELS_HIRES)
+        for key in ("per_operator_hires_b8_f16", "per_operator_hires_b8_f32"):       # counter traffic beside it (committed passes)
+            out[key]["traffic"] = _hires_traffic(out[key]["features"])
     return out
 
 
@@ -812,6 +844,7 @@ def main():
         "value": None if dry else round(world * B * args.steps / elapsed, 3),
         "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": warmup,
+        "warmup_requested": args.warmup,                  # `warmup` = max(--warmup, 2 per lane): every lane's graph has replayed twice
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "repeats": len(repeats), "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in repeats[:16]],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

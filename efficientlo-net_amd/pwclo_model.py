@@ -156,7 +156,7 @@ def _adjacent_frames(a, b):
 # Test hook: a list here receives (level, scratch, B, N, H, W, projected xyz grid) of every warp-refinement projection of an
 # eager inference forward -- `scratch` is elo_warp_project_args.scratch, whose words [B*H*W + 4B, B*H*W + 4B + B*N) are the
 # projection cell of every warped point: the product's own DISCRETE decisions (which cell, and through the grid which point
-# won it), for tests/test_parity_flips_gpu.py to compare with the oracle's.
+# won it), for tests/test_parity_flips_gpu.py to compare with the oracle's; the warped points themselves come last.
 PROJECTION_TAP = None
 
 _ZEROS = {}
@@ -365,7 +365,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
         _warped, xyz_warp_proj_f1, points_warp_proj_f1 = warp_and_project(
             xyz_f1, pts_f1[level], q_coarse, t_coarse, out_h_list[g], out_w_list[g], next_buffers)
         if PROJECTION_TAP is not None and next_buffers is not None:      # (parity tests: the cell every warped point landed in)
-            PROJECTION_TAP.append((level, next_buffers.scratch, batch_size, xyz_f1.shape[1], out_h_list[g], out_w_list[g], xyz_warp_proj_f1))
+            PROJECTION_TAP.append((level, next_buffers.scratch, batch_size, xyz_f1.shape[1], out_h_list[g], out_w_list[g], xyz_warp_proj_f1, _warped))
         next_buffers = projection_buffers(level - 1, g - 1) if level > 0 else None
         xyz_warp_f1 = xyz_warp_proj_f1.reshape(batch_size, -1, 3)
         points_warp_f1 = points_warp_proj_f1.reshape(batch_size, out_h_list[g] * out_w_list[g], -1)

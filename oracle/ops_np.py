@@ -336,6 +336,21 @@ def projection_constants(H_input, W_input):
     return F(az), F(vres), F(voff)
 
 
+def projection_coordinates64(P, H_input, W_input):
+    """The CONTINUOUS coordinates behind ProjectPC2SphericalRing's two truncations, in float64 from the given points (N,3):
+    (col, tmp) with iCol = int(col), iRow = H - int(tmp) (model_util.py:234-242), using the float32 constants both
+    implementations use.  For the parity statistic: a point whose float32 cell differs between two correct implementations
+    must sit within a few float32 ulps (of the index) of an integer value of one of them."""
+    az, vres, voff = projection_constants(H_input, W_input)
+    P = np.asarray(P, np.float64)
+    x, y, z = P[:, 0], P[:, 1], P[:, 2]
+    r = np.sqrt(x * x + y * y + z * z)
+    with np.errstate(all="ignore"):
+        col = (np.float64(F(np.pi)) - np.arctan2(y, x)) / np.float64(az)
+        tmp = np.arcsin(z / r) / np.float64(vres) + np.float64(voff)
+    return col, tmp
+
+
 def scatter_min_range(cell, r, values, ncell, out_shape):
     """model_util.py:255-273: per-cell minimum range (tf.unique + unsorted_segment_min + gather),
     mask_same = (r == min_r), then tf.scatter_nd of the masked rows -- duplicates are ADDED.
@@ -372,6 +387,7 @@ def ProjectPC2SphericalRing(PC, Feature, H_input, W_input):
         cell = iRow * W_input + iCol
         min_r_pt, out_xyz[b] = scatter_min_range(cell, r, cur, H_input * W_input, (H_input, W_input, 3))
         _rec("cell", np.stack([cell, (r == min_r_pt).astype(np.int64), (r > 0).astype(np.int64)]))
+        _rec("warped", np.concatenate([cur, r[:, None]], 1))       # (continuous: the points and ranges the decisions above were taken on)
         if Feature is not None:
             _, out_feat[b] = scatter_min_range(cell, r, Feature[b].astype(F), H_input * W_input,
                                                (H_input, W_input, Feature.shape[-1]))

@@ -43,17 +43,18 @@ def test_full_pyramid_matches_oracle(B, H, W):
     got = net.forward(a, b)
     torch.cuda.synchronize()
     # protocol of the batch-8 test below (see the comment there): every level against the oracle warped by the SAME coarse
-    # poses at north_star's 1e-4; the coarse level also free-running; the free-running refinement levels only bounded --
-    # one projection cell or neighbour decided the other way (a 1e-7 difference upstream is enough: this case passed
-    # free-running at 1e-4 until softmax_valid moved from expf to the hardware exp2, then showed 3.6e-4 at l0) is not a
-    # parity defect and not bounded by a tolerance
+    # poses at north_star's 1e-4; the coarse level also free-running.  The free-running refinement levels are NOT compared
+    # against a tolerance here: one projection cell or neighbour decided the other way (a 1e-7 difference upstream is enough:
+    # this case passed free-running at 1e-4 until softmax_valid moved from expf to the hardware exp2, then showed 3.6e-4 at
+    # l0) is not a parity defect -- tests/test_parity_flips_gpu.py holds every free-running miss to a counted, attributed flip
     params = export(net.store)
     free = O.get_model_from_projection(params, shuffle_fn, f1, f2)
     forced = _forced(params, f1, f2, got)
     for n, g, fr, fo in zip(NAMES, got, free, forced):
         assert torch.isfinite(g).all(), n
         close(g, fo, atol=1e-4, rtol=1e-4)
-        close(g, fr, atol=1e-4 if n.startswith("l3") or n == "l0_xyz_f1" else FREE_RUNNING_TOL, rtol=1e-4 if n.startswith("l3") else 0)
+        if n.startswith("l3") or n == "l0_xyz_f1":
+            close(g, fr, atol=1e-4, rtol=1e-4 if n.startswith("l3") else 0)
     # variable names/shapes are those of the shipped checkpoint index
     shapes = net.store.tf_shapes
     assert shapes["sa1/layer0/conv0/weights"] == (1, 1, 6, 8)
@@ -75,8 +76,8 @@ def test_full_pyramid_matches_oracle(B, H, W):
 # So: l3 (no warp upstream) is compared free-running, and ALL levels are compared TEACHER-FORCED -- the oracle warps each
 # level by the product's coarse pose (oracle get_model_from_projection(coarse_pose=...)) -- at north_star's own 1e-4
 # (measured: fp16 storage <= 8.5e-5, fp32 <= 2.6e-5 over 3 seeds x 8 pairs x 4 levels); the free-running refinement
-# levels only have to stay within FREE_RUNNING_TOL (a gross-error bound, not a parity claim).
-FREE_RUNNING_TOL = 0.1
+# levels are the subject of tests/test_parity_flips_gpu.py (every miss carries a counted, attributed discrete flip), not of
+# a tolerance here.
 NAMES = ["l0_q", "l0_t", "l1_q", "l1_t", "l2_q", "l2_t", "l3_q", "l3_t", "l0_xyz_f1"]
 
 
@@ -109,8 +110,6 @@ def test_batch8_matches_oracle_level_by_level(kernel_path, features):
         close(g, fo, atol=1e-4, rtol=1e-4)                                  # every level, same coarse pose: north_star's tolerance
         if n.startswith("l3") or n == "l0_xyz_f1":
             close(g, fr, atol=1e-4, rtol=1e-4)                              # nothing discrete upstream of the coarse pose
-        else:
-            close(g, fr, atol=FREE_RUNNING_TOL, rtol=0)
     if features == "f16":
         # the storage type matters: the fp16-storage oracle and the fp32 oracle differ by more than the parity tolerance
         ref32 = O.get_model_from_projection(params, shuffle_fn, f1, f2)

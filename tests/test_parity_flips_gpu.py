@@ -7,8 +7,10 @@ hide that behind a loose tolerance; per (seed, pair, level) it demands
 
   * teacher-forced (the oracle warps a level by the PRODUCT's coarse pose): |product - oracle| <= 1e-4, OR the product's
     own projection kernel put a warped point in another cell than the oracle did FROM THE SAME POSE (the product's cell
-    of every point is read back from its scratch, pwclo_model.PROJECTION_TAP: a point on a cell border is decided by the
-    last place of atan2f / asinf -- round 4; until then no seed of the suite had hit one at the forced level);
+    of every point is read back from its scratch, pwclo_model.PROJECTION_TAP) AND that point provably sits within
+    BORDER_ULPS float32 ulps of a cell border (its coordinate recomputed in float64), or two ranges of a cell tie within one
+    ulp -- _product_flips; any other difference between the product's and the oracle's projected grids FAILS the test
+    (round 5: until then "the grids differ by more than a millimetre" was accepted as the cause itself);
   * free-running: |product - oracle| <= 1e-4, OR a counted discrete flip explains the miss: the oracle's own
     free-running and teacher-forced runs -- same code, same weights, coarse poses that differ by the product's
     deviation (<= 1e-4 by the first check, ~1e-6 measured) -- took a different discrete decision at that level or a
@@ -43,7 +45,7 @@ def _flips(free_tr, forced_tr, B):
         if lvl is None:
             assert np.array_equal(a, b)      # upstream of every pose: identical by construction
             continue
-        if kind == "grid":                   # a projection's output: continuous in the pose (compared with the product's, below)
+        if kind in ("grid", "warped"):       # a projection's output / input points: continuous in the pose (compared with the product's, below)
             continue
         if kind == "cell":                   # one event per batch element, in order
             i = cell_no.get(lvl, 0)
@@ -55,27 +57,81 @@ def _flips(free_tr, forced_tr, B):
     return out
 
 
+BORDER_ULPS = 4          # float32 ulps OF THE INDEX within which two correct implementations may truncate a coordinate differently
+
+
+def _near_integer(v64, scale):
+    """|v - nearest integer| in float32 ulps at magnitude `scale` (the largest float32 intermediate the coordinate went through)."""
+    return abs(v64 - np.rint(v64)) / float(np.spacing(np.float32(max(abs(scale), 1.0))))
+
+
 def _product_flips(tap, forced_tr, B):
-    """{level: int[B]} -- warped points (non-zero ones) that the PRODUCT's projection kernel put in another cell than the
-    teacher-forced oracle did from the same pose: float32 arithmetic that differs in the last place (atan2f / asinf on the
-    GPU against numpy's) decides a point on a cell border differently.  At 128 x 2048 a column index is ~10^3: one ulp of it
-    is 1e-4 of a cell, so a few points per image sit that close to a border."""
+    """{level: int[B]} -- projection decisions the PRODUCT took differently from the teacher-forced oracle (same pose), each
+    one ATTRIBUTED to float rounding; anything else fails here, so that a wrong projection / scatter kernel cannot supply
+    its own excuse:
+      * a non-zero warped point whose product cell (read back from the projection's scratch) is not the oracle's counts only
+        if the two warps agree (1e-4 relative), the cells are neighbours along the coordinate(s) that differ, and that
+        coordinate -- recomputed in float64 (oracle/ops_np.projection_coordinates64) from the product's OR the oracle's warped
+        point -- lies within BORDER_ULPS float32 ulps of the index from an integer: a point on a cell border, decided by the
+        last place of atan2f / asinf / the warp;
+      * a cell whose content differs by more than a millimetre (the two warps differ by ~1e-5 m) without such a point entering
+        or leaving it counts only if its two smallest ranges tie within one ulp (another winner of the minimum range);
+      * any other difference of the two grids raises."""
     out = {lvl: np.zeros(B, np.int64) for lvl in LEVELS}
-    oracle, grids = {}, {}
+    oracle, grids, warped = {}, {}, {}
     for lvl, kind, a in forced_tr.events:
-        if kind == "cell" and lvl is not None:
+        if lvl is None:
+            continue
+        if kind == "cell":
             oracle.setdefault(lvl, []).append(a)
-        if kind == "grid" and lvl is not None:
+        if kind == "warped":
+            warped.setdefault(lvl, []).append(a)
+        if kind == "grid":
             grids[lvl] = a
-    for lvl, scratch, b_, n_, h_, w_, grid in tap:
-        cells = scratch[b_ * h_ * w_ + 4 * b_: b_ * h_ * w_ + 4 * b_ + b_ * n_].view(torch.int32).reshape(b_, n_).cpu().numpy()
-        events = oracle[lvl][-b_:]                      # the level's projection: one event per batch element
-        # a cell whose content differs by more than a millimetre holds ANOTHER point (a different winner of the minimum
-        # range, or a point that went to the neighbouring cell): the continuous difference of the two warps is ~1e-5 m
-        moved = (np.abs(grid.detach().cpu().numpy() - grids[lvl]).max(-1) > 1e-3).reshape(b_, -1)
+    for lvl, scratch, b_, n_, h_, w_, grid, pts in tap:
+        base = b_ * h_ * w_ + 4 * b_
+        cells = scratch[base: base + b_ * n_].view(torch.int32).reshape(b_, n_).cpu().numpy()
+        events, owarp = oracle[lvl][-b_:], warped[lvl][-b_:]    # the level's projection: one event per batch element
+        G = grid.detach().cpu().numpy().reshape(b_, h_ * w_, 3)
+        OG = grids[lvl].reshape(b_, h_ * w_, 3)
+        P = pts.detach().cpu().numpy().reshape(b_, n_, 3)
+        _az, _vres, voff = O.projection_constants(h_, w_)
         for b in range(b_):
             cell, _same, nonzero = events[b]
-            out[lvl][b] += int(((cells[b] != cell) & (nonzero == 1)).sum()) + int(moved[b].sum())
+            op, orng = owarp[b][:, :3], owarp[b][:, 3]
+            assert np.abs(P[b] - op).max() <= 1e-4 * (1.0 + np.abs(op).max()), "the two warps differ beyond float rounding"
+            differ = np.nonzero((cells[b] != cell) & (nonzero == 1))[0]
+            explained = set()
+            if len(differ):
+                pc, pt = O.projection_coordinates64(P[b][differ], h_, w_)
+                oc, ot = O.projection_coordinates64(op[differ], h_, w_)
+            for j, p in enumerate(differ):
+                (prow, pcol), (orow, ocol) = divmod(int(cells[b][p]), w_), divmod(int(cell[p]), w_)
+                why = []
+                if pcol != ocol:
+                    margin = min(_near_integer(pc[j], pc[j]), _near_integer(oc[j], oc[j]))
+                    assert abs(pcol - ocol) == 1 and margin <= BORDER_ULPS, \
+                        ("level %d pair %d point %d: columns %d / %d, column coordinate %.9f is %.1f ulps from a border" % (lvl, b, p, pcol, ocol, pc[j], margin))
+                    why.append("col %.1f ulp" % margin)
+                if prow != orow:
+                    margin = min(_near_integer(pt[j], max(abs(pt[j]), float(voff))), _near_integer(ot[j], max(abs(ot[j]), float(voff))))
+                    assert abs(prow - orow) == 1 and margin <= BORDER_ULPS, \
+                        ("level %d pair %d point %d: rows %d / %d, row coordinate %.9f is %.1f ulps from a border" % (lvl, b, p, prow, orow, pt[j], margin))
+                    why.append("row %.1f ulp" % margin)
+                explained.update((int(cells[b][p]), int(cell[p])))
+                print("  attributed cell flip: level %d pair %d point %d (%s)" % (lvl, b, p, ", ".join(why)))
+            moved = np.nonzero(np.abs(G[b] - OG[b]).max(-1) > 1e-3)[0]
+            ties = 0
+            for c in moved:
+                if int(c) in explained:
+                    continue
+                rr = np.sort(orng[(cell == c) & (nonzero == 1)])
+                assert len(rr) >= 2 and rr[1] - rr[0] <= np.spacing(rr[0]), \
+                    ("level %d pair %d cell %d holds another point although no border point entered or left it and its ranges do "
+                     "not tie: %s" % (lvl, b, c, rr[:3]))
+                ties += 1
+                print("  attributed winner flip: level %d pair %d cell %d (ranges %.9g / %.9g)" % (lvl, b, c, rr[0], rr[1]))
+            out[lvl][b] += len(differ) + ties
     return out
 
 

@@ -2,6 +2,7 @@
 # Three rocprofv3 passes per (kernel, batch) of tools/roofline_micro.py -- kernel trace, FETCH_SIZE, WRITE_SIZE, each
 # in its own run (never --pmc together with a trace domain) -- into $1 (default gpurun_out/pmc3), then
 # tools/pmc_summary.py folds them.   usage (on the GPU box):  bash tools/pmc_collect.sh gpurun_out/pmc3
+# ELO_PMC_GRID=32x256 (read by roofline_micro.py): the l0 grid of a 128x2048 scan instead of 16x225; ELO_PMC_SPECS: "kernel[_f16]:batch ..."
 set -u
 OUT=$(realpath -m "${1:-gpurun_out/pmc3}"); REPO=$(pwd)
 mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp

@@ -19,10 +19,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--kernel", default="cv1"); ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--reps", type=int, default=20); ap.add_argument("--pregrouped", action="store_true"); ap.add_argument("--time", action="store_true")
 ap.add_argument("--half", action="store_true", help="fp16 feature storage (cv1/encode1/encode2/pool/pool2)")
+ap.add_argument("--grid", default=os.environ.get("ELO_PMC_GRID", "16x225"),
+                help="the l0 grid HxW of the cv1 / encode / pool kernels: 16x225 (64x1800 scans) or 32x256 (128x2048: BASELINE configs[4])")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ops, fused, tf_util, synth, elo = pkg("_ops"), pkg("fused"), pkg("tf_util"), pkg("synth"), pkg()
-B, H, W, C, Kq = a.batch, 16, 225, 16, 6
+B, (H, W), C, Kq = a.batch, map(int, a.grid.split("x")), 16, 6
 N = H * W
 g = torch.Generator(device="cpu").manual_seed(0)
 f1, f2 = synth.frame_pair(B, H, W, seed=5)
@@ -94,4 +96,4 @@ for _ in range(a.reps):
 torch.cuda.synchronize()
 if a.time:
     info["us"] = round(bench._time_launches(run, dev, 200) * 1e6, 2)
-print(json.dumps({"kernel": a.kernel, "batch": B, "half": a.half, **info}))
+print(json.dumps({"kernel": a.kernel, "batch": B, "half": a.half, "grid": a.grid, **info}))
