@@ -861,7 +861,9 @@ def main():
                                                            "hipGraph replay, %d forwards in flight fed by %d host thread%s%s" % (
                                                                lanes, nthreads, "s" if nthreads > 1 else "", ", fresh visiting orders per replay (pool of %d)" % args.fresh_orders
                                                                if args.fresh_orders else ", one fixed draw of the visiting orders")),
-                   "global_batch": B * world, "parallelism": "dp%d" % world},
+                   "global_batch": B * world, "parallelism": "dp%d" % world,
+                   # every choice of kernel form, as the value the timed graphs were captured under (efficientlo-net_amd/tuning.py)
+                   "tuning": None if dry else (getattr(net, "captured_tuning", None) or pkg("tuning").snapshot())},
     }
     if not dry and not args.no_graph and args.products != "half" and args.check_every:
         # the fp16 split's production guard: every N-th replay of a lane ran on the range-checked kernels INSIDE the timed loop

@@ -130,7 +130,7 @@ SetconvArgs = _struct("elo_setconv_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1_grid", _vp), ("centre_hw", _vp), ("centre_xyz", _vp), ("src_xyz", _vp), ("src_feat", _vp),
     ("idx", _vp), ("mask", _vp), ("n_layers", _i), ("layers", Dense * 3), ("out", _vp), ("new_xyz", _vp), ("group", GroupSpec),
-    ("feat_dtype", _i)])
+    ("feat_dtype", _i), ("pre", _vp), ("centre_stride_h", _i), ("centre_stride_w", _i), ("centre_rows", _i), ("centre_cols", _i)])
 MlpArgs = _struct("elo_mlp_args", [
     ("rows", _l), ("n_sources", _i), ("src", _vp * 3), ("src_width", _i * 3), ("n_layers", _i),
     ("layers", Dense * 3), ("out", _vp),
@@ -142,11 +142,17 @@ Cv1Args = _struct("elo_cv1_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("xyz2", _vp), ("feat2", _vp), ("idx", _vp), ("mask", _vp),
     ("cv0", Dense), ("cv1", Dense), ("cv2", Dense), ("cv_xyz", Dense), ("sum_cv0", Dense), ("sum_cv1", Dense),
-    ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i)])
+    ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i), ("pre_c", _vp), ("pre_s", _vp)])
 Cv2Args = _struct("elo_cv2_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("cost", _vp), ("idx", _vp), ("mask", _vp),
-    ("xyz_enc", Dense), ("sum_cost0", Dense), ("sum_cost1", Dense), ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i)])
+    ("xyz_enc", Dense), ("sum_cost0", Dense), ("sum_cost1", Dense), ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i),
+    ("pre_c", _vp), ("pre_s", _vp)])
+Tuning = _struct("elo_tuning", [
+    ("chain_forms", _i), ("narrow_mfma", _i), ("range_check", _i), ("select_dense_waves", _i), ("random_dense_rows", _i),
+    ("encode1_slots", _i), ("setconv_chain_rows", _l), ("mlp_chain_rows", _l), ("small_tile_units", _l), ("tiled_setconv", _i)])
+RowlinearArgs = _struct("elo_rowlinear_args", [
+    ("rows", _l), ("C", _i), ("src", _vp), ("layer", Dense), ("out", _vp), ("feat_dtype", _i)])
 
 # every symbol include/elo.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -155,6 +161,8 @@ SYMBOLS = [
     ("elo_last_error", ctypes.c_char_p, []),
     ("elo_range_check", ctypes.c_int, [ctypes.c_int]),
     ("elo_range_violations", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), _vp]),
+    ("elo_get_tuning", ctypes.c_int, [ctypes.POINTER(Tuning)]),
+    ("elo_set_tuning", ctypes.c_int, [ctypes.POINTER(Tuning)]),
     ("elo_fused_conv_random_k", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
     ("elo_fused_conv_select_k", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
     ("elo_fused_conv_random_k_dense", ctypes.c_int, [ctypes.POINTER(GroupArgs), _vp]),
@@ -195,6 +203,11 @@ SYMBOLS = [
     ("elo_debug_rr_rows", ctypes.c_int, [ctypes.c_long, ctypes.c_long]),
     ("elo_debug_rr_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_debug_narrow_mfma", ctypes.c_int, [ctypes.c_int]),
+    ("elo_debug_narrow_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
+    ("elo_debug_rowlinear_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
+    ("elo_rowlinear_fused2", ctypes.c_int, [ctypes.POINTER(RowlinearArgs), ctypes.POINTER(RowlinearArgs), _vp]),
+    ("elo_setconv_chain_form", ctypes.c_int, [ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs)]),
+    ("elo_cv_chain_form", ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     ("elo_cv_stage2_fused", ctypes.c_int, [ctypes.POINTER(Cv2Args), _vp]),
     ("elo_cv_stage1_setconv_fused", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
 ]
@@ -206,7 +219,7 @@ class EloError(RuntimeError):
     pass
 
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 def lib():
@@ -224,7 +237,31 @@ def lib():
             raise EloError("%s has ABI version %d, this host expects %d: rebuild (python -c 'import __graft_entry__ as g; "
                            "g.build()')" % (LIB_PATH, handle.elo_abi_version(), ABI_VERSION))
         _lib = handle
+        from . import tuning
+        env = tuning.lib_from_env()                      # the ONE place the library's forms meet the environment
+        if env:
+            set_tuning(**env)
     return _lib
+
+
+def get_tuning():
+    """The library's elo_tuning as a dict (include/elo.h)."""
+    t = Tuning()
+    check(lib().elo_get_tuning(ctypes.byref(t)))
+    return {name: int(getattr(t, name)) for name, _ in Tuning._fields_}
+
+
+def set_tuning(**fields):
+    """Change fields of the library's elo_tuning (the others keep their value); raises on a value outside its domain."""
+    t = Tuning()
+    check(lib().elo_get_tuning(ctypes.byref(t)))
+    for name, value in fields.items():
+        if not hasattr(t, name):
+            raise KeyError("elo_tuning has no field %r" % name)
+        setattr(t, name, int(value))
+    check(lib().elo_set_tuning(ctypes.byref(t)))
+    from . import tuning
+    tuning.bump()
 
 
 def check(rc):
@@ -248,6 +285,12 @@ def call2(entry, args_a, args_b, like):
     """Paired launch: `entry(a, b, current stream)`."""
     with torch.cuda.device(like.device):
         check(getattr(lib(), entry)(ctypes.byref(args_a), ctypes.byref(args_b), stream_ptr(like)))
+
+
+def call2n(entry, args_a, args_b, like):
+    """Paired launch whose second job is optional: `entry(a, b or NULL, current stream)`."""
+    with torch.cuda.device(like.device):
+        check(getattr(lib(), entry)(ctypes.byref(args_a), ctypes.byref(args_b) if args_b is not None else None, stream_ptr(like)))
 
 
 def stream_ptr(t):

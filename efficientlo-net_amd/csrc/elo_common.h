@@ -17,6 +17,8 @@ namespace elo {
 char *err_buf();
 int fail(int code, const char *fmt, ...);
 int check_launch(const char *what);
+elo_tuning &tuning();           // the process-wide tuning (elo_set_tuning); the library reads no environment variable
+elo_tuning &tuning_base();      // ... without the elo_debug_* overrides
 
 // ---- device: arithmetic contract -----------------------------------------
 // Squared norms are ((x*x + y*y) + z*z) in fp32 with no fused multiply-add, so

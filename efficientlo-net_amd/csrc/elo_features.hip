@@ -1038,7 +1038,7 @@ extern "C" int elo_cv_encode1(const elo_cv_encode1_args *a, elo_stream_t stream)
         const FastDiv ds = fast_div(5 + a->C), dk = fast_div(a->K);
         hipStream_t s = (hipStream_t)stream;
         const int rpi = ELO_BLOCK / (5 + a->C), batch_rows = rpi * ENC_BATCH;
-        if (batch_rows <= per && rpi * (5 + a->C) * 16 >= ELO_BLOCK * 15 && !getenv("ELO_ENCODE1_SLOTS")) {   // <= 1/16 of the lanes idle
+        if (batch_rows <= per && rpi * (5 + a->C) * 16 >= ELO_BLOCK * 15 && !tuning().encode1_slots) {   // <= 1/16 of the lanes idle
             const int span = per / batch_rows * batch_rows;
             const dim3 cgrid((unsigned)((rows + span - 1) / span));
             if (a->dtype == ELO_F16) {

@@ -709,7 +709,7 @@ extern "C" int elo_fused_conv_random_k_dense(const elo_group_args *a, elo_stream
     if (int rc = check_args(a, who, true)) return rc;
     if (a->batch == 0) return ELO_OK;
     // 4 rows per workgroup share more of the window; 2 rows give twice the workgroups (small grids, large windows)
-    static const int forced = [] { const char *e = getenv("ELO_DENSE_ROWS"); return e ? atoi(e) : 0; }();
+    const int forced = tuning().random_dense_rows;
     const long tiles4 = (long)((a->W + DENSE_COLS - 1) / DENSE_COLS) * ((a->H + 3) / 4) * a->batch;
     int rows = forced ? forced : (tiles4 >= 1024 && dense_lds_bytes(a, 4) ? 4 : 2);
     if (rows == 4 && !dense_lds_bytes(a, 4)) rows = 2;
@@ -740,13 +740,10 @@ extern "C" int elo_fused_conv_select_k(const elo_group_args *a, elo_stream_t str
     return check_launch("elo_fused_conv_select_k");
 }
 
-static int g_select_dense_waves = 0;
-// debugging hook (tests): force 4, 8 or 16 waves per tile in elo_fused_conv_select_k_dense; 0 = by grid size; returns the
-// previous setting
-extern "C" int elo_debug_select_dense_waves(int waves)
+extern "C" int elo_debug_select_dense_waves(int waves)      // (shorthand for elo_set_tuning: elo_tuning.select_dense_waves)
 {
-    const int prev = g_select_dense_waves;
-    g_select_dense_waves = waves;
+    const int prev = elo::tuning().select_dense_waves;
+    elo::tuning().select_dense_waves = waves > 0 ? waves : elo::tuning_base().select_dense_waves;     // 0: back to elo_set_tuning's value
     return prev;
 }
 
@@ -765,10 +762,9 @@ extern "C" int elo_fused_conv_select_k_dense(const elo_group_args *a, elo_stream
     const bool counts = a->valid_idx || a->valid_in_dis_idx;
     const long tiles = (long)((a->W + DENSE_COLS - 1) / DENSE_COLS) * a->H * a->batch;
     // waves per tile: few tiles -> many waves each (latency: a wave's walk is KT / P probes, twice), many tiles -> 4
-    static const int from_env = [] { const char *e = getenv("ELO_SELECT_DENSE_WAVES"); return e ? atoi(e) : 0; }();
-    const int forced = g_select_dense_waves ? g_select_dense_waves : from_env;
+    const int forced = tuning().select_dense_waves;
     int P = forced ? forced : tiles >= 1024 ? 4 : tiles >= 256 ? 8 : 16;
-    if (P != 4 && P != 8 && P != 16) return fail(ELO_ERR_ARG, "%s: ELO_SELECT_DENSE_WAVES must be 4, 8 or 16", who);
+    if (P != 4 && P != 8 && P != 16) return fail(ELO_ERR_ARG, "%s: elo_tuning.select_dense_waves must be 4, 8 or 16", who);
     const size_t lds = sizeof(int) * select_dense_lds_words(P, a->kernel_h, a->kernel_w, a->stride_h, a->stride_w, counts);
     if (lds > 64 * 1024)
         return fail(ELO_ERR_LIMIT, "%s: window %dx%d does not fit the LDS tile (use elo_fused_conv_select_k)", who, a->kernel_h, a->kernel_w);

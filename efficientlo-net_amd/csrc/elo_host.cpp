@@ -25,7 +25,46 @@ int check_launch(const char *what)
     return ELO_OK;
 }
 
+static const elo_tuning kDefaults = {/*chain_forms*/ 1, /*narrow_mfma*/ 1, /*range_check*/ 0, /*select_dense_waves*/ 0, /*random_dense_rows*/ 0,
+                                     /*encode1_slots*/ 0, /*setconv_chain_rows*/ -1, /*mlp_chain_rows*/ -1, /*small_tile_units*/ 512,
+                                     /*tiled_setconv*/ 1};
+elo_tuning &tuning()            // what the launchers read: elo_set_tuning's value with the elo_debug_* overrides on top
+{
+    static elo_tuning t = kDefaults;
+    return t;
+}
+elo_tuning &tuning_base()       // what elo_set_tuning installed: an elo_debug_*(-1) call puts its field back to this
+{
+    static elo_tuning t = kDefaults;
+    return t;
+}
+
 }  // namespace elo
 
-extern "C" int elo_abi_version(void) { return 19; }
+extern "C" int elo_get_tuning(elo_tuning *out)
+{
+    if (!out) return elo::fail(ELO_ERR_ARG, "elo_get_tuning: null pointer");
+    *out = elo::tuning();
+    return ELO_OK;
+}
+
+extern "C" int elo_set_tuning(const elo_tuning *in)
+{
+    const char *who = "elo_set_tuning";
+    if (!in) return elo::fail(ELO_ERR_ARG, "%s: null pointer", who);
+    if ((in->chain_forms | 1) != 1 || in->narrow_mfma < 0 || in->narrow_mfma > 2 || (in->range_check | 1) != 1 || (in->encode1_slots | 1) != 1)
+        return elo::fail(ELO_ERR_ARG, "%s: chain_forms / range_check / encode1_slots are 0 or 1, narrow_mfma 0..2", who);
+    if (in->select_dense_waves != 0 && in->select_dense_waves != 4 && in->select_dense_waves != 8 && in->select_dense_waves != 16)
+        return elo::fail(ELO_ERR_ARG, "%s: select_dense_waves is 0, 4, 8 or 16", who);
+    if (in->random_dense_rows != 0 && in->random_dense_rows != 2 && in->random_dense_rows != 4)
+        return elo::fail(ELO_ERR_ARG, "%s: random_dense_rows is 0, 2 or 4", who);
+    if (in->tiled_setconv < 0 || in->tiled_setconv > 2) return elo::fail(ELO_ERR_ARG, "%s: tiled_setconv is 0, 1 or 2", who);
+    if (in->setconv_chain_rows < -1 || in->mlp_chain_rows < -1 || in->small_tile_units < 0)
+        return elo::fail(ELO_ERR_ARG, "%s: row thresholds are -1 (the regime's default) or >= 0", who);
+    elo::tuning() = *in;
+    elo::tuning_base() = *in;
+    return ELO_OK;
+}
+
+extern "C" int elo_abi_version(void) { return 20; }
 extern "C" const char *elo_last_error(void) { return elo::err_buf(); }

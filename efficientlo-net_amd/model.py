@@ -12,7 +12,7 @@ import time
 
 import torch
 
-from . import _ops, fused, model_util, perm, pwclo_model, tf_util
+from . import _ops, fused, model_util, perm, pwclo_model, tf_util, tuning
 
 
 def distinct_queue_streams(device, want, candidates=16, cycles=500_000):
@@ -218,7 +218,9 @@ class PWCLONet:
             _lib.range_violations(self._lanes[0]["pair"])            # the counter starts at zero
         self._graph, self._static_in, self._static_out = (self._lanes[0]["graph"], self._lanes[0]["in"],
                                                           self._lanes[0]["out"])
-        self._captured_at = (self.store.generation, self.perms.generation)
+        self._captured_at = (self.store.generation, self.perms.generation, tuning.digest())
+        self._tuning_seen = tuning.version()
+        self.captured_tuning = tuning.snapshot()           # the forms this graph has baked in (bench.py: config.tuning)
         return self
 
     def _check_fresh(self):
@@ -227,9 +229,16 @@ class PWCLONet:
         PermSource.reshuffle() drop those tensors: replaying would read stale weights or recycled memory, silently."""
         if self._graph is None:
             raise RuntimeError("no captured graph: call capture() first")
-        if self._captured_at != (self.store.generation, self.perms.generation):
+        if self._captured_at[:2] != (self.store.generation, self.perms.generation):
             raise RuntimeError("the captured graph is stale: the variables or the visiting orders changed after capture() "
                                "(checkpoint load, training step or reshuffle) -- call capture() again")
+        if self._tuning_seen != tuning.version():          # (re-hash only when something was changed: this sits on every submit)
+            if self._captured_at[2] == tuning.digest():
+                self._tuning_seen = tuning.version()
+                return
+            raise RuntimeError("the captured graph is stale: the tuning changed after capture() (a graph keeps the kernel forms of "
+                               "its capture: tuning.py / elo_set_tuning) -- call capture() again; captured under "
+                               "%s, now %s" % (self.captured_tuning, tuning.snapshot()))
 
     def load_inputs(self, xyz_f1_proj, xyz_f2_proj):
         self._static_in[0].copy_(xyz_f1_proj, non_blocking=True)
@@ -250,10 +259,16 @@ class PWCLONet:
 
     def range_violations(self):
         """Matrix-core operands at or beyond the fp16 range (|x| >= 65504, or NaN) seen by the checked replays since the
-        last call (capture(..., check_every=N)); reads and resets the device counter on the current stream -- call it once
-        the lanes' streams have been synchronised or waited on."""
+        last call (capture(..., check_every=N)); takes the count out of the device counter (one atomic exchange, on the
+        current stream) -- call it once the lanes' streams have been synchronised or waited on.  The counter is ONE word for
+        the process: a non-zero count taints EVERY lane (a checked replay of another lane may have recorded it), so each
+        lane's next collect() raises, whichever lane happened to read the counter first."""
         from . import _lib
-        return _lib.range_violations(self._lanes[0]["pair"])
+        bad = _lib.range_violations(self._lanes[0]["pair"])
+        if bad:
+            for lane in self._lanes:
+                lane["tainted"] = lane.get("tainted", 0) + bad
+        return bad
 
     def collect(self, lane_index):
         """lane_poses(lane_index) for a lane whose work is DONE: synchronises the lane's stream, and raises if a checked
@@ -261,7 +276,8 @@ class PWCLONet:
         lane = self._lanes[lane_index]
         lane["stream"].synchronize()
         if lane.get("check_every"):
-            bad = self.range_violations()
+            self.range_violations()                  # (a count found here, or by another lane's collection, taints this lane too)
+            bad = lane.pop("tainted", 0)
             if bad:
                 raise RuntimeError("%d matrix-core operands at or beyond the fp16 range (|x| >= 65504 or NaN) since the last "
                                    "collection: the hi/lo split of the fused kernels saturated them -- rescale the inputs / "

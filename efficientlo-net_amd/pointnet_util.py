@@ -22,19 +22,20 @@ import os
 
 import torch
 
-from . import _ops, fused, tf_util
+from . import _ops, fused, tf_util, tuning
 from .fused_conv import fused_conv_random_k, fused_conv_select_k, register_dense_index
 from .perm import random_shuffle
 
 
 # Inference uses the fused "gather -> conv chain -> pool" kernels (csrc/elo_fused.hip); ELO_FUSED=0 or
 # use_fused(False) selects the per-operator kernels + hipBLASLt GEMMs instead (same results to ~1e-6).
-_FUSED = os.environ.get("ELO_FUSED", "1") != "0"
+_FUSED = tuning.get("fused")                       # (tuning.py: ELO_FUSED, read once)
 
 
 def use_fused(flag):
     global _FUSED
     _FUSED = bool(flag)
+    tuning.set_host("fused", _FUSED)
 
 
 def _fused_path(is_training):
@@ -100,6 +101,8 @@ def _centre_hw(selected_idx):
     if hit is None or hit[0] is not selected_idx:
         B = selected_idx.shape[0]
         hit = (selected_idx, selected_idx.reshape(B, -1, 3)[:, :, 1:].contiguous())
+        if getattr(selected_idx, "elo_strided", None) is not None:          # (model_util.get_selected_idx: strided pixels, row-major)
+            hit[1].elo_strided = selected_idx.elo_strided
         if len(_centre_hw_cache) > 64:
             _centre_hw_cache.clear()
         _centre_hw_cache[key] = hit
@@ -280,11 +283,10 @@ def fused_pairs_available(is_training):
 # the merge is taken -- for ALL levels of a forward or for none -- up to this many centre points at the finest level (batch x
 # H x W of l0).  End of round 2 (pairs/s, 8 lanes; none / levels under the threshold / all): batch 2 13 330 / 13 940 / 14 090,
 # batch 4 16 650 / 15 990 / 16 530, batch 8 18 170 / 18 150 / 17 790: merging SOME levels is the worst choice at batch 4.
-_MERGE_POINTS = int(os.environ.get("ELO_MERGE_POINTS", "8192"))
 
 
 def merge_branches(is_training, points):
-    return _fused_path(is_training) and points <= _MERGE_POINTS
+    return _fused_path(is_training) and points <= tuning.get("merge_points")
 
 
 def flow_predictor_pair(call_a, call_b):

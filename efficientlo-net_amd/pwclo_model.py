@@ -17,7 +17,7 @@ import os
 import numpy as np
 import torch
 
-from . import _ops, fused, tf_util
+from . import _ops, fused, tf_util, tuning
 from .model_util import (PreProcess, ProjectPC2SphericalRing, input_stage, preprocess_gt, get_selected_idx, inv_q, mul_point_q, mul_q_point,
                          softmax_valid, warp_and_project)
 from .pointnet_util import (cost_volume, down_conv, down_conv_job, flow_predictor, fused_pairs_available, merge_branches,
@@ -109,7 +109,7 @@ def set_concurrent_branches(flag):
 # embedding and embedding-mask set-upconv) and its two predictors are ~35 conv + batch-norm layers of ten launch-bound
 # kernels each, with their own variables and moving statistics -- nothing shared but inputs; autograd runs each branch's
 # backward on the stream its forward ran on.
-_CONCURRENT_TRAIN = os.environ.get("ELO_TRAIN_BRANCHES", "0") == "1"
+_CONCURRENT_TRAIN = tuning.get("train_branches")
 
 
 def set_training_branches(flag):
@@ -340,7 +340,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
         # partial-sums launch + head take 17.0 / 18.3 / 20.8 us, and a workgroup that needs a whole CU waits for one when
         # eight lanes are in flight (10 200 -> 9 640 frame-pairs/s; one lane 3 290 -> 3 230).  DESIGN.md, round 3.
         return (inference and fused_pairs_available(is_training) and xyz_bn3.shape[1] <= _ops.L.POSE_DIRECT_MAX and
-                os.environ.get("ELO_POSE_DIRECT", "0") == "1")
+                tuning.get("pose_direct"))
     def next_warp(level):          # the cloud + features the NEXT warp moves: run by the pose head's own launches
         return (xyz_proj_f1[level].reshape(batch_size, -1, 3), pts_f1[level]) if inference else None
     next_buffers = projection_buffers(2, 4)

@@ -27,9 +27,9 @@ import os
 import torch
 import torch.nn.functional as Fnn
 
-from . import _ops
+from . import _ops, tuning
 
-_TRAIN_KERNELS = os.environ.get("ELO_TRAIN_KERNELS", "1") != "0"     # 0: torch's batch norm + GEMM weight gradients (comparison)
+_TRAIN_KERNELS = tuning.get("train_kernels")     # 0: torch's batch norm + GEMM weight gradients (comparison)
 BN_EPS = 1e-3            # tf.contrib.layers.batch_norm default (utils/tf_util.py:526-531)
 _DEFAULT_BN_DECAY = 0.9  # utils/tf_util.py:525
 

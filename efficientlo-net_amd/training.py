@@ -51,16 +51,30 @@ def data_augmentation(rng=None):
 
 
 class FlatAdam:
-    """Adam (torch.optim.Adam's arithmetic, betas 0.9 / 0.999, eps 1e-8; main.py:171-176) as ONE launch per step: the
-    parameters are re-seated as views of one flat fp32 buffer (as FlatGradBucket does for the gradients), the two moment
-    buffers are flat as well, and `elo_adam_flat` walks all 899 134 floats at once -- torch's foreach Adam is ~46 launches
-    for the 382 tensors.  The step's scalars go to the device in ONE small async copy (`hyper`), which also makes the
-    optimiser capturable: a hipGraph reads them, the host rewrites them before every replay."""
+    """Adam (betas 0.9 / 0.999, eps 1e-8; main.py:171-176) as ONE launch per step: the parameters are re-seated as views of
+    one flat fp32 buffer (as FlatGradBucket does for the gradients), the two moment buffers are flat as well, and
+    `elo_adam_flat` walks all 899 134 floats at once -- torch's foreach Adam is ~46 launches for the 382 tensors.  The
+    step's scalars go to the device in ONE small async copy (`hyper`), which also makes the optimiser capturable: a
+    hipGraph reads them, the host rewrites them before every replay -- from a RING of pinned slots, each guarded by an event
+    (a captured step never synchronises, so the host runs steps ahead: with one pinned buffer it overwrote step t's scalars
+    while step t's copy was still queued).
+    `epsilon`: where eps sits.  "tf" (default) is tf.train.AdamOptimizer's, the optimiser the reference trains with
+    (main.py:174): p -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps); "torch" is torch.optim.Adam's:
+    p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  They differ where sqrt(v) is of the order of eps (early steps
+    of the small pose-head gradients, w_x / w_q).  Every parameter handed over is stepped, also one the loss did not reach
+    (zero gradient: its moments decay) -- torch.optim.Adam skips those."""
+    RING = 32
 
-    def __init__(self, params, bucket, lr=BASE_LEARNING_RATE, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, bucket, lr=BASE_LEARNING_RATE, betas=(0.9, 0.999), eps=1e-8, epsilon="tf"):
         from . import _lib
         self._lib = _lib
+        if epsilon not in ("tf", "torch"):
+            raise ValueError("epsilon is 'tf' (tf.train.AdamOptimizer, the reference's) or 'torch' (torch.optim.Adam)")
+        self.epsilon = epsilon
         self.params, self.bucket, self.lr, self.betas, self.eps = [p for p in params if p.requires_grad], bucket, lr, betas, eps
+        if sum(p.numel() for p in self.params) != bucket.flat.numel():
+            raise ValueError("FlatAdam and its FlatGradBucket must be built from the same parameter list (%d against %d values)"
+                             % (sum(p.numel() for p in self.params), bucket.flat.numel()))
         dev = self.params[0].device
         n = bucket.flat.numel()
         self.flat = torch.empty((n,), dtype=torch.float32, device=dev)
@@ -78,21 +92,36 @@ class FlatAdam:
                 off += k
         self.t = 0                                             # steps taken (the bias corrections' exponent)
         self.hyper = torch.zeros((4,), dtype=torch.float32, device=dev)
-        self._host = torch.zeros((4,), dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros((4,))
+        self._host = torch.zeros((self.RING, 4), dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros((self.RING, 4))
+        self._copied = [None] * self.RING                      # event behind the async copy that last read slot i
         self._args = _lib.AdamFlatArgs(n, self.flat.data_ptr(), bucket.flat.data_ptr(), self.exp_avg.data_ptr(),
                                        self.exp_avg_sq.data_ptr(), self.hyper.data_ptr(), betas[0], betas[1], 1.0 - betas[0], 1.0 - betas[1])
 
     def set_hyper(self):
         """The scalars of step t + 1 to the device (call before step(), or before replaying a graph that recorded it)."""
         t = self.t + 1
-        self._host[0] = self.lr / (1.0 - self.betas[0] ** t)
-        self._host[1] = 1.0 / math.sqrt(1.0 - self.betas[1] ** t)
-        self._host[2] = self.eps
-        self.hyper.copy_(self._host, non_blocking=True)
+        slot = t % self.RING
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()                   # the copy that read this slot RING steps ago has run
+        host = self._host[slot]
+        bc1, bc2 = 1.0 - self.betas[0] ** t, 1.0 - self.betas[1] ** t
+        if self.epsilon == "tf":                               # lr_t = lr sqrt(bc2) / bc1, plain sqrt(v) + eps
+            host[0], host[1] = self.lr * math.sqrt(bc2) / bc1, 1.0
+        else:
+            host[0], host[1] = self.lr / bc1, 1.0 / math.sqrt(bc2)
+        host[2] = self.eps
+        self.hyper.copy_(host, non_blocking=True)
+        if self.hyper.is_cuda:
+            ev = self._copied[slot] or torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.hyper.device))
+            self._copied[slot] = ev
         self.t = t
 
     def launch(self):
         """The update itself (the launch a captured training step records)."""
+        if self.params[0].data_ptr() != self.flat.data_ptr():
+            raise RuntimeError("the variables no longer live in this FlatAdam's flat buffer (another FlatAdam / Trainer re-seated "
+                               "them): its update would step an orphaned copy -- keep ONE optimiser per set of variables")
         self._lib.call("elo_adam_flat", self._args, self.flat)
 
     def step(self):

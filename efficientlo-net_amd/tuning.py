@@ -1,0 +1,138 @@
+"""The configuration as a VALUE, not an environment.
+
+Every choice of kernel FORM that is not a function of a call's arguments lives in one place:
+
+  * the library's `elo_tuning` (include/elo.h: chain forms, row thresholds, narrow-set-conv form, ...): the C library reads no
+    environment variable; `_lib.lib()` fills the struct ONCE from the ELO_* variables below when it loads the library;
+  * the host-side choices of this package (which operators take a grouping pre-pass, the tile count from which select-k is LDS
+    tiled, layer 0 through the gather, the launch-merging bound, ...), read from the environment ONCE, at import.
+
+`snapshot()` is the whole tuning as a plain dict (bench.py prints it as `config.tuning`), `digest()` its hash:
+model.PWCLONet.capture() records the digest and refuses to replay a graph under another tuning (a captured graph has the forms
+of its capture baked in).  `override(...)` changes fields for a `with` block (tests, A/B measurements) and restores them.
+All forms of an entry point compute the same function (bit for bit, or to fp32 summation order where stated): speed choices."""
+import contextlib
+import hashlib
+import json
+import os
+
+# host-side fields: name -> (environment variable, parser, default)
+def _layer0(spec):
+    on = {}
+    for item in spec.replace(" ", "").split(","):
+        if item in ("", "0", "none"):
+            continue
+        name, _, arg = item.partition(":")
+        on[name] = int(arg) if arg else 0
+    return on
+
+
+def _prepass(spec):
+    return None if spec in (None, "") else int(spec)
+
+
+_HOST = {
+    "fused": ("ELO_FUSED", lambda v: v != "0", True),                         # fused inference kernels (False: per-operator kernels + GEMMs)
+    "cv_prepass": ("ELO_CV_PREPASS", _prepass, None),                         # None: the batch regimes; 0 never, 1 always, N from N rows on
+    "select_dense_tiles": ("ELO_SELECT_DENSE_TILES", int, 1024),              # select-k pre-pass: LDS-tiled form from this many 64-centre tiles
+    "layer0_pre": ("ELO_LAYER0_PRE", _layer0, {}),                            # operator -> min channels: first layer through the gather (measured: does not pay)
+    "merge_points": ("ELO_MERGE_POINTS", int, 8192),                          # heterogeneous cost-volume + set-conv launch up to this many centres
+    "pose_direct": ("ELO_POSE_DIRECT", lambda v: v == "1", False),            # pose head reduces softmax_valid itself (one launch less)
+    "train_branches": ("ELO_TRAIN_BRANCHES", lambda v: v == "1", False),
+    "train_kernels": ("ELO_TRAIN_KERNELS", lambda v: v != "0", True),
+}
+# library fields (elo_tuning): name -> (environment variable, default)
+_LIB = {
+    "chain_forms": ("ELO_CV1_RR", 1), "narrow_mfma": ("ELO_SETCONV_NARROW_MFMA", 1), "range_check": ("ELO_RANGE_CHECK", 0),
+    "select_dense_waves": ("ELO_SELECT_DENSE_WAVES", 0), "random_dense_rows": ("ELO_DENSE_ROWS", 0), "encode1_slots": ("ELO_ENCODE1_SLOTS", 0),
+    "setconv_chain_rows": ("ELO_SETCONV_RR_ROWS", -1), "mlp_chain_rows": ("ELO_MLP_RR_ROWS", -1), "small_tile_units": ("ELO_SMALL_TILE_UNITS", 512),
+    "tiled_setconv": ("ELO_TILED_SETCONV", 1),
+}
+
+
+def _host_from_env():
+    out = {}
+    for name, (var, parse, default) in _HOST.items():
+        raw = os.environ.get(var)
+        out[name] = default if raw is None else parse(raw)
+    return out
+
+
+def lib_from_env():
+    """The elo_tuning fields the environment names ({} for the library's defaults): what _lib.lib() installs on load."""
+    out = {}
+    for name, (var, _default) in _LIB.items():
+        raw = os.environ.get(var)
+        if raw is not None:
+            out[name] = (1 if raw else 0) if name == "encode1_slots" else int(raw)
+    return out
+
+
+_host = _host_from_env()
+_version = 0          # bumped by every change made through this module or _lib.set_tuning: model._check_fresh re-hashes only then
+
+
+def version():
+    return _version
+
+
+def bump():
+    global _version
+    _version += 1
+
+
+def get(name):
+    return _host[name]
+
+
+def set_host(name, value):
+    """Set a host-side field for the rest of the process (pointnet_util.use_fused); returns the previous value."""
+    if name not in _HOST:
+        raise KeyError(name)
+    prev, _host[name] = _host[name], value
+    bump()
+    return prev
+
+
+@contextlib.contextmanager
+def override(**fields):
+    """`with tuning.override(cv_prepass=1, chain_forms=0):` -- host-side and library fields alike, restored on exit."""
+    from . import _lib
+    host = {k: v for k, v in fields.items() if k in _HOST}
+    lib = {k: v for k, v in fields.items() if k in _LIB}
+    unknown = set(fields) - set(host) - set(lib)
+    if unknown:
+        raise KeyError("unknown tuning field(s): %s" % sorted(unknown))
+    prev_host = {k: _host[k] for k in host}
+    prev_lib = _lib.get_tuning() if lib else None
+    try:
+        _host.update(host)
+        bump()
+        if lib:
+            _lib.set_tuning(**lib)
+        yield
+    finally:
+        _host.update(prev_host)
+        bump()
+        if prev_lib is not None:
+            _lib.set_tuning(**prev_lib)
+
+
+def snapshot():
+    """The whole tuning as a plain dict: host-side fields, the library's elo_tuning, the products mode and storage type."""
+    from . import _lib, fused
+    snap = {k: (dict(v) if isinstance(v, dict) else v) for k, v in _host.items()}
+    snap["lib"] = _lib.get_tuning()
+    snap["products"] = "half" if fused.products_mode() == fused.PRODUCTS_HALF else "split"
+    snap["storage"] = str(fused.storage_dtype()).replace("torch.", "")
+    snap["build"] = "fp32-mfma" if fused.fp32_mfma() else "fp16-split"
+    return snap
+
+
+def digest():
+    """Hash of the kernel-FORM choices (host-side fields + the library's elo_tuning).  The products mode and the storage type are
+    in the snapshot for the record but not in the hash: they are arguments of a capture (a graph keeps the mode it was captured
+    under and may be replayed outside the `with` block that set it)."""
+    snap = snapshot()
+    forms = {k: v for k, v in snap.items() if k not in ("products", "storage", "build")}
+    return hashlib.sha256(json.dumps(forms, sort_keys=True).encode()).hexdigest()[:16]

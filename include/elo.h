@@ -36,9 +36,36 @@ const char *elo_last_error(void);   /* thread-local, never NULL                 
  * while enabled, the fused kernels run instances that COUNT every activation / gathered feature with |x| >= 65504 or
  * NaN on its way into a matrix-core operand (where the fp16 split saturates instead of raising).
  * elo_range_check(1 / 0) switches it and returns the previous setting (-1: only query);
- * elo_range_violations() synchronises `stream`, returns the count since the last call and resets it. */
+ * elo_range_violations() takes the count since the last call out of the device counter with ONE atomic exchange (a
+ * violation recorded meanwhile by a checked launch on another stream is kept for the next call), synchronises `stream`
+ * and returns it.  The counter is process-wide: a caller with several streams in flight attributes a non-zero count to
+ * all of them (efficientlo-net_amd/model.py taints every lane). */
 int elo_range_check(int enable);
 int elo_range_violations(unsigned long long *count, elo_stream_t stream);
+
+/* The library's tuning: every choice of KERNEL FORM that is not a function of the arguments alone, as ONE value.  The library
+ * itself reads no environment variable; the host fills this once (efficientlo-net_amd/_lib.py maps the ELO_* variables named
+ * below onto it when it loads the library) and may change it between launches.  A form baked into a captured hipGraph stays
+ * what it was at capture time: the host hashes the tuning into its capture generation and refuses to replay a graph under
+ * another tuning (efficientlo-net_amd/model.py).  Every form of an entry point computes the same function (bit for bit, or to
+ * fp32 summation order where a comment says so): these are speed choices.  The elo_debug_* hooks further down are
+ * single-field shorthands for elo_set_tuning. */
+typedef struct elo_tuning {
+    int chain_forms;            /* 1: the register-resident ("chain") kernels may be taken, 0: tile kernels only   [ELO_CV1_RR]            */
+    int narrow_mfma;            /* narrow set-conv layers: 0 VALU kernel, 1 matrix cores for 19 -> 16 -> 16 -> 32, 2 for both [ELO_SETCONV_NARROW_MFMA] */
+    int range_check;            /* 1: the fused kernels run their operand-range-checked instances (elo_range_check) [ELO_RANGE_CHECK]       */
+    int select_dense_waves;     /* elo_fused_conv_select_k_dense: 4 / 8 / 16 waves per tile, 0 = by grid size     [ELO_SELECT_DENSE_WAVES]  */
+    int random_dense_rows;      /* elo_fused_conv_random_k_dense: 2 / 4 rows per tile, 0 = by grid size            [ELO_DENSE_ROWS]          */
+    int encode1_slots;          /* elo_cv_encode1: 1 = the slot-indexed kernel also where the column-owner form tiles [ELO_ENCODE1_SLOTS]    */
+    long setconv_chain_rows;    /* rows per launch from which elo_setconv_fused2 takes the chain form; -1: 20 000 from batch
+                                   ELO_THROUGHPUT_BATCH on, 100 000 below                                          [ELO_SETCONV_RR_ROWS]     */
+    long mlp_chain_rows;        /* ... elo_mlp_fused2; -1: 2048 / 8192                                            [ELO_MLP_RR_ROWS]         */
+    long small_tile_units;      /* 16-row tiles while 32-row tiles would give fewer workgroups than this (512)     [ELO_SMALL_TILE_UNITS]    */
+    int tiled_setconv;          /* narrow set-conv layers with structured centres on the LDS-staged window tile: 0 off, 1 the
+                                   6 -> 8 -> 8 -> 16 layer, 2 also the 19 -> 16 -> 16 -> 32 layer                  [ELO_TILED_SETCONV]       */
+} elo_tuning;
+int elo_get_tuning(elo_tuning *out);
+int elo_set_tuning(const elo_tuning *in);      /* ELO_ERR_ARG on a field outside its domain (nothing is changed then) */
 
 /* ------------------------------------------------------------------------- *
  * Neighbour grouping on the H x W range image.
@@ -639,6 +666,19 @@ typedef struct elo_setconv_args {
     float *new_xyz;               /* (batch,npoints,3) or NULL              */
     elo_group_spec group;         /* random-k; needs xyz1_grid; centre_hw == NULL: centre n is pixel (n / W, n % W) */
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
+    /* "Layer 0 through the gather" (optional; chain form only, see elo_setconv_chain_form): pre[b,h2,w2,:] = bias +
+     * W_feat . src_feat[b,h2,w2] for EVERY source cell (elo_rowlinear_fused2 with the feature rows of layers[0]); layers[0] is
+     * then the layer's xyz-difference rows only (K == 3, same bias) and a row's accumulators start at pre[its neighbour]
+     * (a masked row: at the bias).  The layer is linear, so this is utils/pointnet_util.py:213-217 / :284-289 with the
+     * feature part of the first 1x1 convolution done once per source point instead of once per gathered row. */
+    const float *pre;             /* (batch,H2,W2,layers[0].N) fp32, or NULL */
+    /* STRUCTURED centres (optional): centre n is the pixel ((n / centre_cols) * centre_stride_h, (n % centre_cols) * centre_stride_w)
+     * of xyz1_grid, npoints == centre_rows * centre_cols -- what model_util.get_selected_idx (model_util.py:296-316) lists for every
+     * down_conv of the model.  centre_cols == 0: unstructured (centre_hw or centre_xyz say where the centres are).  With both
+     * given, centre_hw must list exactly these pixels (precondition, not checked: the contents live on the device); the
+     * narrow set-conv layers then stage the window union of 32 neighbouring centres in LDS (setconv_tiled_kernel). */
+    int centre_stride_h, centre_stride_w;
+    int centre_rows, centre_cols;
 } elo_setconv_args;
 int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream);
 /* two independent jobs of identical shape in ONE launch (b may be NULL): the embedding and the embedding-mask
@@ -704,6 +744,12 @@ typedef struct elo_cv1_args {
     void *out;                    /* (batch,npoints,64) feat_dtype */
     elo_group_spec group;         /* select-k of xyz2 around every pixel of xyz1 (npoints == H2*W2, stride 1) */
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
+    /* "Layer 0 through the gather" (optional, both or neither; chain form only, see elo_cv_chain_form): CV_0's feature rows
+     * applied per point -- pre_c[b,n,:] = bias + W_feat1 . feat1[b,n], pre_s[b,h2,w2,:] = W_feat2 . feat2[b,h2,w2] (no bias) --
+     * by elo_rowlinear_fused2; cv0 is then CV_0's geometry rows only (K == 10) and a row starts at pre_c[centre] + mask *
+     * pre_s[neighbour] (utils/pointnet_util.py:62-72 up to the order of three fp32 additions). */
+    const float *pre_c;           /* (batch,npoints,128) fp32, or NULL */
+    const float *pre_s;           /* (batch,H2,W2,128) fp32, or NULL   */
 } elo_cv1_args;
 int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream);
 /* debugging hooks of the register-resident ("chain") kernel forms -- cv1_rr_kernel, cv2_rr_kernel, setconv_rr_kernel,
@@ -718,12 +764,17 @@ int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream);
 int elo_debug_cv1_rr(int on);
 int elo_debug_rr_rows(long setconv_rows, long mlp_rows);
 int elo_debug_rr_launches(unsigned long long *counts4, int reset);
+int elo_debug_rowlinear_launches(unsigned long long *count, int reset);   /* ... and of rowlinear_rr_kernel (elo_rowlinear_fused2) */
 /* the two narrow set-conv layers of the pyramid (6 -> 8 -> 8 -> 16 and 19 -> 16 -> 16 -> 32, K = 32; elo_setconv_fused with
  * elo_dense.w_plain given): 1 = setconv_narrow_kernel, the MLP on the matrix cores, for the 19-channel layer (the default;
  * also ELO_SETCONV_NARROW_MFMA), 2 = for both layers (the 6-channel one is slower that way: measured), 0 =
  * setconv_small_kernel, the fp32 VALU form, for both (the only one in the fp32-MFMA build), -1 = back to the environment's
  * choice; returns the previous setting.  Results agree to fp32-class rounding. */
 int elo_debug_narrow_mfma(int on);
+/* elo_debug_narrow_launches(counts2, reset): launches of [setconv_narrow_kernel, setconv_small_kernel] since the last reset
+ * -- now three: [setconv_narrow_kernel, setconv_small_kernel, setconv_tiled_kernel] --
+ * (the oracle test of the matrix-core form asserts through it which kernel produced the tensor) */
+int elo_debug_narrow_launches(unsigned long long *counts3, int reset);
 /* elo_cv_stage1_fused AND one or two set-conv jobs (elo_setconv_fused / elo_setconv_fused2 semantics, tile-kernel form;
  * jb may be NULL) in ONE launch: the first workgroups of the grid run cost-volume tiles, the rest set-conv tiles.
  * For branches that only share inputs -- the cost volume and the two set-upconvs of a refinement level
@@ -746,8 +797,36 @@ typedef struct elo_cv2_args {
     void *out;                    /* (batch,npoints,64) feat_dtype */
     elo_group_spec group;         /* random-k of xyz1 around every pixel of xyz1 (stride 1) */
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
+    /* "Layer 0 through the gather" (optional, both or neither; chain form only): sum_cost_volume_0's rows of feat1 and of the
+     * grouped cost applied per point -- pre_c[b,n,:] = bias + W_feat1 . feat1[b,n], pre_s[b,n,:] = W_cost . cost[b,n] (no bias);
+     * sum_cost0 is then the layer's xyz-encoding rows only (K == 64) and a row starts at pre_c[centre] + mask *
+     * pre_s[neighbour] (utils/pointnet_util.py:129-133).  `cost` is still read: it is the value the softmax weights. */
+    const float *pre_c;           /* (batch,npoints,128) fp32, or NULL */
+    const float *pre_s;           /* (batch,npoints,128) fp32, or NULL */
 } elo_cv2_args;
 int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream);
+
+/* The per-POINT part of a grouped operator's first layer ("layer 0 through the gather"): out[row,:] = bias + W . src[row,:] for a
+ * list of points, 128 fp32 columns, NO activation -- the producer of the pre / pre_c / pre_s fields above.  `layer` holds the
+ * rows of the operator's first layer that belong to this source (K == C, N == 128; packed as any elo_dense: the host slices the
+ * row-permuted weight, efficientlo-net_amd/fused.py PackedDense.part); layer.relu is ignored.  C in {16, 32, 64}; tensors
+ * 16-byte aligned.  elo_rowlinear_fused2 runs two jobs (b may be NULL; rows and C may differ) in ONE launch. */
+typedef struct elo_rowlinear_args {
+    long rows;
+    int C;
+    const void *src;              /* (rows, C) feat_dtype */
+    elo_dense layer;
+    float *out;                   /* (rows, 128) fp32 */
+    int feat_dtype;               /* ELO_F32 / ELO_F16 */
+} elo_rowlinear_args;
+int elo_rowlinear_fused2(const elo_rowlinear_args *a, const elo_rowlinear_args *b, elo_stream_t stream);
+/* 1 when the call would run the register-resident ("chain") kernel -- the only form that takes the pre* fields --, 0 when it
+ * would run a tile kernel, negative on invalid arguments.  elo_setconv_chain_form looks at the shapes, the row threshold of
+ * the batch regime and the grouping spec of the two jobs (b may be NULL) exactly as elo_setconv_fused2 will (a->pre and the
+ * width of layers[0] are not looked at: ask before splitting the layer); elo_cv_chain_form answers for the pre-grouped
+ * (idx / mask) calls of elo_cv_stage1_fused / elo_cv_stage2_fused with C feature channels in the given products mode. */
+int elo_setconv_chain_form(const elo_setconv_args *a, const elo_setconv_args *b);
+int elo_cv_chain_form(int C, int products);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,25 @@ def test_bench_launches_its_own_ranks():
     assert r["all_reduce_bytes"] == 899134 * 4 and "numa" in r
 
 
+def test_bench_dry_run_with_eight_ranks():
+    """The line of the node configs[3] / SCALE_rNN names: `--gpus 8` self-launches eight ranks (gloo here), n_gpus == 8, the
+    global batch and the rccl object carry the world size, and `warmup` / `warmup_requested` explain the driver's warm-up."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ELO_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "20",
+                          "--warmup", "5", "--batch", "8"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 20 and d["config"]["parallelism"] == "dp8" and d["config"]["global_batch"] == 64
+    assert d["warmup_requested"] == 5 and d["warmup"] >= 5 and d["scaling"] == "weak" and d["value"] is None
+    r = d["rccl"]
+    assert r["world_size"] == 8 and r["backend"] == "gloo" and r["all_reduce_bytes"] == 899134 * 4
+    assert r["all_gather_bytes"] == 8 * 20 * 8 * 7 * 4                 # every rank's 20 steps x 8 pairs x 7 floats
+    assert set(r) >= {"world_size", "backend", "all_reduce_us", "all_reduce_bytes", "all_gather_us", "all_gather_bytes", "numa"}
+
+
 def test_bench_single_rank_dry_run_needs_no_launcher():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "3", "--warmup", "1"],

@@ -32,13 +32,9 @@ def chain_regime(monkeypatch):
     if fused.fp32_mfma():
         pytest.skip("the fp32-MFMA comparison build has no register-resident kernels")
     load_pkg("pointnet_util").use_fused(True)
-    monkeypatch.setenv("ELO_CV_PREPASS", "1")
-    lib.lib().elo_debug_cv1_rr(1)
-    lib.lib().elo_debug_rr_rows(0, 0)
-    lib.lib().elo_debug_rr_launches(None, 1)
-    yield
-    lib.lib().elo_debug_cv1_rr(-1)
-    lib.lib().elo_debug_rr_rows(-1, -1)
+    with load_pkg("tuning").override(cv_prepass=1, chain_forms=1, setconv_chain_rows=0, mlp_chain_rows=0):
+        lib.lib().elo_debug_rr_launches(None, 1)
+        yield
 
 
 def launches():
@@ -193,3 +189,51 @@ def test_down_conv_on_the_chain_kernel_matches_the_oracle(B, H, W, K, ks, dist, 
         want = O.down_conv(export(store), shuffle_fn, f1, feat, sel_np, K, ks, dist, mlp, "layerC")
     compare(got[0], want[0], storage, "down_conv")
     assert np.array_equal(got[1].cpu().numpy(), want[1])
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_narrow_down_conv_on_the_matrix_cores_matches_the_oracle(storage):
+    """down_conv of the pyramid's second layer (19 -> 16 -> 16 -> 32 on the 16x225 level, K = 32; utils/pointnet_util.py:179-250)
+    at batch 8 on setconv_narrow_kernel (round 4: the MLP as 16-row MFMA blocks): EVERY element of the pooled feature tensor
+    against the oracle -- until round 5 this kernel met the oracle at batch 1 only and the VALU kernel otherwise -- with the
+    library's launch counter asserting that the matrix-core form is the one that ran."""
+    pu, mu, synth, lib = load_pkg("pointnet_util"), load_pkg("model_util"), load_pkg("synth"), load_pkg("_lib")
+    B, H, W, K, ks, dist, mlp = 8, 16, 225, 32, [7, 11], 3.0, [16, 16, 32]
+    store, perms = ctx()
+    f1, _ = synth.frame_pair(B, H, W, seed=49)
+    feat = features(np.random.default_rng(19), (B, H, W, 16), storage)
+    oh, ow = (H + 1) // 2, (W + 1) // 2
+    sel_np = O.get_selected_idx(B, 2, 2, oh, ow)
+    xyz = t(f1)
+    sel = mu.get_selected_idx(xyz, 2, 2, oh, ow)
+    counts = (ctypes.c_ulonglong * 2)()
+    try:
+        lib.lib().elo_debug_narrow_mfma(1)
+        lib.lib().elo_debug_narrow_launches(None, 1)
+        got = run_twice(lambda: pu.down_conv(xyz, dev_feat(feat, storage), sel, K_sample=K, kernel_size=ks, distance=dist, mlp=mlp,
+                                             mlp2=None, flag_add=False, is_training=False, bn_decay=None, scope='layerN'), store, perms)
+        lib.lib().elo_debug_narrow_launches(counts, 1)
+    finally:
+        lib.lib().elo_debug_narrow_mfma(-1)
+    assert counts[0] == 2 and counts[1] == 0, list(counts)        # (run_twice: two forwards, both on setconv_narrow_kernel)
+    with O.feature_storage(np.float16 if storage == "f16" else None):
+        want = O.down_conv(export(store), shuffle_fn, f1, feat, sel_np, K, ks, dist, mlp, "layerN")
+    compare(got[0], want[0], storage, "down_conv 19 -> 16 -> 16 -> 32 (setconv_narrow_kernel)")
+    assert np.array_equal(got[1].cpu().numpy(), want[1])
+
+
+def test_setconv_launcher_rejects_a_queried_grid_smaller_than_the_strided_centres():
+    """the raw-pointer window walk has no final clamp, so the launcher must refuse a queried grid that does not
+    cover ceil(H / stride) x ceil(W / stride) of the centres' grid instead of reading out of bounds."""
+    fused, lib = load_pkg("fused"), load_pkg("_lib")
+    tf_util = load_pkg("tf_util")
+    store = tf_util.VariableStore(DEV, seed=0)
+    B, H, W, C = 1, 16, 64, 16
+    xyz1 = torch.randn((B, H, W, 3), device=DEV)
+    src = torch.randn((B, 4, 16, 3), device=DEV)                   # stride 2 x 2 would need an 8 x 32 queried grid
+    feat = torch.randn((B, 4, 16, C), device=DEV)
+    order = torch.randperm(15, device=DEV).to(torch.int32)
+    with tf_util.default_store(store), torch.no_grad():
+        layers = [fused.packed_layer("rej0", 3 + C, 16, row_order=fused.setconv_row_order(C)), fused.packed_layer("rej1", 16, 16)]
+    with pytest.raises(lib.EloError, match="smaller than the centres' grid"):
+        fused.setconv(src, feat, None, None, layers, xyz1_grid=xyz1, group=fused.Grouping(order, [3, 5], 2.0, 2, 2), K=8)

@@ -50,6 +50,12 @@ def _worker(rank, world, port, n_pairs, out):
         mean_scale = sum(r + 1 for r in range(world)) / world
         for i, p in enumerate(params):
             assert torch.allclose(p.grad, torch.full_like(p, mean_scale * (i + 1)))
+        if world >= 8:      # BASELINE configs[3]'s exchange at its real size: ONE all-reduce of the 899 134-float gradient bucket
+            big = [torch.nn.Parameter(torch.zeros(899134))]
+            bucket8 = D.FlatGradBucket(big)
+            (big[0].sum() * float(rank + 1)).backward()
+            bucket8.all_reduce_mean()
+            assert bucket8.flat.numel() == 899134 and torch.equal(big[0].grad, torch.full_like(big[0], (world + 1) / 2.0))
         if rank == 0:
             out.put("ok")
     finally:
@@ -65,6 +71,23 @@ def test_world_size_2_gloo():
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert out.get() == "ok"
+
+
+def test_world_size_8_gloo_on_the_stream_of_configs3():
+    """Eight ranks (the node configs[3] names) over gloo: the 15 237 pairs of KITTI seq 00-06 (kitti_dataset.py:28) shard
+    UNEVENLY (15237 = 8 x 1904 + 5: five ranks own one pair more), the pose gather returns them in global order on every rank
+    with and without the total known, and the full-size flat gradient bucket goes through ONE all-reduce."""
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, 15237, out)) for r in range(8)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert out.get() == "ok"
+    D = load_pkg("distributed")
+    sizes = [D.shard_range(15237, r, 8)[1] - D.shard_range(15237, r, 8)[0] for r in range(8)]
+    assert sizes == [1905] * 5 + [1904] * 3
 
 
 def test_shard_range_covers_everything_once():

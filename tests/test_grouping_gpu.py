@@ -368,3 +368,65 @@ def test_dense_select_k_refuses_what_it_cannot_do():
     perm = np.arange(15, dtype=np.int32)
     with pytest.raises(ValueError, match="K <= 7"):
         elo.fused_conv_select_k(t(f1), t(f2), t(synth.hw_index(1, 8, 64)), t(perm), 8, 64, 512, 3, 5, 8, 0, 1.0, 1, 1, dense=True)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=64, W=450, C=3, cs=(4, 8), win=(9, 15), d=0.5, mlp=[8, 8, 16], holes=0.05),       # the pyramid's first set-conv (64x1800 at full size)
+    dict(B=2, H=64, W=450, C=3, cs=(4, 8), win=(9, 15), d=0.12, mlp=[8, 8, 16], holes=0.5),        # sparse cloud, small radius: several rounds, short lists
+    dict(B=3, H=16, W=225, C=16, cs=(2, 2), win=(7, 11), d=3.0, mlp=[16, 16, 32], holes=0.1),      # the second one (8x113 centres: a ragged last tile)
+    dict(B=1, H=6, W=21, C=3, cs=(1, 1), win=(9, 15), d=2.0, mlp=[8, 8, 16], holes=0.2),           # window taller than the grid, columns wrap both ways
+    dict(B=2, H=9, W=70, C=16, cs=(2, 3), win=(5, 9), d=1000.0, mlp=[16, 16, 32], holes=0.0),      # everything in range: the walk stops after one round
+    dict(B=1, H=8, W=64, C=3, cs=(2, 2), win=(9, 15), d=0.5, mlp=[8, 8, 16], holes=1.0)])          # an EMPTY cloud: every centre invalid
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_lds_tiled_setconv_grouping_is_bit_exact(case, storage):
+    """setconv_tiled_kernel (round 5: the window union of 32 strided centres staged in LDS, eight lanes per centre walk the
+    visiting order 64 positions per round, hit ranks by an in-group scan): its neighbour indices / masks equal the ORACLE's
+    random-k bit for bit, and its pooled features and new_xyz equal setconv_small_kernel's (the same MLP on the same rows)."""
+    fused, tf_util, pu, mu, synth, tuning, lib = (load_pkg("fused"), load_pkg("tf_util"), load_pkg("pointnet_util"), load_pkg("model_util"),
+                                                  load_pkg("synth"), load_pkg("tuning"), load_pkg("_lib"))
+    import ctypes
+    dev = "cuda:0"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    B, H, W, C, (sh, sw), (kH, kW) = case["B"], case["H"], case["W"], case["C"], case["cs"], case["win"]
+    f1, _ = synth.frame_pair(B, H, W, seed=H * W + C)
+    rng = np.random.default_rng(kH * kW + C)
+    f1 = f1.copy()
+    f1[rng.random((B, H, W)) < case["holes"]] = 0                              # empty pixels: skipped as neighbours, invalid as centres
+    oh, ow = -(-H // sh), -(-W // sw)
+    feat = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
+    feat_dev = t(feat).half() if storage == "f16" else t(feat)
+    perm = rng.permutation(kH * kW).astype(np.int32)
+    xyz = t(f1)
+    sel = mu.get_selected_idx(xyz, sh, sw, oh, ow)
+    centre_hw = pu._centre_hw(sel)
+    assert centre_hw.elo_strided == (sh, sw, oh, ow)
+    store = tf_util.VariableStore(dev, seed=2)
+    widths = [3 + C] + case["mlp"]
+    with tf_util.default_store(store), torch.no_grad():
+        layers = [fused.packed_layer("t%d" % i, widths[i], widths[i + 1], row_order=fused.setconv_row_order(C) if i == 0 else None)
+                  for i in range(3)]
+        for p_ in layers:
+            p_.b.copy_(torch.from_numpy(rng.normal(0, 0.1, p_.b.shape).astype(np.float32)))
+
+        def run():
+            g = fused.Grouping(t(perm), [kH, kW], case["d"], want_indices=True)
+            out, new_xyz = fused.setconv(xyz, feat_dev, None, None, layers, xyz1_grid=xyz, centre_hw=centre_hw, K=32, group=g)
+            return out, new_xyz, g.idx, g.mask
+        counts = (ctypes.c_ulonglong * 3)()
+        with tuning.override(tiled_setconv=0, narrow_mfma=0):
+            small = run()
+        lib.lib().elo_debug_narrow_launches(None, 1)
+        with tuning.override(tiled_setconv=2, narrow_mfma=0):
+            tiled = run()
+        lib.lib().elo_debug_narrow_launches(counts, 1)
+    torch.cuda.synchronize()
+    assert list(counts) == [0, 0, 1], list(counts)
+    hw = synth.strided_index(B, oh, ow, sh, sw)
+    want = G.fused_conv_random_k(f1, f1, hw, perm, H, W, oh * ow, kH, kW, 32, 0, case["d"], 1, 1)
+    assert np.array_equal(tiled[2].cpu().numpy(), want[0]) and np.array_equal(tiled[3].cpu().numpy()[..., None], want[3])
+    for a_, b_ in zip(tiled, small):
+        assert a_.dtype == b_.dtype and torch.equal(a_, b_)
+    if case["holes"] < 1.0:
+        assert 0 < float(want[3].mean()) and float(tiled[0].float().abs().max()) > 0
+    else:
+        assert float(want[3].max()) == 0

@@ -299,6 +299,39 @@ def test_stale_graph_refuses_to_replay():
         net.replay()
 
 
+def test_a_graph_captured_under_one_tuning_refuses_to_replay_under_another():
+    """The configuration is a VALUE (efficientlo-net_amd/tuning.py + the library's elo_tuning): a captured graph has the kernel
+    forms of its capture baked in, capture() records the tuning's digest, and a replay under ANOTHER tuning raises -- whether
+    a host-side field changed (the cost volumes' grouping pre-pass) or a library field (chain forms off).  Going back to the
+    captured tuning replays again, and the same forward captured under the second tuning gives the same poses (every form
+    of an entry point computes the same function)."""
+    model, synth, tuning = load_pkg("model"), load_pkg("synth"), load_pkg("tuning")
+    B = 4                                                  # (from batch 4 on every level takes the pre-pass + chain forms)
+    f1, f2 = synth.frame_pair(B, 64, 900, seed=4)
+    a, b = torch.from_numpy(f1).to(DEV), torch.from_numpy(f2).to(DEV)
+    net = model.PWCLONet(DEV, seed=1)
+    net.capture(B, 64, 900, lanes=1)
+    first = [x.clone() for x in net(a, b)]
+    assert net.captured_tuning["lib"]["chain_forms"] == 1 and net.captured_tuning["cv_prepass"] is None
+    for fields in (dict(cv_prepass=0), dict(chain_forms=0), dict(layer0_pre={"setconv": 0})):
+        with tuning.override(**fields):
+            with pytest.raises(RuntimeError, match="the tuning changed"):
+                net.replay()
+        again = net(a, b)                                  # the override is gone: the graph is fresh again
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(first, again))
+    with tuning.override(chain_forms=0, cv_prepass=0):     # tile kernels everywhere
+        other = model.PWCLONet(DEV, seed=1)
+        other.capture(B, 64, 900, lanes=1)
+        assert other.captured_tuning["lib"]["chain_forms"] == 0
+        tiles = [x.clone() for x in other(a, b)]
+    torch.cuda.synchronize()
+    for x, y in zip(first, tiles):
+        assert float((x - y).abs().max()) <= 2e-5 * (1.0 + float(y.abs().max()))
+    with pytest.raises(RuntimeError, match="the tuning changed"):
+        other.replay()                                      # captured under the override, replayed outside it
+
+
 def test_pose_ring_keeps_every_replay_of_a_lane():
     """capture(..., pose_ring=R): the l0 pose-head kernel writes replay r of a lane into slot r % R of the lane's ring
     (cursor on the device, include/elo.h pose7_slots / pose7_cursor), so a stream of pairs needs no copy-out launch per

@@ -189,7 +189,7 @@ def test_flat_adam_is_torch_adam():
     mine = [torch.nn.Parameter(torch.tensor(rng.normal(0, 1, s_), dtype=torch.float32, device=DEV)) for s_ in shapes]
     ref = [torch.nn.Parameter(p_.detach().clone()) for p_ in mine]
     bucket = dist_mod.FlatGradBucket(mine)
-    opt = training.FlatAdam(mine, bucket, lr=1e-3)
+    opt = training.FlatAdam(mine, bucket, lr=1e-3, epsilon="torch")
     topt = torch.optim.Adam(ref, lr=1e-3)
     for step in range(6):
         lr = 1e-3 * 0.7 ** step
@@ -210,3 +210,39 @@ def test_flat_adam_is_torch_adam():
             assert float((mine_m - ref_m).abs().max()) <= 1e-6 * max(1e-3, float(ref_m.abs().max())), i   # (torch: lerp / addcmul)
         assert p_.data_ptr() >= opt.flat.data_ptr() and p_.data_ptr() < opt.flat.data_ptr() + opt.flat.numel() * 4
     assert opt.t == 6
+    with pytest.raises(RuntimeError, match="orphaned"):     # a second optimiser re-seats the variables: the first must refuse to step
+        training.FlatAdam(mine, bucket, lr=1e-3)
+        opt.launch()
+
+
+def test_flat_adam_default_is_tensorflows_adam_and_survives_a_host_that_runs_ahead():
+    """The default epsilon placement is tf.train.AdamOptimizer's (the optimiser the reference trains with, main.py:174):
+    p -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps), against a float64 restatement -- with gradients of the order
+    of eps, where the two placements differ visibly.  150 steps are enqueued WITHOUT a synchronisation and with a learning
+    rate that changes every step: every step must read ITS scalars (a single pinned staging buffer was overwritten by the
+    host while earlier copies were still queued)."""
+    training, dist_mod = load_pkg("training"), load_pkg("distributed")
+    rng = np.random.default_rng(9)
+    mine = [torch.nn.Parameter(torch.tensor(rng.normal(0, 1, (257,)), dtype=torch.float32, device=DEV))]
+    bucket = dist_mod.FlatGradBucket(mine)
+    opt = training.FlatAdam(mine, bucket)
+    steps, b1, b2, eps = 150, 0.9, 0.999, 1e-8
+    grads = rng.normal(0, 1, (steps, 257)) * np.where(rng.random(257) < 0.5, 1e-8, 1.0)
+    gdev = torch.tensor(grads, dtype=torch.float32, device=DEV)
+    p = mine[0].detach().cpu().double().numpy().copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    filler = torch.zeros((1 << 22,), device=DEV)
+    for t in range(1, steps + 1):
+        lr = 1e-3 * (1.0 + (t % 7))
+        opt.lr = lr
+        filler.add_(1.0)                                       # keeps the stream behind the host
+        mine[0].grad.copy_(gdev[t - 1])
+        opt.step()
+        g = grads[t - 1].astype(np.float32).astype(np.float64)
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        p -= lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m / (np.sqrt(v) + eps)
+    torch.cuda.synchronize()
+    got = mine[0].detach().cpu().double().numpy()
+    assert np.abs(got - p).max() <= 5e-5 * max(1.0, np.abs(p).max()), float(np.abs(got - p).max())
+    assert opt.t == steps

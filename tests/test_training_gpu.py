@@ -214,7 +214,8 @@ def test_captured_training_step_trains():
     assert tr.step_count == start + 8 and all(np.isfinite(losses)) and min(losses[4:]) < losses[0], losses
     lr = training.learning_rate(tr.step_count - 1, 2)
     assert abs(tr.opt.lr - lr) < 1e-12 and tr.opt.t == tr.step_count           # the schedule; one Adam step per optimisation step
-    assert abs(float(tr.opt.hyper[0]) - lr / (1 - 0.9 ** tr.opt.t)) < 1e-9       # ... and what the captured launch reads
+    # ... and what the captured launch reads: tf.train.AdamOptimizer's step size lr sqrt(1 - b2^t) / (1 - b1^t) (FlatAdam's default)
+    assert abs(float(tr.opt.hyper[0]) - lr * (1 - 0.999 ** tr.opt.t) ** 0.5 / (1 - 0.9 ** tr.opt.t)) < 1e-9 and float(tr.opt.hyper[1]) == 1.0
     g1, g2 = synth.frame_pair(2, 64, 900, seed=21)
     other = float(tr.step_graph(t(g1), t(g2), q_gt, t_gt))
     assert np.isfinite(other) and other != losses[-1]

@@ -58,7 +58,7 @@ for lv in a.levels.split(","):
         x1f = x1.reshape(B, N, 3)
         ft1f = ft1.reshape(B, N, C)
         def run(prepass):
-            os.environ["ELO_CV_PREPASS"] = prepass
+            pkg("tuning").set_host("cv_prepass", int(prepass))
             return fused.cv_stage1(x1f, ft1f, x2, ft2, None, None, *layers, group=grp, K=Kq)
         row["cv1"] = round(bench._time_launches(lambda: run("0"), dev, a.reps) * 1e6, 2)
         pre = lambda: fused.cv_stage1(x1f, ft1f, x2, ft2, idx, m, *layers)
