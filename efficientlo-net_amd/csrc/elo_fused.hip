@@ -1240,7 +1240,12 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
 //   3. runs gather -> MLP -> masked max exactly as setconv_small_kernel does (half a wave per centre, a lane per neighbour
 //      row), the neighbours' xyz coming from the staged cells.
 // A wave keeps its 8 centres through 2 and 3: no workgroup barrier after the staging.  Same outputs bit for bit
-// (tests/test_grouping_gpu.py, tests/test_ops_gpu.py).
+// (tests/test_grouping_gpu.py::test_lds_tiled_setconv_grouping_is_bit_exact).
+// MEASURED SLOWER and therefore off by default (elo_tuning.tiled_setconv = 0; profiles/r05_ab_tiled.txt): 51 us against 37 us on the
+// 6 -> 8 -> 8 -> 16 layer at 16 images, 32 against 28 (17 for the matrix-core form) on the 19-channel layer, 28.1 k -> 26.7 k pairs/s at
+// batch 8.  The strided centres' windows barely overlap (15 columns wide at a stride of 8: 1.9 x reuse; 74 staged cells per centre
+// against <= 135 slots walked, usually 64), the 38 KB tile leaves 3 workgroups = 12 waves per CU where the L2 walk runs 32, and a
+// wave's four MLP passes each pay their own feature-gather round trip: the kernel is its latency chain times its occupancy.
 constexpr int TILED_TC = 32;                      // centres per workgroup (8 per wave)
 
 __host__ __device__ inline int tiled_region_cols(int centre_stride_w, int stride_w, int kernel_w)

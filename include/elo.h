@@ -61,8 +61,9 @@ typedef struct elo_tuning {
                                    ELO_THROUGHPUT_BATCH on, 100 000 below                                          [ELO_SETCONV_RR_ROWS]     */
     long mlp_chain_rows;        /* ... elo_mlp_fused2; -1: 2048 / 8192                                            [ELO_MLP_RR_ROWS]         */
     long small_tile_units;      /* 16-row tiles while 32-row tiles would give fewer workgroups than this (512)     [ELO_SMALL_TILE_UNITS]    */
-    int tiled_setconv;          /* narrow set-conv layers with structured centres on the LDS-staged window tile: 0 off, 1 the
-                                   6 -> 8 -> 8 -> 16 layer, 2 also the 19 -> 16 -> 16 -> 32 layer                  [ELO_TILED_SETCONV]       */
+    int tiled_setconv;          /* narrow set-conv layers with structured centres on the LDS-staged window tile: 0 off (default:
+                                   measured slower, profiles/r05_ab_tiled.txt), 1 the 6 -> 8 -> 8 -> 16 layer, 2 also the
+                                   19 -> 16 -> 16 -> 32 layer                                                      [ELO_TILED_SETCONV]       */
 } elo_tuning;
 int elo_get_tuning(elo_tuning *out);
 int elo_set_tuning(const elo_tuning *in);      /* ELO_ERR_ARG on a field outside its domain (nothing is changed then) */
