@@ -51,6 +51,27 @@ def test_the_hazard_is_followed_across_branches():
     assert len(hits) == 1 and hits[0][3] == 1
 
 
+@pytest.mark.parametrize("first,second,srcc,gap,flagged", [
+    # round 5: the full shape cross-product (tools/mfma_hazard_matrix.sh, profiles/r05_mfma_srcc_hazard.txt).  SrcC == the first's vDst:
+    ("v_mfma_f32_16x16x32_bf16 v[22:25], v[30:33], v[34:37], v[22:25]", "v_mfma_f32_32x32x8_f16 v[40:55], v[60:61], v[62:63], {c}", "v[22:37]", "s_nop 3", True),
+    ("v_mfma_f32_16x16x32_f16 v[22:25], v[30:33], v[34:37], v[22:25]", "v_mfma_f32_4x4x4_16b_f16 v[40:43], v[60:61], v[62:63], {c}", "v[22:25]", "s_nop 3", True),
+    ("v_mfma_f32_16x16x32_f16 v[22:25], v[30:33], v[34:37], v[22:25]", "v_mfma_f32_4x4x4_16b_f16 v[40:43], v[60:61], v[62:63], {c}", "v[22:25]", "s_nop 4", False),
+    # the gfx950 double-rate shapes behind each other and the 32x32 shapes in front of anything are interlocked when SrcC IS the vDst ...
+    ("v_mfma_f32_16x16x32_f16 v[22:25], v[30:33], v[34:37], v[22:25]", "v_mfma_f32_16x16x32_bf16 v[40:43], v[30:33], v[34:37], {c}", "v[22:25]", "s_nop 0", False),
+    ("v_mfma_f32_32x32x16_f16 v[0:15], v[30:33], v[34:37], v[0:15]", "v_mfma_f32_16x16x16_f16 v[40:43], v[60:61], v[62:63], {c}", "v[0:3]", "s_nop 0", False),
+    # ... but not when it only OVERLAPS it: same shape, SrcC shifted by two registers needs 7 wait states
+    ("v_mfma_f32_16x16x32_f16 v[22:25], v[30:33], v[34:37], v[22:25]", "v_mfma_f32_16x16x32_f16 v[40:43], v[30:33], v[34:37], {c}", "v[24:27]", "s_nop 5", True),
+    ("v_mfma_f32_16x16x32_f16 v[22:25], v[30:33], v[34:37], v[22:25]", "v_mfma_f32_16x16x32_f16 v[40:43], v[30:33], v[34:37], {c}", "v[24:27]", "s_nop 6", False),
+    ("v_mfma_f32_16x16x4_f32 v[22:25], v30, v31, v[22:25]", "v_mfma_f32_16x16x4_f32 v[40:43], v30, v31, {c}", "v[24:27]", "s_nop 7", True),
+    ("v_mfma_f32_16x16x4_f32 v[22:25], v30, v31, v[22:25]", "v_mfma_f32_16x16x4_f32 v[40:43], v30, v31, {c}", "v[22:25]", "s_nop 0", False)])
+def test_every_measured_pair_is_in_the_table(first, second, srcc, gap, flagged):
+    """The checker knows every (first, second) pair the cross-product measured, for SrcC == vDst and for a partial overlap (a
+    sub-range of a wider vDst is a partial overlap; a 32x32 MFMA in front is interlocked either way: measured 0)."""
+    text = "0000000000001000 <kernel_c>:\n\t%s\n\t%s\n\t%s\n\ts_endpgm\n" % (first, gap, second.format(c=srcc))
+    assert bool(H.check_text(text)) == flagged, H.check_text(text)
+    assert len(H.TABLE) >= 27 and H.TABLE[("v_mfma_f32_16x16x32_f16", "v_mfma_f32_16x16x16_f16")]["exact"] == 5
+
+
 @pytest.mark.parametrize("lib", ["libelo_hip.so", "libelo_hip_f32.so"])
 def test_shipped_libraries_are_free_of_the_pair(lib):
     path = os.path.join(ROOT, "efficientlo-net_amd", lib)
