@@ -360,14 +360,12 @@ __device__ __forceinline__ void mma_pair(f32x4 (&acc)[RB][TPW], int c0, const Ac
 template <int RB, int TPW, int MT>
 __device__ __forceinline__ void mfma_shape_guard(f32x4 (&acc)[RB][TPW], int c0)
 {
-#ifndef ELO_NO_MFMA_SHAPE_GUARD                     // (tools/rr_bisect.sh builds the unguarded form to show the failure)
     static_assert(RB * MT == 1 || RB * MT == 2 || RB * MT == 4, "accumulators of one tail step");
     if constexpr (RB * MT == 1) asm volatile("s_nop 5" : "+v"(acc[0][c0]));
     else if constexpr (RB == 1 && MT == 2) asm volatile("s_nop 5" : "+v"(acc[0][c0]), "+v"(acc[0][c0 + 1]));
     else if constexpr (RB == 2 && MT == 1) asm volatile("s_nop 5" : "+v"(acc[0][c0]), "+v"(acc[1][c0]));
     else if constexpr (RB == 1 && MT == 4) asm volatile("s_nop 5" : "+v"(acc[0][c0]), "+v"(acc[0][c0 + 1]), "+v"(acc[0][c0 + 2]), "+v"(acc[0][c0 + 3]));
     else asm volatile("s_nop 5" : "+v"(acc[0][c0]), "+v"(acc[0][c0 + 1]), "+v"(acc[1][c0]), "+v"(acc[1][c0 + 1]));
-#endif
 }
 #endif
 
@@ -1548,11 +1546,7 @@ __device__ __forceinline__ elo_dense kernarg_dense(size_t byte_offset)
     struct Raw { Quad a, b, c; } raw = {q[0], q[1], q[2]};
     return __builtin_bit_cast(elo_dense, raw);
 }
-#ifdef ELO_CV1_EARLY_DESCRIPTORS
-#define CV1_LAYER(field) (a.field)
-#else
 #define CV1_LAYER(field) kernarg_dense(offsetof(elo_cv1_args, field))
-#endif
 
 // GROUP = false: an instance without the in-kernel select-k (the neighbours come from a.idx / a.mask, written by
 // elo_fused_conv_select_k_dense in front of this launch): the window registers and the grouping's scalars are gone
@@ -1579,10 +1573,6 @@ __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, flo
         load_meta<TILE>(meta, first_point, total_points, P, K, a.idx, a.mask, a.H2, a.W2);
         __syncthreads();
     }
-#if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 1
-    if (tid == 0) feat_store(a.out, first_point * 64, meta.mask[0], f16);
-    return;
-#endif
     CV1_STAMP(1);
     const int F = 128, G = F + 2 * C;                                                             // :54-66
     {
@@ -1605,10 +1595,6 @@ __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, flo
     const elo_dense cv0 = CV1_LAYER(cv0);
     prefetch<TILE, Sub<TILE, 128>::TPW, MODE>(cv0, p128);           // in flight while the barrier drains the gather
     __syncthreads();
-#if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 2
-    if (tid == 0) feat_store(a.out, first_point * 64, act[F] + p128.b[0].x, f16);
-    return;
-#endif
     CV1_STAMP(2);
     const elo_dense cv1 = CV1_LAYER(cv1);
     dense_pf<TILE, 128, 64, MODE>(act, S, F, to_tile(0), cv0, p128, &cv1, &p64, bad);          // feat_cat -> 128          :72-76
@@ -1627,10 +1613,6 @@ __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, flo
     CV1_STAMP(7);
     dense_pf<TILE, 64, 0, MODE>(act, S, 64, to_pool(64), sum_cv1, p64, nullptr, nullptr, bad);   // -> 64 logits at [64,128) (plain fp32)
     CV1_STAMP(8);
-#if defined(ELO_CV1_STOP) && ELO_CV1_STOP == 3
-    if (tid == 0) feat_store(a.out, first_point * 64, act[F], f16);
-    return;
-#endif
     pool_masked_softmax(act, S, 64, 0, meta, P, K, first_point, total_points, a.out, f16);   // :92-98
     CV1_STAMP(9);
     report_violations<MODE>(bad);
@@ -1713,20 +1695,7 @@ struct RrW { WPair w[2]; };                        // one k-step of two column b
 
 // workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. the W loads
 // that are meant to stay in flight across it
-#if defined(ELO_RR_BARRIER) && ELO_RR_BARRIER == 1        // bisect builds (tools/rr_bisect.sh): the full barrier ...
-__device__ __forceinline__ void rr_barrier() { __syncthreads(); }
-#elif defined(ELO_RR_BARRIER) && ELO_RR_BARRIER == 2      // ... or the compiler's own workgroup fences around the barrier builtin
-__device__ __forceinline__ void rr_barrier()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-#elif defined(ELO_RR_BARRIER) && ELO_RR_BARRIER == 3      // timing experiment (wrong results): the waves run free
-__device__ __forceinline__ void rr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#else
 __device__ __forceinline__ void rr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
 
 // The W stream of a register-resident chain.  PLAN: NL layers with KP[l] k-pairs (+ TL[l]: a 16-k tail) and NCB[l]
 // column blocks; steps run layer by layer, pass by pass (two column blocks), k-step by k-step; two steps = a superstep =
@@ -1747,14 +1716,12 @@ struct RrStream {
     __device__ __forceinline__ void issue(int S)                          // request this wave's chunk of superstep S
     {
         if (2 * S >= total()) return;
-#ifndef ELO_RR_EQUAL_LOADS
         // MODE_HALF: a pair chunk has no lo half, the odd waves have nothing to stage and issue no load.  (Round 3 shipped
         // them fetching their partner's kilobyte and dropping it, because without a load on their path "one or two waves of a
         // few workgroups gave wrong rows".  The loads were never the cause: that build's schedule put a 16-k tail MFMA two
         // wait states behind the pair MFMA whose accumulator it continues -- mfma_shape_guard, above mma_tail.
-        // -DELO_RR_EQUAL_LOADS restores round 3's form for tools/rr_bisect.sh.)
+        // tools/micro/patches/elo_fused_experiments.patch + -DELO_RR_EQUAL_LOADS restores round 3's form for tools/rr_bisect.sh.)
         if (MODE == MODE_HALF && (wave & 1)) return;
-#endif
         const int g = 2 * S;
         int l = 0;
 #pragma unroll
@@ -1789,12 +1756,8 @@ struct RrStream {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             dst.w[t].hi = slot[t * 128];
-#ifdef ELO_RR_WHATIF_HALF_READS                                            // timing experiment (wrong results): half the ring reads
-            dst.w[t].lo = dst.w[t].hi;
-#else
             if constexpr (MODE != MODE_HALF) dst.w[t].lo = slot[t * 128 + 64];
             else dst.w[t].lo = uint4{0u, 0u, 0u, 0u};
-#endif
         }
     }
     // end of superstep S: superstep S + 1 goes into the slot S - 1 used (every wave read it before the last barrier)

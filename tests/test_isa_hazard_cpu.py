@@ -106,3 +106,23 @@ def test_inference_kernels_keep_their_accumulators_in_vgprs_and_their_dpp_maxima
             if "setconv_narrow_kernel" in name:
                 assert moves <= 32, (name, moves)
     assert seen > 50
+
+
+def test_the_experiment_switches_live_in_a_patch_that_still_applies():
+    """The product source has no "wrong results" / bisect macros (they are tools/micro/patches/elo_fused_experiments.patch, applied to
+    a scratch copy by tools/micro/experiment_source.sh); the patch must keep applying to the current csrc/elo_fused.hip."""
+    import re
+    import shutil
+    import subprocess
+    src = open(os.path.join(ROOT, "efficientlo-net_amd", "csrc", "elo_fused.hip")).read()
+    for macro in ("ELO_RR_WHATIF_HALF_READS", "ELO_NO_MFMA_SHAPE_GUARD", "ELO_CV1_STOP", "ELO_RR_BARRIER", "ELO_CV1_EARLY_DESCRIPTORS"):
+        assert not re.search(r"#\s*if.*%s" % macro, src), macro
+    assert "getenv" not in "".join(open(os.path.join(ROOT, "efficientlo-net_amd", "csrc", f)).read()
+                                   for f in os.listdir(os.path.join(ROOT, "efficientlo-net_amd", "csrc")))
+    if shutil.which("patch") is None:
+        pytest.skip("no patch(1) here")
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "micro", "experiment_source.sh")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    patched = open(out.stdout.strip()).read()
+    assert "ELO_RR_WHATIF_HALF_READS" in patched and "#ifndef ELO_NO_MFMA_SHAPE_GUARD" in patched
+    shutil.rmtree(os.path.dirname(os.path.dirname(os.path.dirname(out.stdout.strip()))), ignore_errors=True)

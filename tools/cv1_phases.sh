@@ -5,11 +5,12 @@
 #   usage (GPU box, repo root):  bash tools/cv1_phases.sh [batch]
 set -u
 B=${1:-8}; REPO=$(pwd)
+XSRC=$(dirname $(bash $REPO/tools/micro/experiment_source.sh))     # csrc/ with the experiment switches patched in (ELO_CV1_STOP)
 cd /tmp; export TMPDIR=/tmp
 for stop in 1 2 3 0; do
     def=""; [ $stop != 0 ] && def="-DELO_CV1_STOP=$stop"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off $def -I$REPO/include \
-        $REPO/efficientlo-net_amd/csrc/*.hip $REPO/efficientlo-net_amd/csrc/*.cpp -o /tmp/libelo_stop$stop.so &
+        $XSRC/*.hip $XSRC/*.cpp -o /tmp/libelo_stop$stop.so &
 done
 wait
 for stop in 1 2 3 0; do

@@ -27,8 +27,9 @@ case "$1" in
 build)
     mkdir -p $OUT
     python $PKG/build.py > /dev/null
+    XSRC=$(bash $ROOT/tools/micro/experiment_source.sh)      # elo_fused.hip with the bisect switches patched in (they are not in the product source)
     for v in $ORDER; do
-        ( /opt/rocm/bin/hipcc $FLAGS ${V[$v]} -c $PKG/csrc/elo_fused.hip -o $OUT/elo_fused.$v.o &&
+        ( /opt/rocm/bin/hipcc $FLAGS ${V[$v]} -c $XSRC -o $OUT/elo_fused.$v.o &&
           /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/elo_fused.$v.o $(ls $PKG/build/*.hip.o | grep -v elo_fused) -o $OUT/libelo_$v.so &&
           rm $OUT/elo_fused.$v.o && echo built $v ) &
     done

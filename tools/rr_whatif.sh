@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timing-only what-if builds of the chain kernels (WRONG results; built by hand into tools/micro/build/ with the recipe of
-# tools/rr_bisect.sh): HALF_READS = every step reads two of its four W fragments from the ring, NO_BARRIER = the superstep
+# tools/rr_bisect.sh from the PATCHED source -- tools/micro/experiment_source.sh: -DELO_RR_WHATIF_HALF_READS, -DELO_RR_BARRIER=3 --): HALF_READS = every step reads two of its four W fragments from the ring, NO_BARRIER = the superstep
 # barrier is only its s_waitcnt (the eight waves run free), BOTH.  Batch 8, fp16 storage: throughput at 8 lanes and the
 # chain kernels' durations at one lane.
 OUT=$(realpath -m "${1:-gpurun_out/rr_whatif}"); REPO=$(pwd); mkdir -p $OUT
