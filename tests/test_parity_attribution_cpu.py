@@ -69,7 +69,7 @@ def test_a_border_point_is_counted_with_its_margin():
         grid2, _ = O.ProjectPC2SphericalRing(P2, None, H, W)
     cells2 = np.stack([e[2][0] for e in tr2.events if e[1] == "cell"]).astype(np.int32)
     col64, _ = O.projection_coordinates64(P2[0, 50:51], H, W)
-    margin = abs(col64[0] - np.rint(col64[0])) / np.spacing(np.float32(col64[0]))
+    margin = abs(col64[0] - np.rint(col64[0])) / np.spacing(np.float32(max(col64[0], W / 2.0)))
     if margin > BORDER_ULPS:
         pytest.skip("float32 rounding of the constructed point left it %.1f ulps from the border" % margin)
     other = cells2.copy()                                       # the "product" truncated the other way
@@ -86,3 +86,36 @@ def test_a_border_point_is_counted_with_its_margin():
             g[0, c] = P2[0, members[r[members] == m]].sum(0)
     flips = _product_flips(_tap(P2, g.reshape(grid2.shape), other), tr2, B)
     assert int(flips[2][0]) >= 1 and int(flips[2][1]) == 0
+
+
+def test_the_seam_of_the_cylinder_is_a_border_too():
+    """Column 0 and column W - 1 are neighbours: the column coordinate runs from 0 (azimuth +pi) to W (azimuth -pi, clipped), so a
+    point on the negative x axis is decided by the sign of a rounding error in y.  A claim of the far column is accepted for a
+    point on the seam and refused for a point in the middle of column 0."""
+    P, grid, cells, tr = _case(seed=3)
+    P2 = P.copy()
+    P2[0, 60] = np.array([-12.0, 1e-9, -1.0], np.float32)          # azimuth pi - 8e-11: column coordinate ~ 1e-9
+    with O.discrete_trace() as tr2:
+        tr2.level = 2
+        grid2, _ = O.ProjectPC2SphericalRing(P2, None, H, W)
+    cells2 = np.stack([e[2][0] for e in tr2.events if e[1] == "cell"]).astype(np.int32)
+    assert cells2[0, 60] % W == 0
+    other = cells2.copy()
+    other[0, 60] += W - 1                                           # the "product" saw azimuth -pi: column W - 1 of the same row
+    g = grid2.copy().reshape(B, H * W, 3)
+    r = np.sqrt((P2[0].astype(np.float32) ** 2).sum(1)).astype(np.float32)
+    for c in (int(cells2[0, 60]), int(other[0, 60])):
+        members = np.nonzero(other[0] == c)[0]
+        g[0, c] = P2[0, members[r[members] == r[members].min()]].sum(0) if len(members) else 0
+    flips = _product_flips(_tap(P2, g.reshape(grid2.shape), other), tr2, B)
+    assert int(flips[2][0]) >= 1
+    P3 = P.copy()
+    P3[0, 60] = np.array([-12.0, 0.2, -1.0], np.float32)            # well inside column 0
+    with O.discrete_trace() as tr3:
+        tr3.level = 2
+        grid3, _ = O.ProjectPC2SphericalRing(P3, None, H, W)
+    cells3 = np.stack([e[2][0] for e in tr3.events if e[1] == "cell"]).astype(np.int32)
+    bad = cells3.copy()
+    bad[0, 60] += W - 1
+    with pytest.raises(AssertionError, match="ulps from a border"):
+        _product_flips(_tap(P3, grid3, bad), tr3, B)

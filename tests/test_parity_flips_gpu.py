@@ -109,8 +109,12 @@ def _product_flips(tap, forced_tr, B):
                 (prow, pcol), (orow, ocol) = divmod(int(cells[b][p]), w_), divmod(int(cell[p]), w_)
                 why = []
                 if pcol != ocol:
-                    margin = min(_near_integer(pc[j], pc[j]), _near_integer(oc[j], oc[j]))
-                    assert abs(pcol - ocol) == 1 and margin <= BORDER_ULPS, \
+                    # (the column coordinate is (pi - atan2f) / az: a DIFFERENCE of two numbers of magnitude pi, so its float32 error is
+                    #  an ulp of pi / az = an ulp of W / 2 in index units, also where the index itself is small)
+                    margin = min(_near_integer(pc[j], max(abs(pc[j]), w_ / 2.0)), _near_integer(oc[j], max(abs(oc[j]), w_ / 2.0)))
+                    # neighbours along the row -- or across the SEAM: the column coordinate (pi - atan2(y, x)) / az runs from 0 (azimuth
+                    # +pi) to W (azimuth -pi, clipped to W - 1): a point on the negative x axis is in column 0 or W - 1 by the sign of a zero
+                    assert abs(pcol - ocol) in (1, w_ - 1) and margin <= BORDER_ULPS, \
                         ("level %d pair %d point %d: columns %d / %d, column coordinate %.9f is %.1f ulps from a border" % (lvl, b, p, pcol, ocol, pc[j], margin))
                     why.append("col %.1f ulp" % margin)
                 if prow != orow:
