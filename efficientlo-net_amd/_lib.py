@@ -50,7 +50,7 @@ ELO_F32, ELO_F16 = 0, 1
 SoftmaxValidArgs = _struct("elo_softmax_valid_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp), ("out", _vp),
     ("scratch", _vp), ("stats", _vp)])
-SV_MAX_PARTS = 64      # ELO_SV_MAX_PARTS
+SV_MAX_PARTS = 512     # ELO_SV_MAX_PARTS
 POSE_DIRECT_MAX = 1024 # ELO_POSE_DIRECT_MAX
 PermRefreshArgs = _struct("elo_perm_refresh_args", [
     ("pool", _vp), ("versions", _i), ("total", _i), ("cursor", _vp), ("flat", _vp), ("decoded", _vp), ("entry_of", _vp),
@@ -60,7 +60,7 @@ PoseHeadArgs = _struct("elo_pose_head_args", [
     ("W_big", _vp), ("b_big", _vp), ("W_q", _vp), ("b_q", _vp), ("W_t", _vp), ("b_t", _vp),
     ("q_coarse", _vp), ("t_coarse", _vp), ("q", _vp), ("t", _vp), ("q_norm", _vp), ("scratch", _vp), ("pose7", _vp),
     ("clear_scratch", _vp), ("clear_xyz", _vp), ("clear_feat", _vp), ("clear_cells", ctypes.c_long), ("clear_C", _i),
-    ("feat_dtype", _i), ("pose7_slots", _i), ("pose7_cursor", _vp), ("next_orders", PermRefreshArgs), ("direct", _i)])
+    ("feat_dtype", _i), ("pose7_slots", _i), ("pose7_cursor", _vp), ("next_orders", PermRefreshArgs), ("direct", _i), ("ready_parts", _i)])
 WarpProjectArgs = _struct("elo_warp_project_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("H", _i), ("W", _i),
     ("az_res", _f), ("vert_res", _f), ("vert_off", _f),
@@ -137,7 +137,7 @@ MlpArgs = _struct("elo_mlp_args", [
     ("n_layers2", _i), ("layers2", Dense * 3), ("before", _vp), ("w_before", _i), ("after", _vp), ("w_after", _i),
     ("out2", _vp), ("feat_dtype", _i),
     ("clear_scratch", _vp), ("clear_xyz", _vp), ("clear_feat", _vp), ("clear_cells", _l), ("clear_C", _i), ("clear_images", _i),
-    ("batch_hint", _i)])
+    ("batch_hint", _i), ("sv_scratch", _vp), ("sv_xyz", _vp), ("sv_feature", _vp), ("sv_npoints", _i)])
 Cv1Args = _struct("elo_cv1_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("xyz2", _vp), ("feat2", _vp), ("idx", _vp), ("mask", _vp),
@@ -198,6 +198,7 @@ SYMBOLS = [
     ("elo_mlp_fused", ctypes.c_int, [ctypes.POINTER(MlpArgs), _vp]),
     ("elo_setconv_fused2", ctypes.c_int, [ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
     ("elo_mlp_fused2", ctypes.c_int, [ctypes.POINTER(MlpArgs), ctypes.POINTER(MlpArgs), _vp]),
+    ("elo_mlp_sv_parts", ctypes.c_int, [ctypes.POINTER(MlpArgs), ctypes.POINTER(MlpArgs)]),
     ("elo_cv_stage1_fused", ctypes.c_int, [ctypes.POINTER(Cv1Args), _vp]),
     ("elo_debug_cv1_rr", ctypes.c_int, [ctypes.c_int]),
     ("elo_debug_rr_rows", ctypes.c_int, [ctypes.c_long, ctypes.c_long]),
@@ -205,6 +206,7 @@ SYMBOLS = [
     ("elo_debug_narrow_mfma", ctypes.c_int, [ctypes.c_int]),
     ("elo_debug_narrow_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_debug_rowlinear_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
+    ("elo_debug_sv_ride_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_rowlinear_fused2", ctypes.c_int, [ctypes.POINTER(RowlinearArgs), ctypes.POINTER(RowlinearArgs), _vp]),
     ("elo_setconv_chain_form", ctypes.c_int, [ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs)]),
     ("elo_cv_chain_form", ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
@@ -219,7 +221,7 @@ class EloError(RuntimeError):
     pass
 
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 def lib():

@@ -388,6 +388,20 @@ class ProjectionBuffers:
         self.result = None          # (warped, out_xyz, out_feat) once a pose head has run the projection itself
 
 
+class SvPartials:
+    """softmax_valid's partial sums as a hand-over: the launch that produces the pose head's inputs (fused.mlp2_pair / fused.mlp
+    with sv=...) reduces each of its row tiles to a (maximum, denominator, weighted sum) triple per channel and leaves them in
+    `scratch`; pose_head(partials=...) merges them instead of running its partial-sums launch (include/elo.h elo_mlp_args.sv_*,
+    elo_pose_head_args.ready_parts).  `parts` = slices per batch element, 0 until (unless) a launch has taken the ride.
+    xyz: (B,N,3) the cloud whose validity masks the softmax; feature: (B,N,64) for a SINGLE launch (whose output are the logits)."""
+
+    def __init__(self, xyz_bn3, feature_bnc=None):
+        (self.xyz,) = _f32(xyz_bn3)
+        self.feature = feature_bnc
+        self.scratch = torch.empty((3 * xyz_bn3.shape[0] * L.SV_MAX_PARTS * 64,), dtype=torch.float32, device=xyz_bn3.device)
+        self.parts = 0
+
+
 class PoseRing:
     """(slots, B, 7) rows [q_norm | t] + a per-batch-element cursor: the pose output of a launch that is REPLAYED from a
     captured graph.  Replay r writes slot cursor % slots and advances the cursor, so a stream of frame pairs needs no
@@ -406,13 +420,15 @@ class PoseRing:
 
 
 def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse=None, t_coarse=None, pose7=None,
-              clear=None, warp=None, next_orders=None, direct=False):
+              clear=None, warp=None, next_orders=None, direct=False, partials=None):
     """softmax_valid -> conv1d(256) -> q,t heads -> normalise -> compose with the coarse pose, two launches.
     `direct` (N <= L.POSE_DIRECT_MAX, C = 64, hidden = 256): ONE launch -- the head's workgroups reduce the rows themselves
     (elo_pose_head_args.direct); `clear` must then already have been cleared by an earlier launch (fused.mlp(clear=...)).
     pwclo_model.py:194-208 / :262-280.  Returns (q (B,4), t (B,3), q_norm (B,4)); `pose7` (B,7), if given, also receives [q_norm | t].
     `next_orders`: an elo_perm_refresh_args (perm.PermSource.refresh_args): the next pooled set of visiting orders is
     loaded by this launch once the pose is written (the last launch of a captured forward).
+    `partials`: an SvPartials a preceding launch has filled (partials.parts > 0): no partial-sums launch here; `clear` must
+    then already have been cleared by that launch, as with `direct`.
     `clear`: ProjectionBuffers of the projection that will consume this pose (cleared on the side).
     `warp` = (xyz (B,N,3), feat (B,N,C) or None) with `clear`: that projection itself -- warp by this pose, spherical
     re-projection -- is run by this call (elo_pose_head_warp: 3 launches instead of 2 + 2); its result is left in
@@ -428,7 +444,10 @@ def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t
     q = torch.empty((B, 4), dtype=torch.float32, device=dev)
     t = torch.empty((B, 3), dtype=torch.float32, device=dev)
     q_norm = torch.empty((B, 4), dtype=torch.float32, device=dev)
-    scratch = torch.empty((3 * B * L.SV_MAX_PARTS * C,), dtype=torch.float32, device=dev)
+    ready = partials.parts if partials is not None else 0
+    if ready and (direct or C != 64):
+        raise ValueError("partials= goes with the 64-channel head and not with direct=True")
+    scratch = partials.scratch if ready else torch.empty((3 * B * L.SV_MAX_PARTS * C,), dtype=torch.float32, device=dev)
     ptr = lambda x: x.data_ptr() if x is not None else None
     ring = pose7 if isinstance(pose7, PoseRing) else None
     if ring is not None:
@@ -442,9 +461,9 @@ def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t
                                       clear.shape[0] * clear.shape[2] * clear.shape[3], clear.shape[4])
                                      if clear is not None else (None, None, None, 0, 0)), fcode,
                        ring.slots if ring is not None else 0, ring.cursor.data_ptr() if ring is not None else None,
-                       next_orders if next_orders is not None else L.PermRefreshArgs(), 1 if direct else 0)
-    if direct and clear is not None and not clear.cleared:
-        raise ValueError("direct=True: the ProjectionBuffers must have been cleared by an earlier launch (fused.mlp(clear=...))")
+                       next_orders if next_orders is not None else L.PermRefreshArgs(), 1 if direct else 0, ready)
+    if (direct or ready) and clear is not None and not clear.cleared:
+        raise ValueError("direct=True / partials=: the ProjectionBuffers must have been cleared by an earlier launch (fused.mlp(clear=...))")
     if clear is not None and clear.out_feat is not None and clear.out_feat.dtype != fdt:
         raise TypeError("the projection buffers and the pose head's features must share one storage dtype")
     if warp is not None:

@@ -770,21 +770,32 @@ __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_ar
         const int c = tid & 63, q = tid >> 6;
         float M = -INFINITY, D = 0.0f, A = 0.0f;
         if (c < a.C) {
-            constexpr int MINE = ELO_SV_MAX_PARTS / 4;    // slices per thread: all their loads go out together
-            float m_[MINE], d_[MINE], a_[MINE];
+            // slices q, q + 4, ... of channel c; per trip MINE slices per thread, all their loads out together (unconditional, on
+            // clamped indices: a load under a condition costs a full wait).  One trip of 16 for the <= 64 slices of a partial-sums
+            // launch; trips of 32 for the row tiles of an MLP launch that computed the partial sums itself (elo_pose_head_args.
+            // ready_parts: 225 tiles at l0 of a 64 x 1800 scan = two dependent round trips).  The two forms sit in a branch that is
+            // uniform for the launch, each with its loads AND their use inside.
+            auto trips = [&](auto mine) {
+                constexpr int MINE = decltype(mine)::value;
+                for (int i0 = q; i0 < parts; i0 += 4 * MINE) {
+                    float m_[MINE], d_[MINE], a_[MINE];
 #pragma unroll
-            for (int u = 0; u < MINE; ++u) {
-                const int i = q + 4 * u;
-                const size_t at = ((size_t)b * ELO_SV_MAX_PARTS + (i < parts ? i : 0)) * a.C + c;
-                m_[u] = s.mx[at]; a_[u] = s.acc[at];
-                d_[u] = i < parts ? s.den[at] : 0.0f;
-            }
+                    for (int u = 0; u < MINE; ++u) {
+                        const int i = i0 + 4 * u;
+                        const size_t at = ((size_t)b * ELO_SV_MAX_PARTS + (i < parts ? i : 0)) * a.C + c;
+                        m_[u] = s.mx[at]; a_[u] = s.acc[at];
+                        d_[u] = i < parts ? s.den[at] : 0.0f;
+                    }
 #pragma unroll
-            for (int u = 0; u < MINE; ++u) {
-                if (d_[u] == 0.0f) continue;
-                if (m_[u] > M) { const float sc = exp_acc(M - m_[u]); D = D * sc + d_[u]; A = A * sc + a_[u]; M = m_[u]; }
-                else { const float sc = exp_acc(m_[u] - M); D += d_[u] * sc; A += a_[u] * sc; }
-            }
+                    for (int u = 0; u < MINE; ++u) {
+                        if (d_[u] == 0.0f) continue;
+                        if (m_[u] > M) { const float sc = exp_acc(M - m_[u]); D = D * sc + d_[u]; A = A * sc + a_[u]; M = m_[u]; }
+                        else { const float sc = exp_acc(m_[u] - M); D += d_[u] * sc; A += a_[u] * sc; }
+                    }
+                }
+            };
+            if (parts <= 64) trips(std::integral_constant<int, 16>());
+            else trips(std::integral_constant<int, 32>());
         }
         mpart[(0 * 4 + q) * 64 + c] = M; mpart[(1 * 4 + q) * 64 + c] = D; mpart[(2 * 4 + q) * 64 + c] = A;
         __syncthreads();
@@ -1130,8 +1141,9 @@ extern "C" int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_strea
 
 static int sv_parts(int npoints)
 {
+    constexpr int SV_MAX_SLICES = 64;                // (the scratch layout has room for ELO_SV_MAX_PARTS: the row tiles of elo_mlp_args.sv_*)
     int parts = (npoints + 63) / 64;                 // >= 64 points (16 per wave) per block
-    return parts < 1 ? 1 : parts > ELO_SV_MAX_PARTS ? ELO_SV_MAX_PARTS : parts;
+    return parts < 1 ? 1 : parts > SV_MAX_SLICES ? SV_MAX_SLICES : parts;
 }
 
 extern "C" int elo_softmax_valid(const elo_softmax_valid_args *a, elo_stream_t stream)
@@ -1172,6 +1184,7 @@ static int pose_head_impl(const elo_pose_head_args *a, const elo_warp_project_ar
     ELO_REQUIRE((a->q_coarse == nullptr) == (a->t_coarse == nullptr), who, "q_coarse and t_coarse go together");
     ELO_REQUIRE(!a->clear_scratch || (a->clear_xyz && a->clear_cells > 0 && a->clear_C >= 0 && (a->clear_feat || a->clear_C == 0)),
                 who, "incomplete clear_* side job");
+    ELO_REQUIRE(!a->clear_scratch || a->clear_cells * (a->clear_C > 3 ? a->clear_C : 3) < (1l << 31), who, "clear_* side job: more than 2^31 words");
     ELO_REQUIRE(a->feat_dtype == ELO_F32 || a->feat_dtype == ELO_F16, who, "feat_dtype must be ELO_F32 or ELO_F16");
     const int f16 = a->feat_dtype == ELO_F16;
     ELO_REQUIRE(!f16 || a->clear_C % 2 == 0, who, "fp16 feature storage needs an even clear_C");
@@ -1189,6 +1202,9 @@ static int pose_head_impl(const elo_pose_head_args *a, const elo_warp_project_ar
     }
     ELO_REQUIRE(!a->direct || (a->npoints <= ELO_POSE_DIRECT_MAX && a->C == 64 && a->hidden == 256), who,
                 "direct takes npoints <= ELO_POSE_DIRECT_MAX, C == 64, hidden == 256");
+    ELO_REQUIRE(a->ready_parts >= 0 && a->ready_parts <= ELO_SV_MAX_PARTS && !(a->ready_parts && a->direct), who,
+                "ready_parts is 0..ELO_SV_MAX_PARTS and not combined with direct");
+    ELO_REQUIRE(!a->ready_parts || a->C == 64, who, "ready_parts: the partial sums of an MLP launch are 64 channels wide");
     if (a->batch == 0) return ELO_OK;
     hipStream_t s = (hipStream_t)stream;
     if (a->direct) {                                  // one launch: the head's workgroups reduce the rows themselves
@@ -1198,11 +1214,12 @@ static int pose_head_impl(const elo_pose_head_args *a, const elo_warp_project_ar
         if (f16) hipLaunchKernelGGL((pose_head_kernel<DB, 2>), dim3(xb, a->batch), dim3(DB), lds, s, *a, 0, wv, w ? 1 : 0);
         else hipLaunchKernelGGL((pose_head_kernel<DB, 1>), dim3(xb, a->batch), dim3(DB), lds, s, *a, 0, wv, w ? 1 : 0);
     } else {
-        const int parts = sv_parts(a->npoints);
+        const int parts = a->ready_parts ? a->ready_parts : sv_parts(a->npoints);
         const ProjectionClear clear{a->clear_scratch, a->clear_xyz, (unsigned *)a->clear_feat, a->clear_cells,
                                     f16 ? a->clear_C / 2 : a->clear_C, a->batch};
         const dim3 pgrid(parts, a->batch, (a->C + ELO_WAVE - 1) / ELO_WAVE);
-        if (f16)
+        if (a->ready_parts) {}                            // the launch that produced feature / weight wrote the partial sums (and cleared)
+        else if (f16)
             hipLaunchKernelGGL(softmax_valid_partial_kernel<true>, pgrid, dim3(ELO_BLOCK), 0, s, a->feature, a->weight, a->xyz,
                                a->npoints, a->C, parts, a->scratch, clear);
         else

@@ -35,6 +35,10 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 constexpr int FUSED_BLOCK = 256;   // 4 waves cooperate on one tile of rows
 constexpr int FUSED_WAVES = 4;
+// A thread's index within the 4-wave group that works on one tile.  Every tile kernel but mlp_sv_kernel's paired form is
+// launched with FUSED_BLOCK threads and says so in its __launch_bounds__ (the compiler then knows threadIdx.x < 256 and the
+// mask folds away); the paired form runs TWO such groups, one tile each, in a 512-thread workgroup.
+__device__ __forceinline__ int ftid() { return (int)(threadIdx.x & (FUSED_BLOCK - 1)); }
 
 // how a kernel instance computes its products (template parameter MODE)
 constexpr int MODE_SPLIT = 0;      // fp32-class: hi/lo split operands, three fp16 MFMA products
@@ -444,7 +448,10 @@ __device__ __forceinline__ void store_quad(float *act, int S, int row, int col, 
     }
     if (o.lds_off >= 0) {
         const int word = row * S + o.lds_off + col;
-        if (o.plain) quad_store(act, word, __builtin_bit_cast(uint4, v));
+        if (o.plain && o.gout && o.gf16) {            // (mlp_sv_kernel: the pooled value is the fp16 the consumer would read back)
+            const half2v a = __builtin_bit_cast(half2v, stored.x), b = __builtin_bit_cast(half2v, stored.y);
+            quad_store(act, word, __builtin_bit_cast(uint4, float4{(float)a.x, (float)a.y, (float)b.x, (float)b.y}));
+        } else if (o.plain) quad_store(act, word, __builtin_bit_cast(uint4, v));
         else if (o.gout && o.gf16) quad_store(act, word, quad_of_halves(stored));
         else quad_store(act, word, pack_quad<MODE>(v, violations));          // columns >= N hold relu(0 + 0) = 0: the next layer's K padding
     }
@@ -519,7 +526,7 @@ __device__ __forceinline__ void dense_impl(float *act, int S, int in_off, const 
     constexpr int MT = TPW < 2 ? TPW : 2, PASSES = TPW / MT;
     // the wave index as a SCALAR: column blocks and with them every W / bias base address live in SGPRs,
     // so a W load is `buffer_load_dwordx4 v, v_lane_off, s[rsrc], s_off` with no vector address arithmetic
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(ftid() >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     const int cb0 = wave;
     const int KS = ceil16(L.K) >> 4, CB = ceil16(L.N) >> 4;
@@ -772,7 +779,7 @@ __device__ __forceinline__ void seg_load(uint4 (&r)[SEG_ITEMS], const void *__re
     const int q = W >> (f16 ? 3 : 2), items = TILE * q;
 #pragma unroll
     for (int u = 0; u < SEG_ITEMS; ++u) {
-        const int it = threadIdx.x + u * FUSED_BLOCK < items ? threadIdx.x + u * FUSED_BLOCK : items - 1;
+        const int it = ftid() + u * FUSED_BLOCK < items ? ftid() + u * FUSED_BLOCK : items - 1;
         int row, c4;
         seg_split(it, q, row, c4);
         const long sr = rowof(row);
@@ -788,7 +795,7 @@ __device__ __forceinline__ void seg_store(float *act, int S, int col0, int W, in
     const int q = W >> (f16 ? 3 : 2), items = TILE * q;
 #pragma unroll
     for (int u = 0; u < SEG_ITEMS; ++u) {
-        const int it = threadIdx.x + u * FUSED_BLOCK;
+        const int it = ftid() + u * FUSED_BLOCK;
         if (it < items) {
             int row, c4;
             seg_split(it, q, row, c4);
@@ -811,11 +818,11 @@ __device__ __forceinline__ void zero_cols(float *act, int S, int from, int to)
 {
     if (((from | to) & 3) == 0) {
         const int w = (to - from) >> 2;
-        for (int e = threadIdx.x; e < TILE * w; e += FUSED_BLOCK) { const int er = small_div(e, w); quad_store(act, er * S + from + 4 * (e - er * w), uint4{0u, 0u, 0u, 0u}); }
+        for (int e = ftid(); e < TILE * w; e += FUSED_BLOCK) { const int er = small_div(e, w); quad_store(act, er * S + from + 4 * (e - er * w), uint4{0u, 0u, 0u, 0u}); }
     } else {
         const int w = to - from;
         unsigned none = 0;
-        for (int e = threadIdx.x; e < TILE * w; e += FUSED_BLOCK) { const int er = small_div(e, w); act_put<MODE>(act, er * S + from + (e - er * w), 0.0f, none); }
+        for (int e = ftid(); e < TILE * w; e += FUSED_BLOCK) { const int er = small_div(e, w); act_put<MODE>(act, er * S + from + (e - er * w), 0.0f, none); }
     }
 }
 
@@ -1443,22 +1450,14 @@ __global__ __launch_bounds__(ELO_BLOCK, 4) void setconv_tiled_kernel(const elo_s
 // ================================================================ row-wise MLP over concatenated sources
 // stage 1: columns [0, w0 + w1 + w2) = the sources; its last layer writes `out` to HBM straight from the accumulators
 // and, with a second stage, to columns [0, N) of the tile; stage 2: [out (N) | before | after] -> layers2 -> out2.
+// The tile's rows are the global rows [first, min(first + TILE, end)).  keep_final: the LAST layer's output also stays in the tile,
+// columns [0, N), as plain floats (the values as stored: fp16 storage rounds them) -- the input of mlp_sv_kernel's reduction.
 template <int TILE, int MODE>
-__global__ __launch_bounds__(FUSED_BLOCK, TILE == 32 ? ELO_TILE32_WAVES : ELO_TILE_WAVES) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
+__device__ __forceinline__ void mlp_tile(const elo_mlp_args &a, float *act, const int S, const long first, const long end,
+                                         const bool keep_final, unsigned &bad)
 {
-    const elo_mlp_args &a = jobs.job[blockIdx.y];
-    extern __shared__ __align__(16) float lds[];
-    float *act = lds;
-    const int tid = threadIdx.x, f16 = a.feat_dtype == ELO_F16;
-    unsigned bad = 0;
-    {   // side job (elo_mlp_args.clear_*, job 0's): every workgroup of the launch clears its share of a later projection's buffers
-        const elo_mlp_args &j0 = jobs.job[0];
-        clear_projection(ProjectionClear{j0.clear_scratch, j0.clear_xyz, (unsigned *)j0.clear_feat, j0.clear_cells,
-                                         j0.feat_dtype == ELO_F16 ? j0.clear_C / 2 : j0.clear_C, j0.clear_images});
-    }
-    const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * TILE;
-    if (first >= a.rows) return;
-    auto row_of = [&](int row) { return first + row < a.rows ? first + row : -1L; };
+    const int tid = ftid(), f16 = a.feat_dtype == ELO_F16;
+    auto row_of = [&](int row) { return first + row < end ? first + row : -1L; };
     auto all = [](int) { return true; };
     const int w0 = a.src_width[0], w1 = a.n_sources > 1 ? a.src_width[1] : 0, w2 = a.n_sources > 2 ? a.src_width[2] : 0;
     const int CT = w0 + w1 + w2, CTp = ceil16(CT);
@@ -1476,7 +1475,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, TILE == 32 ? ELO_TILE32_WAVES : ELO_TI
             const int row = small_div(e, CTp), ch = e - row * CTp;
             const long gr = first + row;
             float v = 0.0f;
-            if (gr < a.rows && ch < CT) {
+            if (gr < end && ch < CT) {
                 v = ch < w0 ? feat_load(a.src[0], gr * w0 + ch, f16)
                   : ch < w0 + w1 ? feat_load(a.src[1], gr * w1 + (ch - w0), f16)
                                  : feat_load(a.src[2], gr * w2 + (ch - w0 - w1), f16);
@@ -1489,8 +1488,8 @@ __global__ __launch_bounds__(FUSED_BLOCK, TILE == 32 ? ELO_TILE32_WAVES : ELO_TI
     const bool two = a.n_layers2 > 0;
     for (int l = 0; l < a.n_layers; ++l)
         dense<TILE, MODE>(act, S, 0, a.layers[l],
-                          l == a.n_layers - 1 ? LayerOut{two ? 0 : -1, 0, a.out, first, a.rows, f16} : to_tile(0), bad);
-    if (!two) { report_violations<MODE>(bad); return; }
+                          l == a.n_layers - 1 ? LayerOut{two || keep_final ? 0 : -1, !two && keep_final ? 1 : 0, a.out, first, end, f16} : to_tile(0), bad);
+    if (!two) return;
     // ---- second stage: [out | before | after] -> layers2 -> out2       (`out` already sits at columns [0, N))
     const int wb = a.w_before, wa = a.w_after, CT2 = N + wb + wa;
     if ((N & 3) == 0 && (wb == 0 || seg_ok(a.before, wb, TILE, f16)) && (wa == 0 || seg_ok(a.after, wa, TILE, f16))) {
@@ -1503,17 +1502,133 @@ __global__ __launch_bounds__(FUSED_BLOCK, TILE == 32 ? ELO_TILE32_WAVES : ELO_TI
         for (int e = tid; e < TILE * (wb + wa); e += FUSED_BLOCK) {
             const int row = small_div(e, wb + wa), ch = e - row * (wb + wa);
             const long gr = first + row;
-            const long grc = gr < a.rows ? gr : a.rows - 1;
+            const long grc = gr < end ? gr : end - 1;
             const float v = ch < wb ? feat_load(a.before, grc * wb + ch, f16) : feat_load(a.after, grc * wa + (ch - wb), f16);
-            act_put<MODE>(act, row * S + N + ch, gr < a.rows ? v : 0.0f, bad);
+            act_put<MODE>(act, row * S + N + ch, gr < end ? v : 0.0f, bad);
         }
     }
     zero_cols<TILE, MODE>(act, S, CT2, ceil16(CT2));
     __syncthreads();
     for (int l = 0; l < a.n_layers2; ++l)
         dense<TILE, MODE>(act, S, 0, a.layers2[l],
-                          l == a.n_layers2 - 1 ? LayerOut{-1, 0, a.out2, first, a.rows, f16} : to_tile(0), bad);
+                          l == a.n_layers2 - 1 ? LayerOut{keep_final ? 0 : -1, keep_final ? 1 : 0, a.out2, first, end, f16} : to_tile(0), bad);
+}
+
+template <int TILE, int MODE>
+__global__ __launch_bounds__(FUSED_BLOCK, TILE == 32 ? ELO_TILE32_WAVES : ELO_TILE_WAVES) void mlp_kernel(const JobPair<elo_mlp_args> jobs, const int S)
+{
+    const elo_mlp_args &a = jobs.job[blockIdx.y];
+    extern __shared__ __align__(16) float lds[];
+    unsigned bad = 0;
+    {   // side job (elo_mlp_args.clear_*, job 0's): every workgroup of the launch clears its share of a later projection's buffers
+        const elo_mlp_args &j0 = jobs.job[0];
+        clear_projection(ProjectionClear{j0.clear_scratch, j0.clear_xyz, (unsigned *)j0.clear_feat, j0.clear_cells,
+                                         j0.feat_dtype == ELO_F16 ? j0.clear_C / 2 : j0.clear_C, j0.clear_images});
+    }
+    const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * TILE;
+    if (first >= a.rows) return;
+    mlp_tile<TILE, MODE>(a, lds, S, first, a.rows, false, bad);
     report_violations<MODE>(bad);
+}
+
+// The row-wise MLP(s) that end in softmax_valid's inputs, WITH the first half of softmax_valid (model_util.py:319-343: a
+// softmax over the valid points of every channel's logits, the weighted sum of the features): a tile's final rows are in
+// LDS when its last layer is done, so the workgroup reduces them to one (max, denominator, weighted sum) triple per channel
+// -- what softmax_valid_partial_kernel computes from HBM in a launch of its own (7-9 us of a batch-1 level) -- and the pose
+// head merges the tiles' triples instead of that launch's slices (elo_pose_head_args.ready_parts).
+//   PAIR: job 0 produces the logits (the embedding-mask branch, `weight`), job 1 the features (`predict`): the two
+//     4-wave groups of a 512-thread workgroup run them SIDE BY SIDE on the same rows (twins back to back on one tile were
+//     measured slower than the paired launch: a level's tail is a latency chain), each on its own tile;
+//   single (the coarse level: the features are an existing tensor, sv_feature): staged into LDS at the start.
+// Tiles never straddle two batch elements (tiles_pb per element); the triple of tile t of element b goes to slot
+// (b, t) of sv_scratch -- the layout of softmax_valid_partial_kernel's scratch.
+template <int TILE, int MODE, bool PAIR>
+__global__ __launch_bounds__(PAIR ? 2 * FUSED_BLOCK : FUSED_BLOCK, TILE == 32 ? 4 : ELO_TILE_WAVES)      // (32 rows: the held registers do not fit mlp_kernel's 96)
+void mlp_sv_kernel(const JobPair<elo_mlp_args> jobs, const int S, const int tiles_pb)
+{
+    constexpr int C = 64;
+    const int group = PAIR ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
+    const elo_mlp_args &j0 = jobs.job[0];
+    const elo_mlp_args &a = jobs.job[group];
+    extern __shared__ __align__(16) float lds[];
+    const int tile_words = TILE * S;
+    float *act = lds + group * tile_words;
+    float *staged = lds + (PAIR ? 2 : 1) * tile_words;        // single: the tile's feature rows [TILE][64]
+    unsigned bad = 0;
+    clear_projection(ProjectionClear{j0.clear_scratch, j0.clear_xyz, (unsigned *)j0.clear_feat, j0.clear_cells,
+                                     j0.feat_dtype == ELO_F16 ? j0.clear_C / 2 : j0.clear_C, j0.clear_images});
+    const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int b = (int)(tile / (unsigned)tiles_pb), t = (int)(tile - (unsigned)b * (unsigned)tiles_pb);
+    const long first = (long)b * j0.sv_npoints + (long)t * TILE, end = (long)(b + 1) * j0.sv_npoints;
+    const int f16 = j0.feat_dtype == ELO_F16;
+    // Requested now, CONSUMED after the MLP (nothing below waits for them before the tile's own loads are out):
+    //   the tile's points -- lane r < TILE of the first wave holds row r's xyz; a row is valid unless all three are exactly 0
+    //   (model_util.py:325), handed to the reduction as one ballot;
+    //   single: the tile's feature rows, 16 bytes (8 for fp16 storage) per thread and 16 rows, staged into LDS behind the MLP.
+    const int vr = threadIdx.x < TILE ? (int)threadIdx.x : 0;
+    const long vrow = first + vr < end ? first + vr : end - 1;
+    const float px = j0.sv_xyz[vrow * 3 + 0], py = j0.sv_xyz[vrow * 3 + 1], pz = j0.sv_xyz[vrow * 3 + 2];
+    constexpr int STAGE = PAIR ? 1 : TILE / 16;
+    uint4 held[STAGE];
+    if constexpr (!PAIR) {
+#pragma unroll
+        for (int u = 0; u < STAGE; ++u) {
+            const int e = (int)threadIdx.x + u * FUSED_BLOCK, fr = e >> 4, q = e & 15;
+            const long grow = first + fr < end ? first + fr : end - 1;
+            if (f16) { const uint2 h = reinterpret_cast<const uint2 *>(j0.sv_feature)[grow * (C / 4) + q]; held[u] = uint4{h.x, h.y, 0u, 0u}; }
+            else held[u] = reinterpret_cast<const uint4 *>(j0.sv_feature)[grow * (C / 4) + q];
+        }
+    }
+    mlp_tile<TILE, MODE>(a, act, S, first, end, true, bad);       // (ends with the last layer's barrier: both tiles are complete)
+    report_violations<MODE>(bad);
+    if constexpr (!PAIR) {
+#pragma unroll
+        for (int u = 0; u < STAGE; ++u) {
+            const int e = (int)threadIdx.x + u * FUSED_BLOCK, fr = e >> 4, q = e & 15;
+            float4 v;
+            if (f16) {
+                const half2v h0 = __builtin_bit_cast(half2v, held[u].x), h1 = __builtin_bit_cast(half2v, held[u].y);
+                v = float4{(float)h0.x, (float)h0.y, (float)h1.x, (float)h1.y};
+            } else {
+                v = __builtin_bit_cast(float4, held[u]);
+            }
+            *reinterpret_cast<float4 *>(staged + fr * C + 4 * q) = v;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x >= C) return;
+    const unsigned long long okm = __ballot((threadIdx.x < TILE) & (first + vr < end) & !((px == 0.0f) & (py == 0.0f) & (pz == 0.0f)));
+    const int c = threadIdx.x;
+    const float *logit = lds + c, *value = PAIR ? lds + tile_words + c : staged + c;
+    const int vs = PAIR ? S : C;
+    float M = -INFINITY, D = 0.0f, A = 0.0f;
+#pragma unroll
+    for (int r0 = 0; r0 < TILE; r0 += 16) {                     // 16 rows at a time: softmax_valid_partial_kernel's step
+        float l[16], v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { l[r] = logit[(r0 + r) * S]; v[r] = value[(r0 + r) * vs]; }
+        const unsigned ok = (unsigned)(okm >> r0) & 0xffffu;
+        float bm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bm = (ok >> r & 1u) ? fmaxf(bm, l[r]) : bm;
+        if (bm > -INFINITY) {
+            float d16 = 0.0f, a16 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = (ok >> r & 1u) ? exp_acc(l[r] - bm) : 0.0f;
+                d16 += e;
+                a16 += e * v[r];
+            }
+            const float m2 = fmaxf(M, bm), s0 = exp_acc(M - m2), s1 = exp_acc(bm - m2);      // exp_acc(-inf) = 0 on the first step
+            D = D * s0 + d16 * s1;
+            A = A * s0 + a16 * s1;
+            M = m2;
+        }
+    }
+    float *sc = j0.sv_scratch;
+    const size_t n = (size_t)(gridDim.x / (unsigned)tiles_pb) * ELO_SV_MAX_PARTS * C;      // (batch, ELO_SV_MAX_PARTS, C) x {max, den, acc}
+    const size_t at = ((size_t)b * ELO_SV_MAX_PARTS + t) * C + c;
+    sc[at] = M; sc[n + at] = D; sc[2 * n + at] = A;
 }
 
 // ================================================================ cost volume, stage 1
@@ -3058,6 +3173,13 @@ static inline int pad16(int x) { return (x + 15) & ~15; }
     } while (0)
 #endif
 
+// CALL_T(MODE) for the products mode of a launch (the heterogeneous launch, mlp_sv_kernel)
+#ifdef ELO_DENSE_F32
+#define ELO_PICK_MODE(M_, CALL_T) do { if ((M_) == MODE_CHECKED) CALL_T(MODE_CHECKED); else CALL_T(MODE_SPLIT); } while (0)
+#else
+#define ELO_PICK_MODE(M_, CALL_T) do { if ((M_) == MODE_HALF) CALL_T(MODE_HALF); else if ((M_) == MODE_CHECKED) CALL_T(MODE_CHECKED); else CALL_T(MODE_SPLIT); } while (0)
+#endif
+
 // column budget of an in-place chain starting from `width` input columns
 static int chain_cols(const elo_dense *layers, int n_layers, int width)
 {
@@ -3213,6 +3335,13 @@ extern "C" int elo_debug_rr_launches(unsigned long long *counts4, int reset)
         if (counts4) counts4[i] = g_rr_launches[i].load();
         if (reset) g_rr_launches[i].store(0);
     }
+    return ELO_OK;
+}
+static std::atomic<unsigned long long> g_sv_ride_launches;    // mlp_sv_kernel (elo_mlp_args.sv_*)
+extern "C" int elo_debug_sv_ride_launches(unsigned long long *count, int reset)
+{
+    if (count) *count = g_sv_ride_launches.load();
+    if (reset) g_sv_ride_launches.store(0);
     return ELO_OK;
 }
 extern "C" int elo_debug_rowlinear_launches(unsigned long long *count, int reset)
@@ -3468,6 +3597,7 @@ static int check_mlp(const elo_mlp_args *a, const char *who, int *in_width)
     ELO_REQUIRE(!a->clear_scratch || (a->clear_xyz && a->clear_cells > 0 && a->clear_images > 0 && a->clear_C >= 0 &&
                                       (a->clear_feat || a->clear_C == 0) && (a->feat_dtype != ELO_F16 || a->clear_C % 2 == 0)),
                 who, "incomplete clear_* side job");
+    ELO_REQUIRE(!a->clear_scratch || a->clear_cells * (a->clear_C > 3 ? a->clear_C : 3) < (1l << 31), who, "clear_* side job: more than 2^31 words");
     ELO_REQUIRE(a->n_layers2 >= 0 && a->n_layers2 <= ELO_MAX_CHAIN, who, "0..3 second-stage layers");
     if (a->n_layers2 > 0) {
         ELO_REQUIRE(a->out2 && a->w_before >= 0 && a->w_after >= 0 && (a->before || a->w_before == 0) &&
@@ -3494,9 +3624,11 @@ static int mlp_cols(const elo_mlp_args *a, int in_width)
     return cols;
 }
 
-extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_stream_t stream)
+// everything elo_mlp_fused2 decides before it launches
+struct MlpPlan { int S, mode, C; bool t16, chain; int sv_tiles; };     // sv_tiles: row tiles per batch element of the softmax_valid ride (0: none)
+
+static int plan_mlp(const elo_mlp_args *a, const elo_mlp_args *b, MlpPlan *p, const char *who)
 {
-    const char *who = "elo_mlp_fused";
     int in_width = 0, in_width_b = 0;
     if (int rc = check_mlp(a, who, &in_width)) return rc;
     if (b) {
@@ -3509,51 +3641,110 @@ extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_
         if (!same) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must have the same shape", who);
     }
     if (b && b->clear_scratch) return fail(ELO_ERR_ARG, "%s: the clear_* side job belongs to the first job of a pair", who);
-    if (a->rows == 0)
-        return a->clear_scratch ? fail(ELO_ERR_ARG, "%s: a clear_* side job needs rows to ride on", who) : ELO_OK;
-    const int S = row_stride(mlp_cols(a, in_width));
-    const long u32 = (a->rows + 31) / 32, u16 = (a->rows + 15) / 16;
-    int mode = 0, mode_b = 0;
-    if (int rc = products_mode(who, &mode, a->layers, a->n_layers, a->layers2, a->n_layers2)) return rc;
+    if (b && (b->sv_scratch || b->sv_feature)) return fail(ELO_ERR_ARG, "%s: the sv_* fields belong to the first job of a pair", who);
+    p->S = row_stride(mlp_cols(a, in_width));
+    const long u32 = (a->rows + 31) / 32;
+    p->mode = 0;
+    int mode_b = 0;
+    if (int rc = products_mode(who, &p->mode, a->layers, a->n_layers, a->layers2, a->n_layers2)) return rc;
     if (b) {
         if (int rc = products_mode(who, &mode_b, b->layers, b->n_layers, b->layers2, b->n_layers2)) return rc;
-        if (mode != mode_b) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must share one products mode", who);
+        if (p->mode != mode_b) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must share one products mode", who);
     }
-    const bool t16 = small_tile(u32 * (b ? 2 : 1), 1);
-    const size_t lds = tile_lds_bytes(t16 ? 16 : 32, S);
-    JobPair<elo_mlp_args> pair;
-    pair.job[0] = *a;
-    pair.job[1] = b ? *b : *a;
+    p->t16 = small_tile(u32 * (b ? 2 : 1), 1);
+    p->chain = false;
+    p->C = a->n_sources == 2 ? a->src_width[1] : 0;
 #ifndef ELO_DENSE_F32
     {   // the register-resident form (mlp2_rr_kernel) for the model's two-stage shape, from ELO_MLP_RR_ROWS rows per launch on
         // two regimes (fused._prepass_rows): batch >= 4 keeps the GPU full -- 24.0 k -> 25.5 k pairs/s at batch 8 with the chain at
         // every level; at batch 1 (7200 rows at l0) the tile kernel is faster: 10.2 k vs 9.8 k
         const long min_rows = mlp_rr_rows(a->batch_hint);
-        const int C = a->n_sources == 2 ? a->src_width[1] : 0;
+        const int C = p->C;
         const bool aligned = ((uintptr_t)a->src[0] | (uintptr_t)a->src[1] | (uintptr_t)a->before | (uintptr_t)a->after | (uintptr_t)a->out |
                               (uintptr_t)a->out2) % 16 == 0 &&
                              (!b || ((uintptr_t)b->src[0] | (uintptr_t)b->src[1] | (uintptr_t)b->before | (uintptr_t)b->after | (uintptr_t)b->out |
                                      (uintptr_t)b->out2) % 16 == 0);
-        if ((mode == MODE_SPLIT || mode == MODE_HALF) && cv1_rr_on() && a->n_sources == 2 && a->src_width[0] == 64 && (C == 16 || C == 32 || C == 64) &&
-            a->n_layers == 2 && a->layers[0].N == 128 && a->layers[1].N == 64 && a->n_layers2 == 2 && a->layers2[0].N == 128 &&
-            a->layers2[1].N == 64 && a->w_before == C && a->w_after == 64 && aligned && a->rows * (b ? 2 : 1) >= min_rows) {
-            const dim3 rgrid((unsigned)((a->rows + RR_ROWS - 1) / RR_ROWS), b ? 2u : 1u);
-            const bool f16 = a->feat_dtype == ELO_F16;
-            hipStream_t rs = (hipStream_t)stream;
+        p->chain = (p->mode == MODE_SPLIT || p->mode == MODE_HALF) && cv1_rr_on() && a->n_sources == 2 && a->src_width[0] == 64 &&
+                   (C == 16 || C == 32 || C == 64) && a->n_layers == 2 && a->layers[0].N == 128 && a->layers[1].N == 64 && a->n_layers2 == 2 &&
+                   a->layers2[0].N == 128 && a->layers2[1].N == 64 && a->w_before == C && a->w_after == 64 && aligned &&
+                   a->rows * (b ? 2 : 1) >= min_rows;
+    }
+#endif
+    // the softmax_valid ride (elo_mlp_args.sv_*): tile kernel, 64-wide final output, whole tiles per batch element
+    p->sv_tiles = 0;
+    const int final_n = a->n_layers2 > 0 ? a->layers2[a->n_layers2 - 1].N : a->layers[a->n_layers - 1].N;
+    if (!p->chain && final_n == 64 && a->sv_npoints > 0 && a->rows > 0 && a->rows % a->sv_npoints == 0) {
+        const int tile = p->t16 ? 16 : 32;
+        const long tiles = ((long)a->sv_npoints + tile - 1) / tile;
+        if (tiles <= ELO_SV_MAX_PARTS) p->sv_tiles = (int)tiles;
+    }
+    return ELO_OK;
+}
+
+extern "C" int elo_mlp_sv_parts(const elo_mlp_args *a, const elo_mlp_args *b)
+{
+    MlpPlan p;
+    if (plan_mlp(a, b, &p, "elo_mlp_sv_parts")) return 0;
+    return p.sv_tiles;
+}
+
+extern "C" int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_stream_t stream)
+{
+    const char *who = "elo_mlp_fused";
+    MlpPlan plan;
+    if (int rc = plan_mlp(a, b, &plan, who)) return rc;
+    if (a->rows == 0)
+        return a->clear_scratch || a->sv_scratch ? fail(ELO_ERR_ARG, "%s: a clear_* / sv_* side job needs rows to ride on", who) : ELO_OK;
+    const int S = plan.S, mode = plan.mode;
+    const bool t16 = plan.t16;
+    const long u32 = (a->rows + 31) / 32, u16 = (a->rows + 15) / 16;
+    JobPair<elo_mlp_args> pair;
+    pair.job[0] = *a;
+    pair.job[1] = b ? *b : *a;
+    if (a->sv_scratch) {               // the launch also reduces its final rows to softmax_valid's partial sums (mlp_sv_kernel)
+        if (!plan.sv_tiles)
+            return fail(ELO_ERR_ARG, "%s: sv_scratch is set but this launch cannot compute softmax_valid's partial sums "
+                                     "(elo_mlp_sv_parts returns 0: chain-kernel regime, final width != 64, rows %% sv_npoints != 0 or too many tiles)", who);
+        if (!a->sv_xyz) return fail(ELO_ERR_ARG, "%s: sv_scratch without sv_xyz", who);
+        if ((b != nullptr) == (a->sv_feature != nullptr))
+            return fail(ELO_ERR_ARG, "%s: a paired launch takes its features from job b (sv_feature NULL), a single launch from sv_feature", who);
+        if (!b && ((uintptr_t)a->sv_feature & 15)) return fail(ELO_ERR_ARG, "%s: unaligned sv_feature", who);
+        const int tile = t16 ? 16 : 32, groups = b ? 2 : 1;
+        const size_t lds = sizeof(float) * ((size_t)groups * tile * S + (b ? 0 : (size_t)tile * 64));
+        const dim3 grid((unsigned)(a->rows / a->sv_npoints) * (unsigned)plan.sv_tiles);
+        hipStream_t s = (hipStream_t)stream;
+#define CALL_SV(T_, M_)                                                                                                         \
+        do {                                                                                                                    \
+            if (b) hipLaunchKernelGGL((mlp_sv_kernel<T_, M_, true>), grid, dim3(2 * FUSED_BLOCK), lds, s, pair, S, plan.sv_tiles); \
+            else hipLaunchKernelGGL((mlp_sv_kernel<T_, M_, false>), grid, dim3(FUSED_BLOCK), lds, s, pair, S, plan.sv_tiles);     \
+        } while (0)
+#define CALL_SV_T(M_) do { if (t16) CALL_SV(16, M_); else CALL_SV(32, M_); } while (0)
+        ELO_PICK_MODE(mode, CALL_SV_T);
+#undef CALL_SV_T
+#undef CALL_SV
+        ++g_sv_ride_launches;
+        return check_launch(who);
+    }
+    const size_t lds = tile_lds_bytes(t16 ? 16 : 32, S);
+#ifndef ELO_DENSE_F32
+    if (plan.chain) {
+        const int C = plan.C;
+        const dim3 rgrid((unsigned)((a->rows + RR_ROWS - 1) / RR_ROWS), b ? 2u : 1u);
+        const bool f16 = a->feat_dtype == ELO_F16;
+        hipStream_t rs = (hipStream_t)stream;
 #define RRM(C_)                                                                                                                      \
-            do {                                                                                                                    \
-                if (f16 && mode == MODE_HALF) hipLaunchKernelGGL((mlp2_rr_kernel<C_, true, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);             \
-                else if (f16) hipLaunchKernelGGL((mlp2_rr_kernel<C_, true, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);             \
-                else if (mode == MODE_HALF) hipLaunchKernelGGL((mlp2_rr_kernel<C_, false, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);                \
-                else hipLaunchKernelGGL((mlp2_rr_kernel<C_, false, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);                \
-            } while (0)
-            if (C == 16) RRM(16);
-            else if (C == 32) RRM(32);
-            else RRM(64);
+        do {                                                                                                                    \
+            if (f16 && mode == MODE_HALF) hipLaunchKernelGGL((mlp2_rr_kernel<C_, true, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);             \
+            else if (f16) hipLaunchKernelGGL((mlp2_rr_kernel<C_, true, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);             \
+            else if (mode == MODE_HALF) hipLaunchKernelGGL((mlp2_rr_kernel<C_, false, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);                \
+            else hipLaunchKernelGGL((mlp2_rr_kernel<C_, false, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, rs, pair);                \
+        } while (0)
+        if (C == 16) RRM(16);
+        else if (C == 32) RRM(32);
+        else RRM(64);
 #undef RRM
-            ++g_rr_launches[3];
-            return check_launch(who);
-        }
+        ++g_rr_launches[3];
+        return check_launch(who);
     }
 #endif
     const dim3 grid((unsigned)(t16 ? u16 : u32), b ? 2u : 1u);
@@ -3654,12 +3845,6 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
     return check_launch(who);
 }
 
-// KERNEL<TILE_CV, TILE_SC, MODE> for the heterogeneous launch
-#ifdef ELO_DENSE_F32
-#define ELO_PICK_MODE(M_, CALL_T) do { if ((M_) == MODE_CHECKED) CALL_T(MODE_CHECKED); else CALL_T(MODE_SPLIT); } while (0)
-#else
-#define ELO_PICK_MODE(M_, CALL_T) do { if ((M_) == MODE_HALF) CALL_T(MODE_HALF); else if ((M_) == MODE_CHECKED) CALL_T(MODE_CHECKED); else CALL_T(MODE_SPLIT); } while (0)
-#endif
 
 extern "C" int elo_cv_stage1_setconv_fused(const elo_cv1_args *a, const elo_setconv_args *ja, const elo_setconv_args *jb,
                                            elo_stream_t stream)

@@ -66,5 +66,5 @@ extern "C" int elo_set_tuning(const elo_tuning *in)
     return ELO_OK;
 }
 
-extern "C" int elo_abi_version(void) { return 20; }
+extern "C" int elo_abi_version(void) { return 21; }
 extern "C" const char *elo_last_error(void) { return elo::err_buf(); }

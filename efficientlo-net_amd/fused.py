@@ -403,11 +403,39 @@ def _ride_clear(a, clear, dt):
     clear.cleared = True
 
 
-def mlp(sources, layers, clear=None):
+def _ride_sv(a, b, sv, dt):
+    """elo_mlp_args.sv_*: the launch also reduces its final rows to softmax_valid's partial sums (sv: an _ops.SvPartials).
+    Returns True when the launch takes the ride (sv.parts is then the slice count), False when it cannot (chain-kernel regime,
+    shape): the pose head then runs its own partial-sums launch."""
+    if sv is None:
+        return False
+    B, N, _ = sv.xyz.shape
+    if a.rows != B * N:
+        raise ValueError("the SvPartials cloud (%d x %d points) does not match the MLP's %d rows" % (B, N, a.rows))
+    a.sv_npoints = N
+    parts = L.lib().elo_mlp_sv_parts(ctypes.byref(a), ctypes.byref(b) if b is not None else None)
+    if parts <= 0:
+        a.sv_npoints = 0
+        return False
+    a.sv_scratch, a.sv_xyz = sv.scratch.data_ptr(), sv.xyz.data_ptr()
+    if b is None:
+        feat = sv.feature
+        if feat is None or feat.shape != (B, N, 64) or feat.dtype != dt:
+            raise ValueError("a single launch takes its (B, N, 64) features of the MLP's storage dtype from SvPartials.feature")
+        sv.feature = feat = feat.contiguous()
+        a.sv_feature = feat.data_ptr()
+    sv.parts = parts
+    return True
+
+
+def mlp(sources, layers, clear=None, sv=None):
     """Row-wise MLP over concat(sources, -1) without building the concat.  sources: (..., C_i) tensors.
-    `clear`: ProjectionBuffers of a later projection, cleared on the side (for a pose head run with direct=True)."""
+    `clear`: ProjectionBuffers of a later projection, cleared on the side (for a pose head run with direct=True).
+    `sv`: an _ops.SvPartials (with .feature): the output are softmax_valid's logits and the launch also computes its partial
+    sums -- when it can (sv.parts > 0 afterwards); `clear` then rides only if it does."""
     a, out, _keep = _mlp_args(sources, layers)
-    _ride_clear(a, clear, out.dtype)
+    if _ride_sv(a, None, sv, out.dtype) or sv is None:
+        _ride_clear(a, clear, out.dtype)
     L.call("elo_mlp_fused", a, out)
     return out.reshape(sources[0].shape[:-1] + (layers[-1].N,))
 
@@ -434,14 +462,17 @@ def _mlp2_args(sources, layers, before, after, layers2):
     return a, out, out2, (keep, before, after, layers2)
 
 
-def mlp2_pair(job_a, job_b, clear=None):
+def mlp2_pair(job_a, job_b, clear=None, sv=None):
     """Two jobs of identical shape, each TWO chained row-wise MLPs, in ONE launch:
     out = layers(concat(sources)); out2 = layers2(concat(before, out, after)).  job: dict(sources, layers, before,
     after, layers2); layers2[0] is packed with `row_order=stage2_row_order(w_before, N, w_after)` (the kernel's columns
-    are [out | before | after]).  Returns ((out_a, out2_a), (out_b, out2_b))."""
+    are [out | before | after]).  Returns ((out_a, out2_a), (out_b, out2_b)).
+    `sv`: an _ops.SvPartials: out2_a are softmax_valid's logits, out2_b its features, and the launch also computes the partial
+    sums when it can (see mlp)."""
     a, out_a, out2_a, _ka = _mlp2_args(**job_a)
     b, out_b, out2_b, _kb = _mlp2_args(**job_b)
-    _ride_clear(a, clear, out_a.dtype)                            # (clear: as for mlp)
+    if _ride_sv(a, b, sv, out_a.dtype) or sv is None:
+        _ride_clear(a, clear, out_a.dtype)                        # (clear: as for mlp)
     L.call2("elo_mlp_fused2", a, b, out_a)
     lead = job_a["sources"][0].shape[:-1]
     shape = lambda t: t.reshape(lead + (t.shape[-1],))

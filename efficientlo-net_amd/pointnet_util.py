@@ -248,8 +248,10 @@ def _cost_volume_stage2(warped_xyz1_proj, points1_proj, pi_feat1_new, pc_idx, ma
 
 
 @_storage_boundary("points_f1", "upsampled_feat", "cost_volume")
-def flow_predictor(points_f1, upsampled_feat, cost_volume, mlp, is_training, bn_decay, scope, bn=True, clear=None):
-    """utils/pointnet_util.py:153-175: MLP over concat[points_f1, upsampled_feat?, cost_volume?] -> (B,N,mlp[-1])."""
+def flow_predictor(points_f1, upsampled_feat, cost_volume, mlp, is_training, bn_decay, scope, bn=True, clear=None, sv=None):
+    """utils/pointnet_util.py:153-175: MLP over concat[points_f1, upsampled_feat?, cost_volume?] -> (B,N,mlp[-1]).
+    `sv` (fused inference only): an _ops.SvPartials -- the output are softmax_valid's logits and the launch also leaves its
+    partial sums there (fused.mlp)."""
     with tf_util.variable_scope(scope):
         parts = [points_f1]
         if upsampled_feat is not None:
@@ -260,7 +262,7 @@ def flow_predictor(points_f1, upsampled_feat, cost_volume, mlp, is_training, bn_
             widths = [sum(p.shape[-1] for p in parts)] + list(mlp)
             layers = [fused.packed_layer('conv_predictor%d' % i, widths[i], widths[i + 1], bn=bn)
                       for i in range(len(mlp))]
-            return fused.mlp(parts, layers, clear=clear)                                          # one launch (clear: a side job)
+            return fused.mlp(parts, layers, clear=clear, sv=sv)                                   # one launch (clear, sv: side jobs)
         parts = [p.unsqueeze(2) for p in parts]                                                   # :166
         x = None
         for i, num_out_channel in enumerate(mlp):
@@ -359,8 +361,9 @@ def up_conv_stage1_jobs(up_a, up_b):
     return jobs
 
 
-def up_conv_predict_finish(up_a, up_b, fp_a, fp_b, up_a_pooled, up_b_pooled, clear=None):
-    """Stage 2 of both set-upconvs and the two flow predictors they feed, in ONE launch (see up_conv_predict_pair)."""
+def up_conv_predict_finish(up_a, up_b, fp_a, fp_b, up_a_pooled, up_b_pooled, clear=None, sv=None):
+    """Stage 2 of both set-upconvs and the two flow predictors they feed, in ONE launch (see up_conv_predict_pair).
+    `sv`: an _ops.SvPartials: predictor a's output are softmax_valid's logits, predictor b's its features (fused.mlp2_pair)."""
     stage2 = []
     for up, fp, pooled in ((up_a, fp_a, up_a_pooled), (up_b, fp_b, up_b_pooled)):
         P = fused.packed_layer
@@ -379,7 +382,7 @@ def up_conv_predict_finish(up_a, up_b, fp_a, fp_b, up_a_pooled, up_b_pooled, cle
                          row_order=fused.stage2_row_order(w_before, mlp2[-1], w_after) if i == 0 else None)
                        for i in range(len(fp["mlp"]))]
         stage2.append(dict(sources=[pooled, points1], layers=layers, before=before, after=after, layers2=layers2))
-    (out_a, pred_a), (out_b, pred_b) = fused.mlp2_pair(stage2[0], stage2[1], clear=clear)
+    (out_a, pred_a), (out_b, pred_b) = fused.mlp2_pair(stage2[0], stage2[1], clear=clear, sv=sv)
     return out_a, pred_a, out_b, pred_b
 
 

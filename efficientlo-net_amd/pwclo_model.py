@@ -190,7 +190,8 @@ def _pose_head(feat_b1c, level, coarse, is_training, raw=False):
     return (q if raw else _normalise_q(q)), t
 
 
-def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training, pose7=None, clear=None, warp=None, direct=False):
+def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training, pose7=None, clear=None, warp=None, direct=False,
+                   partials=None):
     """softmax_valid + pose head + composition with the coarse pose (q_coarse None at l3).
     Returns (q (B,4), t (B,3), q_norm (B,4)): the level's pose and its final normalisation (:427-430).
     Inference: two fused HIP launches (_ops.pose_head).  Training: the literal operator chain."""
@@ -204,7 +205,8 @@ def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training,
         # the l0 head is the last launch of a forward: in a graph captured with fresh_orders it also loads the NEXT replay's orders
         from . import perm
         nxt = perm.tail_refresh_args() if level == 0 else None
-        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7, clear, warp, nxt, direct)
+        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7, clear, warp, nxt, direct,
+                              partials)
     summed = softmax_valid(feature_bnc=predict, weight_bnc=weight, mask_valid=xyz)                  # :194 / :262
     if predict.is_cuda and pose7 is None:
         # the pose algebra of :206-208 / :271-280 in ONE launch forward and one backward (_ops.pose_compose; the literal chain
@@ -341,16 +343,24 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
         # eight lanes are in flight (10 200 -> 9 640 frame-pairs/s; one lane 3 290 -> 3 230).  DESIGN.md, round 3.
         return (inference and fused_pairs_available(is_training) and xyz_bn3.shape[1] <= _ops.L.POSE_DIRECT_MAX and
                 tuning.get("pose_direct"))
+    def sv_ride(xyz_bn3, feature=None):
+        # softmax_valid's partial sums ride on the launch that produces the pose head's inputs (tuning sv_ride; one launch less
+        # per level where that launch is a tile kernel: fused.mlp / fused.mlp2_pair decide)
+        if inference and fused_pairs_available(is_training) and tuning.get("sv_ride") and not direct_head(xyz_bn3):
+            return _ops.SvPartials(xyz_bn3, feature)
+        return None
     def next_warp(level):          # the cloud + features the NEXT warp moves: run by the pose head's own launches
         return (xyz_proj_f1[level].reshape(batch_size, -1, 3), pts_f1[level]) if inference else None
     next_buffers = projection_buffers(2, 4)
+    sv3 = sv_ride(l3_xyz_f1, l3_points_predict)
     l3_cost_volume_w = flow_predictor(pts_f1[3], None, l3_points_predict, mlp=[128, 64], is_training=is_training,
                                       bn_decay=bn_decay, scope='l3_costvolume_predict_ww',
-                                      clear=next_buffers if direct_head(l3_xyz_f1) else None)
+                                      clear=next_buffers if direct_head(l3_xyz_f1) or sv3 is not None else None,
+                                      **({"sv": sv3} if sv3 is not None else {}))
     l3_cost_volume_w_proj = l3_cost_volume_w.reshape(batch_size, out_h_list[5], out_w_list[5], -1)
     l3_q, l3_t, l3_q_norm = _estimate_pose(l3_points_predict, l3_cost_volume_w, l3_xyz_f1, 3, None, None,
                                            is_training, clear=next_buffers, warp=next_warp(2),
-                                           direct=direct_head(l3_xyz_f1))                           # :194-208
+                                           direct=direct_head(l3_xyz_f1), partials=sv3)             # :194-208
 
     # three warp-refinement levels (:211-425); one loop instead of three pasted blocks
     cv_kernel2 = {2: [5, 15], 1: [7, 25], 0: [11, 41]}                                              # :243,:317,:391
@@ -403,13 +413,15 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                 (up_w_pooled, _), (up_c_pooled, _) = fused.setconv_pair(jobs[0], jobs[1])
             fp = dict(points_f1=points_warp_f1, cost_volume=cost, mlp=[128, 64])
             # set-upconv stage 2 and the predictor it feeds share a launch
+            sv = sv_ride(xyz_warp_f1)
             w_up_sample, weight, cost_up_sample, predict = up_conv_predict_finish(
                 up_w, up_c, dict(fp, scope='l%d_w_predict' % level), dict(fp, scope='l%d_costvolume_predict' % level),
-                up_w_pooled, up_c_pooled, clear=next_buffers if direct_head(xyz_warp_f1) else None)
+                up_w_pooled, up_c_pooled, clear=next_buffers if direct_head(xyz_warp_f1) or sv is not None else None, sv=sv)
         else:
             # the cost volume and the two set-upconvs only share inputs: optional concurrent branches
             cost, w_up_sample, cost_up_sample = _parallel([branch_cost, lambda: branch_up('w', coarse_w_proj),
                                                            lambda: branch_up('costvolume', coarse_predict_proj)], is_training)
+            sv = None
             predict, weight = _parallel([
                 lambda: flow_predictor(points_warp_f1, cost_up_sample, cost, mlp=[128, 64], is_training=is_training,
                                        bn_decay=bn_decay, scope='l%d_costvolume_predict' % level),     # :253
@@ -419,7 +431,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                                                 is_training, pose_out if level == 0 else None,
                                                 clear=next_buffers,
                                                 warp=next_warp(level - 1) if level > 0 else None,
-                                                direct=direct_head(xyz_warp_f1))  # :262-280
+                                                direct=direct_head(xyz_warp_f1), partials=sv)  # :262-280
         poses[level] = (q_norm, t_prev)
 
         coarse_w_proj = weight.reshape(batch_size, out_h_list[g], out_w_list[g], -1)                # :256-257

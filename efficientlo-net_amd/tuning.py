@@ -38,6 +38,7 @@ _HOST = {
     "layer0_pre": ("ELO_LAYER0_PRE", _layer0, {}),                            # operator -> min channels: first layer through the gather (measured: does not pay)
     "merge_points": ("ELO_MERGE_POINTS", int, 8192),                          # heterogeneous cost-volume + set-conv launch up to this many centres
     "pose_direct": ("ELO_POSE_DIRECT", lambda v: v == "1", False),            # pose head reduces softmax_valid itself (one launch less)
+    "sv_ride": ("ELO_SV_RIDE", lambda v: v != "0", True),                     # softmax_valid's partial sums ride on the launch that produces its inputs (one launch less per level)
     "train_branches": ("ELO_TRAIN_BRANCHES", lambda v: v == "1", False),
     "train_kernels": ("ELO_TRAIN_KERNELS", lambda v: v != "0", True),
 }

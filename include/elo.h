@@ -248,8 +248,10 @@ int elo_perm_refresh(const elo_perm_refresh_args *a, elo_stream_t stream);
  * VALID points (xyz != (0,0,0)) per channel, out[b,0,c] = sum_n softmax*feature.
  * Two launches: `parts` blocks per batch element reduce slices of the point axis
  * with an online softmax, a second kernel merges the partials.
- * scratch: 3 * batch * ELO_SV_MAX_PARTS * C floats. */
-#define ELO_SV_MAX_PARTS 64
+ * scratch: 3 * batch * ELO_SV_MAX_PARTS * C floats, laid out (3, batch, ELO_SV_MAX_PARTS, C): [maximum | denominator |
+ * weighted sum] of slice `part` of batch element b (the partial launch writes at most 64 slices; a row-wise MLP launch that
+ * computes the partial sums itself -- elo_mlp_args.sv_* -- one slice per row tile, up to ELO_SV_MAX_PARTS). */
+#define ELO_SV_MAX_PARTS 512
 typedef struct elo_softmax_valid_args {
     int batch, npoints, C;
     const float *feature;         /* (batch,npoints,C) */
@@ -310,6 +312,11 @@ typedef struct elo_pose_head_args {
      * by this call -- the caller has had an earlier launch do it (elo_mlp_args.clear_*: the launch that produces
      * `feature` / `weight`); with elo_pose_head_warp they still name the warp's buffers. */
     int direct;
+    /* ready_parts > 0: the partial sums of softmax_valid are ALREADY in `scratch`, ready_parts slices per batch element, written
+     * by the launch that produced `feature` / `weight` (elo_mlp_fused / elo_mlp_fused2 with sv_scratch == scratch;
+     * elo_mlp_sv_parts gives the count): no partial-sums launch here -- one launch less per pyramid level.  As with `direct`
+     * the clear_* buffers are then not cleared by this call (elo_mlp_args.clear_* did it).  Not together with `direct`. */
+    int ready_parts;
 } elo_pose_head_args;
 #define ELO_POSE_DIRECT_MAX 1024
 int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream);
@@ -722,10 +729,27 @@ typedef struct elo_mlp_args {
      * register-resident kernel for every launch of 2048 rows or more (the GPU is full: a kernel costs its CU-time), below
      * that only from 8192 rows (a forward is a latency chain there and the tile kernel is faster). */
     int batch_hint;
+    /* Optional (sv_scratch != NULL, the first job of a launch): the launch ALSO computes the first half of softmax_valid
+     * (model_util.py:319-343) over its final output -- per row tile and channel the (maximum, denominator, weighted sum) triple
+     * of the masked softmax over the tile's points, in elo_softmax_valid's scratch layout -- so the pose head that follows needs
+     * no partial-sums launch (elo_pose_head_args.ready_parts = elo_mlp_sv_parts(a, b)).  The final output (out2, or out of a
+     * one-stage MLP) must be 64 wide.
+     *   paired launch (elo_mlp_fused2):  job a's final output are the LOGITS (`weight`), job b's the FEATURES; sv_feature NULL;
+     *   single launch (elo_mlp_fused):   the final output are the logits, the features are sv_feature.
+     * Rows are (batch, sv_npoints): a row tile never straddles two batch elements.  Taken by the tile kernel only: call
+     * elo_mlp_sv_parts first -- 0 means this launch would run as a register-resident chain (or has another shape) and the
+     * sv_* fields must stay NULL. */
+    float *sv_scratch;            /* 3 * batch * ELO_SV_MAX_PARTS * 64 floats */
+    const float *sv_xyz;          /* (batch, sv_npoints, 3): a row is a valid point unless all three are exactly 0 */
+    const void *sv_feature;       /* single launch: (rows, 64) feat_dtype; paired launch: NULL */
+    int sv_npoints;               /* rows per batch element (rows % sv_npoints == 0) */
 } elo_mlp_args;
 #define ELO_THROUGHPUT_BATCH 4
 int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream);
 int elo_mlp_fused2(const elo_mlp_args *a, const elo_mlp_args *b, elo_stream_t stream);   /* paired launch, as above */
+/* Slices per batch element the launch (a, b) -- b NULL: a single launch -- would write with sv_scratch set (the sv_* fields
+ * of `a` need not be filled yet, sv_npoints must be); 0: it cannot (chain-kernel regime, shape, more than ELO_SV_MAX_PARTS tiles). */
+int elo_mlp_sv_parts(const elo_mlp_args *a, const elo_mlp_args *b);
 
 /* Attentive cost volume, stage 1 (utils/pointnet_util.py:54-100) in one launch:
  * encode -> CV_0..2 -> CV_xyz -> sum_CV_0..1 -> masked softmax over K -> weighted sum.
@@ -766,6 +790,7 @@ int elo_debug_cv1_rr(int on);
 int elo_debug_rr_rows(long setconv_rows, long mlp_rows);
 int elo_debug_rr_launches(unsigned long long *counts4, int reset);
 int elo_debug_rowlinear_launches(unsigned long long *count, int reset);   /* ... and of rowlinear_rr_kernel (elo_rowlinear_fused2) */
+int elo_debug_sv_ride_launches(unsigned long long *count, int reset);     /* ... and of mlp_sv_kernel (elo_mlp_args.sv_*) */
 /* the two narrow set-conv layers of the pyramid (6 -> 8 -> 8 -> 16 and 19 -> 16 -> 16 -> 32, K = 32; elo_setconv_fused with
  * elo_dense.w_plain given): 1 = setconv_narrow_kernel, the MLP on the matrix cores, for the 19-channel layer (the default;
  * also ELO_SETCONV_NARROW_MFMA), 2 = for both layers (the 6-channel one is slower that way: measured), 0 =

@@ -237,7 +237,10 @@ def test_chain_kernels_leave_a_batch8_forward_unchanged(kernel_path, products, f
     f1, f2 = synth.frame_pair(8, 64, 1800, seed=43)
     a, b = torch.from_numpy(f1).to(DEV), torch.from_numpy(f2).to(DEV)
     dt = torch.float16 if features == "f16" else torch.float32
-    with fused.products(products):
+    # (sv_ride off: with the chain kernels switched off the row-wise MLP launches are tile kernels again and would take
+    #  softmax_valid's partial sums along -- per 16-row tile instead of per 64-row slice: another summation order, not a kernel
+    #  under test here; tests/test_sv_ride_gpu.py)
+    with fused.products(products), load_pkg("tuning").override(sv_ride=False):
         net = model.PWCLONet(DEV, seed=5, perm_source=perm.PermSource(fn=shuffle_fn), feature_dtype=dt)
         with fused.recording() as rec:
             chain = [x.clone() for x in net.forward(a, b)[:8]]

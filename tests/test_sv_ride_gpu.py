@@ -1,0 +1,174 @@
+"""GPU: softmax_valid's partial sums riding on the launch that produces the pose head's inputs (elo_mlp_args.sv_*,
+mlp_sv_kernel; elo_pose_head_args.ready_parts).  The row-wise MLP outputs must be the bits of the plain launch, the pose
+must equal the oracle's softmax_valid -> pose head -> composition (model_util.py:319-343, pwclo_model.py:262-280) on those
+outputs and the two-launch form to summation order; launch counters prove which kernel ran."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg
+from oracle import ops_np as O
+from util_params import close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _rides(reset=False):
+    lib = load_pkg("_lib")
+    n = ctypes.c_ulonglong(0)
+    lib.check(lib.lib().elo_debug_sv_ride_launches(ctypes.byref(n), 1 if reset else 0))
+    return n.value
+
+
+def _head(rng, level=1):
+    names = ("l%d_big", "l%d_q_det", "l%d_t_det")
+    params = {}
+    for n, s in zip(names, ((64, 256), (256, 4), (256, 3))):
+        params[n % level + "/weights"] = rng.normal(0, 0.1, s).astype(np.float32)
+        params[n % level + "/biases"] = rng.normal(0, 0.1, s[1:]).astype(np.float32)
+    order = [n % level + k for n in names for k in ("/weights", "/biases")]
+    return params, [t(params[k]) for k in order]
+
+
+def _cloud(rng, B, N, empty_element):
+    xyz = rng.normal(0, 5, (B, N, 3)).astype(np.float32)
+    xyz[rng.random((B, N)) < 0.2] = 0
+    if empty_element and B > 1:
+        xyz[B - 1] = 0                                   # a batch element without any valid point
+    return xyz
+
+
+def _want(params, f, w, xyz, q_c, t_c, level=1):
+    pooled = O.softmax_valid(f, w, ~np.all(xyz == 0, -1))
+    q_det, t_det = O.pose_head(params, pooled, level, False)
+    return O.compose(q_det, t_det, q_c, t_c)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("B,N,C", [(1, 228, 64), (1, 904, 32), (1, 3600, 16), (2, 450, 32), (3, 57, 64)])
+def test_paired_two_stage_mlp_leaves_softmax_valids_partial_sums(B, N, C, dt):
+    """A refinement level's tail: set-upconv stage 2 + predictor of the embedding-mask (job a: the logits) and the embedding
+    (job b: the features) branch in ONE 512-thread launch, two 4-wave groups side by side, plus the per-tile triples."""
+    fused, tf_util, ops = load_pkg("fused"), load_pkg("tf_util"), load_pkg("_ops")
+    rng = np.random.default_rng(B * 1000 + N)
+    store = tf_util.VariableStore(DEV, seed=N)
+    r = lambda *s: t(rng.normal(0, 1, s).astype(np.float32)).to(dt)
+
+    def job(tag):
+        with tf_util.default_store(store), torch.no_grad(), tf_util.variable_scope("sv_ride_%s" % tag):
+            P = fused.packed_layer
+            layers = [P("a0", 64 + C, 128), P("a1", 128, 64)]
+            layers2 = [P("b0", C + 64 + 64, 128, row_order=fused.stage2_row_order(C, 64, 64)), P("b1", 128, 64)]
+            for p_ in layers + layers2:
+                p_.b.copy_(torch.from_numpy(rng.normal(0, 0.1, p_.b.shape).astype(np.float32)))
+        return dict(sources=[r(B, N, 64), r(B, N, C)], layers=layers, before=r(B, N, C), after=r(B, N, 64), layers2=layers2)
+    ja, jb = job("w"), job("c")
+    xyz = _cloud(rng, B, N, empty_element=True)
+    params, head = _head(rng)
+    q_c = O.normalise_q(rng.normal(0, 1, (B, 1, 4)).astype(np.float32))
+    t_c = rng.normal(0, 1, (B, 1, 3)).astype(np.float32)
+    kw = dict(q_coarse=t(q_c), t_coarse=t(t_c))
+
+    (o1a, weight), (o1b, predict) = fused.mlp2_pair(ja, jb)                       # the plain paired launch
+    _rides(reset=True)
+    sv = ops.SvPartials(t(xyz))
+    H, W, Cf = 8, 29, 16
+    buf = ops.ProjectionBuffers(B, H * W, H, W, Cf, DEV, dt)
+    buf.out_xyz.fill_(float("nan")); buf.out_feat.fill_(3.0); buf.scratch.fill_(-1)
+    (r1a, r_weight), (r1b, r_predict) = fused.mlp2_pair(ja, jb, clear=buf, sv=sv)
+    assert _rides() == 1 and sv.parts == -(-N // 16) and buf.cleared
+    for got, want in ((r1a, o1a), (r_weight, weight), (r1b, o1b), (r_predict, predict)):
+        assert torch.equal(got, want)                                             # same layers, same order: same bits
+
+    two = ops.pose_head(predict, weight, t(xyz), *head, **kw)                      # partial-sums launch + head
+    pc, pf = r(B, H * W, 3) * 8, r(B, H * W, Cf)
+    one = ops.pose_head(r_predict, r_weight, t(xyz), *head, clear=buf, warp=(pc.float(), pf), partials=sv, **kw)
+    want_q, want_t = _want(params, predict.float().cpu().numpy(), weight.float().cpu().numpy(), xyz, q_c, t_c)
+    for got, ref, want in zip(one, two, (want_q, want_t, O.normalise_q(want_q))):
+        close(got, want, atol=2e-5, rtol=1e-4)                                     # the oracle on the stored rows
+        close(got, ref.cpu().numpy(), atol=2e-6, rtol=1e-5)                        # the two-launch form: summation order only
+    # the projection the head ran inside its launch on the buffers the MLP launch cleared = the stand-alone one
+    want_proj = ops.warp_project(pc.float(), pf, one[0], one[1], H, W)
+    got = ops.warp_project(pc.float(), pf, one[0], one[1], H, W, buffers=buf)
+    assert torch.equal(got[0], want_proj[0]) and torch.equal(got[1], want_proj[1])
+    assert torch.allclose(got[2].float(), want_proj[2].float(), atol=1e-3 if dt == torch.float16 else 1e-4)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("B,N", [(1, 58), (2, 58), (1, 512)])
+def test_single_mlp_leaves_softmax_valids_partial_sums(B, N, dt):
+    """The coarse level: the predictor's output are the logits, the features are an existing tensor (SvPartials.feature)."""
+    fused, tf_util, ops = load_pkg("fused"), load_pkg("tf_util"), load_pkg("_ops")
+    rng = np.random.default_rng(N + B)
+    store = tf_util.VariableStore(DEV, seed=N)
+    r = lambda *s: t(rng.normal(0, 1, s).astype(np.float32)).to(dt)
+    with tf_util.default_store(store), torch.no_grad(), tf_util.variable_scope("sv_ride_single"):
+        layers = [fused.packed_layer("p0", 128 + 64, 128), fused.packed_layer("p1", 128, 64)]
+    srcs = [r(B, N, 128), r(B, N, 64)]
+    feature = srcs[1]
+    xyz = _cloud(rng, B, N, empty_element=False)
+    params, head = _head(rng, level=3)
+    weight = fused.mlp(srcs, layers)
+    _rides(reset=True)
+    sv = ops.SvPartials(t(xyz), feature)
+    r_weight = fused.mlp(srcs, layers, sv=sv)
+    assert _rides() == 1 and sv.parts == -(-N // 16) and torch.equal(r_weight, weight)
+    two = ops.pose_head(feature, weight, t(xyz), *head)
+    one = ops.pose_head(feature, r_weight, t(xyz), *head, partials=sv)
+    pooled = O.softmax_valid(feature.float().cpu().numpy(), weight.float().cpu().numpy(), ~np.all(xyz == 0, -1))
+    names = {"l3_q_coarse": "l3_q_det", "l3_t_coarse": "l3_t_det"}
+    coarse_params = dict(params, **{k.replace(v, c): params[k] for c, v in names.items() for k in list(params) if k.startswith(v)})
+    q_det, t_det = O.pose_head(coarse_params, pooled, 3, True)
+    for got, ref, want in zip(one, two, (q_det[:, 0], t_det[:, 0], O.normalise_q(q_det[:, 0]))):
+        close(got, want, atol=2e-5, rtol=1e-4)
+        close(got, ref.cpu().numpy(), atol=2e-6, rtol=1e-5)
+
+
+def test_the_ride_is_refused_where_it_cannot_be_taken():
+    """elo_mlp_sv_parts == 0 (a 32-wide final layer; the register-resident chain regime): fused.mlp* leave sv.parts at 0 and do
+    NOT clear on the side, so the pose head runs its own partial-sums launch; sv_* set by hand on such a launch is an error."""
+    fused, tf_util, ops, lib = load_pkg("fused"), load_pkg("tf_util"), load_pkg("_ops"), load_pkg("_lib")
+    rng = np.random.default_rng(5)
+    store = tf_util.VariableStore(DEV, seed=5)
+    r = lambda *s: t(rng.normal(0, 1, s).astype(np.float32))
+    with tf_util.default_store(store), torch.no_grad(), tf_util.variable_scope("sv_ride_refused"):
+        layers = [fused.packed_layer("p0", 64, 32)]
+    B, N = 1, 100
+    sv = ops.SvPartials(t(_cloud(rng, B, N, False)), r(B, N, 64))
+    buf = ops.ProjectionBuffers(B, 4 * 5, 4, 5, 0, DEV)
+    _rides(reset=True)
+    fused.mlp([r(B, N, 64)], layers, clear=buf, sv=sv)
+    assert _rides() == 0 and sv.parts == 0 and not buf.cleared
+    a, _out, _keep = fused._mlp_args([r(B, N, 64)], layers)
+    a.sv_npoints, a.sv_scratch, a.sv_xyz, a.sv_feature = N, sv.scratch.data_ptr(), sv.xyz.data_ptr(), sv.feature.data_ptr()
+    with pytest.raises(lib.EloError, match="elo_mlp_sv_parts returns 0"):
+        lib.call("elo_mlp_fused", a, sv.scratch)
+
+
+@pytest.mark.parametrize("feat", [torch.float32, torch.float16])
+def test_a_forward_with_the_ride_equals_the_forward_without(feat):
+    """Whole pyramid at batch 1, 64 x 1800: four launches less (one per level).  The coarse pose agrees to summation order;
+    the refinement levels follow it through DISCRETE decisions (a warped point's projection cell, a neighbour entering a
+    window: tests/test_parity_flips_gpu.py), so they are held to a loose bound here -- their parity against the oracle,
+    level by level on the same coarse poses, is tests/test_model_gpu.py's (which runs with the ride on: the default)."""
+    from util_params import randomise, shuffle_fn
+    model, synth, tuning, perm = load_pkg("model"), load_pkg("synth"), load_pkg("tuning"), load_pkg("perm")
+    f1, f2 = synth.frame_pair(1, 64, 1800, seed=3)
+    both = torch.from_numpy(np.concatenate([f1, f2], 0)).to(DEV)
+    net = model.PWCLONet(DEV, seed=5, perm_source=perm.PermSource(fn=shuffle_fn), feature_dtype=feat)
+    net.forward(both[:1], both[1:])
+    randomise(net.store, seed=7)
+    outs = {}
+    for ride in (True, False):
+        with tuning.override(sv_ride=ride):
+            _rides(reset=True)
+            outs[ride] = [x.clone() for x in net.forward(both[:1], both[1:])[:8]]
+            assert _rides() == (4 if ride else 0)
+    for i, (a, b) in enumerate(zip(outs[True], outs[False])):
+        assert torch.isfinite(a).all()
+        tight = i >= 6                                       # (l3_q, l3_t)
+        assert torch.allclose(a, b, atol=2e-5 if tight else 2e-2, rtol=1e-4), (i, a, b)
