@@ -26,7 +26,7 @@ int check_launch(const char *what)
 }
 
 static const elo_tuning kDefaults = {/*chain_forms*/ 1, /*narrow_mfma*/ 1, /*range_check*/ 0, /*select_dense_waves*/ 0, /*random_dense_rows*/ 0,
-                                     /*encode1_slots*/ 0, /*setconv_chain_rows*/ -1, /*mlp_chain_rows*/ -1, /*small_tile_units*/ 512,
+                                     /*encode1_slots*/ 0, /*setconv_chain_rows*/ -1, /*mlp_chain_rows*/ -1, /*small_tile_units*/ 64,
                                      /*tiled_setconv*/ 0};
 elo_tuning &tuning()            // what the launchers read: elo_set_tuning's value with the elo_debug_* overrides on top
 {

@@ -46,7 +46,7 @@ _HOST = {
 _LIB = {
     "chain_forms": ("ELO_CV1_RR", 1), "narrow_mfma": ("ELO_SETCONV_NARROW_MFMA", 1), "range_check": ("ELO_RANGE_CHECK", 0),
     "select_dense_waves": ("ELO_SELECT_DENSE_WAVES", 0), "random_dense_rows": ("ELO_DENSE_ROWS", 0), "encode1_slots": ("ELO_ENCODE1_SLOTS", 0),
-    "setconv_chain_rows": ("ELO_SETCONV_RR_ROWS", -1), "mlp_chain_rows": ("ELO_MLP_RR_ROWS", -1), "small_tile_units": ("ELO_SMALL_TILE_UNITS", 512),
+    "setconv_chain_rows": ("ELO_SETCONV_RR_ROWS", -1), "mlp_chain_rows": ("ELO_MLP_RR_ROWS", -1), "small_tile_units": ("ELO_SMALL_TILE_UNITS", 64),
     "tiled_setconv": ("ELO_TILED_SETCONV", 0),
 }
 

@@ -60,7 +60,7 @@ typedef struct elo_tuning {
     long setconv_chain_rows;    /* rows per launch from which elo_setconv_fused2 takes the chain form; -1: 20 000 from batch
                                    ELO_THROUGHPUT_BATCH on, 100 000 below                                          [ELO_SETCONV_RR_ROWS]     */
     long mlp_chain_rows;        /* ... elo_mlp_fused2; -1: 2048 / 8192                                            [ELO_MLP_RR_ROWS]         */
-    long small_tile_units;      /* 16-row tiles while 32-row tiles would give fewer workgroups than this (512)     [ELO_SMALL_TILE_UNITS]    */
+    long small_tile_units;      /* 16-row tiles while 32-row tiles would give fewer workgroups than this (64)      [ELO_SMALL_TILE_UNITS]    */
     int tiled_setconv;          /* narrow set-conv layers with structured centres on the LDS-staged window tile: 0 off (default:
                                    measured slower, profiles/r05_ab_tiled.txt), 1 the 6 -> 8 -> 8 -> 16 layer, 2 also the
                                    19 -> 16 -> 16 -> 32 layer                                                      [ELO_TILED_SETCONV]       */
