@@ -3311,7 +3311,8 @@ extern "C" int elo_debug_rr_rows(long setconv_rows, long mlp_rows)
 static long setconv_rr_rows(int batch)
 {
     const long t = tuning().setconv_chain_rows;
-    return t >= 0 ? t : batch >= ELO_THROUGHPUT_BATCH ? 20000L : 100000L;
+    (void)batch;                                   // (below ELO_THROUGHPUT_BATCH: 100000 until round 5 -- profiles/r05_batch1_regimes.txt)
+    return t >= 0 ? t : 20000L;
 }
 static long mlp_rr_rows(int batch_hint)
 {

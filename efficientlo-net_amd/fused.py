@@ -489,12 +489,14 @@ def _prepass_rows(stage=1, batch=1):
     grouping.  Two regimes, measured with 8 lanes and fp16 features (pairs/s, tile-kernel thresholds against chain-kernel
     thresholds): batch 1 10 320 / 9 760 and batch 2 14 520 / 14 310 -- a forward is a latency chain, the tile kernels (with
     the set-upconv riders of their level, and no extra launch) are faster, so only the largest launches take the chain
-    (stage 1 from 24 576 rows, stage 2 from 65 536); batch 4 19 520 / 21 330 and batch 8 24 040 / 25 450 -- the GPU is full, a
+    (stage 1 from 20 000 rows -- 24 576 until round 5: with four forwards in flight l0 of a 64 x 1800 pair, 21 600 rows, is
+    faster on the chain kernel next to an unmerged set-upconv chain launch, 11.2 -> 11.7 k pairs/s, profiles/r05_batch1_regimes.txt
+    -- stage 2 from 65 536); batch 4 19 520 / 21 330 and batch 8 24 040 / 25 450 -- the GPU is full, a
     kernel costs its CU-time, and every level takes the chain (from 8192 rows; the same switch sits in elo_setconv_fused2 and
     elo_mlp_fused2).  tuning `cv_prepass` (ELO_CV_PREPASS): 0 = never, 1 = always, N = from N rows on (both stages, any batch)."""
     e = tuning.get("cv_prepass")
     if e is None:
-        return 8192 if batch >= THROUGHPUT_BATCH else (24576 if stage == 1 else 65536)
+        return 8192 if batch >= THROUGHPUT_BATCH else (20000 if stage == 1 else 65536)
     return (1 << 60) if e == 0 else 0 if e == 1 else int(e)
 
 

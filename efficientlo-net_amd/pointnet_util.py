@@ -282,13 +282,18 @@ def fused_pairs_available(is_training):
 # Branches that only share inputs ride on ONE heterogeneous launch (fused.cv_stage1(side=...)) while the GPU is
 # underfilled: measured at 64x1800 (8 lanes) batch 1 8770 -> 9290 pairs/s, one lane 2700 -> 3020; at batch 8 the merged
 # grid is slower (15 800 -> 15 200: the set-conv tiles run at the cost-volume kernel's register / LDS footprint), so
-# the merge is taken -- for ALL levels of a forward or for none -- up to this many centre points at the finest level (batch x
-# H x W of l0).  End of round 2 (pairs/s, 8 lanes; none / levels under the threshold / all): batch 2 13 330 / 13 940 / 14 090,
-# batch 4 16 650 / 15 990 / 16 530, batch 8 18 170 / 18 150 / 17 790: merging SOME levels is the worst choice at batch 4.
+# the merge is taken only in forwards of up to `merge_points` centre points at the finest level (batch x H x W of l0; end of
+# round 2, pairs/s at 8 lanes, none / levels under the threshold / all: batch 2 13 330 / 13 940 / 14 090, batch 4 16 650 /
+# 15 990 / 16 530, batch 8 18 170 / 18 150 / 17 790) -- and, since round 5, there only at the LEVELS of up to
+# `merge_level_points` centre points: with the register-resident kernels of rounds 3-4 a level whose merged grid would not
+# fit the GPU at once (l0 of a 64 x 1800 pair: 2520 workgroups on 1280 slots) is faster as a cost-volume chain launch + a
+# set-conv chain launch, once four forwards are in flight (batch 1, 8 lanes: 11.14 -> 11.74 k pairs/s with l0 unmerged and on
+# the chain kernels; one lane alone 3.55 -> 3.46 k: profiles/r05_batch1_regimes.txt).
 
 
-def merge_branches(is_training, points):
-    return _fused_path(is_training) and points <= tuning.get("merge_points")
+def merge_branches(is_training, finest_points, level_points=0):
+    return (_fused_path(is_training) and finest_points <= tuning.get("merge_points") and
+            level_points <= tuning.get("merge_level_points"))
 
 
 def flow_predictor_pair(call_a, call_b):

@@ -239,7 +239,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
     out_h_list, out_w_list = pyramid_sizes(H_input, W_input)
 
     zero_features = _zero_features                                                                  # :69-70
-    # one decision per forward (pointnet_util.merge_branches): merging some levels and not others measured worst
+    # (pointnet_util.merge_branches: a forward small enough to merge at all, then level by level)
     finest_points = batch_size * out_h_list[2] * out_w_list[2]
 
     # strided centre grids (:88-114).  Only the index tensors matter: down_conv re-gathers the xyz itself.
@@ -264,7 +264,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
                                            kernel_size=[5, 9], distance=Down_conv_dis[2], mlp=[32, 32, 64], mlp2=None,
                                            flag_add=False, is_training=is_training, bn_decay=bn_decay, scope='layer2')
         l2_points_proj = l2_points.reshape(batch_size, out_h_list[4], out_w_list[4], -1)
-        if merge_branches(is_training, finest_points):
+        if merge_branches(is_training, finest_points, batch_size * out_h_list[4] * out_w_list[4]):
             # inference: the layer-3 set-conv is only needed at the coarse pose (:187-194); it rides on the first launch of
             # the initial cost volume (:170), which only shares its inputs -- one launch and one serial stage less
             deferred.append(down_conv_job(l2_xyz_proj, l2_points_proj, l3_selected_idx, K_sample=16, kernel_size=[5, 9],
@@ -406,7 +406,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
             # ONE launch runs cost-volume stage 1 and both set-conv jobs (both branches in flight together, one launch
             # boundary less); a full GPU takes them as two launches
             jobs = up_conv_stage1_jobs(up_w, up_c)
-            if merge_branches(is_training, finest_points):
+            if merge_branches(is_training, finest_points, batch_size * out_h_list[g] * out_w_list[g]):
                 cost, ((up_w_pooled, _), (up_c_pooled, _)) = branch_cost(side_jobs=jobs)
             else:
                 cost = branch_cost()

@@ -36,7 +36,8 @@ _HOST = {
     "cv_prepass": ("ELO_CV_PREPASS", _prepass, None),                         # None: the batch regimes; 0 never, 1 always, N from N rows on
     "select_dense_tiles": ("ELO_SELECT_DENSE_TILES", int, 1024),              # select-k pre-pass: LDS-tiled form from this many 64-centre tiles
     "layer0_pre": ("ELO_LAYER0_PRE", _layer0, {}),                            # operator -> min channels: first layer through the gather (measured: does not pay)
-    "merge_points": ("ELO_MERGE_POINTS", int, 8192),                          # heterogeneous cost-volume + set-conv launch up to this many centres
+    "merge_points": ("ELO_MERGE_POINTS", int, 8192),                          # heterogeneous cost-volume + set-conv launches in forwards of up to this many l0 centres ...
+    "merge_level_points": ("ELO_MERGE_LEVEL_POINTS", int, 2000),              # ... at the levels of up to this many centres
     "pose_direct": ("ELO_POSE_DIRECT", lambda v: v == "1", False),            # pose head reduces softmax_valid itself (one launch less)
     "sv_ride": ("ELO_SV_RIDE", lambda v: v != "0", True),                     # softmax_valid's partial sums ride on the launch that produces its inputs (one launch less per level)
     "train_branches": ("ELO_TRAIN_BRANCHES", lambda v: v == "1", False),

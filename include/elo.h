@@ -57,8 +57,8 @@ typedef struct elo_tuning {
     int select_dense_waves;     /* elo_fused_conv_select_k_dense: 4 / 8 / 16 waves per tile, 0 = by grid size     [ELO_SELECT_DENSE_WAVES]  */
     int random_dense_rows;      /* elo_fused_conv_random_k_dense: 2 / 4 rows per tile, 0 = by grid size            [ELO_DENSE_ROWS]          */
     int encode1_slots;          /* elo_cv_encode1: 1 = the slot-indexed kernel also where the column-owner form tiles [ELO_ENCODE1_SLOTS]    */
-    long setconv_chain_rows;    /* rows per launch from which elo_setconv_fused2 takes the chain form; -1: 20 000 from batch
-                                   ELO_THROUGHPUT_BATCH on, 100 000 below                                          [ELO_SETCONV_RR_ROWS]     */
+    long setconv_chain_rows;    /* rows per launch from which elo_setconv_fused2 takes the chain form; -1: 20 000 (below batch
+                                   ELO_THROUGHPUT_BATCH: 100 000 until round 5)                                    [ELO_SETCONV_RR_ROWS]     */
     long mlp_chain_rows;        /* ... elo_mlp_fused2; -1: 2048 / 8192                                            [ELO_MLP_RR_ROWS]         */
     long small_tile_units;      /* 16-row tiles while 32-row tiles would give fewer workgroups than this (64)      [ELO_SMALL_TILE_UNITS]    */
     int tiled_setconv;          /* narrow set-conv layers with structured centres on the LDS-staged window tile: 0 off (default:

@@ -24,6 +24,14 @@ def _rides(reset=False):
     return n.value
 
 
+def _tiles(B, N, jobs):
+    """Row tiles per batch element of a launch over B x N rows (elo_tuning.small_tile_units: 16-row tiles while 32-row tiles would
+    give fewer workgroups than that)."""
+    units = -(-B * N // 32) * jobs
+    tile = 16 if units < load_pkg("_lib").get_tuning()["small_tile_units"] else 32
+    return -(-N // tile)
+
+
 def _head(rng, level=1):
     names = ("l%d_big", "l%d_q_det", "l%d_t_det")
     params = {}
@@ -80,7 +88,7 @@ def test_paired_two_stage_mlp_leaves_softmax_valids_partial_sums(B, N, C, dt):
     buf = ops.ProjectionBuffers(B, H * W, H, W, Cf, DEV, dt)
     buf.out_xyz.fill_(float("nan")); buf.out_feat.fill_(3.0); buf.scratch.fill_(-1)
     (r1a, r_weight), (r1b, r_predict) = fused.mlp2_pair(ja, jb, clear=buf, sv=sv)
-    assert _rides() == 1 and sv.parts == -(-N // 16) and buf.cleared
+    assert _rides() == 1 and sv.parts == _tiles(B, N, 2) and buf.cleared
     for got, want in ((r1a, o1a), (r_weight, weight), (r1b, o1b), (r_predict, predict)):
         assert torch.equal(got, want)                                             # same layers, same order: same bits
 
@@ -116,7 +124,7 @@ def test_single_mlp_leaves_softmax_valids_partial_sums(B, N, dt):
     _rides(reset=True)
     sv = ops.SvPartials(t(xyz), feature)
     r_weight = fused.mlp(srcs, layers, sv=sv)
-    assert _rides() == 1 and sv.parts == -(-N // 16) and torch.equal(r_weight, weight)
+    assert _rides() == 1 and sv.parts == _tiles(B, N, 1) and torch.equal(r_weight, weight)
     two = ops.pose_head(feature, weight, t(xyz), *head)
     one = ops.pose_head(feature, r_weight, t(xyz), *head, partials=sv)
     pooled = O.softmax_valid(feature.float().cpu().numpy(), weight.float().cpu().numpy(), ~np.all(xyz == 0, -1))
