@@ -214,13 +214,20 @@ def _live_traffic(batch, features, timeout=150):
                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
             except (subprocess.SubprocessError, OSError) as e:
                 return None, "%s pass failed: %s" % (counter, type(e).__name__)
-            vals = []
+            # the stage's launches: the tile kernel (in-kernel grouping), or the select-k pre-pass + the register-resident kernel
+            vals = {"cv1_kernel": [], "cv1_rr_kernel": [], "group_select_k": []}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                vals += [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-                         if r.get("Counter_Name") == counter and ("cv1_kernel" in r.get("Kernel_Name", "") or "cv1_rr_kernel" in r.get("Kernel_Name", ""))]
-            if len(vals) < 20:
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") != counter:
+                        continue
+                    for key in vals:
+                        if key in r.get("Kernel_Name", ""):
+                            vals[key].append(float(r["Counter_Value"]))
+            chain = len(vals["cv1_rr_kernel"]) >= 20
+            groups = [vals["cv1_rr_kernel"], vals["group_select_k"]] if chain else [vals["cv1_kernel"]]
+            if any(len(g) < 20 for g in groups):
                 return None, "%s pass: no cv1 launches in the counter file" % counter
-            got[counter] = sum(vals[-20:]) / 20                    # the last 20 of the 25 repeats (the recording forwards come first)
+            got[counter] = sum(sum(g[-20:]) / 20 for g in groups)   # the last 20 of the 25 repeats (the recording forwards come first)
     finally:
         shutil.rmtree(work, ignore_errors=True)
     return int((2 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024), (
@@ -372,8 +379,10 @@ def per_operator_leg(dev, batch, half, reps=20, level="l0", table=None):
 
 
 def roofline_leg(args, dev, net, reps=50):
-    """Primary object: the dominant kernel of the timed path -- the fused cost-volume stage 1 at l0 (`cv1_kernel`: in-kernel
-    select-k grouping + gather/encode + six 1x1 convolutions + masked softmax pooling) at the timed batch -- with
+    """Primary object: the dominant cost-volume launch of the timed path -- the fused cost-volume stage 1 at l0, in the form the
+    forward runs it (fused.cv_stage1's own switch): from 20 000 rows per launch the select-k pre-pass + `cv1_rr_kernel` (batch 1
+    of a 64 x 1800 pair since round 5), below that `cv1_kernel` (in-kernel select-k grouping + gather/encode + six 1x1
+    convolutions + masked softmax pooling) -- at the timed batch, with
     SURVEY 8(d)'s accounting: achieved = its algorithmic bytes (A1 + P1) per launch / its average launch duration
     (HIP events on the launch stream), peak 8 TB/s.  `traffic` is its measured HBM traffic per launch from the committed
     counter passes (`traffic_source`).  The kernel does not move the algorithmic bytes (it keeps the (N,K,10+2C) /
@@ -388,14 +397,15 @@ def roofline_leg(args, dev, net, reps=50):
     flops = cv1_flops(L["N"], L["C"], L["Kq"]) * B
     gbs = nbytes / sec / 1e9
     ex = MFMA_PRODUCTS if args.products == "split" else 1
+    chain = L["N"] * L["Kq"] * B >= pkg("fused")._prepass_rows(1, B)      # (fused.cv_stage1's own switch: what the timed path runs)
     traffic, traffic_source = (None, "--no-live-traffic") if args.no_live_traffic else _live_traffic(B, args.features)
     if traffic is None:                                 # the committed passes of the same kernel and shape
         why = traffic_source
-        traffic = _pmc_traffic("cv1_kernel", B, args.features)
+        traffic = _pmc_traffic("cv1_rr_kernel" if chain else "cv1_kernel", B, args.features)
         traffic_source = (os.path.relpath(PMC_SUMMARY, ROOT) + _pmc_commit() + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                           "not measured in this run: %s)" % why)
-    out = {"bound": "hbm", "kernel": "cv1_kernel (fused cost-volume stage 1 at l0 on the tensors of a real forward: %d points, K=%d, batch %d, %s features)"
-                                     % (L["N"], L["Kq"], B, args.features),
+    out = {"bound": "hbm", "kernel": "%s (fused cost-volume stage 1 at l0 on the tensors of a real forward: %d points, K=%d, batch %d, %s features)"
+                                     % ("group_select_k pre-pass + cv1_rr_kernel, timed together" if chain else "cv1_kernel", L["N"], L["Kq"], B, args.features),
            "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
            "traffic": traffic, "traffic_source": traffic_source,
            "us_per_launch": round(sec * 1e6, 3), "algorithmic_bytes_per_launch": int(nbytes),
