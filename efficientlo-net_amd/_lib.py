@@ -207,6 +207,9 @@ SYMBOLS = [
     ("elo_debug_narrow_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_debug_rowlinear_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_debug_sv_ride_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
+    ("elo_debug_chain_pair_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
+    ("elo_cv_stage1_setconv_chain_form", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs)]),
+    ("elo_cv_stage1_setconv_chain", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
     ("elo_rowlinear_fused2", ctypes.c_int, [ctypes.POINTER(RowlinearArgs), ctypes.POINTER(RowlinearArgs), _vp]),
     ("elo_setconv_chain_form", ctypes.c_int, [ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs)]),
     ("elo_cv_chain_form", ctypes.c_int, [ctypes.c_int, ctypes.c_int]),

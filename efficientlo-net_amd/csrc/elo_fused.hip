@@ -2146,8 +2146,9 @@ template <int FP, bool PRE = false> struct Cv1Plan {   // CV_0 (FP pairs + geome
 // PRE ("layer 0 through the gather"): CV_0 = W_geo . geometry + (b + W_1 . feat1[centre]) + mask * (W_2 . feat2[neighbour]); the two
 // bracketed terms are rows of a.pre_c / a.pre_s (rowlinear_rr_kernel: once per point instead of once per (point, neighbour) row),
 // a.cv0 is then the geometry-only layer (K = 10).  Same sums up to the order of three fp32 additions.
+// `block` of `nblocks`: blockIdx.x / gridDim.x of a plain launch, or the workgroup's share of a heterogeneous one (cv1_setconv_rr_kernel)
 template <int C, bool F16, int MODE = MODE_SPLIT, bool PRE = false>
-__global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_args a)
+__device__ __forceinline__ void cv1_rr_body(const elo_cv1_args &a, const unsigned block, const unsigned nblocks)
 {
     extern __shared__ __align__(16) float lds[];
     constexpr int FP = C / 16;                       // 16-channel blocks per feature tensor; CV_0's pairs: FP (feat1 | feat2 blocks paired up)
@@ -2156,7 +2157,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
     uint4 *ring = reinterpret_cast<uint4 *>(lds);    // [2 slots][8 chunks][64 lanes] x 16 bytes
     const int K = a.K, P = RR_ROWS / K;              // points per workgroup: rows r = point * K + slot, r < P * K <= 128
     const long total_points = (long)a.batch * a.npoints;
-    const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
+    const long first_point = (long)xcd_tile(block, nblocks) * P;
     unsigned bad = 0;
     RR_STAMP(0);
     // ---- the W stream.  Steps per layer: CV_0 4*(FP+1), CV_1 2*4, CV_2 2*2, CV_xyz 2*1, sum_CV_0 4*4, sum_CV_1 2*4
@@ -2273,6 +2274,12 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_
     rr_pool<F16>(lds, logit, xe[0], xe[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
     RR_STAMP(9);
     report_violations<MODE>(bad);
+}
+
+template <int C, bool F16, int MODE = MODE_SPLIT, bool PRE = false>
+__global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_args a)
+{
+    cv1_rr_body<C, F16, MODE, PRE>(a, blockIdx.x, gridDim.x);
 }
 // ---- cost volume, stage 2, register-resident (see cv1_rr_kernel): xyz-encoding (geometry tail -> 64), sum_cost_volume_0
 // ([grouped cost (64) | encoding (64) | feat1 (C)] -> 128), sum_cost_volume_1 (-> 64 logits), masked softmax over the K
@@ -2643,16 +2650,15 @@ __device__ __forceinline__ void rr_pool_max(float *lds, const float4 (&last)[NOU
 // rows only (K = 3).  A row starts at pre[its neighbour] (a masked row at b: its features are zero) and adds the geometry tail:
 // the SAME bits as the whole layer run per row -- 904 sources instead of 28 800 rows at the l0 set-upconv.
 template <int FPB, int N1, int N2, int N3, bool F16, int MODE = MODE_SPLIT, bool PRE = false>
-__global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobPair<elo_setconv_args> jobs)
+__device__ __forceinline__ void setconv_rr_body(const elo_setconv_args &a, const unsigned block, const unsigned nblocks)
 {
     extern __shared__ __align__(16) float lds[];
-    const elo_setconv_args &a = jobs.job[blockIdx.y];
     constexpr int C = 16 * FPB, NOUT = N3 ? N3 : N2;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4, tid = threadIdx.x;
     const int K = a.K, P = RR_ROWS / K;
     const long total_points = (long)a.batch * a.npoints;
-    const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
+    const long first_point = (long)xcd_tile(block, nblocks) * P;
     unsigned bad = 0;
     RR_STAMP(0);
     typedef RrStream<ScPlan<FPB, N1, N2, N3, PRE>, MODE> Stream;
@@ -2814,6 +2820,28 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobP
     else rr_pool_max<NOUT, F16>(lds, last, mk, r, wave, lane, K, P, first_point, total_points, a.out);
     RR_STAMP(8);
     report_violations<MODE>(bad);
+}
+
+template <int FPB, int N1, int N2, int N3, bool F16, int MODE = MODE_SPLIT, bool PRE = false>
+__global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobPair<elo_setconv_args> jobs)
+{
+    setconv_rr_body<FPB, N1, N2, N3, F16, MODE, PRE>(jobs.job[blockIdx.y], blockIdx.x, gridDim.x);
+}
+
+// Cost-volume stage 1 (from the select-k pre-pass's idx / mask) and stage 1 of the level's two set-upconvs (128 -> 64, in-kernel
+// random-k) only share inputs (pwclo_model.py:242-250): ONE launch of register-resident workgroups -- the first n_cv run
+// cv1_rr_body, the next n_sc set-conv job 0, the rest job 1 -- instead of two dependent launches that each leave most of the
+// GPU idle at batch 1-3 (cv1_setconv_kernel is the same move for the tile kernels).  The bodies are the plain kernels': same bits.
+template <int C, bool F16, int MODE>
+__global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_setconv_rr_kernel(const elo_cv1_args a, const JobPair<elo_setconv_args> jobs,
+                                                                         const unsigned n_cv, const unsigned n_sc)
+{
+    if (blockIdx.x < n_cv) {
+        cv1_rr_body<C, F16, MODE, false>(a, blockIdx.x, n_cv);
+    } else {
+        const unsigned r = blockIdx.x - n_cv, j = r >= n_sc ? 1u : 0u;
+        setconv_rr_body<4, 128, 64, 0, F16, MODE, false>(jobs.job[j], j ? r - n_sc : r, n_sc);
+    }
 }
 // ================================================================ the same narrow set-conv, MLP on the matrix cores (round 4)
 // setconv_small_kernel spends 1507 (6 -> 8 -> 8 -> 16) / 2756 (19 -> 16 -> 16 -> 32) vector instructions per wave, three
@@ -3336,6 +3364,13 @@ extern "C" int elo_debug_rr_launches(unsigned long long *counts4, int reset)
         if (counts4) counts4[i] = g_rr_launches[i].load();
         if (reset) g_rr_launches[i].store(0);
     }
+    return ELO_OK;
+}
+static std::atomic<unsigned long long> g_chain_pair_launches; // cv1_setconv_rr_kernel (elo_cv_stage1_setconv_chain)
+extern "C" int elo_debug_chain_pair_launches(unsigned long long *count, int reset)
+{
+    if (count) *count = g_chain_pair_launches.load();
+    if (reset) g_chain_pair_launches.store(0);
     return ELO_OK;
 }
 static std::atomic<unsigned long long> g_sv_ride_launches;    // mlp_sv_kernel (elo_mlp_args.sv_*)
@@ -3883,6 +3918,82 @@ extern "C" int elo_cv_stage1_setconv_fused(const elo_cv1_args *a, const elo_setc
     ELO_PICK_MODE(pc.mode, CALL_T);
 #undef CALL_T
     return check_launch(who);
+}
+
+// The chain-kernel twin of elo_cv_stage1_setconv_fused (cv1_setconv_rr_kernel): the cost volume comes PRE-GROUPED (idx / mask
+// of the select-k pre-pass), the two set-conv jobs are the level's set-upconv stage 1 (in-kernel random-k, 64 + 3 -> 128 -> 64).
+// elo_cv_stage1_setconv_chain_form: 1 when (C, the layers' products mode, the jobs' shape and size) take it -- the host asks
+// before it runs the pre-pass.
+static int chain_pair_form(const elo_cv1_args *a, const elo_setconv_args *ja, const elo_setconv_args *jb, int *mode_out, const char *who)
+{
+#ifdef ELO_DENSE_F32
+    (void)a; (void)ja; (void)jb; (void)mode_out; (void)who;
+    return 0;
+#else
+    if (!a || !ja || !jb) return 0;
+    int mode = 0, mode_sc = 0, mode_sb = 0;
+    if (products_mode(who, &mode, a->cv0, a->cv1, a->cv2, a->cv_xyz, a->sum_cv0, a->sum_cv1)) return 0;
+    if (ja->n_layers != 2 || jb->n_layers != 2 || products_mode(who, &mode_sc, ja->layers, 2) || products_mode(who, &mode_sb, jb->layers, 2)) return 0;
+    if (mode != mode_sc || mode != mode_sb || !same_shape(ja, jb) || ja->feat_dtype != a->feat_dtype) return 0;
+    if (a->pre_c || a->pre_s || ja->pre || jb->pre) return 0;
+    if (!cv_chain(a->C, mode) || setconv_chain_shape(ja, jb, mode) != 1) return 0;
+    if (a->K <= 0 || a->K > 32) return 0;
+    *mode_out = mode;
+    return 1;
+#endif
+}
+
+extern "C" int elo_cv_stage1_setconv_chain_form(const elo_cv1_args *a, const elo_setconv_args *ja, const elo_setconv_args *jb)
+{
+    int mode = 0;
+    return chain_pair_form(a, ja, jb, &mode, "elo_cv_stage1_setconv_chain_form");
+}
+
+extern "C" int elo_cv_stage1_setconv_chain(const elo_cv1_args *a, const elo_setconv_args *ja, const elo_setconv_args *jb,
+                                           elo_stream_t stream)
+{
+    const char *who = "elo_cv_stage1_setconv_chain";
+#ifdef ELO_DENSE_F32
+    (void)a; (void)ja; (void)jb; (void)stream;
+    return fail(ELO_ERR_LIMIT, "%s: the fp32-MFMA comparison build has no register-resident kernels", who);
+#else
+    TilePlan pc, ps;
+    if (int rc = plan_cv1(a, &pc, who)) return rc;
+    ELO_REQUIRE(jb, who, "two set-conv jobs");
+    if (int rc = check_setconv(ja, who)) return rc;
+    if (int rc = check_setconv(jb, who)) return rc;
+    if (!same_shape(ja, jb)) return fail(ELO_ERR_ARG, "%s: the two set-conv jobs must have the same shape", who);
+    if (int rc = plan_setconv(ja, jb, &ps, who)) return rc;
+    if (a->group.random_hw || !a->idx || !a->mask) return fail(ELO_ERR_ARG, "%s: the cost volume comes pre-grouped (idx / mask of the select-k pre-pass)", who);
+    int mode = 0;
+    if (!chain_pair_form(a, ja, jb, &mode, who) || mode != pc.mode || mode != ps.mode)
+        return fail(ELO_ERR_ARG, "%s: not a chain-form launch (elo_cv_stage1_setconv_chain_form returns 0)", who);
+    const long pts_cv = (long)a->batch * a->npoints, pts_sc = (long)ja->batch * ja->npoints;
+    if (pts_cv == 0 || pts_sc == 0) return fail(ELO_ERR_ARG, "%s: empty batch (call the separate entry points)", who);
+    const int Pc = RR_ROWS / a->K, Ps = RR_ROWS / ja->K;
+    const unsigned n_cv = (unsigned)((pts_cv + Pc - 1) / Pc), n_sc = (unsigned)((pts_sc + Ps - 1) / Ps);
+    const dim3 grid(n_cv + 2u * n_sc);
+    JobPair<elo_setconv_args> pair;
+    pair.job[0] = *ja;
+    pair.job[1] = *jb;
+    hipStream_t s = (hipStream_t)stream;
+    const bool f16 = a->feat_dtype == ELO_F16;
+#define RRP(CC)                                                                                                                              \
+    do {                                                                                                                                    \
+        if (f16 && mode == MODE_HALF) hipLaunchKernelGGL((cv1_setconv_rr_kernel<CC, true, MODE_HALF>), grid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a, pair, n_cv, n_sc);   \
+        else if (f16) hipLaunchKernelGGL((cv1_setconv_rr_kernel<CC, true, MODE_SPLIT>), grid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a, pair, n_cv, n_sc);                 \
+        else if (mode == MODE_HALF) hipLaunchKernelGGL((cv1_setconv_rr_kernel<CC, false, MODE_HALF>), grid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a, pair, n_cv, n_sc);   \
+        else hipLaunchKernelGGL((cv1_setconv_rr_kernel<CC, false, MODE_SPLIT>), grid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a, pair, n_cv, n_sc);                          \
+    } while (0)
+    if (a->C == 16) RRP(16);
+    else if (a->C == 32) RRP(32);
+    else RRP(64);
+#undef RRP
+    ++g_rr_launches[0];
+    ++g_rr_launches[2];
+    ++g_chain_pair_launches;
+    return check_launch(who);
+#endif
 }
 
 extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)

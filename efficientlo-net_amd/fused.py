@@ -583,10 +583,14 @@ def _record(stage, args, kwargs):
 
 
 def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1, group=None, K=None,
-              side=None):
+              side=None, side_chain=False):
     """Cost-volume stage 1 in one launch.  `side`: one or two set-conv jobs (dicts of setconv() keyword arguments, same
     shape) that only share inputs with the cost volume -- run INSIDE this launch (elo_cv_stage1_setconv_fused); the call
-    then returns (out, [(out_a, new_xyz_a), ...])."""
+    then returns (out, [(out_a, new_xyz_a), ...]).
+    `side_chain` (with two side jobs): the side jobs ride only if stage 1 AND they take the register-resident chain form
+    (select-k pre-pass, then ONE launch of cv1_rr + set-conv chain workgroups: elo_cv_stage1_setconv_chain); otherwise the
+    cost volume runs alone -- in whatever form its size asks for -- and the call returns (out, None): the caller launches
+    the set-convs itself."""
     L.require_gpu(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask)
     if _RECORD is not None:
         _record(1, (xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1), dict(group=group, K=K, side=side))
@@ -595,7 +599,18 @@ def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_x
     _, H2, W2, C = feat2_proj.shape
     B, N = xyz1.shape[0], xyz1.shape[1]
     ptr = lambda x: x.data_ptr() if x is not None else None
-    if not side and N == H2 * W2 and _rr_path(group, B, N, K, C):
+    chain_jobs = None
+    if side and side_chain:
+        rr = len(side) == 2 and N == H2 * W2 and _rr_path(group, B, N, K, C)
+        if rr:
+            chain_jobs = [_setconv_args(**job) for job in side]          # (args, out, new_xyz, keep-alive)
+            probe = L.Cv1Args(B, N, K, H2, W2, C, None, None, None, None, None, None, cv0.struct(), cv1.struct(), cv2.struct(),
+                              cv_xyz.struct(), sum_cv0.struct(), sum_cv1.struct(), None, _NO_GROUP, code, None, None)
+            if L.lib().elo_cv_stage1_setconv_chain_form(ctypes.byref(probe), ctypes.byref(chain_jobs[0][0]), ctypes.byref(chain_jobs[1][0])) != 1:
+                chain_jobs = None
+        if chain_jobs is None:
+            return cv_stage1_alone(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1, group, K), None
+    if (not side or chain_jobs) and N == H2 * W2 and _rr_path(group, B, N, K, C):
         idx, mask = group_prepass("select", xyz1.reshape(B, H2, W2, 3), xyz2_proj, group, K)
         group = None
     if group is None:
@@ -611,12 +626,25 @@ def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_x
                   ptr(idx), ptr(mask), cv0.struct(), cv1.struct(), cv2.struct(), cv_xyz.struct(),
                   sum_cv0.struct(), sum_cv1.struct(), out.data_ptr(),
                   group.struct(B, N, K, xyz1.device) if group is not None else _NO_GROUP, code, ptr(pre_c), ptr(pre_s))
+    if chain_jobs:
+        L.call3("elo_cv_stage1_setconv_chain", a, chain_jobs[0][0], chain_jobs[1][0], out)
+        return out, [(j[1], j[2]) for j in chain_jobs]
     if side:
         jobs = [_setconv_args(**job) for job in side]                  # (args, out, new_xyz, keep-alive)
         L.call3("elo_cv_stage1_setconv_fused", a, jobs[0][0], jobs[1][0] if len(jobs) > 1 else None, out)
         return out, [(j[1], j[2]) for j in jobs]
     L.call("elo_cv_stage1_fused", a, out)
     return out
+
+
+def cv_stage1_alone(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1, group, K):
+    """cv_stage1 without side jobs and without a second recording of the call (cv_stage1(side_chain=True) falls back on it)."""
+    global _RECORD
+    keep, _RECORD = _RECORD, None
+    try:
+        return cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_xyz, sum_cv0, sum_cv1, group=group, K=K)
+    finally:
+        _RECORD = keep
 
 
 def cv_stage2(xyz1_proj, feat1_proj, cost_proj, idx, mask, xyz_enc, sum_cost0, sum_cost1, group=None, K=None):

@@ -152,10 +152,11 @@ def _split_conv(parts, num_output_channels, scope, is_training, bn_decay, bn=Tru
 @_storage_boundary("points1_proj", "points2_proj")
 def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_size1, kernel_size2, nsample,
                 nsample_q, distance, mlp1, mlp2, is_training, bn_decay, scope, bn=True, pooling='max', knn=True,
-                corr_func='elementwise_product', side_jobs=None):
+                corr_func='elementwise_product', side_jobs=None, side_chain=False):
     """Attentive cost volume, utils/pointnet_util.py:33-149.  Returns (B, H*W, mlp2[-1]).
     `side_jobs` (fused inference path only): one or two set-conv jobs (fused.setconv keyword dicts) that only share
-    inputs with this cost volume; they run inside stage 1's launch and the call returns (cost, [(out, new_xyz), ...])."""
+    inputs with this cost volume; they run inside stage 1's launch and the call returns (cost, [(out, new_xyz), ...]).
+    `side_chain`: they ride only on the chain form of stage 1 (fused.cv_stage1); else the second element is None."""
     with tf_util.variable_scope(scope):
         B, H, W, _ = warped_xyz1_proj.shape
         N = H * W
@@ -178,7 +179,7 @@ def cost_volume(warped_xyz1_proj, xyz2_proj, points1_proj, points2_proj, kernel_
                 P('CV_xyz', 10, 64),
                 P('sum_CV_0', 128, 128, row_order=list(range(64, 128)) + list(range(64))),      # kernel order [x | enc]
                 P('sum_CV_1', 128, 64),
-                group=fused.Grouping(random_HW_q, kernel_size2, 1000), K=nsample_q, side=side_jobs)       # :49-100
+                group=fused.Grouping(random_HW_q, kernel_size2, 1000), K=nsample_q, side=side_jobs, side_chain=side_chain)   # :49-100
             pi_feat1_new, side_out = stage1 if side_jobs else (stage1, None)
             pi_feat1_new = pi_feat1_new.reshape(B, H, W, -1)
             order = list(range(64 + C, 128 + C)) + list(range(64)) + list(range(64, 64 + C))   # [grouped | enc | feat1]

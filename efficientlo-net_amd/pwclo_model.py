@@ -380,12 +380,13 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
         xyz_warp_f1 = xyz_warp_proj_f1.reshape(batch_size, -1, 3)
         points_warp_f1 = points_warp_proj_f1.reshape(batch_size, out_h_list[g] * out_w_list[g], -1)
 
-        def branch_cost(side_jobs=None):
+        def branch_cost(side_jobs=None, side_chain=False):
             return cost_volume(xyz_warp_proj_f1, xyz_proj_f2[level], points_warp_proj_f1, pts_proj_f2[level],
                                kernel_size1=[3, 5], kernel_size2=cv_kernel2[level], nsample=4, nsample_q=6,
                                distance=Cost_volume_dis[level], mlp1=[128, 64, 64], mlp2=[128, 64],
                                is_training=is_training, bn_decay=bn_decay, scope='flow_embedding_l%d' % level,
-                               bn=True, pooling='max', knn=True, corr_func='concat', side_jobs=side_jobs)   # :242
+                               bn=True, pooling='max', knn=True, corr_func='concat', side_jobs=side_jobs,
+                               **({"side_chain": True} if side_chain else {}))                             # :242
 
         def branch_up(kind, coarse_feat_proj):
             return up_conv(xyz_warp_proj_f1, coarse_xyz_proj, points_warp_proj_f1, coarse_feat_proj,
@@ -409,8 +410,10 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
             if merge_branches(is_training, finest_points, batch_size * out_h_list[g] * out_w_list[g]):
                 cost, ((up_w_pooled, _), (up_c_pooled, _)) = branch_cost(side_jobs=jobs)
             else:
-                cost = branch_cost()
-                (up_w_pooled, _), (up_c_pooled, _) = fused.setconv_pair(jobs[0], jobs[1])
+                # ... and where both are register-resident chain launches (a larger level below the throughput batch), the
+                # chain kernels' heterogeneous launch (tuning chain_pair); the select-k pre-pass stays a launch of its own
+                cost, sides = branch_cost(side_jobs=jobs, side_chain=True) if tuning.get("chain_pair") else (branch_cost(), None)
+                (up_w_pooled, _), (up_c_pooled, _) = sides if sides is not None else fused.setconv_pair(jobs[0], jobs[1])
             fp = dict(points_f1=points_warp_f1, cost_volume=cost, mlp=[128, 64])
             # set-upconv stage 2 and the predictor it feeds share a launch
             sv = sv_ride(xyz_warp_f1)

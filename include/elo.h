@@ -791,6 +791,7 @@ int elo_debug_rr_rows(long setconv_rows, long mlp_rows);
 int elo_debug_rr_launches(unsigned long long *counts4, int reset);
 int elo_debug_rowlinear_launches(unsigned long long *count, int reset);   /* ... and of rowlinear_rr_kernel (elo_rowlinear_fused2) */
 int elo_debug_sv_ride_launches(unsigned long long *count, int reset);     /* ... and of mlp_sv_kernel (elo_mlp_args.sv_*) */
+int elo_debug_chain_pair_launches(unsigned long long *count, int reset);  /* ... and of cv1_setconv_rr_kernel (elo_cv_stage1_setconv_chain) */
 /* the two narrow set-conv layers of the pyramid (6 -> 8 -> 8 -> 16 and 19 -> 16 -> 16 -> 32, K = 32; elo_setconv_fused with
  * elo_dense.w_plain given): 1 = setconv_narrow_kernel, the MLP on the matrix cores, for the 19-channel layer (the default;
  * also ELO_SETCONV_NARROW_MFMA), 2 = for both layers (the 6-channel one is slower that way: measured), 0 =
@@ -807,6 +808,13 @@ int elo_debug_narrow_launches(unsigned long long *counts3, int reset);
  * (pwclo_model.py:242-250), the initial cost volume and the layer-3 set-conv of the pyramid (:138, :170) -- so that a
  * small-batch forward pays one launch boundary and keeps both branches in flight together.  Same results bit for bit. */
 int elo_cv_stage1_setconv_fused(const elo_cv1_args *a, const elo_setconv_args *ja, const elo_setconv_args *jb, elo_stream_t stream);
+/* The same move on the register-resident kernels (round 5): the cost volume PRE-GROUPED (idx / mask of the select-k pre-pass), two
+ * set-conv jobs of the set-upconv shape (64 + 3 -> 128 -> 64, in-kernel random-k): one launch of 512-thread chain workgroups, the
+ * first ones on the cost volume, then job a, then job b -- the bits of elo_cv_stage1_fused + elo_setconv_fused2.
+ * elo_cv_stage1_setconv_chain_form: 1 when (a's C and layers, the jobs' shape / size / products mode) take it; `a` need not carry
+ * idx / mask or a grouping spec yet. */
+int elo_cv_stage1_setconv_chain_form(const elo_cv1_args *a, const elo_setconv_args *ja, const elo_setconv_args *jb);
+int elo_cv_stage1_setconv_chain(const elo_cv1_args *a, const elo_setconv_args *ja, const elo_setconv_args *jb, elo_stream_t stream);
 
 /* Attentive cost volume, stage 2 (utils/pointnet_util.py:104-146) in one launch.
  * sum_cost0 expects input rows ordered [cost[idx]*m (64), xyz-encoding (64), feat1 (C)]

@@ -180,3 +180,34 @@ def test_a_forward_with_the_ride_equals_the_forward_without(feat):
         assert torch.isfinite(a).all()
         tight = i >= 6                                       # (l3_q, l3_t)
         assert torch.allclose(a, b, atol=2e-5 if tight else 2e-2, rtol=1e-4), (i, a, b)
+
+
+@pytest.mark.parametrize("feat", [torch.float32, torch.float16])
+@pytest.mark.parametrize("B", [1, 2])
+def test_the_chain_kernels_heterogeneous_launch_leaves_a_forward_unchanged(B, feat):
+    """cv1_setconv_rr_kernel (elo_cv_stage1_setconv_chain: cost-volume stage 1 from the select-k pre-pass + the level's two
+    set-upconv stage-1 jobs as ONE launch of register-resident workgroups, taken below the throughput batch where both are chain
+    forms -- l0 of a 64 x 1800 forward) runs the plain kernels' bodies: every pose output of the forward is BIT-identical
+    with tuning.chain_pair off, and the launch counter says the kernel ran."""
+    from util_params import randomise, shuffle_fn
+    model, synth, tuning, perm, lib = load_pkg("model"), load_pkg("synth"), load_pkg("tuning"), load_pkg("perm"), load_pkg("_lib")
+    if load_pkg("fused").fp32_mfma():
+        pytest.skip("the fp32-MFMA comparison build has no register-resident kernels")
+    f1, f2 = synth.frame_pair(B, 64, 1800, seed=11)
+    both = torch.from_numpy(np.concatenate([f1, f2], 0)).to(DEV)
+    net = model.PWCLONet(DEV, seed=5, perm_source=perm.PermSource(fn=shuffle_fn), feature_dtype=feat)
+    net.forward(both[:B], both[B:])
+    randomise(net.store, seed=7)
+
+    def pairs(reset=False):
+        n = ctypes.c_ulonglong(0)
+        lib.check(lib.lib().elo_debug_chain_pair_launches(ctypes.byref(n), 1 if reset else 0))
+        return n.value
+    outs = {}
+    for on in (True, False):
+        with tuning.override(chain_pair=on):
+            pairs(reset=True)
+            outs[on] = [x.clone() for x in net.forward(both[:B], both[B:])[:8]]
+            assert pairs() == (1 if on else 0)                        # l0 (the smaller levels ride on the tile kernels' merged launch)
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
