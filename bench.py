@@ -410,6 +410,9 @@ def roofline_leg(args, dev, net, reps=50):
            "traffic": traffic, "traffic_source": traffic_source,
            "us_per_launch": round(sec * 1e6, 3), "algorithmic_bytes_per_launch": int(nbytes),
            "carries_riders_in_the_forward": L["riders"],      # batch 1-2: the forward's launch also runs the level's two set-upconv jobs
+           "in_the_forward": ("cv1_setconv_rr_kernel (this stage + the level's two set-upconv stage-1 jobs in one launch) behind group_select_k"
+                              if chain and L["riders"] else "cv1_setconv_kernel (this stage + the level's two set-upconv stage-1 jobs in one launch)"
+                              if L["riders"] else "the same launches"),
            "mfma": {"executed_TFLOPs": round(ex * flops / sec / 1e12, 2), "algorithmic_TFLOPs": round(flops / sec / 1e12, 2),
                     "peak": F16_MFMA_PEAK_TFLOPS, "frac": round(ex * flops / sec / 1e12 / F16_MFMA_PEAK_TFLOPS, 5),
                     "issued_as": "v_mfma_f32_16x16x32_f16 x%d per 32-k pair, v_mfma_f32_16x16x16_f16 x%d on a 16-k tail (%s)" % (

@@ -412,7 +412,10 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
             else:
                 # ... and where both are register-resident chain launches (a larger level below the throughput batch), the
                 # chain kernels' heterogeneous launch (tuning chain_pair); the select-k pre-pass stays a launch of its own
-                cost, sides = branch_cost(side_jobs=jobs, side_chain=True) if tuning.get("chain_pair") else (branch_cost(), None)
+                # (only in the forwards small enough to merge at all: from batch 4 on the GPU is full and the two launches are faster,
+                #  batch 4 23.3 -> 21.9 k pairs/s, batch 8 fp16 28.0 -> 27.4 k: profiles/r05_batch1_regimes.txt)
+                pair = tuning.get("chain_pair") and finest_points <= tuning.get("merge_points")
+                cost, sides = branch_cost(side_jobs=jobs, side_chain=True) if pair else (branch_cost(), None)
                 (up_w_pooled, _), (up_c_pooled, _) = sides if sides is not None else fused.setconv_pair(jobs[0], jobs[1])
             fp = dict(points_f1=points_warp_f1, cost_volume=cost, mlp=[128, 64])
             # set-upconv stage 2 and the predictor it feeds share a launch
