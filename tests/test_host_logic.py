@@ -246,3 +246,23 @@ def test_store_and_perm_generations_track_invalidation():
     assert store.generation == g0 + 1 and src.generation == p0 + 1
     store.load_state_dict({})
     assert store.generation == g0 + 2
+
+
+def test_the_regime_switches_of_a_forward_are_tuning_values():
+    """Which levels of a forward merge their cost volume with the set-upconvs (tile kernels' heterogeneous launch), from how many rows
+    a stage takes the register-resident kernels, and the two round-5 rides, are fields of tuning.snapshot() -- hashed into every
+    captured graph -- with the measured defaults (profiles/r05_batch1_regimes.txt, r05_small_tile_units.txt, r05_sv_ride.txt)."""
+    tuning, pu, fused = load_pkg("tuning"), load_pkg("pointnet_util"), load_pkg("fused")
+    for name, default in (("merge_points", 8192), ("merge_level_points", 2000), ("sv_ride", True), ("chain_pair", True)):
+        assert tuning.get(name) == default, name
+    # a 64 x 1800 pair at batch 1: l2 (228 centres) and l1 (904) merge, l0 (3600) does not; from batch 3 on nothing merges
+    assert [pu.merge_branches(False, 3600, n) for n in (228, 904, 3600)] == [True, True, False]
+    assert not pu.merge_branches(False, 3 * 3600, 3 * 228) and not pu.merge_branches(True, 3600, 228)
+    with tuning.override(merge_level_points=10 ** 9):
+        assert pu.merge_branches(False, 3600, 3600)
+    # stage 1 of the l0 cost volume (3600 x 6 rows) takes the pre-pass + chain kernel below the throughput batch, stage 2 does not
+    assert fused._prepass_rows(1, 1) <= 3600 * 6 < fused._prepass_rows(2, 1) and fused._prepass_rows(1, 8) == fused._prepass_rows(2, 8) == 8192
+    before = tuning.digest()
+    with tuning.override(sv_ride=False):
+        assert tuning.digest() != before
+    assert tuning.digest() == before
