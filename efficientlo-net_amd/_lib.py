@@ -207,6 +207,7 @@ SYMBOLS = [
     ("elo_debug_narrow_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_debug_rowlinear_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_debug_sv_ride_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
+    ("elo_graph_submit", ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_ulong]),
     ("elo_debug_chain_pair_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_cv_stage1_setconv_chain_form", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs)]),
     ("elo_cv_stage1_setconv_chain", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
@@ -224,7 +225,7 @@ class EloError(RuntimeError):
     pass
 
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 def lib():

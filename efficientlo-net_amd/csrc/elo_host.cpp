@@ -66,5 +66,24 @@ extern "C" int elo_set_tuning(const elo_tuning *in)
     return ELO_OK;
 }
 
-extern "C" int elo_abi_version(void) { return 21; }
+// One lane submit of the host runtime as ONE native call: the optional device-to-device copy of the lane's input, then the lane's
+// instantiated graph, both on the lane's stream (include/elo.h).  Through torch the same pair -- Tensor.copy_ + CUDAGraph.replay() --
+// costs the submitting thread 29 us a step, this 16 (tools/submit_native_probe.py): with 20 steps between two synchronisations (the
+// driver's protocol) the four queues' first forwards start that much closer together.
+extern "C" int elo_graph_submit(void *graph_exec, elo_stream_t stream, void *dst, const void *src, unsigned long bytes)
+{
+    const char *who = "elo_graph_submit";
+    if (!graph_exec) return elo::fail(ELO_ERR_ARG, "%s: null graph", who);
+    hipStream_t s = (hipStream_t)stream;
+    if (bytes) {
+        if (!dst || !src) return elo::fail(ELO_ERR_ARG, "%s: a copy needs both pointers", who);
+        const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return elo::fail(ELO_ERR_LAUNCH, "%s: hipMemcpyAsync: %s", who, hipGetErrorString(e));
+    }
+    const hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, s);
+    if (e != hipSuccess) return elo::fail(ELO_ERR_LAUNCH, "%s: hipGraphLaunch: %s", who, hipGetErrorString(e));
+    return ELO_OK;
+}
+
+extern "C" int elo_abi_version(void) { return 22; }
 extern "C" const char *elo_last_error(void) { return elo::err_buf(); }

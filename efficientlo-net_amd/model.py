@@ -210,6 +210,7 @@ class PWCLONet:
             # the graph holds raw device pointers into the module-level index / decoded-order caches; those caches evict
             # (clear()) when they grow: the lane keeps the tensors alive for as long as its graph exists
             lane["keep"] = _cached_tensors()
+            lane["native"] = self._native_submit(lane, dev)
             self._lanes.append(lane)
         self.perms.active_lane, self.perms.tail_armed = 0, False
         torch.cuda.synchronize(dev)
@@ -222,6 +223,23 @@ class PWCLONet:
         self._tuning_seen = tuning.version()
         self.captured_tuning = tuning.snapshot()           # the forms this graph has baked in (bench.py: config.tuning)
         return self
+
+    @staticmethod
+    def _native_submit(lane, dev):
+        """What submit() hands to elo_graph_submit for this lane (tuning native_submit), or None: torch's own copy_ + replay().  Needs the
+        graphs' raw exec handles (torch >= 2.8) and the lane's device to be the thread's current one (one process per GPU)."""
+        if not tuning.get("native_submit") or dev.index != torch.cuda.current_device():
+            return None
+        from . import _lib
+        try:
+            execs = [lane[k].raw_cuda_graph_exec() if k in lane else None for k in ("graph", "graph_checked")]
+        except (AttributeError, RuntimeError):
+            return None
+        import ctypes
+        pair = lane["pair"]
+        return {"submit": _lib.lib().elo_graph_submit, "exec": ctypes.c_void_p(execs[0]), "exec_checked": ctypes.c_void_p(execs[1] or execs[0]),
+                "stream": ctypes.c_void_p(lane["stream"].cuda_stream), "dst": ctypes.c_void_p(pair.data_ptr()),
+                "nbytes": pair.numel() * pair.element_size()}
 
     def _check_fresh(self):
         """A captured graph holds raw device pointers to the folded / packed inference weights and to the decoded
@@ -298,6 +316,27 @@ class PWCLONet:
         input buffer was written in place (lane_input): no copy."""
         self._check_fresh()
         lane = self._lanes[lane_index]
+        native = lane.get("native")
+        if native is not None and xyz_f2_proj is None:
+            # the host runtime's own submit (csrc/elo_host.cpp elo_graph_submit): the copy and the graph launch as ONE native call on
+            # the lane's stream -- 16 us of host time instead of 29 through torch (tools/submit_native_probe.py)
+            pair = lane["pair"]
+            if xyz_f1_proj is None:
+                src, nbytes = None, 0
+            else:
+                if (xyz_f1_proj.shape != pair.shape or xyz_f1_proj.dtype != pair.dtype or xyz_f1_proj.device != pair.device
+                        or not xyz_f1_proj.is_contiguous()):
+                    native = None                     # (a conversion is needed: torch's copy_ below does it)
+                else:
+                    src, nbytes = xyz_f1_proj.data_ptr(), native["nbytes"]
+            if native is not None:
+                n = lane.get("check_every", 0)
+                lane["total"] = lane.get("total", 0) + 1
+                checked = n and lane["total"] % n == 0
+                from . import _lib
+                _lib.check(native["submit"](native["exec_checked"] if checked else native["exec"], native["stream"], native["dst"], src, nbytes))
+                lane["replays"] += 1
+                return lane["out_checked"] if checked else lane["out"]
         with torch.cuda.stream(lane["stream"]):
             if xyz_f1_proj is None:
                 pass

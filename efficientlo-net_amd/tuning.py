@@ -40,6 +40,7 @@ _HOST = {
     "merge_level_points": ("ELO_MERGE_LEVEL_POINTS", int, 2000),              # ... at the levels of up to this many centres
     "pose_direct": ("ELO_POSE_DIRECT", lambda v: v == "1", False),            # pose head reduces softmax_valid itself (one launch less)
     "chain_pair": ("ELO_CHAIN_PAIR", lambda v: v != "0", True),               # cost-volume stage 1 + the level's set-upconv stage 1 as ONE chain-kernel launch where both are chain forms
+    "native_submit": ("ELO_NATIVE_SUBMIT", lambda v: v != "0", True),         # a lane submit as ONE C call (copy + hipGraphLaunch on the raw exec handle) instead of torch's copy_ + replay()
     "sv_ride": ("ELO_SV_RIDE", lambda v: v != "0", True),                     # softmax_valid's partial sums ride on the launch that produces its inputs (one launch less per level)
     "train_branches": ("ELO_TRAIN_BRANCHES", lambda v: v == "1", False),
     "train_kernels": ("ELO_TRAIN_KERNELS", lambda v: v != "0", True),

@@ -43,6 +43,12 @@ const char *elo_last_error(void);   /* thread-local, never NULL                 
 int elo_range_check(int enable);
 int elo_range_violations(unsigned long long *count, elo_stream_t stream);
 
+/* Host runtime: one step of a captured forward (a "lane": a hipGraphExec_t with fixed input / output buffers) as one call --
+ * if bytes != 0 a device-to-device hipMemcpyAsync(dst <- src) of the lane's input, then hipGraphLaunch, both on `stream`.
+ * graph_exec: the hipGraphExec_t (torch: CUDAGraph.raw_cuda_graph_exec()).  The caller keeps src alive until the stream has
+ * run the copy, as with any asynchronous copy. */
+int elo_graph_submit(void *graph_exec, elo_stream_t stream, void *dst, const void *src, unsigned long bytes);
+
 /* The library's tuning: every choice of KERNEL FORM that is not a function of the arguments alone, as ONE value.  The library
  * itself reads no environment variable; the host fills this once (efficientlo-net_amd/_lib.py maps the ELO_* variables named
  * below onto it when it loads the library) and may change it between launches.  A form baked into a captured hipGraph stays

@@ -213,3 +213,35 @@ def test_the_chain_kernels_heterogeneous_launch_leaves_a_forward_unchanged(B, fe
             assert pairs() == (1 if on else 0)                        # l0 (the smaller levels ride on the tile kernels' merged launch)
     for a, b in zip(outs[True], outs[False]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_the_native_submit_replays_what_torch_replays():
+    """model.submit through elo_graph_submit (one C call: hipMemcpyAsync + hipGraphLaunch on the raw exec handle; tuning
+    native_submit) against torch's copy_ + CUDAGraph.replay() on the same lanes: the same poses bit for bit, pair after pair,
+    with the in-place form (no copy) and the checked graph every second replay in between."""
+    model, synth, tuning = load_pkg("model"), load_pkg("synth"), load_pkg("tuning")
+    pairs = []
+    for i in range(6):
+        f1, f2 = synth.frame_pair(1, 64, 1800, seed=70 + i)
+        pairs.append(torch.from_numpy(np.concatenate([f1, f2], 0)).to(DEV))
+    got = {}
+    for native in (True, False):
+        with tuning.override(native_submit=native):
+            net = model.PWCLONet(DEV, seed=3)
+            net.capture(1, 64, 1800, lanes=2, check_every=2)
+            assert (net._lanes[0]["native"] is not None) == native
+            rows = []
+            for i, p in enumerate(pairs):
+                out = net.submit(i % 2, p)
+                torch.cuda.synchronize()
+                rows.append(torch.cat([out[0].reshape(-1), out[1].reshape(-1)]).clone())
+            net.lane_input(0).copy_(pairs[3])                    # in place: no copy in the submit
+            torch.cuda.synchronize()
+            out = net.submit(0)
+            torch.cuda.synchronize()
+            rows.append(torch.cat([out[0].reshape(-1), out[1].reshape(-1)]).clone())
+            net.collect(0); net.collect(1)                       # (no range violation on healthy inputs)
+            got[native] = rows
+    for a, b in zip(got[True], got[False]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert torch.equal(got[True][-1], got[True][3])              # the in-place replay of pair 3 = the copied one
