@@ -244,4 +244,4 @@ def test_the_native_submit_replays_what_torch_replays():
             got[native] = rows
     for a, b in zip(got[True], got[False]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
-    assert torch.equal(got[True][-1], got[True][3])              # the in-place replay of pair 3 = the copied one
+    assert torch.equal(got[True][6], got[True][3])               # the in-place replay of pair 3 = the copied one
