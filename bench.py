@@ -89,6 +89,11 @@ def parse():
                     help="host threads that enqueue the steps of a repeat (step i goes to thread i %% N).  Measured at the driver's "
                          "--steps 20: 1 thread 9.65 k pairs/s, 2 threads 9.4-9.8 k, 4 threads 9.3 k, 8 threads 8.7 k -- the "
                          "interpreter lock costs more than the staggered start of the four queues; default 1")
+    ap.add_argument("--submit-order", choices=("caller", "stream"), default="caller",
+                    help="caller: submit(..., ready=False) -- the pooled pairs are resident and synchronised before the timed region, the bench "
+                         "owns the ordering (the unordered fast path); stream: submit()'s default -- every step first orders the lane's stream "
+                         "behind the caller's current stream (one hipEventRecord + hipStreamWaitEvent inside the native submit) and "
+                         "record_stream()s the pair")
     ap.add_argument("--check-every", type=int, default=64,
                     help="every N-th replay of a lane runs the graph recorded on the range-checked kernels (the fp16 split's "
                          "production guard, PWCLONet.capture(check_every=N)); 0: off")
@@ -168,6 +173,76 @@ def _time_launches(fn, dev, reps):
     sec = start.elapsed_time(stop) / 1e3 / reps
     del graph
     return sec
+
+
+LLC_BYTES = 256 * 1024 * 1024     # MI355X_MICROARCH.md: 256 MB Infinity Cache in front of HBM (memory side, all XCDs)
+
+
+def _tensors(tree):
+    """The torch tensors of a (nested tuple / list / dict) argument tree."""
+    import torch
+    if torch.is_tensor(tree):
+        return [tree]
+    if isinstance(tree, dict):
+        tree = list(tree.values())
+    if isinstance(tree, (list, tuple)):
+        return [t for v in tree for t in _tensors(v)]
+    return []
+
+
+def _clone_tensors(tree):
+    """The same tree with every tensor cloned (new addresses, same contents); anything else -- packed weights, grouping
+    descriptions, scalars -- is shared: weights are the small hot operand in the product too."""
+    import torch
+    if torch.is_tensor(tree):
+        return tree.clone()
+    if isinstance(tree, dict):
+        return {k: _clone_tensors(v) for k, v in tree.items()}
+    if isinstance(tree, (list, tuple)):
+        return type(tree)(_clone_tensors(v) for v in tree)
+    return tree
+
+
+def _footprint(args, kwargs, out):
+    seen, total = set(), 0
+    for t in _tensors((args, kwargs, out)):
+        key = t.untyped_storage().data_ptr()
+        if key not in seen:
+            seen.add(key)
+            total += t.untyped_storage().nbytes()
+    return total
+
+
+def _time_ring(call, args, kwargs, dev, between=2 * LLC_BYTES, passes=3, max_ring=768):
+    """COLD duration of one launch of call(*args, **kwargs): the launch is issued over a RING of R distinct tensor sets
+    (tensor arguments cloned, outputs kept alive through the capture so that every launch writes its own), R chosen so
+    that >= `between` bytes (default 2 x the 256 MB Infinity Cache) of OTHER sets' inputs and outputs pass between two
+    uses of the same set -- by the time a set comes round again neither L2 nor the Infinity Cache can still hold it, so
+    every launch reads its inputs from HBM and its writes cannot be absorbed by a later overwrite.  One pass over the
+    ring is captured in a hipGraph; `passes` replays between two HIP events on the launch stream.
+    -> (seconds per launch, {"footprint_bytes", "ring", "between_uses_bytes"})."""
+    import torch
+    kwargs = kwargs or {}
+    foot = _footprint(args, kwargs, call(*args, **kwargs))
+    ring = min(max_ring, max(3, -(-between // max(foot, 1)) + 1))
+    sets = [(args, kwargs)] + [(_clone_tensors(args), _clone_tensors(kwargs)) for _ in range(ring - 1)]
+    for a, k in sets:
+        call(*a, **k)
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        keep = [call(*a, **k) for a, k in sets]
+    graph.replay()
+    torch.cuda.synchronize(dev)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(passes):
+        graph.replay()
+    stop.record()
+    torch.cuda.synchronize(dev)
+    sec = start.elapsed_time(stop) / 1e3 / (ring * passes)
+    del graph, keep, sets
+    return sec, {"footprint_bytes": int(foot), "ring": ring, "between_uses_bytes": int(foot * (ring - 1))}
 
 
 def _pmc_commit():
@@ -279,11 +354,12 @@ def recorded_cost_volume(dev, B, H_in, W_in, half, seed=5):
     for name, c1, c2 in zip(LEVELS, s1, s2):
         xyz1, feat1 = c1[1][0], c1[1][1]
         out[name] = dict(run1=(lambda c=c1: fused.cv_stage1(*c[1], **c[2])), run2=(lambda c=c2: fused.cv_stage2(*c[1], **c[2])),
+                         call1=(fused.cv_stage1, c1[1], c1[2]), call2=(fused.cv_stage2, c2[1], c2[2]),
                          N=xyz1.shape[1], C=feat1.shape[-1], Kq=c1[2]["K"], Kp=c2[2]["K"], riders=c1[3])
     return out
 
 
-def cost_volume_leg(dev, B, H_in, W_in, half, reps=20):
+def cost_volume_leg(dev, B, H_in, W_in, half, reps=20, cold=True):
     """SURVEY 8(d)'s cost-volume figure ON THE PATH THE VALUE RUNS: the eight fused launches (stage 1 + stage 2 at
     l2_origin, l2, l1, l0; from 24.6 k rows on a stage is a grouping pre-pass + the register-resident kernel, timed
     together) of one forward at batch B ON THAT FORWARD'S OWN TENSORS (recorded_cost_volume), each timed with HIP events;
@@ -293,25 +369,34 @@ def cost_volume_leg(dev, B, H_in, W_in, half, reps=20):
     vector work, `mfma` (executed fp16 products against the 2.5 PFLOP/s fp16 peak)."""
     s = 2 if half else 4
     rec = recorded_cost_volume(dev, B, H_in, W_in, half)
-    levels, tot_b, tot_s, tot_f = {}, 0, 0.0, 0
+    levels, tot_b, tot_s, tot_w, tot_f = {}, 0, 0.0, 0.0, 0
     for lv in ("l0", "l1", "l2", "l2_origin"):
         L = rec[lv]
-        t1, t2 = _time_launches(L["run1"], dev, reps), _time_launches(L["run2"], dev, reps)
+        w1, w2 = _time_launches(L["run1"], dev, reps), _time_launches(L["run2"], dev, reps)
+        (t1, r1), (t2, r2) = (_time_ring(*L["call1"], dev), _time_ring(*L["call2"], dev)) if cold else ((w1, {}), (w2, {}))
         cb = cost_volume_bytes(L["N"], L["C"], L["Kq"], L["Kp"], s)
         b1, b2 = (cb["A1"] + cb["P1"]) * B, (cb["A2"] + cb["P2"]) * B
         fl = (cv1_flops(L["N"], L["C"], L["Kq"]) + cv2_flops(L["N"], L["C"], L["Kp"])) * B
-        levels[lv] = {"cv1_us": round(t1 * 1e6, 2), "cv2_us": round(t2 * 1e6, 2), "bytes": int(b1 + b2),
-                      "GBps": round((b1 + b2) / (t1 + t2) / 1e9, 1), "frac": round((b1 + b2) / (t1 + t2) / 1e9 / HBM_PEAK_GBS, 4)}
-        tot_b, tot_s, tot_f = tot_b + b1 + b2, tot_s + t1 + t2, tot_f + fl
+        levels[lv] = {"cv1_us": round(t1 * 1e6, 2), "cv2_us": round(t2 * 1e6, 2), "cv1_us_warm": round(w1 * 1e6, 2), "cv2_us_warm": round(w2 * 1e6, 2),
+                      "bytes": int(b1 + b2), "GBps": round((b1 + b2) / (t1 + t2) / 1e9, 1),
+                      "frac": round((b1 + b2) / (t1 + t2) / 1e9 / HBM_PEAK_GBS, 4), "frac_warm": round((b1 + b2) / (w1 + w2) / 1e9 / HBM_PEAK_GBS, 4)}
+        if cold:
+            levels[lv]["footprint_bytes"] = [r1["footprint_bytes"], r2["footprint_bytes"]]
+            levels[lv]["between_uses_bytes"] = min(r1["between_uses_bytes"], r2["between_uses_bytes"])
+        tot_b, tot_s, tot_w, tot_f = tot_b + b1 + b2, tot_s + t1 + t2, tot_w + w1 + w2, tot_f + fl
     gbs = tot_b / tot_s / 1e9
     tfs = MFMA_PRODUCTS * tot_f / tot_s / 1e12
-    return {"kernel": "cost-volume stage 1 + stage 2 at l0, l1, l2, l2_origin (the launches of one forward, on its own tensors)",
-            "batch": B, "features": "f16" if half else "f32", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b), "us": round(tot_s * 1e6, 2),
-            "target_us_at_60pct": round(tot_b / (0.6 * HBM_PEAK_GBS * 1e9) * 1e6, 1),
-            "mfma": {"executed_TFLOPs": round(tfs, 1), "peak": F16_MFMA_PEAK_TFLOPS,
-                     "frac": round(tfs / F16_MFMA_PEAK_TFLOPS, 5), "issued_as": "v_mfma_f32_16x16x32_f16 x3 per 32-k pair (v_mfma_f32_16x16x16_f16 x3 on a 16-k tail)"},
-            "levels": levels}
+    out = {"kernel": "cost-volume stage 1 + stage 2 at l0, l1, l2, l2_origin (the launches of one forward, on its own tensors)",
+           "batch": B, "features": "f16" if half else "f32", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b), "us": round(tot_s * 1e6, 2),
+           "frac_warm": round(tot_b / tot_w / 1e9 / HBM_PEAK_GBS, 5), "us_warm": round(tot_w * 1e6, 2),
+           "target_us_at_60pct": round(tot_b / (0.6 * HBM_PEAK_GBS * 1e9) * 1e6, 1),
+           "mfma": {"executed_TFLOPs": round(tfs, 1), "peak": F16_MFMA_PEAK_TFLOPS,
+                    "frac": round(tfs / F16_MFMA_PEAK_TFLOPS, 5), "issued_as": "v_mfma_f32_16x16x32_f16 x3 per 32-k pair (v_mfma_f32_16x16x16_f16 x3 on a 16-k tail)"},
+           "levels": levels}
+    if cold:
+        out.update(frac_cold=out["frac"], us_cold=out["us"], reading=COLD_NOTE)
+    return out
 
 
 # the four cost volumes of a 64 x 1800 forward: grid, feature channels, stage-1 neighbours, stage-1 window (pwclo_model.py:170,
@@ -330,15 +415,21 @@ def per_operator_all_levels_leg(dev, batch, half, table=None):
     table = table or PER_OPERATOR_LEVELS
     levels = {lv: per_operator_leg(dev, batch, half, level=lv, table=table) for lv in table}
     tot_b, tot_us = sum(r["bytes"] for r in levels.values()), sum(r["us"] for r in levels.values())
+    tot_w = sum(r["us_warm"] for r in levels.values())
     gbs = tot_b / tot_us / 1e3
     return {"kernel": "ELO_FUSED=0 cost volume, all four levels: 4 x (cv_encode1 + softmax_pool + cv_encode2 + softmax_pool)",
             "batch": batch, "features": "f16" if half else "f32", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b), "us": round(tot_us, 2),
+            "frac_cold": round(gbs / HBM_PEAK_GBS, 5), "us_cold": round(tot_us, 2),
+            "frac_warm": round(tot_b / tot_w / 1e3 / HBM_PEAK_GBS, 5), "us_warm": round(tot_w, 2), "reading": COLD_NOTE,
             "target_us_at_60pct": round(tot_b / (0.6 * HBM_PEAK_GBS * 1e3), 1),
-            "levels": {lv: {"us": r["us"], "bytes": r["bytes"], "frac": r["frac"]} for lv, r in levels.items()}}
+            "levels": {lv: {"us": r["us"], "us_warm": r["us_warm"], "bytes": r["bytes"], "frac": r["frac"], "frac_warm": r["frac_warm"],
+                            "terms_frac_cold": {t: v["frac"] for t, v in r["terms"].items()},
+                            "between_uses_bytes": min(v["between_uses_bytes"] for v in r["terms"].values())}
+                       for lv, r in levels.items()}}
 
 
-def per_operator_leg(dev, batch, half, reps=20, level="l0", table=None):
+def per_operator_leg(dev, batch, half, reps=20, level="l0", table=None, cold=True):
     """The four HBM-bound kernels of the ELO_FUSED=0 cost volume at one level (default l0) (SURVEY 8(d) terms A1, P1, A2, P2:
     gather/encode and masked softmax pooling with the GEMMs between them left to hipBLASLt), each against its own
     algorithmic bytes.  `table`: the level shapes (PER_OPERATOR_LEVELS, or PER_OPERATOR_LEVELS_HIRES for configs[4]'s scans)."""
@@ -362,20 +453,33 @@ def per_operator_leg(dev, batch, half, reps=20, level="l0", table=None):
     cost = cast(torch.randn((batch, H, W, 64), generator=g).to(dev))
     lq, vq = (cast(torch.randn((batch, N, Kq, 64), generator=g).to(dev)) for _ in range(2))
     lp, vp = (cast(torch.randn((batch, N, Kp, 64), generator=g).to(dev)) for _ in range(2))
-    legs = {"A1": lambda: ops.cv_encode1(x1.reshape(batch, N, 3), ft1.reshape(batch, N, C), x2, ft2, idx_q, m_q),
-            "P1": lambda: ops.masked_softmax_pool(lq, vq, m_q),
-            "A2": lambda: ops.cv_encode2(x1, ft1, cost, idx_p, m_p),
-            "P2": lambda: ops.masked_softmax_pool(lp, vp, m_p)}
-    terms, tot_b, tot_s = {}, 0, 0.0
-    for term, fn in legs.items():
-        sec = _time_launches(fn, dev, reps)
+    legs = {"A1": (ops.cv_encode1, (x1.reshape(batch, N, 3), ft1.reshape(batch, N, C), x2, ft2, idx_q, m_q)),
+            "P1": (ops.masked_softmax_pool, (lq, vq, m_q)),
+            "A2": (ops.cv_encode2, (x1, ft1, cost, idx_p, m_p)),
+            "P2": (ops.masked_softmax_pool, (lp, vp, m_p))}
+    terms, tot_b, tot_w, tot_c = {}, 0, 0.0, 0.0
+    for term, (fn, a) in legs.items():
+        warm = _time_launches(lambda: fn(*a), dev, reps)
+        cold_s, ring = _time_ring(fn, a, None, dev) if cold else (warm, {})
         nbytes = cvb[term] * batch
-        terms[term] = {"bytes": int(nbytes), "us": round(sec * 1e6, 2), "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4)}
-        tot_b, tot_s = tot_b + nbytes, tot_s + sec
-    gbs = tot_b / tot_s / 1e9
-    return {"kernel": "ELO_FUSED=0 cost volume at %s (%dx%d grid): cv_encode1 + softmax_pool + cv_encode2 + softmax_pool" % (level, H, W), "batch": batch,
-            "features": "f16" if half else "f32", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b), "us": round(tot_s * 1e6, 2), "terms": terms}
+        terms[term] = {"bytes": int(nbytes), "us": round(cold_s * 1e6, 2), "frac": round(nbytes / cold_s / 1e9 / HBM_PEAK_GBS, 4),
+                       "us_warm": round(warm * 1e6, 2), "frac_warm": round(nbytes / warm / 1e9 / HBM_PEAK_GBS, 4)}
+        if cold:
+            terms[term].update(us_cold=terms[term]["us"], frac_cold=terms[term]["frac"], **ring)
+        tot_b, tot_w, tot_c = tot_b + nbytes, tot_w + warm, tot_c + cold_s
+    gbs, gbs_w = tot_b / tot_c / 1e9, tot_b / tot_w / 1e9
+    out = {"kernel": "ELO_FUSED=0 cost volume at %s (%dx%d grid): cv_encode1 + softmax_pool + cv_encode2 + softmax_pool" % (level, H, W), "batch": batch,
+           "features": "f16" if half else "f32", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": int(tot_b), "us": round(tot_c * 1e6, 2),
+           "frac_warm": round(gbs_w / HBM_PEAK_GBS, 5), "us_warm": round(tot_w * 1e6, 2), "terms": terms}
+    if cold:
+        out.update(frac_cold=out["frac"], us_cold=out["us"], reading=COLD_NOTE)
+    return out
+
+
+COLD_NOTE = ("frac / us / frac_cold = COLD: every launch on its own tensor set of a ring with >= 2 x 256 MB (Infinity Cache) of other "
+             "sets' traffic between two uses of a set -- inputs come from HBM; frac_warm = 20 back-to-back launches on ONE set "
+             "(Infinity-Cache resident below 256 MB: not an HBM reading)")
 
 
 def roofline_leg(args, dev, net, reps=50):
@@ -392,6 +496,7 @@ def roofline_leg(args, dev, net, reps=50):
     half = args.features == "f16"
     L = recorded_cost_volume(dev, B, args.height, args.width, half)["l0"]
     sec = _time_launches(L["run1"], dev, reps)
+    cold_sec, cold_ring = _time_ring(*L["call1"], dev)
     cb = cost_volume_bytes(L["N"], L["C"], L["Kq"], L["Kp"], 2 if half else 4)
     nbytes = (cb["A1"] + cb["P1"]) * B
     flops = cv1_flops(L["N"], L["C"], L["Kq"]) * B
@@ -409,6 +514,9 @@ def roofline_leg(args, dev, net, reps=50):
            "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
            "traffic": traffic, "traffic_source": traffic_source,
            "us_per_launch": round(sec * 1e6, 3), "algorithmic_bytes_per_launch": int(nbytes),
+           # the same launch with its inputs out of every cache (ring of tensor sets, _time_ring); `frac` above is the launch as the
+           # timed loop runs it: a batch-1 pair's tensors (8 lanes x a few MB) live in L2 / the Infinity Cache
+           "frac_cold": round(nbytes / cold_sec / 1e9 / HBM_PEAK_GBS, 5), "us_per_launch_cold": round(cold_sec * 1e6, 3), "cold_ring": cold_ring,
            "carries_riders_in_the_forward": L["riders"],      # batch 1-2: the forward's launch also runs the level's two set-upconv jobs
            "in_the_forward": ("cv1_setconv_rr_kernel (this stage + the level's two set-upconv stage-1 jobs in one launch) behind group_select_k"
                               if chain and L["riders"] else "cv1_setconv_kernel (this stage + the level's two set-upconv stage-1 jobs in one launch)"
@@ -458,8 +566,9 @@ def cpu_baseline_leg(args, net):
                          r["pairs_threaded"], r["seconds"][2])}
 
 
-def batch_rate(dev, B, H, W, lanes, products, features, steps=240):
-    """frame-pairs/s of a fresh net at batch B through `lanes` captured graphs, inputs resident in HBM."""
+def batch_rate(dev, B, H, W, lanes, products, features, steps=240, ready=False):
+    """frame-pairs/s of a fresh net at batch B through `lanes` captured graphs, inputs resident in HBM (`ready`: submit()'s ordering
+    argument -- False: the caller owns it, the inputs were synchronised; None: submit()'s default, ordered behind the current stream)."""
     import torch
     model, synth, fused = pkg("model"), pkg("synth"), pkg("fused")
     with fused.products(products):
@@ -470,11 +579,11 @@ def batch_rate(dev, B, H, W, lanes, products, features, steps=240):
             pairs.append(torch.cat([torch.from_numpy(f1), torch.from_numpy(f2)], 0).to(dev))
         net.capture(B, H, W, lanes=lanes)
         for i in range(2 * lanes):
-            net.submit(i % lanes, pairs[i % 4])
+            net.submit(i % lanes, pairs[i % 4], ready=ready)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for i in range(steps):
-            net.submit(i % lanes, pairs[i % 4])
+            net.submit(i % lanes, pairs[i % 4], ready=ready)
         torch.cuda.synchronize(dev)
         return round(B * steps / (time.perf_counter() - t0), 1)
 
@@ -498,11 +607,11 @@ def raw_cloud_rate(dev, B, H, W, lanes, points=150000, steps=400):
         clouds.append(torch.from_numpy(c).to(dev))
     net.capture(B, H, W, lanes=lanes, num_points=points)
     for i in range(2 * lanes):
-        net.submit_points(i % lanes, clouds[i % 4])
+        net.submit_points(i % lanes, clouds[i % 4], ready=False)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(steps):
-        net.submit_points(i % lanes, clouds[i % 4])
+        net.submit_points(i % lanes, clouds[i % 4], ready=False)
     torch.cuda.synchronize(dev)
     return round(B * steps / (time.perf_counter() - t0), 1)
 
@@ -522,7 +631,7 @@ def hires_leg(dev, lanes):
             "batch1": batch_rate(dev, 1, H, W, lanes, "split", "f32", steps=160),
             "batch8_f32": batch_rate(dev, 8, H, W, lanes, "split", "f32", steps=48),
             "batch8_f16_features": batch_rate(dev, 8, H, W, lanes, "split", "f16", steps=48),
-            "cost_volume_b8_f16": {k: cv[k] for k in ("us", "bytes", "frac", "levels", "mfma")},
+            "cost_volume_b8_f16": {k: cv[k] for k in ("us", "bytes", "frac", "frac_cold", "frac_warm", "us_warm", "levels", "mfma")},
             "lds_bytes_per_workgroup": lds, "workgroups_per_cu_by_lds": {k: min(160 * 1024 // v, 32) for k, v in lds.items()}}
 
 
@@ -542,12 +651,13 @@ def dense_f32_leg(args):
         return {"value": None, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
-def train_dp_leg(args, dev, rank, world, dist):
+def train_dp_leg(args, dev, rank, world, dist, group=None):
     """BASELINE configs[3]'s exchange under a clock: per-GPU batch 8, one optimisation step = zero grads -> forward
     (batch-statistics BN, dropout) -> get_loss -> backward -> ONE all-reduce of the flat 899 134-float gradient bucket
     (RCCL over xGMI when world > 1) -> Adam (main.py:344-397 + SURVEY 8(e)), captured as hipGraphs around the eager
     collective (training.Trainer.step_graph).  All ranks run it; barrier + synchronize on both sides, MAX over ranks."""
     import torch
+    group = world > 1 if group is None else group
     model, training, synth, mu = pkg("model"), pkg("training"), pkg("synth"), pkg("model_util")
     B, H, W = 8, args.height, args.width
     net = model.PWCLONet(dev, seed=0)
@@ -561,16 +671,16 @@ def train_dp_leg(args, dev, rank, world, dist):
     for _ in range(2):
         tr.step_graph(a, b, q_gt, t_gt)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if group:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.train_steps):
         loss = tr.step_graph(a, b, q_gt, t_gt)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if group:
         dist.barrier()
     el = time.perf_counter() - t0
-    if world > 1:
+    if group:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -579,7 +689,7 @@ def train_dp_leg(args, dev, rank, world, dist):
             "batch_per_gpu": B, "steps": args.train_steps, "ms_per_step": round(el / args.train_steps * 1e3, 3),
             "collective": "one all_reduce(SUM) of the flat gradient bucket per step, %d floats = %.2f MB, backend %s"
                           % (tr.bucket.flat.numel(), tr.bucket.flat.numel() * 4 / 1e6,
-                             dist.get_backend() if world > 1 else "none (1 rank)")}
+                             dist.get_backend() if group else "none (1 rank)")}
 
 
 # ----------------------------------------------------------------------------- multi-rank evidence (N > 1)
@@ -700,8 +810,14 @@ def main():
     numa = pin_to_numa_node(torch, local) if (not dry and world > 1) else {"numa_node": None}
     backend = None
     sync = (lambda: None) if dry else (lambda: torch.cuda.synchronize(dev))
-    if world > 1:
+    # ELO_BENCH_FORCE_DIST=1: a ONE-rank process group -- on a 1-GPU box the whole distributed path of this file
+    # (init_process_group("nccl", device_id=...), the barriers, the pose all-gather inside the timed region, the flat-bucket
+    # all-reduce of train_dp and rccl_leg, parse_rccl_log on the live NCCL_DEBUG_FILE) runs through RCCL itself
+    group = world > 1 or os.environ.get("ELO_BENCH_FORCE_DIST") == "1"
+    if group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         backend = os.environ.get("ELO_BENCH_BACKEND", "gloo" if dry else "nccl")          # nccl == RCCL on ROCm
         if backend == "nccl":
             os.environ.setdefault("NCCL_DEBUG", "INFO")                                   # ring / tree choice and the transport
@@ -755,13 +871,15 @@ def main():
                 net.lane_input(lane).copy_(pool[lane % len(pool)])
             sync()
 
+        ready = False if args.submit_order == "caller" else None
+
         def step(i):
             pair = pool[i % len(pool)]
             if args.no_graph:                            # the l0 pose-head kernel writes the log row itself
                 return net.forward(pair[:B], pair[B:], pose_out=pose_log[i])
             if args.inputs == "in-place":                # the lane's buffer holds its pair (filled before the timed region)
-                return net.submit(i % lanes)
-            return net.submit(i % lanes, pair)           # step i rides lane i % lanes: one copy in (the stacked pair), graph replay
+                return net.submit(i % lanes, ready=ready)
+            return net.submit(i % lanes, pair, ready=ready)   # step i rides lane i % lanes: one copy in (the stacked pair), graph replay
 
         def begin_repeat(reset=False):
             if not args.no_graph:
@@ -773,7 +891,7 @@ def main():
                 for lane in range(min(lanes, n)):
                     with torch.cuda.stream(net.lane_stream(lane)):
                         pose_log[lane:n:lanes].copy_(net.lane_poses(lane), non_blocking=True)
-    gathered = [torch.empty_like(pose_log[:args.steps]) for _ in range(world)] if world > 1 else None
+    gathered = [torch.empty_like(pose_log[:args.steps]) for _ in range(world)] if group else None
 
     # Host submission.  A step costs the host ~50 us (one copy + one graph launch), so with one submitting thread the four
     # hardware queues receive their first forward of a repeat 50 us apart -- at the driver's 20 steps per repeat (2 ms) the
@@ -823,24 +941,24 @@ def main():
     sync()
     begin_repeat(reset=True)                              # (untimed: the rings start the timed repeats at slot 0)
     sync()
-    if world > 1:
+    if group:
         dist.all_gather(gathered, pose_log[:args.steps].contiguous())     # untimed: RCCL sets its channels up on first use
     repeats, total = [], 0.0
     while total < MIN_TIMED_S and len(repeats) < 200:
         sync()
-        if world > 1:
+        if group:
             dist.barrier()
         t0 = time.perf_counter()
         begin_repeat()
         submit_all(args.steps)
         end_repeat(args.steps)
         sync()
-        if world > 1:
+        if group:
             dist.all_gather(gathered, pose_log[:args.steps].contiguous())
             sync()
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        if world > 1:                                     # the clock of a repeat is its slowest rank
+        if group:                                     # the clock of a repeat is its slowest rank
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -871,8 +989,10 @@ def main():
                                "set-upconv), %dx%d range-image pairs, batch %d per GPU, %s feature storage, "
                                "random-init weights, %s" % (H, W, B, "fp16" if args.features == "f16" else "fp32",
                                                            "eager launches" if args.no_graph else
-                                                           "hipGraph replay, %d forwards in flight fed by %d host thread%s%s" % (
-                                                               lanes, nthreads, "s" if nthreads > 1 else "", ", fresh visiting orders per replay (pool of %d)" % args.fresh_orders
+                                                           "hipGraph replay, %d forwards in flight fed by %d host thread%s (%s)%s" % (
+                                                               lanes, nthreads, "s" if nthreads > 1 else "",
+                                                               "submit ready=False: inputs resident and synchronised, the bench owns the ordering" if args.submit_order == "caller"
+                                                               else "submit()'s default ordering behind the current stream", ", fresh visiting orders per replay (pool of %d)" % args.fresh_orders
                                                                if args.fresh_orders else ", one fixed draw of the visiting orders")),
                    "global_batch": B * world, "parallelism": "dp%d" % world,
                    # every choice of kernel form, as the value the timed graphs were captured under (efficientlo-net_amd/tuning.py)
@@ -884,7 +1004,7 @@ def main():
         assert line["range_check"]["violations"] == 0
     legs = not args.no_legs and not dry
     if legs and args.train_steps > 0 and (H, W) == (64, 1800):
-        train = train_dp_leg(args, dev, rank, world, dist)          # every rank takes part (one collective per step)
+        train = train_dp_leg(args, dev, rank, world, dist, group)          # every rank takes part (one collective per step)
         line["train_dp"] = train
     if legs and rank == 0 and world == 1:
         line["roofline"] = roofline_leg(args, dev, net)
@@ -899,14 +1019,19 @@ def main():
                               "f32": batch_rate(dev, 8, H, W, lanes, "split", "f32"),
                               "f16_features": batch_rate(dev, 8, H, W, lanes, "split", "f16"),
                               "f16_features_f16_products": batch_rate(dev, 8, H, W, lanes, "half", "f16")}
+            # submit()'s DEFAULT (ordered behind the caller's current stream + record_stream) against the unordered fast path the timed
+            # loop uses, same lanes, saturated (240 steps between two synchronisations)
+            line["submit_ordering"] = {"unit": "frame-pairs/s", "batch": 1, "steps": 240,
+                                       "caller_owned_ready_False": batch_rate(dev, 1, H, W, lanes, "split", "f32"),
+                                       "default_ordered": batch_rate(dev, 1, H, W, lanes, "split", "f32", ready=None)}
             line["hires"] = hires_leg(dev, lanes)
             if os.environ.get("ELO_DENSE_F32") != "1":
                 line["dense_f32"] = dense_f32_leg(args)
-    if world > 1:                                         # every rank takes part; rank 0 reports
+    if group:                                         # every rank takes part; rank 0 reports
         line["rccl"] = rccl_leg(dist, dev, backend, world, rank, pose_log[:args.steps].contiguous(), numa)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if group:
         dist.destroy_process_group()
 
 

@@ -119,6 +119,10 @@ PoseLossArgs = _struct("elo_pose_loss_args", [
 WeightGradArgs = _struct("elo_weight_grad_args", [
     ("rows", ctypes.c_long), ("Cin", _i), ("Cout", _i), ("x", _vp), ("g", _vp), ("dW", _vp), ("db", _vp), ("scratch", _vp)])
 BN_MAX_PARTS = 512     # ELO_BN_MAX_PARTS
+BN_REPLICAS = 8        # ELO_BN_REPLICAS
+BnForwardArgs = _struct("elo_bn_forward_args", [
+    ("rows", ctypes.c_long), ("C", _i), ("z", _vp), ("acc", _vp), ("eps", _f), ("momentum", _f), ("gamma", _vp), ("beta", _vp), ("relu", _i),
+    ("mean", _vp), ("invstd", _vp), ("running_mean", _vp), ("running_var", _vp), ("y", _vp)])
 
 Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i), ("w_plain", _vp),
                               ("products", _i)])
@@ -150,7 +154,7 @@ Cv2Args = _struct("elo_cv2_args", [
     ("pre_c", _vp), ("pre_s", _vp)])
 Tuning = _struct("elo_tuning", [
     ("chain_forms", _i), ("narrow_mfma", _i), ("range_check", _i), ("select_dense_waves", _i), ("random_dense_rows", _i),
-    ("encode1_slots", _i), ("setconv_chain_rows", _l), ("mlp_chain_rows", _l), ("small_tile_units", _l), ("tiled_setconv", _i)])
+    ("encode1_slots", _i), ("setconv_chain_rows", _l), ("mlp_chain_rows", _l), ("small_tile_units", _l), ("tiled_setconv", _i), ("pool_wave", _i)])
 RowlinearArgs = _struct("elo_rowlinear_args", [
     ("rows", _l), ("C", _i), ("src", _vp), ("layer", Dense), ("out", _vp), ("feat_dtype", _i)])
 
@@ -194,6 +198,10 @@ SYMBOLS = [
     ("elo_pose_compose", ctypes.c_int, [ctypes.POINTER(PoseComposeArgs), _vp]),
     ("elo_pose_loss", ctypes.c_int, [ctypes.POINTER(PoseLossArgs), _vp]),
     ("elo_weight_grad_slices", ctypes.c_int, [ctypes.c_long, ctypes.c_int, ctypes.c_int]),
+    ("elo_weight_grad_atomic", ctypes.c_int, [ctypes.c_long, ctypes.c_int, ctypes.c_int]),
+    ("elo_dense_weight_grad_acc", ctypes.c_int, [ctypes.POINTER(WeightGradArgs), _vp]),
+    ("elo_bn_forward", ctypes.c_int, [ctypes.POINTER(BnForwardArgs), _vp]),
+    ("elo_bn_backward_acc", ctypes.c_int, [ctypes.POINTER(BnBackwardArgs), _vp]),
     ("elo_setconv_fused", ctypes.c_int, [ctypes.POINTER(SetconvArgs), _vp]),
     ("elo_mlp_fused", ctypes.c_int, [ctypes.POINTER(MlpArgs), _vp]),
     ("elo_setconv_fused2", ctypes.c_int, [ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
@@ -207,7 +215,8 @@ SYMBOLS = [
     ("elo_debug_narrow_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_debug_rowlinear_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_debug_sv_ride_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
-    ("elo_graph_submit", ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_ulong]),
+    ("elo_get_tuning_base", ctypes.c_int, [ctypes.POINTER(Tuning)]),
+    ("elo_graph_submit", ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_ulong, _vp, _vp, ctypes.c_int]),
     ("elo_debug_chain_pair_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_cv_stage1_setconv_chain_form", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs)]),
     ("elo_cv_stage1_setconv_chain", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
@@ -225,7 +234,7 @@ class EloError(RuntimeError):
     pass
 
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 
 def lib():
@@ -257,10 +266,19 @@ def get_tuning():
     return {name: int(getattr(t, name)) for name, _ in Tuning._fields_}
 
 
-def set_tuning(**fields):
-    """Change fields of the library's elo_tuning (the others keep their value); raises on a value outside its domain."""
+def get_tuning_base():
+    """What elo_set_tuning last installed (without pending elo_debug_* overrides)."""
     t = Tuning()
-    check(lib().elo_get_tuning(ctypes.byref(t)))
+    check(lib().elo_get_tuning_base(ctypes.byref(t)))
+    return {name: int(getattr(t, name)) for name, _ in Tuning._fields_}
+
+
+def set_tuning(**fields):
+    """Change fields of the library's elo_tuning (the others keep their value); raises on a value outside its domain.
+    The read-modify-write starts from what elo_set_tuning last installed (elo_get_tuning_base), not from the launchers' view: a pending
+    elo_debug_* override is not promoted into the base by an unrelated change."""
+    t = Tuning()
+    check(lib().elo_get_tuning_base(ctypes.byref(t)))
     for name, value in fields.items():
         if not hasattr(t, name):
             raise KeyError("elo_tuning has no field %r" % name)

@@ -443,6 +443,72 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_vec_kernel(const elo_s
                  &reinterpret_cast<V4 *>(static_cast<T *>(a.out) + r * a.C)[sub]);
 }
 
+// Wave-per-point form for C = 64 (every pooled width of the model), round 6: the quarter-wave form above keeps 2 x U 16-byte loads
+// in flight PER LANE and issues them in one burst per workgroup -- the access shape tools/micro/hbm_probe.hip measures at 0.54 of
+// 8 TB/s from HBM-cold data (one-shot, 8 loads per thread), where one light load per thread reaches 0.81.  Here the 64 lanes of a
+// wave share ONE (b,n) point: lane (g = lane / 16, sub = lane % 16) owns 4 channels of the neighbours k = g, g + 4, g + 8, ...
+// (K = 6: two loads per tensor and lane, K = 4: one), so a wave's load instruction covers four whole neighbour rows of one point
+// and there are four times as many, four times lighter waves.  Two-pass softmax exactly as written in the reference (max over K,
+// exponentials against it, sum): the per-lane maxima / sums meet through two DPP-class butterfly steps over the four lane groups.
+// Loads are nontemporal (every byte is read once).  Same arithmetic contract as the quarter-wave form (fp32, hardware exp2).
+template <class T, int J>                           // J = ceil(K / 4) neighbour rows per lane group
+__global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_wave_kernel(const elo_softmax_pool_args a, const long rows)
+{
+    typedef typename Store<T>::V4 V4;
+    const int lane = threadIdx.x & 63, g = lane >> 4, sub = lane & 15;
+    const long r = (long)xcd_tile(blockIdx.x, gridDim.x) * (ELO_BLOCK / 64) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const V4 *lg = reinterpret_cast<const V4 *>(static_cast<const T *>(a.logits) + r * a.K * 64) + sub;
+    const V4 *vl = reinterpret_cast<const V4 *>(static_cast<const T *>(a.values) + r * a.K * (long)a.values_stride) + sub;
+    const int vstep = a.values_stride >> 2;
+    const float *m = a.mask + r * a.K;
+    V4 l4[J], v4[J];
+    float mk[J];
+    bool live[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = g + 4 * j;
+        live[j] = k < a.K;
+        const int kc = live[j] ? k : 0;
+        l4[j] = __builtin_nontemporal_load(lg + (long)kc * 16);
+        v4[j] = __builtin_nontemporal_load(vl + (long)kc * vstep);
+        mk[j] = m[kc];
+    }
+    auto ex = [](float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896f); };
+    float lv[J][4], mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            lv[j][c] = !live[j] ? -INFINITY : mk[j] == 1.0f ? (float)l4[j][c] : -1e10f;
+            mx[c] = fmaxf(mx[c], lv[j][c]);
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], 16, 64));
+        mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], 32, 64));
+    }
+    float den[4] = {0, 0, 0, 0}, acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float e = live[j] ? ex(lv[j][c] - mx[c]) : 0.0f;
+            den[c] += e;
+            acc[c] += e * (float)v4[j][c];
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        den[c] += __shfl_xor(den[c], 16, 64);
+        den[c] += __shfl_xor(den[c], 32, 64);
+        acc[c] += __shfl_xor(acc[c], 16, 64);
+        acc[c] += __shfl_xor(acc[c], 32, 64);
+    }
+    if (g == 0)
+        STREAM_STORE((V4{(T)(acc[0] / den[0]), (T)(acc[1] / den[1]), (T)(acc[2] / den[2]), (T)(acc[3] / den[3])}),
+                     &reinterpret_cast<V4 *>(static_cast<T *>(a.out) + r * 64)[sub]);
+}
+
 // scalar form for any C / alignment
 __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_kernel(const elo_softmax_pool_args a, const long rows)
 {
@@ -1122,6 +1188,22 @@ extern "C" int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_strea
     const bool vec = a->C % 4 == 0 && a->C <= 1024 && ELO_BLOCK % (a->C / 4) == 0 && a->values_stride % 4 == 0 &&
                      ((uintptr_t)a->logits | (uintptr_t)a->values | (uintptr_t)a->out) % (4 * esz) == 0;
     if (a->dtype == ELO_F16 && !vec) return fail(ELO_ERR_ARG, "%s: fp16 needs C % 4 == 0 and 8-byte aligned tensors", who);
+    if (vec && a->C == 64 && a->K <= 32 && tuning().pool_wave) {        // wave per point (round 6): light loads, 4 x the waves
+        const dim3 grid((unsigned)((rows + ELO_BLOCK / 64 - 1) / (ELO_BLOCK / 64)));
+        hipStream_t s = (hipStream_t)stream;
+        const int J = (a->K + 3) / 4;
+#define ELO_POOL_WAVE(J_)                                                                                                          \
+        do {                                                                                                                      \
+            if (a->dtype == ELO_F16) hipLaunchKernelGGL((softmax_pool_wave_kernel<half_t, J_>), grid, dim3(ELO_BLOCK), 0, s, *a, rows); \
+            else hipLaunchKernelGGL((softmax_pool_wave_kernel<float, J_>), grid, dim3(ELO_BLOCK), 0, s, *a, rows);                \
+        } while (0)
+        if (J == 1) ELO_POOL_WAVE(1);
+        else if (J == 2) ELO_POOL_WAVE(2);
+        else if (J <= 4) ELO_POOL_WAVE(4);
+        else ELO_POOL_WAVE(8);
+#undef ELO_POOL_WAVE
+        return check_launch(who);
+    }
     if (vec) {
         const int rows_per_block = ELO_BLOCK / (a->C / 4);
         const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));

@@ -3710,9 +3710,16 @@ static int plan_mlp(const elo_mlp_args *a, const elo_mlp_args *b, MlpPlan *p, co
     p->sv_tiles = 0;
     const int final_n = a->n_layers2 > 0 ? a->layers2[a->n_layers2 - 1].N : a->layers[a->n_layers - 1].N;
     if (!p->chain && final_n == 64 && a->sv_npoints > 0 && a->rows > 0 && a->rows % a->sv_npoints == 0) {
-        const int tile = p->t16 ? 16 : 32;
+        // the ride launches (batch x row tiles per element) workgroups -- a pair is ONE 512-thread workgroup, and an element's last tile
+        // may be ragged -- so the 16- / 32-row choice is made on THAT grid, not on the plain launch's
+        const bool t16 = small_tile((a->rows / a->sv_npoints) * (((long)a->sv_npoints + 31) / 32), 1);
+        const int tile = t16 ? 16 : 32, groups = b ? 2 : 1;
         const long tiles = ((long)a->sv_npoints + tile - 1) / tile;
-        if (tiles <= ELO_SV_MAX_PARTS) p->sv_tiles = (int)tiles;
+        const size_t lds = sizeof(float) * ((size_t)groups * tile * p->S + (b ? 0 : (size_t)tile * 64));   // (mlp_sv_kernel's dynamic LDS)
+        if (tiles <= ELO_SV_MAX_PARTS && lds <= 64 * 1024) {      // a wider generic MLP falls back on the separate partial-sums launch
+            p->sv_tiles = (int)tiles;
+            p->t16 = t16;
+        }
     }
     return ELO_OK;
 }

@@ -175,6 +175,9 @@ class PWCLONet:
             lane = {"stream": streams[i % len(streams)], "pair": both, "in": (both[:batch_size], both[batch_size:]),
                     "graph": torch.cuda.CUDAGraph(), "replays": 0,
                     "pose": _ops.PoseRing(pose_ring, batch_size, dev) if pose_ring else torch.zeros((batch_size, 7), device=dev)}
+            lane["order"] = torch.cuda.Event()        # submit()'s producer ordering: recorded on the caller's stream, waited on by the lane's
+            with torch.cuda.stream(side):
+                lane["order"].record()                # (materialises the hipEvent_t: elo_graph_submit gets the raw handle)
             if num_points is not None:
                 lane["cloud"] = torch.zeros((batch_size, 2 * num_points, point_stride), device=dev)
             if fresh_orders:                          # this lane's order buffers; caches keyed on them filled before the capture
@@ -227,8 +230,11 @@ class PWCLONet:
     @staticmethod
     def _native_submit(lane, dev):
         """What submit() hands to elo_graph_submit for this lane (tuning native_submit), or None: torch's own copy_ + replay().  Needs the
-        graphs' raw exec handles (torch >= 2.8) and the lane's device to be the thread's current one (one process per GPU)."""
-        if not tuning.get("native_submit") or dev.index != torch.cuda.current_device():
+        graphs' raw exec handles (torch >= 2.8).  The lane's device index goes along: the native call makes it current for its duration when
+        the submitting thread's current device is another one (one process per GPU is the design; a second thread need not set_device).
+        Restriction: a graph launched this way skips CUDAGraph.replay()'s generator prologue -- the inference forward draws no torch random
+        numbers (dropout is off, visiting orders are explicit inputs: perm.PermSource), so nothing is registered."""
+        if not tuning.get("native_submit"):
             return None
         from . import _lib
         try:
@@ -239,7 +245,7 @@ class PWCLONet:
         pair = lane["pair"]
         return {"submit": _lib.lib().elo_graph_submit, "exec": ctypes.c_void_p(execs[0]), "exec_checked": ctypes.c_void_p(execs[1] or execs[0]),
                 "stream": ctypes.c_void_p(lane["stream"].cuda_stream), "dst": ctypes.c_void_p(pair.data_ptr()),
-                "nbytes": pair.numel() * pair.element_size()}
+                "nbytes": pair.numel() * pair.element_size(), "event": ctypes.c_void_p(lane["order"].cuda_event), "device": int(dev.index)}
 
     def _check_fresh(self):
         """A captured graph holds raw device pointers to the folded / packed inference weights and to the decoded
@@ -309,17 +315,42 @@ class PWCLONet:
         self._check_fresh()
         return self._lanes[lane_index]["pair"]
 
-    def submit(self, lane_index, xyz_f1_proj=None, xyz_f2_proj=None):
+    def _order_lane(self, lane, ready, *inputs):
+        """submit()'s producer ordering on the torch path: the lane's stream waits for `ready` (an event the caller recorded behind
+        the producer) or, by default, for everything enqueued so far on the CURRENT stream; inputs are marked as in use on the lane's
+        stream (record_stream: the caching allocator must not hand their memory out before the lane's copy has run)."""
+        if ready is False:
+            return
+        stream = lane["stream"]
+        if ready is None or ready is True:
+            cur = torch.cuda.current_stream(self.device)
+            if cur != stream:
+                lane["order"].record(cur)
+                stream.wait_event(lane["order"])
+        else:
+            stream.wait_event(ready)
+        for x in inputs:
+            if x is not None:
+                x.record_stream(stream)
+
+    def submit(self, lane_index, xyz_f1_proj=None, xyz_f2_proj=None, ready=None):
         """Enqueue one forward on lane `lane_index` (its own stream); returns the lane's static outputs,
         valid once that stream has been synchronised (or waited on).  With `xyz_f2_proj` None the first
         argument is the stacked pair (2B,H,W,3) = [frame 1 | frame 2]: one copy instead of two; with both None the lane's
-        input buffer was written in place (lane_input): no copy."""
+        input buffer was written in place (lane_input): no copy.
+
+        ORDERING (the reference's sess.run(feed_dict=...) is synchronous, main.py:372-381; a lane is not): `ready=None` (default)
+        -- the lane's stream first waits for everything enqueued so far on the caller's CURRENT stream, so a pair uploaded
+        or computed there (or a lane_input() written in place there) is complete before the lane reads it, and the inputs are
+        record_stream()-ed on the lane's stream; `ready=<torch.cuda.Event>` -- waits for that event instead (a producer on
+        some other stream); `ready=False` -- no ordering and no record_stream: the caller owns both (inputs resident and
+        synchronised -- bench.py's pool -- or produced on the lane's own stream)."""
         self._check_fresh()
         lane = self._lanes[lane_index]
         native = lane.get("native")
-        if native is not None and xyz_f2_proj is None:
-            # the host runtime's own submit (csrc/elo_host.cpp elo_graph_submit): the copy and the graph launch as ONE native call on
-            # the lane's stream -- 16 us of host time instead of 29 through torch (tools/submit_native_probe.py)
+        if native is not None and xyz_f2_proj is None and (ready is None or isinstance(ready, bool)):
+            # the host runtime's own submit (csrc/elo_host.cpp elo_graph_submit): the ordering, the copy and the graph launch as ONE
+            # native call on the lane's stream -- 16 us of host time instead of 29 through torch (tools/submit_native_probe.py)
             pair = lane["pair"]
             if xyz_f1_proj is None:
                 src, nbytes = None, 0
@@ -334,9 +365,17 @@ class PWCLONet:
                 lane["total"] = lane.get("total", 0) + 1
                 checked = n and lane["total"] % n == 0
                 from . import _lib
-                _lib.check(native["submit"](native["exec_checked"] if checked else native["exec"], native["stream"], native["dst"], src, nbytes))
+                if ready is False:
+                    producer = event = None
+                else:
+                    producer, event = torch.cuda.current_stream(self.device).cuda_stream, native["event"]
+                    if xyz_f1_proj is not None:
+                        xyz_f1_proj.record_stream(lane["stream"])
+                _lib.check(native["submit"](native["exec_checked"] if checked else native["exec"], native["stream"], native["dst"], src, nbytes,
+                                            producer, event, native["device"]))
                 lane["replays"] += 1
                 return lane["out_checked"] if checked else lane["out"]
+        self._order_lane(lane, ready, xyz_f1_proj, xyz_f2_proj)
         with torch.cuda.stream(lane["stream"]):
             if xyz_f1_proj is None:
                 pass
@@ -348,10 +387,11 @@ class PWCLONet:
             out = self._replay_lane(lane)
         return out
 
-    def submit_points(self, lane_index, point_cloud):
-        """Enqueue one forward from raw clouds (B, 2N, stride) on a lane captured with `num_points`."""
+    def submit_points(self, lane_index, point_cloud, ready=None):
+        """Enqueue one forward from raw clouds (B, 2N, stride) on a lane captured with `num_points`.  `ready`: as submit()."""
         self._check_fresh()
         lane = self._lanes[lane_index]
+        self._order_lane(lane, ready, point_cloud)
         with torch.cuda.stream(lane["stream"]):
             lane["cloud"].copy_(point_cloud, non_blocking=True)
             out = self._replay_lane(lane)

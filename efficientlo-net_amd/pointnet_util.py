@@ -29,19 +29,15 @@ from .perm import random_shuffle
 
 # Inference uses the fused "gather -> conv chain -> pool" kernels (csrc/elo_fused.hip); ELO_FUSED=0 or
 # use_fused(False) selects the per-operator kernels + hipBLASLt GEMMs instead (same results to ~1e-6).
-_FUSED = tuning.get("fused")                       # (tuning.py: ELO_FUSED, read once)
-
-
+# The switch is tuning's host field "fused" (ELO_FUSED), read at the point of use: tuning.override(fused=...) and use_fused agree.
 def use_fused(flag):
-    global _FUSED
-    _FUSED = bool(flag)
-    tuning.set_host("fused", _FUSED)
+    tuning.set_host("fused", bool(flag))
 
 
 def _fused_path(is_training):
     """The implementation is chosen by the CALLER's `is_training` (as in the reference, where it selects batch statistics
     and dropout), never by the global autograd mode: inference under torch.enable_grad() stays on the fused kernels."""
-    return _FUSED and not is_training
+    return tuning.get("fused") and not is_training
 
 
 # ---- fp16 feature STORAGE on the per-operator path (BASELINE configs[2] with ELO_FUSED=0) ---------------------------

@@ -109,18 +109,14 @@ def set_concurrent_branches(flag):
 # embedding and embedding-mask set-upconv) and its two predictors are ~35 conv + batch-norm layers of ten launch-bound
 # kernels each, with their own variables and moving statistics -- nothing shared but inputs; autograd runs each branch's
 # backward on the stream its forward ran on.
-_CONCURRENT_TRAIN = tuning.get("train_branches")
-
-
 def set_training_branches(flag):
-    global _CONCURRENT_TRAIN
-    _CONCURRENT_TRAIN = bool(flag)
+    tuning.set_host("train_branches", bool(flag))         # (read at the point of use: tuning.override(train_branches=...) agrees)
 
 
 def _parallel(branches, is_training=False):
     """Run independent closures on forked streams and join; results in order.  Sequential on CPU tensors or when switched
     off (inference: set_concurrent_branches; training: set_training_branches)."""
-    on = _CONCURRENT_TRAIN if is_training else _CONCURRENT
+    on = tuning.get("train_branches") if is_training else _CONCURRENT
     if not on or len(branches) < 2 or not torch.cuda.is_available():
         return [b() for b in branches]
     dev = torch.cuda.current_device()

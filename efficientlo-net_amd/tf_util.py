@@ -29,7 +29,7 @@ import torch.nn.functional as Fnn
 
 from . import _ops, tuning
 
-_TRAIN_KERNELS = tuning.get("train_kernels")     # 0: torch's batch norm + GEMM weight gradients (comparison)
+# tuning "train_kernels" (ELO_TRAIN_KERNELS; False: torch's batch norm + GEMM weight gradients, the comparison) is read at the point of use
 BN_EPS = 1e-3            # tf.contrib.layers.batch_norm default (utils/tf_util.py:526-531)
 _DEFAULT_BN_DECAY = 0.9  # utils/tf_util.py:525
 
@@ -191,7 +191,7 @@ def _dense(inputs, num_output_channels, scope, tf_kernel_dims, activation_fn, bn
     training = bool(is_training) if is_training is not None else False
     if training:                                 # batch statistics, autograd (the caller's is_training decides, not the autograd mode)
         decay = _DEFAULT_BN_DECAY if bn_decay is None else float(bn_decay)
-        if (bn and _TRAIN_KERNELS and (activation_fn is relu or activation_fn is None)
+        if (bn and tuning.get("train_kernels") and (activation_fn is relu or activation_fn is None)
                 and _ops.dense_bn_supported(x2, num_output_channels)):
             # the row reductions of conv -> batch norm -> ReLU on hand-written kernels (csrc/elo_train.hip)
             y = _ops.dense_bn(x2, W, b, bn_vars[0], bn_vars[1], bn_vars[2], bn_vars[3], 1.0 - decay, BN_EPS,

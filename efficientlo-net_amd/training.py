@@ -11,7 +11,7 @@ import os
 import numpy as np
 import torch
 
-from . import perm, pwclo_model, tf_checkpoint, tf_util
+from . import _lib, _ops, perm, pwclo_model, tf_checkpoint, tf_util
 from .distributed import FlatGradBucket
 
 BASE_LEARNING_RATE, DECAY_STEP, DECAY_RATE = 0.001, 200000, 0.7          # main.py:46-51
@@ -156,6 +156,9 @@ class Trainer:
         self.params = net.store.parameters() + [self.w_x, self.w_q]      # 382 tensors, 899 134 values
         self.bucket = FlatGradBucket(self.params)
         self.opt = FlatAdam(self.params, self.bucket, lr=BASE_LEARNING_RATE)   # main.py:174; one launch per step, capturable as it is
+        # the zeroed accumulators of a step's reductions (batch-norm replica sums, few-slice weight gradients): one memset per step
+        n_acc = sum(p.numel() for p in self.params) + 4 * _lib.BN_REPLICAS * 2 * sum(p.numel() for p in self.params if p.dim() == 1)
+        self.arena = _ops.ZeroArena(n_acc + (1 << 16), dev)
         self.step_count = 0
 
     def _global_batch(self, B):
@@ -169,7 +172,8 @@ class Trainer:
         """zero grads -> forward -> loss -> backward: this rank's gradients, in the flat bucket."""
         self.bucket.zero()
         self.bucket.release()
-        with torch.enable_grad():
+        self.arena.begin()
+        with torch.enable_grad(), self.arena:
             with tf_util.default_store(self.net.store), perm.default_perm_source(self.net.perms):
                 out = pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, True, decay)
             loss = pwclo_model.get_loss(*out[:8], q_gt, t_gt, self.w_x, self.w_q)

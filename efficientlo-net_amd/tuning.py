@@ -44,14 +44,18 @@ _HOST = {
     "sv_ride": ("ELO_SV_RIDE", lambda v: v != "0", True),                     # softmax_valid's partial sums ride on the launch that produces its inputs (one launch less per level)
     "train_branches": ("ELO_TRAIN_BRANCHES", lambda v: v == "1", False),
     "train_kernels": ("ELO_TRAIN_KERNELS", lambda v: v != "0", True),
+    "train_atomics": ("ELO_TRAIN_ATOMICS", lambda v: v != "0", True),         # training layer: replica-accumulator reductions (7 launches per layer instead of 10)
 }
 # library fields (elo_tuning): name -> (environment variable, default)
 _LIB = {
     "chain_forms": ("ELO_CV1_RR", 1), "narrow_mfma": ("ELO_SETCONV_NARROW_MFMA", 1), "range_check": ("ELO_RANGE_CHECK", 0),
     "select_dense_waves": ("ELO_SELECT_DENSE_WAVES", 0), "random_dense_rows": ("ELO_DENSE_ROWS", 0), "encode1_slots": ("ELO_ENCODE1_SLOTS", 0),
     "setconv_chain_rows": ("ELO_SETCONV_RR_ROWS", -1), "mlp_chain_rows": ("ELO_MLP_RR_ROWS", -1), "small_tile_units": ("ELO_SMALL_TILE_UNITS", 64),
-    "tiled_setconv": ("ELO_TILED_SETCONV", 0),
+    "tiled_setconv": ("ELO_TILED_SETCONV", 0), "pool_wave": ("ELO_POOL_WAVE", 1),
 }
+
+
+_LIB_BOOLEAN = ("chain_forms", "range_check", "encode1_slots", "pool_wave")
 
 
 def _host_from_env():
@@ -68,7 +72,8 @@ def lib_from_env():
     for name, (var, _default) in _LIB.items():
         raw = os.environ.get(var)
         if raw is not None:
-            out[name] = (1 if raw else 0) if name == "encode1_slots" else int(raw)
+            value = int(raw)
+            out[name] = (1 if value else 0) if name in _LIB_BOOLEAN else value      # (ELO_RANGE_CHECK=2 meant "on" to the old atoi != 0)
     return out
 
 
@@ -108,7 +113,7 @@ def override(**fields):
     if unknown:
         raise KeyError("unknown tuning field(s): %s" % sorted(unknown))
     prev_host = {k: _host[k] for k in host}
-    prev_lib = _lib.get_tuning() if lib else None
+    prev_lib = _lib.get_tuning_base() if lib else None        # (the installed value: a pending elo_debug_* override is not promoted on exit)
     try:
         _host.update(host)
         bump()

@@ -45,9 +45,17 @@ int elo_range_violations(unsigned long long *count, elo_stream_t stream);
 
 /* Host runtime: one step of a captured forward (a "lane": a hipGraphExec_t with fixed input / output buffers) as one call --
  * if bytes != 0 a device-to-device hipMemcpyAsync(dst <- src) of the lane's input, then hipGraphLaunch, both on `stream`.
- * graph_exec: the hipGraphExec_t (torch: CUDAGraph.raw_cuda_graph_exec()).  The caller keeps src alive until the stream has
- * run the copy, as with any asynchronous copy. */
-int elo_graph_submit(void *graph_exec, elo_stream_t stream, void *dst, const void *src, unsigned long bytes);
+ * graph_exec: the hipGraphExec_t (torch: CUDAGraph.raw_cuda_graph_exec()).
+ * ORDERING (ABI 23; the contract replaced is the reference's synchronous sess.run(feed_dict=...), main.py:372-381): with
+ * order_event != NULL (a hipEvent_t the lane owns) the call records it on `producer` -- the stream whose work so far produced
+ * src, or wrote the lane's input buffer in place (0 = the null stream) -- and makes `stream` wait for it before the copy and
+ * the graph, so a caller may submit right behind the kernels that fill src.  order_event == NULL: no ordering -- the caller
+ * guarantees src (or the in-place input) is complete before `stream` reaches this step (inputs resident and synchronised,
+ * or produced on `stream` itself).
+ * LIFETIME: the caller keeps src alive until `stream` has run the copy, as with any asynchronous copy (torch: record_stream).
+ * device >= 0: the lane's device; made current for the call when the calling thread's current device differs (and put back). */
+int elo_graph_submit(void *graph_exec, elo_stream_t stream, void *dst, const void *src, unsigned long bytes,
+                     elo_stream_t producer, void *order_event, int device);
 
 /* The library's tuning: every choice of KERNEL FORM that is not a function of the arguments alone, as ONE value.  The library
  * itself reads no environment variable; the host fills this once (efficientlo-net_amd/_lib.py maps the ELO_* variables named
@@ -70,8 +78,11 @@ typedef struct elo_tuning {
     int tiled_setconv;          /* narrow set-conv layers with structured centres on the LDS-staged window tile: 0 off (default:
                                    measured slower, profiles/r05_ab_tiled.txt), 1 the 6 -> 8 -> 8 -> 16 layer, 2 also the
                                    19 -> 16 -> 16 -> 32 layer                                                      [ELO_TILED_SETCONV]       */
+    int pool_wave;              /* elo_masked_softmax_pool with C = 64, K <= 32: 1 (default) one WAVE per point, one or two light nontemporal
+                                   loads per lane and tensor (HBM-cold streaming: tools/micro/hbm_probe.hip), 0 the quarter-wave form  [ELO_POOL_WAVE] */
 } elo_tuning;
-int elo_get_tuning(elo_tuning *out);
+int elo_get_tuning(elo_tuning *out);             /* what the launchers read now: elo_set_tuning's value with pending elo_debug_* overrides on top */
+int elo_get_tuning_base(elo_tuning *out);        /* what elo_set_tuning installed (no elo_debug_* override): the value a read-modify-write starts from */
 int elo_set_tuning(const elo_tuning *in);      /* ELO_ERR_ARG on a field outside its domain (nothing is changed then) */
 
 /* ------------------------------------------------------------------------- *
@@ -528,6 +539,27 @@ typedef struct elo_bn_backward_args {
 } elo_bn_backward_args;
 int elo_bn_backward(const elo_bn_backward_args *a, elo_stream_t stream);
 
+/* The same two passes in TWO launches each instead of three (round 6): a block adds its partial sums with float atomics into one
+ * of ELO_BN_REPLICAS replicas of the (2, C) totals -- `acc` / `scratch`: (ELO_BN_REPLICAS, 2, C) floats ZEROED by the caller (one
+ * memset per training step over an arena) -- and the consumer kernel totals the replicas in its prologue.
+ * elo_bn_forward = the statistics + y = act(gamma * (z - mean) * invstd + beta); mean / invstd (saved for backward) and the moving
+ * averages are written by the apply kernel.  elo_bn_backward_acc = elo_bn_backward with `scratch` = the zeroed accumulators.
+ * Summation order depends on the run (atomics): results agree with the three-launch forms to fp32 rounding, not bit for bit. */
+#define ELO_BN_REPLICAS 8
+typedef struct elo_bn_forward_args {
+    long rows; int C;
+    const float *z;               /* (rows,C) */
+    float *acc;                   /* (ELO_BN_REPLICAS, 2, C) IN: zeros */
+    float eps, momentum;
+    const float *gamma, *beta;
+    int relu;
+    float *mean, *invstd;         /* (C) OUT */
+    float *running_mean, *running_var;   /* (C) IN/OUT or both NULL */
+    float *y;                     /* (rows,C) OUT (may alias z) */
+} elo_bn_forward_args;
+int elo_bn_forward(const elo_bn_forward_args *a, elo_stream_t stream);
+int elo_bn_backward_acc(const elo_bn_backward_args *a, elo_stream_t stream);
+
 /* dW = x^T g (Cin,Cout row-major), db = column sums of g (or NULL): fp32 operands on v_mfma_f32_16x16x4_f32, fp32
  * accumulation per row slice, slices summed in order.  Any Cin, Cout.
  * scratch: elo_weight_grad_slices(rows, Cin, Cout) * (Cin*Cout + Cout) floats. */
@@ -541,6 +573,12 @@ typedef struct elo_weight_grad_args {
 } elo_weight_grad_args;
 int elo_weight_grad_slices(long rows, int Cin, int Cout);
 int elo_dense_weight_grad(const elo_weight_grad_args *a, elo_stream_t stream);
+/* ONE launch where the row slices are few (elo_weight_grad_atomic(rows, Cin, Cout) == 1: <= ELO_WG_ATOMIC_SLICES slices): every
+ * slice ADDS its block into dW / db with float atomics -- dW and db come ZEROED from the caller, scratch may be NULL.  Otherwise
+ * (many slices: the big layers) the call is elo_dense_weight_grad's two launches and needs its scratch. */
+#define ELO_WG_ATOMIC_SLICES 128
+int elo_weight_grad_atomic(long rows, int Cin, int Cout);
+int elo_dense_weight_grad_acc(const elo_weight_grad_args *a, elo_stream_t stream);
 
 /* Adam (torch.optim.Adam's arithmetic; the reference trains with tf.train.AdamOptimizer, main.py:171-176) over ONE flat
  * fp32 parameter buffer in one launch: every variable, its gradient and its two moments are views of four buffers of n

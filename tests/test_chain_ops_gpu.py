@@ -206,7 +206,7 @@ def test_narrow_down_conv_on_the_matrix_cores_matches_the_oracle(storage):
     sel_np = O.get_selected_idx(B, 2, 2, oh, ow)
     xyz = t(f1)
     sel = mu.get_selected_idx(xyz, 2, 2, oh, ow)
-    counts = (ctypes.c_ulonglong * 2)()
+    counts = (ctypes.c_ulonglong * 3)()
     try:
         lib.lib().elo_debug_narrow_mfma(1)
         lib.lib().elo_debug_narrow_launches(None, 1)
@@ -237,3 +237,57 @@ def test_setconv_launcher_rejects_a_queried_grid_smaller_than_the_strided_centre
         layers = [fused.packed_layer("rej0", 3 + C, 16, row_order=fused.setconv_row_order(C)), fused.packed_layer("rej1", 16, 16)]
     with pytest.raises(lib.EloError, match="smaller than the centres' grid"):
         fused.setconv(src, feat, None, None, layers, xyz1_grid=xyz1, group=fused.Grouping(order, [3, 5], 2.0, 2, 2), K=8)
+
+
+@pytest.mark.parametrize("profile", ["dense", "kitti"])
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("B", [1, 2])
+def test_the_heterogeneous_chain_launch_matches_the_oracle_elementwise(B, storage, profile):
+    """cv1_setconv_rr_kernel (elo_cv_stage1_setconv_chain): cost-volume stage 1 behind its select-k pre-pass AND the level's two
+    set-upconv stage-1 jobs in ONE launch whose workgroups are partitioned between three jobs (n_cv | n_sc | n_sc) -- at l0 of a
+    64 x 1800 forward, batch 1 and 2, the shape the product takes it at.  All THREE output tensors element-wise against the
+    oracle (utils/pointnet_util.py:33-100, :254-298), on the dense scene and on the KITTI-density one (all-masked windows,
+    masked slots gathering batch 0 pixel (0,0)); the pair-launch counter proves the kernel produced them.  (Round 5 pinned this
+    launch only by 'forward with == forward without'.)"""
+    pu, synth, lib, fused = load_pkg("pointnet_util"), load_pkg("synth"), load_pkg("_lib"), load_pkg("fused")
+    H, W, C, Kq, ks2, dist = 16, 225, 16, 6, [11, 41], 1.0
+    sh = sw = 2
+    store, perms = ctx()
+    g1, g2 = synth.frame_pair(B, 64, 1800, seed=61, profile=profile)
+    f1, f2 = np.ascontiguousarray(g1[:, ::4, ::8]), np.ascontiguousarray(g2[:, ::4, ::8])      # the l0 grid of that pair (strides 4 x 8)
+    assert f1.shape == (B, H, W, 3)
+    H2, W2 = -(-H // sh), -(-W // sw)
+    sparse_xyz = np.ascontiguousarray(f1[:, ::sh, ::sw][:, :H2, :W2])
+    rng = np.random.default_rng(7 + B)
+    fa, fb = features(rng, (B, H, W, C), storage), features(rng, (B, H, W, C), storage)
+    sparse = [features(rng, (B, H2, W2, 64), storage) for _ in range(2)]
+    d = lambda x: dev_feat(x, storage)
+    common = dict(xyz1_proj=t(f1), xyz2_proj=t(sparse_xyz), feat1_proj=d(fa), kernel_size=[7, 15], stride_h=sh, stride_w=sw,
+                  nsample=8, distance=3.0, mlp=[128, 64], mlp2=[128, 64])
+    ups = [dict(common, feat2_proj=d(sparse[j]), scope="up_%s" % tag) for j, tag in enumerate("ab")]
+    n_pair = ctypes.c_ulonglong(0)
+
+    def forward():
+        jobs = pu.up_conv_stage1_jobs(ups[0], ups[1])
+        with fused.recording() as calls:
+            out, sides = pu.cost_volume(t(f1), t(f2), d(fa), d(fb), kernel_size1=[3, 5], kernel_size2=ks2, nsample=4, nsample_q=Kq,
+                                        distance=dist, mlp1=[128, 64, 64], mlp2=[128, 64], is_training=False, bn_decay=None,
+                                        scope='flow_embedding_c', bn=True, pooling='max', knn=True, corr_func='concat',
+                                        side_jobs=jobs, side_chain=True)
+        assert sides is not None, "the chain-pair form was not taken"
+        return out, [c for c in calls if c[0] == 2][0][1][2], sides[0][0], sides[1][0]
+    lib.check(lib.lib().elo_debug_chain_pair_launches(ctypes.byref(n_pair), 1))
+    got, got_stage1, up_a, up_b = run_twice(forward, store, perms)
+    lib.check(lib.lib().elo_debug_chain_pair_launches(ctypes.byref(n_pair), 1))
+    assert n_pair.value == 2, n_pair.value                          # (run_twice: two forwards, one heterogeneous launch each)
+    params, taps = export(store), {}
+    args = (params, shuffle_fn, f1, f2, fa, fb, [3, 5], ks2, 4, Kq, dist, [128, 64, 64], [128, 64], "flow_embedding_c")
+    with O.feature_storage(np.float16 if storage == "f16" else None):
+        O.cost_volume(*args, taps=taps)
+        compare(got_stage1, taps["stage1"], storage, "cost-volume stage 1 inside cv1_setconv_rr_kernel")
+        want = O.cost_volume(*args, stage1=got_stage1.float().cpu().numpy())
+        compare(got, want, storage, "cost volume (stage 2 on the product's stage-1 tensor)")
+        for j, (tag, up) in enumerate(zip("ab", (up_a, up_b))):
+            taps_u = {}
+            O.up_conv(params, shuffle_fn, f1, sparse_xyz, fa, sparse[j], [7, 15], sh, sw, 8, 3.0, [128, 64], [], "up_%s" % tag, taps=taps_u)   # (stage 1 only: no up_2_* variables exist)
+            compare(up, taps_u["pooled"], storage, "set-upconv %s stage 1 inside cv1_setconv_rr_kernel" % tag)

@@ -245,3 +245,86 @@ def test_the_native_submit_replays_what_torch_replays():
     for a, b in zip(got[True], got[False]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
     assert torch.equal(got[True][6], got[True][3])               # the in-place replay of pair 3 = the copied one
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_submit_waits_for_the_producer_of_its_input(native):
+    """submit()'s default ordering (the contract replaced is the reference's synchronous sess.run(feed_dict=...), main.py:372-381):
+    the pair is filled by work still QUEUED on the caller's current stream -- a long spin kernel, then the copy that writes the real
+    range images over zeros -- and submitted immediately.  The lane's stream must wait for that work (elo_graph_submit's
+    hipEventRecord + hipStreamWaitEvent on the native path, Event.record / Stream.wait_event through torch): the pose is the one of
+    a synchronised submit, bit for bit.  With ready=False (the caller owns the ordering) the same sequence reads the zeros: the test
+    asserts that too, so it would have failed on the unordered submit of round 5.  submit_points likewise."""
+    model, synth, tuning = load_pkg("model"), load_pkg("synth"), load_pkg("tuning")
+    f1, f2 = synth.frame_pair(1, 64, 1800, seed=91)
+    real = torch.from_numpy(np.concatenate([f1, f2], 0)).to(DEV)
+    with tuning.override(native_submit=native):
+        net = model.PWCLONet(DEV, seed=3)
+        net.capture(1, 64, 1800, lanes=2)
+        assert (net._lanes[0]["native"] is not None) == native
+        flat = lambda out: torch.cat([out[0].reshape(-1), out[1].reshape(-1)]).clone()
+        out = net.submit(0, real)
+        torch.cuda.synchronize()
+        want = flat(out)
+        out = net.submit(0, torch.zeros_like(real))
+        torch.cuda.synchronize()
+        zeros = flat(out)
+        assert not torch.equal(want, zeros)
+
+        def late_input():
+            x = torch.zeros_like(real)
+            torch.cuda.synchronize()
+            torch.cuda._sleep(200_000_000)                       # ~0.1 s of spinning on the current stream ...
+            x.copy_(real, non_blocking=True)                     # ... in front of the kernel that produces the input
+            return x
+
+        out = net.submit(1, late_input())                  # default: ordered behind the current stream; x dies here (record_stream)
+
+        torch.cuda.synchronize()
+
+        got = flat(out)
+        assert torch.equal(got, want)
+        ev = torch.cuda.Event()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):                            # a producer on some other stream, handed over as an event
+            x = late_input()
+            ev.record()
+        out = net.submit(1, x, ready=ev)
+        torch.cuda.synchronize()
+        got = flat(out)
+        assert torch.equal(got, want)
+        x = late_input()
+        out = net.submit(1, x, ready=False)                # the caller owns the ordering -- and here does not provide it
+        torch.cuda.synchronize()
+        got = flat(out)
+        assert torch.equal(got, zeros)
+        # in place: lane_input() written on the current stream behind a spin, submit(lane) without a copy
+        torch.cuda.synchronize()
+        torch.cuda._sleep(200_000_000)
+        net.lane_input(0).copy_(real, non_blocking=True)
+        out = net.submit(0)
+        torch.cuda.synchronize()
+        got = flat(out)
+        assert torch.equal(got, want)
+
+
+def test_submit_points_waits_for_the_producer_of_its_cloud():
+    model = load_pkg("model")
+    rng = np.random.default_rng(5)
+    P = 20000
+    az, el, r = rng.uniform(-np.pi, np.pi, (1, 2 * P)), np.deg2rad(rng.uniform(-24.8, 2.0, (1, 2 * P))), rng.uniform(2.0, 30.0, (1, 2 * P))
+    cloud = torch.from_numpy(np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], -1).astype(np.float32)).to(DEV)
+    net = model.PWCLONet(DEV, seed=3)
+    net.capture(1, 64, 1800, lanes=1, num_points=P)
+    flat = lambda out: torch.cat([out[0].reshape(-1), out[1].reshape(-1)]).clone()
+    out = net.submit_points(0, cloud)
+    torch.cuda.synchronize()
+    want = flat(out)
+    x = torch.zeros_like(cloud)
+    torch.cuda.synchronize()
+    torch.cuda._sleep(200_000_000)
+    x.copy_(cloud, non_blocking=True)
+    out = net.submit_points(0, x)
+    torch.cuda.synchronize()
+    got = flat(out)
+    assert torch.equal(got, want)

@@ -13,6 +13,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True, params=["atomics", "three-launch"])
+def reduction_form(request):
+    """Every test runs on both forms of the layer's reductions: per-block partials added into zeroed replica accumulators and
+    totalled in the consumer's prologue (round 6: elo_bn_forward / elo_bn_backward_acc / elo_dense_weight_grad_acc, the default)
+    and partials + a combine launch (elo_bn_stats / elo_bn_backward / elo_dense_weight_grad)."""
+    with load_pkg("tuning").override(train_atomics=request.param == "atomics"):
+        yield request.param
+
+
 def _reference(x, W, b, gamma, beta, rm, rv, momentum, eps, relu, gy, mask):
     """`mask`: the ReLU decisions of the fp32 forward (y > 0).  The float64 reference uses THE SAME decisions: among
     millions of pre-activations one lies within fp32 rounding of zero now and then, and a reference that decides it the
@@ -72,20 +81,16 @@ def test_training_layer_matches_float64(rows, cin, cout, relu):
 def test_training_layer_is_what_torch_computes():
     """The kernel path and the torch path of tf_util._dense (ELO_TRAIN_KERNELS=0: addmm + F.batch_norm + relu) agree to fp32
     rounding on the same variables, moving averages included."""
-    tf_util = load_pkg("tf_util")
+    tf_util, tuning = load_pkg("tf_util"), load_pkg("tuning")
     rng = np.random.default_rng(0)
     x = torch.from_numpy(rng.normal(0, 1, (2, 500, 6, 16)).astype(np.float32)).to(DEV)
     outs = []
     for kernels in (True, False):
         store = tf_util.VariableStore(DEV, seed=9)
-        prev, tf_util._TRAIN_KERNELS = tf_util._TRAIN_KERNELS, kernels
-        try:
-            with tf_util.default_store(store):
-                xi = x.clone().requires_grad_(True)
-                y = tf_util.conv2d(xi, 32, [1, 1], scope="l", bn=True, is_training=True, bn_decay=0.9)
-                y.square().sum().backward()
-        finally:
-            tf_util._TRAIN_KERNELS = prev
+        with tuning.override(train_kernels=kernels), tf_util.default_store(store):     # (the field is read at the point of use)
+            xi = x.clone().requires_grad_(True)
+            y = tf_util.conv2d(xi, 32, [1, 1], scope="l", bn=True, is_training=True, bn_decay=0.9)
+            y.square().sum().backward()
         outs.append((y.detach(), xi.grad, store.params["l/weights"].grad, store.params["l/bn/gamma"].grad,
                      store.buffers["l/bn/moving_mean"].clone(), store.buffers["l/bn/moving_variance"].clone()))
     for a, b in zip(*outs):

@@ -10,7 +10,7 @@ SPECS=${ELO_PMC_SPECS:-"cv1:1 cv1:8 encode1:8 pool:8 encode2:8 pool2:8 encode1:6
 for spec in $SPECS; do
     k=${spec%%:*}; b=${spec##*:}; tag=${k}_b${b}; half=""
     case "$k" in *_f16) k=${k%_f16}; half="--half";; esac      # e.g. encode1_f16:64
-    cmd="python $REPO/tools/roofline_micro.py --kernel $k --batch $b --reps 25 $half"
+    cmd="python $REPO/tools/roofline_micro.py --kernel $k --batch $b --reps 25 $half ${ELO_PMC_COLD:+--cold}"      # ELO_PMC_COLD=1: ring of tensor sets (HBM-cold launches)
     $cmd > "$OUT/$tag.info" 2>/dev/null
     rocprofv3 --kernel-trace --output-format csv -d "$OUT/$tag.trace" -o t -- $cmd > /dev/null 2>&1
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$tag.fetch" -o f -- $cmd > /dev/null 2>&1

@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 pkg = lambda m: importlib.import_module("efficientlo-net_amd." + m)
 model, training, synth = pkg("model"), pkg("training"), pkg("synth")
 dev = "cuda:0"
-for B in (1, 4, 8):
+for B in ([int(x) for x in sys.argv[1:]] or (1, 4, 8)):      # python tools/train_step_time.py [B ...]
     net = model.PWCLONet(dev, seed=0)
     tr = training.Trainer(net)
     f1, f2 = synth.frame_pair(B, 64, 1800, seed=1)
