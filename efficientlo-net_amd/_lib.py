@@ -51,7 +51,6 @@ SoftmaxValidArgs = _struct("elo_softmax_valid_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("feature", _vp), ("weight", _vp), ("xyz", _vp), ("out", _vp),
     ("scratch", _vp), ("stats", _vp)])
 SV_MAX_PARTS = 512     # ELO_SV_MAX_PARTS
-POSE_DIRECT_MAX = 1024 # ELO_POSE_DIRECT_MAX
 PermRefreshArgs = _struct("elo_perm_refresh_args", [
     ("pool", _vp), ("versions", _i), ("total", _i), ("cursor", _vp), ("flat", _vp), ("decoded", _vp), ("entry_of", _vp),
     ("table", _vp), ("n_entries", _i)])
@@ -60,7 +59,7 @@ PoseHeadArgs = _struct("elo_pose_head_args", [
     ("W_big", _vp), ("b_big", _vp), ("W_q", _vp), ("b_q", _vp), ("W_t", _vp), ("b_t", _vp),
     ("q_coarse", _vp), ("t_coarse", _vp), ("q", _vp), ("t", _vp), ("q_norm", _vp), ("scratch", _vp), ("pose7", _vp),
     ("clear_scratch", _vp), ("clear_xyz", _vp), ("clear_feat", _vp), ("clear_cells", ctypes.c_long), ("clear_C", _i),
-    ("feat_dtype", _i), ("pose7_slots", _i), ("pose7_cursor", _vp), ("next_orders", PermRefreshArgs), ("direct", _i), ("ready_parts", _i)])
+    ("feat_dtype", _i), ("pose7_slots", _i), ("pose7_cursor", _vp), ("next_orders", PermRefreshArgs), ("ready_parts", _i)])
 WarpProjectArgs = _struct("elo_warp_project_args", [
     ("batch", _i), ("npoints", _i), ("C", _i), ("H", _i), ("W", _i),
     ("az_res", _f), ("vert_res", _f), ("vert_off", _f),
@@ -119,11 +118,6 @@ PoseLossArgs = _struct("elo_pose_loss_args", [
 WeightGradArgs = _struct("elo_weight_grad_args", [
     ("rows", ctypes.c_long), ("Cin", _i), ("Cout", _i), ("x", _vp), ("g", _vp), ("dW", _vp), ("db", _vp), ("scratch", _vp)])
 BN_MAX_PARTS = 512     # ELO_BN_MAX_PARTS
-BN_REPLICAS = 8        # ELO_BN_REPLICAS
-BnForwardArgs = _struct("elo_bn_forward_args", [
-    ("rows", ctypes.c_long), ("C", _i), ("z", _vp), ("acc", _vp), ("eps", _f), ("momentum", _f), ("gamma", _vp), ("beta", _vp), ("relu", _i),
-    ("mean", _vp), ("invstd", _vp), ("running_mean", _vp), ("running_var", _vp), ("y", _vp)])
-
 Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i), ("w_plain", _vp),
                               ("products", _i)])
 _l = ctypes.c_long
@@ -134,7 +128,7 @@ SetconvArgs = _struct("elo_setconv_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1_grid", _vp), ("centre_hw", _vp), ("centre_xyz", _vp), ("src_xyz", _vp), ("src_feat", _vp),
     ("idx", _vp), ("mask", _vp), ("n_layers", _i), ("layers", Dense * 3), ("out", _vp), ("new_xyz", _vp), ("group", GroupSpec),
-    ("feat_dtype", _i), ("pre", _vp), ("centre_stride_h", _i), ("centre_stride_w", _i), ("centre_rows", _i), ("centre_cols", _i)])
+    ("feat_dtype", _i)])
 MlpArgs = _struct("elo_mlp_args", [
     ("rows", _l), ("n_sources", _i), ("src", _vp * 3), ("src_width", _i * 3), ("n_layers", _i),
     ("layers", Dense * 3), ("out", _vp),
@@ -146,17 +140,14 @@ Cv1Args = _struct("elo_cv1_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("xyz2", _vp), ("feat2", _vp), ("idx", _vp), ("mask", _vp),
     ("cv0", Dense), ("cv1", Dense), ("cv2", Dense), ("cv_xyz", Dense), ("sum_cv0", Dense), ("sum_cv1", Dense),
-    ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i), ("pre_c", _vp), ("pre_s", _vp)])
+    ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i)])
 Cv2Args = _struct("elo_cv2_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("cost", _vp), ("idx", _vp), ("mask", _vp),
-    ("xyz_enc", Dense), ("sum_cost0", Dense), ("sum_cost1", Dense), ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i),
-    ("pre_c", _vp), ("pre_s", _vp)])
+    ("xyz_enc", Dense), ("sum_cost0", Dense), ("sum_cost1", Dense), ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i)])
 Tuning = _struct("elo_tuning", [
     ("chain_forms", _i), ("narrow_mfma", _i), ("range_check", _i), ("select_dense_waves", _i), ("random_dense_rows", _i),
-    ("encode1_slots", _i), ("setconv_chain_rows", _l), ("mlp_chain_rows", _l), ("small_tile_units", _l), ("tiled_setconv", _i), ("pool_wave", _i)])
-RowlinearArgs = _struct("elo_rowlinear_args", [
-    ("rows", _l), ("C", _i), ("src", _vp), ("layer", Dense), ("out", _vp), ("feat_dtype", _i)])
+    ("setconv_chain_rows", _l), ("mlp_chain_rows", _l), ("small_tile_units", _l), ("pool_wave", _i)])
 
 # every symbol include/elo.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -198,10 +189,6 @@ SYMBOLS = [
     ("elo_pose_compose", ctypes.c_int, [ctypes.POINTER(PoseComposeArgs), _vp]),
     ("elo_pose_loss", ctypes.c_int, [ctypes.POINTER(PoseLossArgs), _vp]),
     ("elo_weight_grad_slices", ctypes.c_int, [ctypes.c_long, ctypes.c_int, ctypes.c_int]),
-    ("elo_weight_grad_atomic", ctypes.c_int, [ctypes.c_long, ctypes.c_int, ctypes.c_int]),
-    ("elo_dense_weight_grad_acc", ctypes.c_int, [ctypes.POINTER(WeightGradArgs), _vp]),
-    ("elo_bn_forward", ctypes.c_int, [ctypes.POINTER(BnForwardArgs), _vp]),
-    ("elo_bn_backward_acc", ctypes.c_int, [ctypes.POINTER(BnBackwardArgs), _vp]),
     ("elo_setconv_fused", ctypes.c_int, [ctypes.POINTER(SetconvArgs), _vp]),
     ("elo_mlp_fused", ctypes.c_int, [ctypes.POINTER(MlpArgs), _vp]),
     ("elo_setconv_fused2", ctypes.c_int, [ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
@@ -213,16 +200,12 @@ SYMBOLS = [
     ("elo_debug_rr_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_debug_narrow_mfma", ctypes.c_int, [ctypes.c_int]),
     ("elo_debug_narrow_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
-    ("elo_debug_rowlinear_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_debug_sv_ride_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_get_tuning_base", ctypes.c_int, [ctypes.POINTER(Tuning)]),
     ("elo_graph_submit", ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_ulong, _vp, _vp, ctypes.c_int]),
     ("elo_debug_chain_pair_launches", ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     ("elo_cv_stage1_setconv_chain_form", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs)]),
     ("elo_cv_stage1_setconv_chain", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
-    ("elo_rowlinear_fused2", ctypes.c_int, [ctypes.POINTER(RowlinearArgs), ctypes.POINTER(RowlinearArgs), _vp]),
-    ("elo_setconv_chain_form", ctypes.c_int, [ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs)]),
-    ("elo_cv_chain_form", ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     ("elo_cv_stage2_fused", ctypes.c_int, [ctypes.POINTER(Cv2Args), _vp]),
     ("elo_cv_stage1_setconv_fused", ctypes.c_int, [ctypes.POINTER(Cv1Args), ctypes.POINTER(SetconvArgs), ctypes.POINTER(SetconvArgs), _vp]),
 ]
@@ -234,7 +217,7 @@ class EloError(RuntimeError):
     pass
 
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 
 def lib():

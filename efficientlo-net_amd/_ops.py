@@ -12,7 +12,6 @@ import ctypes
 import torch
 
 from . import _lib as L
-from . import tuning
 
 
 def _wants_grad(*ts):
@@ -421,15 +420,13 @@ class PoseRing:
 
 
 def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse=None, t_coarse=None, pose7=None,
-              clear=None, warp=None, next_orders=None, direct=False, partials=None):
+              clear=None, warp=None, next_orders=None, partials=None):
     """softmax_valid -> conv1d(256) -> q,t heads -> normalise -> compose with the coarse pose, two launches.
-    `direct` (N <= L.POSE_DIRECT_MAX, C = 64, hidden = 256): ONE launch -- the head's workgroups reduce the rows themselves
-    (elo_pose_head_args.direct); `clear` must then already have been cleared by an earlier launch (fused.mlp(clear=...)).
     pwclo_model.py:194-208 / :262-280.  Returns (q (B,4), t (B,3), q_norm (B,4)); `pose7` (B,7), if given, also receives [q_norm | t].
     `next_orders`: an elo_perm_refresh_args (perm.PermSource.refresh_args): the next pooled set of visiting orders is
     loaded by this launch once the pose is written (the last launch of a captured forward).
     `partials`: an SvPartials a preceding launch has filled (partials.parts > 0): no partial-sums launch here; `clear` must
-    then already have been cleared by that launch, as with `direct`.
+    then already have been cleared by that launch (fused.mlp(clear=...))).
     `clear`: ProjectionBuffers of the projection that will consume this pose (cleared on the side).
     `warp` = (xyz (B,N,3), feat (B,N,C) or None) with `clear`: that projection itself -- warp by this pose, spherical
     re-projection -- is run by this call (elo_pose_head_warp: 3 launches instead of 2 + 2); its result is left in
@@ -446,8 +443,8 @@ def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t
     t = torch.empty((B, 3), dtype=torch.float32, device=dev)
     q_norm = torch.empty((B, 4), dtype=torch.float32, device=dev)
     ready = partials.parts if partials is not None else 0
-    if ready and (direct or C != 64):
-        raise ValueError("partials= goes with the 64-channel head and not with direct=True")
+    if ready and C != 64:
+        raise ValueError("partials= goes with the 64-channel head")
     scratch = partials.scratch if ready else torch.empty((3 * B * L.SV_MAX_PARTS * C,), dtype=torch.float32, device=dev)
     ptr = lambda x: x.data_ptr() if x is not None else None
     ring = pose7 if isinstance(pose7, PoseRing) else None
@@ -462,9 +459,9 @@ def pose_head(feature_bnc, weight_bnc, xyz_bn3, W_big, b_big, W_q, b_q, W_t, b_t
                                       clear.shape[0] * clear.shape[2] * clear.shape[3], clear.shape[4])
                                      if clear is not None else (None, None, None, 0, 0)), fcode,
                        ring.slots if ring is not None else 0, ring.cursor.data_ptr() if ring is not None else None,
-                       next_orders if next_orders is not None else L.PermRefreshArgs(), 1 if direct else 0, ready)
-    if (direct or ready) and clear is not None and not clear.cleared:
-        raise ValueError("direct=True / partials=: the ProjectionBuffers must have been cleared by an earlier launch (fused.mlp(clear=...))")
+                       next_orders if next_orders is not None else L.PermRefreshArgs(), ready)
+    if ready and clear is not None and not clear.cleared:
+        raise ValueError("partials=: the ProjectionBuffers must have been cleared by an earlier launch (fused.mlp(clear=...))")
     if clear is not None and clear.out_feat is not None and clear.out_feat.dtype != fdt:
         raise TypeError("the projection buffers and the pose head's features must share one storage dtype")
     if warp is not None:
@@ -609,45 +606,6 @@ def dense_bn_supported(x2, cout):
     return x2.is_cuda and x2.dtype == torch.float32 and 4 <= cout <= 256 and cout & (cout - 1) == 0 and x2.shape[0] > 0
 
 
-class ZeroArena:
-    """A flat fp32 buffer that is ZERO at the start of a training step: the accumulators of a step's reductions (the replica
-    sums of the batch-norm kernels, the weight / bias gradients the few-slice weight-gradient kernel adds into) are slices of
-    it, so a step zeroes them with ONE memset instead of one fill launch each (training.Trainer owns one and calls begin() per
-    step; inside a captured step the slices are the same addresses on every replay).  Without an active arena -- a layer run
-    on its own, as the tests do -- take() is a torch.zeros."""
-    active = None
-
-    def __init__(self, nfloats, device):
-        self.buf = torch.zeros((int(nfloats),), dtype=torch.float32, device=device)
-        self.off = 0
-        self.spilled = 0          # floats asked for beyond the capacity in the current step (served by torch.zeros)
-
-    def begin(self):
-        self.buf.zero_()
-        self.off, self.spilled = 0, 0
-
-    def __enter__(self):
-        self.prev, ZeroArena.active = ZeroArena.active, self
-        return self
-
-    def __exit__(self, *exc):
-        ZeroArena.active = self.prev
-
-    @staticmethod
-    def take(n, device):
-        """n zero floats, 16-byte aligned."""
-        a = ZeroArena.active
-        n = int(n)
-        if a is not None and a.buf.device == device:
-            pad = (n + 3) & ~3
-            if a.off + pad <= a.buf.numel():
-                out = a.buf[a.off:a.off + n]
-                a.off += pad
-                return out
-            a.spilled += n
-        return torch.zeros((n,), dtype=torch.float32, device=device)
-
-
 class _DenseBN(torch.autograd.Function):
     """y = act(batch_norm(x @ W + b)) with batch statistics.  The two dense products (forward, dx) are library GEMMs; every
     pass OVER THE ROWS -- the batch moments, the normalisation, the two sums of batch norm's backward, dz, the weight
@@ -661,22 +619,15 @@ class _DenseBN(torch.autograd.Function):
         z = torch.addmm(b, x2, W)
         M, C = z.shape
         dev = z.device
-        stats = torch.empty((2 * C,), dtype=torch.float32, device=dev)
-        mean, invstd = stats[:C], stats[C:]
+        scratch = torch.empty((L.BN_MAX_PARTS * 2 * C,), dtype=torch.float32, device=dev)
+        mean = torch.empty((C,), dtype=torch.float32, device=dev)
+        invstd = torch.empty((C,), dtype=torch.float32, device=dev)
         g, bt = gamma.detach().contiguous(), beta.detach().contiguous()
+        L.call("elo_bn_stats", L.BnStatsArgs(M, C, z.data_ptr(), scratch.data_ptr(), float(eps), float(momentum), mean.data_ptr(),
+                                             invstd.data_ptr(), running_mean.data_ptr(), running_var.data_ptr()), z)
         y = torch.empty_like(z)
-        if tuning.get("train_atomics"):
-            # two launches: per-block partial sums added into zeroed replica accumulators, totalled in the apply kernel's prologue
-            acc = ZeroArena.take(L.BN_REPLICAS * 2 * C, dev)
-            L.call("elo_bn_forward", L.BnForwardArgs(M, C, z.data_ptr(), acc.data_ptr(), float(eps), float(momentum), g.data_ptr(), bt.data_ptr(),
-                                                     1 if relu else 0, mean.data_ptr(), invstd.data_ptr(), running_mean.data_ptr(),
-                                                     running_var.data_ptr(), y.data_ptr()), z)
-        else:
-            scratch = torch.empty((L.BN_MAX_PARTS * 2 * C,), dtype=torch.float32, device=dev)
-            L.call("elo_bn_stats", L.BnStatsArgs(M, C, z.data_ptr(), scratch.data_ptr(), float(eps), float(momentum), mean.data_ptr(),
-                                                 invstd.data_ptr(), running_mean.data_ptr(), running_var.data_ptr()), z)
-            L.call("elo_bn_apply", L.BnApplyArgs(M, C, z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g.data_ptr(), bt.data_ptr(),
-                                                 1 if relu else 0, y.data_ptr()), z)
+        L.call("elo_bn_apply", L.BnApplyArgs(M, C, z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g.data_ptr(), bt.data_ptr(),
+                                             1 if relu else 0, y.data_ptr()), z)
         ctx.save_for_backward(x2, W, z, mean, invstd, g, bt)
         ctx.relu = bool(relu)
         return y
@@ -687,34 +638,21 @@ class _DenseBN(torch.autograd.Function):
         (dy,) = _f32(dy)
         M, C = z.shape
         dev = z.device
-        atomics = tuning.get("train_atomics")
+        scratch = torch.empty((L.BN_MAX_PARTS * 2 * C,), dtype=torch.float32, device=dev)
         sums = torch.empty((2 * C,), dtype=torch.float32, device=dev)
         dz = torch.empty_like(z)
-        if atomics:
-            acc = ZeroArena.take(L.BN_REPLICAS * 2 * C, dev)
-            L.call("elo_bn_backward_acc", L.BnBackwardArgs(M, C, dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g.data_ptr(),
-                                                           bt.data_ptr(), 1 if ctx.relu else 0, acc.data_ptr(), sums.data_ptr(),
-                                                           dz.data_ptr()), z)
-        else:
-            scratch = torch.empty((L.BN_MAX_PARTS * 2 * C,), dtype=torch.float32, device=dev)
-            L.call("elo_bn_backward", L.BnBackwardArgs(M, C, dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g.data_ptr(),
-                                                       bt.data_ptr(), 1 if ctx.relu else 0, scratch.data_ptr(), sums.data_ptr(),
-                                                       dz.data_ptr()), z)
+        L.call("elo_bn_backward", L.BnBackwardArgs(M, C, dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g.data_ptr(),
+                                                   bt.data_ptr(), 1 if ctx.relu else 0, scratch.data_ptr(), sums.data_ptr(),
+                                                   dz.data_ptr()), z)
         dbeta, dgamma = sums[:C], sums[C:]
         dx = dz @ W.t() if ctx.needs_input_grad[0] else None
         cin = W.shape[0]
-        if atomics and L.lib().elo_weight_grad_atomic(M, cin, C):
-            # few row slices: every slice adds its block into the zeroed dW | db -- one launch, no partial blocks, no combine
-            both = ZeroArena.take(cin * C + C, dev)
-            dW, db = both[:cin * C].view(cin, C), both[cin * C:]
-            L.call("elo_dense_weight_grad_acc", L.WeightGradArgs(M, cin, C, x2.data_ptr(), dz.data_ptr(), dW.data_ptr(), db.data_ptr(), None), z)
-        else:
-            dW = torch.empty_like(W, memory_format=torch.contiguous_format)
-            db = torch.empty((C,), dtype=torch.float32, device=dev)
-            slices = L.lib().elo_weight_grad_slices(M, cin, C)
-            wscratch = torch.empty((slices * (cin * C + C),), dtype=torch.float32, device=dev)
-            L.call("elo_dense_weight_grad", L.WeightGradArgs(M, cin, C, x2.data_ptr(), dz.data_ptr(), dW.data_ptr(), db.data_ptr(),
-                                                             wscratch.data_ptr()), z)
+        dW = torch.empty_like(W, memory_format=torch.contiguous_format)
+        db = torch.empty((C,), dtype=torch.float32, device=dev)
+        slices = L.lib().elo_weight_grad_slices(M, cin, C)
+        wscratch = torch.empty((slices * (cin * C + C),), dtype=torch.float32, device=dev)
+        L.call("elo_dense_weight_grad", L.WeightGradArgs(M, cin, C, x2.data_ptr(), dz.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                                                         wscratch.data_ptr()), z)
         return dx, dW, db, dgamma, dbeta, None, None, None, None, None
 
 

@@ -443,26 +443,57 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_vec_kernel(const elo_s
                  &reinterpret_cast<V4 *>(static_cast<T *>(a.out) + r * a.C)[sub]);
 }
 
-// Wave-per-point form for C = 64 (every pooled width of the model), round 6: the quarter-wave form above keeps 2 x U 16-byte loads
-// in flight PER LANE and issues them in one burst per workgroup -- the access shape tools/micro/hbm_probe.hip measures at 0.54 of
-// 8 TB/s from HBM-cold data (one-shot, 8 loads per thread), where one light load per thread reaches 0.81.  Here the 64 lanes of a
-// wave share ONE (b,n) point: lane (g = lane / 16, sub = lane % 16) owns 4 channels of the neighbours k = g, g + 4, g + 8, ...
-// (K = 6: two loads per tensor and lane, K = 4: one), so a wave's load instruction covers four whole neighbour rows of one point
-// and there are four times as many, four times lighter waves.  Two-pass softmax exactly as written in the reference (max over K,
-// exponentials against it, sum): the per-lane maxima / sums meet through two DPP-class butterfly steps over the four lane groups.
-// Loads are nontemporal (every byte is read once).  Same arithmetic contract as the quarter-wave form (fp32, hardware exp2).
+// Wave-per-point form for C = 64 (every pooled width of the model), round 6: the quarter-wave form above keeps 2 x U loads in flight
+// PER LANE and issues them in one burst per workgroup -- the access shape tools/micro/hbm_probe.hip measures at 0.54 of 8 TB/s from
+// HBM-cold data (one-shot, 8 loads per thread), where one light load per thread reaches 0.81.  Here every lane moves 16 bytes per
+// load and a point's K neighbour rows are spread over FOUR lane groups: a 64-channel row is LPR = 64 / E lanes wide (E = 4 floats or 8
+// halves per 16 bytes), lane group g owns the neighbours k = g, g + 4, g + 8, ... (K = 6: two loads per tensor and lane, K = 4: one),
+// a point takes 4 * LPR lanes -- the whole wave in fp32, HALF a wave in fp16 storage (two points per wave: a wave per point there
+// was instruction-bound, 52 us where the quarter-wave form took 23).  Four times as many, that much lighter waves.  Two-pass softmax
+// exactly as written in the reference (max over K, exponentials against it, sum): the per-lane maxima and sums meet through two
+// butterfly steps across the lane groups (bfly: DPP / v_permlane*_swap, no LDS).  Loads are nontemporal (every byte is read once).
+// Same arithmetic contract as the quarter-wave form (fp32 arithmetic, hardware exp2).  Measured HBM-cold at the 128 x 2048 l0 shape,
+// batch 8, fp32: P1 42.4 -> 38.0 us (0.65 -> 0.72 of 8 TB/s), P2 31.6 -> 27.5 (0.60 -> 0.69); tools/cold_sweep.py.
+// The value of lane (l ^ D) for D = 8, 16, 32 WITHOUT the LDS crossbar: D = 8 is a DPP rotation inside the 16-lane row, D = 16 / 32
+// are gfx950's v_permlane16_swap / v_permlane32_swap (swapping a register's odd rows / upper half with a copy's even rows / lower
+// half leaves [r0 r0 r2 r2] + [r1 r1 r3 r3], resp. [lo lo] + [hi hi]: both partners in every lane).  __shfl_xor is a ds_bpermute.
+template <int D, class Op>
+__device__ __forceinline__ float bfly(float v, Op op)
+{
+    const unsigned u = __float_as_uint(v);
+    if constexpr (D == 8) {
+        return op(v, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)u, (int)u, 0x128 /* row_ror:8 */, 0xf, 0xf, false)));
+    } else if constexpr (D == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    } else {
+        static_assert(D == 32, "butterfly distance");
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+}
+template <int LPR, class Op>                        // all-reduce over a point's FOUR lane groups (LPR lanes wide each): every lane ends with the total
+__device__ __forceinline__ float across_groups(float v, Op op)
+{
+    v = bfly<LPR>(v, op);
+    return bfly<2 * LPR>(v, op);
+}
+
 template <class T, int J>                           // J = ceil(K / 4) neighbour rows per lane group
 __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_wave_kernel(const elo_softmax_pool_args a, const long rows)
 {
-    typedef typename Store<T>::V4 V4;
-    const int lane = threadIdx.x & 63, g = lane >> 4, sub = lane & 15;
-    const long r = (long)xcd_tile(blockIdx.x, gridDim.x) * (ELO_BLOCK / 64) + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const V4 *lg = reinterpret_cast<const V4 *>(static_cast<const T *>(a.logits) + r * a.K * 64) + sub;
-    const V4 *vl = reinterpret_cast<const V4 *>(static_cast<const T *>(a.values) + r * a.K * (long)a.values_stride) + sub;
-    const int vstep = a.values_stride >> 2;
+    typedef typename Store<T>::V16 V16;
+    constexpr int E = Store<T>::PER16, LPR = 64 / E;  // elements per lane, lanes per 64-channel row (= a lane group's width)
+    constexpr int LPP = 4 * LPR, PPW = 64 / LPP;      // lanes per point, points per wave (1 in fp32, 2 in fp16)
+    const int lane = threadIdx.x & 63, g = (lane % LPP) / LPR, sub = lane % LPR;
+    long r = ((long)xcd_tile(blockIdx.x, gridDim.x) * (ELO_BLOCK / 64) + (threadIdx.x >> 6)) * PPW + lane / LPP;
+    const bool mine = r < rows;                       // (fp16: the second half-wave of the last wave may have no point; it follows the
+    if (!mine) r = rows - 1;                          //  first one through the butterflies on a clamped row and stores nothing)
+    const V16 *lg = reinterpret_cast<const V16 *>(static_cast<const T *>(a.logits) + r * a.K * 64) + sub;
+    const V16 *vl = reinterpret_cast<const V16 *>(static_cast<const T *>(a.values) + r * a.K * (long)a.values_stride) + sub;
+    const int vstep = a.values_stride / E;
     const float *m = a.mask + r * a.K;
-    V4 l4[J], v4[J];
+    V16 l4[J], v4[J];
     float mk[J];
     bool live[J];
 #pragma unroll
@@ -470,43 +501,47 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_wave_kernel(const elo_
         const int k = g + 4 * j;
         live[j] = k < a.K;
         const int kc = live[j] ? k : 0;
-        l4[j] = __builtin_nontemporal_load(lg + (long)kc * 16);
+        l4[j] = __builtin_nontemporal_load(lg + (long)kc * LPR);
         v4[j] = __builtin_nontemporal_load(vl + (long)kc * vstep);
         mk[j] = m[kc];
     }
     auto ex = [](float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896f); };
-    float lv[J][4], mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    float lv[J][E], mx[E];
+#pragma unroll
+    for (int c = 0; c < E; ++c) mx[c] = -INFINITY;
 #pragma unroll
     for (int j = 0; j < J; ++j)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < E; ++c) {
             lv[j][c] = !live[j] ? -INFINITY : mk[j] == 1.0f ? (float)l4[j][c] : -1e10f;
             mx[c] = fmaxf(mx[c], lv[j][c]);
         }
+    auto fmax2 = [](float x, float y) { return fmaxf(x, y); };
+    auto add2 = [](float x, float y) { return x + y; };
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], 16, 64));
-        mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], 32, 64));
-    }
-    float den[4] = {0, 0, 0, 0}, acc[4] = {0, 0, 0, 0};
+    for (int c = 0; c < E; ++c) mx[c] = across_groups<LPR>(mx[c], fmax2);
+    float den[E], acc[E];
+#pragma unroll
+    for (int c = 0; c < E; ++c) den[c] = acc[c] = 0.0f;
 #pragma unroll
     for (int j = 0; j < J; ++j)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < E; ++c) {
             const float e = live[j] ? ex(lv[j][c] - mx[c]) : 0.0f;
             den[c] += e;
             acc[c] += e * (float)v4[j][c];
         }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        den[c] += __shfl_xor(den[c], 16, 64);
-        den[c] += __shfl_xor(den[c], 32, 64);
-        acc[c] += __shfl_xor(acc[c], 16, 64);
-        acc[c] += __shfl_xor(acc[c], 32, 64);
+    for (int c = 0; c < E; ++c) {
+        den[c] = across_groups<LPR>(den[c], add2);
+        acc[c] = across_groups<LPR>(acc[c], add2);
     }
-    if (g == 0)
-        STREAM_STORE((V4{(T)(acc[0] / den[0]), (T)(acc[1] / den[1]), (T)(acc[2] / den[2]), (T)(acc[3] / den[3])}),
-                     &reinterpret_cast<V4 *>(static_cast<T *>(a.out) + r * 64)[sub]);
+    if (g == 0 && mine) {
+        V16 o;
+#pragma unroll
+        for (int c = 0; c < E; ++c) o[c] = (T)(acc[c] / den[c]);
+        STREAM_STORE(o, &reinterpret_cast<V16 *>(static_cast<T *>(a.out) + r * 64)[sub]);
+    }
 }
 
 // scalar form for any C / alignment
@@ -746,11 +781,7 @@ __device__ __forceinline__ void normalise_q(const float *q, float *o)
 // same head redundantly -- identical instructions on identical inputs, a few microseconds -- block 0 stores it, and
 // then each block warps its 256 points of the NEXT level's cloud by that pose and does pass A of the projection:
 // the warp no longer waits for a kernel boundary after the pose head.
-// DIRECT (elo_pose_head_args.direct; 1: fp32 storage, 2: fp16): BLOCK = 1024 and the workgroup computes softmax_valid
-// itself -- wave g walks rows g, g+16, ... with 16 rows in flight, lane = channel -- instead of merging the slices of a
-// partial-sums launch: for clouds of <= 1024 points that launch (8.5 us + a launch boundary, three per forward) is all
-// latency.  Only the first 256 threads own a unit of the hidden layer.
-template <int BLOCK, int DIRECT>
+template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_args a, const int parts,
                                                           const elo_warp_project_args w, const int with_warp)
 {
@@ -761,12 +792,11 @@ __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_ar
     // The model's head (C = 64, hidden = 256 = one unit per thread): this thread's column of W_big and its rows of
     // W_q / W_t do not depend on anything computed here -- requested now, they arrive while the slices are merged
     // (otherwise four dependent batches of 16 loads sit between the merge and the heads).
-    constexpr int HEAD_C = 64, HEAD_HIDDEN = 256;
-    const bool model_head = DIRECT ? true : (a.C == HEAD_C && a.hidden == BLOCK);
-    const bool unit = !DIRECT || tid < HEAD_HIDDEN;    // this thread owns hidden unit `tid`
+    constexpr int HEAD_C = 64;
+    const bool model_head = a.C == HEAD_C && a.hidden == BLOCK;
     float wb[HEAD_C], wq[4], wt[3], bias_big = 0.0f;
     auto request_weights = [&]() {
-        const int j = unit ? tid : 0;
+        const int j = tid;                              // this thread owns hidden unit `tid`
 #pragma unroll
         for (int c = 0; c < HEAD_C; ++c) wb[c] = a.W_big[(size_t)c * a.hidden + j];
 #pragma unroll
@@ -775,115 +805,60 @@ __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_ar
         for (int o = 0; o < 3; ++o) wt[o] = a.W_t[(size_t)j * 3 + o];
         bias_big = a.b_big[j];
     };
-    float *mpart = head + 8 + 8 * (BLOCK / ELO_WAVE);                  // [3][G][64], G = 4 (merge) or BLOCK / 64 (direct)
-    if constexpr (DIRECT != 0) {
-        typedef typename std::conditional<DIRECT == 2, _Float16, float>::type feat_t;
-        const feat_t *__restrict__ feature = reinterpret_cast<const feat_t *>(a.feature) + (size_t)b * a.npoints * HEAD_C;
-        const feat_t *__restrict__ weight = reinterpret_cast<const feat_t *>(a.weight) + (size_t)b * a.npoints * HEAD_C;
-        const float *__restrict__ p = a.xyz + (size_t)b * a.npoints * 3;
-        constexpr int G = BLOCK / ELO_WAVE, U = 16;
-        // (g stays a vector value: as a scalar the validity test becomes s_load + s_waitcnt lgkmcnt(0) per row, and the 16
-        // rows of a step turn into 16 dependent round trips -- 7 us per step, measured)
-        const int c = tid & 63, g = tid >> 6, N = a.npoints;
-        float mx = -INFINITY, den = 0.0f, acc = 0.0f;
-        for (int n0 = g; n0 < N; n0 += G * U) {
-            // which of the step's 16 rows are valid points: lane u < 16 tests row n0 + u*G, one ballot (three registers
-            // instead of 48 for the coordinates); straight-line code below -- a branch around the second half of the
-            // loads or around an exponential splits the step into dependent round trips
-            const int nv = n0 + (c & 15) * G, nvc = nv < N ? nv : N - 1;
-            const float px = p[nvc * 3 + 0], py = p[nvc * 3 + 1], pz = p[nvc * 3 + 2];
-            float l[U], v[U];
+    float *mpart = head + 8 + 8 * (BLOCK / ELO_WAVE);                  // [3][4][64]: the four slice groups of the merge
+    // merge the slices: 4 threads per channel (C <= 64), each over every 4th slice, then a 4-way combine
+    if (model_head) request_weights();
+    const int c = tid & 63, q = tid >> 6;
+    float M = -INFINITY, D = 0.0f, A = 0.0f;
+    if (c < a.C) {
+        // slices q, q + 4, ... of channel c; per trip MINE slices per thread, all their loads out together (unconditional, on
+        // clamped indices: a load under a condition costs a full wait).  One trip of 16 for the <= 64 slices of a partial-sums
+        // launch; trips of 32 for the row tiles of an MLP launch that computed the partial sums itself (elo_pose_head_args.
+        // ready_parts: 225 tiles at l0 of a 64 x 1800 scan = two dependent round trips).  The two forms sit in a branch that is
+        // uniform for the launch, each with its loads AND their use inside.
+        auto trips = [&](auto mine) {
+            constexpr int MINE = decltype(mine)::value;
+            for (int i0 = q; i0 < parts; i0 += 4 * MINE) {
+                float m_[MINE], d_[MINE], a_[MINE];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int n = n0 + u * G, nn = n < N ? n : N - 1;
-                l[u] = (float)weight[nn * HEAD_C + c];
-                v[u] = (float)feature[nn * HEAD_C + c];
-            }
-            const unsigned okm = (unsigned)__ballot((c < U) & (nv < N) & !((px == 0.0f) & (py == 0.0f) & (pz == 0.0f)));
-            float bm = -INFINITY;
-#pragma unroll
-            for (int u = 0; u < U; ++u) bm = (okm >> u & 1u) ? fmaxf(bm, l[u]) : bm;
-            const float bz = bm > -INFINITY ? bm : 0.0f;
-            float d16 = 0.0f, a16 = 0.0f;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float e = (okm >> u & 1u) ? exp_acc(l[u] - bz) : 0.0f;
-                d16 += e;
-                a16 += e * v[u];
-            }
-            const float m2 = fmaxf(mx, bm);
-            const float s0 = mx > -INFINITY ? exp_acc(mx - m2) : 0.0f, s1 = bm > -INFINITY ? exp_acc(bm - m2) : 0.0f;
-            den = den * s0 + d16 * s1;
-            acc = acc * s0 + a16 * s1;
-            mx = m2;
-        }
-        request_weights();                             // (after the loop: its 32 values per step and these 72 do not fit 128 registers together)
-        mpart[(0 * G + g) * 64 + c] = mx; mpart[(1 * G + g) * 64 + c] = den; mpart[(2 * G + g) * 64 + c] = acc;
-        __syncthreads();
-        if (tid < 64) {
-            float MM = -INFINITY;
-            for (int i = 0; i < G; ++i) MM = fmaxf(MM, mpart[(0 * G + i) * 64 + tid]);
-            float DD = 0.0f, AA = 0.0f;
-            for (int i = 0; i < G; ++i) {
-                if (mpart[(1 * G + i) * 64 + tid] == 0.0f) continue;
-                const float sc = exp_acc(mpart[(0 * G + i) * 64 + tid] - MM);
-                DD += mpart[(1 * G + i) * 64 + tid] * sc; AA += mpart[(2 * G + i) * 64 + tid] * sc;
-            }
-            feat[tid] = DD > 0.0f ? AA / DD : 0.0f;
-        }
-    } else {   // merge the slices: 4 threads per channel (C <= 64), each over every 4th slice, then a 4-way combine
-        if (model_head) request_weights();
-        const int c = tid & 63, q = tid >> 6;
-        float M = -INFINITY, D = 0.0f, A = 0.0f;
-        if (c < a.C) {
-            // slices q, q + 4, ... of channel c; per trip MINE slices per thread, all their loads out together (unconditional, on
-            // clamped indices: a load under a condition costs a full wait).  One trip of 16 for the <= 64 slices of a partial-sums
-            // launch; trips of 32 for the row tiles of an MLP launch that computed the partial sums itself (elo_pose_head_args.
-            // ready_parts: 225 tiles at l0 of a 64 x 1800 scan = two dependent round trips).  The two forms sit in a branch that is
-            // uniform for the launch, each with its loads AND their use inside.
-            auto trips = [&](auto mine) {
-                constexpr int MINE = decltype(mine)::value;
-                for (int i0 = q; i0 < parts; i0 += 4 * MINE) {
-                    float m_[MINE], d_[MINE], a_[MINE];
-#pragma unroll
-                    for (int u = 0; u < MINE; ++u) {
-                        const int i = i0 + 4 * u;
-                        const size_t at = ((size_t)b * ELO_SV_MAX_PARTS + (i < parts ? i : 0)) * a.C + c;
-                        m_[u] = s.mx[at]; a_[u] = s.acc[at];
-                        d_[u] = i < parts ? s.den[at] : 0.0f;
-                    }
-#pragma unroll
-                    for (int u = 0; u < MINE; ++u) {
-                        if (d_[u] == 0.0f) continue;
-                        if (m_[u] > M) { const float sc = exp_acc(M - m_[u]); D = D * sc + d_[u]; A = A * sc + a_[u]; M = m_[u]; }
-                        else { const float sc = exp_acc(m_[u] - M); D += d_[u] * sc; A += a_[u] * sc; }
-                    }
+                for (int u = 0; u < MINE; ++u) {
+                    const int i = i0 + 4 * u;
+                    const size_t at = ((size_t)b * ELO_SV_MAX_PARTS + (i < parts ? i : 0)) * a.C + c;
+                    m_[u] = s.mx[at]; a_[u] = s.acc[at];
+                    d_[u] = i < parts ? s.den[at] : 0.0f;
                 }
-            };
-            if (parts <= 64) trips(std::integral_constant<int, 16>());
-            else trips(std::integral_constant<int, 32>());
-        }
-        mpart[(0 * 4 + q) * 64 + c] = M; mpart[(1 * 4 + q) * 64 + c] = D; mpart[(2 * 4 + q) * 64 + c] = A;
-        __syncthreads();
-        if (tid < 64) {
-            float MM = -INFINITY;
-            for (int i = 0; i < 4; ++i) MM = fmaxf(MM, mpart[(0 * 4 + i) * 64 + tid]);
-            float DD = 0.0f, AA = 0.0f;
-            for (int i = 0; i < 4; ++i) {
-                if (mpart[(1 * 4 + i) * 64 + tid] == 0.0f) continue;
-                const float sc = exp_acc(mpart[(0 * 4 + i) * 64 + tid] - MM);
-                DD += mpart[(1 * 4 + i) * 64 + tid] * sc; AA += mpart[(2 * 4 + i) * 64 + tid] * sc;
+#pragma unroll
+                for (int u = 0; u < MINE; ++u) {
+                    if (d_[u] == 0.0f) continue;
+                    if (m_[u] > M) { const float sc = exp_acc(M - m_[u]); D = D * sc + d_[u]; A = A * sc + a_[u]; M = m_[u]; }
+                    else { const float sc = exp_acc(m_[u] - M); D += d_[u] * sc; A += a_[u] * sc; }
+                }
             }
-            if (tid < a.C) feat[tid] = DD > 0.0f ? AA / DD : 0.0f;
-        }
-        for (int c2 = 64 + tid; c2 < a.C; c2 += blockDim.x) feat[c2] = sv_merge(s, b, c2, a.C, parts);   // C > 64 (not the model)
+        };
+        if (parts <= 64) trips(std::integral_constant<int, 16>());
+        else trips(std::integral_constant<int, 32>());
     }
+    mpart[(0 * 4 + q) * 64 + c] = M; mpart[(1 * 4 + q) * 64 + c] = D; mpart[(2 * 4 + q) * 64 + c] = A;
+    __syncthreads();
+    if (tid < 64) {
+        float MM = -INFINITY;
+        for (int i = 0; i < 4; ++i) MM = fmaxf(MM, mpart[(0 * 4 + i) * 64 + tid]);
+        float DD = 0.0f, AA = 0.0f;
+        for (int i = 0; i < 4; ++i) {
+            if (mpart[(1 * 4 + i) * 64 + tid] == 0.0f) continue;
+            const float sc = exp_acc(mpart[(0 * 4 + i) * 64 + tid] - MM);
+            DD += mpart[(1 * 4 + i) * 64 + tid] * sc; AA += mpart[(2 * 4 + i) * 64 + tid] * sc;
+        }
+        if (tid < a.C) feat[tid] = DD > 0.0f ? AA / DD : 0.0f;
+    }
+    for (int c2 = 64 + tid; c2 < a.C; c2 += blockDim.x) feat[c2] = sv_merge(s, b, c2, a.C, parts);   // C > 64 (not the model)
+
     __syncthreads();
     if (model_head) {                                      // conv1d C -> hidden, no activation (:197), same summation order
         float v = bias_big;
 #pragma unroll
         for (int c = 0; c < HEAD_C; ++c) v += feat[c] * wb[c];
-        if (unit) big[tid] = v;
+        big[tid] = v;
     } else {
         for (int j = tid; j < a.hidden; j += blockDim.x) {
             float v = a.b_big[j];
@@ -896,7 +871,7 @@ __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_ar
     {   // conv1d hidden -> 4 (q) and hidden -> 3 (t): 7 dot products over `hidden`, reduced wave-wide then across waves
         float part[7] = {0, 0, 0, 0, 0, 0, 0};
         if (model_head) {
-            const float bj = unit ? big[tid] : 0.0f;
+            const float bj = big[tid];
 #pragma unroll
             for (int o = 0; o < 4; ++o) part[o] += bj * wq[o];
 #pragma unroll
@@ -1115,7 +1090,7 @@ extern "C" int elo_cv_encode1(const elo_cv_encode1_args *a, elo_stream_t stream)
         const FastDiv ds = fast_div(5 + a->C), dk = fast_div(a->K);
         hipStream_t s = (hipStream_t)stream;
         const int rpi = ELO_BLOCK / (5 + a->C), batch_rows = rpi * ENC_BATCH;
-        if (batch_rows <= per && rpi * (5 + a->C) * 16 >= ELO_BLOCK * 15 && !tuning().encode1_slots) {   // <= 1/16 of the lanes idle
+        if (batch_rows <= per && rpi * (5 + a->C) * 16 >= ELO_BLOCK * 15) {   // <= 1/16 of the lanes idle
             const int span = per / batch_rows * batch_rows;
             const dim3 cgrid((unsigned)((rows + span - 1) / span));
             if (a->dtype == ELO_F16) {
@@ -1188,10 +1163,12 @@ extern "C" int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_strea
     const bool vec = a->C % 4 == 0 && a->C <= 1024 && ELO_BLOCK % (a->C / 4) == 0 && a->values_stride % 4 == 0 &&
                      ((uintptr_t)a->logits | (uintptr_t)a->values | (uintptr_t)a->out) % (4 * esz) == 0;
     if (a->dtype == ELO_F16 && !vec) return fail(ELO_ERR_ARG, "%s: fp16 needs C % 4 == 0 and 8-byte aligned tensors", who);
-    if (vec && a->C == 64 && a->K <= 32 && tuning().pool_wave) {        // wave per point (round 6): light loads, 4 x the waves
-        const dim3 grid((unsigned)((rows + ELO_BLOCK / 64 - 1) / (ELO_BLOCK / 64)));
+    if (vec && a->C == 64 && a->K <= 32 && a->values_stride % (16 / esz) == 0 &&
+        ((uintptr_t)a->logits | (uintptr_t)a->values | (uintptr_t)a->out) % 16 == 0 && tuning().pool_wave) {   // wave per point (round 6): 16-byte loads, many light waves
+        const long ppb = (ELO_BLOCK / 64) * (a->dtype == ELO_F16 ? 2 : 1);      // points per workgroup
+        const dim3 grid((unsigned)((rows + ppb - 1) / ppb));
         hipStream_t s = (hipStream_t)stream;
-        const int J = (a->K + 3) / 4;
+        const int J = (a->K + 3) / 4;                                            // neighbour rows per lane group
 #define ELO_POOL_WAVE(J_)                                                                                                          \
         do {                                                                                                                      \
             if (a->dtype == ELO_F16) hipLaunchKernelGGL((softmax_pool_wave_kernel<half_t, J_>), grid, dim3(ELO_BLOCK), 0, s, *a, rows); \
@@ -1282,20 +1259,11 @@ static int pose_head_impl(const elo_pose_head_args *a, const elo_warp_project_ar
         wv.q = a->q;                                  // pass B only asks whether a warp happened (reads `warped`)
         wv.t = a->t;
     }
-    ELO_REQUIRE(!a->direct || (a->npoints <= ELO_POSE_DIRECT_MAX && a->C == 64 && a->hidden == 256), who,
-                "direct takes npoints <= ELO_POSE_DIRECT_MAX, C == 64, hidden == 256");
-    ELO_REQUIRE(a->ready_parts >= 0 && a->ready_parts <= ELO_SV_MAX_PARTS && !(a->ready_parts && a->direct), who,
-                "ready_parts is 0..ELO_SV_MAX_PARTS and not combined with direct");
+    ELO_REQUIRE(a->ready_parts >= 0 && a->ready_parts <= ELO_SV_MAX_PARTS, who, "ready_parts is 0..ELO_SV_MAX_PARTS");
     ELO_REQUIRE(!a->ready_parts || a->C == 64, who, "ready_parts: the partial sums of an MLP launch are 64 channels wide");
     if (a->batch == 0) return ELO_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (a->direct) {                                  // one launch: the head's workgroups reduce the rows themselves
-        constexpr int DB = 1024;
-        const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (DB / ELO_WAVE) + 3 * (DB / ELO_WAVE) * 64);
-        const unsigned xb = w ? (unsigned)((w->npoints + DB - 1) / DB) : 1u;
-        if (f16) hipLaunchKernelGGL((pose_head_kernel<DB, 2>), dim3(xb, a->batch), dim3(DB), lds, s, *a, 0, wv, w ? 1 : 0);
-        else hipLaunchKernelGGL((pose_head_kernel<DB, 1>), dim3(xb, a->batch), dim3(DB), lds, s, *a, 0, wv, w ? 1 : 0);
-    } else {
+    {
         const int parts = a->ready_parts ? a->ready_parts : sv_parts(a->npoints);
         const ProjectionClear clear{a->clear_scratch, a->clear_xyz, (unsigned *)a->clear_feat, a->clear_cells,
                                     f16 ? a->clear_C / 2 : a->clear_C, a->batch};
@@ -1309,7 +1277,7 @@ static int pose_head_impl(const elo_pose_head_args *a, const elo_warp_project_ar
                                a->npoints, a->C, parts, a->scratch, clear);
         const size_t lds = sizeof(float) * ((size_t)a->C + a->hidden + 8 + 8 * (ELO_BLOCK / ELO_WAVE) + 3 * 4 * 64);
         const unsigned xb = w ? (unsigned)((w->npoints + ELO_BLOCK - 1) / ELO_BLOCK) : 1u;
-        hipLaunchKernelGGL((pose_head_kernel<ELO_BLOCK, 0>), dim3(xb, a->batch), dim3(ELO_BLOCK), lds, s, *a, parts, wv, w ? 1 : 0);
+        hipLaunchKernelGGL((pose_head_kernel<ELO_BLOCK>), dim3(xb, a->batch), dim3(ELO_BLOCK), lds, s, *a, parts, wv, w ? 1 : 0);
     }
     if (w) {
         const size_t cells = (size_t)w->batch * w->H * w->W, pts = (size_t)w->batch * w->npoints;

@@ -1227,226 +1227,6 @@ __global__ __launch_bounds__(ELO_BLOCK) void setconv_small_kernel(const elo_setc
     }
 }
 
-// ================================================================ the same narrow set-conv on an LDS-staged window tile (round 5)
-// setconv_small_kernel's walk is "half a wave per centre, a lane per window slot": every centre fetches its whole window
-// slot by slot from L2 (five 12-byte gathers per lane) and judges it with a ballot per 32 slots -- 495 of the kernel's 627
-// vector instructions per wave, a third of a batch-8 forward's grouping cost (profiles/r04_sq_forward_budget.txt).  When the
-// centres are the STRIDED PIXELS of a grid in row-major order (model_util.get_selected_idx: every down_conv of the model;
-// elo_setconv_args.centre_cols) the windows of neighbouring centres overlap or abut, so a workgroup takes TC = 32
-// consecutive centres of one centre row and
-//   1. stages the UNION of their windows once, coalesced, as 16-byte cells {x, y, z, (h << 16) | w or -1} (-1: a row outside
-//      the grid or an empty pixel -- the reference skips both the same way, fused_conv_g.cu:83-111), with the single
-//      cylindrical wrap of the columns applied while staging;
-//   2. walks the window in the caller's visiting order with EIGHT LANES PER CENTRE: a round covers 64 positions of the
-//      order, lane q of a centre probes positions 64 r + 8 q .. + 7 -- eight independent LDS reads, no L2 round trip, no
-//      ballot --, the lanes' hit counts are scanned inside the 8-lane group (DPP) and every hit gets its rank in visiting
-//      order; ranks < K are the neighbours (the reference takes the first K hits and stops: the same set in the same
-//      order), and the walk stops after the round in which every centre of the wave has its K hits;
-//   3. runs gather -> MLP -> masked max exactly as setconv_small_kernel does (half a wave per centre, a lane per neighbour
-//      row), the neighbours' xyz coming from the staged cells.
-// A wave keeps its 8 centres through 2 and 3: no workgroup barrier after the staging.  Same outputs bit for bit
-// (tests/test_grouping_gpu.py::test_lds_tiled_setconv_grouping_is_bit_exact).
-// MEASURED SLOWER and therefore off by default (elo_tuning.tiled_setconv = 0; profiles/r05_ab_tiled.txt): 51 us against 37 us on the
-// 6 -> 8 -> 8 -> 16 layer at 16 images, 32 against 28 (17 for the matrix-core form) on the 19-channel layer, 28.1 k -> 26.7 k pairs/s at
-// batch 8.  The strided centres' windows barely overlap (15 columns wide at a stride of 8: 1.9 x reuse; 74 staged cells per centre
-// against <= 135 slots walked, usually 64), the 38 KB tile leaves 3 workgroups = 12 waves per CU where the L2 walk runs 32, and a
-// wave's four MLP passes each pay their own feature-gather round trip: the kernel is its latency chain times its occupancy.
-constexpr int TILED_TC = 32;                      // centres per workgroup (8 per wave)
-
-__host__ __device__ inline int tiled_region_cols(int centre_stride_w, int stride_w, int kernel_w)
-{
-    return ((TILED_TC - 1) * centre_stride_w) / stride_w + kernel_w + 1;     // (+1: floor(a/s) + floor(b/s) <= floor((a+b)/s))
-}
-
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }   // 0 where the source lane is out of the row
-
-template <int CIN, int N1, int N2, int N3>
-__global__ __launch_bounds__(ELO_BLOCK, 4) void setconv_tiled_kernel(const elo_setconv_args a, const int RW)
-{
-    constexpr int G = 32, TC = TILED_TC, C = CIN - 3;
-    constexpr int W1 = 0, B1 = W1 + CIN * N1, W2 = B1 + N1, B2 = W2 + N1 * N2, W3 = B2 + N2, B3 = W3 + N2 * N3,
-                  WEND = B3 + N3;
-    extern __shared__ __align__(16) float lds[];
-    const elo_group_spec &gs = a.group;
-    const int kH = gs.kernel_h, kW = gs.kernel_w, KT = kH * kW, cells = kH * RW;
-    float4 *region = reinterpret_cast<float4 *>(lds);                        // [kH * RW]
-    int *tab = reinterpret_cast<int *>(region + cells);                      // [KT] visiting order as tile-local cell offsets
-    int *hits = tab + ((KT + 3) & ~3);                                       // [TC][G] tile-local cell of neighbour `rank`, -1: none
-    float *cxyz = reinterpret_cast<float *>(hits + TC * G);                  // [TC][4]
-    float *wsm = cxyz + TC * 4;                                              // [WEND]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- everything whose address is known goes out first: weights (registers until the MLP), the order, the centres
-    constexpr int WITER = (WEND + ELO_BLOCK - 1) / ELO_BLOCK;
-    float wv[WITER];
-#pragma unroll
-    for (int u = 0; u < WITER; ++u) {
-        const int i = tid + u * ELO_BLOCK < WEND ? tid + u * ELO_BLOCK : WEND - 1;
-        const float *src = i < B1 ? a.layers[0].w_plain + (i - W1) : i < W2 ? a.layers[0].bias + (i - B1)
-                         : i < B2 ? a.layers[1].w_plain + (i - W2) : i < W3 ? a.layers[1].bias + (i - B2)
-                         : i < B3 ? a.layers[2].w_plain + (i - W3) : a.layers[2].bias + (i - B3);
-        wv[u] = *src;
-    }
-    const int b = blockIdx.z, ci = blockIdx.y, j0 = blockIdx.x * TC;         // batch element, centre row, first centre column
-    const int hc = ci * a.centre_stride_h;
-    const int base_h = div_stride(hc, gs.stride_h), bw0 = div_stride(j0 * a.centre_stride_w, gs.stride_w);
-    const int h0 = base_h - kH / 2, w0 = bw0 - kW / 2;                        // region origin in the queried grid (unwrapped)
-    const float *grid2 = a.src_xyz + (size_t)b * a.H2 * a.W2 * 3;
-    for (int i = tid; i < KT; i += ELO_BLOCK) {
-        int dh, dw;
-        if (gs.decoded_hw) { const int o = gs.decoded_hw[i]; dh = o >> 16; dw = (int)(short)(o & 0xffff); }
-        else { const int p = gs.random_hw[i]; dh = p / kW - kH / 2; dw = p % kW - kW / 2; }
-        tab[i] = (dh + kH / 2) * RW + dw + kW / 2;
-    }
-    if (tid < TC) {
-        const int j = j0 + tid;
-        const bool mine = j < a.centre_cols;
-        const int wc = (mine ? j : a.centre_cols - 1) * a.centre_stride_w;
-        const float *cp = a.xyz1_grid + (((size_t)b * a.H + hc) * a.W + wc) * 3;
-        const float cx = cp[0], cy = cp[1], cz = cp[2];
-        cxyz[tid * 4 + 0] = cx; cxyz[tid * 4 + 1] = cy; cxyz[tid * 4 + 2] = cz;
-        if (mine && a.new_xyz) {
-            float *o = a.new_xyz + (((size_t)b * a.centre_rows + ci) * a.centre_cols + j) * 3;
-            o[0] = cx; o[1] = cy; o[2] = cz;                                  // :206
-        }
-    }
-    {   // the window union: all of a thread's loads of a batch go out before its first LDS write
-        constexpr int PER = 4;
-        for (int e0 = 0; e0 < cells; e0 += PER * ELO_BLOCK) {
-            float x[PER], y[PER], z[PER];
-            int hw[PER];
-            bool in[PER];
-#pragma unroll
-            for (int v = 0; v < PER; ++v) {
-                const int e = min(e0 + v * ELO_BLOCK + tid, cells - 1);
-                const int rr = small_div(e, RW), cc = e - rr * RW;
-                const int h = h0 + rr;
-                int w = (w0 + cc) % a.W2;
-                if (w < 0) w += a.W2;                                         // the cylindrical wrap (:89-97; kW/2 <= W2: one wrap = modulo)
-                in[v] = h >= 0 && h < a.H2;
-                hw[v] = (h << 16) | w;
-                const float *q = grid2 + ((size_t)(in[v] ? h : 0) * a.W2 + w) * 3;
-                x[v] = q[0]; y[v] = q[1]; z[v] = q[2];
-            }
-#pragma unroll
-            for (int v = 0; v < PER; ++v) {
-                const int e = e0 + v * ELO_BLOCK + tid;
-                if (e < cells) {
-                    const bool ok = in[v] && !(sq3(x[v], y[v], z[v]) <= ELO_EPS);             // :83-86, :106-111
-                    region[e] = float4{x[v], y[v], z[v], __int_as_float(ok ? hw[v] : -1)};
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < WITER; ++u)
-        if (tid + u * ELO_BLOCK < WEND) wsm[tid + u * ELO_BLOCK] = wv[u];
-    for (int i = tid; i < TC * G; i += ELO_BLOCK) hits[i] = -1;
-    __syncthreads();
-
-    // ---- random-k: wave w owns centres 8w .. 8w+7, lane (cw, q) = (lane / 8, lane % 8)
-    {
-        const int cw = lane >> 3, q = lane & 7, c = wave * 8 + cw;
-        const int j = j0 + c;
-        const bool live = j < a.centre_cols;
-        const float cx = cxyz[c * 4 + 0], cy = cxyz[c * 4 + 1], cz = cxyz[c * 4 + 2];
-        const bool centre_ok = live && !(pick_max(sq3(cx, cy, cz), ELO_EPS) <= ELO_EPS);          // :62-70
-        const int origin = div_stride((live ? j : j0) * a.centre_stride_w, gs.stride_w) - bw0;
-        const float r2 = gs.distance * gs.distance;
-        int taken = 0;
-#pragma unroll 1
-        for (int r0 = 0; r0 < KT; r0 += 64) {
-            int cell[8];
-            float4 pq[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int p = r0 + q * 8 + u;
-                cell[u] = tab[p < KT ? p : 0] + origin;
-                pq[u] = region[cell[u]];
-            }
-            unsigned m = 0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float d = pick_max(sq3(__fsub_rn(cx, pq[u].x), __fsub_rn(cy, pq[u].y), __fsub_rn(cz, pq[u].z)), ELO_EPS);   // :118
-                const bool hit = centre_ok && r0 + q * 8 + u < KT && __float_as_int(pq[u].w) >= 0 && !(d > r2);
-                m |= hit ? 1u << u : 0u;
-            }
-            const int cnt = __popc(m);
-            // inclusive scan of the counts over the 8 lanes of the centre (the other half of the DPP row is masked by q)
-            int s = cnt;
-            { const int t = dpp_i<0x111>(s); s += q >= 1 ? t : 0; }           // row_shr:1
-            { const int t = dpp_i<0x112>(s); s += q >= 2 ? t : 0; }           // row_shr:2
-            { const int t = dpp_i<0x114>(s); s += q >= 4 ? t : 0; }           // row_shr:4
-            int tot = cnt;                                                    // the centre's hits of this round, in every lane
-            tot += dpp_i<0xb1>(tot);                                          // quad_perm:[1,0,3,2]
-            tot += dpp_i<0x4e>(tot);                                          // quad_perm:[2,3,0,1]
-            tot += dpp_i<0x141>(tot);                                         // row_half_mirror: the other quad of the 8 lanes
-            int rank = taken + s - cnt;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if ((m >> u) & 1u) {
-                    if (rank < G) hits[c * G + rank] = cell[u];
-                    ++rank;
-                }
-            }
-            taken += tot;
-            if (__builtin_amdgcn_ballot_w64(centre_ok && taken < G) == 0) break;             // (uniform) every centre of the wave is full
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- gather -> MLP -> masked max: half a wave per centre, a lane per neighbour row; four passes over the wave's 8 centres
-    const int row = lane & 31, half = lane >> 5;
-    const int f16 = a.feat_dtype == ELO_F16;
-    // a masked row gathers pixel (0,0,0) of batch element 0 and multiplies it by 0 (tf.gather_nd(...) * mask, SURVEY.md Appendix
-    // A.4; setconv_small_kernel does the same): one uniform load for the kernel
-    const float z0 = a.src_xyz[0], z1 = a.src_xyz[1], z2 = a.src_xyz[2];
-#pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-        asm volatile("" ::: "memory");           // (the weights are re-read from LDS per pass: hoisted out of the loop, the ~270 / ~1100
-                                                  //  loop-invariant ds_reads of the MLP became as many live registers and spilled)
-        const int c = wave * 8 + pass * 2 + half;
-        const int j = j0 + c;
-        const bool live = j < a.centre_cols;
-        const long pt = ((long)b * a.centre_rows + ci) * a.centre_cols + (live ? j : a.centre_cols - 1);
-        const float cx = cxyz[c * 4 + 0], cy = cxyz[c * 4 + 1], cz = cxyz[c * 4 + 2];
-        const int hit = hits[c * G + row];
-        const float4 nq = region[hit >= 0 ? hit : 0];
-        const int hw = hit >= 0 ? __float_as_int(nq.w) : -1;
-        const float m = hw >= 0 ? 1.0f : 0.0f;
-        const long cell = hw >= 0 ? ((long)b * a.H2 + (hw >> 16)) * a.W2 + (hw & 0xffff) : 0;   // empty slot: index (0,0,0)
-        if (live && gs.idx_out) {
-            int *o = gs.idx_out + (pt * G + row) * 3;
-            o[0] = hw >= 0 ? b : 0; o[1] = hw >= 0 ? hw >> 16 : 0; o[2] = hw >= 0 ? hw & 0xffff : 0;
-        }
-        if (live && gs.mask_out) gs.mask_out[pt * G + row] = m;
-        float x[32], y[32];
-        if (f16) {
-            const _Float16 *sf = reinterpret_cast<const _Float16 *>(a.src_feat) + cell * C;
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) x[ch] = (float)sf[ch];
-        } else {
-            const float *sf = reinterpret_cast<const float *>(a.src_feat) + cell * C;
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) x[ch] = sf[ch];
-        }
-        const float s0 = hw >= 0 ? nq.x : z0, s1 = hw >= 0 ? nq.y : z1, s2 = hw >= 0 ? nq.z : z2;
-        x[C + 0] = s0 * m - cx; x[C + 1] = s1 * m - cy; x[C + 2] = s2 * m - cz;
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) x[ch] *= m;
-        small_layer<CIN, N1>(x, y, wsm + W1, wsm + B1, a.layers[0].relu);
-        small_layer<N1, N2>(y, x, wsm + W2, wsm + B2, a.layers[1].relu);
-        small_layer<N2, N3>(x, y, wsm + W3, wsm + B3, a.layers[2].relu);
-#pragma unroll
-        for (int ch = 0; ch < N3; ++ch) y[ch] = half_wave_max_nonneg(y[ch] * m);
-        if (live && row == G - 1) {
-#pragma unroll
-            for (int ch = 0; ch < N3; ch += 4) feat_store4(a.out, pt * N3 + ch, float4{y[ch], y[ch + 1], y[ch + 2], y[ch + 3]}, f16);
-        }
-    }
-}
-
 // ================================================================ row-wise MLP over concatenated sources
 // stage 1: columns [0, w0 + w1 + w2) = the sources; its last layer writes `out` to HBM straight from the accumulators
 // and, with a second stage, to columns [0, N) of the tile; stage 2: [out (N) | before | after] -> layers2 -> out2.
@@ -1902,10 +1682,6 @@ struct RrStream {
 // emit(pass, t, acc): epilogue of column block 2*pass + t.
 // XMASK bit k: pair k of `in` holds exact fp16 values (lo == 0); XTAIL: so does the tail block -- see mma_pair's A_EXACT
 // init(cb, b): the accumulators' initial value for column block cb, given the block's bias quad b (default: the bias itself).
-// Round 5, "layer 0 through the gather": the first layer of a grouped operator is linear in its gathered inputs, so the part of
-// it that belongs to a SOURCE point (W_s . feat[source]) or to the CENTRE (W_c . feat[centre] + bias) is computed once per
-// point by rowlinear_rr_kernel and enters here as the starting value -- the per-row matrix work of the layer is then only its
-// per-row inputs (the geometry tail, the xyz encoding).
 struct RrBiasInit { __device__ __forceinline__ f32x4 operator()(int, const float4 b) const { return f32x4{b.x, b.y, b.z, b.w}; } };
 template <int KP, bool TAIL, int NCB, int G0, int MODE = MODE_SPLIT, unsigned XMASK = 0u, bool XTAIL = false, class Fetch, class Advance, class Emit,
           class Init = RrBiasInit>
@@ -2138,16 +1914,13 @@ __device__ __forceinline__ float rr_bias_request(const float *const (&b)[NL], co
 }
 __device__ __forceinline__ void rr_bias_store(float *lds, int tid, int total, float v) { if (tid < total) lds[RR_BIAS_OFF + tid] = v; }
 
-template <int FP, bool PRE = false> struct Cv1Plan {   // CV_0 (FP pairs + geometry tail -> 128), CV_1, CV_2, CV_xyz (tail -> 64), sum_CV_0, sum_CV_1
-    static constexpr int NL = 6;                     // PRE: CV_0's feature pairs were applied per point (a.pre_c, a.pre_s): the geometry tail only
-    static constexpr int KP[6] = {PRE ? 0 : FP, 4, 2, 0, 4, 4}, TL[6] = {1, 0, 0, 1, 0, 0}, NCB[6] = {8, 4, 4, 4, 8, 4};
+template <int FP> struct Cv1Plan {   // CV_0 (FP pairs + geometry tail -> 128), CV_1, CV_2, CV_xyz (tail -> 64), sum_CV_0, sum_CV_1
+    static constexpr int NL = 6;
+    static constexpr int KP[6] = {FP, 4, 2, 0, 4, 4}, TL[6] = {1, 0, 0, 1, 0, 0}, NCB[6] = {8, 4, 4, 4, 8, 4};
 };
 
-// PRE ("layer 0 through the gather"): CV_0 = W_geo . geometry + (b + W_1 . feat1[centre]) + mask * (W_2 . feat2[neighbour]); the two
-// bracketed terms are rows of a.pre_c / a.pre_s (rowlinear_rr_kernel: once per point instead of once per (point, neighbour) row),
-// a.cv0 is then the geometry-only layer (K = 10).  Same sums up to the order of three fp32 additions.
 // `block` of `nblocks`: blockIdx.x / gridDim.x of a plain launch, or the workgroup's share of a heterogeneous one (cv1_setconv_rr_kernel)
-template <int C, bool F16, int MODE = MODE_SPLIT, bool PRE = false>
+template <int C, bool F16, int MODE = MODE_SPLIT>
 __device__ __forceinline__ void cv1_rr_body(const elo_cv1_args &a, const unsigned block, const unsigned nblocks)
 {
     extern __shared__ __align__(16) float lds[];
@@ -2161,7 +1934,7 @@ __device__ __forceinline__ void cv1_rr_body(const elo_cv1_args &a, const unsigne
     unsigned bad = 0;
     RR_STAMP(0);
     // ---- the W stream.  Steps per layer: CV_0 4*(FP+1), CV_1 2*4, CV_2 2*2, CV_xyz 2*1, sum_CV_0 4*4, sum_CV_1 2*4
-    typedef RrStream<Cv1Plan<FP, PRE>, MODE> Stream;
+    typedef RrStream<Cv1Plan<FP>, MODE> Stream;
     Stream ws{{a.cv0.w_packed, a.cv1.w_packed, a.cv2.w_packed, a.cv_xyz.w_packed, a.sum_cv0.w_packed, a.sum_cv1.w_packed}, ring, wave, lane, {}};
     constexpr int E0 = Stream::first(1), E1 = Stream::first(2), E2 = Stream::first(3), E3 = Stream::first(4), E4 = Stream::first(5);
     auto fetch = [&](int g, RrW &dst) { ws.fetch(g, dst); };
@@ -2187,42 +1960,26 @@ __device__ __forceinline__ void cv1_rr_body(const elo_cv1_args &a, const unsigne
     const bool keep2 = used && mk != 0.0f;
     ActPair in0[FP];                                 // CV_0's input pairs: [feat1 | feat2] blocks, two per pair
     uint4 geo;                                       // its tail: quad kq of [p, g*m, g*m - p, |g*m - p|, 0 ...]
-    float4 start0[PRE ? 8 : 1];                      // PRE: CV_0's accumulators start at b + W_1 feat1[pt] + mk * W_2 feat2[cell]
     {
         typedef typename std::conditional<F16, uint2, float4>::type Item;     // 4 channels
         Item f1[FP], f2[FP];
-        float4 pcq[PRE ? 8 : 1], psq[PRE ? 8 : 1];
-        if constexpr (PRE) {
-            const float4 *rc = reinterpret_cast<const float4 *>(a.pre_c) + pt * 32 + kq;
-            const float4 *rs = reinterpret_cast<const float4 *>(a.pre_s) + (long)cell * 32 + kq;
+        const Item *r1 = reinterpret_cast<const Item *>(a.feat1) + (pt * C >> 2) + kq;
+        const Item *r2 = reinterpret_cast<const Item *>(a.feat2) + ((long)cell * C >> 2) + kq;
 #pragma unroll
-            for (int cb = 0; cb < 8; ++cb) { pcq[cb] = rc[cb * 4]; psq[cb] = rs[cb * 4]; }
-        } else {
-            const Item *r1 = reinterpret_cast<const Item *>(a.feat1) + (pt * C >> 2) + kq;
-            const Item *r2 = reinterpret_cast<const Item *>(a.feat2) + ((long)cell * C >> 2) + kq;
-#pragma unroll
-            for (int j = 0; j < FP; ++j) { f1[j] = r1[j * 4]; f2[j] = r2[j * 4]; }
-        }
+        for (int j = 0; j < FP; ++j) { f1[j] = r1[j * 4]; f2[j] = r2[j * 4]; }
         const float *c = a.xyz1 + pt * 3, *g = a.xyz2 + (long)cell * 3;
         const float pc0 = c[0], pc1 = c[1], pc2 = c[2], pg0 = g[0], pg1 = g[1], pg2 = g[2];
         ws.prime();                                  // superstep 0 into the ring (its load went out first)
-        if constexpr (PRE) {
+        auto quad = [&](const Item &v, bool keep) {
+            const uint4 z{0u, 0u, 0u, 0u};
+            if constexpr (F16) return keep ? quad_of_halves(v) : z;
+            else return keep ? pack_quad<MODE>(v, bad) : z;
+        };
+        // CV_0's k-blocks in order: feat1 blocks 0..FP-1, feat2 blocks 0..FP-1, geometry; block b sits in pair b / 2, half b % 2
 #pragma unroll
-            for (int cb = 0; cb < 8; ++cb)           // (mk is exactly 0 or 1: the product is exact, the sum rounds once)
-                start0[cb] = float4{__builtin_fmaf(mk, psq[cb].x, pcq[cb].x), __builtin_fmaf(mk, psq[cb].y, pcq[cb].y),
-                                    __builtin_fmaf(mk, psq[cb].z, pcq[cb].z), __builtin_fmaf(mk, psq[cb].w, pcq[cb].w)};
-        } else {
-            auto quad = [&](const Item &v, bool keep) {
-                const uint4 z{0u, 0u, 0u, 0u};
-                if constexpr (F16) return keep ? quad_of_halves(v) : z;
-                else return keep ? pack_quad<MODE>(v, bad) : z;
-            };
-            // CV_0's k-blocks in order: feat1 blocks 0..FP-1, feat2 blocks 0..FP-1, geometry; block b sits in pair b / 2, half b % 2
+        for (int j = 0; j < FP; ++j) put_quad(in0[j / 2], j % 2, quad(f1[j], used));
 #pragma unroll
-            for (int j = 0; j < FP; ++j) put_quad(in0[j / 2], j % 2, quad(f1[j], used));
-#pragma unroll
-            for (int j = 0; j < FP; ++j) put_quad(in0[(FP + j) / 2], (FP + j) % 2, quad(f2[j], keep2));
-        }
+        for (int j = 0; j < FP; ++j) put_quad(in0[(FP + j) / 2], (FP + j) % 2, quad(f2[j], keep2));
         const float g0 = pg0 * mk, g1 = pg1 * mk, g2 = pg2 * mk;
         const float d0 = g0 - pc0, d1 = g1 - pc1, d2 = g2 - pc2;
         const float e = sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + 1e-20f);
@@ -2238,12 +1995,7 @@ __device__ __forceinline__ void cv1_rr_body(const elo_cv1_args &a, const unsigne
     const uint4 none{0u, 0u, 0u, 0u};
     ActPair h128[4];                                 // CV_0's output (128 channels = 4 pairs)
     auto emit0 = [&](int pass, int t, const f32x4 acc) { put_quad(h128[pass], t, pack_quad<MODE>(relu4(acc, a.cv0.relu), bad)); };
-    if constexpr (PRE) {
-        ActPair unused[1];
-        rr_layer<0, true, 8, 0, MODE>(unused, geo, bt, bt + B1, bias, fetch, advance, emit0,
-                                      [&](int cb, const float4) { const float4 v = start0[cb]; return f32x4{v.x, v.y, v.z, v.w}; });
-    } else
-        rr_layer<FP, true, 8, 0, MODE, (F16 ? ~0u : 0u)>(in0, geo, bt, bt + B1, bias, fetch, advance, emit0);
+    rr_layer<FP, true, 8, 0, MODE, (F16 ? ~0u : 0u)>(in0, geo, bt, bt + B1, bias, fetch, advance, emit0);
     RR_LAYER_STAMP(3);
     ActPair h64[2];
     rr_layer<4, false, 4, E0, MODE>(h128, none, bt + B1, bt + B2, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
@@ -2276,23 +2028,20 @@ __device__ __forceinline__ void cv1_rr_body(const elo_cv1_args &a, const unsigne
     report_violations<MODE>(bad);
 }
 
-template <int C, bool F16, int MODE = MODE_SPLIT, bool PRE = false>
+template <int C, bool F16, int MODE = MODE_SPLIT>
 __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_rr_kernel(const elo_cv1_args a)
 {
-    cv1_rr_body<C, F16, MODE, PRE>(a, blockIdx.x, gridDim.x);
+    cv1_rr_body<C, F16, MODE>(a, blockIdx.x, gridDim.x);
 }
 // ---- cost volume, stage 2, register-resident (see cv1_rr_kernel): xyz-encoding (geometry tail -> 64), sum_cost_volume_0
 // ([grouped cost (64) | encoding (64) | feat1 (C)] -> 128), sum_cost_volume_1 (-> 64 logits), masked softmax over the K
 // rows of a point weighting the grouped cost (utils/pointnet_util.py:110-146).  Neighbours from a.idx / a.mask.
-template <int C, bool PRE = false> struct Cv2Plan {    // PRE: sum_cost_volume_0 runs on the xyz encoding only (2 pairs), see cv1_rr_kernel
+template <int C> struct Cv2Plan {
     static constexpr int NL = 3;
-    static constexpr int KP[3] = {0, PRE ? 2 : 4 + C / 32, 4}, TL[3] = {1, (!PRE && C == 16) ? 1 : 0, 0}, NCB[3] = {4, 8, 4};
+    static constexpr int KP[3] = {0, 4 + C / 32, 4}, TL[3] = {1, C == 16 ? 1 : 0, 0}, NCB[3] = {4, 8, 4};
 };
 
-// PRE: sum_cost_volume_0 = W_enc . encoding + (b + W_f . feat1[centre]) + mask * (W_c . cost[neighbour]): a.pre_c / a.pre_s hold the
-// bracketed terms per point, a.sum_cost0 is the encoding-only layer (K = 64).  The grouped cost is still gathered: it is the
-// value the softmax weights.
-template <int C, bool F16, int MODE = MODE_SPLIT, bool PRE = false>
+template <int C, bool F16, int MODE = MODE_SPLIT>
 __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_args a)
 {
     extern __shared__ __align__(16) float lds[];
@@ -2303,7 +2052,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
     const long total_points = (long)a.batch * a.npoints;
     const long first_point = (long)xcd_tile(blockIdx.x, gridDim.x) * P;
     unsigned bad = 0;
-    typedef RrStream<Cv2Plan<C, PRE>, MODE> Stream;
+    typedef RrStream<Cv2Plan<C>, MODE> Stream;
     Stream ws{{a.xyz_enc.w_packed, a.sum_cost0.w_packed, a.sum_cost1.w_packed}, reinterpret_cast<uint4 *>(lds), wave, lane, {}};
     constexpr int E0 = Stream::first(1), E1 = Stream::first(2);
     auto fetch = [&](int g, RrW &dst) { ws.fetch(g, dst); };
@@ -2327,11 +2076,10 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
     const int cell = (id0 * a.H + id1) * a.W + id2;
     if (!used) mk = 0.0f;
     const bool keep2 = used && mk != 0.0f;
-    ActPair in1[KP1];                                // sum_cost_volume_0's pairs: [grouped cost | encoding | feat1]  (PRE: only the first four are used)
+    ActPair in1[KP1];                                // sum_cost_volume_0's pairs: [grouped cost | encoding | feat1]
     uint4 geo, ftail = uint4{0u, 0u, 0u, 0u};        // the geometry quad (xyz-encoding's input); feat1's quad when C == 16 (a tail block)
-    float4 start1[PRE ? 8 : 1];                      // PRE: sum_cost_volume_0's accumulators start at b + W_f feat1[pt] + mk * W_c cost[cell]
     typedef typename std::conditional<F16, uint2, float4>::type Item;         // 4 channels
-    Item fc[4];                                      // the grouped cost rows (PRE: requested late, they are the pooling's values only)
+    Item fc[4];                                      // the grouped cost rows
     const Item *rc = reinterpret_cast<const Item *>(a.cost) + ((long)cell * 64 >> 2) + kq;
     auto quad = [&](const Item &v, bool keep) {
         const uint4 z{0u, 0u, 0u, 0u};
@@ -2340,35 +2088,20 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
     };
     {
         Item f1[FP];
-        float4 pcq[PRE ? 8 : 1], psq[PRE ? 8 : 1];
         const Item *r1 = reinterpret_cast<const Item *>(a.feat1) + (pt * C >> 2) + kq;
-        if constexpr (PRE) {
-            const float4 *qc = reinterpret_cast<const float4 *>(a.pre_c) + pt * 32 + kq;
-            const float4 *qs = reinterpret_cast<const float4 *>(a.pre_s) + (long)cell * 32 + kq;
 #pragma unroll
-            for (int cb = 0; cb < 8; ++cb) { pcq[cb] = qc[cb * 4]; psq[cb] = qs[cb * 4]; }
-        } else {
+        for (int j = 0; j < 4; ++j) fc[j] = rc[j * 4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fc[j] = rc[j * 4];
-#pragma unroll
-            for (int j = 0; j < FP; ++j) f1[j] = r1[j * 4];
-        }
+        for (int j = 0; j < FP; ++j) f1[j] = r1[j * 4];
         const float *c = a.xyz1 + pt * 3, *g = a.xyz1 + (long)cell * 3;
         const float pc0 = c[0], pc1 = c[1], pc2 = c[2], pg0 = g[0], pg1 = g[1], pg2 = g[2];
         ws.prime();
-        if constexpr (PRE) {
 #pragma unroll
-            for (int cb = 0; cb < 8; ++cb)           // (mk is exactly 0 or 1: the product is exact, the sum rounds once)
-                start1[cb] = float4{__builtin_fmaf(mk, psq[cb].x, pcq[cb].x), __builtin_fmaf(mk, psq[cb].y, pcq[cb].y),
-                                    __builtin_fmaf(mk, psq[cb].z, pcq[cb].z), __builtin_fmaf(mk, psq[cb].w, pcq[cb].w)};
-        } else {
+        for (int j = 0; j < 4; ++j) put_quad(in1[j / 2], j % 2, quad(fc[j], keep2));       // cost[idx] * mask   :110
+        if constexpr (C == 16) ftail = quad(f1[0], used);
+        else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) put_quad(in1[j / 2], j % 2, quad(fc[j], keep2));       // cost[idx] * mask   :110
-            if constexpr (C == 16) ftail = quad(f1[0], used);
-            else {
-#pragma unroll
-                for (int j = 0; j < FP; ++j) put_quad(in1[4 + j / 2], j % 2, quad(f1[j], used));   // centre features    :115
-            }
+            for (int j = 0; j < FP; ++j) put_quad(in1[4 + j / 2], j % 2, quad(f1[j], used));   // centre features    :115
         }
         const float g0 = pg0 * mk, g1 = pg1 * mk, g2 = pg2 * mk;
         const float d0 = g0 - pc0, d1 = g1 - pc1, d2 = g2 - pc2;
@@ -2388,22 +2121,11 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
     }
     ActPair h128[4];
     auto emit1 = [&](int pass, int t, const f32x4 acc) { put_quad(h128[pass], t, pack_quad<MODE>(relu4(acc, a.sum_cost0.relu), bad)); };
-    if constexpr (PRE) {
-        const ActPair enc[2] = {in1[2], in1[3]};
-        rr_layer<2, false, 8, E0, MODE>(enc, none, bt + B1, bt + B2, bias, fetch, advance, emit1,
-                                        [&](int cb, const float4) { const float4 v = start1[cb]; return f32x4{v.x, v.y, v.z, v.w}; });
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fc[j] = rc[j * 4];            // requested here, used after the last layer (8 k-steps later)
-    } else
-        rr_layer<KP1, C == 16, 8, E0, MODE, (F16 ? ~0xcu : 0u), F16>(in1, ftail, bt + B1, bt + B2, bias, fetch, advance, emit1);
+    rr_layer<KP1, C == 16, 8, E0, MODE, (F16 ? ~0xcu : 0u), F16>(in1, ftail, bt + B1, bt + B2, bias, fetch, advance, emit1);
     float4 logit[4];
     rr_layer<4, false, 4, E1, MODE>(h128, none, bt + B2, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         logit[2 * pass + t] = relu4(acc, a.sum_cost1.relu);
     });
-    if constexpr (PRE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) put_quad(in1[j / 2], j % 2, quad(fc[j], keep2));           // cost[idx] * mask   :110
-    }
     if (K == 4 && a.sum_cost1.relu) rr_pool_softmax4_inwave<F16>(logit, in1[0], in1[1], mk, r, lane, first_point, total_points, a.out);
     else rr_pool<F16>(lds, logit, in1[0], in1[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
     report_violations<MODE>(bad);
@@ -2525,87 +2247,14 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void mlp2_rr_kernel(const JobPair
     });
     report_violations<MODE>(bad);
 }
-// ---- "layer 0 through the gather" (round 5): the per-POINT part of a grouped operator's first layer.  That layer is linear
-// and its batch norm is folded, so  W . [geometry | feat[centre] | feat[neighbour]] = W_g . geometry + W_c . feat[centre] +
-// W_s . feat[neighbour]:  the last two terms do not depend on the (centre, neighbour) ROW but on one point each -- K rows of a
-// centre share the second, every row that gathers a source shares the third (904 sources feed 28 800 rows in the l0
-// set-upconv).  This kernel computes out[row] = bias + W . src[row] (128 fp32 columns, no activation) for a point list, as a
-// one-layer chain (rr_layer: the same pair / tail steps on the same products as the consumers' layer 0 -- for set-conv,
-// whose kernel order is [features | xyz], the consumer CONTINUES these accumulators and gets the same bits as before).
-// blockIdx.y selects one of two jobs, which may differ in rows and in input width (C0 / C1).
-template <int C> struct RowLinPlan {
-    static constexpr int NL = 1;
-    static constexpr int KP[1] = {C / 32}, TL[1] = {C % 32 ? 1 : 0}, NCB[1] = {8};
-};
-
-template <int C, bool F16, int MODE>
-__device__ __forceinline__ void rowlinear_body(const elo_rowlinear_args &a, float *lds)
-{
-    constexpr int FP = C / 16, KP1 = C / 32;
-    constexpr bool T1 = C % 32 != 0;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i16 = lane & 15, kq = lane >> 4;
-    const long first = (long)blockIdx.x * RR_ROWS;
-    if (first >= a.rows) return;                         // (uniform: the other job of the launch is longer)
-    unsigned bad = 0;
-    typedef RrStream<RowLinPlan<C>, MODE> Stream;
-    Stream ws{{a.layer.w_packed}, reinterpret_cast<uint4 *>(lds), wave, lane, {}};
-    auto fetch = [&](int g, RrW &dst) { ws.fetch(g, dst); };
-    auto advance = [&](int S) { ws.advance(S); };
-    ws.start();
-    float4 bias[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const float4 *>(a.layer.bias + t * 16 + 4 * kq);
-    const float *const bsrc[1] = {a.layer.bias};
-    constexpr int BN[1] = {128};
-    const float bias_word = rr_bias_request(bsrc, BN, (int)threadIdx.x);
-    const float *bt = lds + RR_BIAS_OFF;
-    const int r = wave * 16 + i16;
-    const bool used = first + r < a.rows;
-    const long gr = used ? first + r : a.rows - 1;
-    typedef typename std::conditional<F16, uint2, float4>::type Item;         // 4 channels
-    ActPair in1[KP1 > 0 ? KP1 : 1];
-    uint4 tail1{0u, 0u, 0u, 0u};
-    {
-        Item s0[FP];
-        const Item *p0 = reinterpret_cast<const Item *>(a.src) + (gr * C >> 2) + kq;
-#pragma unroll
-        for (int j = 0; j < FP; ++j) s0[j] = p0[j * 4];
-        ws.prime();
-        auto quad = [&](const Item &v) {
-            const uint4 z{0u, 0u, 0u, 0u};
-            if constexpr (F16) return used ? quad_of_halves(v) : z;
-            else return used ? pack_quad<MODE>(v, bad) : z;
-        };
-#pragma unroll
-        for (int j = 0; j < FP; ++j) {
-            if (T1 && j == FP - 1) tail1 = quad(s0[j]);
-            else put_quad(in1[j / 2], j % 2, quad(s0[j]));
-        }
-    }
-    rr_bias_store(lds, (int)threadIdx.x, 128, bias_word);
-    rr_barrier();
-    rr_layer<KP1, T1, 8, 0, MODE, (F16 ? ~0u : 0u), F16>(in1, tail1, bt, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
-        if (used) *reinterpret_cast<float4 *>(a.out + (first + r) * 128 + (2 * pass + t) * 16 + 4 * kq) = float4{acc[0], acc[1], acc[2], acc[3]};
-    });
-    report_violations<MODE>(bad);
-}
-
-template <int C0, int C1, bool F16, int MODE = MODE_SPLIT>
-__global__ __launch_bounds__(RR_WAVES * 64, 4) void rowlinear_rr_kernel(const JobPair<elo_rowlinear_args> jobs)
-{
-    extern __shared__ __align__(16) float lds[];
-    if (blockIdx.y == 0) rowlinear_body<C0, F16, MODE>(jobs.job[0], lds);
-    else rowlinear_body<C1, F16, MODE>(jobs.job[1], lds);
-}
 // ---- set-conv / set-upconv stage 1, register-resident (see cv1_rr_kernel): in-kernel random-k grouping (a wave groups
 // the points its 16 rows belong to), gather [features (16 FPB) | xyz difference], two or three layers of compile-time
 // widths, masked max over the K rows of a point (utils/pointnet_util.py:197-230, :272-298).  Instantiated for the
 // model's shapes whose layers all have an even number of k-steps: the set-upconvs (64 + 3 -> 128 -> 64), sa1/layer3
 // (64 + 3 -> 64 -> 64 -> 128) and new_layer3 (64 + 3 -> 128 -> 64 -> 64); blockIdx.y selects one of two jobs.
-template <int FPB, int N1, int N2, int N3, bool PRE = false> struct ScPlan {     // PRE: layer 0 runs on the xyz difference only (a.pre: see below)
+template <int FPB, int N1, int N2, int N3> struct ScPlan {
     static constexpr int NL = N3 ? 3 : 2;
-    static constexpr int KP[3] = {PRE ? 0 : FPB / 2, N1 / 32, N2 / 32}, TL[3] = {1, 0, 0}, NCB[3] = {N1 / 16, N2 / 16, (N3 ? N3 : 32) / 16};
+    static constexpr int KP[3] = {FPB / 2, N1 / 32, N2 / 32}, TL[3] = {1, 0, 0}, NCB[3] = {N1 / 16, N2 / 16, (N3 ? N3 : 32) / 16};
 };
 
 // masked max over the K rows of a point of the NOUT channels the lane quads hold (`last[cb]`: channels cb*16 + 4kq ..),
@@ -2645,11 +2294,7 @@ __device__ __forceinline__ void rr_pool_max(float *lds, const float4 (&last)[NOU
     }
 }
 
-// PRE ("layer 0 through the gather"): a.pre[cell] = b + W_feat . src_feat[cell] for every SOURCE cell (rowlinear_rr_kernel: the
-// layer's feature pairs in the same order on the same products, the accumulator stored as fp32), a.layers[0] = the layer's xyz
-// rows only (K = 3).  A row starts at pre[its neighbour] (a masked row at b: its features are zero) and adds the geometry tail:
-// the SAME bits as the whole layer run per row -- 904 sources instead of 28 800 rows at the l0 set-upconv.
-template <int FPB, int N1, int N2, int N3, bool F16, int MODE = MODE_SPLIT, bool PRE = false>
+template <int FPB, int N1, int N2, int N3, bool F16, int MODE = MODE_SPLIT>
 __device__ __forceinline__ void setconv_rr_body(const elo_setconv_args &a, const unsigned block, const unsigned nblocks)
 {
     extern __shared__ __align__(16) float lds[];
@@ -2661,7 +2306,7 @@ __device__ __forceinline__ void setconv_rr_body(const elo_setconv_args &a, const
     const long first_point = (long)xcd_tile(block, nblocks) * P;
     unsigned bad = 0;
     RR_STAMP(0);
-    typedef RrStream<ScPlan<FPB, N1, N2, N3, PRE>, MODE> Stream;
+    typedef RrStream<ScPlan<FPB, N1, N2, N3>, MODE> Stream;
     Stream ws{};
     ws.w[0] = a.layers[0].w_packed; ws.w[1] = a.layers[1].w_packed;
     if constexpr (N3 != 0) ws.w[2] = a.layers[2].w_packed;
@@ -2755,33 +2400,24 @@ __device__ __forceinline__ void setconv_rr_body(const elo_setconv_args &a, const
     const float c0 = cxyz[(pi < P ? pi : 0) * 3 + 0], c1 = cxyz[(pi < P ? pi : 0) * 3 + 1], c2 = cxyz[(pi < P ? pi : 0) * 3 + 2];
     ActPair in0[FPB / 2];
     uint4 dxyz;
-    float4 start0[PRE ? N1 / 16 : 1];                // PRE: layer 0's accumulators after the feature pairs, from the source's row of a.pre
     const bool keep = used && mk != 0.0f;
     {
         typedef typename std::conditional<F16, uint2, float4>::type Item;
         Item f[FPB];
         const long cc = used ? cell : 0;
-        if constexpr (PRE) {
-            const float4 *rp = reinterpret_cast<const float4 *>(a.pre) + cc * (N1 / 4) + kq;
+        const Item *rf = reinterpret_cast<const Item *>(a.src_feat) + (cc * C >> 2) + kq;
 #pragma unroll
-            for (int cb = 0; cb < N1 / 16; ++cb) start0[cb] = rp[cb * 4];
-        } else {
-            const Item *rf = reinterpret_cast<const Item *>(a.src_feat) + (cc * C >> 2) + kq;
-#pragma unroll
-            for (int j = 0; j < FPB; ++j) f[j] = rf[j * 4];
-        }
+        for (int j = 0; j < FPB; ++j) f[j] = rf[j * 4];
         const float *g = a.src_xyz + cc * 3;
         const float x = g[0], y = g[1], z = g[2];
         ws.prime();
-        if constexpr (!PRE) {
-            auto quad = [&](const Item &v) {
-                const uint4 zq{0u, 0u, 0u, 0u};
-                if constexpr (F16) return keep ? quad_of_halves(v) : zq;
-                else return keep ? pack_quad<MODE>(v, bad) : zq;
-            };
+        auto quad = [&](const Item &v) {
+            const uint4 zq{0u, 0u, 0u, 0u};
+            if constexpr (F16) return keep ? quad_of_halves(v) : zq;
+            else return keep ? pack_quad<MODE>(v, bad) : zq;
+        };
 #pragma unroll
-            for (int j = 0; j < FPB; ++j) put_quad(in0[j / 2], j % 2, quad(f[j]));
-        }
+        for (int j = 0; j < FPB; ++j) put_quad(in0[j / 2], j % 2, quad(f[j]));
         const float4 d = kq == 0 ? float4{x * mk - c0, y * mk - c1, z * mk - c2, 0.0f} : float4{0.0f, 0.0f, 0.0f, 0.0f};
         dxyz = used ? pack_quad<MODE>(d, bad) : uint4{0u, 0u, 0u, 0u};
     }
@@ -2792,14 +2428,7 @@ __device__ __forceinline__ void setconv_rr_body(const elo_setconv_args &a, const
     const uint4 none{0u, 0u, 0u, 0u};
     ActPair h1[N1 / 32];
     auto emit0 = [&](int pass, int t, const f32x4 acc) { put_quad(h1[pass], t, pack_quad<MODE>(relu4(acc, a.layers[0].relu), bad)); };
-    if constexpr (PRE) {
-        ActPair unused[1];
-        rr_layer<0, true, N1 / 16, 0, MODE>(unused, dxyz, bt, bt + B1, bias, fetch, advance, emit0, [&](int cb, const float4 b) {
-            const float4 v = keep ? start0[cb] : b;                      // a masked row gathered zeros: it starts at the bias
-            return f32x4{v.x, v.y, v.z, v.w};
-        });
-    } else
-        rr_layer<FPB / 2, true, N1 / 16, 0, MODE, (F16 ? ~0u : 0u)>(in0, dxyz, bt, bt + B1, bias, fetch, advance, emit0);
+    rr_layer<FPB / 2, true, N1 / 16, 0, MODE, (F16 ? ~0u : 0u)>(in0, dxyz, bt, bt + B1, bias, fetch, advance, emit0);
     RR_STAMP(6);
     float4 last[NOUT / 16];
     if constexpr (N3 == 0) {
@@ -2822,10 +2451,10 @@ __device__ __forceinline__ void setconv_rr_body(const elo_setconv_args &a, const
     report_violations<MODE>(bad);
 }
 
-template <int FPB, int N1, int N2, int N3, bool F16, int MODE = MODE_SPLIT, bool PRE = false>
+template <int FPB, int N1, int N2, int N3, bool F16, int MODE = MODE_SPLIT>
 __global__ __launch_bounds__(RR_WAVES * 64, 4) void setconv_rr_kernel(const JobPair<elo_setconv_args> jobs)
 {
-    setconv_rr_body<FPB, N1, N2, N3, F16, MODE, PRE>(jobs.job[blockIdx.y], blockIdx.x, gridDim.x);
+    setconv_rr_body<FPB, N1, N2, N3, F16, MODE>(jobs.job[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 // Cost-volume stage 1 (from the select-k pre-pass's idx / mask) and stage 1 of the level's two set-upconvs (128 -> 64, in-kernel
@@ -2837,10 +2466,10 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv1_setconv_rr_kernel(const 
                                                                          const unsigned n_cv, const unsigned n_sc)
 {
     if (blockIdx.x < n_cv) {
-        cv1_rr_body<C, F16, MODE, false>(a, blockIdx.x, n_cv);
+        cv1_rr_body<C, F16, MODE>(a, blockIdx.x, n_cv);
     } else {
         const unsigned r = blockIdx.x - n_cv, j = r >= n_sc ? 1u : 0u;
-        setconv_rr_body<4, 128, 64, 0, F16, MODE, false>(jobs.job[j], j ? r - n_sc : r, n_sc);
+        setconv_rr_body<4, 128, 64, 0, F16, MODE>(jobs.job[j], j ? r - n_sc : r, n_sc);
     }
 }
 // ================================================================ the same narrow set-conv, MLP on the matrix cores (round 4)
@@ -3233,16 +2862,8 @@ static int check_setconv(const elo_setconv_args *a, const char *who)
         ((a->H - 1) / a->group.stride_h >= a->H2 || (a->W - 1) / a->group.stride_w >= a->W2))
         return fail(ELO_ERR_ARG, "%s: the queried grid %dx%d is smaller than the centres' grid %dx%d over the strides %dx%d", who, a->H2, a->W2,
                     a->H, a->W, a->group.stride_h, a->group.stride_w);
-    if (a->centre_cols != 0) {                               // structured centres: the strided pixels of xyz1_grid, row-major
-        ELO_REQUIRE(a->centre_cols > 0 && a->centre_rows > 0 && a->centre_stride_h > 0 && a->centre_stride_w > 0 && a->xyz1_grid, who,
-                    "structured centres need centre_rows / centre_cols / centre_stride_* > 0 and xyz1_grid");
-        ELO_REQUIRE((long)a->centre_rows * a->centre_cols == a->npoints, who, "centre_rows * centre_cols must equal npoints");
-        ELO_REQUIRE((long)(a->centre_rows - 1) * a->centre_stride_h < a->H && (long)(a->centre_cols - 1) * a->centre_stride_w < a->W, who,
-                    "the strided centres leave the centres' grid");
-    }
     if (int rc = check_dtype(a->feat_dtype, who)) return rc;
-    if (a->pre && ((uintptr_t)a->pre & 15)) return fail(ELO_ERR_ARG, "%s: pre must be 16-byte aligned", who);
-    int width = a->pre ? 3 : 3 + a->C;                    // pre: the feature rows of layers[0] were applied per source cell
+    int width = 3 + a->C;
     for (int l = 0; l < a->n_layers; ++l) {
         if (int rc = check_dense(a->layers[l], width, 0, who, "mlp")) return rc;
         width = a->layers[l].N;
@@ -3257,8 +2878,7 @@ static bool same_shape(const elo_setconv_args *a, const elo_setconv_args *b)
 {
     if (a->batch != b->batch || a->npoints != b->npoints || a->K != b->K || a->C != b->C || a->n_layers != b->n_layers ||
         a->H2 != b->H2 || a->W2 != b->W2 || a->group.kernel_h != b->group.kernel_h || a->group.kernel_w != b->group.kernel_w ||
-        (a->group.random_hw == nullptr) != (b->group.random_hw == nullptr) || a->feat_dtype != b->feat_dtype ||
-        (a->pre == nullptr) != (b->pre == nullptr))
+        (a->group.random_hw == nullptr) != (b->group.random_hw == nullptr) || a->feat_dtype != b->feat_dtype)
         return false;
     for (int l = 0; l < a->n_layers; ++l)
         if (a->layers[l].K != b->layers[l].K || a->layers[l].N != b->layers[l].N) return false;
@@ -3350,14 +2970,13 @@ static long mlp_rr_rows(int batch_hint)
 extern "C" int elo_debug_narrow_mfma(int on)
 {
     const int prev = tuning().narrow_mfma;
-    tuning().narrow_mfma = on >= 0 ? (on > 2 ? 2 : on) : tuning_base().narrow_mfma;
+    tuning().narrow_mfma = on >= 0 ? (on ? 1 : 0) : tuning_base().narrow_mfma;
     return prev;
 }
-static int narrow_mfma_level() { return tuning().narrow_mfma; }
-static bool narrow_mfma_on() { return narrow_mfma_level() != 0; }
+static bool narrow_mfma_on() { return tuning().narrow_mfma != 0; }
 // launches of the register-resident kernels since the last reset: [cv1_rr, cv2_rr, setconv_rr, mlp2_rr].  The parity tests
 // of the chain regime assert through it that the kernel under test is the one that ran.
-static std::atomic<unsigned long long> g_rr_launches[5];      // [4]: rowlinear_rr_kernel (elo_debug_rowlinear_launches)
+static std::atomic<unsigned long long> g_rr_launches[4];
 extern "C" int elo_debug_rr_launches(unsigned long long *counts4, int reset)
 {
     for (int i = 0; i < 4; ++i) {
@@ -3380,20 +2999,12 @@ extern "C" int elo_debug_sv_ride_launches(unsigned long long *count, int reset)
     if (reset) g_sv_ride_launches.store(0);
     return ELO_OK;
 }
-extern "C" int elo_debug_rowlinear_launches(unsigned long long *count, int reset)
+// launches of the narrow set-conv forms since the last reset: [setconv_narrow_kernel (matrix cores), setconv_small_kernel (VALU)]
+static std::atomic<unsigned long long> g_narrow_launches[2];
+extern "C" int elo_debug_narrow_launches(unsigned long long *counts2, int reset)
 {
-    if (count) *count = g_rr_launches[4].load();
-    if (reset) g_rr_launches[4].store(0);
-    return ELO_OK;
-}
-
-// launches of the narrow set-conv forms since the last reset: [setconv_narrow_kernel (matrix cores), setconv_small_kernel (VALU),
-// setconv_tiled_kernel (LDS-staged windows)]
-static std::atomic<unsigned long long> g_narrow_launches[3];
-extern "C" int elo_debug_narrow_launches(unsigned long long *counts3, int reset)
-{
-    for (int i = 0; i < 3; ++i) {
-        if (counts3) counts3[i] = g_narrow_launches[i].load();
+    for (int i = 0; i < 2; ++i) {
+        if (counts2) counts2[i] = g_narrow_launches[i].load();
         if (reset) g_narrow_launches[i].store(0);
     }
     return ELO_OK;
@@ -3401,8 +3012,7 @@ extern "C" int elo_debug_narrow_launches(unsigned long long *counts3, int reset)
 
 // The register-resident form (setconv_rr_kernel) is taken for the model's wide shapes -- 64 feature channels, layers
 // 128 -> 64 (the set-upconvs: shape 1), 64 -> 64 -> 128 (2) or 128 -> 64 -> 64 (3) -- with in-kernel grouping, from
-// ELO_SETCONV_RR_ROWS rows per launch on (regimes: elo_mlp_fused2).  0 = the tile kernel.  One predicate for the launcher and
-// for elo_setconv_chain_form (the host asks before it splits layers[0] for the pre form).
+// ELO_SETCONV_RR_ROWS rows per launch on (regimes: elo_mlp_fused2).  0 = the tile kernel.  
 static int setconv_chain_shape(const elo_setconv_args *a, const elo_setconv_args *b, int mode)
 {
 #ifdef ELO_DENSE_F32
@@ -3422,20 +3032,6 @@ static int setconv_chain_shape(const elo_setconv_args *a, const elo_setconv_args
 #endif
 }
 
-extern "C" int elo_setconv_chain_form(const elo_setconv_args *a, const elo_setconv_args *b)
-{
-    const char *who = "elo_setconv_chain_form";
-    if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
-    if (a->n_layers < 1 || a->n_layers > ELO_MAX_CHAIN || (b && b->n_layers != a->n_layers)) return fail(ELO_ERR_ARG, "%s: 1..3 layers", who);
-    int mode = 0, mode_b = 0;
-    if (int rc = products_mode(who, &mode, a->layers, a->n_layers)) return rc;
-    if (b) {
-        if (int rc = products_mode(who, &mode_b, b->layers, b->n_layers)) return rc;
-        if (mode != mode_b || !same_shape(a, b)) return 0;
-    }
-    return setconv_chain_shape(a, b, mode) != 0 ? 1 : 0;
-}
-
 // the pre-grouped cost-volume calls take the chain kernels (cv1_rr_kernel / cv2_rr_kernel) in the plain products modes
 static bool cv_chain(int C, int mode)
 {
@@ -3443,65 +3039,6 @@ static bool cv_chain(int C, int mode)
     return false;
 #else
     return (mode == MODE_SPLIT || mode == MODE_HALF) && cv1_rr_on() && (C == 16 || C == 32 || C == 64);
-#endif
-}
-
-extern "C" int elo_cv_chain_form(int C, int products)
-{
-    if (products != ELO_PRODUCTS_SPLIT && products != ELO_PRODUCTS_HALF) return fail(ELO_ERR_ARG, "elo_cv_chain_form: bad products mode");
-    const int mode = products == ELO_PRODUCTS_HALF ? MODE_HALF : range_check_flag() ? MODE_CHECKED : MODE_SPLIT;
-    return cv_chain(C, mode) ? 1 : 0;
-}
-
-extern "C" int elo_rowlinear_fused2(const elo_rowlinear_args *a, const elo_rowlinear_args *b, elo_stream_t stream)
-{
-    const char *who = "elo_rowlinear_fused";
-#ifdef ELO_DENSE_F32
-    (void)a; (void)b; (void)stream;
-    return fail(ELO_ERR_LIMIT, "%s: the fp32-MFMA comparison build has no register-resident kernels", who);
-#else
-    ELO_REQUIRE(a, who, "null argument block");
-    int mode = 0;
-    for (const elo_rowlinear_args *j : {a, b}) {
-        if (!j) continue;
-        ELO_REQUIRE(j->rows >= 0 && j->src && j->out, who, "bad sizes / null tensor pointer");
-        if (j->C != 16 && j->C != 32 && j->C != 64) return fail(ELO_ERR_LIMIT, "%s: C = %d (16, 32 or 64)", who, j->C);
-        if (int rc = check_dtype(j->feat_dtype, who)) return rc;
-        if (int rc = check_dense(j->layer, j->C, 128, who, "layer")) return rc;
-        if (((uintptr_t)j->src | (uintptr_t)j->out) & 15) return fail(ELO_ERR_ARG, "%s: tensors must be 16-byte aligned", who);
-        int m = 0;
-        if (int rc = products_mode(who, &m, &j->layer, 1)) return rc;
-        if (j != a && m != mode) return fail(ELO_ERR_ARG, "%s: the two jobs of a paired launch must share one products mode", who);
-        mode = m;
-    }
-    if (b && b->feat_dtype != a->feat_dtype) return fail(ELO_ERR_ARG, "%s: the two jobs must share one feature storage type", who);
-    if (mode == MODE_CHECKED) mode = MODE_SPLIT;         // (the chain kernels have no checked instances: the consumers of `out` are not launched in that mode)
-    const long rows = b && b->rows > a->rows ? b->rows : a->rows;
-    if (rows == 0) return ELO_OK;
-    JobPair<elo_rowlinear_args> pair;
-    pair.job[0] = *a;
-    pair.job[1] = b ? *b : *a;
-    const dim3 grid((unsigned)((rows + RR_ROWS - 1) / RR_ROWS), b ? 2u : 1u);
-    const bool f16 = a->feat_dtype == ELO_F16;
-    hipStream_t s = (hipStream_t)stream;
-    const int c0 = a->C, c1 = b ? b->C : a->C;
-#define RL(C0_, C1_)                                                                                                                    \
-    do {                                                                                                                            \
-        if (f16 && mode == MODE_HALF) hipLaunchKernelGGL((rowlinear_rr_kernel<C0_, C1_, true, MODE_HALF>), grid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);   \
-        else if (f16) hipLaunchKernelGGL((rowlinear_rr_kernel<C0_, C1_, true, MODE_SPLIT>), grid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);             \
-        else if (mode == MODE_HALF) hipLaunchKernelGGL((rowlinear_rr_kernel<C0_, C1_, false, MODE_HALF>), grid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);    \
-        else hipLaunchKernelGGL((rowlinear_rr_kernel<C0_, C1_, false, MODE_SPLIT>), grid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);                     \
-    } while (0)
-    // (C0, C1): set-upconv / cost-volume stage 1 use one width for both jobs, stage 2 pairs feat1 (C) with the 64-channel cost
-    if (c0 == 16 && c1 == 16) RL(16, 16);
-    else if (c0 == 32 && c1 == 32) RL(32, 32);
-    else if (c0 == 64 && c1 == 64) RL(64, 64);
-    else if (c0 == 16 && c1 == 64) RL(16, 64);
-    else if (c0 == 32 && c1 == 64) RL(32, 64);
-    else return fail(ELO_ERR_LIMIT, "%s: job widths (%d, %d): equal, or (16 | 32, 64)", who, c0, c1);
-#undef RL
-    ++g_rr_launches[4];
-    return check_launch(who);
 #endif
 }
 
@@ -3522,37 +3059,11 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
         const int cin = 3 + a->C, n1 = a->layers[0].N, n2 = a->layers[1].N, n3 = a->layers[2].N;
         const unsigned grid = (unsigned)((points + 7) / 8);
         if (int rc = check_group(a->group, a->H2, a->W2, 0, who)) return rc;
-        if (a->centre_cols > 0 && tuning().tiled_setconv) {   // round 5: structured centres -> the window union of 32 centres staged in LDS
-            const int RW = tiled_region_cols(a->centre_stride_w, a->group.stride_w, a->group.kernel_w);
-            const int KT = a->group.kernel_h * a->group.kernel_w;
-            const int wend = cin * n1 + n1 + n1 * n2 + n2 + n2 * n3 + n3;
-            const size_t lds = sizeof(float) * ((size_t)4 * a->group.kernel_h * RW + ((KT + 3) & ~3) + TILED_TC * 32 + TILED_TC * 4 + wend);
-            const dim3 tgrid((unsigned)((a->centre_cols + TILED_TC - 1) / TILED_TC), (unsigned)a->centre_rows, (unsigned)a->batch);
-            if (lds <= 64 * 1024 && a->batch <= 65535 && a->centre_rows <= 65535) {
-                if (cin == 6 && n1 == 8 && n2 == 8 && n3 == 16) {
-                    hipLaunchKernelGGL((setconv_tiled_kernel<6, 8, 8, 16>), tgrid, dim3(ELO_BLOCK), lds, s, *a, RW);
-                    ++g_narrow_launches[2];
-                    return check_launch(who);
-                }
-                if (cin == 19 && n1 == 16 && n2 == 16 && n3 == 32 && tuning().tiled_setconv >= 2) {
-                    hipLaunchKernelGGL((setconv_tiled_kernel<19, 16, 16, 32>), tgrid, dim3(ELO_BLOCK), lds, s, *a, RW);
-                    ++g_narrow_launches[2];
-                    return check_launch(who);
-                }
-            }
-        }
 #ifndef ELO_DENSE_F32
         if (narrow_mfma_on()) {                              // round 4: the same kernel with its MLP on the matrix cores
             const bool checked = range_check_flag();
-            // (6 -> 8 -> 8 -> 16, the layer on the 64x1800 input: measured SLOWER on the matrix cores -- 64 us against 36.5 us at
-            // batch 8: its MLP is 240 FMAs per row, the kernel is the latency chain of its grouping times its occupancy, and the
-            // MFMA form's 88 registers cost three of the eight waves per SIMD.  ELO_SETCONV_NARROW_MFMA=2 forces it, for the test.)
-            if (cin == 6 && n1 == 8 && n2 == 8 && n3 == 16 && narrow_mfma_level() >= 2) {
-                if (checked) hipLaunchKernelGGL((setconv_narrow_kernel<6, 8, 8, 16, MODE_CHECKED>), dim3(grid), dim3(ELO_BLOCK), 0, s, *a);
-                else hipLaunchKernelGGL((setconv_narrow_kernel<6, 8, 8, 16, MODE_SPLIT>), dim3(grid), dim3(ELO_BLOCK), 0, s, *a);
-                ++g_narrow_launches[0];
-                return check_launch(who);
-            }
+            // (the 6 -> 8 -> 8 -> 16 layer stays on the VALU kernel: on the matrix cores it measured 64 us against 36.5 us at batch 8 --
+            //  240 FMAs per row, the kernel is the latency chain of its grouping times its occupancy: profiles/r04_ab_narrow.txt)
             if (cin == 19 && n1 == 16 && n2 == 16 && n3 == 32) {
                 if (checked) hipLaunchKernelGGL((setconv_narrow_kernel<19, 16, 16, 32, MODE_CHECKED>), dim3(grid), dim3(ELO_BLOCK), 0, s, *a);
                 else hipLaunchKernelGGL((setconv_narrow_kernel<19, 16, 16, 32, MODE_SPLIT>), dim3(grid), dim3(ELO_BLOCK), 0, s, *a);
@@ -3582,24 +3093,21 @@ extern "C" int elo_setconv_fused2(const elo_setconv_args *a, const elo_setconv_a
         const int P = RR_ROWS / a->K;
         const dim3 rgrid((unsigned)((points + P - 1) / P), b ? 2u : 1u);
         const bool f16 = a->feat_dtype == ELO_F16;
-        if (a->pre && shape != 1) return fail(ELO_ERR_ARG, "%s: pre is taken by the 128 -> 64 chain form only (ask elo_setconv_chain_form)", who);
-#define RRS(N1_, N2_, N3_, PRE_)                                                                                                        \
+#define RRS(N1_, N2_, N3_)                                                                                                              \
         do {                                                                                                                        \
-            if (f16 && plan.mode == MODE_HALF) hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, true, MODE_HALF, PRE_>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);  \
-            else if (f16) hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, true, MODE_SPLIT, PRE_>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);  \
-            else if (plan.mode == MODE_HALF) hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, false, MODE_HALF, PRE_>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);     \
-            else hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, false, MODE_SPLIT, PRE_>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);     \
+            if (f16 && plan.mode == MODE_HALF) hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, true, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);  \
+            else if (f16) hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, true, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);  \
+            else if (plan.mode == MODE_HALF) hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, false, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);     \
+            else hipLaunchKernelGGL((setconv_rr_kernel<4, N1_, N2_, N3_, false, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, pair);     \
         } while (0)
-        if (shape == 1 && a->pre) RRS(128, 64, 0, true);
-        else if (shape == 1) RRS(128, 64, 0, false);
-        else if (shape == 2) RRS(64, 64, 128, false);
-        else RRS(128, 64, 64, false);
+        if (shape == 1) RRS(128, 64, 0);
+        else if (shape == 2) RRS(64, 64, 128);
+        else RRS(128, 64, 64);
 #undef RRS
         ++g_rr_launches[2];
         return check_launch(who);
     }
 #endif
-    if (a->pre) return fail(ELO_ERR_ARG, "%s: pre is taken by the chain form only (ask elo_setconv_chain_form before splitting layers[0])", who);
     const dim3 grid((unsigned)plan.units, b ? 2u : 1u);
     const size_t lds = plan.lds;
     const int S = plan.S;
@@ -3821,9 +3329,7 @@ static int plan_cv1(const elo_cv1_args *a, TilePlan *p, const char *who)
     ELO_REQUIRE(!a->group.random_hw || a->npoints == a->H2 * a->W2, who, "in-kernel grouping needs npoints == H2*W2");
     if (int rc = check_dtype(a->feat_dtype, who)) return rc;
     if (int rc = check_cv_features(who, a->C, a->feat_dtype == ELO_F16, {a->feat1, a->feat2})) return rc;
-    ELO_REQUIRE((a->pre_c == nullptr) == (a->pre_s == nullptr), who, "pre_c and pre_s come together");
-    if (a->pre_c && (((uintptr_t)a->pre_c | (uintptr_t)a->pre_s) & 15)) return fail(ELO_ERR_ARG, "%s: pre_c / pre_s must be 16-byte aligned", who);
-    const int CT = a->pre_c ? 10 : 10 + 2 * a->C;         // pre: CV_0's feature rows were applied per point
+    const int CT = 10 + 2 * a->C;
     if (int rc = check_dense(a->cv0, CT, 128, who, "CV_0")) return rc;
     if (int rc = check_dense(a->cv1, 128, 64, who, "CV_1")) return rc;
     if (int rc = check_dense(a->cv2, 64, 64, who, "CV_2")) return rc;
@@ -3860,23 +3366,21 @@ extern "C" int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream)
         hipStream_t s = (hipStream_t)stream;
         const bool f16 = a->feat_dtype == ELO_F16;
         static_assert(RR_LDS_BYTES <= 64 * 1024, "dynamic LDS within the default limit");
-#define RR(CC, PRE_)                                                                                                \
+#define RR(CC)                                                                                                      \
         do {                                                                                                        \
-            if (f16 && plan.mode == MODE_HALF) hipLaunchKernelGGL((cv1_rr_kernel<CC, true, MODE_HALF, PRE_>), grid, dim3(RR_WAVES * 64), lds, s, *a);          \
-            else if (f16) hipLaunchKernelGGL((cv1_rr_kernel<CC, true, MODE_SPLIT, PRE_>), grid, dim3(RR_WAVES * 64), lds, s, *a);          \
-            else if (plan.mode == MODE_HALF) hipLaunchKernelGGL((cv1_rr_kernel<CC, false, MODE_HALF, PRE_>), grid, dim3(RR_WAVES * 64), lds, s, *a);             \
-            else hipLaunchKernelGGL((cv1_rr_kernel<CC, false, MODE_SPLIT, PRE_>), grid, dim3(RR_WAVES * 64), lds, s, *a);             \
+            if (f16 && plan.mode == MODE_HALF) hipLaunchKernelGGL((cv1_rr_kernel<CC, true, MODE_HALF>), grid, dim3(RR_WAVES * 64), lds, s, *a);          \
+            else if (f16) hipLaunchKernelGGL((cv1_rr_kernel<CC, true, MODE_SPLIT>), grid, dim3(RR_WAVES * 64), lds, s, *a);          \
+            else if (plan.mode == MODE_HALF) hipLaunchKernelGGL((cv1_rr_kernel<CC, false, MODE_HALF>), grid, dim3(RR_WAVES * 64), lds, s, *a);             \
+            else hipLaunchKernelGGL((cv1_rr_kernel<CC, false, MODE_SPLIT>), grid, dim3(RR_WAVES * 64), lds, s, *a);             \
         } while (0)
-        if (a->pre_c) { if (a->C == 16) RR(16, true); else if (a->C == 32) RR(32, true); else RR(64, true); }
-        else if (a->C == 16) RR(16, false);
-        else if (a->C == 32) RR(32, false);
-        else RR(64, false);
+        if (a->C == 16) RR(16);
+        else if (a->C == 32) RR(32);
+        else RR(64);
 #undef RR
         ++g_rr_launches[0];
         return check_launch(who);
     }
 #endif
-    if (a->pre_c) return fail(ELO_ERR_ARG, "%s: pre_c / pre_s are taken by the chain form only (pre-grouped call, elo_cv_chain_form)", who);
     const dim3 grid((unsigned)plan.units);
     const size_t lds = plan.lds;
     const int S = plan.S;
@@ -3902,7 +3406,6 @@ extern "C" int elo_cv_stage1_setconv_fused(const elo_cv1_args *a, const elo_setc
     }
     if (int rc = plan_setconv(ja, jb, &ps, who)) return rc;
     if (ps.mode != pc.mode) return fail(ELO_ERR_ARG, "%s: the cost volume and the set-conv jobs must share one products mode", who);
-    if (a->pre_c || ja->pre || (jb && jb->pre)) return fail(ELO_ERR_ARG, "%s: the pre* fields are taken by the chain forms only", who);
     if ((long)a->batch * a->npoints == 0 || (long)ja->batch * ja->npoints == 0)
         return fail(ELO_ERR_ARG, "%s: empty batch (call the separate entry points)", who);
     SideJobs side;
@@ -3942,7 +3445,6 @@ static int chain_pair_form(const elo_cv1_args *a, const elo_setconv_args *ja, co
     if (products_mode(who, &mode, a->cv0, a->cv1, a->cv2, a->cv_xyz, a->sum_cv0, a->sum_cv1)) return 0;
     if (ja->n_layers != 2 || jb->n_layers != 2 || products_mode(who, &mode_sc, ja->layers, 2) || products_mode(who, &mode_sb, jb->layers, 2)) return 0;
     if (mode != mode_sc || mode != mode_sb || !same_shape(ja, jb) || ja->feat_dtype != a->feat_dtype) return 0;
-    if (a->pre_c || a->pre_s || ja->pre || jb->pre) return 0;
     if (!cv_chain(a->C, mode) || setconv_chain_shape(ja, jb, mode) != 1) return 0;
     if (a->K <= 0 || a->K > 32) return 0;
     *mode_out = mode;
@@ -4016,9 +3518,7 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
     if (int rc = check_dtype(a->feat_dtype, who)) return rc;
     if (int rc = check_cv_features(who, a->C, a->feat_dtype == ELO_F16, {a->feat1, a->cost})) return rc;
     if (int rc = check_dense(a->xyz_enc, 10, 64, who, "sum_xyz_encoding")) return rc;
-    ELO_REQUIRE((a->pre_c == nullptr) == (a->pre_s == nullptr), who, "pre_c and pre_s come together");
-    if (a->pre_c && (((uintptr_t)a->pre_c | (uintptr_t)a->pre_s) & 15)) return fail(ELO_ERR_ARG, "%s: pre_c / pre_s must be 16-byte aligned", who);
-    if (int rc = check_dense(a->sum_cost0, a->pre_c ? 64 : 128 + a->C, 128, who, "sum_cost_volume_0")) return rc;   // pre: the encoding rows only
+    if (int rc = check_dense(a->sum_cost0, 128 + a->C, 128, who, "sum_cost_volume_0")) return rc;
     if (int rc = check_dense(a->sum_cost1, 128, 64, who, "sum_cost_volume_1")) return rc;
     const long points = (long)a->batch * a->npoints;
     if (points >= 0x7fffffffL) return fail(ELO_ERR_LIMIT, "%s: batch * npoints beyond 2^31", who);
@@ -4038,23 +3538,21 @@ extern "C" int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream)
         const int P = RR_ROWS / a->K;                              // points per workgroup (128 rows)
         const dim3 rgrid((unsigned)((points + P - 1) / P));
         const bool f16 = a->feat_dtype == ELO_F16;
-#define RR(CC, PRE_)                                                                                                     \
+#define RR(CC)                                                                                                           \
         do {                                                                                                             \
-            if (f16 && mode == MODE_HALF) hipLaunchKernelGGL((cv2_rr_kernel<CC, true, MODE_HALF, PRE_>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);     \
-            else if (f16) hipLaunchKernelGGL((cv2_rr_kernel<CC, true, MODE_SPLIT, PRE_>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);     \
-            else if (mode == MODE_HALF) hipLaunchKernelGGL((cv2_rr_kernel<CC, false, MODE_HALF, PRE_>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);        \
-            else hipLaunchKernelGGL((cv2_rr_kernel<CC, false, MODE_SPLIT, PRE_>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);        \
+            if (f16 && mode == MODE_HALF) hipLaunchKernelGGL((cv2_rr_kernel<CC, true, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);     \
+            else if (f16) hipLaunchKernelGGL((cv2_rr_kernel<CC, true, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);     \
+            else if (mode == MODE_HALF) hipLaunchKernelGGL((cv2_rr_kernel<CC, false, MODE_HALF>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);        \
+            else hipLaunchKernelGGL((cv2_rr_kernel<CC, false, MODE_SPLIT>), rgrid, dim3(RR_WAVES * 64), RR_LDS_BYTES, s, *a);        \
         } while (0)
-        if (a->pre_c) { if (a->C == 16) RR(16, true); else if (a->C == 32) RR(32, true); else RR(64, true); }
-        else if (a->C == 16) RR(16, false);
-        else if (a->C == 32) RR(32, false);
-        else RR(64, false);
+        if (a->C == 16) RR(16);
+        else if (a->C == 32) RR(32);
+        else RR(64);
 #undef RR
         ++g_rr_launches[1];
         return check_launch(who);
     }
 #endif
-    if (a->pre_c) return fail(ELO_ERR_ARG, "%s: pre_c / pre_s are taken by the chain form only (pre-grouped call, elo_cv_chain_form)", who);
     const dim3 grid((unsigned)(t16 ? u16 : u32));
 #define CALL(k) hipLaunchKernelGGL(k, grid, dim3(FUSED_BLOCK), lds, s, *a, S)
     ELO_PICK(cv2_kernel, t16, mode, CALL);

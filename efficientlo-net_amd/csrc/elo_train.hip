@@ -238,7 +238,7 @@ __global__ __launch_bounds__(TB) void bn_bwd_apply_kernel(const float *__restric
 // 128 -> 128 layer, at 1.8 TB/s the whole 200 us).  No reduction inside the workgroup: a wave stores its block of the
 // slice's partial dW; slices_combine_kernel sums the slices in a fixed order.  Loads are 4 bytes per lane (4 rows x 16
 // consecutive channels per instruction), U row groups in flight.
-template <int CI, int CO, bool ATOMIC = false>        // ATOMIC: a slice ADDS its block into the (zeroed) dW / db instead of storing a partial
+template <int CI, int CO>
 __global__ __launch_bounds__(TB, 2) void weight_grad_kernel(const float *__restrict__ x, const float *__restrict__ g, long M, int Cin,
                                                          int Cout, int gy, int gz, float *__restrict__ part, float *__restrict__ bpart)
 {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(TB, 2) void weight_grad_kernel(const float *__restr
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    float *dst = ATOMIC ? part : part + (size_t)blockIdx.x * Cin * Cout;
+    float *dst = part + (size_t)blockIdx.x * Cin * Cout;
 #pragma unroll
     for (int a = 0; a < CI; ++a)
 #pragma unroll
@@ -300,10 +300,7 @@ __global__ __launch_bounds__(TB, 2) void weight_grad_kernel(const float *__restr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = ci0 + a * 16 + 4 * k4 + r;
-                if (ci < Cin && co < Cout) {
-                    if (ATOMIC) unsafeAtomicAdd(&dst[(size_t)ci * Cout + co], acc[a][b][r]);
-                    else dst[(size_t)ci * Cout + co] = acc[a][b][r];
-                }
+                if (ci < Cin && co < Cout) dst[(size_t)ci * Cout + co] = acc[a][b][r];
             }
         }
     if (bpart && ci0 == 0) {
@@ -313,10 +310,7 @@ __global__ __launch_bounds__(TB, 2) void weight_grad_kernel(const float *__restr
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             const int co = co0 + b * 16 + i16;
-            if (k4 == 0 && co < Cout) {
-                if (ATOMIC) unsafeAtomicAdd(&bpart[co], v);
-                else bpart[(size_t)blockIdx.x * Cout + co] = v;
-            }
+            if (k4 == 0 && co < Cout) bpart[(size_t)blockIdx.x * Cout + co] = v;
         }
     }
 }
@@ -353,179 +347,6 @@ __global__ __launch_bounds__(TB) void slices_combine_kernel(const float *__restr
         for (int r = 0; r < 16; ++r) t += red[r][j];
         out[i] = t;
     }
-}
-
-// ================================================================ round 6: the same passes in FEWER launches
-// A training layer cost ten launches (GEMM, bn_stats, bn_finalize, bn_apply | bn_bwd_reduce, bn_bwd_combine, bn_bwd_apply,
-// GEMM, weight_grad, slices_combine) and ~100 layers make a step: 1444 launches of ~10 us.  The three "combine" launches only
-// total per-block partial sums.  Here a block ADDS its partials into one of ELO_BN_REPLICAS replicas of the (2, C) totals with
-// float atomics (replica = block % 8: at most parts / 8 <= 64 same-address atomics, ~1.5 us of tail in the worst case, where
-// round 2's single accumulator serialised 1800 of them: 46 us) and the CONSUMER's prologue sums the 8 replicas (8 x 2C floats
-// from L2, spread over the block's threads: one round trip) -- no launch, no ticket, no fence.  The accumulators come zeroed from
-// the caller (one memset per training STEP over an arena: _ops.ZeroArena).  The sums are no longer bit-reproducible from run to run
-// (the order of the atomics); a training step never was (the scatter adjoints of elo_backward.hip).
-constexpr int REP = ELO_BN_REPLICAS;
-
-__device__ __forceinline__ void add4(float *acc, int C, int which, int cg, const float4 v)
-{
-    float *dst = acc + ((size_t)(blockIdx.x % REP) * 2 + which) * C + 4 * cg;
-    unsafeAtomicAdd(dst + 0, v.x); unsafeAtomicAdd(dst + 1, v.y); unsafeAtomicAdd(dst + 2, v.z); unsafeAtomicAdd(dst + 3, v.w);
-}
-
-__global__ __launch_bounds__(TB) void bn_stats_acc_kernel(const float *__restrict__ z, long M, int C, float *__restrict__ acc)
-{
-    __shared__ float4 lds[TB];
-    const int q = C >> 2, rpb = TB / q, cg = threadIdx.x % q, rr = threadIdx.x / q;
-    long r0, r1;
-    block_rows(M, rpb, r0, r1);
-    float4 s{0.f, 0.f, 0.f, 0.f}, ss{0.f, 0.f, 0.f, 0.f};
-    for (long r = r0 + rr; r < r1; r += (long)rpb * ROW_UNROLL) {
-        float4 v[ROW_UNROLL];
-#pragma unroll
-        for (int u = 0; u < ROW_UNROLL; ++u) {
-            const long ru = r + (long)u * rpb;
-            v[u] = ld4(z, (ru < r1 ? ru : r) * q + cg);
-            if (ru >= r1) v[u] = float4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < ROW_UNROLL; ++u) {
-            s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
-            ss.x += v[u].x * v[u].x; ss.y += v[u].y * v[u].y; ss.z += v[u].z * v[u].z; ss.w += v[u].w * v[u].w;
-        }
-    }
-    const float4 ts = reduce_groups(s, q, lds), tss = reduce_groups(ss, q, lds);
-    if (threadIdx.x < q && r0 < r1) { add4(acc, C, 0, cg, ts); add4(acc, C, 1, cg, tss); }
-}
-
-// the two per-channel totals of the replicas -> LDS tot[0..C) / tot[C..2C); every thread of the block takes part
-__device__ __forceinline__ void total_replicas(const float *__restrict__ acc, int C, float *tot)
-{
-    for (int i = threadIdx.x; i < 2 * C; i += TB) {
-        float v[REP];
-#pragma unroll
-        for (int p = 0; p < REP; ++p) v[p] = acc[(size_t)p * 2 * C + i];
-        double t = 0.0;
-#pragma unroll
-        for (int p = 0; p < REP; ++p) t += (double)v[p];
-        tot[i] = (float)t;
-    }
-    __syncthreads();
-}
-
-// y = act(batch norm(z)) with the moments taken from the accumulators in the prologue; block 0 also publishes mean / invstd
-// (saved for backward) and updates the moving averages
-__global__ __launch_bounds__(TB) void bn_apply_acc_kernel(const float *__restrict__ z, long n4, long M, int C, const float *__restrict__ acc,
-                                                          float eps, float momentum, const float *__restrict__ gamma,
-                                                          const float *__restrict__ beta, int relu, float *__restrict__ mean,
-                                                          float *__restrict__ invstd, float *__restrict__ running_mean,
-                                                          float *__restrict__ running_var, float *__restrict__ y)
-{
-    __shared__ __attribute__((aligned(16))) float tot[2 * 256];
-    total_replicas(acc, C, tot);
-    for (int c = threadIdx.x; c < C; c += TB) {                       // (s, ss) -> (mean, invstd), in place
-        const double mm = (double)tot[c] / (double)M;
-        double var = (double)tot[C + c] / (double)M - mm * mm;
-        var = var > 0.0 ? var : 0.0;
-        const float mf = (float)mm, inv = (float)(1.0 / sqrt(var + (double)eps));
-        if (blockIdx.x == 0) {
-            mean[c] = mf;
-            invstd[c] = inv;
-            if (running_mean) {
-                const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-                running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mm);
-                running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
-            }
-        }
-        tot[c] = mf;
-        tot[C + c] = inv;
-    }
-    __syncthreads();
-    const int cg = threadIdx.x & ((C >> 2) - 1);
-    const float4 m = reinterpret_cast<const float4 *>(tot)[cg], s = reinterpret_cast<const float4 *>(tot + C)[cg], g = ld4(gamma, cg), b = ld4(beta, cg);
-    const long stride = (long)gridDim.x * TB;
-    auto one = [&](const float4 v) {
-        float4 o{(v.x - m.x) * s.x * g.x + b.x, (v.y - m.y) * s.y * g.y + b.y, (v.z - m.z) * s.z * g.z + b.z,
-                 (v.w - m.w) * s.w * g.w + b.w};
-        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        return o;
-    };
-    long i = (long)blockIdx.x * TB + threadIdx.x;
-    for (; i + (BN_APPLY_UNROLL - 1) * stride < n4; i += BN_APPLY_UNROLL * stride) {
-        float4 v[BN_APPLY_UNROLL];
-#pragma unroll
-        for (int u = 0; u < BN_APPLY_UNROLL; ++u) v[u] = ld4(z, i + u * stride);
-#pragma unroll
-        for (int u = 0; u < BN_APPLY_UNROLL; ++u) reinterpret_cast<float4 *>(y)[i + u * stride] = one(v[u]);
-    }
-    for (; i < n4; i += stride) reinterpret_cast<float4 *>(y)[i] = one(ld4(z, i));
-}
-
-__global__ __launch_bounds__(TB) void bn_bwd_reduce_acc_kernel(const float *__restrict__ dy, const float *__restrict__ z, long M, int C,
-                                                               const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                               const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                               int relu, float *__restrict__ acc)
-{
-    __shared__ float4 lds[TB];
-    const int q = C >> 2, rpb = TB / q, cg = threadIdx.x % q, rr = threadIdx.x / q;
-    const BnCol p{ld4(mean, cg), ld4(invstd, cg), ld4(gamma, cg), ld4(beta, cg)};
-    long r0, r1;
-    block_rows(M, rpb, r0, r1);
-    float4 s1{0.f, 0.f, 0.f, 0.f}, s2{0.f, 0.f, 0.f, 0.f};
-    constexpr int U = ROW_UNROLL / 2;
-    for (long r = r0 + rr; r < r1; r += (long)rpb * U) {
-        float4 a[U], b[U];
-        bool live[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long ru = r + (long)u * rpb;
-            live[u] = ru < r1;
-            a[u] = ld4(dy, (live[u] ? ru : r) * q + cg);
-            b[u] = ld4(z, (live[u] ? ru : r) * q + cg);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float4 g, xh;
-            bn_back(a[u], b[u], p, relu, g, xh);
-            if (!live[u]) g = float4{0.f, 0.f, 0.f, 0.f};
-            s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
-            s2.x += g.x * xh.x; s2.y += g.y * xh.y; s2.z += g.z * xh.z; s2.w += g.w * xh.w;
-        }
-    }
-    const float4 t1 = reduce_groups(s1, q, lds), t2 = reduce_groups(s2, q, lds);
-    if (threadIdx.x < q && r0 < r1) { add4(acc, C, 0, cg, t1); add4(acc, C, 1, cg, t2); }
-}
-
-// dz with the two sums taken from the accumulators in the prologue; block 0 publishes them ([d beta | d gamma])
-__global__ __launch_bounds__(TB) void bn_bwd_apply_acc_kernel(const float *__restrict__ dy, const float *__restrict__ z, long n4, long M,
-                                                              int C, const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                              const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
-                                                              const float *__restrict__ acc, float *__restrict__ sums, float *__restrict__ dz)
-{
-    __shared__ __attribute__((aligned(16))) float tot[2 * 256];
-    total_replicas(acc, C, tot);
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < 2 * C; i += TB) sums[i] = tot[i];
-    const int cg = threadIdx.x & ((C >> 2) - 1);
-    const long stride = (long)gridDim.x * TB;
-    const float inv_m = 1.0f / (float)M;
-    const BnCol p{ld4(mean, cg), ld4(invstd, cg), ld4(gamma, cg), ld4(beta, cg)};
-    const float4 a1 = reinterpret_cast<const float4 *>(tot)[cg], a2 = reinterpret_cast<const float4 *>(tot + C)[cg];
-    const float4 k1{a1.x * inv_m, a1.y * inv_m, a1.z * inv_m, a1.w * inv_m}, k2{a2.x * inv_m, a2.y * inv_m, a2.z * inv_m, a2.w * inv_m};
-    auto one = [&](const float4 dyv, const float4 zv) {
-        float4 g, xh;
-        bn_back(dyv, zv, p, relu, g, xh);
-        return float4{p.g.x * p.s.x * (g.x - k1.x - xh.x * k2.x), p.g.y * p.s.y * (g.y - k1.y - xh.y * k2.y),
-                      p.g.z * p.s.z * (g.z - k1.z - xh.z * k2.z), p.g.w * p.s.w * (g.w - k1.w - xh.w * k2.w)};
-    };
-    long i = (long)blockIdx.x * TB + threadIdx.x;
-    for (; i + (BN_APPLY_UNROLL - 1) * stride < n4; i += BN_APPLY_UNROLL * stride) {
-        float4 a[BN_APPLY_UNROLL], b[BN_APPLY_UNROLL];
-#pragma unroll
-        for (int u = 0; u < BN_APPLY_UNROLL; ++u) { a[u] = ld4(dy, i + u * stride); b[u] = ld4(z, i + u * stride); }
-#pragma unroll
-        for (int u = 0; u < BN_APPLY_UNROLL; ++u) reinterpret_cast<float4 *>(dz)[i + u * stride] = one(a[u], b[u]);
-    }
-    for (; i < n4; i += stride) reinterpret_cast<float4 *>(dz)[i] = one(ld4(dy, i), ld4(z, i));
 }
 
 bool pow2_width(int C) { return C >= 4 && C <= 256 && (C & (C - 1)) == 0; }
@@ -595,36 +416,6 @@ extern "C" int elo_bn_backward(const elo_bn_backward_args *a, elo_stream_t strea
     return check_launch(who);
 }
 
-extern "C" int elo_bn_forward(const elo_bn_forward_args *a, elo_stream_t stream)
-{
-    const char *who = "elo_bn_forward";
-    if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
-    if (int rc = check_bn(who, a->rows, a->C, {a->z, a->acc, a->mean, a->invstd, a->gamma, a->beta, a->y})) return rc;
-    if ((a->running_mean == nullptr) != (a->running_var == nullptr)) return fail(ELO_ERR_ARG, "%s: running_mean and running_var go together", who);
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_stats_acc_kernel, dim3(grid_for(a->rows, a->C)), dim3(TB), 0, s, a->z, a->rows, a->C, a->acc);
-    const long n4 = a->rows * (a->C >> 2);
-    const long blocks = (n4 + TB * 4 - 1) / (TB * 4);
-    hipLaunchKernelGGL(bn_apply_acc_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(TB), 0, s, a->z, n4, a->rows, a->C, a->acc,
-                       a->eps, a->momentum, a->gamma, a->beta, a->relu, a->mean, a->invstd, a->running_mean, a->running_var, a->y);
-    return check_launch(who);
-}
-
-extern "C" int elo_bn_backward_acc(const elo_bn_backward_args *a, elo_stream_t stream)
-{
-    const char *who = "elo_bn_backward_acc";
-    if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
-    if (int rc = check_bn(who, a->rows, a->C, {a->dy, a->z, a->mean, a->invstd, a->gamma, a->beta, a->scratch, a->sums, a->dz})) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_reduce_acc_kernel, dim3(grid_for(a->rows, a->C)), dim3(TB), 0, s, a->dy, a->z, a->rows, a->C, a->mean, a->invstd,
-                       a->gamma, a->beta, a->relu, a->scratch);
-    const long n4 = a->rows * (a->C >> 2);
-    const long blocks = (n4 + TB * 4 - 1) / (TB * 4);
-    hipLaunchKernelGGL(bn_bwd_apply_acc_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(TB), 0, s, a->dy, a->z, n4, a->rows, a->C,
-                       a->mean, a->invstd, a->gamma, a->beta, a->relu, a->scratch, a->sums, a->dz);
-    return check_launch(who);
-}
-
 // row slices of the weight gradient: a slice is one workgroup's rows (its waves own different blocks of dW): enough
 // slices to fill the GPU and hide the load latency of the narrow layers, few enough that the partial blocks stay
 // <= 32 MB and every slice has >= 32 row groups
@@ -638,36 +429,15 @@ extern "C" int elo_weight_grad_slices(long rows, int Cin, int Cout)
     return (int)(s < 1 ? 1 : s);
 }
 
-// 1: elo_dense_weight_grad_acc adds into zeroed dW / db in ONE launch (few slices: <= ELO_WG_ATOMIC_SLICES same-address atomics per
-// element); 0: it falls back on elo_dense_weight_grad's two launches (many slices: the caller provides scratch as for that entry)
-extern "C" int elo_weight_grad_atomic(long rows, int Cin, int Cout)
-{
-    return elo_weight_grad_slices(rows, Cin, Cout) <= ELO_WG_ATOMIC_SLICES ? 1 : 0;
-}
-
-static int weight_grad_impl(const elo_weight_grad_args *a, elo_stream_t stream, bool acc, const char *who);
-
 extern "C" int elo_dense_weight_grad(const elo_weight_grad_args *a, elo_stream_t stream)
 {
-    return weight_grad_impl(a, stream, false, "elo_dense_weight_grad");
-}
-
-extern "C" int elo_dense_weight_grad_acc(const elo_weight_grad_args *a, elo_stream_t stream)
-{
-    const char *who = "elo_dense_weight_grad_acc";
-    if (a && !elo_weight_grad_atomic(a->rows, a->Cin, a->Cout)) return weight_grad_impl(a, stream, false, who);
-    return weight_grad_impl(a, stream, true, who);
-}
-
-static int weight_grad_impl(const elo_weight_grad_args *a, elo_stream_t stream, bool atomic, const char *who)
-{
+    const char *who = "elo_dense_weight_grad";
     if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
     if (a->rows <= 0 || a->Cin <= 0 || a->Cout <= 0) return fail(ELO_ERR_ARG, "%s: bad sizes", who);
-    if (!a->x || !a->g || !a->dW || (!atomic && !a->scratch)) return fail(ELO_ERR_ARG, "%s: null tensor pointer", who);
+    if (!a->x || !a->g || !a->dW || !a->scratch) return fail(ELO_ERR_ARG, "%s: null tensor pointer", who);
     const int cit = (a->Cin + 15) / 16, cot = (a->Cout + 15) / 16;
     const int slices = elo_weight_grad_slices(a->rows, a->Cin, a->Cout);
-    float *bpart = atomic ? a->db : a->db ? a->scratch + (size_t)slices * a->Cin * a->Cout : nullptr;
-    float *wpart = atomic ? a->dW : a->scratch;
+    float *bpart = a->db ? a->scratch + (size_t)slices * a->Cin * a->Cout : nullptr;
     hipStream_t s = (hipStream_t)stream;
     // blocks of dW: all column tiles of a <= 64-wide output (1, 2 or 4); row tiles: the count in 1..4 that pads the input
     // width least, larger on a tie or when the padding stays <= 25 % (138 channels = 9 tiles: 3 x 3; 80 = 5 tiles: 2 x 3)
@@ -680,16 +450,12 @@ static int weight_grad_impl(const elo_weight_grad_args *a, elo_stream_t stream, 
     const int gy = (cit + CI - 1) / CI, gz = (cot + CO - 1) / CO, nb = gy * gz, wpb = nb < TB / 64 ? nb : TB / 64;
     const dim3 grid((unsigned)slices, (unsigned)((nb + wpb - 1) / wpb));
 #define ELO_WG(CI_, CO_)                                                                                                      \
-    if (CI == CI_ && CO == CO_) {                                                                                             \
-        if (atomic) hipLaunchKernelGGL((weight_grad_kernel<CI_, CO_, true>), grid, dim3(64 * wpb), 0, s, a->x, a->g, a->rows, a->Cin, a->Cout, gy, gz, \
-                                       wpart, bpart);                                                                         \
-        else hipLaunchKernelGGL((weight_grad_kernel<CI_, CO_, false>), grid, dim3(64 * wpb), 0, s, a->x, a->g, a->rows, a->Cin, a->Cout, gy, gz, \
-                                wpart, bpart);                                                                                \
-    }
+    if (CI == CI_ && CO == CO_)                                                                                               \
+        hipLaunchKernelGGL((weight_grad_kernel<CI_, CO_>), grid, dim3(64 * wpb), 0, s, a->x, a->g, a->rows, a->Cin, a->Cout, gy, gz, \
+                           a->scratch, bpart)
     ELO_WG(1, 1); ELO_WG(1, 2); ELO_WG(1, 4); ELO_WG(2, 1); ELO_WG(2, 2); ELO_WG(2, 4);
     ELO_WG(3, 1); ELO_WG(3, 2); ELO_WG(3, 4); ELO_WG(4, 1); ELO_WG(4, 2); ELO_WG(4, 4);
 #undef ELO_WG
-    if (atomic) return check_launch(who);
     const long n = (long)a->Cin * a->Cout;
     const unsigned bw = (unsigned)((n + 15) / 16), bb = a->db ? (unsigned)((a->Cout + 15) / 16) : 0u;
     hipLaunchKernelGGL(slices_combine_kernel, dim3(bw + bb), dim3(TB), 0, s, a->scratch, slices, n, a->dW, bw, bpart, (long)a->Cout, a->db);

@@ -110,8 +110,15 @@ class FlatGradBucket:
     def world_size():
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
+    force_collective = False      # True: the all-reduce also runs on a world of ONE rank (bench.py ELO_BENCH_FORCE_DIST=1: RCCL's code path on a 1-GPU box)
+
+    @classmethod
+    def has_collective(cls):
+        """Whether a training step has its exchange step: a process group of more than one rank (or the one-rank rehearsal)."""
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or cls.force_collective)
+
     def all_reduce_mean(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if self.has_collective():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
         return self.flat

@@ -139,20 +139,6 @@ class PackedDense:
         self.b[:N] = b
         self.K, self.N, self.relu = K, N, relu
         self.plain = W.contiguous() if max(K, N) <= 32 else None      # narrow layers: also kept row-major (K,N)
-        self._rows, self._half, self._parts = W, half, {}             # (row-ordered folded weight: part() slices it)
-
-    def part(self, lo, hi, bias=True):
-        """The layer restricted to its input rows [lo, hi) (in the kernel's row order), packed as a layer of its own -- with
-        the layer's bias, or with a zero bias: "layer 0 through the gather" splits a grouped operator's first layer into the
-        rows of each source (elo_rowlinear_fused2 applies them once per point) and the per-row rest (include/elo.h, the
-        pre / pre_c / pre_s fields).  16-k blocks of the slice keep the values and the order they have in the whole layer
-        when lo is a multiple of 16, so the partial sums are the whole layer's.  Cached with the layer."""
-        key = (lo, hi, bias)
-        hit = self._parts.get(key)
-        if hit is None:
-            b = self.b[:self.N] if bias else torch.zeros_like(self.b[:self.N])
-            hit = self._parts[key] = PackedDense(self._rows[lo:hi], b, self.relu, None, self._half)
-        return hit
 
     def struct(self):
         return L.Dense(self.w.data_ptr(), self.b.data_ptr(), self.K, self.N, 1 if self.relu else 0,
@@ -286,10 +272,6 @@ def _setconv_args(src_xyz, src_feat, idx, mask, layers, centre_xyz=None, xyz1_gr
     a = L.SetconvArgs(B, n, K, H, W, H2, W2, C, ptr(xyz1_grid), ptr(centre_hw), ptr(centre_xyz), src_xyz.data_ptr(),
                       src_feat.data_ptr(), ptr(idx), ptr(mask), len(layers), _chain(layers), out.data_ptr(), ptr(new_xyz),
                       group.struct(B, n, K, dev) if group is not None else _NO_GROUP, code)
-    strided = getattr(centre_hw, "elo_strided", None) if centre_hw is not None else None
-    if strided is not None and xyz1_grid is not None and strided[2] * strided[3] == n:
-        # the centres are the strided pixels of xyz1_grid in row-major order (get_selected_idx said so): structured centres
-        a.centre_stride_h, a.centre_stride_w, a.centre_rows, a.centre_cols = strided
     keep = (src_xyz, src_feat, idx, mask, centre_xyz, xyz1_grid, centre_hw, layers, group)   # alive until the launch
     return a, out, new_xyz, keep
 
@@ -300,77 +282,13 @@ def setconv(src_xyz, src_feat, idx, mask, layers, centre_xyz=None, xyz1_grid=Non
     layers[0] is packed with `row_order=setconv_row_order(C)` (the kernel's columns are [features | xyz difference]).
     Returns (out (B,n,Cout) in src_feat's dtype, new_xyz (B,n,3) or None)."""
     job = _setconv_args(src_xyz, src_feat, idx, mask, layers, centre_xyz, xyz1_grid, centre_hw, group, K)
-    _alive = _setconv_pre([job])
     L.call("elo_setconv_fused", job[0], job[1])
     return job[1], job[2]
-
-
-class layer0_pre:
-    """`with fused.layer0_pre({"setconv": 0, "cv2": 0, "cv1": 32}):` -- which grouped operators run their first layer "through
-    the gather" on the chain kernels (operator -> minimum feature channels; {} = none), for tests and A/B measurements.
-    The process default is tuning's `layer0_pre` (ELO_LAYER0_PRE, e.g. "setconv,cv2,cv1:32"; "0" = none): NONE -- measured at
-    batch 8, the per-point tables (512 bytes of fp32 per point, gathered per row) cost what the matrix work they replace
-    cost: profiles/r05_layer0_through_the_gather.txt, DESIGN.md section 3b round 5."""
-
-    def __init__(self, on):
-        self.on = dict(on)
-
-    def __enter__(self):
-        self.prev = tuning.set_host("layer0_pre", self.on)
-        return self
-
-    def __exit__(self, *exc):
-        tuning.set_host("layer0_pre", self.prev)
-
-
-def _pre_on(op, C):
-    on = tuning.get("layer0_pre")
-    return op in on and C >= on[op] and not fp32_mfma()
-
-
-def rowlinear(jobs):
-    """out[row] = bias + W . src[row] (128 fp32 columns, no activation) for one or two (src (..., C), PackedDense) jobs in ONE
-    launch (elo_rowlinear_fused2): the per-point part of a grouped operator's first layer.  Two jobs: equal widths, or the
-    narrower one first with a 64-channel second."""
-    args, outs, keep = [], [], []
-    for src, layer in jobs:
-        L.require_gpu(src)
-        (src,), _dt, code = _features(src)
-        C = src.shape[-1]
-        rows = src.numel() // C
-        out = torch.empty((rows, 128), dtype=torch.float32, device=src.device)
-        args.append(L.RowlinearArgs(rows, C, src.data_ptr(), layer.struct(), out.data_ptr(), code))
-        outs.append(out)
-        keep.append((src, layer))
-    L.call2n("elo_rowlinear_fused2", args[0], args[1] if len(args) > 1 else None, outs[0])
-    return outs
-
-
-def _setconv_pre(jobs):
-    """jobs: one or two _setconv_args() results.  When the launch will take the chain form and its first layer is [64 features
-    | xyz] -> 128 (the set-upconvs), apply the layer's feature rows once per SOURCE cell (rowlinear: pre[cell] = b + W_feat .
-    feat[cell]) and hand the kernel the xyz rows only (elo_setconv_args.pre).  Returns what must stay alive until the launch."""
-    args = [j[0] for j in jobs]
-    layers = [j[3][7] for j in jobs]                           # (_setconv_args' keep-alive tuple: ..., src_feat at 1, layers at 7)
-    feats = [j[3][1] for j in jobs]
-    C = args[0].C
-    if not (_pre_on("setconv", C) and all(len(l) == 2 and l[0].N == 128 and l[0].K == 3 + C for l in layers)):
-        return ()                                              # (the pre form exists for the 64 + 3 -> 128 -> 64 chain: the set-upconvs)
-    second = ctypes.byref(args[1]) if len(args) > 1 else None
-    if L.lib().elo_setconv_chain_form(ctypes.byref(args[0]), second) != 1:
-        return ()
-    pres = rowlinear([(f, l[0].part(0, C)) for f, l in zip(feats, layers)])
-    geos = [l[0].part(C, C + 3) for l in layers]
-    for a, pre, geo in zip(args, pres, geos):
-        a.layers[0] = geo.struct()
-        a.pre = pre.data_ptr()
-    return pres, geos
 
 
 def setconv_pair(job_a, job_b):
     """Two set-conv jobs of identical shape (dicts of setconv() keyword arguments) in ONE launch."""
     ja, jb = _setconv_args(**job_a), _setconv_args(**job_b)
-    _alive = _setconv_pre([ja, jb])
     L.call2("elo_setconv_fused2", ja[0], jb[0], ja[1])
     return (ja[1], ja[2]), (jb[1], jb[2])
 
@@ -430,7 +348,7 @@ def _ride_sv(a, b, sv, dt):
 
 def mlp(sources, layers, clear=None, sv=None):
     """Row-wise MLP over concat(sources, -1) without building the concat.  sources: (..., C_i) tensors.
-    `clear`: ProjectionBuffers of a later projection, cleared on the side (for a pose head run with direct=True).
+    `clear`: ProjectionBuffers of a later projection, cleared on the side (for a pose head that takes the partial sums of `sv`).
     `sv`: an _ops.SvPartials (with .feature): the output are softmax_valid's logits and the launch also computes its partial
     sums -- when it can (sv.parts > 0 afterwards); `clear` then rides only if it does."""
     a, out, _keep = _mlp_args(sources, layers)
@@ -605,7 +523,7 @@ def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_x
         if rr:
             chain_jobs = [_setconv_args(**job) for job in side]          # (args, out, new_xyz, keep-alive)
             probe = L.Cv1Args(B, N, K, H2, W2, C, None, None, None, None, None, None, cv0.struct(), cv1.struct(), cv2.struct(),
-                              cv_xyz.struct(), sum_cv0.struct(), sum_cv1.struct(), None, _NO_GROUP, code, None, None)
+                              cv_xyz.struct(), sum_cv0.struct(), sum_cv1.struct(), None, _NO_GROUP, code)
             if L.lib().elo_cv_stage1_setconv_chain_form(ctypes.byref(probe), ctypes.byref(chain_jobs[0][0]), ctypes.byref(chain_jobs[1][0])) != 1:
                 chain_jobs = None
         if chain_jobs is None:
@@ -617,15 +535,10 @@ def cv_stage1(xyz1, feat1, xyz2_proj, feat2_proj, idx, mask, cv0, cv1, cv2, cv_x
         idx, mask = idx.contiguous(), _f32c(mask)
         K = idx.shape[2]
     out = torch.empty((B, N, 64), dtype=dt, device=xyz1.device)
-    pre_c = pre_s = None
-    if group is None and not side and cv0.K == 10 + 2 * C and _pre_on("cv1", C) and L.lib().elo_cv_chain_form(C, cv0.products) == 1:
-        # layer 0 through the gather: CV_0's rows of feat1 once per centre (with the bias), of feat2 once per source cell
-        pre_c, pre_s = rowlinear([(feat1, cv0.part(0, C)), (feat2_proj, cv0.part(C, 2 * C, bias=False))])
-        cv0 = cv0.part(2 * C, 2 * C + 10)                         # ... and the kernel runs the geometry rows per row
     a = L.Cv1Args(B, N, K, H2, W2, C, xyz1.data_ptr(), feat1.data_ptr(), xyz2_proj.data_ptr(), feat2_proj.data_ptr(),
                   ptr(idx), ptr(mask), cv0.struct(), cv1.struct(), cv2.struct(), cv_xyz.struct(),
                   sum_cv0.struct(), sum_cv1.struct(), out.data_ptr(),
-                  group.struct(B, N, K, xyz1.device) if group is not None else _NO_GROUP, code, ptr(pre_c), ptr(pre_s))
+                  group.struct(B, N, K, xyz1.device) if group is not None else _NO_GROUP, code)
     if chain_jobs:
         L.call3("elo_cv_stage1_setconv_chain", a, chain_jobs[0][0], chain_jobs[1][0], out)
         return out, [(j[1], j[2]) for j in chain_jobs]
@@ -663,14 +576,8 @@ def cv_stage2(xyz1_proj, feat1_proj, cost_proj, idx, mask, xyz_enc, sum_cost0, s
         idx, mask = idx.contiguous(), _f32c(mask)
         K = idx.shape[2]
     out = torch.empty((B, N, 64), dtype=dt, device=xyz1_proj.device)
-    pre_c = pre_s = None
-    if group is None and sum_cost0.K == 128 + C and _pre_on("cv2", C) and L.lib().elo_cv_chain_form(C, sum_cost0.products) == 1:
-        # layer 0 through the gather: sum_cost_volume_0's rows of feat1 once per centre (with the bias), of the stage-1 cost once
-        # per source point; the kernel keeps the xyz-encoding rows (kernel order [cost (64) | encoding (64) | feat1 (C)])
-        pre_c, pre_s = rowlinear([(feat1_proj, sum_cost0.part(128, 128 + C)), (cost_proj, sum_cost0.part(0, 64, bias=False))])
-        sum_cost0 = sum_cost0.part(64, 128)
     a = L.Cv2Args(B, N, K, H, W, C, xyz1_proj.data_ptr(), feat1_proj.data_ptr(), cost_proj.data_ptr(), ptr(idx),
                   ptr(mask), xyz_enc.struct(), sum_cost0.struct(), sum_cost1.struct(), out.data_ptr(),
-                  group.struct(B, N, K, xyz1_proj.device) if group is not None else _NO_GROUP, code, ptr(pre_c), ptr(pre_s))
+                  group.struct(B, N, K, xyz1_proj.device) if group is not None else _NO_GROUP, code)
     L.call("elo_cv_stage2_fused", a, out)
     return out

@@ -15,6 +15,18 @@ import torch
 from . import _ops, fused, model_util, perm, pwclo_model, tf_util, tuning
 
 
+def graph_capture(graph):
+    """torch.cuda.graph(graph) -- in the capture mode a process with a process group needs.  torch captures in hipStreamCaptureModeGlobal
+    by default: while a capture is open, a hipEventQuery from ANY thread fails -- and the RCCL watchdog thread of torch.distributed
+    polls the events of the collectives still in flight (the pose all-gather of the timed loop, a gradient all-reduce) all the time:
+    "Exception raised from query at HIPEvent.h" and an abort, found by the one-rank RCCL rehearsal of round 6.  With a process group
+    initialised the capture is therefore thread-local (only the capturing thread is held to the capture rules)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return torch.cuda.graph(graph, capture_error_mode="thread_local")
+    return torch.cuda.graph(graph)
+
+
 def distinct_queue_streams(device, want, candidates=16, cycles=500_000):
     """Up to `want` torch streams that sit on DIFFERENT hardware queues.
 
@@ -186,7 +198,7 @@ class PWCLONet:
                     self.forward(both[:batch_size], both[batch_size:])
                 torch.cuda.synchronize(dev)
             self.perms.tail_armed = bool(fresh_orders)    # the recorded forward's last launch loads the NEXT replay's orders
-            with torch.cuda.graph(lane["graph"]):
+            with graph_capture(lane["graph"]):
                 if num_points is not None:
                     _pts, staged = model_util.input_stage(lane["cloud"], None, None, H_input, W_input)
                     lane["out"] = self.forward(staged[:batch_size], staged[batch_size:], pose_out=lane["pose"])
@@ -202,7 +214,7 @@ class PWCLONet:
                         self.forward(*lane["in"])
                     torch.cuda.synchronize(dev)
                     self.perms.tail_armed = bool(fresh_orders)
-                    with torch.cuda.graph(lane["graph_checked"]):
+                    with graph_capture(lane["graph_checked"]):
                         if num_points is not None:
                             _pts, staged = model_util.input_stage(lane["cloud"], None, None, H_input, W_input)
                             lane["out_checked"] = self.forward(staged[:batch_size], staged[batch_size:], pose_out=lane["pose"])
@@ -324,7 +336,7 @@ class PWCLONet:
         stream = lane["stream"]
         if ready is None or ready is True:
             cur = torch.cuda.current_stream(self.device)
-            if cur != stream:
+            if cur != stream and not cur.query():         # (an idle producer has nothing to wait for: no cross-queue barrier)
                 lane["order"].record(cur)
                 stream.wait_event(lane["order"])
         else:

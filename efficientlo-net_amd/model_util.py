@@ -114,9 +114,6 @@ def get_selected_idx(array, stride_h, stride_w, out_h, out_w):
         ww = (torch.arange(out_w, dtype=torch.int32, device=dev) * stride_w).view(1, 1, -1, 1).expand(batch, out_h, out_w, 1)
         bb = torch.arange(batch, dtype=torch.int32, device=dev).view(-1, 1, 1, 1).expand(batch, out_h, out_w, 1)
         grid = torch.cat([bb, hh, ww], -1).contiguous()
-        # what the grid lists, as metadata the operator library can use without reading the device tensor: the strided pixels in
-        # row-major order (elo_setconv_args.centre_stride_* / centre_rows / centre_cols: the LDS-tiled set-conv form)
-        grid.elo_strided = (int(stride_h), int(stride_w), int(out_h), int(out_w))
         if capturing:
             return grid                     # a tensor born inside a graph's private pool is never cached
         if len(_sel_cache) >= 256:

@@ -97,8 +97,6 @@ def _centre_hw(selected_idx):
     if hit is None or hit[0] is not selected_idx:
         B = selected_idx.shape[0]
         hit = (selected_idx, selected_idx.reshape(B, -1, 3)[:, :, 1:].contiguous())
-        if getattr(selected_idx, "elo_strided", None) is not None:          # (model_util.get_selected_idx: strided pixels, row-major)
-            hit[1].elo_strided = selected_idx.elo_strided
         if len(_centre_hw_cache) > 64:
             _centre_hw_cache.clear()
         _centre_hw_cache[key] = hit

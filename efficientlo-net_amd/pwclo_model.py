@@ -95,48 +95,11 @@ def placeholder_inputs(batch_size, NUM_POINTS, device="cuda"):
     return z(batch_size, NUM_POINTS * 2, 6), z(batch_size, 4, 4), z(batch_size, 4, 4), z(batch_size, 4, 4)
 
 
-_side_streams = {}
-_CONCURRENT = False      # measured: forked branches inside the hipGraph cost 8% at 1 lane and 35% at 8 lanes
-
-
-def set_concurrent_branches(flag):
-    """Run independent operator branches of a refinement level on forked HIP streams (default off)."""
-    global _CONCURRENT
-    _CONCURRENT = bool(flag)
-
-
-# The same fork in TRAINING (ELO_TRAIN_BRANCHES=1 / set_training_branches): there a level's three branches (cost volume,
-# embedding and embedding-mask set-upconv) and its two predictors are ~35 conv + batch-norm layers of ten launch-bound
-# kernels each, with their own variables and moving statistics -- nothing shared but inputs; autograd runs each branch's
-# backward on the stream its forward ran on.
-def set_training_branches(flag):
-    tuning.set_host("train_branches", bool(flag))         # (read at the point of use: tuning.override(train_branches=...) agrees)
-
-
 def _parallel(branches, is_training=False):
-    """Run independent closures on forked streams and join; results in order.  Sequential on CPU tensors or when switched
-    off (inference: set_concurrent_branches; training: set_training_branches)."""
-    on = tuning.get("train_branches") if is_training else _CONCURRENT
-    if not on or len(branches) < 2 or not torch.cuda.is_available():
-        return [b() for b in branches]
-    dev = torch.cuda.current_device()
-    cur = torch.cuda.current_stream(dev)
-    key = (dev, cur.cuda_stream)
-    pool = _side_streams.setdefault(key, [])
-    while len(pool) < len(branches) - 1:
-        pool.append(torch.cuda.Stream(device=dev))
-    results = [None] * len(branches)
-    for i, b in enumerate(branches[1:]):
-        pool[i].wait_stream(cur)
-        with torch.cuda.stream(pool[i]):
-            results[i + 1] = b()
-    results[0] = branches[0]()
-    for i in range(len(branches) - 1):
-        cur.wait_stream(pool[i])
-        for t in (results[i + 1] if isinstance(results[i + 1], (tuple, list)) else [results[i + 1]]):
-            if torch.is_tensor(t):
-                t.record_stream(cur)
-    return results
+    """Independent closures of a refinement level, run in order on the current stream.  (Forking them onto side streams was built and
+    measured in rounds 1 and 5 -- inference: 8 % slower at one lane, 35 % at eight; the captured training step 15.2 -> 15.9 ms --
+    cross-stream edges in a hipGraph cost more than the overlap of these small kernels gives: DESIGN.md.)"""
+    return [b() for b in branches]
 
 
 def _adjacent_frames(a, b):
@@ -186,8 +149,7 @@ def _pose_head(feat_b1c, level, coarse, is_training, raw=False):
     return (q if raw else _normalise_q(q)), t
 
 
-def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training, pose7=None, clear=None, warp=None, direct=False,
-                   partials=None):
+def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training, pose7=None, clear=None, warp=None, partials=None):
     """softmax_valid + pose head + composition with the coarse pose (q_coarse None at l3).
     Returns (q (B,4), t (B,3), q_norm (B,4)): the level's pose and its final normalisation (:427-430).
     Inference: two fused HIP launches (_ops.pose_head).  Training: the literal operator chain."""
@@ -201,8 +163,7 @@ def _estimate_pose(predict, weight, xyz, level, q_coarse, t_coarse, is_training,
         # the l0 head is the last launch of a forward: in a graph captured with fresh_orders it also loads the NEXT replay's orders
         from . import perm
         nxt = perm.tail_refresh_args() if level == 0 else None
-        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7, clear, warp, nxt, direct,
-                              partials)
+        return _ops.pose_head(predict, weight, xyz, W_big, b_big, W_q, b_q, W_t, b_t, q_coarse, t_coarse, pose7, clear, warp, nxt, partials)
     summed = softmax_valid(feature_bnc=predict, weight_bnc=weight, mask_valid=xyz)                  # :194 / :262
     if predict.is_cuda and pose7 is None:
         # the pose algebra of :206-208 / :271-280 in ONE launch forward and one backward (_ops.pose_compose; the literal chain
@@ -331,18 +292,10 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
             return None
         return _ops.ProjectionBuffers(batch_size, xyz_proj_f1[level].shape[1] * xyz_proj_f1[level].shape[2],
                                       out_h_list[g], out_w_list[g], pts_f1[level].shape[-1], dev, pts_f1[level].dtype)
-    def direct_head(xyz_bn3):
-        # ELO_POSE_DIRECT=1: for small clouds (l3, l2, l1 of the 64 x 1800 input) the pose head reduces softmax_valid itself
-        # (one launch less per level; the projection buffers are then cleared by the launch that produces the head's
-        # inputs).  OFF by default -- measured slower: the 1024-thread head takes 13.8 / 16.2 / 24.3 us where the
-        # partial-sums launch + head take 17.0 / 18.3 / 20.8 us, and a workgroup that needs a whole CU waits for one when
-        # eight lanes are in flight (10 200 -> 9 640 frame-pairs/s; one lane 3 290 -> 3 230).  DESIGN.md, round 3.
-        return (inference and fused_pairs_available(is_training) and xyz_bn3.shape[1] <= _ops.L.POSE_DIRECT_MAX and
-                tuning.get("pose_direct"))
     def sv_ride(xyz_bn3, feature=None):
         # softmax_valid's partial sums ride on the launch that produces the pose head's inputs (tuning sv_ride; one launch less
         # per level where that launch is a tile kernel: fused.mlp / fused.mlp2_pair decide)
-        if inference and fused_pairs_available(is_training) and tuning.get("sv_ride") and not direct_head(xyz_bn3):
+        if inference and fused_pairs_available(is_training) and tuning.get("sv_ride"):
             return _ops.SvPartials(xyz_bn3, feature)
         return None
     def next_warp(level):          # the cloud + features the NEXT warp moves: run by the pose head's own launches
@@ -351,12 +304,11 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
     sv3 = sv_ride(l3_xyz_f1, l3_points_predict)
     l3_cost_volume_w = flow_predictor(pts_f1[3], None, l3_points_predict, mlp=[128, 64], is_training=is_training,
                                       bn_decay=bn_decay, scope='l3_costvolume_predict_ww',
-                                      clear=next_buffers if direct_head(l3_xyz_f1) or sv3 is not None else None,
+                                      clear=next_buffers if sv3 is not None else None,
                                       **({"sv": sv3} if sv3 is not None else {}))
     l3_cost_volume_w_proj = l3_cost_volume_w.reshape(batch_size, out_h_list[5], out_w_list[5], -1)
     l3_q, l3_t, l3_q_norm = _estimate_pose(l3_points_predict, l3_cost_volume_w, l3_xyz_f1, 3, None, None,
-                                           is_training, clear=next_buffers, warp=next_warp(2),
-                                           direct=direct_head(l3_xyz_f1), partials=sv3)             # :194-208
+                                           is_training, clear=next_buffers, warp=next_warp(2), partials=sv3)             # :194-208
 
     # three warp-refinement levels (:211-425); one loop instead of three pasted blocks
     cv_kernel2 = {2: [5, 15], 1: [7, 25], 0: [11, 41]}                                              # :243,:317,:391
@@ -418,7 +370,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
             sv = sv_ride(xyz_warp_f1)
             w_up_sample, weight, cost_up_sample, predict = up_conv_predict_finish(
                 up_w, up_c, dict(fp, scope='l%d_w_predict' % level), dict(fp, scope='l%d_costvolume_predict' % level),
-                up_w_pooled, up_c_pooled, clear=next_buffers if direct_head(xyz_warp_f1) or sv is not None else None, sv=sv)
+                up_w_pooled, up_c_pooled, clear=next_buffers if sv is not None else None, sv=sv)
         else:
             # the cost volume and the two set-upconvs only share inputs: optional concurrent branches
             cost, w_up_sample, cost_up_sample = _parallel([branch_cost, lambda: branch_up('w', coarse_w_proj),
@@ -432,8 +384,7 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
         q_prev, t_prev, q_norm = _estimate_pose(predict, weight, xyz_warp_f1, level, q_coarse, t_coarse,
                                                 is_training, pose_out if level == 0 else None,
                                                 clear=next_buffers,
-                                                warp=next_warp(level - 1) if level > 0 else None,
-                                                direct=direct_head(xyz_warp_f1), partials=sv)  # :262-280
+                                                warp=next_warp(level - 1) if level > 0 else None, partials=sv)  # :262-280
         poses[level] = (q_norm, t_prev)
 
         coarse_w_proj = weight.reshape(batch_size, out_h_list[g], out_w_list[g], -1)                # :256-257

@@ -11,8 +11,9 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, _ops, perm, pwclo_model, tf_checkpoint, tf_util
+from . import perm, pwclo_model, tf_checkpoint, tf_util
 from .distributed import FlatGradBucket
+from .model import graph_capture
 
 BASE_LEARNING_RATE, DECAY_STEP, DECAY_RATE = 0.001, 200000, 0.7          # main.py:46-51
 BN_INIT_DECAY, BN_DECAY_DECAY_RATE, BN_DECAY_CLIP = 0.5, 0.5, 0.99       # main.py:62-65
@@ -156,9 +157,6 @@ class Trainer:
         self.params = net.store.parameters() + [self.w_x, self.w_q]      # 382 tensors, 899 134 values
         self.bucket = FlatGradBucket(self.params)
         self.opt = FlatAdam(self.params, self.bucket, lr=BASE_LEARNING_RATE)   # main.py:174; one launch per step, capturable as it is
-        # the zeroed accumulators of a step's reductions (batch-norm replica sums, few-slice weight gradients): one memset per step
-        n_acc = sum(p.numel() for p in self.params) + 4 * _lib.BN_REPLICAS * 2 * sum(p.numel() for p in self.params if p.dim() == 1)
-        self.arena = _ops.ZeroArena(n_acc + (1 << 16), dev)
         self.step_count = 0
 
     def _global_batch(self, B):
@@ -172,8 +170,7 @@ class Trainer:
         """zero grads -> forward -> loss -> backward: this rank's gradients, in the flat bucket."""
         self.bucket.zero()
         self.bucket.release()
-        self.arena.begin()
-        with torch.enable_grad(), self.arena:
+        with torch.enable_grad():
             with tf_util.default_store(self.net.store), perm.default_perm_source(self.net.perms):
                 out = pwclo_model.get_model_from_projection(xyz_f1_proj, xyz_f2_proj, True, decay)
             loss = pwclo_model.get_loss(*out[:8], q_gt, t_gt, self.w_x, self.w_q)
@@ -225,14 +222,14 @@ class Trainer:
         self.net.perms.reshuffle()
         # With several ranks the collective stays OUTSIDE the graphs: [gradients] -> eager RCCL all-reduce of the flat
         # bucket -> [Adam] (two graphs); one rank: the whole step is one graph.
-        self._split = self.bucket.world_size() > 1
+        self._split = self.bucket.has_collective()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with graph_capture(self._graph):
             self._loss = (self._gradients if self._split else self._body)(*self._static, self._decay)
         self._graph_opt = None
         if self._split:
             self._graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_opt):
+            with graph_capture(self._graph_opt):
                 self.opt.launch()
         # the graphs hold raw device pointers into the module-level index / decoded-order caches, which evict when they grow:
         # keep what they point at alive for as long as the graphs exist (model._cached_tensors, as the inference lanes do)

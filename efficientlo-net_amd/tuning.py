@@ -5,7 +5,7 @@ Every choice of kernel FORM that is not a function of a call's arguments lives i
   * the library's `elo_tuning` (include/elo.h: chain forms, row thresholds, narrow-set-conv form, ...): the C library reads no
     environment variable; `_lib.lib()` fills the struct ONCE from the ELO_* variables below when it loads the library;
   * the host-side choices of this package (which operators take a grouping pre-pass, the tile count from which select-k is LDS
-    tiled, layer 0 through the gather, the launch-merging bound, ...), read from the environment ONCE, at import.
+    tiled, the launch-merging bound, ...), read from the environment ONCE, at import.
 
 `snapshot()` is the whole tuning as a plain dict (bench.py prints it as `config.tuning`), `digest()` its hash:
 model.PWCLONet.capture() records the digest and refuses to replay a graph under another tuning (a captured graph has the forms
@@ -17,16 +17,6 @@ import json
 import os
 
 # host-side fields: name -> (environment variable, parser, default)
-def _layer0(spec):
-    on = {}
-    for item in spec.replace(" ", "").split(","):
-        if item in ("", "0", "none"):
-            continue
-        name, _, arg = item.partition(":")
-        on[name] = int(arg) if arg else 0
-    return on
-
-
 def _prepass(spec):
     return None if spec in (None, "") else int(spec)
 
@@ -35,27 +25,23 @@ _HOST = {
     "fused": ("ELO_FUSED", lambda v: v != "0", True),                         # fused inference kernels (False: per-operator kernels + GEMMs)
     "cv_prepass": ("ELO_CV_PREPASS", _prepass, None),                         # None: the batch regimes; 0 never, 1 always, N from N rows on
     "select_dense_tiles": ("ELO_SELECT_DENSE_TILES", int, 1024),              # select-k pre-pass: LDS-tiled form from this many 64-centre tiles
-    "layer0_pre": ("ELO_LAYER0_PRE", _layer0, {}),                            # operator -> min channels: first layer through the gather (measured: does not pay)
     "merge_points": ("ELO_MERGE_POINTS", int, 8192),                          # heterogeneous cost-volume + set-conv launches in forwards of up to this many l0 centres ...
     "merge_level_points": ("ELO_MERGE_LEVEL_POINTS", int, 2000),              # ... at the levels of up to this many centres
-    "pose_direct": ("ELO_POSE_DIRECT", lambda v: v == "1", False),            # pose head reduces softmax_valid itself (one launch less)
     "chain_pair": ("ELO_CHAIN_PAIR", lambda v: v != "0", True),               # cost-volume stage 1 + the level's set-upconv stage 1 as ONE chain-kernel launch where both are chain forms
     "native_submit": ("ELO_NATIVE_SUBMIT", lambda v: v != "0", True),         # a lane submit as ONE C call (copy + hipGraphLaunch on the raw exec handle) instead of torch's copy_ + replay()
     "sv_ride": ("ELO_SV_RIDE", lambda v: v != "0", True),                     # softmax_valid's partial sums ride on the launch that produces its inputs (one launch less per level)
-    "train_branches": ("ELO_TRAIN_BRANCHES", lambda v: v == "1", False),
     "train_kernels": ("ELO_TRAIN_KERNELS", lambda v: v != "0", True),
-    "train_atomics": ("ELO_TRAIN_ATOMICS", lambda v: v != "0", True),         # training layer: replica-accumulator reductions (7 launches per layer instead of 10)
 }
 # library fields (elo_tuning): name -> (environment variable, default)
 _LIB = {
     "chain_forms": ("ELO_CV1_RR", 1), "narrow_mfma": ("ELO_SETCONV_NARROW_MFMA", 1), "range_check": ("ELO_RANGE_CHECK", 0),
-    "select_dense_waves": ("ELO_SELECT_DENSE_WAVES", 0), "random_dense_rows": ("ELO_DENSE_ROWS", 0), "encode1_slots": ("ELO_ENCODE1_SLOTS", 0),
+    "select_dense_waves": ("ELO_SELECT_DENSE_WAVES", 0), "random_dense_rows": ("ELO_DENSE_ROWS", 0),
     "setconv_chain_rows": ("ELO_SETCONV_RR_ROWS", -1), "mlp_chain_rows": ("ELO_MLP_RR_ROWS", -1), "small_tile_units": ("ELO_SMALL_TILE_UNITS", 64),
-    "tiled_setconv": ("ELO_TILED_SETCONV", 0), "pool_wave": ("ELO_POOL_WAVE", 1),
+    "pool_wave": ("ELO_POOL_WAVE", 1),
 }
 
 
-_LIB_BOOLEAN = ("chain_forms", "range_check", "encode1_slots", "pool_wave")
+_LIB_BOOLEAN = ("chain_forms", "narrow_mfma", "range_check", "pool_wave")
 
 
 def _host_from_env():

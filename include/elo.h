@@ -49,7 +49,8 @@ int elo_range_violations(unsigned long long *count, elo_stream_t stream);
  * ORDERING (ABI 23; the contract replaced is the reference's synchronous sess.run(feed_dict=...), main.py:372-381): with
  * order_event != NULL (a hipEvent_t the lane owns) the call records it on `producer` -- the stream whose work so far produced
  * src, or wrote the lane's input buffer in place (0 = the null stream) -- and makes `stream` wait for it before the copy and
- * the graph, so a caller may submit right behind the kernels that fill src.  order_event == NULL: no ordering -- the caller
+ * the graph, so a caller may submit right behind the kernels that fill src (a producer found idle by hipStreamQuery has nothing
+ * to wait for: no event is recorded then).  order_event == NULL: no ordering -- the caller
  * guarantees src (or the in-place input) is complete before `stream` reaches this step (inputs resident and synchronised,
  * or produced on `stream` itself).
  * LIFETIME: the caller keeps src alive until `stream` has run the copy, as with any asynchronous copy (torch: record_stream).
@@ -66,18 +67,14 @@ int elo_graph_submit(void *graph_exec, elo_stream_t stream, void *dst, const voi
  * single-field shorthands for elo_set_tuning. */
 typedef struct elo_tuning {
     int chain_forms;            /* 1: the register-resident ("chain") kernels may be taken, 0: tile kernels only   [ELO_CV1_RR]            */
-    int narrow_mfma;            /* narrow set-conv layers: 0 VALU kernel, 1 matrix cores for 19 -> 16 -> 16 -> 32, 2 for both [ELO_SETCONV_NARROW_MFMA] */
+    int narrow_mfma;            /* narrow set-conv layers: 0 VALU kernel, 1 matrix cores for 19 -> 16 -> 16 -> 32  [ELO_SETCONV_NARROW_MFMA] */
     int range_check;            /* 1: the fused kernels run their operand-range-checked instances (elo_range_check) [ELO_RANGE_CHECK]       */
     int select_dense_waves;     /* elo_fused_conv_select_k_dense: 4 / 8 / 16 waves per tile, 0 = by grid size     [ELO_SELECT_DENSE_WAVES]  */
     int random_dense_rows;      /* elo_fused_conv_random_k_dense: 2 / 4 rows per tile, 0 = by grid size            [ELO_DENSE_ROWS]          */
-    int encode1_slots;          /* elo_cv_encode1: 1 = the slot-indexed kernel also where the column-owner form tiles [ELO_ENCODE1_SLOTS]    */
     long setconv_chain_rows;    /* rows per launch from which elo_setconv_fused2 takes the chain form; -1: 20 000 (below batch
                                    ELO_THROUGHPUT_BATCH: 100 000 until round 5)                                    [ELO_SETCONV_RR_ROWS]     */
     long mlp_chain_rows;        /* ... elo_mlp_fused2; -1: 2048 / 8192                                            [ELO_MLP_RR_ROWS]         */
     long small_tile_units;      /* 16-row tiles while 32-row tiles would give fewer workgroups than this (64)      [ELO_SMALL_TILE_UNITS]    */
-    int tiled_setconv;          /* narrow set-conv layers with structured centres on the LDS-staged window tile: 0 off (default:
-                                   measured slower, profiles/r05_ab_tiled.txt), 1 the 6 -> 8 -> 8 -> 16 layer, 2 also the
-                                   19 -> 16 -> 16 -> 32 layer                                                      [ELO_TILED_SETCONV]       */
     int pool_wave;              /* elo_masked_softmax_pool with C = 64, K <= 32: 1 (default) one WAVE per point, one or two light nontemporal
                                    loads per lane and tensor (HBM-cold streaming: tools/micro/hbm_probe.hip), 0 the quarter-wave form  [ELO_POOL_WAVE] */
 } elo_tuning;
@@ -323,19 +320,12 @@ typedef struct elo_pose_head_args {
      * visiting orders (elo_perm_refresh semantics) once this pose is written -- the NEXT replay of the graph then walks
      * fresh orders without a launch of its own.  next_orders.pool == NULL: no side job. */
     elo_perm_refresh_args next_orders;
-    /* direct != 0: ONE launch less.  softmax_valid is computed by the head launch itself (every workgroup reduces the
-     * npoints rows on its own: 1024 threads, 16 rows of 64 channels per step) instead of by a partial-sums launch in
-     * front of it: for npoints <= ELO_POSE_DIRECT_MAX, C == 64, hidden == 256.  The clear_* buffers are then NOT cleared
-     * by this call -- the caller has had an earlier launch do it (elo_mlp_args.clear_*: the launch that produces
-     * `feature` / `weight`); with elo_pose_head_warp they still name the warp's buffers. */
-    int direct;
     /* ready_parts > 0: the partial sums of softmax_valid are ALREADY in `scratch`, ready_parts slices per batch element, written
      * by the launch that produced `feature` / `weight` (elo_mlp_fused / elo_mlp_fused2 with sv_scratch == scratch;
-     * elo_mlp_sv_parts gives the count): no partial-sums launch here -- one launch less per pyramid level.  As with `direct`
-     * the clear_* buffers are then not cleared by this call (elo_mlp_args.clear_* did it).  Not together with `direct`. */
+     * elo_mlp_sv_parts gives the count): no partial-sums launch here -- one launch less per pyramid level.  The clear_* buffers
+     * are then not cleared by this call (elo_mlp_args.clear_* did it). */
     int ready_parts;
 } elo_pose_head_args;
-#define ELO_POSE_DIRECT_MAX 1024
 int elo_pose_head(const elo_pose_head_args *a, elo_stream_t stream);
 
 /* Pose warp + spherical re-projection.
@@ -539,27 +529,6 @@ typedef struct elo_bn_backward_args {
 } elo_bn_backward_args;
 int elo_bn_backward(const elo_bn_backward_args *a, elo_stream_t stream);
 
-/* The same two passes in TWO launches each instead of three (round 6): a block adds its partial sums with float atomics into one
- * of ELO_BN_REPLICAS replicas of the (2, C) totals -- `acc` / `scratch`: (ELO_BN_REPLICAS, 2, C) floats ZEROED by the caller (one
- * memset per training step over an arena) -- and the consumer kernel totals the replicas in its prologue.
- * elo_bn_forward = the statistics + y = act(gamma * (z - mean) * invstd + beta); mean / invstd (saved for backward) and the moving
- * averages are written by the apply kernel.  elo_bn_backward_acc = elo_bn_backward with `scratch` = the zeroed accumulators.
- * Summation order depends on the run (atomics): results agree with the three-launch forms to fp32 rounding, not bit for bit. */
-#define ELO_BN_REPLICAS 8
-typedef struct elo_bn_forward_args {
-    long rows; int C;
-    const float *z;               /* (rows,C) */
-    float *acc;                   /* (ELO_BN_REPLICAS, 2, C) IN: zeros */
-    float eps, momentum;
-    const float *gamma, *beta;
-    int relu;
-    float *mean, *invstd;         /* (C) OUT */
-    float *running_mean, *running_var;   /* (C) IN/OUT or both NULL */
-    float *y;                     /* (rows,C) OUT (may alias z) */
-} elo_bn_forward_args;
-int elo_bn_forward(const elo_bn_forward_args *a, elo_stream_t stream);
-int elo_bn_backward_acc(const elo_bn_backward_args *a, elo_stream_t stream);
-
 /* dW = x^T g (Cin,Cout row-major), db = column sums of g (or NULL): fp32 operands on v_mfma_f32_16x16x4_f32, fp32
  * accumulation per row slice, slices summed in order.  Any Cin, Cout.
  * scratch: elo_weight_grad_slices(rows, Cin, Cout) * (Cin*Cout + Cout) floats. */
@@ -573,12 +542,6 @@ typedef struct elo_weight_grad_args {
 } elo_weight_grad_args;
 int elo_weight_grad_slices(long rows, int Cin, int Cout);
 int elo_dense_weight_grad(const elo_weight_grad_args *a, elo_stream_t stream);
-/* ONE launch where the row slices are few (elo_weight_grad_atomic(rows, Cin, Cout) == 1: <= ELO_WG_ATOMIC_SLICES slices): every
- * slice ADDS its block into dW / db with float atomics -- dW and db come ZEROED from the caller, scratch may be NULL.  Otherwise
- * (many slices: the big layers) the call is elo_dense_weight_grad's two launches and needs its scratch. */
-#define ELO_WG_ATOMIC_SLICES 128
-int elo_weight_grad_atomic(long rows, int Cin, int Cout);
-int elo_dense_weight_grad_acc(const elo_weight_grad_args *a, elo_stream_t stream);
 
 /* Adam (torch.optim.Adam's arithmetic; the reference trains with tf.train.AdamOptimizer, main.py:171-176) over ONE flat
  * fp32 parameter buffer in one launch: every variable, its gradient and its two moments are views of four buffers of n
@@ -718,19 +681,6 @@ typedef struct elo_setconv_args {
     float *new_xyz;               /* (batch,npoints,3) or NULL              */
     elo_group_spec group;         /* random-k; needs xyz1_grid; centre_hw == NULL: centre n is pixel (n / W, n % W) */
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
-    /* "Layer 0 through the gather" (optional; chain form only, see elo_setconv_chain_form): pre[b,h2,w2,:] = bias +
-     * W_feat . src_feat[b,h2,w2] for EVERY source cell (elo_rowlinear_fused2 with the feature rows of layers[0]); layers[0] is
-     * then the layer's xyz-difference rows only (K == 3, same bias) and a row's accumulators start at pre[its neighbour]
-     * (a masked row: at the bias).  The layer is linear, so this is utils/pointnet_util.py:213-217 / :284-289 with the
-     * feature part of the first 1x1 convolution done once per source point instead of once per gathered row. */
-    const float *pre;             /* (batch,H2,W2,layers[0].N) fp32, or NULL */
-    /* STRUCTURED centres (optional): centre n is the pixel ((n / centre_cols) * centre_stride_h, (n % centre_cols) * centre_stride_w)
-     * of xyz1_grid, npoints == centre_rows * centre_cols -- what model_util.get_selected_idx (model_util.py:296-316) lists for every
-     * down_conv of the model.  centre_cols == 0: unstructured (centre_hw or centre_xyz say where the centres are).  With both
-     * given, centre_hw must list exactly these pixels (precondition, not checked: the contents live on the device); the
-     * narrow set-conv layers then stage the window union of 32 neighbouring centres in LDS (setconv_tiled_kernel). */
-    int centre_stride_h, centre_stride_w;
-    int centre_rows, centre_cols;
 } elo_setconv_args;
 int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream);
 /* two independent jobs of identical shape in ONE launch (b may be NULL): the embedding and the embedding-mask
@@ -762,7 +712,7 @@ typedef struct elo_mlp_args {
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
     /* Optional side job (job 0 of a paired launch only): the launch's workgroups also clear the buffers of an
      * elo_warp_project / elo_pose_head_warp call further down the stream -- elo_pose_head_args.clear_* semantics, for a
-     * pose head run with `direct` (which has no launch of its own left to do it).  clear_scratch == NULL: no side job. */
+     * pose head run with ready_parts (which has no partial-sums launch of its own left to do it).  clear_scratch == NULL: no side job. */
     unsigned *clear_scratch;      /* first clear_cells + 4*clear_images words <- 0x7f7f7f7f */
     float *clear_xyz;             /* clear_cells*3 floats <- 0 */
     void *clear_feat;             /* clear_cells*clear_C elements of feat_dtype <- 0, NULL when clear_C == 0 */
@@ -813,12 +763,6 @@ typedef struct elo_cv1_args {
     void *out;                    /* (batch,npoints,64) feat_dtype */
     elo_group_spec group;         /* select-k of xyz2 around every pixel of xyz1 (npoints == H2*W2, stride 1) */
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
-    /* "Layer 0 through the gather" (optional, both or neither; chain form only, see elo_cv_chain_form): CV_0's feature rows
-     * applied per point -- pre_c[b,n,:] = bias + W_feat1 . feat1[b,n], pre_s[b,h2,w2,:] = W_feat2 . feat2[b,h2,w2] (no bias) --
-     * by elo_rowlinear_fused2; cv0 is then CV_0's geometry rows only (K == 10) and a row starts at pre_c[centre] + mask *
-     * pre_s[neighbour] (utils/pointnet_util.py:62-72 up to the order of three fp32 additions). */
-    const float *pre_c;           /* (batch,npoints,128) fp32, or NULL */
-    const float *pre_s;           /* (batch,H2,W2,128) fp32, or NULL   */
 } elo_cv1_args;
 int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream);
 /* debugging hooks of the register-resident ("chain") kernel forms -- cv1_rr_kernel, cv2_rr_kernel, setconv_rr_kernel,
@@ -833,19 +777,17 @@ int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream);
 int elo_debug_cv1_rr(int on);
 int elo_debug_rr_rows(long setconv_rows, long mlp_rows);
 int elo_debug_rr_launches(unsigned long long *counts4, int reset);
-int elo_debug_rowlinear_launches(unsigned long long *count, int reset);   /* ... and of rowlinear_rr_kernel (elo_rowlinear_fused2) */
 int elo_debug_sv_ride_launches(unsigned long long *count, int reset);     /* ... and of mlp_sv_kernel (elo_mlp_args.sv_*) */
 int elo_debug_chain_pair_launches(unsigned long long *count, int reset);  /* ... and of cv1_setconv_rr_kernel (elo_cv_stage1_setconv_chain) */
 /* the two narrow set-conv layers of the pyramid (6 -> 8 -> 8 -> 16 and 19 -> 16 -> 16 -> 32, K = 32; elo_setconv_fused with
  * elo_dense.w_plain given): 1 = setconv_narrow_kernel, the MLP on the matrix cores, for the 19-channel layer (the default;
- * also ELO_SETCONV_NARROW_MFMA), 2 = for both layers (the 6-channel one is slower that way: measured), 0 =
+ * also ELO_SETCONV_NARROW_MFMA; the 6-channel layer stays on the VALU kernel: slower on the matrix cores, measured), 0 =
  * setconv_small_kernel, the fp32 VALU form, for both (the only one in the fp32-MFMA build), -1 = back to the environment's
  * choice; returns the previous setting.  Results agree to fp32-class rounding. */
 int elo_debug_narrow_mfma(int on);
 /* elo_debug_narrow_launches(counts2, reset): launches of [setconv_narrow_kernel, setconv_small_kernel] since the last reset
- * -- now three: [setconv_narrow_kernel, setconv_small_kernel, setconv_tiled_kernel] --
  * (the oracle test of the matrix-core form asserts through it which kernel produced the tensor) */
-int elo_debug_narrow_launches(unsigned long long *counts3, int reset);
+int elo_debug_narrow_launches(unsigned long long *counts2, int reset);
 /* elo_cv_stage1_fused AND one or two set-conv jobs (elo_setconv_fused / elo_setconv_fused2 semantics, tile-kernel form;
  * jb may be NULL) in ONE launch: the first workgroups of the grid run cost-volume tiles, the rest set-conv tiles.
  * For branches that only share inputs -- the cost volume and the two set-upconvs of a refinement level
@@ -875,36 +817,8 @@ typedef struct elo_cv2_args {
     void *out;                    /* (batch,npoints,64) feat_dtype */
     elo_group_spec group;         /* random-k of xyz1 around every pixel of xyz1 (stride 1) */
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
-    /* "Layer 0 through the gather" (optional, both or neither; chain form only): sum_cost_volume_0's rows of feat1 and of the
-     * grouped cost applied per point -- pre_c[b,n,:] = bias + W_feat1 . feat1[b,n], pre_s[b,n,:] = W_cost . cost[b,n] (no bias);
-     * sum_cost0 is then the layer's xyz-encoding rows only (K == 64) and a row starts at pre_c[centre] + mask *
-     * pre_s[neighbour] (utils/pointnet_util.py:129-133).  `cost` is still read: it is the value the softmax weights. */
-    const float *pre_c;           /* (batch,npoints,128) fp32, or NULL */
-    const float *pre_s;           /* (batch,npoints,128) fp32, or NULL */
 } elo_cv2_args;
 int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream);
-
-/* The per-POINT part of a grouped operator's first layer ("layer 0 through the gather"): out[row,:] = bias + W . src[row,:] for a
- * list of points, 128 fp32 columns, NO activation -- the producer of the pre / pre_c / pre_s fields above.  `layer` holds the
- * rows of the operator's first layer that belong to this source (K == C, N == 128; packed as any elo_dense: the host slices the
- * row-permuted weight, efficientlo-net_amd/fused.py PackedDense.part); layer.relu is ignored.  C in {16, 32, 64}; tensors
- * 16-byte aligned.  elo_rowlinear_fused2 runs two jobs (b may be NULL; rows and C may differ) in ONE launch. */
-typedef struct elo_rowlinear_args {
-    long rows;
-    int C;
-    const void *src;              /* (rows, C) feat_dtype */
-    elo_dense layer;
-    float *out;                   /* (rows, 128) fp32 */
-    int feat_dtype;               /* ELO_F32 / ELO_F16 */
-} elo_rowlinear_args;
-int elo_rowlinear_fused2(const elo_rowlinear_args *a, const elo_rowlinear_args *b, elo_stream_t stream);
-/* 1 when the call would run the register-resident ("chain") kernel -- the only form that takes the pre* fields --, 0 when it
- * would run a tile kernel, negative on invalid arguments.  elo_setconv_chain_form looks at the shapes, the row threshold of
- * the batch regime and the grouping spec of the two jobs (b may be NULL) exactly as elo_setconv_fused2 will (a->pre and the
- * width of layers[0] are not looked at: ask before splitting the layer); elo_cv_chain_form answers for the pre-grouped
- * (idx / mask) calls of elo_cv_stage1_fused / elo_cv_stage2_fused with C feature channels in the given products mode. */
-int elo_setconv_chain_form(const elo_setconv_args *a, const elo_setconv_args *b);
-int elo_cv_chain_form(int C, int products);
 
 #ifdef __cplusplus
 }

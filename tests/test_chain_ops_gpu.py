@@ -206,7 +206,7 @@ def test_narrow_down_conv_on_the_matrix_cores_matches_the_oracle(storage):
     sel_np = O.get_selected_idx(B, 2, 2, oh, ow)
     xyz = t(f1)
     sel = mu.get_selected_idx(xyz, 2, 2, oh, ow)
-    counts = (ctypes.c_ulonglong * 3)()
+    counts = (ctypes.c_ulonglong * 2)()
     try:
         lib.lib().elo_debug_narrow_mfma(1)
         lib.lib().elo_debug_narrow_launches(None, 1)

@@ -378,10 +378,11 @@ def test_dense_select_k_refuses_what_it_cannot_do():
     dict(B=2, H=9, W=70, C=16, cs=(2, 3), win=(5, 9), d=1000.0, mlp=[16, 16, 32], holes=0.0),      # everything in range: the walk stops after one round
     dict(B=1, H=8, W=64, C=3, cs=(2, 2), win=(9, 15), d=0.5, mlp=[8, 8, 16], holes=1.0)])          # an EMPTY cloud: every centre invalid
 @pytest.mark.parametrize("storage", ["f32", "f16"])
-def test_lds_tiled_setconv_grouping_is_bit_exact(case, storage):
-    """setconv_tiled_kernel (round 5: the window union of 32 strided centres staged in LDS, eight lanes per centre walk the
-    visiting order 64 positions per round, hit ranks by an in-group scan): its neighbour indices / masks equal the ORACLE's
-    random-k bit for bit, and its pooled features and new_xyz equal setconv_small_kernel's (the same MLP on the same rows)."""
+def test_narrow_setconv_in_kernel_grouping_is_bit_exact(case, storage):
+    """setconv_small_kernel's in-kernel random-k over STRIDED centres (half a wave per centre, a lane per window slot: the two narrow
+    set-conv layers of the pyramid): its neighbour indices / masks equal the ORACLE's random-k bit for bit on dense, sparse,
+    wrapping and EMPTY clouds.  (Round 5's LDS-staged window form of this kernel, setconv_tiled_kernel, was measured slower and
+    lives in tools/micro/patches/r06_rejected_forms.patch; these are its cases.)"""
     fused, tf_util, pu, mu, synth, tuning, lib = (load_pkg("fused"), load_pkg("tf_util"), load_pkg("pointnet_util"), load_pkg("model_util"),
                                                   load_pkg("synth"), load_pkg("tuning"), load_pkg("_lib"))
     import ctypes
@@ -399,7 +400,6 @@ def test_lds_tiled_setconv_grouping_is_bit_exact(case, storage):
     xyz = t(f1)
     sel = mu.get_selected_idx(xyz, sh, sw, oh, ow)
     centre_hw = pu._centre_hw(sel)
-    assert centre_hw.elo_strided == (sh, sw, oh, ow)
     store = tf_util.VariableStore(dev, seed=2)
     widths = [3 + C] + case["mlp"]
     with tf_util.default_store(store), torch.no_grad():
@@ -412,20 +412,16 @@ def test_lds_tiled_setconv_grouping_is_bit_exact(case, storage):
             g = fused.Grouping(t(perm), [kH, kW], case["d"], want_indices=True)
             out, new_xyz = fused.setconv(xyz, feat_dev, None, None, layers, xyz1_grid=xyz, centre_hw=centre_hw, K=32, group=g)
             return out, new_xyz, g.idx, g.mask
-        counts = (ctypes.c_ulonglong * 3)()
-        with tuning.override(tiled_setconv=0, narrow_mfma=0):
-            small = run()
+        counts = (ctypes.c_ulonglong * 2)()
         lib.lib().elo_debug_narrow_launches(None, 1)
-        with tuning.override(tiled_setconv=2, narrow_mfma=0):
+        with tuning.override(narrow_mfma=0):
             tiled = run()
         lib.lib().elo_debug_narrow_launches(counts, 1)
     torch.cuda.synchronize()
-    assert list(counts) == [0, 0, 1], list(counts)
+    assert list(counts) == [0, 1], list(counts)
     hw = synth.strided_index(B, oh, ow, sh, sw)
     want = G.fused_conv_random_k(f1, f1, hw, perm, H, W, oh * ow, kH, kW, 32, 0, case["d"], 1, 1)
     assert np.array_equal(tiled[2].cpu().numpy(), want[0]) and np.array_equal(tiled[3].cpu().numpy()[..., None], want[3])
-    for a_, b_ in zip(tiled, small):
-        assert a_.dtype == b_.dtype and torch.equal(a_, b_)
     if case["holes"] < 1.0:
         assert 0 < float(want[3].mean()) and float(tiled[0].float().abs().max()) > 0
     else:

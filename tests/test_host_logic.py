@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.lib()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.elo_abi_version() == L.ABI_VERSION == 23
+    assert lib.elo_abi_version() == L.ABI_VERSION == 24
     assert lib.elo_last_error() == b"" or isinstance(lib.elo_last_error(), bytes)
 
 
@@ -266,3 +266,39 @@ def test_the_regime_switches_of_a_forward_are_tuning_values():
     with tuning.override(sv_ride=False):
         assert tuning.digest() != before
     assert tuning.digest() == before
+
+
+def test_kitti_density_profile_of_the_synthetic_scene():
+    """synth.range_image(profile="kitti"): the density of a projected HDL-64 scan after the 35 m crop (kitti_dataset.py:38-103,
+    model_util.py:380-383) -- about half of the grid valid, whole dead beam rows, a sector without returns -- and frame_pair's starved
+    last batch element; the default ("dense") scene is unchanged by the new arguments."""
+    synth = load_pkg("synth")
+    f1, f2 = synth.frame_pair(3, 64, 1800, seed=40, profile="kitti")
+    valid = (f1 != 0).any(-1)
+    assert 0.45 < valid[0].mean() < 0.65 and 0.45 < valid[1].mean() < 0.65
+    assert (valid[0].sum(1) == 0).sum() >= 2                       # dead beam rows
+    assert (valid[0].sum(0) == 0).sum() >= 30                      # the 7-degree sector: 35 columns of 1800
+    assert 1 <= valid[2].sum() <= 6 and 1 <= (f2[2] != 0).any(-1).sum() <= 6       # the starved element
+    r = np.hypot(f1[0][..., 0], f1[0][..., 1])
+    assert r.max() <= 35.0 + 1e-3
+    near, far = valid[0][r < 10].mean() if (r < 10).any() else 1.0, valid[0][(r > 20)].mean()
+    g1, _ = synth.frame_pair(1, 64, 1800, seed=40, profile="kitti", starved=True)
+    assert (g1[0] != 0).any(-1).sum() <= 6
+    d1, d2 = synth.frame_pair(2, 64, 1800, seed=40)
+    assert (d1 != 0).any(-1).mean() > 0.93 and (d1[1] != 0).any(-1).sum() > 100000     # dense default: nobody starves
+    with pytest.raises(ValueError):
+        synth.range_image(profile="nope")
+
+
+def test_bench_ring_helpers_clone_tensors_and_count_bytes():
+    """bench._time_ring's bookkeeping (the COLD roofline reading): tensor arguments are cloned to new addresses, anything else is
+    shared, and the footprint counts every distinct storage once."""
+    import bench
+    a, b = torch.zeros(1000), torch.zeros(10, 10)
+    view = a[:10]
+    args = (a, view, [b, 3], {"k": b, "s": "x"})
+    assert bench._footprint(args, {}, None) == a.numel() * 4 + b.numel() * 4          # `view` shares a's storage, b counted once
+    cl = bench._clone_tensors(args)
+    assert cl[0].data_ptr() != a.data_ptr() and cl[2][0].data_ptr() != b.data_ptr() and cl[2][1] == 3 and cl[3]["s"] == "x"
+    assert torch.equal(cl[0], a) and isinstance(cl[2], list) and isinstance(cl, tuple)
+    assert bench.LLC_BYTES == 256 * 1024 * 1024

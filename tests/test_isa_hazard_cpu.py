@@ -126,3 +126,49 @@ def test_the_experiment_switches_live_in_a_patch_that_still_applies():
     patched = open(out.stdout.strip()).read()
     assert "ELO_RR_WHATIF_HALF_READS" in patched and "#ifndef ELO_NO_MFMA_SHAPE_GUARD" in patched
     shutil.rmtree(os.path.dirname(os.path.dirname(os.path.dirname(out.stdout.strip()))), ignore_errors=True)
+
+
+def test_the_rejected_training_forms_live_in_a_patch_that_still_applies(tmp_path):
+    """Round 6's launch-merged training reductions (replica-accumulator atomics, batch norm's backward-apply inside the weight-gradient
+    kernel, weight gradients on a side stream) were built, tested on the GPU, MEASURED (profiles/r06_training_launch_merging.txt: 336
+    launches fewer, the same 15 ms step) and taken out of csrc/: they are tools/micro/patches/r06_training_launch_merging.patch, which
+    must keep applying to the product tree (and the product must not carry them)."""
+    import shutil
+    import subprocess
+    train = open(os.path.join(ROOT, "efficientlo-net_amd", "csrc", "elo_train.hip")).read()
+    assert "unsafeAtomicAdd" not in train and "bn_stats_acc_kernel" not in train
+    if shutil.which("patch") is None:
+        pytest.skip("no patch(1) here")
+    for d in ("efficientlo-net_amd", "include", "tests"):
+        shutil.copytree(os.path.join(ROOT, d), tmp_path / d, ignore=shutil.ignore_patterns("*.so", "*.o", "build", "__pycache__", "golden"))
+    patch = os.path.join(ROOT, "tools", "micro", "patches", "r06_training_launch_merging.patch")
+    out = subprocess.run(["patch", "-p1", "-s", "-i", patch], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    patched = (tmp_path / "efficientlo-net_amd" / "csrc" / "elo_train.hip").read_text()
+    assert "bn_stats_acc_kernel" in patched and "struct BnFuse" in patched and "elo_dense_bn_backward" in patched
+
+
+def test_the_rejected_kernel_forms_live_in_a_patch_that_still_applies(tmp_path):
+    """Forms that were built, tested, MEASURED slower and therefore taken out of csrc/ in round 6: "layer 0 through the
+    gather" (rowlinear_rr_kernel + the pre forms of the three chain kernels: profiles/r05_layer0_through_the_gather.txt), the LDS-staged
+    narrow set-conv (setconv_tiled_kernel: profiles/r05_ab_tiled.txt), the pose head that reduces softmax_valid itself (direct), the
+    slot-indexed cv_encode1 switch, forked branches, the 6 -> 8 -> 8 -> 16 layer on the matrix cores.  tools/micro/patches/
+    r06_rejected_forms.patch re-creates them (kernels, C ABI, host, tests) on the product tree; the product must not carry them."""
+    import shutil
+    import subprocess
+    fused = open(os.path.join(ROOT, "efficientlo-net_amd", "csrc", "elo_fused.hip")).read()
+    for gone in ("rowlinear_rr_kernel", "setconv_tiled_kernel", "pre_c", "tiled_setconv"):
+        assert gone not in fused, gone
+    assert fused.count("\n") < 3700
+    header = open(os.path.join(ROOT, "include", "elo.h")).read()
+    for gone in ("elo_rowlinear_fused2", "encode1_slots", "tiled_setconv", "ELO_POSE_DIRECT_MAX", "centre_cols"):
+        assert gone not in header, gone
+    if shutil.which("patch") is None:
+        pytest.skip("no patch(1) here")
+    for d in ("efficientlo-net_amd", "include", "tests"):
+        shutil.copytree(os.path.join(ROOT, d), tmp_path / d, ignore=shutil.ignore_patterns("*.so", "*.o", "build", "__pycache__", "golden"))
+    patch = os.path.join(ROOT, "tools", "micro", "patches", "r06_rejected_forms.patch")
+    out = subprocess.run(["patch", "-p1", "-s", "-i", patch], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    patched = (tmp_path / "efficientlo-net_amd" / "csrc" / "elo_fused.hip").read_text()
+    assert "rowlinear_rr_kernel" in patched and "setconv_tiled_kernel" in patched and "bool PRE = false" in patched

@@ -377,7 +377,7 @@ def test_a_graph_captured_under_one_tuning_refuses_to_replay_under_another():
     net.capture(B, 64, 900, lanes=1)
     first = [x.clone() for x in net(a, b)]
     assert net.captured_tuning["lib"]["chain_forms"] == 1 and net.captured_tuning["cv_prepass"] is None
-    for fields in (dict(cv_prepass=0), dict(chain_forms=0), dict(layer0_pre={"setconv": 0})):
+    for fields in (dict(cv_prepass=0), dict(chain_forms=0), dict(merge_points=1)):
         with tuning.override(**fields):
             with pytest.raises(RuntimeError, match="the tuning changed"):
                 net.replay()

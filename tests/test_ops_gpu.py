@@ -323,8 +323,15 @@ def test_cost_volume_kernels_with_fp16_storage(B, H, W, C):
         lg, vl = h(B, N, K, 64) * 3, h(B, N, K, 64)
         p16 = ops.masked_softmax_pool(lg, vl, mask)
         p32 = ops.masked_softmax_pool(lg.float(), vl.float(), mask)
-        # same fp32 arithmetic on the same (fp16-representable) inputs: the fp16 result is the fp32 one rounded once
-        assert p16.dtype == torch.float16 and torch.equal(p16, p32.half())
+        # fp32 arithmetic on the same (fp16-representable) inputs: the fp16 result is the fp32 one rounded once -- up to the ORDER of
+        # the K additions, which follows the storage type's lane layout in the wave-per-point kernel (4 lane groups in fp32, 8 in fp16:
+        # round 6): the two fp32 sums differ in their last bit now and then, and now and then that decides an fp16 rounding
+        assert p16.dtype == torch.float16
+        same = p16 == p32.half()
+        assert float(same.float().mean()) > 0.995
+        assert ((p16.float() - p32).abs() <= 2.0 ** -10 * p32.abs() + 1e-7).all()            # never more than one fp16 ulp apart
+        with load_pkg("tuning").override(pool_wave=0):                                        # the quarter-wave form: one layout, equal bits
+            assert torch.equal(ops.masked_softmax_pool(lg, vl, mask), ops.masked_softmax_pool(lg.float(), vl.float(), mask).half())
         wide = h(B, N, K, 128)                               # values as a channel slice of a wider tensor (stride 128)
         assert torch.allclose(ops.masked_softmax_pool(lg, wide[..., :64], mask).float(),
                               ops.masked_softmax_pool(lg.float(), wide[..., :64].float().contiguous(), mask),
@@ -603,13 +610,7 @@ def test_register_resident_cost_volume_equals_the_tile_kernel(kernel_path, B, H,
             lib.lib().elo_debug_cv1_rr(0)
             tile = run()
             lib.lib().elo_debug_cv1_rr(1)
-            with fused.layer0_pre({}):                               # the whole of CV_0 per row: the tile kernel's sums in its order
-                rr = run()
-            lib.lib().elo_debug_rowlinear_launches(None, 1)
-            with fused.layer0_pre({"cv1": 0}):                       # round 5: CV_0's feature rows once per point (rowlinear_rr_kernel)
-                pre = run()
-            n_pre = ctypes.c_ulonglong(0)
-            lib.lib().elo_debug_rowlinear_launches(ctypes.byref(n_pre), 1)
+            rr = run()                                               # the whole of CV_0 per row: the tile kernel's sums in its order
         finally:
             lib.lib().elo_debug_cv1_rr(-1)
         own = fused.cv_stage1(t(f1).reshape(B, N, 3), t(fa).reshape(B, N, C), t(f2), t(fb), None, None, *layers,
@@ -618,25 +619,6 @@ def test_register_resident_cost_volume_equals_the_tile_kernel(kernel_path, B, H,
     assert rr.dtype == tile.dtype and torch.isfinite(rr.float()).all()
     assert torch.equal(rr, tile) and torch.equal(rr, own)
     assert m.mean() > 0.5 and m.min() == 0                           # masked slots are in the mix
-    assert n_pre.value == 1 and pre.dtype == tile.dtype
-    _same_up_to_summation_order(pre, tile, features, chain_products)
-
-
-def _same_up_to_summation_order(pre, ref, features, products):
-    """"Layer 0 through the gather" regroups three fp32 additions of the first layer (b + W_c f_c + W_s f_s + W_g g): the
-    operator's output moves by fp32 rounding of that layer carried through the chain -- 1e-5 of the value scale in the
-    fp32-class products mode (measured ~1e-6), a rounding boundary of the stored half now and then in fp16 storage; the
-    one-product mode rounds every layer's operands to fp16, so a last-place difference can flip such a rounding: 2e-3."""
-    a_, b_ = pre.float(), ref.float()
-    scale = float(b_.abs().max())
-    assert scale > 0 and torch.isfinite(a_).all()
-    worst = float((a_ - b_).abs().max())
-    if products == "half":
-        assert worst <= 2e-3 * scale, worst
-    elif features == "f32":
-        assert worst <= 1e-5 * scale, worst
-    else:
-        assert worst <= 2.0 ** -10 * scale and float((a_ != b_).float().mean()) < 0.02, worst
 
 
 @pytest.mark.parametrize("B,H,W,C,features", [(2, 16, 225, 16, "f32"), (1, 8, 113, 32, "f32"), (3, 4, 57, 64, "f32"), (2, 16, 225, 16, "f16"),
@@ -671,13 +653,7 @@ def test_register_resident_cost_volume_stage2_equals_the_tile_kernel(kernel_path
             lib.lib().elo_debug_cv1_rr(0)
             tile = run()
             lib.lib().elo_debug_cv1_rr(1)
-            with fused.layer0_pre({}):
-                rr = run()
-            lib.lib().elo_debug_rowlinear_launches(None, 1)
-            with fused.layer0_pre({"cv2": 0}):                       # round 5: sum_cost_volume_0's feat1 / cost rows once per point
-                pre = run()
-            n_pre = ctypes.c_ulonglong(0)
-            lib.lib().elo_debug_rowlinear_launches(ctypes.byref(n_pre), 1)
+            rr = run()
         finally:
             lib.lib().elo_debug_cv1_rr(-1)
         own = fused.cv_stage2(t(f1), t(fa), t(cost), None, None, *layers, group=fused.Grouping(t(perm), [3, 5], 2.0), K=K)
@@ -685,8 +661,6 @@ def test_register_resident_cost_volume_stage2_equals_the_tile_kernel(kernel_path
     assert rr.dtype == tile.dtype and torch.isfinite(rr.float()).all()
     assert torch.equal(rr, tile) and torch.equal(rr, own)
     assert 0.3 < m.mean() and m.min() == 0
-    assert n_pre.value == 1 and pre.dtype == tile.dtype
-    _same_up_to_summation_order(pre, tile, features, chain_products)
 
 
 @pytest.mark.parametrize("case", [dict(B=2, H=16, W=225, sh=2, sw=2, K=8, mlp=[128, 64], win=(7, 15), d=3.0, feat="f32", pair=True),    # set-upconv l0 <- l1
@@ -748,64 +722,23 @@ def test_register_resident_setconv_equals_the_tile_kernel(kernel_path, case, mon
             lib.lib().elo_debug_cv1_rr(1)
             lib.lib().elo_debug_rr_rows(0, -1)
             lib.lib().elo_debug_rr_launches(None, 1)
-            with fused.layer0_pre({}):
-                rr = run()
+            rr = run()
             counts = (ctypes.c_ulonglong * 4)()
             lib.lib().elo_debug_rr_launches(counts, 1)
             assert counts[2] == 1, "the chain kernel is the one under test"
-            # round 5, "layer 0 through the gather": the feature rows of layer 0 once per SOURCE cell (rowlinear_rr_kernel), the
-            # chain kernel continues those accumulators with the xyz rows -- the same products in the same order: the same bits
-            lib.lib().elo_debug_rowlinear_launches(None, 1)
-            with fused.layer0_pre({"setconv": 0}):
-                pre = run()
-            n_pre = ctypes.c_ulonglong(0)
-            lib.lib().elo_debug_rowlinear_launches(ctypes.byref(n_pre), 1)
-            lib.lib().elo_debug_rr_launches(counts, 1)
-            assert counts[2] == 1 and n_pre.value == (1 if case["mlp"] == [128, 64] else 0), (list(counts), n_pre.value)
         finally:
             lib.lib().elo_debug_cv1_rr(-1)
             lib.lib().elo_debug_rr_rows(-1, -1)
     torch.cuda.synchronize()
-    for a_, b_, c_ in zip(rr, tile, pre):
+    for a_, b_ in zip(rr, tile):
         assert a_.dtype == b_.dtype and torch.equal(a_, b_)
-        assert c_.dtype == b_.dtype and torch.equal(c_, b_)
     assert float(rr[0].float().abs().max()) > 0
 
 
-@pytest.mark.parametrize("features", ["f32", "f16"])
-@pytest.mark.parametrize("jobs", [[(16, 700)], [(32, 1000), (32, 129)], [(64, 384), (64, 384)], [(16, 3600), (64, 3600)], [(32, 904), (64, 1)]])
-def test_rowlinear_is_the_layer_without_activation(kernel_path, jobs, features, chain_products):
-    """elo_rowlinear_fused2 (rowlinear_rr_kernel): out[row] = bias + W . src[row], 128 fp32 columns, NO activation -- against
-    a float64 product of the same (fp16-representable in fp16 storage) inputs: fp32-class accuracy in the split mode, one
-    fp16 rounding of every operand in the one-product mode; one and two jobs, different row counts and widths, ragged tiles."""
-    if kernel_path != "fused":
-        pytest.skip("fused kernels only")
-    fused, tf_util = load_pkg("fused"), load_pkg("tf_util")
-    rng = np.random.default_rng(sum(c + r for c, r in jobs))
-    store = tf_util.VariableStore(DEV, seed=11)
-    tdt = torch.float16 if features == "f16" else torch.float32
-    srcs, layers = [], []
-    with tf_util.default_store(store), torch.no_grad():
-        for j, (C, rows) in enumerate(jobs):
-            whole = fused.packed_layer("rl%d_%d" % (j, C), C + 16, 128, row_order=list(range(16, 16 + C)) + list(range(16)))
-            whole.b.copy_(torch.from_numpy(rng.normal(0, 0.5, whole.b.shape).astype(np.float32)))
-            layers.append(whole.part(0, C))                       # the rows of "this source", as the operators slice them
-            srcs.append(t(rng.normal(0, 1, (rows, C)).astype(np.float32)).to(tdt))
-        outs = fused.rowlinear(list(zip(srcs, layers)))
-    torch.cuda.synchronize()
-    for (C, rows), src, layer, out in zip(jobs, srcs, layers, outs):
-        assert out.shape == (rows, 128) and out.dtype == torch.float32
-        W = layer._rows.double().cpu().numpy()
-        want = src.double().cpu().numpy() @ W + layer.b[:128].double().cpu().numpy()
-        err = np.abs(out.double().cpu().numpy() - want).max()
-        tol = (3e-3 if chain_products == "half" else 2e-6) * max(1.0, np.abs(want).max())
-        assert err <= tol, (C, rows, err)
-
-
-@pytest.mark.parametrize("B,H,W,C,ks,dist,mlp,feat", [(1, 64, 450, 3, [9, 15], 0.5, [8, 8, 16], "f32"), (3, 16, 225, 16, [7, 11], 3.0, [16, 16, 32], "f32"),
-                                                      (2, 16, 113, 16, [7, 11], 3.0, [16, 16, 32], "f16"), (5, 6, 21, 3, [9, 15], 2.0, [8, 8, 16], "f16")])
+@pytest.mark.parametrize("B,H,W,C,ks,dist,mlp,feat", [(3, 16, 225, 16, [7, 11], 3.0, [16, 16, 32], "f32"), (2, 16, 113, 16, [7, 11], 3.0, [16, 16, 32], "f16"),
+                                                      (5, 7, 21, 16, [7, 11], 2.0, [16, 16, 32], "f16")])
 def test_narrow_setconv_on_the_matrix_cores_equals_the_valu_kernel(kernel_path, B, H, W, C, ks, dist, mlp, feat):
-    """setconv_narrow_kernel (round 4: the MLP of the two narrow set-conv layers as 16-row MFMA blocks, weights built into
+    """setconv_narrow_kernel (round 4: the MLP of the 19 -> 16 -> 16 -> 32 set-conv layer as 16-row MFMA blocks, weights built into
     fragments in-kernel) against setconv_small_kernel (fp32 FMAs, a lane per row): the same grouping (new_xyz equal bit for
     bit), the pooled features equal to fp32-class rounding (2e-6 of the value scale; in fp16 storage the same stored half
     but for rounding boundaries), ragged centre counts (not a multiple of the 8 centres of a workgroup), fp32 / fp16 storage."""
@@ -825,7 +758,7 @@ def test_narrow_setconv_on_the_matrix_cores_equals_the_valu_kernel(kernel_path, 
     try:
         lib.lib().elo_debug_narrow_mfma(0)
         valu = _run(run, store, perms)
-        lib.lib().elo_debug_narrow_mfma(2)
+        lib.lib().elo_debug_narrow_mfma(1)
         with load_pkg("tf_util").default_store(store), load_pkg("perm").default_perm_source(perms), torch.no_grad():
             mfma = run()
     finally:

@@ -97,34 +97,18 @@ def test_pose_head_and_composition_match_the_oracle(coarse):
         got = ops.warp_project(t(pc), t(pf), q2, t2, H, W, buffers=buf)
         assert torch.equal(got[0], want_proj[0]) and torch.equal(got[1], want_proj[1])
         assert torch.allclose(got[2], want_proj[2], atol=1e-4)
-    # direct (elo_pose_head_args.direct): the head launch reduces softmax_valid itself -- other summation order, same
-    # bound against the oracle -- and the buffers are cleared by a row-wise MLP launch (elo_mlp_args.clear_*) in front of it
+    # elo_mlp_args.clear_*: a row-wise MLP launch clears the projection buffers on the side (for a pose head that is handed the partial
+    # sums of softmax_valid and has no partial-sums launch of its own left to do it: tests/test_sv_ride_gpu.py) -- same rows, buffers cleared
     fused = load_pkg("fused")
     for dt in (torch.float32, torch.float16):
         a16 = tuple(x.to(dt) for x in args[:2]) + args[2:]
-        qd, td, qnd = ops.pose_head(*a16, direct=True, **kw)
-        if dt == torch.float32:
-            want3 = (want_q, want_t, O.normalise_q(want_q))
-        else:                                                        # fp16 storage: the two-launch form on the same rounded inputs
-            want3 = tuple(x.cpu().numpy() for x in ops.pose_head(*a16, **kw))
-        for got, want in zip((qd, td, qnd), want3):
-            close(got, want, atol=2e-5, rtol=1e-4)
-        want_proj = ops.warp_project(t(pc), t(pf).to(dt), qd, td, H, W)
         buf = ops.ProjectionBuffers(B, H * W, H, W, Cf, DEV, dt)
         buf.out_xyz.fill_(float("nan")); buf.out_feat.fill_(3.0); buf.scratch.fill_(-1)
-        with pytest.raises(ValueError, match="cleared by an earlier launch"):
-            ops.pose_head(*a16, clear=buf, warp=(t(pc), t(pf).to(dt)), direct=True, **kw)
         layer = fused.PackedDense(t(rng.normal(0, 0.1, (C, 32)).astype(np.float32)), t(np.zeros(32, np.float32)), True)
         plain_rows = fused.mlp([a16[0]], [layer])
         assert torch.equal(fused.mlp([a16[0]], [layer], clear=buf), plain_rows) and buf.cleared
-        q2, t2, qn2 = ops.pose_head(*a16, clear=buf, warp=(t(pc), t(pf).to(dt)), direct=True, **kw)
-        assert torch.equal(q2, qd) and torch.equal(t2, td) and torch.equal(qn2, qnd)
-        got = ops.warp_project(t(pc), t(pf).to(dt), q2, t2, H, W, buffers=buf)
-        assert torch.equal(got[0], want_proj[0]) and torch.equal(got[1], want_proj[1])
-        assert torch.allclose(got[2].float(), want_proj[2].float(), atol=1e-4 if dt == torch.float32 else 2e-2)
-    with pytest.raises(RuntimeError, match="direct takes"):
-        big = tuple(torch.cat([x] * 5, 1) for x in args[:3]) + args[3:]
-        ops.pose_head(*big, direct=True, **kw)
+        torch.cuda.synchronize()
+        assert float(buf.out_xyz.abs().max()) == 0 and float(buf.out_feat.float().abs().max()) == 0
 
 
 def test_range_check_flags_operands_beyond_fp16():

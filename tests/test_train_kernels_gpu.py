@@ -13,15 +13,6 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(autouse=True, params=["atomics", "three-launch"])
-def reduction_form(request):
-    """Every test runs on both forms of the layer's reductions: per-block partials added into zeroed replica accumulators and
-    totalled in the consumer's prologue (round 6: elo_bn_forward / elo_bn_backward_acc / elo_dense_weight_grad_acc, the default)
-    and partials + a combine launch (elo_bn_stats / elo_bn_backward / elo_dense_weight_grad)."""
-    with load_pkg("tuning").override(train_atomics=request.param == "atomics"):
-        yield request.param
-
-
 def _reference(x, W, b, gamma, beta, rm, rv, momentum, eps, relu, gy, mask):
     """`mask`: the ReLU decisions of the fp32 forward (y > 0).  The float64 reference uses THE SAME decisions: among
     millions of pre-activations one lies within fp32 rounding of zero now and then, and a reference that decides it the

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS tools/micro/patches/r06_rejected_forms.patch applied to the tree (the form measured here was taken out of csrc/ in round 6).
 # A/B of "layer 0 through the gather" (round 5; fused.layer0_pre / ELO_LAYER0_PRE): batch 8 through 8 lanes, fp16 and fp32 feature
 # storage, with the first layer of (a) no operator, (b) the set-upconvs, (c) + cost-volume stage 2, (d) + stage 1 from 32 channels,
 # (e) + stage 1 at every level commuted with the gather.  Three alternating rounds (the pool's boxes drift by ~1 %).

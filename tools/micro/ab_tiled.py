@@ -1,4 +1,5 @@
-"""A/B of the narrow set-conv forms (round 5): setconv_small_kernel (half a wave per centre walks its window from L2), setconv_narrow_kernel
+"""NEEDS tools/micro/patches/r06_rejected_forms.patch applied to the tree (setconv_tiled_kernel was taken out of csrc/ in round 6).
+A/B of the narrow set-conv forms (round 5): setconv_small_kernel (half a wave per centre walks its window from L2), setconv_narrow_kernel
 (the same walk, MLP on the matrix cores) and setconv_tiled_kernel (window union of 32 centres in LDS, eight lanes per centre) on the two
 narrow layers of the pyramid at their batch-8 sizes (the Siamese pyramid runs both frames as one batch of 16 images):
     python tools/ab_tiled.py [--batch 16]"""

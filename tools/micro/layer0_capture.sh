@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS tools/micro/patches/r06_rejected_forms.patch applied to the tree (the form measured here was taken out of csrc/ in round 6).
 # Per-kernel evidence for "layer 0 through the gather" (round 5): the batch-8, fp16-storage forward (bench.py --batch 8 --features
 # f16 --no-legs --lanes 1) under rocprofv3 --kernel-trace, and FETCH_SIZE / WRITE_SIZE in passes of their own, for three settings
 # of ELO_LAYER0_PRE: none, the set-upconvs, every grouped operator.   usage (GPU box): bash tools/layer0_capture.sh gpurun_out/r05/layer0

@@ -16,11 +16,17 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     tr.step(a, b, q, t); torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0])
+buckets = collections.OrderedDict((k, [0, 0.0]) for k in (6, 12, 25, 50, 100, 1e9))
 for e in prof.events():
     if e.device_type == torch.autograd.DeviceType.CUDA:
         agg[e.name[:90]][0] += 1; agg[e.name[:90]][1] += e.device_time
+        for k in buckets:
+            if e.device_time < k:
+                buckets[k][0] += 1; buckets[k][1] += e.device_time
+                break
 tot = sum(v[1] for v in agg.values()); n = sum(v[0] for v in agg.values())
 print("batch %d: %d launches, %.2f ms of GPU time" % (B, n, tot / 1e3))
+print("by duration: " + "  ".join("<%s us: %d launches %.2f ms" % ("%g" % k if k < 1e9 else "inf", v[0], v[1] / 1e3) for k, v in buckets.items()))
 by_count = "--by-count" in sys.argv
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0 if by_count else 1])[:200 if by_count else 30]:
     print("%6.2f ms %5.1f%% x%-5d %s" % (v[1] / 1e3, 100 * v[1] / tot, v[0], k))
