@@ -195,7 +195,9 @@ inline FastDiv fast_div(unsigned d) { return FastDiv{d <= 1 ? 0u : (unsigned)((0
 
 // rows per workgroup: 64 keeps small launches spread over the CUs, 128 amortises the row-facts phase when there are
 // several rounds of workgroups per CU anyway (measured at l0: B=8 10.6 vs 11.4 us, B=64 83 vs 71 us)
-inline int enc_rows(long rows) { return rows > 512 * 1024 ? 128 : 64; }
+// rows per workgroup of the encode kernels: small calls take small workgroups (a 24 576-row l2 call is 384 workgroups of 64 rows on 256 CUs:
+// 8.0 us; 768 of 32: 6.2 us -- round 6)
+inline int enc_rows(long rows) { return rows > 512 * 1024 ? 128 : rows >= 64 * 1024 ? 64 : 32; }
 
 template <int ENC_ROWS>
 struct RowFacts {
@@ -231,7 +233,8 @@ __device__ __forceinline__ void resolve_rows(RowFacts<ENC_ROWS> &rf, long first,
 
 // Outputs of the encode / pool kernels are written once and read by a later launch: non-temporal stores keep them from
 // allocating in L2 on the way out (measured at l0: A1 9.5 -> 8.4 us at B=8 and 70 -> 53 us at B=64, A2 99 -> 61 us at
-// B=64).  Non-temporal LOADS of the pool's inputs were mixed (P1 B=8 15.8 -> 17.1 us, P2 11.9 -> 10.4) and are not used.
+// B=64).  Non-temporal LOADS of the pool's inputs were mixed on Infinity-Cache-resident tensors (P1 B=8 15.8 -> 17.1 us, P2 11.9 -> 10.4:
+// round 2); round 6 measured them HBM-COLD, where they pay, and uses them (softmax_pool_vec_kernel<.., NT>, softmax_pool_wave_kernel).
 #define STREAM_STORE(v, p) __builtin_nontemporal_store(v, p)
 
 constexpr int ENC_UNROLL = 3;                        // slots in flight per thread
@@ -342,6 +345,74 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_col_kernel(const elo_cv_
     }
 }
 
+#ifndef ELO_ENCODE1_PAIRS
+#define ELO_ENCODE1_PAIRS 1                          // (0: an A/B build without the pair form)
+#endif
+// Pair form of the column-owner kernel (round 6): TWO consecutive rows are one "super-row" of 2 * (5 + C) two-element slots = (5 + C)
+// FOUR-element slots, and a thread owns one four-element slot column: its two halves are loop-invariant (row parity, column) pairs --
+// the first (5 + C) two-element slots of a super-row are its even row, the rest its odd row; with an odd 5 + C one thread straddles the
+// rows -- so a store is 16 bytes in fp32 and 8 in fp16 storage instead of 8 / 4, contiguous over the wave (a super-row starts on a
+// 16- / 8-byte boundary because rows are taken from an even first row), half the store instructions and half the trips of the
+// column-owner form for the same two gathers per trip.  rows and span are even.
+template <int ENC_ROWS, class T>
+__global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_pair_kernel(const elo_cv_encode1_args a, const long rows,
+                                                                    const FastDiv by_slots, const FastDiv by_K,
+                                                                    const int spi, const int span)
+{
+    typedef typename Store<T>::V2 V2;
+    typedef typename Store<T>::V4 V4;
+    __shared__ RowFacts<ENC_ROWS> rf;
+    const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * span;
+    if (first >= rows) return;
+    const int C = a.C, HC = C >> 1, HP = 5 + C;
+    const int nrows = (int)(rows - first < span ? rows - first : span);
+    const long bn0 = point_batch(first, a.K);
+    const unsigned rem0 = (unsigned)(first - bn0 * a.K);
+    resolve_rows(rf, first, nrows, bn0, rem0, by_K, a.idx, a.mask, a.xyz1, a.xyz2, a.H2, a.W2);
+    const int sr0 = (int)by_slots(threadIdx.x), jj = (int)threadIdx.x - sr0 * HP;    // super-row of the trip, four-element column
+    if (sr0 >= spi) return;                          // the 256 % (5 + C) lanes over
+    int par[2], g2[2];
+    bool geo[2], own[2];
+    const T *src[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int sl = 2 * jj + e;                   // two-element slot of the super-row
+        par[e] = sl >= HP;
+        const int j = sl - par[e] * HP;
+        geo[e] = j < 5; own[e] = j < 5 + HC;
+        src[e] = own[e] ? static_cast<const T *>(a.feat1) + (geo[e] ? 0 : 2 * (j - 5))
+                        : static_cast<const T *>(a.feat2) + 2 * (j - 5 - HC);
+        g2[e] = geo[e] ? 2 * j : 0;
+    }
+    V4 *__restrict__ out = reinterpret_cast<V4 *>(static_cast<T *>(a.out) + first * (2 * HP)) + threadIdx.x;
+    const int step = spi * HP, nsr = nrows >> 1;
+    for (int s = sr0; s < nsr; s += spi * ENC_BATCH, out += step * ENC_BATCH) {
+        V2 f[ENC_BATCH][2];
+        int lr[ENC_BATCH][2];
+#pragma unroll
+        for (int u = 0; u < ENC_BATCH; ++u)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int su = s + u * spi < nsr ? s + u * spi : nsr - 1;           // clamped (last workgroup only)
+                lr[u][e] = 2 * su + par[e];
+                const long from = own[e] ? bn0 + by_K(rem0 + lr[u][e]) : rf.cell[lr[u][e]];
+                f[u][e] = *reinterpret_cast<const V2 *>(src[e] + from * C);
+            }
+#pragma unroll
+        for (int u = 0; u < ENC_BATCH; ++u) {
+            V4 v;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float sc = own[e] ? 1.0f : rf.mask[lr[u][e]];
+                const float2 gv = *reinterpret_cast<const float2 *>(&rf.geo[lr[u][e]][g2[e]]);
+                v[2 * e] = (T)(geo[e] ? gv.x : (float)f[u][e].x * sc);
+                v[2 * e + 1] = (T)(geo[e] ? gv.y : (float)f[u][e].y * sc);
+            }
+            if (s + u * spi < nsr) STREAM_STORE(v, &out[u * step]);
+        }
+    }
+}
+
 // Stage 2 has two outputs: xyz_cat rows of 10 elements (two-element slots, straight from the row facts) and rest
 // rows of C + Cc elements in 16-byte slots (4 floats / 8 halves: C and Cc multiples of that).
 template <int ENC_ROWS, class T>
@@ -392,7 +463,10 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_vec_kernel(const elo_cv_
 // point, so a wave streams 4 points' K x C logits and values with 16-byte (fp32) / 8-byte (fp16) loads -- every load
 // instruction of the wave covers four full rows -- in ONE pass (online softmax, fp32 arithmetic) and writes 4 channels
 // per lane.
-template <class T, int U>                           // U neighbour rows in flight per lane (6 when K is a multiple of 6, else 4)
+// NT (fp16 storage since round 6): the inputs are read once -- nontemporal loads, measured HBM-cold at the 128 x 2048 l0 shape, batch 8:
+// P1 23.9 -> 22.3 us, P2 17.6 -> 15.6 (0.58 -> 0.62, 0.54 -> 0.61 of 8 TB/s); on ONE Infinity-Cache-resident set 19.2 -> 20.2 / 14.3 -> 14.5
+// (gpurun_out/r06/cold_sweep_f16_e*.txt).  fp32 storage takes the wave-per-point form below.
+template <class T, int U, bool NT = false>          // U neighbour rows in flight per lane (6 when K is a multiple of 6, else 4); NT: nontemporal loads
 __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_vec_kernel(const elo_softmax_pool_args a, const long rows)
 {
     typedef typename Store<T>::V4 V4;
@@ -416,8 +490,8 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_vec_kernel(const elo_s
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = k0 + u < a.K ? k0 + u : a.K - 1;
-            l4[u] = lg[(long)k * lstep];
-            v4[u] = vl[(long)k * vstep];
+            l4[u] = NT ? __builtin_nontemporal_load(lg + (long)k * lstep) : lg[(long)k * lstep];
+            v4[u] = NT ? __builtin_nontemporal_load(vl + (long)k * vstep) : vl[(long)k * vstep];
             mk[u] = m[k];
         }
 #pragma unroll
@@ -448,8 +522,8 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_vec_kernel(const elo_s
 // HBM-cold data (one-shot, 8 loads per thread), where one light load per thread reaches 0.81.  Here every lane moves 16 bytes per
 // load and a point's K neighbour rows are spread over FOUR lane groups: a 64-channel row is LPR = 64 / E lanes wide (E = 4 floats or 8
 // halves per 16 bytes), lane group g owns the neighbours k = g, g + 4, g + 8, ... (K = 6: two loads per tensor and lane, K = 4: one),
-// a point takes 4 * LPR lanes -- the whole wave in fp32, HALF a wave in fp16 storage (two points per wave: a wave per point there
-// was instruction-bound, 52 us where the quarter-wave form took 23).  Four times as many, that much lighter waves.  Two-pass softmax
+// a point takes 4 * LPR lanes -- the whole wave in fp32, half a wave in fp16 storage.  LAUNCHED FOR FP32 ONLY: in fp16 a point is 768
+// bytes per tensor and the form is instruction-bound (a wave per point 52 us, two points per wave 31.9 us, the quarter-wave form 23.5).  Four times as many, that much lighter waves.  Two-pass softmax
 // exactly as written in the reference (max over K, exponentials against it, sum): the per-lane maxima and sums meet through two
 // butterfly steps across the lane groups (bfly: DPP / v_permlane*_swap, no LDS).  Loads are nontemporal (every byte is read once).
 // Same arithmetic contract as the quarter-wave form (fp32 arithmetic, hardware exp2).  Measured HBM-cold at the 128 x 2048 l0 shape,
@@ -777,6 +851,17 @@ __device__ __forceinline__ void normalise_q(const float *q, float *o)
     for (int i = 0; i < 4; ++i) o[i] = q[i] / n;
 }
 
+// -DELO_POSE_CLOCK (a debugging build, tools/pose_clock.sh): thread 0 of workgroup (0, 0) of pose_head_kernel stamps the shader clock at
+// its phase boundaries (elo_debug_pose_clock reads the stamps): where the 8-12 us of the smallest launch of a forward go.
+#ifdef ELO_POSE_CLOCK
+__device__ unsigned long long g_pose_clock[4 * 8 + 1];         // [launch % 4][stamp], [32]: launches so far (a forward has four pose heads)
+#define POSE_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                                    \
+        if ((i) == 0) pose_slot = (int)(g_pose_clock[32]++ % 4);                                                          \
+        g_pose_clock[pose_slot * 8 + (i)] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define POSE_STAMP(i) do { } while (0)
+#endif
+
 // grid (X, batch).  X = 1: the plain pose head.  X > 1 (elo_pose_head_warp): every block of a batch element computes the
 // same head redundantly -- identical instructions on identical inputs, a few microseconds -- block 0 stores it, and
 // then each block warps its 256 points of the NEXT level's cloud by that pose and does pass A of the projection:
@@ -789,6 +874,10 @@ __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_ar
     float *feat = sm, *big = sm + a.C, *head = big + a.hidden;
     const int b = blockIdx.y, tid = threadIdx.x;
     const SvPartials s = sv_partials(a.scratch, gridDim.y, a.C);
+#ifdef ELO_POSE_CLOCK
+    int pose_slot = 0;
+#endif
+    POSE_STAMP(0);                                     // first instruction of the workgroup
     // The model's head (C = 64, hidden = 256 = one unit per thread): this thread's column of W_big and its rows of
     // W_q / W_t do not depend on anything computed here -- requested now, they arrive while the slices are merged
     // (otherwise four dependent batches of 16 loads sit between the merge and the heads).
@@ -838,6 +927,7 @@ __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_ar
         if (parts <= 64) trips(std::integral_constant<int, 16>());
         else trips(std::integral_constant<int, 32>());
     }
+    POSE_STAMP(1);                                     // this thread's slices merged (the partial sums have landed)
     mpart[(0 * 4 + q) * 64 + c] = M; mpart[(1 * 4 + q) * 64 + c] = D; mpart[(2 * 4 + q) * 64 + c] = A;
     __syncthreads();
     if (tid < 64) {
@@ -854,6 +944,7 @@ __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_ar
     for (int c2 = 64 + tid; c2 < a.C; c2 += blockDim.x) feat[c2] = sv_merge(s, b, c2, a.C, parts);   // C > 64 (not the model)
 
     __syncthreads();
+    POSE_STAMP(2);                                         // softmax_valid's (C) vector is in LDS
     if (model_head) {                                      // conv1d C -> hidden, no activation (:197), same summation order
         float v = bias_big;
 #pragma unroll
@@ -868,6 +959,7 @@ __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_ar
         }
     }
     __syncthreads();
+    POSE_STAMP(3);                                         // hidden layer done (the W_big column was requested at the top)
     {   // conv1d hidden -> 4 (q) and hidden -> 3 (t): 7 dot products over `hidden`, reduced wave-wide then across waves
         float part[7] = {0, 0, 0, 0, 0, 0, 0};
         if (model_head) {
@@ -899,6 +991,7 @@ __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_ar
         }
     }
     __syncthreads();
+    POSE_STAMP(4);                                         // the 7 head values are in LDS
     if (tid == 0) {
         float q_det[4], q[4], t[3], qn[4];
         normalise_q(head, q_det);
@@ -937,7 +1030,9 @@ __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_ar
             for (int i = 0; i < 3; ++i) head[12 + i] = t[i];
         }
     }
+    POSE_STAMP(5);                                         // pose composed and stored
     if (a.next_orders.pool && blockIdx.x == 0 && blockIdx.y == 0) perm_refresh_block(a.next_orders);   // (uniform per workgroup)
+    POSE_STAMP(6);                                         // (l0 only: next replay's visiting orders loaded)
     if (!with_warp) return;
     __syncthreads();
     const long n = (long)blockIdx.x * blockDim.x + tid;
@@ -945,6 +1040,7 @@ __global__ __launch_bounds__(BLOCK) void pose_head_kernel(const elo_pose_head_ar
         warp_cell_point(w, (long)b * w.npoints + n, b, head + 8, head + 12,
                         proj_scratch(w.scratch, (size_t)w.batch * w.H * w.W, w.batch, (size_t)w.batch * w.npoints));
     }
+    POSE_STAMP(7);                                         // this workgroup's 256 points warped and binned
 }
 
 // ------------------------------------------------------------ warp + spherical re-projection
@@ -1090,14 +1186,29 @@ extern "C" int elo_cv_encode1(const elo_cv_encode1_args *a, elo_stream_t stream)
         const FastDiv ds = fast_div(5 + a->C), dk = fast_div(a->K);
         hipStream_t s = (hipStream_t)stream;
         const int rpi = ELO_BLOCK / (5 + a->C), batch_rows = rpi * ENC_BATCH;
-        if (batch_rows <= per && rpi * (5 + a->C) * 16 >= ELO_BLOCK * 15) {   // <= 1/16 of the lanes idle
-            const int span = per / batch_rows * batch_rows;
+        // The pair form (two rows per four-element slot column: 16- / 8-byte stores), one load batch per workgroup.  fp32: 16.6 -> 15.4 us at
+        // the 128 x 2048 l0 shape, batch 8, HBM-cold (0.62 -> 0.67 of 8 TB/s); fp16 at C = 16: no gain over the column-owner form (13.5
+        // -> 13.8 us: the kernel is bound by its per-slot work there, not by the store width); where the column-owner form does not
+        // tile the workgroup (C = 32 / 64: 87 % / 81 % of the lanes busy) the pair form LOSES to the slot-indexed kernel on the large
+        // calls (l2_origin, 131 072 rows of 138 channels: 16.6 -> 19.1 us): fp32 with C = 16 only.  gpurun_out/r06/cold_sweep_*_pairs.txt,
+        // cold_levels_f32.txt
+        const bool col_tiles = rpi * (5 + a->C) * 16 >= ELO_BLOCK * 15;      // <= 1/16 of the lanes idle
+        if (ELO_ENCODE1_PAIRS && a->dtype == ELO_F32 && col_tiles && rows >= 8192 && 2 * batch_rows <= 128 && rows % 2 == 0 &&
+            (uintptr_t)a->out % (4 * esz) == 0) {
+            const int span = 2 * batch_rows;
+            const dim3 cgrid((unsigned)((rows + span - 1) / span));
+            hipLaunchKernelGGL((cv_encode1_pair_kernel<128, float>), cgrid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk, rpi, span);
+            return check_launch(who);
+        }
+        const int cper = per < 64 ? 64 : per;                                 // (the column-owner form keeps its 64-row workgroups on small calls)
+        if (batch_rows <= cper && col_tiles) {
+            const int span = cper / batch_rows * batch_rows;
             const dim3 cgrid((unsigned)((rows + span - 1) / span));
             if (a->dtype == ELO_F16) {
-                if (per == 128) hipLaunchKernelGGL((cv_encode1_col_kernel<128, half_t>), cgrid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk, rpi, span);
+                if (cper == 128) hipLaunchKernelGGL((cv_encode1_col_kernel<128, half_t>), cgrid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk, rpi, span);
                 else hipLaunchKernelGGL((cv_encode1_col_kernel<64, half_t>), cgrid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk, rpi, span);
             } else {
-                if (per == 128) hipLaunchKernelGGL((cv_encode1_col_kernel<128, float>), cgrid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk, rpi, span);
+                if (cper == 128) hipLaunchKernelGGL((cv_encode1_col_kernel<128, float>), cgrid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk, rpi, span);
                 else hipLaunchKernelGGL((cv_encode1_col_kernel<64, float>), cgrid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk, rpi, span);
             }
             return check_launch(who);
@@ -1105,10 +1216,12 @@ extern "C" int elo_cv_encode1(const elo_cv_encode1_args *a, elo_stream_t stream)
         const dim3 grid((unsigned)((rows + per - 1) / per));
         if (a->dtype == ELO_F16) {
             if (per == 128) hipLaunchKernelGGL((cv_encode1_vec_kernel<128, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
-            else hipLaunchKernelGGL((cv_encode1_vec_kernel<64, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+            else if (per == 64) hipLaunchKernelGGL((cv_encode1_vec_kernel<64, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+            else hipLaunchKernelGGL((cv_encode1_vec_kernel<32, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
         } else {
             if (per == 128) hipLaunchKernelGGL((cv_encode1_vec_kernel<128, float>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
-            else hipLaunchKernelGGL((cv_encode1_vec_kernel<64, float>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+            else if (per == 64) hipLaunchKernelGGL((cv_encode1_vec_kernel<64, float>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+            else hipLaunchKernelGGL((cv_encode1_vec_kernel<32, float>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
         }
         return check_launch(who);
     }
@@ -1138,10 +1251,12 @@ extern "C" int elo_cv_encode2(const elo_cv_encode2_args *a, elo_stream_t stream)
         hipStream_t s = (hipStream_t)stream;
         if (a->dtype == ELO_F16) {
             if (per == 128) hipLaunchKernelGGL((cv_encode2_vec_kernel<128, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
-            else hipLaunchKernelGGL((cv_encode2_vec_kernel<64, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+            else if (per == 64) hipLaunchKernelGGL((cv_encode2_vec_kernel<64, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+            else hipLaunchKernelGGL((cv_encode2_vec_kernel<32, half_t>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
         } else {
             if (per == 128) hipLaunchKernelGGL((cv_encode2_vec_kernel<128, float>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
-            else hipLaunchKernelGGL((cv_encode2_vec_kernel<64, float>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+            else if (per == 64) hipLaunchKernelGGL((cv_encode2_vec_kernel<64, float>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
+            else hipLaunchKernelGGL((cv_encode2_vec_kernel<32, float>), grid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk);
         }
         return check_launch(who);
     }
@@ -1163,17 +1278,15 @@ extern "C" int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_strea
     const bool vec = a->C % 4 == 0 && a->C <= 1024 && ELO_BLOCK % (a->C / 4) == 0 && a->values_stride % 4 == 0 &&
                      ((uintptr_t)a->logits | (uintptr_t)a->values | (uintptr_t)a->out) % (4 * esz) == 0;
     if (a->dtype == ELO_F16 && !vec) return fail(ELO_ERR_ARG, "%s: fp16 needs C % 4 == 0 and 8-byte aligned tensors", who);
-    if (vec && a->C == 64 && a->K <= 32 && a->values_stride % (16 / esz) == 0 &&
+    // (fp32 storage only: in fp16 a point is 768 bytes per tensor -- even at two points per wave the form is instruction-bound,
+    //  31.9 us against the quarter-wave form's 23.5 at the 128 x 2048 l0 shape, batch 8: gpurun_out/r06/cold_sweep_f16_pw1d.txt)
+    if (vec && a->dtype == ELO_F32 && a->C == 64 && a->K <= 32 && a->values_stride % (16 / esz) == 0 &&
         ((uintptr_t)a->logits | (uintptr_t)a->values | (uintptr_t)a->out) % 16 == 0 && tuning().pool_wave) {   // wave per point (round 6): 16-byte loads, many light waves
-        const long ppb = (ELO_BLOCK / 64) * (a->dtype == ELO_F16 ? 2 : 1);      // points per workgroup
+        const long ppb = ELO_BLOCK / 64;                                         // points per workgroup
         const dim3 grid((unsigned)((rows + ppb - 1) / ppb));
         hipStream_t s = (hipStream_t)stream;
         const int J = (a->K + 3) / 4;                                            // neighbour rows per lane group
-#define ELO_POOL_WAVE(J_)                                                                                                          \
-        do {                                                                                                                      \
-            if (a->dtype == ELO_F16) hipLaunchKernelGGL((softmax_pool_wave_kernel<half_t, J_>), grid, dim3(ELO_BLOCK), 0, s, *a, rows); \
-            else hipLaunchKernelGGL((softmax_pool_wave_kernel<float, J_>), grid, dim3(ELO_BLOCK), 0, s, *a, rows);                \
-        } while (0)
+#define ELO_POOL_WAVE(J_) hipLaunchKernelGGL((softmax_pool_wave_kernel<float, J_>), grid, dim3(ELO_BLOCK), 0, s, *a, rows)
         if (J == 1) ELO_POOL_WAVE(1);
         else if (J == 2) ELO_POOL_WAVE(2);
         else if (J <= 4) ELO_POOL_WAVE(4);
@@ -1186,10 +1299,10 @@ extern "C" int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_strea
         const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
         hipStream_t s = (hipStream_t)stream;
         if (a->K % 6 == 0) {
-            if (a->dtype == ELO_F16) hipLaunchKernelGGL((softmax_pool_vec_kernel<half_t, 6>), grid, dim3(ELO_BLOCK), 0, s, *a, rows);
+            if (a->dtype == ELO_F16) hipLaunchKernelGGL((softmax_pool_vec_kernel<half_t, 6, true>), grid, dim3(ELO_BLOCK), 0, s, *a, rows);
             else hipLaunchKernelGGL((softmax_pool_vec_kernel<float, 6>), grid, dim3(ELO_BLOCK), 0, s, *a, rows);
         } else {
-            if (a->dtype == ELO_F16) hipLaunchKernelGGL((softmax_pool_vec_kernel<half_t, 4>), grid, dim3(ELO_BLOCK), 0, s, *a, rows);
+            if (a->dtype == ELO_F16) hipLaunchKernelGGL((softmax_pool_vec_kernel<half_t, 4, true>), grid, dim3(ELO_BLOCK), 0, s, *a, rows);
             else hipLaunchKernelGGL((softmax_pool_vec_kernel<float, 4>), grid, dim3(ELO_BLOCK), 0, s, *a, rows);
         }
         return check_launch(who);
@@ -1197,6 +1310,13 @@ extern "C" int elo_masked_softmax_pool(const elo_softmax_pool_args *a, elo_strea
     hipLaunchKernelGGL(softmax_pool_kernel, dim3(grid_for_rows(rows)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
     return check_launch(who);
 }
+
+#ifdef ELO_POSE_CLOCK
+extern "C" int elo_debug_pose_clock(unsigned long long *out33)
+{
+    return hipMemcpyFromSymbol(out33, HIP_SYMBOL(g_pose_clock), 33 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 static int sv_parts(int npoints)
 {

@@ -342,7 +342,7 @@ class PWCLONet:
         else:
             stream.wait_event(ready)
         for x in inputs:
-            if x is not None:
+            if x is not None and x.is_cuda:            # (a host tensor is copied by the lane's own H2D copy: nothing to mark)
                 x.record_stream(stream)
 
     def submit(self, lane_index, xyz_f1_proj=None, xyz_f2_proj=None, ready=None):
