@@ -345,74 +345,77 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_col_kernel(const elo_cv_
     }
 }
 
-#ifndef ELO_ENCODE1_PAIRS
-#define ELO_ENCODE1_PAIRS 1                          // (0: an A/B build without the pair form)
-#endif
-// Pair form of the column-owner kernel (round 6): TWO consecutive rows are one "super-row" of 2 * (5 + C) two-element slots = (5 + C)
-// FOUR-element slots, and a thread owns one four-element slot column: its two halves are loop-invariant (row parity, column) pairs --
-// the first (5 + C) two-element slots of a super-row are its even row, the rest its odd row; with an odd 5 + C one thread straddles the
-// rows -- so a store is 16 bytes in fp32 and 8 in fp16 storage instead of 8 / 4, contiguous over the wave (a super-row starts on a
-// 16- / 8-byte boundary because rows are taken from an even first row), half the store instructions and half the trips of the
-// column-owner form for the same two gathers per trip.  rows and span are even.
+// Staged form of stage 1 (round 6): the workgroup BUILDS its rows of the output in LDS, in the output's own byte layout, and then
+// streams the tile out as 16-byte vectors.  The column-owner / pair forms above pay one 4- or 8-byte gather and one narrow store per
+// two-element slot (8.3 M slots at the 128 x 2048 l0 shape, batch 8: ~13 us in either storage type -- bound by the slot count, not
+// by the bytes).  Here a row's two feature rows are fetched as 16-byte chunks (C = 16 in fp16: two loads per source row instead of
+// eight), scaled and laid into the tile next to the row's geometry code, and the tile -- contiguous in HBM -- leaves as whole
+// 16-byte vectors: every global access is 16 bytes wide and coalesced.  Same values bit for bit (the same conversions in the same order).
+//   rows per workgroup ENC_ROWS (a multiple of 4: a tile starts on a 16-byte boundary in both storage types); dynamic LDS: the tile.
 template <int ENC_ROWS, class T>
-__global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_pair_kernel(const elo_cv_encode1_args a, const long rows,
-                                                                    const FastDiv by_slots, const FastDiv by_K,
-                                                                    const int spi, const int span)
+__global__ __launch_bounds__(ELO_BLOCK) void cv_encode1_staged_kernel(const elo_cv_encode1_args a, const long rows, const FastDiv by_K)
 {
-    typedef typename Store<T>::V2 V2;
-    typedef typename Store<T>::V4 V4;
+    typedef typename Store<T>::V16 V16;
+    constexpr int E = Store<T>::PER16;               // elements per 16 bytes
+    extern __shared__ __align__(16) unsigned char tile_raw[];
     __shared__ RowFacts<ENC_ROWS> rf;
-    const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * span;
+    T *tile = reinterpret_cast<T *>(tile_raw);
+    const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * ENC_ROWS;
     if (first >= rows) return;
-    const int C = a.C, HC = C >> 1, HP = 5 + C;
-    const int nrows = (int)(rows - first < span ? rows - first : span);
+    const int C = a.C, RW = 10 + 2 * C, CH = C / E;   // row width in elements, 16-byte chunks per feature row
+    const int nrows = (int)(rows - first < ENC_ROWS ? rows - first : ENC_ROWS);
     const long bn0 = point_batch(first, a.K);
     const unsigned rem0 = (unsigned)(first - bn0 * a.K);
     resolve_rows(rf, first, nrows, bn0, rem0, by_K, a.idx, a.mask, a.xyz1, a.xyz2, a.H2, a.W2);
-    const int sr0 = (int)by_slots(threadIdx.x), jj = (int)threadIdx.x - sr0 * HP;    // super-row of the trip, four-element column
-    if (sr0 >= spi) return;                          // the 256 % (5 + C) lanes over
-    int par[2], g2[2];
-    bool geo[2], own[2];
-    const T *src[2];
+    const T *feat1 = static_cast<const T *>(a.feat1), *feat2 = static_cast<const T *>(a.feat2);
+    // features: work item = (row, tensor, chunk); 2 * CH items per row, U in flight per thread
+    constexpr int U = 4;
+    const int per_row = 2 * CH, items = nrows * per_row;
+    for (int i0 = threadIdx.x; i0 < items; i0 += ELO_BLOCK * U) {
+        V16 f[U];
+        int lr[U], ch[U];
+        bool own[U];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int sl = 2 * jj + e;                   // two-element slot of the super-row
-        par[e] = sl >= HP;
-        const int j = sl - par[e] * HP;
-        geo[e] = j < 5; own[e] = j < 5 + HC;
-        src[e] = own[e] ? static_cast<const T *>(a.feat1) + (geo[e] ? 0 : 2 * (j - 5))
-                        : static_cast<const T *>(a.feat2) + 2 * (j - 5 - HC);
-        g2[e] = geo[e] ? 2 * j : 0;
-    }
-    V4 *__restrict__ out = reinterpret_cast<V4 *>(static_cast<T *>(a.out) + first * (2 * HP)) + threadIdx.x;
-    const int step = spi * HP, nsr = nrows >> 1;
-    for (int s = sr0; s < nsr; s += spi * ENC_BATCH, out += step * ENC_BATCH) {
-        V2 f[ENC_BATCH][2];
-        int lr[ENC_BATCH][2];
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * ELO_BLOCK < items ? i0 + u * ELO_BLOCK : items - 1;       // clamped: loads stay unconditional
+            lr[u] = i / per_row;
+            const int w = i - lr[u] * per_row;
+            own[u] = w < CH;
+            ch[u] = own[u] ? w : w - CH;
+            const long from = own[u] ? bn0 + by_K(rem0 + lr[u]) : rf.cell[lr[u]];
+            f[u] = *reinterpret_cast<const V16 *>((own[u] ? feat1 : feat2) + from * C + ch[u] * E);
+        }
 #pragma unroll
-        for (int u = 0; u < ENC_BATCH; ++u)
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u * ELO_BLOCK >= items) continue;
+            const float sc = own[u] ? 1.0f : rf.mask[lr[u]];
+            T *dst = tile + lr[u] * RW + 10 + (own[u] ? 0 : C) + ch[u] * E;              // (4-byte aligned: RW and the offsets are even)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int su = s + u * spi < nsr ? s + u * spi : nsr - 1;           // clamped (last workgroup only)
-                lr[u][e] = 2 * su + par[e];
-                const long from = own[e] ? bn0 + by_K(rem0 + lr[u][e]) : rf.cell[lr[u][e]];
-                f[u][e] = *reinterpret_cast<const V2 *>(src[e] + from * C);
+            for (int e = 0; e < E; e += 2) {
+                typename Store<T>::V2 v{(T)((float)f[u][e] * sc), (T)((float)f[u][e + 1] * sc)};
+                *reinterpret_cast<typename Store<T>::V2 *>(dst + e) = v;
             }
-#pragma unroll
-        for (int u = 0; u < ENC_BATCH; ++u) {
-            V4 v;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float sc = own[e] ? 1.0f : rf.mask[lr[u][e]];
-                const float2 gv = *reinterpret_cast<const float2 *>(&rf.geo[lr[u][e]][g2[e]]);
-                v[2 * e] = (T)(geo[e] ? gv.x : (float)f[u][e].x * sc);
-                v[2 * e + 1] = (T)(geo[e] ? gv.y : (float)f[u][e].y * sc);
-            }
-            if (s + u * spi < nsr) STREAM_STORE(v, &out[u * step]);
         }
     }
+    for (int i = threadIdx.x; i < nrows * 5; i += ELO_BLOCK) {                           // geometry: five two-element slots per row
+        const int r = i / 5, j = i - r * 5;
+        const float2 g = *reinterpret_cast<const float2 *>(&rf.geo[r][2 * j]);
+        typename Store<T>::V2 v{(T)g.x, (T)g.y};
+        *reinterpret_cast<typename Store<T>::V2 *>(tile + r * RW + 2 * j) = v;
+    }
+    __syncthreads();
+    // the tile leaves as it lies: nrows * RW elements from `first * RW` on
+    const int total = nrows * RW, nvec = total / E;
+    T *out = static_cast<T *>(a.out) + first * RW;
+    for (int v = threadIdx.x; v < nvec; v += ELO_BLOCK)
+        STREAM_STORE(reinterpret_cast<const V16 *>(tile)[v], reinterpret_cast<V16 *>(out) + v);
+    for (int e = nvec * E + 2 * threadIdx.x; e < total; e += 2 * ELO_BLOCK)             // a ragged last tile: the bytes past the last whole vector
+        *reinterpret_cast<typename Store<T>::V2 *>(out + e) = *reinterpret_cast<const typename Store<T>::V2 *>(tile + e);
 }
 
+#ifndef ELO_ENCODE1_STAGED
+#define ELO_ENCODE1_STAGED 1                         // (0: an A/B build without the staged form)
+#endif
 // Stage 2 has two outputs: xyz_cat rows of 10 elements (two-element slots, straight from the row facts) and rest
 // rows of C + Cc elements in 16-byte slots (4 floats / 8 halves: C and Cc multiples of that).
 template <int ENC_ROWS, class T>
@@ -1186,20 +1189,30 @@ extern "C" int elo_cv_encode1(const elo_cv_encode1_args *a, elo_stream_t stream)
         const FastDiv ds = fast_div(5 + a->C), dk = fast_div(a->K);
         hipStream_t s = (hipStream_t)stream;
         const int rpi = ELO_BLOCK / (5 + a->C), batch_rows = rpi * ENC_BATCH;
-        // The pair form (two rows per four-element slot column: 16- / 8-byte stores), one load batch per workgroup.  fp32: 16.6 -> 15.4 us at
-        // the 128 x 2048 l0 shape, batch 8, HBM-cold (0.62 -> 0.67 of 8 TB/s); fp16 at C = 16: no gain over the column-owner form (13.5
-        // -> 13.8 us: the kernel is bound by its per-slot work there, not by the store width); where the column-owner form does not
-        // tile the workgroup (C = 32 / 64: 87 % / 81 % of the lanes busy) the pair form LOSES to the slot-indexed kernel on the large
-        // calls (l2_origin, 131 072 rows of 138 channels: 16.6 -> 19.1 us): fp32 with C = 16 only.  gpurun_out/r06/cold_sweep_*_pairs.txt,
-        // cold_levels_f32.txt
-        const bool col_tiles = rpi * (5 + a->C) * 16 >= ELO_BLOCK * 15;      // <= 1/16 of the lanes idle
-        if (ELO_ENCODE1_PAIRS && a->dtype == ELO_F32 && col_tiles && rows >= 8192 && 2 * batch_rows <= 128 && rows % 2 == 0 &&
-            (uintptr_t)a->out % (4 * esz) == 0) {
-            const int span = 2 * batch_rows;
-            const dim3 cgrid((unsigned)((rows + span - 1) / span));
-            hipLaunchKernelGGL((cv_encode1_pair_kernel<128, float>), cgrid, dim3(ELO_BLOCK), 0, s, *a, rows, ds, dk, rpi, span);
-            return check_launch(who);
+        // The staged form (the tile built in LDS, 16-byte accesses only) where the feature rows are whole 16-byte chunks and the tile fits.
+        // HBM-cold at the 128 x 2048 level shapes, batch 8, fp16 storage: l0 13.3 -> 10.3 us (0.42 -> 0.55 of 8 TB/s), l1 8.9 -> 5.7,
+        // l2_origin 15.7 -> 11.2; fp32 unchanged (15.3 us at l0: 82 MB, bound by its bytes there).  A "pair" form of the column-owner
+        // kernel (two rows per 16-byte slot column) was also measured -- fp32 l0 16.6 -> 15.4 us, fp16 no gain -- and is superseded by
+        // this one.  gpurun_out/r06/cold_levels_*staged.txt, cold_sweep_*_pairs.txt
+        const int per16 = 16 / esz;
+        if (ELO_ENCODE1_STAGED && a->C % per16 == 0 && rows >= 8192 &&
+            ((uintptr_t)a->feat1 | (uintptr_t)a->feat2 | (uintptr_t)a->out) % 16 == 0) {
+            const size_t row_bytes = (size_t)(10 + 2 * a->C) * esz;
+            const int R = 128 * row_bytes <= 40 * 1024 ? 128 : 64;
+            if (R * row_bytes <= 40 * 1024) {
+                const dim3 sgrid((unsigned)((rows + R - 1) / R));
+                const size_t lds = R * row_bytes;
+                if (a->dtype == ELO_F16) {
+                    if (R == 128) hipLaunchKernelGGL((cv_encode1_staged_kernel<128, half_t>), sgrid, dim3(ELO_BLOCK), lds, s, *a, rows, dk);
+                    else hipLaunchKernelGGL((cv_encode1_staged_kernel<64, half_t>), sgrid, dim3(ELO_BLOCK), lds, s, *a, rows, dk);
+                } else {
+                    if (R == 128) hipLaunchKernelGGL((cv_encode1_staged_kernel<128, float>), sgrid, dim3(ELO_BLOCK), lds, s, *a, rows, dk);
+                    else hipLaunchKernelGGL((cv_encode1_staged_kernel<64, float>), sgrid, dim3(ELO_BLOCK), lds, s, *a, rows, dk);
+                }
+                return check_launch(who);
+            }
         }
+        const bool col_tiles = rpi * (5 + a->C) * 16 >= ELO_BLOCK * 15;      // <= 1/16 of the lanes idle
         const int cper = per < 64 ? 64 : per;                                 // (the column-owner form keeps its 64-row workgroups on small calls)
         if (batch_rows <= cper && col_tiles) {
             const int span = cper / batch_rows * batch_rows;
