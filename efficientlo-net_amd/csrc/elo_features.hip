@@ -468,7 +468,9 @@ __global__ __launch_bounds__(ELO_BLOCK) void cv_encode2_vec_kernel(const elo_cv_
 // per lane.
 // NT (fp16 storage since round 6): the inputs are read once -- nontemporal loads, measured HBM-cold at the 128 x 2048 l0 shape, batch 8:
 // P1 23.9 -> 22.3 us, P2 17.6 -> 15.6 (0.58 -> 0.62, 0.54 -> 0.61 of 8 TB/s); on ONE Infinity-Cache-resident set 19.2 -> 20.2 / 14.3 -> 14.5
-// (gpurun_out/r06/cold_sweep_f16_e*.txt).  fp32 storage takes the wave-per-point form below.
+// (gpurun_out/r06/cold_sweep_f16_e*.txt).  fp32 storage takes the wave-per-point form below.  Also measured for fp16 and NOT taken: 16-byte
+// loads with an eighth-wave per point (half the load instructions, twice the work per lane): P1 22.7 -> 26.3 us, P2 16.3 -> 18.5
+// (gpurun_out/r06/cold_levels_f16_wide.txt) -- like tools/micro/hbm_probe.hip's one-shot rows, the lighter thread wins.
 template <class T, int U, bool NT = false>          // U neighbour rows in flight per lane (6 when K is a multiple of 6, else 4); NT: nontemporal loads
 __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_vec_kernel(const elo_softmax_pool_args a, const long rows)
 {
