@@ -55,6 +55,21 @@ def test_bench_single_rank_dry_run_needs_no_launcher():
     assert d["n_gpus"] == 1 and "launching" not in out.stderr
 
 
+def test_bench_one_rank_process_group_rehearsal():
+    """ELO_BENCH_FORCE_DIST=1: a ONE-rank process group (the 1-GPU box's rehearsal of the distributed path through RCCL,
+    tests/test_bench_gpu.py) -- here over gloo and --dry-run: the group comes up without a launcher and without MASTER_* in the
+    environment, the collectives run on the world of one, the line carries the `rccl` object, n_gpus stays 1."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ELO_BENCH_FORCE_DIST="1", ELO_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "4", "--warmup", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "dp1" and "launching" not in out.stderr
+    r = d["rccl"]
+    assert r["world_size"] == 1 and r["backend"] == "gloo" and r["all_reduce_us"] > 0 and r["all_gather_bytes"] == 4 * 7 * 4
+
+
 RING_LOG = """\
 node0:4242:4242 [0] NCCL INFO cudaDriverVersion 12000
 node0:4242:4242 [0] NCCL INFO RCCL version 2.22.3+hip7.0 HEAD:abcdef0
