@@ -69,14 +69,24 @@ def build(force=False, verbose=False, extra_flags=(), only=None):
         links.append((lib, objs))
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         list(pool.map(_compile, jobs))
+    linked = 0
+    global LAST_BUILD
     for lib, objs in links:
+        linked += 1 if (force or _newer(objs, lib)) else 0
         if force or _newer(objs, lib):
             cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+    # what this call did (the driver's "does it build" check reuses objects that are newer than their sources: say so)
+    LAST_BUILD = {"build_mode": "compiled" if jobs else "reused", "objects_compiled": len(jobs), "objects_total": sum(len(o) for _l, o in links),
+                  "libraries_linked": linked, "forced": bool(force)}
+    if verbose:
+        print("[build] %s" % LAST_BUILD, flush=True)
     return LIB
 
+
+LAST_BUILD = None
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
