@@ -44,19 +44,18 @@ def gather_poses(q, t, n_total=None):
 
 
 def quat2mat(q):
-    """main.py:401-434: rotation matrix of a (w,x,y,z) quaternion, numpy float64."""
-    w, x, y, z = (float(v) for v in q)
-    Nq = w * w + x * x + y * y + z * z
-    if Nq < 1e-8:
+    """Rotation matrix of a (w,x,y,z) quaternion in numpy float64 (what main.py:401-434 computes: the quaternion need not be
+    unit length, a near-zero one gives the identity).  Written from the outer product P = (2/|q|^2) q q^T:
+    R = I + [vector part of P, symmetrised off the diagonal] with the w-row of P supplying the antisymmetric part."""
+    quat = np.asarray([float(v) for v in q], np.float64)
+    norm2 = float(quat @ quat)
+    if norm2 < 1e-8:
         return np.eye(3)
-    s = 2.0 / Nq
-    X, Y, Z = x * s, y * s, z * s
-    wX, wY, wZ = w * X, w * Y, w * Z
-    xX, xY, xZ = x * X, x * Y, x * Z
-    yY, yZ, zZ = y * Y, y * Z, z * Z
-    return np.array([[1.0 - (yY + zZ), xY - wZ, xZ + wY],
-                     [xY + wZ, 1.0 - (xX + zZ), yZ - wX],
-                     [xZ - wY, yZ + wX, 1.0 - (xX + yY)]])
+    P = np.outer(quat, quat) * (2.0 / norm2)
+    sym = P[1:, 1:]                                   # 2 v v^T / |q|^2
+    wv = P[0, 1:]                                     # 2 w v / |q|^2
+    skew = np.array([[0.0, -wv[2], wv[1]], [wv[2], 0.0, -wv[0]], [-wv[1], wv[0], 0.0]])
+    return np.eye(3) * (1.0 - np.trace(sym)) + sym + skew
 
 
 def chain_poses(poses_n7, Tr=None):
