@@ -12,6 +12,7 @@ import ctypes
 import torch
 
 from . import _lib as L
+from . import tuning
 
 
 def _wants_grad(*ts):
@@ -606,6 +607,37 @@ def dense_bn_supported(x2, cout):
     return x2.is_cuda and x2.dtype == torch.float32 and 4 <= cout <= 256 and cout & (cout - 1) == 0 and x2.shape[0] > 0
 
 
+def dense_rows_supported(x2, W):
+    """elo_dense_rows takes fp32 (rows, Cin) x (Cin, Cout) on the GPU with Cout <= 192 and W within 160 KB of LDS."""
+    return (x2.is_cuda and x2.dtype == torch.float32 and W.dtype == torch.float32 and x2.shape[0] > 0
+            and bool(L.lib().elo_dense_rows_supported(x2.shape[0], W.shape[0], W.shape[1]))
+            and bool(L.lib().elo_dense_rows_supported(x2.shape[0], W.shape[1], W.shape[0])))
+
+
+def dense_rows(x2, W, bias=None, transposed=False, moments=None):
+    """x2 @ W + bias ((rows, Cin) x (Cin, Cout)), or x2 @ W.t() with transposed=True ((rows, Cout) x (Cin, Cout)^T), on
+    csrc/elo_train_dense.hip.  moments = (eps, momentum, mean, invstd, running_mean, running_var): also the batch-norm moments of
+    the result, written into mean / invstd (and the moving averages updated) -- what elo_bn_stats does in a second pass."""
+    L.require_gpu(x2, W)
+    x2, Wc = x2.contiguous(), W.detach().contiguous()
+    cin, cout = (Wc.shape[1], Wc.shape[0]) if transposed else (Wc.shape[0], Wc.shape[1])
+    if x2.shape[1] != cin:
+        raise ValueError("dense_rows: x is %s, W %s%s" % (tuple(x2.shape), tuple(W.shape), " (transposed)" if transposed else ""))
+    out = torch.empty((x2.shape[0], cout), dtype=torch.float32, device=x2.device)
+    bias_c = bias.detach().contiguous() if bias is not None else None
+    if moments is None:
+        a = L.DenseRowsArgs(x2.shape[0], cin, cout, x2.data_ptr(), Wc.data_ptr(), 1 if transposed else 0, _ptr(bias_c), out.data_ptr(),
+                            None, 0.0, 0.0, None, None, None, None)
+        L.call("elo_dense_rows", a, x2)
+        return out
+    eps, momentum, mean, invstd, running_mean, running_var = moments
+    scratch = torch.empty((L.DENSE_MAX_PARTS * 2 * cout,), dtype=torch.float32, device=x2.device)
+    a = L.DenseRowsArgs(x2.shape[0], cin, cout, x2.data_ptr(), Wc.data_ptr(), 1 if transposed else 0, _ptr(bias_c), out.data_ptr(),
+                        scratch.data_ptr(), eps, momentum, mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var))
+    L.call("elo_dense_rows", a, x2)
+    return out
+
+
 class _DenseBN(torch.autograd.Function):
     """y = act(batch_norm(x @ W + b)) with batch statistics.  The two dense products (forward, dx) are library GEMMs; every
     pass OVER THE ROWS -- the batch moments, the normalisation, the two sums of batch norm's backward, dz, the weight
@@ -616,15 +648,21 @@ class _DenseBN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, W, b, gamma, beta, running_mean, running_var, momentum, eps, relu):
         x2 = x2.contiguous()
-        z = torch.addmm(b, x2, W)
-        M, C = z.shape
-        dev = z.device
-        scratch = torch.empty((L.BN_MAX_PARTS * 2 * C,), dtype=torch.float32, device=dev)
+        M, C = x2.shape[0], W.shape[1]
+        dev = x2.device
         mean = torch.empty((C,), dtype=torch.float32, device=dev)
         invstd = torch.empty((C,), dtype=torch.float32, device=dev)
         g, bt = gamma.detach().contiguous(), beta.detach().contiguous()
-        L.call("elo_bn_stats", L.BnStatsArgs(M, C, z.data_ptr(), scratch.data_ptr(), float(eps), float(momentum), mean.data_ptr(),
-                                             invstd.data_ptr(), running_mean.data_ptr(), running_var.data_ptr()), z)
+        ctx.own_dense = bool(tuning.get("train_dense")) and dense_rows_supported(x2, W)
+        wide_and_short = W.shape[0] > 128 and M < tuning.get("train_dense_dx_rows")
+        if ctx.own_dense and M >= tuning.get("train_dense_rows") and not wide_and_short:
+            # the product AND the batch moments in one pass over the rows
+            z = dense_rows(x2, W, b, moments=(float(eps), float(momentum), mean, invstd, running_mean, running_var))
+        else:
+            z = torch.addmm(b, x2, W)
+            scratch = torch.empty((L.BN_MAX_PARTS * 2 * C,), dtype=torch.float32, device=dev)
+            L.call("elo_bn_stats", L.BnStatsArgs(M, C, z.data_ptr(), scratch.data_ptr(), float(eps), float(momentum), mean.data_ptr(),
+                                                 invstd.data_ptr(), running_mean.data_ptr(), running_var.data_ptr()), z)
         y = torch.empty_like(z)
         L.call("elo_bn_apply", L.BnApplyArgs(M, C, z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g.data_ptr(), bt.data_ptr(),
                                              1 if relu else 0, y.data_ptr()), z)
@@ -645,7 +683,10 @@ class _DenseBN(torch.autograd.Function):
                                                    bt.data_ptr(), 1 if ctx.relu else 0, scratch.data_ptr(), sums.data_ptr(),
                                                    dz.data_ptr()), z)
         dbeta, dgamma = sums[:C], sums[C:]
-        dx = dz @ W.t() if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            own = ctx.own_dense and M >= tuning.get("train_dense_dx_rows")
+            dx = dense_rows(dz, W, None, transposed=True) if own else dz @ W.t()
         cin = W.shape[0]
         dW = torch.empty_like(W, memory_format=torch.contiguous_format)
         db = torch.empty((C,), dtype=torch.float32, device=dev)

@@ -56,7 +56,17 @@ __device__ __forceinline__ void combine(const float *part, int parts, int C, int
 {
     const int lane = threadIdx.x & 63;
     double a = 0.0, b = 0.0;
-    for (int i = lane; i < parts; i += 64) { a += (double)part[((size_t)i * 2) * C + c]; b += (double)part[((size_t)i * 2 + 1) * C + c]; }
+    for (int i0 = lane; i0 < parts; i0 += 64 * 8) {        // 16 loads in flight (one dependent trip per 64 partial rows before:
+        float va[8], vb[8];                                //  a 2048-part reduction was 32 round trips behind each other)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 64 * u, ic = i < parts ? i : lane;
+            va[u] = part[((size_t)ic * 2) * C + c]; vb[u] = part[((size_t)ic * 2 + 1) * C + c];
+            if (i >= parts) { va[u] = 0.f; vb[u] = 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a += (double)va[u]; b += (double)vb[u]; }
+    }
     for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
     t0 = a; t1 = b;
 }
@@ -369,6 +379,12 @@ int check_bn(const char *who, long M, int C, std::initializer_list<const void *>
 }
 
 }  // namespace
+
+void bn_finalize_launch(const float *part, int parts, long M, int C, float eps, float momentum, float *mean, float *invstd,
+                        float *running_mean, float *running_var, hipStream_t s)       // for elo_train_dense.hip's fused moments
+{
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, parts, M, C, eps, momentum, mean, invstd, running_mean, running_var);
+}
 }  // namespace elo
 
 using namespace elo;

@@ -543,6 +543,26 @@ typedef struct elo_weight_grad_args {
 int elo_weight_grad_slices(long rows, int Cin, int Cout);
 int elo_dense_weight_grad(const elo_weight_grad_args *a, elo_stream_t stream);
 
+/* out = x W (+ bias) over the rows of a training layer (utils/tf_util.py:120-185: conv2d 1x1 and its adjoint dx = dz W^T with
+ * transposed = 1), fp32 on v_mfma_f32_16x16x4_f32: one pass over x, W staged once per workgroup in LDS.  Any Cin; Cout <= 192
+ * and ceil(Cin/16) * ceil(Cout/16) <= 160 (elo_dense_rows_supported).  scratch != NULL: ALSO the batch-norm moments of out, from the
+ * accumulators (what elo_bn_stats computes with one more pass over out): mean, invstd and the moving averages as there. */
+#define ELO_DENSE_MAX_PARTS 2048  /* scratch = 2 * Cout * ELO_DENSE_MAX_PARTS floats */
+typedef struct elo_dense_rows_args {
+    long rows; int Cin, Cout;
+    const float *x;               /* (rows,Cin), 16-byte aligned */
+    const float *W;               /* (Cin,Cout) row-major; transposed = 1: (Cout,Cin) row-major */
+    int transposed;
+    const float *bias;            /* (Cout) or NULL */
+    float *out;                   /* (rows,Cout) OUT, 16-byte aligned */
+    float *scratch;               /* NULL: no moments */
+    float eps, momentum;
+    float *mean, *invstd;         /* (Cout) OUT when scratch != NULL */
+    float *running_mean, *running_var;   /* (Cout) IN/OUT or both NULL */
+} elo_dense_rows_args;
+int elo_dense_rows_supported(long rows, int Cin, int Cout);
+int elo_dense_rows(const elo_dense_rows_args *a, elo_stream_t stream);
+
 /* Adam (torch.optim.Adam's arithmetic; the reference trains with tf.train.AdamOptimizer, main.py:171-176) over ONE flat
  * fp32 parameter buffer in one launch: every variable, its gradient and its two moments are views of four buffers of n
  * floats.  hyper (device, 4 floats, written by the host before the step): [lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), eps, -]. */

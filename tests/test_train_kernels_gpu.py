@@ -31,7 +31,8 @@ def _reference(x, W, b, gamma, beta, rm, rv, momentum, eps, relu, gy, mask):
 
 
 @pytest.mark.parametrize("rows,cin,cout,relu", [(4096, 6, 8, True), (921, 3, 4, True), (30000, 42, 128, True), (5000, 138, 64, False),
-                                                (777, 272, 256, True), (65536, 16, 16, True), (13, 19, 32, True), (1, 8, 8, True)])
+                                                (777, 272, 256, True), (65536, 16, 16, True), (13, 19, 32, True), (1, 8, 8, True),
+                                                (120001, 67, 128, True), (150000, 128, 64, True), (100003, 8, 16, False)])
 def test_training_layer_matches_float64(rows, cin, cout, relu):
     tf_util = load_pkg("tf_util")
     rng = np.random.default_rng(rows + cin)
@@ -242,3 +243,73 @@ def test_flat_adam_default_is_tensorflows_adam_and_survives_a_host_that_runs_ahe
     got = mine[0].detach().cpu().double().numpy()
     assert np.abs(got - p).max() <= 5e-5 * max(1.0, np.abs(p).max()), float(np.abs(got - p).max())
     assert opt.t == steps
+
+
+# ---- the layer's dense products on elo_dense_rows (csrc/elo_train_dense.hip) ---------------------------------------------------
+@pytest.mark.parametrize("rows,cin,cout", [(1, 3, 4), (15, 6, 8), (33, 8, 8), (1000, 19, 16), (4097, 16, 32), (2049, 35, 32), (3001, 67, 64),
+                                           (5003, 64, 128), (2000, 138, 128), (999, 192, 128), (777, 10, 64), (1234, 128, 138), (555, 64, 6),
+                                           (640, 128, 192), (300000, 8, 8), (200001, 128, 128)])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_dense_rows_matches_float64(rows, cin, cout, transposed):
+    """x W + b and x W^T for every width class of the kernel (1, 2, 4, 8, 12 tiles; Cin % 4 == 0 or not; Cout % 4 == 0 or not; rows
+    that end inside a 16-row block; W as a misaligned view, which a weight of the flat parameter buffer is), with the fused
+    batch moments and moving averages where there is a bias (the forward product of a training layer)."""
+    ops = load_pkg("_ops")
+    g = torch.Generator(device="cpu").manual_seed(rows * 7 + cin)
+    x = torch.randn(rows, cin, generator=g).to(DEV)
+    flat = torch.randn(cin * cout + 3, generator=g).to(DEV) * 0.3
+    W = flat[1:1 + cin * cout].view((cout, cin) if transposed else (cin, cout))      # 4-byte offset: the unaligned staging path
+    b = None if transposed else torch.randn(cout, generator=g).to(DEV)
+    want = x.double() @ (W.double().t() if transposed else W.double()) + (0 if b is None else b.double())
+    got = ops.dense_rows(x, W, b, transposed=transposed)
+    assert got.shape == want.shape
+    tol = 2e-6 * (float(want.abs().max()) + 1.0) * max(1.0, cin ** 0.5 / 4)
+    assert float((got.double() - want).abs().max()) <= tol
+    W2 = W.contiguous()                                                              # 16-byte aligned: the vector staging path
+    assert torch.equal(ops.dense_rows(x, W2, b, transposed=transposed), got)
+    if b is not None and rows > 1:
+        mean, invstd = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+        rm, rv = torch.full((cout,), 0.25, device=DEV), torch.full((cout,), 2.0, device=DEV)
+        z = ops.dense_rows(x, W, b, moments=(1e-3, 0.3, mean, invstd, rm, rv))
+        assert torch.equal(z, got)
+        m, v = want.mean(0), want.var(0, unbiased=False)
+        assert float((mean.double() - m).abs().max()) <= 1e-5 * (float(m.abs().max()) + 1.0)
+        assert float(((invstd.double() - 1 / torch.sqrt(v + 1e-3)) * torch.sqrt(v + 1e-3)).abs().max()) <= 2e-5
+        assert float((rm.double() - (0.7 * 0.25 + 0.3 * m)).abs().max()) <= 1e-5 * (float(m.abs().max()) + 1.0)
+        assert float(((rv.double() - (0.7 * 2.0 + 0.3 * v * rows / (rows - 1))) / (v + 1.0)).abs().max()) <= 2e-5
+
+
+def test_dense_rows_rejects_what_it_cannot_run():
+    ops, L = load_pkg("_ops"), load_pkg("_lib")
+    x = torch.randn(64, 16, device=DEV)
+    with pytest.raises(ValueError):
+        ops.dense_rows(x, torch.randn(8, 32, device=DEV))                          # inner sizes differ
+    with pytest.raises(RuntimeError):
+        ops.dense_rows(x, torch.randn(16, 200, device=DEV))                        # > 192 output columns
+    assert L.lib().elo_dense_rows_supported(1000, 512, 192) == 0                   # W beyond 160 KB of LDS
+    with pytest.raises((RuntimeError, TypeError, ValueError)):
+        ops.dense_rows(x.cpu(), torch.randn(16, 8))                                # no CPU path
+
+
+def test_the_layer_is_the_same_on_both_dense_paths():
+    """tuning.train_dense off (library GEMM + elo_bn_stats) and on (elo_dense_rows, moments fused): outputs, moving averages and
+    all five gradients of one layer agree to fp32 rounding."""
+    tf_util, tuning = load_pkg("tf_util"), load_pkg("tuning")
+    rows, cin, cout = 130000, 67, 128
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x0 = torch.randn(1, rows, 1, cin, generator=g).to(DEV)
+    gy = torch.randn(rows, cout, generator=g).to(DEV)
+    res = []
+    for own in (False, True):
+        store = tf_util.VariableStore(DEV, seed=3)
+        x = x0.clone().requires_grad_(True)
+        with tuning.override(train_dense=own), tf_util.default_store(store):
+            y = tf_util.conv2d(x, cout, [1, 1], scope="layer", bn=True, is_training=True, bn_decay=0.7, activation_fn=tf_util.relu)
+            (y.reshape(rows, cout) * gy).sum().backward()
+        P = store.params
+        res.append([y.detach(), store.buffers["layer/bn/moving_mean"], store.buffers["layer/bn/moving_variance"], x.grad,
+                    P["layer/weights"].grad, P["layer/biases"].grad, P["layer/bn/gamma"].grad, P["layer/bn/beta"].grad])
+    for i, (a, b) in enumerate(zip(*res)):
+        # (the bias gradient of a batch-normalised layer is zero in exact arithmetic: what is left is rounding on the scale of dW)
+        scale = float(res[0][4].abs().max()) if i == 5 else float(a.abs().max()) + 1e-3
+        assert float((a - b).abs().max()) <= 3e-5 * scale, i

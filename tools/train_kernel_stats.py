@@ -1,5 +1,5 @@
 """One eager training step at batch B under the torch profiler: GPU time per kernel (top 30) and the launch count.
-    python tools/train_kernel_stats.py [B] [--by-count]"""
+    python tools/train_kernel_stats.py [B] [--by-count] [--sequence]   (--sequence: every launch of >= 12 us in launch order)"""
 import importlib, sys, collections
 import torch
 from torch.profiler import profile, ProfilerActivity
@@ -15,6 +15,12 @@ for _ in range(3): tr.step(a, b, q, t)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     tr.step(a, b, q, t); torch.cuda.synchronize()
+if "--sequence" in sys.argv:
+    evs = sorted((e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA), key=lambda e: e.time_range.start)
+    t0 = evs[0].time_range.start
+    for i, e in enumerate(evs):
+        if e.device_time >= 12:
+            print("%5d %9.1f us  %6.1f us  %s" % (i, e.time_range.start - t0, e.device_time, e.name[:110]))
 agg = collections.defaultdict(lambda: [0, 0.0])
 buckets = collections.OrderedDict((k, [0, 0.0]) for k in (6, 12, 25, 50, 100, 1e9))
 for e in prof.events():
