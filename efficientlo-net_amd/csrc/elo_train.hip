@@ -248,7 +248,23 @@ __global__ __launch_bounds__(TB) void bn_bwd_apply_kernel(const float *__restric
 // 128 -> 128 layer, at 1.8 TB/s the whole 200 us).  No reduction inside the workgroup: a wave stores its block of the
 // slice's partial dW; slices_combine_kernel sums the slices in a fixed order.  Loads are 4 bytes per lane (4 rows x 16
 // consecutive channels per instruction), U row groups in flight.
-template <int CI, int CO>
+// Round 6, two changes:
+//  * 16-BYTE LOADS.  A lane used to load ONE channel of a row for each of its CI (CO) tiles; now (XV / GV: the block lies inside
+//    the matrix and its width allows aligned vectors) it loads CI (CO) CONSECUTIVE channels of its row in one instruction and uses
+//    component a as the operand of tile a -- tile a then holds the channels ci0 + CI * i + a instead of ci0 + 16 a + i: a permutation
+//    of dW's rows (columns) inside the block that only the final store has to know.  A quarter of the load instructions, whole
+//    256-byte row segments per quarter-wave.
+//  * THE NEXT TRIP'S LOADS ARE IN FLIGHT DURING THIS TRIP'S MFMAs (two register sets, the trip loop unrolled twice; loads are
+//    unconditional -- clamped to valid rows -- because the compiler cannot count loads issued behind a branch and waits for all of
+//    them; dead rows are weighted out where a ragged trip is USED).  Before, every trip of 16 rows began with a full HBM round trip.
+//    (A third register set -- two trips ahead -- measured the same or slower: tools/wgrad_micro.py.)
+template <int W> struct VecOf;
+template <> struct VecOf<1> { typedef float T; };
+template <> struct VecOf<2> { typedef float2 T; };
+template <> struct VecOf<4> { typedef float4 T; };
+template <> struct VecOf<3> { typedef float T; };      // (never loaded as a vector)
+
+template <int CI, int CO, bool XV, bool GV>
 __global__ __launch_bounds__(TB, 2) void weight_grad_kernel(const float *__restrict__ x, const float *__restrict__ g, long M, int Cin,
                                                          int Cout, int gy, int gz, float *__restrict__ part, float *__restrict__ bpart)
 {
@@ -267,29 +283,47 @@ __global__ __launch_bounds__(TB, 2) void weight_grad_kernel(const float *__restr
     float bsum[CO];
 #pragma unroll
     for (int b = 0; b < CO; ++b) bsum[b] = 0.f;
+    // column offsets of this lane's operands (scalar form: one per tile, clamped into the matrix -- a clamped column feeds only rows
+    // / columns of the block that are never stored)
     int xc[CI], gc[CO];
-    bool xok[CI], gok[CO];
 #pragma unroll
-    for (int a = 0; a < CI; ++a) { xc[a] = ci0 + a * 16 + i16; xok[a] = xc[a] < Cin; xc[a] = xok[a] ? xc[a] : 0; }
+    for (int a = 0; a < CI; ++a) { const int c = XV ? ci0 + CI * i16 + a : ci0 + a * 16 + i16; xc[a] = c < Cin ? c : 0; }
 #pragma unroll
-    for (int b = 0; b < CO; ++b) { gc[b] = co0 + b * 16 + i16; gok[b] = gc[b] < Cout; gc[b] = gok[b] ? gc[b] : 0; }
-    constexpr int U = CI * CO >= 8 ? 4 : 8;                        // row groups in flight (narrow layers are load-latency bound)
-    for (long gr = g0; gr < g1; gr += U) {
-        float xv[U][CI], gv[U][CO];
+    for (int b = 0; b < CO; ++b) { const int c = GV ? co0 + CO * i16 + b : co0 + b * 16 + i16; gc[b] = c < Cout ? c : 0; }
+    constexpr int U = CI * CO >= 8 ? 4 : 8;                        // row groups per trip (narrow layers are load-latency bound)
+    auto load = [&](float (&xv)[U][CI], float (&gv)[U][CO], long gr) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long row = (gr + u) * 4 + k4;
-            const bool live = gr + u < g1 && row < M;
-            const long rc = live ? row : 0;
+            const long row = (gr + u) * 4 + k4, rc = row < M ? row : M - 1;
+            if (XV) {
+                const typename VecOf<CI>::T v = *reinterpret_cast<const typename VecOf<CI>::T *>(x + rc * Cin + xc[0]);
+                const float *f = reinterpret_cast<const float *>(&v);
 #pragma unroll
-            // (a multiply, not a select: behind a select the compiler predicates the LOAD, and every predicated load is a
-            //  branch plus a full s_waitcnt -- 32 dependent round trips per trip instead of one)
-            for (int a = 0; a < CI; ++a) xv[u][a] = x[rc * Cin + xc[a]] * (live && xok[a] ? 1.f : 0.f);
+                for (int a = 0; a < CI; ++a) xv[u][a] = f[a];
+            } else {
 #pragma unroll
-            for (int b = 0; b < CO; ++b) gv[u][b] = g[rc * Cout + gc[b]] * (live && gok[b] ? 1.f : 0.f);
+                for (int a = 0; a < CI; ++a) xv[u][a] = x[rc * Cin + xc[a]];
+            }
+            if (GV) {
+                const typename VecOf<CO>::T v = *reinterpret_cast<const typename VecOf<CO>::T *>(g + rc * Cout + gc[0]);
+                const float *f = reinterpret_cast<const float *>(&v);
+#pragma unroll
+                for (int b = 0; b < CO; ++b) gv[u][b] = f[b];
+            } else {
+#pragma unroll
+                for (int b = 0; b < CO; ++b) gv[u][b] = g[rc * Cout + gc[b]];
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);         // ALL loads of the trip go out before the first MFMA waits for one (left to
-                                                   // itself the scheduler interleaves them per row group: four round trips)
+    };
+    auto use = [&](float (&xv)[U][CI], float (&gv)[U][CO], long gr) {
+        if (gr + U > g1 || (gr + U) * 4 > M) {                    // a ragged trip: rows past the slice or the matrix count for nothing
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float w = gr + u < g1 && (gr + u) * 4 + k4 < M ? 1.f : 0.f;
+#pragma unroll
+                for (int b = 0; b < CO; ++b) gv[u][b] *= w;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -299,6 +333,18 @@ __global__ __launch_bounds__(TB, 2) void weight_grad_kernel(const float *__restr
 #pragma unroll
             for (int b = 0; b < CO; ++b) bsum[b] += gv[u][b];
         }
+    };
+    float xa[U][CI], ga[U][CO], xb[U][CI], gb[U][CO];
+    load(xa, ga, g0);
+#pragma unroll 1
+    for (long gr = g0; gr < g1; gr += 2 * U) {
+        load(xb, gb, gr + U);
+        __builtin_amdgcn_sched_barrier(0);         // the loads go out before the MFMAs that hide them
+        use(xa, ga, gr);
+        __builtin_amdgcn_sched_barrier(0);
+        load(xa, ga, gr + 2 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        if (gr + U < g1) use(xb, gb, gr + U);
         __builtin_amdgcn_sched_barrier(0);
     }
     float *dst = part + (size_t)blockIdx.x * Cin * Cout;
@@ -306,10 +352,10 @@ __global__ __launch_bounds__(TB, 2) void weight_grad_kernel(const float *__restr
     for (int a = 0; a < CI; ++a)
 #pragma unroll
         for (int b = 0; b < CO; ++b) {
-            const int co = co0 + b * 16 + i16;
+            const int co = GV ? co0 + CO * i16 + b : co0 + b * 16 + i16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ci = ci0 + a * 16 + 4 * k4 + r;
+                const int i = 4 * k4 + r, ci = XV ? ci0 + CI * i + a : ci0 + a * 16 + i;
                 if (ci < Cin && co < Cout) dst[(size_t)ci * Cout + co] = acc[a][b][r];
             }
         }
@@ -319,7 +365,7 @@ __global__ __launch_bounds__(TB, 2) void weight_grad_kernel(const float *__restr
             float v = bsum[b];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            const int co = co0 + b * 16 + i16;
+            const int co = GV ? co0 + CO * i16 + b : co0 + b * 16 + i16;
             if (k4 == 0 && co < Cout) bpart[(size_t)blockIdx.x * Cout + co] = v;
         }
     }
@@ -465,12 +511,22 @@ extern "C" int elo_dense_weight_grad(const elo_weight_grad_args *a, elo_stream_t
     }
     const int gy = (cit + CI - 1) / CI, gz = (cot + CO - 1) / CO, nb = gy * gz, wpb = nb < TB / 64 ? nb : TB / 64;
     const dim3 grid((unsigned)slices, (unsigned)((nb + wpb - 1) / wpb));
+    // vector loads: the tile count is a vector width (1, 2, 4), every block of the grid is whole, rows stay 16-byte aligned
+    const bool xv = CI != 3 && a->Cin % (16 * CI) == 0 && ((uintptr_t)a->x & 15) == 0;
+    const bool gv = a->Cout % (16 * CO) == 0 && ((uintptr_t)a->g & 15) == 0;
+#define ELO_WG4(CI_, CO_, XV_, GV_)                                                                                           \
+    hipLaunchKernelGGL((weight_grad_kernel<CI_, CO_, XV_, GV_>), grid, dim3(64 * wpb), 0, s, a->x, a->g, a->rows, a->Cin, a->Cout, gy, gz, \
+                       a->scratch, bpart)
 #define ELO_WG(CI_, CO_)                                                                                                      \
-    if (CI == CI_ && CO == CO_)                                                                                               \
-        hipLaunchKernelGGL((weight_grad_kernel<CI_, CO_>), grid, dim3(64 * wpb), 0, s, a->x, a->g, a->rows, a->Cin, a->Cout, gy, gz, \
-                           a->scratch, bpart)
+    if (CI == CI_ && CO == CO_) {                                                                                             \
+        if (xv && gv) ELO_WG4(CI_, CO_, (CI_ != 3), true);                                                                    \
+        else if (gv) ELO_WG4(CI_, CO_, false, true);                                                                          \
+        else if (xv) ELO_WG4(CI_, CO_, (CI_ != 3), false);                                                                    \
+        else ELO_WG4(CI_, CO_, false, false);                                                                                 \
+    }
     ELO_WG(1, 1); ELO_WG(1, 2); ELO_WG(1, 4); ELO_WG(2, 1); ELO_WG(2, 2); ELO_WG(2, 4);
     ELO_WG(3, 1); ELO_WG(3, 2); ELO_WG(3, 4); ELO_WG(4, 1); ELO_WG(4, 2); ELO_WG(4, 4);
+#undef ELO_WG4
 #undef ELO_WG
     const long n = (long)a->Cin * a->Cout;
     const unsigned bw = (unsigned)((n + 15) / 16), bb = a->db ? (unsigned)((a->Cout + 15) / 16) : 0u;
