@@ -117,11 +117,9 @@ PoseLossArgs = _struct("elo_pose_loss_args", [
     ("grad_out", _vp), ("grad_q", _vp * 4), ("grad_t", _vp * 4), ("grad_w_x", _vp), ("grad_w_q", _vp)])
 WeightGradArgs = _struct("elo_weight_grad_args", [
     ("rows", ctypes.c_long), ("Cin", _i), ("Cout", _i), ("x", _vp), ("g", _vp), ("dW", _vp), ("db", _vp), ("scratch", _vp)])
-BN_MAX_PARTS = 512     # ELO_BN_MAX_PARTS
 DenseRowsArgs = _struct("elo_dense_rows_args", [
     ("rows", ctypes.c_long), ("Cin", _i), ("Cout", _i), ("x", _vp), ("W", _vp), ("transposed", _i), ("bias", _vp), ("out", _vp),
     ("scratch", _vp), ("eps", _f), ("momentum", _f), ("mean", _vp), ("invstd", _vp), ("running_mean", _vp), ("running_var", _vp)])
-DENSE_MAX_PARTS = 2048  # ELO_DENSE_MAX_PARTS
 Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i), ("w_plain", _vp),
                               ("products", _i)])
 _l = ctypes.c_long
@@ -191,6 +189,8 @@ SYMBOLS = [
     ("elo_dense_weight_grad", ctypes.c_int, [ctypes.POINTER(WeightGradArgs), _vp]),
     ("elo_dense_rows", ctypes.c_int, [ctypes.POINTER(DenseRowsArgs), _vp]),
     ("elo_dense_rows_supported", ctypes.c_int, [ctypes.c_long, ctypes.c_int, ctypes.c_int]),
+    ("elo_dense_rows_scratch_floats", ctypes.c_long, [ctypes.c_int]),
+    ("elo_bn_scratch_floats", ctypes.c_long, [ctypes.c_int]),
     ("elo_adam_flat", ctypes.c_int, [ctypes.POINTER(AdamFlatArgs), _vp]),
     ("elo_pose_compose", ctypes.c_int, [ctypes.POINTER(PoseComposeArgs), _vp]),
     ("elo_pose_loss", ctypes.c_int, [ctypes.POINTER(PoseLossArgs), _vp]),

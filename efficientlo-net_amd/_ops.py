@@ -631,7 +631,7 @@ def dense_rows(x2, W, bias=None, transposed=False, moments=None):
         L.call("elo_dense_rows", a, x2)
         return out
     eps, momentum, mean, invstd, running_mean, running_var = moments
-    scratch = torch.empty((L.DENSE_MAX_PARTS * 2 * cout,), dtype=torch.float32, device=x2.device)
+    scratch = torch.empty((L.lib().elo_dense_rows_scratch_floats(cout),), dtype=torch.float32, device=x2.device)
     a = L.DenseRowsArgs(x2.shape[0], cin, cout, x2.data_ptr(), Wc.data_ptr(), 1 if transposed else 0, _ptr(bias_c), out.data_ptr(),
                         scratch.data_ptr(), eps, momentum, mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var))
     L.call("elo_dense_rows", a, x2)
@@ -660,7 +660,7 @@ class _DenseBN(torch.autograd.Function):
             z = dense_rows(x2, W, b, moments=(float(eps), float(momentum), mean, invstd, running_mean, running_var))
         else:
             z = torch.addmm(b, x2, W)
-            scratch = torch.empty((L.BN_MAX_PARTS * 2 * C,), dtype=torch.float32, device=dev)
+            scratch = torch.empty((L.lib().elo_bn_scratch_floats(C),), dtype=torch.float32, device=dev)
             L.call("elo_bn_stats", L.BnStatsArgs(M, C, z.data_ptr(), scratch.data_ptr(), float(eps), float(momentum), mean.data_ptr(),
                                                  invstd.data_ptr(), running_mean.data_ptr(), running_var.data_ptr()), z)
         y = torch.empty_like(z)
@@ -676,7 +676,7 @@ class _DenseBN(torch.autograd.Function):
         (dy,) = _f32(dy)
         M, C = z.shape
         dev = z.device
-        scratch = torch.empty((L.BN_MAX_PARTS * 2 * C,), dtype=torch.float32, device=dev)
+        scratch = torch.empty((L.lib().elo_bn_scratch_floats(C),), dtype=torch.float32, device=dev)
         sums = torch.empty((2 * C,), dtype=torch.float32, device=dev)
         dz = torch.empty_like(z)
         L.call("elo_bn_backward", L.BnBackwardArgs(M, C, dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g.data_ptr(),

@@ -294,24 +294,26 @@ __global__ __launch_bounds__(TB, 2) void weight_grad_kernel(const float *__restr
     auto load = [&](float (&xv)[U][CI], float (&gv)[U][CO], long gr) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long row = (gr + u) * 4 + k4, rc = row < M ? row : M - 1;
+            // (32-bit element offsets -- the launcher bounds rows * width by 2^31 --: a min, a multiply-add and the scaled-offset
+            //  addressing mode instead of ~12 64-bit VALU instructions per load, ~100 per trip beside its 64 MFMAs)
+            const unsigned row = (unsigned)(gr + u) * 4u + (unsigned)k4, rc = row < (unsigned)M ? row : (unsigned)M - 1u;
             if (XV) {
-                const typename VecOf<CI>::T v = *reinterpret_cast<const typename VecOf<CI>::T *>(x + rc * Cin + xc[0]);
+                const typename VecOf<CI>::T v = *reinterpret_cast<const typename VecOf<CI>::T *>(x + (rc * (unsigned)Cin + (unsigned)xc[0]));
                 const float *f = reinterpret_cast<const float *>(&v);
 #pragma unroll
                 for (int a = 0; a < CI; ++a) xv[u][a] = f[a];
             } else {
 #pragma unroll
-                for (int a = 0; a < CI; ++a) xv[u][a] = x[rc * Cin + xc[a]];
+                for (int a = 0; a < CI; ++a) xv[u][a] = x[rc * (unsigned)Cin + (unsigned)xc[a]];
             }
             if (GV) {
-                const typename VecOf<CO>::T v = *reinterpret_cast<const typename VecOf<CO>::T *>(g + rc * Cout + gc[0]);
+                const typename VecOf<CO>::T v = *reinterpret_cast<const typename VecOf<CO>::T *>(g + (rc * (unsigned)Cout + (unsigned)gc[0]));
                 const float *f = reinterpret_cast<const float *>(&v);
 #pragma unroll
                 for (int b = 0; b < CO; ++b) gv[u][b] = f[b];
             } else {
 #pragma unroll
-                for (int b = 0; b < CO; ++b) gv[u][b] = g[rc * Cout + gc[b]];
+                for (int b = 0; b < CO; ++b) gv[u][b] = g[rc * (unsigned)Cout + (unsigned)gc[b]];
             }
         }
     };
@@ -435,6 +437,8 @@ void bn_finalize_launch(const float *part, int parts, long M, int C, float eps, 
 
 using namespace elo;
 
+extern "C" long elo_bn_scratch_floats(int C) { return 2l * C * ELO_BN_MAX_PARTS; }
+
 extern "C" int elo_bn_stats(const elo_bn_stats_args *a, elo_stream_t stream)
 {
     const char *who = "elo_bn_stats";
@@ -497,6 +501,7 @@ extern "C" int elo_dense_weight_grad(const elo_weight_grad_args *a, elo_stream_t
     if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
     if (a->rows <= 0 || a->Cin <= 0 || a->Cout <= 0) return fail(ELO_ERR_ARG, "%s: bad sizes", who);
     if (!a->x || !a->g || !a->dW || !a->scratch) return fail(ELO_ERR_ARG, "%s: null tensor pointer", who);
+    if (a->rows * (long)(a->Cin > a->Cout ? a->Cin : a->Cout) >= (1l << 31)) return fail(ELO_ERR_LIMIT, "%s: rows * width >= 2^31 (32-bit element offsets)", who);
     const int cit = (a->Cin + 15) / 16, cot = (a->Cout + 15) / 16;
     const int slices = elo_weight_grad_slices(a->rows, a->Cin, a->Cout);
     float *bpart = a->db ? a->scratch + (size_t)slices * a->Cin * a->Cout : nullptr;

