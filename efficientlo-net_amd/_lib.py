@@ -119,7 +119,8 @@ WeightGradArgs = _struct("elo_weight_grad_args", [
     ("rows", ctypes.c_long), ("Cin", _i), ("Cout", _i), ("x", _vp), ("g", _vp), ("dW", _vp), ("db", _vp), ("scratch", _vp)])
 DenseRowsArgs = _struct("elo_dense_rows_args", [
     ("rows", ctypes.c_long), ("Cin", _i), ("Cout", _i), ("x", _vp), ("W", _vp), ("transposed", _i), ("bias", _vp), ("out", _vp),
-    ("scratch", _vp), ("eps", _f), ("momentum", _f), ("mean", _vp), ("invstd", _vp), ("running_mean", _vp), ("running_var", _vp)])
+    ("scratch", _vp), ("eps", _f), ("momentum", _f), ("mean", _vp), ("invstd", _vp), ("running_mean", _vp), ("running_var", _vp),
+    ("bn_z", _vp), ("bn_mean", _vp), ("bn_invstd", _vp), ("bn_gamma", _vp), ("bn_beta", _vp), ("bn_sums", _vp), ("bn_relu", _i), ("bn_dz", _vp)])
 Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i), ("w_plain", _vp),
                               ("products", _i)])
 _l = ctypes.c_long

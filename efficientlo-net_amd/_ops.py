@@ -607,6 +607,10 @@ def dense_bn_supported(x2, cout):
     return x2.is_cuda and x2.dtype == torch.float32 and 4 <= cout <= 256 and cout & (cout - 1) == 0 and x2.shape[0] > 0
 
 
+def _aligned16(*ts):
+    return all(t.data_ptr() % 16 == 0 for t in ts)
+
+
 def dense_rows_supported(x2, W):
     """elo_dense_rows takes fp32 (rows, Cin) x (Cin, Cout) on the GPU with Cout <= 192 and W within 160 KB of LDS."""
     return (x2.is_cuda and x2.dtype == torch.float32 and W.dtype == torch.float32 and x2.shape[0] > 0
@@ -614,10 +618,12 @@ def dense_rows_supported(x2, W):
             and bool(L.lib().elo_dense_rows_supported(x2.shape[0], W.shape[1], W.shape[0])))
 
 
-def dense_rows(x2, W, bias=None, transposed=False, moments=None):
+def dense_rows(x2, W, bias=None, transposed=False, moments=None, bn_backward=None):
     """x2 @ W + bias ((rows, Cin) x (Cin, Cout)), or x2 @ W.t() with transposed=True ((rows, Cout) x (Cin, Cout)^T), on
     csrc/elo_train_dense.hip.  moments = (eps, momentum, mean, invstd, running_mean, running_var): also the batch-norm moments of
-    the result, written into mean / invstd (and the moving averages updated) -- what elo_bn_stats does in a second pass."""
+    the result, written into mean / invstd (and the moving averages updated) -- what elo_bn_stats does in a second pass.
+    bn_backward = (z, mean, invstd, gamma, beta, sums, relu, dz_out): x2 holds dy of a batch-normalised layer and the operand is that
+    layer's dz, formed on the load from dy, z and the two sums of elo_bn_backward(dz=None) and written into dz_out on the way."""
     L.require_gpu(x2, W)
     x2, Wc = x2.contiguous(), W.detach().contiguous()
     cin, cout = (Wc.shape[1], Wc.shape[0]) if transposed else (Wc.shape[0], Wc.shape[1])
@@ -626,14 +632,19 @@ def dense_rows(x2, W, bias=None, transposed=False, moments=None):
     out = torch.empty((x2.shape[0], cout), dtype=torch.float32, device=x2.device)
     bias_c = bias.detach().contiguous() if bias is not None else None
     if moments is None:
+        bn = (None,) * 6 + (0, None)
+        if bn_backward is not None:
+            z, mean, invstd, gamma, beta, sums, relu, dz_out = bn_backward
+            bn = (z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), 1 if relu else 0, dz_out.data_ptr())
         a = L.DenseRowsArgs(x2.shape[0], cin, cout, x2.data_ptr(), Wc.data_ptr(), 1 if transposed else 0, _ptr(bias_c), out.data_ptr(),
-                            None, 0.0, 0.0, None, None, None, None)
+                            None, 0.0, 0.0, None, None, None, None, *bn)
         L.call("elo_dense_rows", a, x2)
         return out
     eps, momentum, mean, invstd, running_mean, running_var = moments
     scratch = torch.empty((L.lib().elo_dense_rows_scratch_floats(cout),), dtype=torch.float32, device=x2.device)
     a = L.DenseRowsArgs(x2.shape[0], cin, cout, x2.data_ptr(), Wc.data_ptr(), 1 if transposed else 0, _ptr(bias_c), out.data_ptr(),
-                        scratch.data_ptr(), eps, momentum, mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var))
+                        scratch.data_ptr(), eps, momentum, mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
+                        None, None, None, None, None, None, 0, None)
     L.call("elo_dense_rows", a, x2)
     return out
 
@@ -679,14 +690,18 @@ class _DenseBN(torch.autograd.Function):
         scratch = torch.empty((L.lib().elo_bn_scratch_floats(C),), dtype=torch.float32, device=dev)
         sums = torch.empty((2 * C,), dtype=torch.float32, device=dev)
         dz = torch.empty_like(z)
+        own_dx = ctx.needs_input_grad[0] and ctx.own_dense and M >= tuning.get("train_dense_dx_rows")
+        fused = own_dx and tuning.get("train_dense_fused_dz") and _aligned16(mean, invstd, g, bt)
+        # (fused: the reduction's two launches only -- dz is formed by the dx kernel on its operand load and written from there)
         L.call("elo_bn_backward", L.BnBackwardArgs(M, C, dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g.data_ptr(),
                                                    bt.data_ptr(), 1 if ctx.relu else 0, scratch.data_ptr(), sums.data_ptr(),
-                                                   dz.data_ptr()), z)
+                                                   None if fused else dz.data_ptr()), z)
         dbeta, dgamma = sums[:C], sums[C:]
         dx = None
-        if ctx.needs_input_grad[0]:
-            own = ctx.own_dense and M >= tuning.get("train_dense_dx_rows")
-            dx = dense_rows(dz, W, None, transposed=True) if own else dz @ W.t()
+        if fused:
+            dx = dense_rows(dy, W, None, transposed=True, bn_backward=(z, mean, invstd, g, bt, sums, ctx.relu, dz))
+        elif ctx.needs_input_grad[0]:
+            dx = dense_rows(dz, W, None, transposed=True) if own_dx else dz @ W.t()
         cin = W.shape[0]
         dW = torch.empty_like(W, memory_format=torch.contiguous_format)
         db = torch.empty((C,), dtype=torch.float32, device=dev)

@@ -469,12 +469,13 @@ extern "C" int elo_bn_backward(const elo_bn_backward_args *a, elo_stream_t strea
 {
     const char *who = "elo_bn_backward";
     if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
-    if (int rc = check_bn(who, a->rows, a->C, {a->dy, a->z, a->mean, a->invstd, a->gamma, a->beta, a->scratch, a->sums, a->dz})) return rc;
+    if (int rc = check_bn(who, a->rows, a->C, {a->dy, a->z, a->mean, a->invstd, a->gamma, a->beta, a->scratch, a->sums, a->dz ? a->dz : a->sums})) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int parts = grid_for(a->rows, a->C);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(parts), dim3(TB), 0, s, a->dy, a->z, a->rows, a->C, a->mean, a->invstd,
                        a->gamma, a->beta, a->relu, a->scratch);
     hipLaunchKernelGGL(bn_bwd_combine_kernel, dim3(a->C), dim3(64), 0, s, a->scratch, parts, a->C, a->sums);
+    if (!a->dz) return check_launch(who);
     const long n4 = a->rows * (a->C >> 2);
     const long blocks = (n4 + TB * 4 - 1) / (TB * 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(TB), 0, s, a->dy, a->z, n4, a->rows, a->C,

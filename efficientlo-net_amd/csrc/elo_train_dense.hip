@@ -42,17 +42,28 @@ __device__ __forceinline__ float row_sum(float v)
     return v;
 }
 
-template <int NT> struct RowBlocks { static constexpr int value = NT <= 1 ? 8 : NT <= 4 ? 4 : 2; };
+template <int NT, bool BNB = false> struct RowBlocks { static constexpr int value = NT <= 1 ? (BNB ? 4 : 8) : NT <= 4 ? (BNB && NT <= 2 ? 2 : 4) : 2; };   // (BNB: two operand streams)
 template <int NT> struct MinBlocks { static constexpr int value = NT <= 2 ? 4 : 2; };     // workgroups per CU the register budget allows
+
+// BNB: the x operand is not read but FORMED -- batch norm's backward applied on the way in (x holds dy; bn.z the layer's
+// pre-normalisation output, its moments / gamma / beta and the two sums elo_bn_backward's reduction left): the arithmetic of
+// bn_bwd_apply_kernel per element, dz = gamma invstd (g - sum_g / M - xhat sum_gxhat / M); the wave that loads an element also WRITES dz
+// (the weight gradient reads it), so the bn_bwd_apply launch and its pass over (rows, C) are gone from the big layers' backward.
+struct BnBack {
+    const float *z, *mean, *invstd, *gamma, *beta, *sums;
+    float *dz;
+    int relu;
+    float inv_m;
+};
 
 // out(rows, N) = x(rows, K) W (+ bias);  W: (K, N) row-major, or (N, K) row-major when `transposed` (out = x W^T).
 // nt = ceil(N / 16) <= NT.  part (STATS): [block][2][N] partial sums of out and out^2.
-template <int NT, bool VEC, bool STATS, bool FULL>       // FULL: nt == NT, no per-tile branch splits the MFMA stream
+template <int NT, bool VEC, bool STATS, bool FULL, bool BNB>  // FULL: nt == NT, no per-tile branch splits the MFMA stream
 __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ bias,
                                                          float *__restrict__ out, long M, int K, int N, int nt, int transposed,
-                                                         float *__restrict__ part)
+                                                         float *__restrict__ part, const BnBack bn)
 {
-    constexpr int RB = RowBlocks<NT>::value;
+    constexpr int RB = RowBlocks<NT, BNB>::value;
     extern __shared__ float4 wl[];                          // [KC][nt][64] x 4 steps, then (STATS) the waves' column sums
     const int KC = (K + 15) >> 4;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
@@ -103,6 +114,24 @@ __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(c
             }
         }
     }
+    // BNB: per channel quad of the reduction index, seven vectors: xhat = z A + B;  pre-activation = xhat G + Bt;  dz = P g + Q + R xhat
+    float4 *tbl = wl + KC * nt * 64;
+    if (BNB) {
+        for (int i = threadIdx.x; i < (K >> 2); i += DTB) {
+            const float4 m = reinterpret_cast<const float4 *>(bn.mean)[i], sd = reinterpret_cast<const float4 *>(bn.invstd)[i];
+            const float4 g = reinterpret_cast<const float4 *>(bn.gamma)[i], b = reinterpret_cast<const float4 *>(bn.beta)[i];
+            const float4 s1 = reinterpret_cast<const float4 *>(bn.sums)[i], s2 = reinterpret_cast<const float4 *>(bn.sums + K)[i];
+            const float im = bn.inv_m;
+            tbl[i * 7 + 0] = sd;
+            tbl[i * 7 + 1] = float4{-m.x * sd.x, -m.y * sd.y, -m.z * sd.z, -m.w * sd.w};
+            tbl[i * 7 + 2] = g;
+            tbl[i * 7 + 3] = b;
+            const float4 P{g.x * sd.x, g.y * sd.y, g.z * sd.z, g.w * sd.w};
+            tbl[i * 7 + 4] = P;
+            tbl[i * 7 + 5] = float4{-P.x * s1.x * im, -P.y * s1.y * im, -P.z * s1.z * im, -P.w * s1.w * im};
+            tbl[i * 7 + 6] = float4{-P.x * s2.x * im, -P.y * s2.y * im, -P.z * s2.z * im, -P.w * s2.w * im};
+        }
+    }
     __syncthreads();
     const bool vec_store = (N & 3) == 0;
     f32x4 bq[NT];                                           // this lane's four channels of every tile: 16t + 4q ..
@@ -132,13 +161,15 @@ __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(c
     };
     // (the loads only: columns past K are read from a clamped address and weighted out WHERE THEY ARE USED -- weighting them here
     //  made every fetch wait for its own loads, i.e. no prefetch at all: the first form's matrix pipe idled 60 % of the time)
-    auto fetch = [&](f32x4 (&dst)[RB], const float *const (&xr)[RB], int c) {
+    const long zoff = BNB ? bn.z - x : 0;                   // z and dz have x's shape: the same element offsets
+    auto fetch = [&](f32x4 (&dst)[RB], f32x4 (&zdst)[BNB ? RB : 1], const float *const (&xr)[RB], int c) {
         if (VEC) {
             const int k0 = 16 * c + 4 * q, kc = k0 < K ? k0 : 0;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const float4 v = *reinterpret_cast<const float4 *>(xr[rb] + kc);
                 dst[rb] = f32x4{v.x, v.y, v.z, v.w};
+                if (BNB) { const float4 w = *reinterpret_cast<const float4 *>(xr[rb] + zoff + kc); zdst[rb] = f32x4{w.x, w.y, w.z, w.w}; }
             }
         } else {
 #pragma unroll
@@ -156,11 +187,11 @@ __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(c
         return m;
     };
     const float *xc[RB], *xn[RB];
-    f32x4 xb[D][RB];
+    f32x4 xb[D][RB], zb[BNB ? D : 1][BNB ? RB : 1];
     rows_of(first < macro ? first : 0, xc);
     if (D > 1) {
 #pragma unroll
-        for (int d = 0; d < D - 1; ++d) fetch(xb[d], xc, d);
+        for (int d = 0; d < D - 1; ++d) fetch(xb[d], zb[BNB ? d : 0], xc, d);
     }
 #pragma unroll 1
     for (long mb = first; mb < macro; mb += stride) {
@@ -186,9 +217,30 @@ __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(c
                     const float *xf[RB];
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) xf[rb] = here ? xc[rb] : xn[rb];
-                    fetch(xb[(u + D - 1) % D], xf, here ? cf : cf - KCp);
-                } else fetch(xb[0], xc, c);
+                    fetch(xb[(u + D - 1) % D], zb[BNB ? (u + D - 1) % D : 0], xf, here ? cf : cf - KCp);
+                } else fetch(xb[0], zb[0], xc, c);
                 if (c < KC) {
+                    if (BNB) {
+                        const int k0 = 16 * c + 4 * q, i = (k0 < K ? k0 : 0) >> 2;
+                        const float4 tA = tbl[i * 7 + 0], tB = tbl[i * 7 + 1], tG = tbl[i * 7 + 2], tT = tbl[i * 7 + 3];
+                        const float4 tP = tbl[i * 7 + 4], tQ = tbl[i * 7 + 5], tR = tbl[i * 7 + 6];
+                        const f32x4 A{tA.x, tA.y, tA.z, tA.w}, B{tB.x, tB.y, tB.z, tB.w}, G{tG.x, tG.y, tG.z, tG.w}, T{tT.x, tT.y, tT.z, tT.w};
+                        const f32x4 P{tP.x, tP.y, tP.z, tP.w}, Q{tQ.x, tQ.y, tQ.z, tQ.w}, R{tR.x, tR.y, tR.z, tR.w};
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) {
+                            const f32x4 xh = zb[BNB ? u : 0][rb] * A + B;
+                            f32x4 g = xb[u][rb];
+                            if (bn.relu) {
+                                const f32x4 pre = xh * G + T;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) g[e] = pre[e] > 0.f ? g[e] : 0.f;
+                            }
+                            const f32x4 d = P * g + Q + R * xh;
+                            xb[u][rb] = d;
+                            const long row = row0 + rb * 16 + j;
+                            if (row < M && k0 < K) *reinterpret_cast<float4 *>(bn.dz + (xc[rb] - x) + k0) = float4{d[0], d[1], d[2], d[3]};
+                        }
+                    }
                     if (16 * c + 16 > K) {                  // the ragged last chunk
                         const f32x4 m = weights(c);
 #pragma unroll
@@ -284,7 +336,7 @@ __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(c
 
 struct Plan { int NT, nt, KC, grid; size_t lds; };
 
-bool plan_dense(long M, int K, int N, bool stats, Plan &p)
+bool plan_dense(long M, int K, int N, bool stats, Plan &p, bool bnb = false)
 {
     p.nt = (N + 15) / 16;
     p.NT = p.nt <= 1 ? 1 : p.nt <= 2 ? 2 : p.nt <= 4 ? 4 : p.nt <= 8 ? 8 : 12;
@@ -293,10 +345,11 @@ bool plan_dense(long M, int K, int N, bool stats, Plan &p)
     p.lds = (size_t)p.KC * p.nt * 64 * sizeof(float4);
     const size_t red = stats ? (size_t)(DTB / 64) * 2 * 16 * p.nt * sizeof(float) : 0;
     if (p.lds < red) p.lds = red;
+    if (bnb) p.lds += (size_t)(K / 4) * 7 * sizeof(float4);
     if (p.lds > 160 * 1024) return false;
     // a resident grid: the workgroups the 256 CUs hold at once (registers: 4 per CU for the narrow forms, 2 for the wide; LDS),
     // twice that for the narrow streaming forms
-    const int rb = p.NT <= 1 ? 8 : p.NT <= 4 ? 4 : 2;
+    const int rb = p.NT <= 1 ? (bnb ? 4 : 8) : p.NT <= 4 ? (bnb && p.NT <= 2 ? 2 : 4) : 2;          // RowBlocks<NT, BNB>
     const long macro = (M + 16 * rb - 1) / (16 * rb), blocks = (macro + DTB / 64 - 1) / (DTB / 64);
     int per_cu = p.NT <= 2 ? 4 : 2;
     const int by_lds = (int)((160 * 1024) / (p.lds ? p.lds : 1));
@@ -307,10 +360,11 @@ bool plan_dense(long M, int K, int N, bool stats, Plan &p)
     return true;
 }
 
-template <int NT, bool VEC, bool STATS, bool FULL>
+template <int NT, bool VEC, bool STATS, bool FULL, bool BNB = false>
 int launch_one(const Plan &p, const elo_dense_rows_args *a, hipStream_t s)
 {
-    auto kern = dense_rows_kernel<NT, VEC, STATS, FULL>;
+    auto kern = dense_rows_kernel<NT, VEC, STATS, FULL, BNB>;
+    const BnBack bn{a->bn_z, a->bn_mean, a->bn_invstd, a->bn_gamma, a->bn_beta, a->bn_sums, a->bn_dz, a->bn_relu, 1.0f / (float)a->rows};
     static bool raised = false;                              // > 64 KB of dynamic LDS has to be asked for, once per kernel
     if (!raised && p.lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -318,7 +372,7 @@ int launch_one(const Plan &p, const elo_dense_rows_args *a, hipStream_t s)
         raised = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(DTB), p.lds, s, a->x, a->W, a->bias, a->out, a->rows, a->Cin, a->Cout, p.nt,
-                       a->transposed, a->scratch);
+                       a->transposed, a->scratch, bn);
     return ELO_OK;
 }
 
@@ -327,6 +381,7 @@ int launch_nt(const Plan &p, const elo_dense_rows_args *a, hipStream_t s)
 {
     const bool vec = (a->Cin & 3) == 0, stats = a->scratch != nullptr;
     const bool full = p.nt == NT;
+    if (a->bn_z) return full ? launch_one<NT, true, false, true, true>(p, a, s) : launch_one<NT, true, false, false, true>(p, a, s);
 #define ELO_DR(V, S) (full ? launch_one<NT, V, S, true>(p, a, s) : launch_one<NT, V, S, false>(p, a, s))
     if (vec) return stats ? ELO_DR(true, true) : ELO_DR(true, false);
     return stats ? ELO_DR(false, true) : ELO_DR(false, false);
@@ -356,8 +411,16 @@ extern "C" int elo_dense_rows(const elo_dense_rows_args *a, elo_stream_t stream)
     const bool stats = a->scratch != nullptr;
     if (stats && (!a->mean || !a->invstd)) return fail(ELO_ERR_ARG, "%s: moments asked for without mean / invstd", who);
     if (stats && (a->running_mean == nullptr) != (a->running_var == nullptr)) return fail(ELO_ERR_ARG, "%s: running_mean and running_var go together", who);
+    const bool bnb = a->bn_z != nullptr;
+    if (bnb) {
+        if (stats || (a->Cin & 3) || !a->bn_mean || !a->bn_invstd || !a->bn_gamma || !a->bn_beta || !a->bn_sums || !a->bn_dz)
+            return fail(ELO_ERR_ARG, "%s: the batch-norm-backward operand needs Cin %% 4 == 0, no moments, and all of mean / invstd / gamma / beta / sums / dz", who);
+        if (((uintptr_t)a->bn_z | (uintptr_t)a->bn_dz | (uintptr_t)a->bn_mean | (uintptr_t)a->bn_invstd | (uintptr_t)a->bn_gamma | (uintptr_t)a->bn_beta |
+             (uintptr_t)a->bn_sums) & 15)
+            return fail(ELO_ERR_ARG, "%s: unaligned batch-norm-backward tensor", who);
+    }
     Plan p;
-    if (!plan_dense(a->rows, a->Cin, a->Cout, stats, p))
+    if (!plan_dense(a->rows, a->Cin, a->Cout, stats, p, bnb))
         return fail(ELO_ERR_LIMIT, "%s: Cin = %d, Cout = %d does not fit (<= 192 output columns, W <= 160 KB of LDS)", who, a->Cin, a->Cout);
     hipStream_t s = (hipStream_t)stream;
     int rc = ELO_OK;

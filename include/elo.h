@@ -527,7 +527,7 @@ typedef struct elo_bn_backward_args {
     int relu;
     float *scratch;               /* (ELO_BN_MAX_PARTS, 2, C) */
     float *sums;                  /* (2*C) OUT [d beta | d gamma] */
-    float *dz;                    /* (rows,C) OUT (may alias dy) */
+    float *dz;                    /* (rows,C) OUT (may alias dy); NULL: the sums only (two launches) -- dz is then formed by elo_dense_rows */
 } elo_bn_backward_args;
 int elo_bn_backward(const elo_bn_backward_args *a, elo_stream_t stream);
 
@@ -561,6 +561,12 @@ typedef struct elo_dense_rows_args {
     float eps, momentum;
     float *mean, *invstd;         /* (Cout) OUT when scratch != NULL */
     float *running_mean, *running_var;   /* (Cout) IN/OUT or both NULL */
+    /* bn_z != NULL (dx = dz W^T of a batch-normalised layer; Cin = that layer's width, % 4 == 0; no moments): x holds dy and the operand
+     * is dz = gamma invstd (g - sum_g / rows - xhat sum_gxhat / rows), formed on the load and ALSO written to bn_dz (rows,Cin) --
+     * elo_bn_backward's third launch inside this pass.  bn_sums: its (2*Cin) [sum g | sum g xhat]. */
+    const float *bn_z, *bn_mean, *bn_invstd, *bn_gamma, *bn_beta, *bn_sums;
+    int bn_relu;
+    float *bn_dz;
 } elo_dense_rows_args;
 int elo_dense_rows_supported(long rows, int Cin, int Cout);
 long elo_dense_rows_scratch_floats(int Cout);

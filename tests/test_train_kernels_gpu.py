@@ -291,6 +291,33 @@ def test_dense_rows_rejects_what_it_cannot_run():
         ops.dense_rows(x.cpu(), torch.randn(16, 8))                                # no CPU path
 
 
+@pytest.mark.parametrize("rows,c,cin,relu", [(1000, 8, 6, True), (5001, 16, 19, True), (3000, 32, 16, False), (2049, 64, 128, True), (4100, 128, 67, True),
+                                             (777, 128, 138, True), (130001, 64, 64, True)])
+def test_dense_rows_forms_dz_on_its_operand_load(rows, c, cin, relu):
+    """dx = dz W^T with dz = batch norm's backward formed inside the kernel (elo_bn_backward(dz=NULL) + elo_dense_rows(bn_*)) against the three-
+    launch elo_bn_backward followed by the plain product: the same dz (same arithmetic per element: a few ulp) and the same dx."""
+    ops, L = load_pkg("_ops"), load_pkg("_lib")
+    g = torch.Generator(device="cpu").manual_seed(rows + c)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    dy, z, W = r(rows, c), r(rows, c) * 1.5 + 0.3, r(cin, c) * 0.2
+    gamma, beta = r(c) * 0.3 + 1.0, r(c) * 0.3
+    mean, var = z.mean(0), z.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-3)
+    scratch = torch.empty(L.lib().elo_bn_scratch_floats(c), device=DEV)
+    sums, dz_ref = torch.empty(2 * c, device=DEV), torch.empty_like(z)
+    args = lambda dzp, s: L.BnBackwardArgs(rows, c, dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                           1 if relu else 0, scratch.data_ptr(), s.data_ptr(), dzp)
+    L.call("elo_bn_backward", args(dz_ref.data_ptr(), sums), z)
+    dx_ref = ops.dense_rows(dz_ref, W, None, transposed=True)
+    sums2, dz = torch.empty(2 * c, device=DEV), torch.full_like(z, float("nan"))
+    L.call("elo_bn_backward", args(None, sums2), z)
+    assert torch.equal(sums, sums2)
+    dx = ops.dense_rows(dy, W, None, transposed=True, bn_backward=(z, mean, invstd, gamma, beta, sums2, relu, dz))
+    scale = float(dz_ref.abs().max())
+    assert float((dz - dz_ref).abs().max()) <= 2e-6 * scale
+    assert float((dx - dx_ref).abs().max()) <= 5e-6 * float(dx_ref.abs().max())
+
+
 def test_the_layer_is_the_same_on_both_dense_paths():
     """tuning.train_dense off (library GEMM + elo_bn_stats) and on (elo_dense_rows, moments fused): outputs, moving averages and
     all five gradients of one layer agree to fp32 rounding."""
