@@ -4,7 +4,7 @@
 // Why not the library: these products are TALL AND SKINNY -- 921 600 x 6 -> 8, 230 400 x 67 -> 128 -- and the GEMM kernels torch
 // dispatches to tile for square problems (MT16x256x32 for an 8-wide output): tools/train_layer_shapes.py measures 57-84 us for
 // layers whose operands are 6-22 us of HBM traffic.  One pass over the rows, here:
-//   * W (Cin x Cout, <= 96 KB) is staged ONCE per workgroup into LDS, already in v_mfma_f32_16x16x4_f32 operand order
+//   * W (Cin x Cout, <= 160 KB) is staged ONCE per workgroup into LDS, already in v_mfma_f32_16x16x4_f32 operand order
 //     (one ds_read_b128 per lane = the A operands of four MFMA steps, conflict-free);
 //   * a wave owns blocks of 16 rows x ALL output columns: x streams from HBM straight into the B operand -- 16-byte loads
 //     when Cin % 4 == 0 (the reduction index is visited in the order the loads deliver it: lane (row j, quarter q) holds
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(c
             }
         }
     }
-    // BNB: per channel quad of the reduction index, seven vectors: xhat = z A + B;  pre-activation = xhat G + Bt;  dz = P g + Q + R xhat
+    // BNB: per channel quad of the reduction index, seven vectors: xhat = (z - B) A and pre-activation = xhat G + Bt EXACTLY as the forward's
+    // bn_apply and bn_bwd_apply form them (the ReLU decision must be the forward's, bit for bit);  dz = P g + Q + R xhat
     float4 *tbl = wl + KC * nt * 64;
     if (BNB) {
         for (int i = threadIdx.x; i < (K >> 2); i += DTB) {
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(c
             const float4 s1 = reinterpret_cast<const float4 *>(bn.sums)[i], s2 = reinterpret_cast<const float4 *>(bn.sums + K)[i];
             const float im = bn.inv_m;
             tbl[i * 7 + 0] = sd;
-            tbl[i * 7 + 1] = float4{-m.x * sd.x, -m.y * sd.y, -m.z * sd.z, -m.w * sd.w};
+            tbl[i * 7 + 1] = m;
             tbl[i * 7 + 2] = g;
             tbl[i * 7 + 3] = b;
             const float4 P{g.x * sd.x, g.y * sd.y, g.z * sd.z, g.w * sd.w};
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(c
                         const f32x4 P{tP.x, tP.y, tP.z, tP.w}, Q{tQ.x, tQ.y, tQ.z, tQ.w}, R{tR.x, tR.y, tR.z, tR.w};
 #pragma unroll
                         for (int rb = 0; rb < RB; ++rb) {
-                            const f32x4 xh = zb[BNB ? u : 0][rb] * A + B;
+                            f32x4 xh = zb[BNB ? u : 0][rb] - B;
+                            xh *= A;
                             f32x4 g = xb[u][rb];
                             if (bn.relu) {
                                 const f32x4 pre = xh * G + T;
