@@ -98,13 +98,13 @@ WarpProjectBwdArgs = _struct("elo_warp_project_bwd_args", [
 
 BnStatsArgs = _struct("elo_bn_stats_args", [
     ("rows", ctypes.c_long), ("C", _i), ("z", _vp), ("scratch", _vp), ("eps", _f), ("momentum", _f), ("mean", _vp), ("invstd", _vp),
-    ("running_mean", _vp), ("running_var", _vp)])
+    ("running_mean", _vp), ("running_var", _vp), ("groups", _i)])
 BnApplyArgs = _struct("elo_bn_apply_args", [
     ("rows", ctypes.c_long), ("C", _i), ("z", _vp), ("mean", _vp), ("invstd", _vp), ("gamma", _vp), ("beta", _vp), ("relu", _i),
-    ("y", _vp)])
+    ("y", _vp), ("groups", _i)])
 BnBackwardArgs = _struct("elo_bn_backward_args", [
     ("rows", ctypes.c_long), ("C", _i), ("dy", _vp), ("z", _vp), ("mean", _vp), ("invstd", _vp), ("gamma", _vp), ("beta", _vp),
-    ("relu", _i), ("scratch", _vp), ("sums", _vp), ("dz", _vp)])
+    ("relu", _i), ("scratch", _vp), ("sums", _vp), ("dz", _vp), ("groups", _i)])
 AdamFlatArgs = _struct("elo_adam_flat_args", [
     ("n", ctypes.c_long), ("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("hyper", _vp),
     ("beta1", _f), ("beta2", _f), ("one_minus_beta1", _f), ("one_minus_beta2", _f)])
@@ -120,7 +120,7 @@ WeightGradArgs = _struct("elo_weight_grad_args", [
 DenseRowsArgs = _struct("elo_dense_rows_args", [
     ("rows", ctypes.c_long), ("Cin", _i), ("Cout", _i), ("x", _vp), ("W", _vp), ("transposed", _i), ("bias", _vp), ("out", _vp),
     ("scratch", _vp), ("eps", _f), ("momentum", _f), ("mean", _vp), ("invstd", _vp), ("running_mean", _vp), ("running_var", _vp),
-    ("bn_z", _vp), ("bn_mean", _vp), ("bn_invstd", _vp), ("bn_gamma", _vp), ("bn_beta", _vp), ("bn_sums", _vp), ("bn_relu", _i), ("bn_dz", _vp)])
+    ("bn_z", _vp), ("bn_mean", _vp), ("bn_invstd", _vp), ("bn_gamma", _vp), ("bn_beta", _vp), ("bn_sums", _vp), ("bn_relu", _i), ("bn_dz", _vp), ("groups", _i)])
 Dense = _struct("elo_dense", [("w_packed", _vp), ("bias", _vp), ("K", _i), ("N", _i), ("relu", _i), ("w_plain", _vp),
                               ("products", _i)])
 _l = ctypes.c_long
@@ -190,8 +190,8 @@ SYMBOLS = [
     ("elo_dense_weight_grad", ctypes.c_int, [ctypes.POINTER(WeightGradArgs), _vp]),
     ("elo_dense_rows", ctypes.c_int, [ctypes.POINTER(DenseRowsArgs), _vp]),
     ("elo_dense_rows_supported", ctypes.c_int, [ctypes.c_long, ctypes.c_int, ctypes.c_int]),
-    ("elo_dense_rows_scratch_floats", ctypes.c_long, [ctypes.c_int]),
-    ("elo_bn_scratch_floats", ctypes.c_long, [ctypes.c_int]),
+    ("elo_dense_rows_scratch_floats", ctypes.c_long, [ctypes.c_int, ctypes.c_int]),
+    ("elo_bn_scratch_floats", ctypes.c_long, [ctypes.c_int, ctypes.c_int]),
     ("elo_adam_flat", ctypes.c_int, [ctypes.POINTER(AdamFlatArgs), _vp]),
     ("elo_pose_compose", ctypes.c_int, [ctypes.POINTER(PoseComposeArgs), _vp]),
     ("elo_pose_loss", ctypes.c_int, [ctypes.POINTER(PoseLossArgs), _vp]),

@@ -618,12 +618,13 @@ def dense_rows_supported(x2, W):
             and bool(L.lib().elo_dense_rows_supported(x2.shape[0], W.shape[1], W.shape[0])))
 
 
-def dense_rows(x2, W, bias=None, transposed=False, moments=None, bn_backward=None):
+def dense_rows(x2, W, bias=None, transposed=False, moments=None, bn_backward=None, groups=1):
     """x2 @ W + bias ((rows, Cin) x (Cin, Cout)), or x2 @ W.t() with transposed=True ((rows, Cout) x (Cin, Cout)^T), on
     csrc/elo_train_dense.hip.  moments = (eps, momentum, mean, invstd, running_mean, running_var): also the batch-norm moments of
     the result, written into mean / invstd (and the moving averages updated) -- what elo_bn_stats does in a second pass.
     bn_backward = (z, mean, invstd, gamma, beta, sums, relu, dz_out): x2 holds dy of a batch-normalised layer and the operand is that
-    layer's dz, formed on the load from dy, z and the two sums of elo_bn_backward(dz=None) and written into dz_out on the way."""
+    layer's dz, formed on the load from dy, z and the two sums of elo_bn_backward(dz=None) and written into dz_out on the way.
+    groups > 1: the rows are that many equal blocks with their own batch statistics (mean, invstd (groups, C); sums (groups, 2C))."""
     L.require_gpu(x2, W)
     x2, Wc = x2.contiguous(), W.detach().contiguous()
     cin, cout = (Wc.shape[1], Wc.shape[0]) if transposed else (Wc.shape[0], Wc.shape[1])
@@ -631,54 +632,57 @@ def dense_rows(x2, W, bias=None, transposed=False, moments=None, bn_backward=Non
         raise ValueError("dense_rows: x is %s, W %s%s" % (tuple(x2.shape), tuple(W.shape), " (transposed)" if transposed else ""))
     out = torch.empty((x2.shape[0], cout), dtype=torch.float32, device=x2.device)
     bias_c = bias.detach().contiguous() if bias is not None else None
+    head = (x2.shape[0], cin, cout, x2.data_ptr(), Wc.data_ptr(), 1 if transposed else 0, _ptr(bias_c), out.data_ptr())
     if moments is None:
         bn = (None,) * 6 + (0, None)
         if bn_backward is not None:
             z, mean, invstd, gamma, beta, sums, relu, dz_out = bn_backward
             bn = (z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sums.data_ptr(), 1 if relu else 0, dz_out.data_ptr())
-        a = L.DenseRowsArgs(x2.shape[0], cin, cout, x2.data_ptr(), Wc.data_ptr(), 1 if transposed else 0, _ptr(bias_c), out.data_ptr(),
-                            None, 0.0, 0.0, None, None, None, None, *bn)
+        a = L.DenseRowsArgs(*head, None, 0.0, 0.0, None, None, None, None, *bn, groups)
         L.call("elo_dense_rows", a, x2)
         return out
     eps, momentum, mean, invstd, running_mean, running_var = moments
-    scratch = torch.empty((L.lib().elo_dense_rows_scratch_floats(cout),), dtype=torch.float32, device=x2.device)
-    a = L.DenseRowsArgs(x2.shape[0], cin, cout, x2.data_ptr(), Wc.data_ptr(), 1 if transposed else 0, _ptr(bias_c), out.data_ptr(),
-                        scratch.data_ptr(), eps, momentum, mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
-                        None, None, None, None, None, None, 0, None)
+    scratch = torch.empty((L.lib().elo_dense_rows_scratch_floats(cout, groups),), dtype=torch.float32, device=x2.device)
+    a = L.DenseRowsArgs(*head, scratch.data_ptr(), eps, momentum, mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
+                        None, None, None, None, None, None, 0, None, groups)
     L.call("elo_dense_rows", a, x2)
     return out
 
 
 class _DenseBN(torch.autograd.Function):
-    """y = act(batch_norm(x @ W + b)) with batch statistics.  The two dense products (forward, dx) are library GEMMs; every
-    pass OVER THE ROWS -- the batch moments, the normalisation, the two sums of batch norm's backward, dz, the weight
-    gradient x^T dz and the bias gradient -- is a hand-written kernel (elo_bn_stats / elo_bn_apply / elo_bn_backward /
-    elo_dense_weight_grad).  Saved for backward: x, W, the pre-normalisation z and the (C) moments; the ReLU mask is
-    recomputed from z.  The moving averages are updated in place exactly as F.batch_norm(training=True) does."""
+    """y = act(batch_norm(x @ W + b)) with batch statistics.  The two dense products (forward, dx) run on elo_dense_rows where the layer
+    has enough rows (tuning.train_dense*; the library GEMM below that); every pass OVER THE ROWS -- the batch moments (from the forward
+    product's accumulators on the own kernel), the normalisation, the two sums of batch norm's backward, dz (on the dx kernel's operand
+    load where that runs), the weight gradient x^T dz and the bias gradient -- is a hand-written kernel.  Saved for backward: x, W, the
+    pre-normalisation z and the moments; the ReLU mask is recomputed from z.  The moving averages are updated in place exactly as
+    F.batch_norm(training=True) does.  groups = G > 1: the rows are G equal blocks normalised with their OWN batch statistics (the
+    reference calls the layer once per frame with shared variables, pwclo_model.py:117-143; one call on the 2B batch does the same
+    arithmetic in half the launches): moments (G, C), moving averages updated G times in order."""
 
     @staticmethod
-    def forward(ctx, x2, W, b, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x2, W, b, gamma, beta, running_mean, running_var, momentum, eps, relu, groups):
         x2 = x2.contiguous()
-        M, C = x2.shape[0], W.shape[1]
+        M, C, G = x2.shape[0], W.shape[1], int(groups)
         dev = x2.device
-        mean = torch.empty((C,), dtype=torch.float32, device=dev)
-        invstd = torch.empty((C,), dtype=torch.float32, device=dev)
+        mean = torch.empty((G * C,), dtype=torch.float32, device=dev)
+        invstd = torch.empty((G * C,), dtype=torch.float32, device=dev)
         g, bt = gamma.detach().contiguous(), beta.detach().contiguous()
         ctx.own_dense = bool(tuning.get("train_dense")) and dense_rows_supported(x2, W)
         wide_and_short = W.shape[0] > 128 and M < tuning.get("train_dense_dx_rows")
         if ctx.own_dense and M >= tuning.get("train_dense_rows") and not wide_and_short:
             # the product AND the batch moments in one pass over the rows
-            z = dense_rows(x2, W, b, moments=(float(eps), float(momentum), mean, invstd, running_mean, running_var))
+            z = dense_rows(x2, W, b, moments=(float(eps), float(momentum), mean, invstd, running_mean, running_var), groups=G)
         else:
             z = torch.addmm(b, x2, W)
-            scratch = torch.empty((L.lib().elo_bn_scratch_floats(C),), dtype=torch.float32, device=dev)
+            scratch = torch.empty((L.lib().elo_bn_scratch_floats(C, G),), dtype=torch.float32, device=dev)
             L.call("elo_bn_stats", L.BnStatsArgs(M, C, z.data_ptr(), scratch.data_ptr(), float(eps), float(momentum), mean.data_ptr(),
-                                                 invstd.data_ptr(), running_mean.data_ptr(), running_var.data_ptr()), z)
+                                                 invstd.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), G), z)
         y = torch.empty_like(z)
         L.call("elo_bn_apply", L.BnApplyArgs(M, C, z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g.data_ptr(), bt.data_ptr(),
-                                             1 if relu else 0, y.data_ptr()), z)
+                                             1 if relu else 0, y.data_ptr(), G), z)
         ctx.save_for_backward(x2, W, z, mean, invstd, g, bt)
         ctx.relu = bool(relu)
+        ctx.groups = G
         return y
 
     @staticmethod
@@ -686,20 +690,22 @@ class _DenseBN(torch.autograd.Function):
         x2, W, z, mean, invstd, g, bt = ctx.saved_tensors
         (dy,) = _f32(dy)
         M, C = z.shape
+        G = ctx.groups
         dev = z.device
-        scratch = torch.empty((L.lib().elo_bn_scratch_floats(C),), dtype=torch.float32, device=dev)
-        sums = torch.empty((2 * C,), dtype=torch.float32, device=dev)
+        scratch = torch.empty((L.lib().elo_bn_scratch_floats(C, G),), dtype=torch.float32, device=dev)
+        sums = torch.empty((G * 2 * C,), dtype=torch.float32, device=dev)
         dz = torch.empty_like(z)
         own_dx = ctx.needs_input_grad[0] and ctx.own_dense and M >= tuning.get("train_dense_dx_rows")
         fused = own_dx and tuning.get("train_dense_fused_dz") and _aligned16(mean, invstd, g, bt)
         # (fused: the reduction's two launches only -- dz is formed by the dx kernel on its operand load and written from there)
         L.call("elo_bn_backward", L.BnBackwardArgs(M, C, dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), g.data_ptr(),
                                                    bt.data_ptr(), 1 if ctx.relu else 0, scratch.data_ptr(), sums.data_ptr(),
-                                                   None if fused else dz.data_ptr()), z)
-        dbeta, dgamma = sums[:C], sums[C:]
+                                                   None if fused else dz.data_ptr(), G), z)
+        total = sums if G == 1 else sums.view(G, 2 * C).sum(0)
+        dbeta, dgamma = total[:C], total[C:]
         dx = None
         if fused:
-            dx = dense_rows(dy, W, None, transposed=True, bn_backward=(z, mean, invstd, g, bt, sums, ctx.relu, dz))
+            dx = dense_rows(dy, W, None, transposed=True, bn_backward=(z, mean, invstd, g, bt, sums, ctx.relu, dz), groups=G)
         elif ctx.needs_input_grad[0]:
             dx = dense_rows(dz, W, None, transposed=True) if own_dx else dz @ W.t()
         cin = W.shape[0]
@@ -709,10 +715,12 @@ class _DenseBN(torch.autograd.Function):
         wscratch = torch.empty((slices * (cin * C + C),), dtype=torch.float32, device=dev)
         L.call("elo_dense_weight_grad", L.WeightGradArgs(M, cin, C, x2.data_ptr(), dz.data_ptr(), dW.data_ptr(), db.data_ptr(),
                                                          wscratch.data_ptr()), z)
-        return dx, dW, db, dgamma, dbeta, None, None, None, None, None
+        return dx, dW, db, dgamma, dbeta, None, None, None, None, None, None
 
 
-def dense_bn(x2, W, b, gamma, beta, running_mean, running_var, momentum, eps, relu):
-    """(rows, Cin) -> (rows, Cout): the training layer on the kernels above (dense_bn_supported(x2, Cout) must hold)."""
+def dense_bn(x2, W, b, gamma, beta, running_mean, running_var, momentum, eps, relu, groups=1):
+    """(rows, Cin) -> (rows, Cout): the training layer on the kernels above (dense_bn_supported(x2, Cout) must hold).  groups: see _DenseBN."""
     L.require_gpu(x2, W, gamma, running_mean)
-    return _DenseBN.apply(x2, W, b, gamma, beta, running_mean, running_var, momentum, eps, relu)
+    if groups < 1 or x2.shape[0] % groups:
+        raise ValueError("dense_bn: %d rows do not split into %d groups" % (x2.shape[0], groups))
+    return _DenseBN.apply(x2, W, b, gamma, beta, running_mean, running_var, momentum, eps, relu, groups)

@@ -79,9 +79,12 @@ __device__ __forceinline__ void block_rows(long M, int rpb, long &r0, long &r1)
     r1 = r0 + per * rpb < M ? r0 + per * rpb : M;
 }
 
+// (blockIdx.y: the GROUP of rows -- M rows each, one set of moments per group: the two frames of a Siamese batch are one launch)
 __global__ __launch_bounds__(TB) void bn_stats_kernel(const float *__restrict__ z, long M, int C, float *__restrict__ part)
 {
     __shared__ float4 lds[TB];
+    z += (size_t)blockIdx.y * M * C;
+    part += (size_t)blockIdx.y * gridDim.x * 2 * C;
     const int q = C >> 2, rpb = TB / q, cg = threadIdx.x % q, rr = threadIdx.x / q;
     long r0, r1;
     block_rows(M, rpb, r0, r1);
@@ -107,28 +110,36 @@ __global__ __launch_bounds__(TB) void bn_stats_kernel(const float *__restrict__ 
 // one wave per channel: moments from the partial sums (fp64), F.batch_norm's moving averages (unbiased variance)
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict__ part, int parts, long M, int C, float eps,
                                                         float momentum, float *__restrict__ mean, float *__restrict__ invstd,
-                                                        float *__restrict__ running_mean, float *__restrict__ running_var)
+                                                        float *__restrict__ running_mean, float *__restrict__ running_var, int groups)
 {
     const int c = blockIdx.x;
-    double s, ss;
-    combine(part, parts, C, c, s, ss);
-    if (threadIdx.x != 0) return;
-    const double m = s / (double)M;
-    double var = ss / (double)M - m * m;
-    var = var > 0.0 ? var : 0.0;
-    mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
-        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    double rm = 0.0, rv = 0.0;
+    if (running_mean && threadIdx.x == 0) { rm = (double)running_mean[c]; rv = (double)running_var[c]; }
+    for (int g = 0; g < groups; ++g) {                 // the moving averages take the groups' moments one after the other, in order
+        double s, ss;
+        combine(part + (size_t)g * parts * 2 * C, parts, C, c, s, ss);
+        if (threadIdx.x != 0) continue;
+        const double m = s / (double)M;
+        double var = ss / (double)M - m * m;
+        var = var > 0.0 ? var : 0.0;
+        mean[(size_t)g * C + c] = (float)m;
+        invstd[(size_t)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            // (rounded to fp32 after every group: exactly what one call per group leaves behind)
+            rm = (double)(float)((1.0 - (double)momentum) * rm + (double)momentum * m);
+            rv = (double)(float)((1.0 - (double)momentum) * rv + (double)momentum * unbiased);
+        }
     }
+    if (running_mean && threadIdx.x == 0) { running_mean[c] = (float)rm; running_var[c] = (float)rv; }
 }
 
 // one wave per channel: sums[c] = sum g, sums[C + c] = sum g * xhat  (= d beta, d gamma)
 __global__ __launch_bounds__(64) void bn_bwd_combine_kernel(const float *__restrict__ part, int parts, int C, float *__restrict__ sums)
 {
     const int c = blockIdx.x;
+    part += (size_t)blockIdx.y * parts * 2 * C;
+    sums += (size_t)blockIdx.y * 2 * C;
     double a, b;
     combine(part, parts, C, c, a, b);
     if (threadIdx.x == 0) { sums[c] = (float)a; sums[C + c] = (float)b; }
@@ -144,6 +155,8 @@ __global__ __launch_bounds__(TB) void bn_apply_kernel(const float *__restrict__ 
                                                       const float *__restrict__ beta, int relu, float *__restrict__ y)
 {
     const int cg = threadIdx.x & ((C >> 2) - 1);
+    z += (size_t)blockIdx.y * n4 * 4; y += (size_t)blockIdx.y * n4 * 4;
+    mean += (size_t)blockIdx.y * C; invstd += (size_t)blockIdx.y * C;
     const float4 m = ld4(mean, cg), s = ld4(invstd, cg), g = ld4(gamma, cg), b = ld4(beta, cg);
     const long stride = (long)gridDim.x * TB;
     auto one = [&](const float4 v) {
@@ -182,6 +195,9 @@ __global__ __launch_bounds__(TB) void bn_bwd_reduce_kernel(const float *__restri
 {
     __shared__ float4 lds[TB];
     const int q = C >> 2, rpb = TB / q, cg = threadIdx.x % q, rr = threadIdx.x / q;
+    dy += (size_t)blockIdx.y * M * C; z += (size_t)blockIdx.y * M * C;
+    mean += (size_t)blockIdx.y * C; invstd += (size_t)blockIdx.y * C;
+    part += (size_t)blockIdx.y * gridDim.x * 2 * C;
     const BnCol p{ld4(mean, cg), ld4(invstd, cg), ld4(gamma, cg), ld4(beta, cg)};
     long r0, r1;
     block_rows(M, rpb, r0, r1);
@@ -216,6 +232,8 @@ __global__ __launch_bounds__(TB) void bn_bwd_apply_kernel(const float *__restric
                                                           const float *__restrict__ sums, float *__restrict__ dz)
 {
     const int cg = threadIdx.x & ((C >> 2) - 1);     // (one channel quad per thread: see bn_apply_kernel)
+    dy += (size_t)blockIdx.y * n4 * 4; z += (size_t)blockIdx.y * n4 * 4; dz += (size_t)blockIdx.y * n4 * 4;
+    mean += (size_t)blockIdx.y * C; invstd += (size_t)blockIdx.y * C; sums += (size_t)blockIdx.y * 2 * C;
     const long stride = (long)gridDim.x * TB;
     const float inv_m = 1.0f / (float)M;
     const BnCol p{ld4(mean, cg), ld4(invstd, cg), ld4(gamma, cg), ld4(beta, cg)};
@@ -429,15 +447,23 @@ int check_bn(const char *who, long M, int C, std::initializer_list<const void *>
 }  // namespace
 
 void bn_finalize_launch(const float *part, int parts, long M, int C, float eps, float momentum, float *mean, float *invstd,
-                        float *running_mean, float *running_var, hipStream_t s)       // for elo_train_dense.hip's fused moments
+                        float *running_mean, float *running_var, int groups, hipStream_t s)      // for elo_train_dense.hip's fused moments
 {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, parts, M, C, eps, momentum, mean, invstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, parts, M, C, eps, momentum, mean, invstd, running_mean, running_var, groups);
 }
 }  // namespace elo
 
 using namespace elo;
 
-extern "C" long elo_bn_scratch_floats(int C) { return 2l * C * ELO_BN_MAX_PARTS; }
+extern "C" long elo_bn_scratch_floats(int C, int groups) { return 2l * C * ELO_BN_MAX_PARTS * (groups > 1 ? groups : 1); }
+
+// rows per group (groups <= 1: one group), or -1
+static long group_rows(const char *who, long rows, int groups)
+{
+    const int g = groups > 1 ? groups : 1;
+    if (g > 64 || rows % g) { fail(ELO_ERR_ARG, "%s: %ld rows do not split into %d groups", who, rows, groups); return -1; }
+    return rows / g;
+}
 
 extern "C" int elo_bn_stats(const elo_bn_stats_args *a, elo_stream_t stream)
 {
@@ -446,10 +472,13 @@ extern "C" int elo_bn_stats(const elo_bn_stats_args *a, elo_stream_t stream)
     if (int rc = check_bn(who, a->rows, a->C, {a->z, a->scratch, a->mean, a->invstd})) return rc;
     if ((a->running_mean == nullptr) != (a->running_var == nullptr)) return fail(ELO_ERR_ARG, "%s: running_mean and running_var go together", who);
     hipStream_t s = (hipStream_t)stream;
-    const int parts = grid_for(a->rows, a->C);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(parts), dim3(TB), 0, s, a->z, a->rows, a->C, a->scratch);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a->C), dim3(64), 0, s, a->scratch, parts, a->rows, a->C, a->eps, a->momentum,
-                       a->mean, a->invstd, a->running_mean, a->running_var);
+    const int G = a->groups > 1 ? a->groups : 1;
+    const long Mg = group_rows(who, a->rows, a->groups);
+    if (Mg < 0) return ELO_ERR_ARG;
+    const int parts = grid_for(Mg, a->C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(parts, G), dim3(TB), 0, s, a->z, Mg, a->C, a->scratch);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a->C), dim3(64), 0, s, a->scratch, parts, Mg, a->C, a->eps, a->momentum,
+                       a->mean, a->invstd, a->running_mean, a->running_var, G);
     return check_launch(who);
 }
 
@@ -458,9 +487,12 @@ extern "C" int elo_bn_apply(const elo_bn_apply_args *a, elo_stream_t stream)
     const char *who = "elo_bn_apply";
     if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
     if (int rc = check_bn(who, a->rows, a->C, {a->z, a->mean, a->invstd, a->gamma, a->beta, a->y})) return rc;
-    const long n4 = a->rows * (a->C >> 2);
+    const int G = a->groups > 1 ? a->groups : 1;
+    const long Mg = group_rows(who, a->rows, a->groups);
+    if (Mg < 0) return ELO_ERR_ARG;
+    const long n4 = Mg * (a->C >> 2);
     const long blocks = (n4 + TB * 4 - 1) / (TB * 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(TB), 0, (hipStream_t)stream, a->z, n4, a->C,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks), G), dim3(TB), 0, (hipStream_t)stream, a->z, n4, a->C,
                        a->mean, a->invstd, a->gamma, a->beta, a->relu, a->y);
     return check_launch(who);
 }
@@ -471,14 +503,17 @@ extern "C" int elo_bn_backward(const elo_bn_backward_args *a, elo_stream_t strea
     if (!a) return fail(ELO_ERR_ARG, "%s: null argument block", who);
     if (int rc = check_bn(who, a->rows, a->C, {a->dy, a->z, a->mean, a->invstd, a->gamma, a->beta, a->scratch, a->sums, a->dz ? a->dz : a->sums})) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int parts = grid_for(a->rows, a->C);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(parts), dim3(TB), 0, s, a->dy, a->z, a->rows, a->C, a->mean, a->invstd,
+    const int G = a->groups > 1 ? a->groups : 1;
+    const long Mg = group_rows(who, a->rows, a->groups);
+    if (Mg < 0) return ELO_ERR_ARG;
+    const int parts = grid_for(Mg, a->C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(parts, G), dim3(TB), 0, s, a->dy, a->z, Mg, a->C, a->mean, a->invstd,
                        a->gamma, a->beta, a->relu, a->scratch);
-    hipLaunchKernelGGL(bn_bwd_combine_kernel, dim3(a->C), dim3(64), 0, s, a->scratch, parts, a->C, a->sums);
+    hipLaunchKernelGGL(bn_bwd_combine_kernel, dim3(a->C, G), dim3(64), 0, s, a->scratch, parts, a->C, a->sums);
     if (!a->dz) return check_launch(who);
-    const long n4 = a->rows * (a->C >> 2);
+    const long n4 = Mg * (a->C >> 2);
     const long blocks = (n4 + TB * 4 - 1) / (TB * 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(TB), 0, s, a->dy, a->z, n4, a->rows, a->C,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks), G), dim3(TB), 0, s, a->dy, a->z, n4, Mg, a->C,
                        a->mean, a->invstd, a->gamma, a->beta, a->relu, a->sums, a->dz);
     return check_launch(who);
 }

@@ -22,7 +22,7 @@
 
 namespace elo {
 void bn_finalize_launch(const float *part, int parts, long M, int C, float eps, float momentum, float *mean, float *invstd,
-                        float *running_mean, float *running_var, hipStream_t s);      // elo_train.hip
+                        float *running_mean, float *running_var, int groups, hipStream_t s);      // elo_train.hip
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -67,6 +67,11 @@ __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(c
     extern __shared__ float4 wl[];                          // [KC][nt][64] x 4 steps, then (STATS) the waves' column sums
     const int KC = (K + 15) >> 4;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, q = lane >> 4;
+    // blockIdx.y: the GROUP of rows (M rows each) with its own batch statistics -- the frames of a Siamese batch in one launch
+    const float *const x_all = x;
+    x += (size_t)blockIdx.y * M * K;
+    out += (size_t)blockIdx.y * M * N;
+    if (STATS) part += (size_t)blockIdx.y * gridDim.x * 2 * N;
     // W into operand order: zeros first (the padding of the last chunk and tile), then W in MEMORY order -- coalesced whichever
     // way it is stored -- scattered to where the MFMA steps read it; 8 loads in flight per thread (the first form walked the LDS
     // image and gathered from W one dependent trip at a time: 25 us of a 35 us launch on a 192 x 128 layer)
@@ -118,10 +123,11 @@ __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(c
     // bn_apply and bn_bwd_apply form them (the ReLU decision must be the forward's, bit for bit);  dz = P g + Q + R xhat
     float4 *tbl = wl + KC * nt * 64;
     if (BNB) {
+        const float *gmean = bn.mean + (size_t)blockIdx.y * K, *ginv = bn.invstd + (size_t)blockIdx.y * K, *gsums = bn.sums + (size_t)blockIdx.y * 2 * K;
         for (int i = threadIdx.x; i < (K >> 2); i += DTB) {
-            const float4 m = reinterpret_cast<const float4 *>(bn.mean)[i], sd = reinterpret_cast<const float4 *>(bn.invstd)[i];
+            const float4 m = reinterpret_cast<const float4 *>(gmean)[i], sd = reinterpret_cast<const float4 *>(ginv)[i];
             const float4 g = reinterpret_cast<const float4 *>(bn.gamma)[i], b = reinterpret_cast<const float4 *>(bn.beta)[i];
-            const float4 s1 = reinterpret_cast<const float4 *>(bn.sums)[i], s2 = reinterpret_cast<const float4 *>(bn.sums + K)[i];
+            const float4 s1 = reinterpret_cast<const float4 *>(gsums)[i], s2 = reinterpret_cast<const float4 *>(gsums + K)[i];
             const float im = bn.inv_m;
             tbl[i * 7 + 0] = sd;
             tbl[i * 7 + 1] = m;
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(c
     };
     // (the loads only: columns past K are read from a clamped address and weighted out WHERE THEY ARE USED -- weighting them here
     //  made every fetch wait for its own loads, i.e. no prefetch at all: the first form's matrix pipe idled 60 % of the time)
-    const long zoff = BNB ? bn.z - x : 0;                   // z and dz have x's shape: the same element offsets
+    const long zoff = BNB ? bn.z - x_all : 0;               // z and dz have x's shape: the same element offsets
     auto fetch = [&](f32x4 (&dst)[RB], f32x4 (&zdst)[BNB ? RB : 1], const float *const (&xr)[RB], int c) {
         if (VEC) {
             const int k0 = 16 * c + 4 * q, kc = k0 < K ? k0 : 0;
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(c
                             const f32x4 d = P * g + Q + R * xh;
                             xb[u][rb] = d;
                             const long row = row0 + rb * 16 + j;
-                            if (row < M && k0 < K) *reinterpret_cast<float4 *>(bn.dz + (xc[rb] - x) + k0) = float4{d[0], d[1], d[2], d[3]};
+                            if (row < M && k0 < K) *reinterpret_cast<float4 *>(bn.dz + (xc[rb] - x_all) + k0) = float4{d[0], d[1], d[2], d[3]};
                         }
                     }
                     if (16 * c + 16 > K) {                  // the ragged last chunk
@@ -336,10 +342,14 @@ __global__ __launch_bounds__(DTB, MinBlocks<NT>::value) void dense_rows_kernel(c
     }
 }
 
-struct Plan { int NT, nt, KC, grid; size_t lds; };
+struct Plan { int NT, nt, KC, grid, groups; long rows; size_t lds; };      // rows: per group
 
-bool plan_dense(long M, int K, int N, bool stats, Plan &p, bool bnb = false)
+bool plan_dense(long M, int K, int N, bool stats, Plan &p, bool bnb = false, int groups = 1)
 {
+    p.groups = (stats || bnb) && groups > 1 ? groups : 1;   // (the plain product has no per-group state: one group of all rows)
+    if (M % p.groups) return false;
+    M /= p.groups;
+    p.rows = M;
     p.nt = (N + 15) / 16;
     p.NT = p.nt <= 1 ? 1 : p.nt <= 2 ? 2 : p.nt <= 4 ? 4 : p.nt <= 8 ? 8 : 12;
     if (p.nt > 12) return false;
@@ -366,14 +376,14 @@ template <int NT, bool VEC, bool STATS, bool FULL, bool BNB = false>
 int launch_one(const Plan &p, const elo_dense_rows_args *a, hipStream_t s)
 {
     auto kern = dense_rows_kernel<NT, VEC, STATS, FULL, BNB>;
-    const BnBack bn{a->bn_z, a->bn_mean, a->bn_invstd, a->bn_gamma, a->bn_beta, a->bn_sums, a->bn_dz, a->bn_relu, 1.0f / (float)a->rows};
+    const BnBack bn{a->bn_z, a->bn_mean, a->bn_invstd, a->bn_gamma, a->bn_beta, a->bn_sums, a->bn_dz, a->bn_relu, 1.0f / (float)p.rows};
     static bool raised = false;                              // > 64 KB of dynamic LDS has to be asked for, once per kernel
     if (!raised && p.lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return fail(ELO_ERR_LAUNCH, "elo_dense_rows: %zu bytes of LDS refused", p.lds);
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.grid), dim3(DTB), p.lds, s, a->x, a->W, a->bias, a->out, a->rows, a->Cin, a->Cout, p.nt,
+    hipLaunchKernelGGL(kern, dim3(p.grid, p.groups), dim3(DTB), p.lds, s, a->x, a->W, a->bias, a->out, p.rows, a->Cin, a->Cout, p.nt,
                        a->transposed, a->scratch, bn);
     return ELO_OK;
 }
@@ -395,7 +405,7 @@ int launch_nt(const Plan &p, const elo_dense_rows_args *a, hipStream_t s)
 
 using namespace elo;
 
-extern "C" long elo_dense_rows_scratch_floats(int Cout) { return 2l * Cout * ELO_DENSE_MAX_PARTS; }
+extern "C" long elo_dense_rows_scratch_floats(int Cout, int groups) { return 2l * Cout * ELO_DENSE_MAX_PARTS * (groups > 1 ? groups : 1); }
 
 extern "C" int elo_dense_rows_supported(long rows, int Cin, int Cout)
 {
@@ -422,8 +432,10 @@ extern "C" int elo_dense_rows(const elo_dense_rows_args *a, elo_stream_t stream)
             return fail(ELO_ERR_ARG, "%s: unaligned batch-norm-backward tensor", who);
     }
     Plan p;
-    if (!plan_dense(a->rows, a->Cin, a->Cout, stats, p, bnb))
-        return fail(ELO_ERR_LIMIT, "%s: Cin = %d, Cout = %d does not fit (<= 192 output columns, W <= 160 KB of LDS)", who, a->Cin, a->Cout);
+    if (a->groups > 64) return fail(ELO_ERR_ARG, "%s: %d groups", who, a->groups);
+    if (!plan_dense(a->rows, a->Cin, a->Cout, stats, p, bnb, a->groups))
+        return fail(ELO_ERR_LIMIT, "%s: Cin = %d, Cout = %d does not fit (<= 192 output columns, W <= 160 KB of LDS), or %ld rows do not split into %d groups",
+                    who, a->Cin, a->Cout, a->rows, a->groups);
     hipStream_t s = (hipStream_t)stream;
     int rc = ELO_OK;
     switch (p.NT) {
@@ -435,6 +447,6 @@ extern "C" int elo_dense_rows(const elo_dense_rows_args *a, elo_stream_t stream)
     }
     if (rc) return rc;
     if (stats)
-        bn_finalize_launch(a->scratch, p.grid, a->rows, a->Cout, a->eps, a->momentum, a->mean, a->invstd, a->running_mean, a->running_var, s);
+        bn_finalize_launch(a->scratch, p.grid, p.rows, a->Cout, a->eps, a->momentum, a->mean, a->invstd, a->running_mean, a->running_var, p.groups, s);
     return check_launch(who);
 }

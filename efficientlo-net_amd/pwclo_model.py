@@ -238,7 +238,27 @@ def get_model_from_projection(xyz_f1_input_proj, xyz_f2_input_proj, is_training,
     deferred = []                      # (job, finish) of set-convs that wait for a cost-volume launch to ride on
     with tf_util.variable_scope('sa1') as scope:                                                    # :117
         both = _adjacent_frames(xyz_f1_input_proj, xyz_f2_input_proj) if not is_training else None
-        if both is not None:
+        siamese_train = (is_training and tuning.get("train_siamese_batch") and tuning.get("train_kernels")
+                         and xyz_f1_input_proj.shape == xyz_f2_input_proj.shape)
+        if siamese_train:
+            # Training: the same ONE pass over the 2B batch; the batch-norm layers keep the frames' statistics apart (tf_util.bn_groups:
+            # moments per frame, moving averages updated frame 1 then frame 2 -- the arithmetic of two calls with shared variables),
+            # the gradients of the shared weights are the sums over both frames as before.  Half the encoder's launches.
+            both_t = torch.cat([xyz_f1_input_proj, xyz_f2_input_proj], 0)
+            sel2 = [get_selected_idx(both_t, stride_h_list[i], stride_w_list[i], out_h_list[i], out_w_list[i])
+                    for i in (2, 3, 4, 5)]
+            with tf_util.bn_groups(2):
+                pts, pts_proj, xyz_proj = feature_pyramid(both_t, zero_features(both_t), sel2)
+            B = batch_size
+            two = lambda t: (None, None) if t is None else t.split(B)          # (split: ONE concatenation in backward, not two padded adds)
+            pts_s = [two(p) for p in pts]
+            pts_f1, pts_f2 = [a for a, _ in pts_s], [b for _, b in pts_s]
+            shape_like = lambda t, ref: None if t is None or ref is None else t.reshape((B,) + tuple(ref.shape[1:]))
+            pts_proj_f1 = [shape_like(a, ref) for a, ref in zip(pts_f1, pts_proj)]
+            pts_proj_f2 = [shape_like(b, ref) for b, ref in zip(pts_f2, pts_proj)]
+            xyz_s = [two(x) for x in xyz_proj]
+            xyz_proj_f1, xyz_proj_f2 = [a for a, _ in xyz_s], [b for _, b in xyz_s]
+        elif both is not None:
             # Siamese pyramid in ONE pass: the two frames share every weight (:143), and inference BN uses moving
             # statistics, so frame 2 is just batch elements B..2B-1 -- half the launches, identical numbers.
             sel2 = [get_selected_idx(both, stride_h_list[i], stride_w_list[i], out_h_list[i], out_w_list[i])

@@ -184,6 +184,22 @@ def folded_variables(scope, cin, num_output_channels, tf_kernel_dims=(1, 1), bn=
     return get_store().folded(name, W, b, bn_vars)
 
 
+_bn_groups = 1
+
+
+@contextlib.contextmanager
+def bn_groups(n):
+    """`with tf_util.bn_groups(2):` -- inside, a TRAINING batch-norm layer treats its batch as n equal blocks with their own batch
+    statistics, and updates the moving averages once per block in order: what calling the layer once per block with shared variables
+    does (the reference's Siamese pyramid, pwclo_model.py:117-143), in one set of launches."""
+    global _bn_groups
+    prev, _bn_groups = _bn_groups, int(n)
+    try:
+        yield
+    finally:
+        _bn_groups = prev
+
+
 def _dense(inputs, num_output_channels, scope, tf_kernel_dims, activation_fn, bn, bn_decay, is_training):
     cin = inputs.shape[-1]
     name, W, b, bn_vars = dense_variables(scope, cin, num_output_channels, tf_kernel_dims, bn)
@@ -195,12 +211,13 @@ def _dense(inputs, num_output_channels, scope, tf_kernel_dims, activation_fn, bn
                 and _ops.dense_bn_supported(x2, num_output_channels)):
             # the row reductions of conv -> batch norm -> ReLU on hand-written kernels (csrc/elo_train.hip)
             y = _ops.dense_bn(x2, W, b, bn_vars[0], bn_vars[1], bn_vars[2], bn_vars[3], 1.0 - decay, BN_EPS,
-                              activation_fn is relu)
+                              activation_fn is relu, groups=_bn_groups)
             return y.reshape(inputs.shape[:-1] + (num_output_channels,))
         y = torch.addmm(b, x2, W)
         if bn:
-            y = Fnn.batch_norm(y, bn_vars[2], bn_vars[3], bn_vars[0], bn_vars[1], training=training,
-                               momentum=1.0 - decay, eps=BN_EPS)
+            y = torch.cat([Fnn.batch_norm(part, bn_vars[2], bn_vars[3], bn_vars[0], bn_vars[1], training=training,
+                                          momentum=1.0 - decay, eps=BN_EPS) for part in y.chunk(_bn_groups)]) if _bn_groups > 1 else \
+                Fnn.batch_norm(y, bn_vars[2], bn_vars[3], bn_vars[0], bn_vars[1], training=training, momentum=1.0 - decay, eps=BN_EPS)
         if activation_fn is not None:
             y = activation_fn(y)
     else:                                        # inference: BN + bias folded into the GEMM

@@ -33,6 +33,7 @@ _HOST = {
     "train_kernels": ("ELO_TRAIN_KERNELS", lambda v: v != "0", True),
     "train_dense": ("ELO_TRAIN_DENSE", lambda v: v != "0", True),             # a training layer's two products (x W + b with the batch moments, dz W^T) on elo_dense_rows instead of the library GEMM ...
     "train_dense_rows": ("ELO_TRAIN_DENSE_ROWS", int, 25000),                 # ... from this many rows on for x W + b (below: one macro-block per wave, the library + elo_bn_stats are faster: tools/dense_rows_micro.py)
+    "train_siamese_batch": ("ELO_TRAIN_SIAMESE_BATCH", lambda v: v != "0", True),   # training: the two frames' feature pyramids as ONE 2B batch whose batch-norm layers keep per-frame statistics (half the encoder's launches)
     "train_dense_fused_dz": ("ELO_TRAIN_DENSE_FUSED_DZ", lambda v: v != "0", True),   # ... and there batch norm's backward-apply happens on that kernel's operand load (dz written on the way): one pass less
     "train_dense_dx_rows": ("ELO_TRAIN_DENSE_DX_ROWS", int, 100000),          # ... and from this many for dz W^T (no moments to fuse: the library holds out longer)
 }

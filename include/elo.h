@@ -506,9 +506,12 @@ typedef struct elo_bn_stats_args {
     float eps, momentum;          /* 1e-3; 1 - bn_decay */
     float *mean, *invstd;         /* (C) OUT: batch mean, 1/sqrt(biased batch variance + eps) */
     float *running_mean, *running_var;   /* (C) IN/OUT or both NULL: r <- (1-momentum) r + momentum * (mean | unbiased var) */
+    int groups;                   /* > 1: the rows are `groups` equal contiguous blocks with their OWN batch statistics (the two frames of a
+                                   * Siamese batch in one launch: utils/tf_util.py's layer called twice with shared variables): mean, invstd
+                                   * are (groups,C), the moving averages take the groups' moments one after the other; 0 / 1: one group */
 } elo_bn_stats_args;
 int elo_bn_stats(const elo_bn_stats_args *a, elo_stream_t stream);
-long elo_bn_scratch_floats(int C);          /* the scratch of elo_bn_stats / elo_bn_backward AS THIS BUILD sizes it (a host that mirrors the #define
+long elo_bn_scratch_floats(int C, int groups);  /* the scratch of elo_bn_stats / elo_bn_backward AS THIS BUILD sizes it (a host that mirrors the #define
                                              * and a stale library disagree silently: ask) */
 
 typedef struct elo_bn_apply_args {
@@ -516,6 +519,7 @@ typedef struct elo_bn_apply_args {
     const float *z, *mean, *invstd, *gamma, *beta;
     int relu;                     /* 1: y = max(., 0) */
     float *y;                     /* (rows,C) OUT (may alias z) */
+    int groups;                   /* as elo_bn_stats_args: mean, invstd (groups,C) */
 } elo_bn_apply_args;
 int elo_bn_apply(const elo_bn_apply_args *a, elo_stream_t stream);
 
@@ -528,6 +532,7 @@ typedef struct elo_bn_backward_args {
     float *scratch;               /* (ELO_BN_MAX_PARTS, 2, C) */
     float *sums;                  /* (2*C) OUT [d beta | d gamma] */
     float *dz;                    /* (rows,C) OUT (may alias dy); NULL: the sums only (two launches) -- dz is then formed by elo_dense_rows */
+    int groups;                   /* as elo_bn_stats_args: mean, invstd (groups,C), sums (groups,2*C) -- d beta / d gamma are their sums over the groups */
 } elo_bn_backward_args;
 int elo_bn_backward(const elo_bn_backward_args *a, elo_stream_t stream);
 
@@ -567,9 +572,11 @@ typedef struct elo_dense_rows_args {
     const float *bn_z, *bn_mean, *bn_invstd, *bn_gamma, *bn_beta, *bn_sums;
     int bn_relu;
     float *bn_dz;
+    int groups;                   /* as elo_bn_stats_args, for the moments (mean, invstd (groups,Cout)) and for the bn_* operand
+                                   * (bn_mean, bn_invstd (groups,Cin), bn_sums (groups,2*Cin)); the plain product ignores it */
 } elo_dense_rows_args;
 int elo_dense_rows_supported(long rows, int Cin, int Cout);
-long elo_dense_rows_scratch_floats(int Cout);
+long elo_dense_rows_scratch_floats(int Cout, int groups);
 int elo_dense_rows(const elo_dense_rows_args *a, elo_stream_t stream);
 
 /* Adam (torch.optim.Adam's arithmetic; the reference trains with tf.train.AdamOptimizer, main.py:171-176) over ONE flat

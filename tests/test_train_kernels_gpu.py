@@ -303,10 +303,10 @@ def test_dense_rows_forms_dz_on_its_operand_load(rows, c, cin, relu):
     gamma, beta = r(c) * 0.3 + 1.0, r(c) * 0.3
     mean, var = z.mean(0), z.var(0, unbiased=False)
     invstd = 1.0 / torch.sqrt(var + 1e-3)
-    scratch = torch.empty(L.lib().elo_bn_scratch_floats(c), device=DEV)
+    scratch = torch.empty(L.lib().elo_bn_scratch_floats(c, 1), device=DEV)
     sums, dz_ref = torch.empty(2 * c, device=DEV), torch.empty_like(z)
     args = lambda dzp, s: L.BnBackwardArgs(rows, c, dy.data_ptr(), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                           1 if relu else 0, scratch.data_ptr(), s.data_ptr(), dzp)
+                                           1 if relu else 0, scratch.data_ptr(), s.data_ptr(), dzp, 1)
     L.call("elo_bn_backward", args(dz_ref.data_ptr(), sums), z)
     dx_ref = ops.dense_rows(dz_ref, W, None, transposed=True)
     sums2, dz = torch.empty(2 * c, device=DEV), torch.full_like(z, float("nan"))
@@ -340,3 +340,33 @@ def test_the_layer_is_the_same_on_both_dense_paths():
         # (the bias gradient of a batch-normalised layer is zero in exact arithmetic: what is left is rounding on the scale of dW)
         scale = float(res[0][4].abs().max()) if i == 5 else float(a.abs().max()) + 1e-3
         assert float((a - b).abs().max()) <= 3e-5 * scale, i
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(2 * 600, 6, 8), (2 * 20000, 19, 16), (2 * 70000, 16, 32), (2 * 60001, 128, 64), (2 * 333, 67, 128)])
+def test_a_two_group_layer_is_two_calls_with_shared_variables(rows, cin, cout):
+    """tf_util.bn_groups(2) (the Siamese training batch): ONE call on the 2B batch against the layer called once per frame with shared
+    variables (pwclo_model.py:117-143): outputs, moving averages (frame 1's update, then frame 2's) and all five gradients -- on the library
+    GEMM + elo_bn_stats path (few rows), on elo_dense_rows with the moments from its accumulators, and with dz formed in the dx kernel."""
+    tf_util = load_pkg("tf_util")
+    g = torch.Generator(device="cpu").manual_seed(rows + cin)
+    x0 = (torch.randn(2, rows // 2, 1, cin, generator=g) * torch.tensor([1.0, 2.5]).view(2, 1, 1, 1) + torch.tensor([0.0, 0.7]).view(2, 1, 1, 1)).to(DEV)
+    gy = torch.randn(rows, cout, generator=g).to(DEV)
+    res = []
+    for joint in (False, True):
+        store = tf_util.VariableStore(DEV, seed=3)
+        x = x0.clone().requires_grad_(True)
+        layer = lambda inp: tf_util.conv2d(inp, cout, [1, 1], scope="layer", bn=True, is_training=True, bn_decay=0.7, activation_fn=tf_util.relu)
+        with tf_util.default_store(store):
+            if joint:
+                with tf_util.bn_groups(2):
+                    y = layer(x.reshape(1, rows, 1, cin)).reshape(rows, cout)
+            else:
+                y = torch.cat([layer(x[0:1]), layer(x[1:2])], 1).reshape(rows, cout)
+            (y * gy).sum().backward()
+        P = store.params
+        res.append([y.detach(), store.buffers["layer/bn/moving_mean"], store.buffers["layer/bn/moving_variance"], x.grad,
+                    P["layer/weights"].grad, P["layer/biases"].grad, P["layer/bn/gamma"].grad, P["layer/bn/beta"].grad])
+    for i, (a, b) in enumerate(zip(*res)):
+        scale = float(res[0][4].abs().max()) if i == 5 else float(a.abs().max()) + 1e-3      # (the bias gradient is zero in exact arithmetic)
+        assert float((a - b).abs().max()) <= 3e-5 * scale, i
+    assert torch.equal(res[0][0], res[1][0]) or float((res[0][0] - res[1][0]).abs().max()) <= 1e-6 * float(res[0][0].abs().max())

@@ -221,3 +221,41 @@ def test_captured_training_step_trains():
     assert np.isfinite(other) and other != losses[-1]
     with pytest.raises(RuntimeError, match="capturable"):
         training.Trainer(model.PWCLONet(DEV, seed=3)).capture(a, b, q_gt, t_gt)
+
+
+def test_the_siamese_training_batch_is_the_two_pyramids_of_the_reference():
+    """tuning.train_siamese_batch (the two frames' feature pyramids as ONE 2B batch with per-frame batch-norm statistics) against the
+    pyramid run once per frame with shared variables (pwclo_model.py:117-143, :143 reuse_variables): the four poses, the loss, every
+    gradient and every moving average of one training forward + backward."""
+    model, training, synth, tuning = load_pkg("model"), load_pkg("training"), load_pkg("synth"), load_pkg("tuning")
+    tf_util, perm, pm = load_pkg("tf_util"), load_pkg("perm"), load_pkg("pwclo_model")
+    f1, f2 = synth.frame_pair(2, 64, 900, seed=21)
+    a, b = t(f1), t(f2)
+    q_gt = t(np.array([[0.99995, 0.0, 0.0, 0.01]] * 2, np.float32))
+    t_gt = t(np.array([[[0.8], [0.0], [0.0]]] * 2, np.float32))
+    res = []
+    for joint in (False, True):
+        torch.manual_seed(0)
+        net = model.PWCLONet(DEV, seed=3)
+        tr = training.Trainer(net)
+        tr.bucket.zero()
+        with tuning.override(train_siamese_batch=joint), torch.enable_grad():
+            with tf_util.default_store(net.store), perm.default_perm_source(net.perms):
+                out = pm.get_model_from_projection(a, b, True, 0.5)
+            loss = pm.get_loss(*out[:8], q_gt, t_gt, tr.w_x, tr.w_q)
+            loss.backward()
+        res.append(([o.detach().clone() for o in out[:8]], float(loss), tr.bucket.flat.clone(),
+                    {k: v.clone() for k, v in net.store.buffers.items()}))
+    (p0, l0, g0, m0), (p1, l1, g1, m1) = res
+    # The layers are equal to rounding (tests/test_train_kernels_gpu.py::test_a_two_group_layer_is_two_calls_with_shared_variables); the
+    # library GEMM of the small layers may pick another kernel for 2B rows, and a 1e-7 change of a coarse pose can move a point across a
+    # projection cell at the finer levels (DESIGN.md "numerics"): tight at l3 / l2, bounded at l1 / l0 (tools/siamese_batch_check.py
+    # prints the same comparison for three scenes, and the sequential form against itself).
+    tol = [2e-2, 2e-2, 2e-3, 2e-3, 2e-4, 2e-4, 2e-5, 2e-5]                      # l0_q, l0_t, l1_q, l1_t, l2_q, l2_t, l3_q, l3_t
+    for x, y, e in zip(p0, p1, tol):
+        assert float((x - y).abs().max()) <= e * (float(x.abs().max()) + 1e-3)
+    assert abs(l0 - l1) <= 2e-3 * abs(l0)
+    cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
+    assert cos > 0.9995, cos
+    for k in m0:
+        assert float((m0[k] - m1[k]).abs().max()) <= 2e-3 * (float(m0[k].abs().max()) + 1e-2), k

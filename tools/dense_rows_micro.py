@@ -32,10 +32,10 @@ for M, K, N in SHAPES:
     x = torch.randn(M, K, device=dev); W = torch.randn(K, N, device=dev) * 0.2; b = torch.randn(N, device=dev); dz = torch.randn(M, N, device=dev)
     mean, invstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
     rm, rv = torch.zeros(N, device=dev), torch.ones(N, device=dev)
-    scratch = torch.empty(L.lib().elo_bn_scratch_floats(N), device=dev)
+    scratch = torch.empty(L.lib().elo_bn_scratch_floats(N, 1), device=dev)
     def lib_stats():
         z = torch.addmm(b, x, W)
-        L.call("elo_bn_stats", L.BnStatsArgs(M, N, z.data_ptr(), scratch.data_ptr(), 1e-3, 0.1, mean.data_ptr(), invstd.data_ptr(), rm.data_ptr(), rv.data_ptr()), z)
+        L.call("elo_bn_stats", L.BnStatsArgs(M, N, z.data_ptr(), scratch.data_ptr(), 1e-3, 0.1, mean.data_ptr(), invstd.data_ptr(), rm.data_ptr(), rv.data_ptr(), 1), z)
         return z
     pow2 = N & (N - 1) == 0
     own = lambda: ops.dense_rows(x, W, b, moments=(1e-3, 0.1, mean, invstd, rm, rv))
