@@ -370,3 +370,46 @@ def test_a_two_group_layer_is_two_calls_with_shared_variables(rows, cin, cout):
         scale = float(res[0][4].abs().max()) if i == 5 else float(a.abs().max()) + 1e-3      # (the bias gradient is zero in exact arithmetic)
         assert float((a - b).abs().max()) <= 3e-5 * scale, i
     assert torch.equal(res[0][0], res[1][0]) or float((res[0][0] - res[1][0]).abs().max()) <= 1e-6 * float(res[0][0].abs().max())
+
+
+def test_dense_rows_and_weight_grad_on_random_shapes():
+    """A seeded sweep over shapes nobody chose: rows 1..6000 (blocks that end anywhere), Cin 1..200, Cout 1..192, either orientation,
+    the fused moments with 1 or 2 groups, misaligned W -- against float64; and elo_dense_weight_grad (vector and scalar operand loads,
+    ragged trips) on the same operands."""
+    ops, L = load_pkg("_ops"), load_pkg("_lib")
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        groups = int(rng.integers(1, 3))
+        rows = int(rng.integers(1, 3000)) * groups
+        cin, cout = int(rng.integers(1, 201)), int(rng.integers(1, 193))
+        if not L.lib().elo_dense_rows_supported(rows, cin, cout) or not L.lib().elo_dense_rows_supported(rows, cout, cin):
+            continue
+        g = torch.Generator(device="cpu").manual_seed(case)
+        x = torch.randn(rows, cin, generator=g).to(DEV)
+        off = int(rng.integers(0, 4))
+        flat = (torch.randn(cin * cout + 4, generator=g) * 0.3).to(DEV)
+        W = flat[off:off + cin * cout].view(cin, cout)
+        b = torch.randn(cout, generator=g).to(DEV)
+        want = x.double() @ W.double() + b.double()
+        tol = 3e-6 * (float(want.abs().max()) + 1.0) * max(1.0, cin ** 0.5 / 4)
+        mean, invstd = torch.empty(groups * cout, device=DEV), torch.empty(groups * cout, device=DEV)
+        rm, rv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+        z = ops.dense_rows(x, W, b, moments=(1e-3, 0.25, mean, invstd, rm, rv), groups=groups)
+        assert float((z.double() - want).abs().max()) <= tol, (case, rows, cin, cout)
+        per = want.view(groups, rows // groups, cout)
+        m, v = per.mean(1), per.var(1, unbiased=False)
+        assert float((mean.view(groups, cout).double() - m).abs().max()) <= 2e-5 * (float(m.abs().max()) + 1.0), (case, rows, cin, cout, groups)
+        # (the variance is E[z^2] - mean^2 from fp32 partial sums, as in elo_bn_stats: where mean^2 >> var the subtraction cancels --
+        #  the tolerance carries that conditioning per channel)
+        cond = (m * m + v) / (v + 1e-3)
+        assert bool((((invstd.view(groups, cout).double() * torch.sqrt(v + 1e-3)) - 1).abs() <= 5e-5 + 2e-6 * cond).all()), (case, rows, cin, cout, groups)
+        dz = torch.randn(rows, cout, generator=g).to(DEV)
+        dx = ops.dense_rows(dz, W, None, transposed=True)
+        dx_want = dz.double() @ W.double().t()
+        assert float((dx.double() - dx_want).abs().max()) <= 3e-6 * (float(dx_want.abs().max()) + 1.0) * max(1.0, cout ** 0.5 / 4), (case, rows, cin, cout)
+        dW, db = torch.empty(cin, cout, device=DEV), torch.empty(cout, device=DEV)
+        scratch = torch.empty(L.lib().elo_weight_grad_slices(rows, cin, cout) * (cin * cout + cout), device=DEV)
+        L.call("elo_dense_weight_grad", L.WeightGradArgs(rows, cin, cout, x.data_ptr(), dz.data_ptr(), dW.data_ptr(), db.data_ptr(), scratch.data_ptr()), x)
+        dW_want = x.double().t() @ dz.double()
+        assert float((dW.double() - dW_want).abs().max()) <= 1e-5 * (float(dW_want.abs().max()) + 1.0), (case, rows, cin, cout)
+        assert float((db.double() - dz.double().sum(0)).abs().max()) <= 1e-5 * (float(dz.abs().sum(0).max()) + 1.0), (case, rows, cin, cout)
