@@ -131,23 +131,25 @@ SetconvArgs = _struct("elo_setconv_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1_grid", _vp), ("centre_hw", _vp), ("centre_xyz", _vp), ("src_xyz", _vp), ("src_feat", _vp),
     ("idx", _vp), ("mask", _vp), ("n_layers", _i), ("layers", Dense * 3), ("out", _vp), ("new_xyz", _vp), ("group", GroupSpec),
-    ("feat_dtype", _i)])
+    ("feat_dtype", _i), ("range_counter", _vp)])
 MlpArgs = _struct("elo_mlp_args", [
     ("rows", _l), ("n_sources", _i), ("src", _vp * 3), ("src_width", _i * 3), ("n_layers", _i),
     ("layers", Dense * 3), ("out", _vp),
     ("n_layers2", _i), ("layers2", Dense * 3), ("before", _vp), ("w_before", _i), ("after", _vp), ("w_after", _i),
     ("out2", _vp), ("feat_dtype", _i),
     ("clear_scratch", _vp), ("clear_xyz", _vp), ("clear_feat", _vp), ("clear_cells", _l), ("clear_C", _i), ("clear_images", _i),
-    ("batch_hint", _i), ("sv_scratch", _vp), ("sv_xyz", _vp), ("sv_feature", _vp), ("sv_npoints", _i)])
+    ("batch_hint", _i), ("sv_scratch", _vp), ("sv_xyz", _vp), ("sv_feature", _vp), ("sv_npoints", _i),
+    ("range_counter", _vp)])
 Cv1Args = _struct("elo_cv1_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H2", _i), ("W2", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("xyz2", _vp), ("feat2", _vp), ("idx", _vp), ("mask", _vp),
     ("cv0", Dense), ("cv1", Dense), ("cv2", Dense), ("cv_xyz", Dense), ("sum_cv0", Dense), ("sum_cv1", Dense),
-    ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i)])
+    ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i), ("range_counter", _vp)])
 Cv2Args = _struct("elo_cv2_args", [
     ("batch", _i), ("npoints", _i), ("K", _i), ("H", _i), ("W", _i), ("C", _i),
     ("xyz1", _vp), ("feat1", _vp), ("cost", _vp), ("idx", _vp), ("mask", _vp),
-    ("xyz_enc", Dense), ("sum_cost0", Dense), ("sum_cost1", Dense), ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i)])
+    ("xyz_enc", Dense), ("sum_cost0", Dense), ("sum_cost1", Dense), ("out", _vp), ("group", GroupSpec), ("feat_dtype", _i),
+    ("range_counter", _vp)])
 Tuning = _struct("elo_tuning", [
     ("chain_forms", _i), ("narrow_mfma", _i), ("range_check", _i), ("select_dense_waves", _i), ("random_dense_rows", _i),
     ("setconv_chain_rows", _l), ("mlp_chain_rows", _l), ("small_tile_units", _l), ("pool_wave", _i)])
@@ -224,7 +226,7 @@ class EloError(RuntimeError):
     pass
 
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 
 def lib():
@@ -283,26 +285,50 @@ def check(rc):
         raise EloError("libelo_hip: %s (status %d)" % (lib().elo_last_error().decode(), rc))
 
 
+# The device word the CHECKED fused kernels of the launches below add their out-of-range operands to (None: the process-wide
+# counter).  model.capture sets it to the lane's own word while it records that lane's checked graph: the pointer is baked into
+# the graph's kernel arguments, so a violation is the lane's that ran the forward, not every lane's.
+_range_counter = None
+
+
+def set_range_counter(ptr):
+    """ptr: device address (int) of an unsigned 64-bit word, or None; returns the previous value."""
+    global _range_counter
+    prev, _range_counter = _range_counter, ptr
+    return prev
+
+
+def _stamp(*structs):
+    if _range_counter is not None:
+        for a in structs:
+            if a is not None and hasattr(a, "range_counter"):
+                a.range_counter = _range_counter
+
+
 def call(entry, args, like):
     """Launch `entry(args, current stream)` on like.device; raise on a non-zero status."""
+    _stamp(args)
     with torch.cuda.device(like.device):
         check(getattr(lib(), entry)(ctypes.byref(args), stream_ptr(like)))
 
 
 def call3(entry, a, b, c, like):
     """`entry(a, b, c or NULL, current stream)`."""
+    _stamp(a, b, c)
     with torch.cuda.device(like.device):
         check(getattr(lib(), entry)(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c) if c is not None else None, stream_ptr(like)))
 
 
 def call2(entry, args_a, args_b, like):
     """Paired launch: `entry(a, b, current stream)`."""
+    _stamp(args_a, args_b)
     with torch.cuda.device(like.device):
         check(getattr(lib(), entry)(ctypes.byref(args_a), ctypes.byref(args_b), stream_ptr(like)))
 
 
 def call2n(entry, args_a, args_b, like):
     """Paired launch whose second job is optional: `entry(a, b or NULL, current stream)`."""
+    _stamp(args_a, args_b)
     with torch.cuda.device(like.device):
         check(getattr(lib(), entry)(ctypes.byref(args_a), ctypes.byref(args_b) if args_b is not None else None, stream_ptr(like)))
 

@@ -253,10 +253,10 @@ __device__ __forceinline__ void act_put(float *act, int word, float v, unsigned 
 
 // MODE_CHECKED: one atomic per thread that saw something (none in a healthy run)
 template <int MODE>
-__device__ __forceinline__ void report_violations(unsigned violations)
+__device__ __forceinline__ void report_violations(unsigned violations, unsigned long long *counter)
 {
     if constexpr (MODE == MODE_CHECKED)
-        if (violations) atomicAdd(&g_range_violations, (unsigned long long)violations);
+        if (violations) atomicAdd(counter ? counter : &g_range_violations, (unsigned long long)violations);      // (a lane's own word, or the process-wide one)
 }
 
 // ---- feature tensors in HBM: fp32 or fp16 ------------------------------------------------------------------------
@@ -1038,7 +1038,7 @@ __device__ __forceinline__ void setconv_tile(const elo_setconv_args &a, const in
     for (int l = 0; l < a.n_layers; ++l)                                       // in place, :217-222
         dense<TILE, MODE>(act, S, 0, a.layers[l], l == a.n_layers - 1 ? to_pool(0) : to_tile(0), bad);
     pool_masked_max(act, S, 0, a.layers[a.n_layers - 1].N, meta, P, K, first_point, total_points, a.out, f16);   // :224-230
-    report_violations<MODE>(bad);
+    report_violations<MODE>(bad, a.range_counter);
 }
 
 template <int TILE, int MODE>
@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, TILE == 32 ? ELO_TILE32_WAVES : ELO_TI
     const long first = (long)xcd_tile(blockIdx.x, gridDim.x) * TILE;
     if (first >= a.rows) return;
     mlp_tile<TILE, MODE>(a, lds, S, first, a.rows, false, bad);
-    report_violations<MODE>(bad);
+    report_violations<MODE>(bad, a.range_counter);
 }
 
 // The row-wise MLP(s) that end in softmax_valid's inputs, WITH the first half of softmax_valid (model_util.py:319-343: a
@@ -1360,7 +1360,7 @@ void mlp_sv_kernel(const JobPair<elo_mlp_args> jobs, const int S, const int tile
         }
     }
     mlp_tile<TILE, MODE>(a, act, S, first, end, true, bad);       // (ends with the last layer's barrier: both tiles are complete)
-    report_violations<MODE>(bad);
+    report_violations<MODE>(bad, a.range_counter);
     if constexpr (!PAIR) {
 #pragma unroll
         for (int u = 0; u < STAGE; ++u) {
@@ -1510,7 +1510,7 @@ __device__ __forceinline__ void cv1_tile(const elo_cv1_args &a, const int S, flo
     CV1_STAMP(8);
     pool_masked_softmax(act, S, 64, 0, meta, P, K, first_point, total_points, a.out, f16);   // :92-98
     CV1_STAMP(9);
-    report_violations<MODE>(bad);
+    report_violations<MODE>(bad, a.range_counter);
 }
 
 template <int TILE, int MODE>
@@ -2025,7 +2025,7 @@ __device__ __forceinline__ void cv1_rr_body(const elo_cv1_args &a, const unsigne
     RR_STAMP(8);
     rr_pool<F16>(lds, logit, xe[0], xe[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
     RR_STAMP(9);
-    report_violations<MODE>(bad);
+    report_violations<MODE>(bad, a.range_counter);
 }
 
 template <int C, bool F16, int MODE = MODE_SPLIT>
@@ -2128,7 +2128,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void cv2_rr_kernel(const elo_cv2_
     });
     if (K == 4 && a.sum_cost1.relu) rr_pool_softmax4_inwave<F16>(logit, in1[0], in1[1], mk, r, lane, first_point, total_points, a.out);
     else rr_pool<F16>(lds, logit, in1[0], in1[1], mk, r, wave, lane, K, P, first_point, total_points, a.out);
-    report_violations<MODE>(bad);
+    report_violations<MODE>(bad, a.range_counter);
 }
 // ---- two chained row-wise MLPs, register-resident (see cv1_rr_kernel): set-upconv stage 2 and the flow predictor it feeds
 // (mlp_kernel's two-stage form: utils/pointnet_util.py:303-311, :161-175) on the model's widths -- stage 1 [pooled (64) |
@@ -2245,7 +2245,7 @@ __global__ __launch_bounds__(RR_WAVES * 64, 4) void mlp2_rr_kernel(const JobPair
     rr_layer<4, false, 4, E2, MODE>(h128, none, bt + O3, nullptr, bias, fetch, advance, [&](int pass, int t, const f32x4 acc) {
         if (used) feat_store4(a.out2, (first + r) * 64 + (2 * pass + t) * 16 + 4 * kq, relu4(acc, a.layers2[1].relu), F16);
     });
-    report_violations<MODE>(bad);
+    report_violations<MODE>(bad, a.range_counter);
 }
 // ---- set-conv / set-upconv stage 1, register-resident (see cv1_rr_kernel): in-kernel random-k grouping (a wave groups
 // the points its 16 rows belong to), gather [features (16 FPB) | xyz difference], two or three layers of compile-time
@@ -2448,7 +2448,7 @@ __device__ __forceinline__ void setconv_rr_body(const elo_setconv_args &a, const
     if ((K == 8 || K == 16) && a.layers[N3 ? 2 : 1].relu) rr_pool_max_inwave<NOUT, F16>(last, mk, r, lane, K, first_point, total_points, a.out);
     else rr_pool_max<NOUT, F16>(lds, last, mk, r, wave, lane, K, P, first_point, total_points, a.out);
     RR_STAMP(8);
-    report_violations<MODE>(bad);
+    report_violations<MODE>(bad, a.range_counter);
 }
 
 template <int FPB, int N1, int N2, int N3, bool F16, int MODE = MODE_SPLIT>
@@ -2678,7 +2678,7 @@ __global__ __launch_bounds__(ELO_BLOCK, 2) void setconv_narrow_kernel(const elo_
             } else best[cb] = float4{o[0], o[1], o[2], o[3]};
         }
     }
-    report_violations<MODE>(bad);
+    report_violations<MODE>(bad, a.range_counter);
 }
 
 #endif   // !ELO_DENSE_F32
@@ -2730,7 +2730,7 @@ __global__ __launch_bounds__(FUSED_BLOCK, ELO_TILE_WAVES) void cv2_kernel(const 
     dense_pf<TILE, 128, 64, MODE>(act, S, 0, to_tile(64), a.sum_cost0, p128, &a.sum_cost1, &p64, bad);   // [grouped | enc | feat1] -> [64,192)   :129-135
     dense_pf<TILE, 64, 0, MODE>(act, S, 64, to_pool(64), a.sum_cost1, p64, nullptr, nullptr, bad);       // -> 64 logits at [64,128)
     pool_masked_softmax(act, S, 64, 0, meta, P, K, first_point, total_points, a.out, f16);   // :137-146
-    report_violations<MODE>(bad);
+    report_violations<MODE>(bad, a.range_counter);
 }
 
 // A 16-row tile halves the serial work per workgroup and doubles their number: take it whenever the

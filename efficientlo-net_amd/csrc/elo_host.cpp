@@ -111,5 +111,5 @@ extern "C" int elo_graph_submit(void *graph_exec, elo_stream_t stream, void *dst
     return ELO_OK;
 }
 
-extern "C" int elo_abi_version(void) { return 25; }
+extern "C" int elo_abi_version(void) { return 26; }
 extern "C" const char *elo_last_error(void) { return elo::err_buf(); }

@@ -207,7 +207,11 @@ class PWCLONet:
             if check_every:                           # the same forward on the checked kernel instances, same buffers
                 from . import _lib
                 lane["graph_checked"], lane["check_every"] = torch.cuda.CUDAGraph(), int(check_every)
+                # the lane's OWN violation word: its address goes into the kernel arguments of the checked graph (ABI 26), so a
+                # saturated operand is counted for the lane whose forward met it -- not for every lane, as one process-wide word did
+                lane["range_counter"] = torch.zeros((1,), dtype=torch.int64, device=dev)
                 prev = _lib.range_check(True)
+                prev_counter = _lib.set_range_counter(lane["range_counter"].data_ptr())
                 try:
                     self.perms.tail_armed = False     # (the warm-up below must not advance the lane's order cursor)
                     with torch.cuda.stream(side):     # the checked path's own allocations / caches, before its capture
@@ -222,6 +226,8 @@ class PWCLONet:
                             lane["out_checked"] = self.forward(*lane["in"], pose_out=lane["pose"])
                 finally:
                     _lib.range_check(bool(prev))
+                    _lib.set_range_counter(prev_counter)
+                lane["range_counter"].zero_()         # (the warm-up forward counted too)
             # the graph holds raw device pointers into the module-level index / decoded-order caches; those caches evict
             # (clear()) when they grow: the lane keeps the tensors alive for as long as its graph exists
             lane["keep"] = _cached_tensors()
@@ -229,9 +235,6 @@ class PWCLONet:
             self._lanes.append(lane)
         self.perms.active_lane, self.perms.tail_armed = 0, False
         torch.cuda.synchronize(dev)
-        if check_every:
-            from . import _lib
-            _lib.range_violations(self._lanes[0]["pair"])            # the counter starts at zero
         self._graph, self._static_in, self._static_out = (self._lanes[0]["graph"], self._lanes[0]["in"],
                                                           self._lanes[0]["out"])
         self._captured_at = (self.store.generation, self.perms.generation, tuning.digest())
@@ -293,18 +296,23 @@ class PWCLONet:
         lane["replays"] += 1
         return lane["out_checked"] if checked else lane["out"]
 
-    def range_violations(self):
-        """Matrix-core operands at or beyond the fp16 range (|x| >= 65504, or NaN) seen by the checked replays since the
-        last call (capture(..., check_every=N)); takes the count out of the device counter (one atomic exchange, on the
-        current stream) -- call it once the lanes' streams have been synchronised or waited on.  The counter is ONE word for
-        the process: a non-zero count taints EVERY lane (a checked replay of another lane may have recorded it), so each
-        lane's next collect() raises, whichever lane happened to read the counter first."""
-        from . import _lib
-        bad = _lib.range_violations(self._lanes[0]["pair"])
-        if bad:
-            for lane in self._lanes:
+    def range_violations(self, lane_index=None):
+        """Matrix-core operands at or beyond the fp16 range (|x| >= 65504, or NaN) seen by the checked replays since the last
+        call (capture(..., check_every=N)): of one lane, or (None) of all lanes together.  Every lane has its own device word,
+        written by its own checked graph only; reading it synchronises with the current stream -- call it once the lane's stream
+        has been synchronised or waited on.  The count is remembered per lane until that lane's collect() raises it."""
+        lanes = self._lanes if lane_index is None else [self._lanes[lane_index]]
+        total = 0
+        for lane in lanes:
+            word = lane.get("range_counter")
+            if word is None:
+                continue
+            bad = int(word.item())
+            if bad:
+                word.zero_()
                 lane["tainted"] = lane.get("tainted", 0) + bad
-        return bad
+                total += bad
+        return total
 
     def collect(self, lane_index):
         """lane_poses(lane_index) for a lane whose work is DONE: synchronises the lane's stream, and raises if a checked
@@ -312,7 +320,7 @@ class PWCLONet:
         lane = self._lanes[lane_index]
         lane["stream"].synchronize()
         if lane.get("check_every"):
-            self.range_violations()                  # (a count found here, or by another lane's collection, taints this lane too)
+            self.range_violations(lane_index)        # this lane's own word
             bad = lane.pop("tainted", 0)
             if bad:
                 raise RuntimeError("%d matrix-core operands at or beyond the fp16 range (|x| >= 65504 or NaN) since the last "

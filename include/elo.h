@@ -38,8 +38,10 @@ const char *elo_last_error(void);   /* thread-local, never NULL                 
  * elo_range_check(1 / 0) switches it and returns the previous setting (-1: only query);
  * elo_range_violations() takes the count since the last call out of the device counter with ONE atomic exchange (a
  * violation recorded meanwhile by a checked launch on another stream is kept for the next call), synchronises `stream`
- * and returns it.  The counter is process-wide: a caller with several streams in flight attributes a non-zero count to
- * all of them (efficientlo-net_amd/model.py taints every lane). */
+ * and returns it.  That counter is process-wide; a caller with several streams in flight gives every fused argument block its
+ * own word instead (ABI 26: `range_counter` in elo_setconv_args / elo_mlp_args / elo_cv1_args / elo_cv2_args -- the checked instances
+ * add there when it is not NULL): efficientlo-net_amd/model.py bakes a lane's word into the lane's checked graph, so a violation is
+ * that lane's alone. */
 int elo_range_check(int enable);
 int elo_range_violations(unsigned long long *count, elo_stream_t stream);
 
@@ -717,6 +719,9 @@ typedef struct elo_setconv_args {
     float *new_xyz;               /* (batch,npoints,3) or NULL              */
     elo_group_spec group;         /* random-k; needs xyz1_grid; centre_hw == NULL: centre n is pixel (n / W, n % W) */
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
+    unsigned long long *range_counter;   /* the CHECKED instances (elo_range_check) add their count of out-of-range operands here (a lane's own
+                                          * device word: a violation is then that lane's, not every lane's); NULL: the process-wide counter of
+                                          * elo_range_violations() */
 } elo_setconv_args;
 int elo_setconv_fused(const elo_setconv_args *a, elo_stream_t stream);
 /* two independent jobs of identical shape in ONE launch (b may be NULL): the embedding and the embedding-mask
@@ -773,6 +778,9 @@ typedef struct elo_mlp_args {
     const float *sv_xyz;          /* (batch, sv_npoints, 3): a row is a valid point unless all three are exactly 0 */
     const void *sv_feature;       /* single launch: (rows, 64) feat_dtype; paired launch: NULL */
     int sv_npoints;               /* rows per batch element (rows % sv_npoints == 0) */
+    unsigned long long *range_counter;   /* the CHECKED instances (elo_range_check) add their count of out-of-range operands here (a lane's own
+                                          * device word: a violation is then that lane's, not every lane's); NULL: the process-wide counter of
+                                          * elo_range_violations() */
 } elo_mlp_args;
 #define ELO_THROUGHPUT_BATCH 4
 int elo_mlp_fused(const elo_mlp_args *a, elo_stream_t stream);
@@ -799,6 +807,9 @@ typedef struct elo_cv1_args {
     void *out;                    /* (batch,npoints,64) feat_dtype */
     elo_group_spec group;         /* select-k of xyz2 around every pixel of xyz1 (npoints == H2*W2, stride 1) */
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
+    unsigned long long *range_counter;   /* the CHECKED instances (elo_range_check) add their count of out-of-range operands here (a lane's own
+                                          * device word: a violation is then that lane's, not every lane's); NULL: the process-wide counter of
+                                          * elo_range_violations() */
 } elo_cv1_args;
 int elo_cv_stage1_fused(const elo_cv1_args *a, elo_stream_t stream);
 /* debugging hooks of the register-resident ("chain") kernel forms -- cv1_rr_kernel, cv2_rr_kernel, setconv_rr_kernel,
@@ -853,6 +864,9 @@ typedef struct elo_cv2_args {
     void *out;                    /* (batch,npoints,64) feat_dtype */
     elo_group_spec group;         /* random-k of xyz1 around every pixel of xyz1 (stride 1) */
     int feat_dtype;               /* ELO_F32 / ELO_F16 */
+    unsigned long long *range_counter;   /* the CHECKED instances (elo_range_check) add their count of out-of-range operands here (a lane's own
+                                          * device word: a violation is then that lane's, not every lane's); NULL: the process-wide counter of
+                                          * elo_range_violations() */
 } elo_cv2_args;
 int elo_cv_stage2_fused(const elo_cv2_args *a, elo_stream_t stream);
 

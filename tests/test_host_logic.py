@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.lib()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.elo_abi_version() == L.ABI_VERSION == 25
+    assert lib.elo_abi_version() == L.ABI_VERSION == 26
     assert lib.elo_last_error() == b"" or isinstance(lib.elo_last_error(), bytes)
 
 
