@@ -2687,7 +2687,7 @@ __global__ __launch_bounds__(ELO_BLOCK, 2) void setconv_narrow_kernel(const elo_
 // LDS columns: [0,64) grouped cost, [64,128) xyz-encoding, [128,128+C) feat1, [192,208) xyz_cat;
 // sum_cost0 reads [0,128+C) and writes [64,192); sum_cost1 maps [64,192) -> [64,128).
 template <int TILE, int MODE>
-__global__ __launch_bounds__(FUSED_BLOCK, ELO_TILE_WAVES) void cv2_kernel(const elo_cv2_args a, const int S)
+__global__ __launch_bounds__(FUSED_BLOCK, TILE == 32 ? ELO_TILE32_WAVES : ELO_TILE_WAVES) void cv2_kernel(const elo_cv2_args a, const int S)   // (32 rows at 6 waves: 4 VGPRs spilled to scratch)
 {
     extern __shared__ __align__(16) float lds[];
     float *act = lds;
