@@ -302,3 +302,47 @@ def test_bench_ring_helpers_clone_tensors_and_count_bytes():
     assert cl[0].data_ptr() != a.data_ptr() and cl[2][0].data_ptr() != b.data_ptr() and cl[2][1] == 3 and cl[3]["s"] == "x"
     assert torch.equal(cl[0], a) and isinstance(cl[2], list) and isinstance(cl, tuple)
     assert bench.LLC_BYTES == 256 * 1024 * 1024
+
+
+def test_bn_groups_on_the_torch_path_is_one_call_per_block():
+    """tf_util.bn_groups(2) (the Siamese training batch) on the torch comparison path (CPU: no kernels): ONE call on the 2B batch equals the
+    layer called once per frame with shared variables -- outputs, the moving averages (frame 1's update, then frame 2's) and the
+    gradients -- the contract the grouped kernels of csrc/elo_train.hip are tested against on the GPU."""
+    tf_util = load_pkg("tf_util")
+    g = torch.Generator().manual_seed(4)
+    x0 = torch.randn(2, 300, 1, 6, generator=g) * torch.tensor([1.0, 3.0]).view(2, 1, 1, 1) + torch.tensor([0.0, 1.5]).view(2, 1, 1, 1)
+    gy = torch.randn(600, 8, generator=g)
+    res = []
+    for joint in (False, True):
+        store = tf_util.VariableStore("cpu", seed=3)
+        x = x0.clone().requires_grad_(True)
+        layer = lambda inp: tf_util.conv2d(inp, 8, [1, 1], scope="layer", bn=True, is_training=True, bn_decay=0.7, activation_fn=tf_util.relu)
+        with tf_util.default_store(store):
+            if joint:
+                with tf_util.bn_groups(2):
+                    y = layer(x.reshape(1, 600, 1, 6)).reshape(600, 8)
+            else:
+                y = torch.cat([layer(x[0:1]), layer(x[1:2])], 1).reshape(600, 8)
+            (y * gy).sum().backward()
+        P = store.params
+        res.append([y.detach(), store.buffers["layer/bn/moving_mean"], store.buffers["layer/bn/moving_variance"], x.grad,
+                    P["layer/weights"].grad, P["layer/bn/gamma"].grad, P["layer/bn/beta"].grad])
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= 1e-5 * (float(a.abs().max()) + 1e-3)
+    # and the two blocks really were normalised apart: each half of the output has its own zero mean before the ReLU's cut shows
+    assert abs(float(res[1][1].mean()) - float(res[0][1].mean())) < 1e-6
+
+
+def test_the_lane_range_counter_is_stamped_into_the_fused_argument_blocks():
+    """_lib.set_range_counter(ptr): every launch helper writes the lane's device word into the argument blocks that have the field
+    (ABI 26); without it the blocks keep NULL = the process-wide counter."""
+    L = load_pkg("_lib")
+    a, b, m = L.SetconvArgs(), L.Cv1Args(), L.MlpArgs()
+    L._stamp(a, b, None, m)
+    assert not a.range_counter and not b.range_counter and not m.range_counter
+    prev = L.set_range_counter(0x1000)
+    try:
+        L._stamp(a, b, None, m, L.Cv2Args(), L.WeightGradArgs())
+        assert a.range_counter == 0x1000 and b.range_counter == 0x1000 and m.range_counter == 0x1000
+    finally:
+        assert L.set_range_counter(prev) == 0x1000
