@@ -107,6 +107,37 @@ __global__ __launch_bounds__(ELO_BLOCK) void masked_maxpool_kernel(const elo_mas
     }
 }
 
+// The same, a THREAD per (point, four consecutive channels): K 16-byte loads, eight in flight, no idle lanes (the wave-per-point form
+// above walks K dependent 4-byte loads with C of its 64 lanes -- 16 of 64 at the l0 set-conv's C = 16).  Same products, same order of
+// the fmaxf chain: same bits.
+__global__ __launch_bounds__(ELO_BLOCK) void masked_maxpool_vec_kernel(const elo_masked_maxpool_args a, const long items)
+{
+    const long e = (long)blockIdx.x * ELO_BLOCK + threadIdx.x;
+    if (e >= items) return;
+    const int q = a.C >> 2;
+    const long pt = point_batch(e, q);
+    const int cq = (int)(e - pt * q);
+    const float4 *x = reinterpret_cast<const float4 *>(a.x + pt * a.K * a.C) + cq;
+    const float *m = a.mask + pt * a.K;
+    float4 best{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    for (int k0 = 0; k0 < a.K; k0 += U) {
+        float4 v[U];
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int k = k0 + u < a.K ? k0 + u : a.K - 1; v[u] = x[(long)k * q]; w[u] = m[k]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (k0 + u < a.K) {
+                const float4 p{v[u].x * w[u], v[u].y * w[u], v[u].z * w[u], v[u].w * w[u]};
+                if (k0 + u == 0) best = p;
+                else best = float4{fmaxf(best.x, p.x), fmaxf(best.y, p.y), fmaxf(best.z, p.z), fmaxf(best.w, p.w)};
+            }
+        }
+    }
+    reinterpret_cast<float4 *>(a.out + pt * a.C)[cq] = best;
+}
+
 // ------------------------------------------------------------ cost volume: encode
 struct Geo { float p[3], g[3], d[3], euc; };
 
@@ -1169,6 +1200,11 @@ extern "C" int elo_masked_maxpool(const elo_masked_maxpool_args *a, elo_stream_t
     ELO_REQUIRE(a->x && a->mask && a->out, who, "null tensor pointer");
     const long rows = (long)a->batch * a->npoints;
     if (rows == 0) return ELO_OK;
+    if (a->C % 4 == 0 && (((uintptr_t)a->x | (uintptr_t)a->out) & 15) == 0) {
+        const long items = rows * (a->C / 4);
+        hipLaunchKernelGGL(masked_maxpool_vec_kernel, dim3((unsigned)((items + ELO_BLOCK - 1) / ELO_BLOCK)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, items);
+        return check_launch(who);
+    }
     hipLaunchKernelGGL(masked_maxpool_kernel, dim3(grid_for_rows(rows)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a, rows);
     return check_launch(who);
 }
