@@ -237,6 +237,110 @@ __global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_bwd_kernel(const elo_s
     }
 }
 
+// The same, a thread per (point, four consecutive channels), the K logits and values held in registers (K = 4, 6, 8 -- the cost volume's
+// neighbour counts at the refinement levels): one pass with 16-byte loads and stores, each exponential computed once.  Same operations
+// per element in the same order (max, exponentials against it, sums in k order): same bits.
+template <int K>
+__global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_bwd_vec_kernel(const elo_softmax_pool_bwd_args a, const long items)
+{
+    const long e = (long)blockIdx.x * ELO_BLOCK + threadIdx.x;
+    if (e >= items) return;
+    const int q = a.C >> 2, vq = a.values_stride >> 2;
+    const long pt = point_batch(e, q);
+    const int cq = (int)(e - pt * q);
+    const float4 *lp = reinterpret_cast<const float4 *>(a.logits + pt * K * a.C) + cq;
+    const float4 *vp = reinterpret_cast<const float4 *>(a.values + pt * K * (long)a.values_stride) + cq;
+    const float *m = a.mask + pt * K;
+    float4 l[K], v[K];
+    bool on[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { l[k] = lp[(long)k * q]; v[k] = vp[(long)k * vq]; on[k] = m[k] == 1.0f; }
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, den[4] = {0.f, 0.f, 0.f, 0.f}, acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float ex[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float lk[4] = {l[k].x, l[k].y, l[k].z, l[k].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mx[i] = fmaxf(mx[i], on[k] ? lk[i] : -1e10f);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float lk[4] = {l[k].x, l[k].y, l[k].z, l[k].w}, vk[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ex[k][i] = expf((on[k] ? lk[i] : -1e10f) - mx[i]);
+            den[i] += ex[k][i];
+            acc[i] += ex[k][i] * vk[i];
+        }
+    }
+    const float4 go = reinterpret_cast<const float4 *>(a.grad_out + pt * a.C)[cq];
+    const float g[4] = {go.x, go.y, go.z, go.w};
+    float out[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = acc[i] / den[i];
+    float4 *gv = reinterpret_cast<float4 *>(a.grad_values + pt * K * a.C) + cq, *gl = reinterpret_cast<float4 *>(a.grad_logits + pt * K * a.C) + cq;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float vk[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        float sv[4], sl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float s = ex[k][i] / den[i];
+            sv[i] = s * g[i];
+            sl[i] = on[k] ? s * (vk[i] - out[i]) * g[i] : 0.0f;      // a masked logit is the constant -1e10 (tf.where): no gradient there
+        }
+        gv[(long)k * q] = float4{sv[0], sv[1], sv[2], sv[3]};
+        gl[(long)k * q] = float4{sl[0], sl[1], sl[2], sl[3]};
+    }
+}
+
+// ... and for K = 16, 32 (the l2 cost volume's 32 candidates): the logits stay in registers and become the exponentials in place; the values
+// are streamed twice (the second time from L2).  Same operations per element, same order.
+template <int K>
+__global__ __launch_bounds__(ELO_BLOCK) void softmax_pool_bwd_vec2_kernel(const elo_softmax_pool_bwd_args a, const long items)
+{
+    const long e = (long)blockIdx.x * ELO_BLOCK + threadIdx.x;
+    if (e >= items) return;
+    const int q = a.C >> 2, vq = a.values_stride >> 2;
+    const long pt = point_batch(e, q);
+    const int cq = (int)(e - pt * q);
+    const float4 *lp = reinterpret_cast<const float4 *>(a.logits + pt * K * a.C) + cq;
+    const float4 *vp = reinterpret_cast<const float4 *>(a.values + pt * K * (long)a.values_stride) + cq;
+    const float *m = a.mask + pt * K;
+    float4 l[K];
+    unsigned on = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { l[k] = lp[(long)k * q]; on |= (m[k] == 1.0f ? 1u : 0u) << k; }
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, den[4] = {0.f, 0.f, 0.f, 0.f}, acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool o = (on >> k) & 1u;
+        mx[0] = fmaxf(mx[0], o ? l[k].x : -1e10f); mx[1] = fmaxf(mx[1], o ? l[k].y : -1e10f);
+        mx[2] = fmaxf(mx[2], o ? l[k].z : -1e10f); mx[3] = fmaxf(mx[3], o ? l[k].w : -1e10f);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool o = (on >> k) & 1u;
+        const float4 v = vp[(long)k * vq];
+        l[k] = float4{expf((o ? l[k].x : -1e10f) - mx[0]), expf((o ? l[k].y : -1e10f) - mx[1]), expf((o ? l[k].z : -1e10f) - mx[2]),
+                      expf((o ? l[k].w : -1e10f) - mx[3])};
+        den[0] += l[k].x; den[1] += l[k].y; den[2] += l[k].z; den[3] += l[k].w;
+        acc[0] += l[k].x * v.x; acc[1] += l[k].y * v.y; acc[2] += l[k].z * v.z; acc[3] += l[k].w * v.w;
+    }
+    const float4 g = reinterpret_cast<const float4 *>(a.grad_out + pt * a.C)[cq];
+    const float out[4] = {acc[0] / den[0], acc[1] / den[1], acc[2] / den[2], acc[3] / den[3]};
+    float4 *gv = reinterpret_cast<float4 *>(a.grad_values + pt * K * a.C) + cq, *gl = reinterpret_cast<float4 *>(a.grad_logits + pt * K * a.C) + cq;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool o = (on >> k) & 1u;
+        const float4 v = vp[(long)k * vq];
+        const float s0 = l[k].x / den[0], s1 = l[k].y / den[1], s2 = l[k].z / den[2], s3 = l[k].w / den[3];
+        gv[(long)k * q] = float4{s0 * g.x, s1 * g.y, s2 * g.z, s3 * g.w};
+        gl[(long)k * q] = float4{o ? s0 * (v.x - out[0]) * g.x : 0.0f, o ? s1 * (v.y - out[1]) * g.y : 0.0f,
+                                 o ? s2 * (v.z - out[2]) * g.z : 0.0f, o ? s3 * (v.w - out[3]) * g.w : 0.0f};
+    }
+}
+
 // ---------------------------------------------------------------- softmax_valid: out[b,c] = sum_n softmax_n(w | valid) f
 // block (64 channels, 4 waves over the points) per (channel group, batch element): pass 1 max, pass 2 sums, pass 3 gradients
 __global__ __launch_bounds__(ELO_BLOCK) void softmax_valid_bwd_kernel(const elo_softmax_valid_bwd_args a)
@@ -464,6 +568,18 @@ extern "C" int elo_masked_softmax_pool_backward(const elo_softmax_pool_bwd_args 
     ELO_REQUIRE(a->logits && a->values && a->mask && a->grad_out && a->grad_logits && a->grad_values, who, "null tensor pointer");
     const long n = (long)a->batch * a->npoints * a->C;
     if (n == 0) return ELO_OK;
+    if (a->C % 4 == 0 && a->values_stride % 4 == 0 && (a->K == 4 || a->K == 6 || a->K == 8 || a->K == 16 || a->K == 32) &&
+        (((uintptr_t)a->logits | (uintptr_t)a->values | (uintptr_t)a->grad_out | (uintptr_t)a->grad_logits | (uintptr_t)a->grad_values) & 15) == 0) {
+        const long items = n / 4;
+        const dim3 grid((unsigned)((items + ELO_BLOCK - 1) / ELO_BLOCK));
+        hipStream_t s = (hipStream_t)stream;
+        if (a->K == 4) hipLaunchKernelGGL(softmax_pool_bwd_vec_kernel<4>, grid, dim3(ELO_BLOCK), 0, s, *a, items);
+        else if (a->K == 6) hipLaunchKernelGGL(softmax_pool_bwd_vec_kernel<6>, grid, dim3(ELO_BLOCK), 0, s, *a, items);
+        else if (a->K == 8) hipLaunchKernelGGL(softmax_pool_bwd_vec_kernel<8>, grid, dim3(ELO_BLOCK), 0, s, *a, items);
+        else if (a->K == 16) hipLaunchKernelGGL(softmax_pool_bwd_vec2_kernel<16>, grid, dim3(ELO_BLOCK), 0, s, *a, items);
+        else hipLaunchKernelGGL(softmax_pool_bwd_vec2_kernel<32>, grid, dim3(ELO_BLOCK), 0, s, *a, items);
+        return check_launch(who);
+    }
     hipLaunchKernelGGL(softmax_pool_bwd_kernel, dim3(grid_for(n)), dim3(ELO_BLOCK), 0, (hipStream_t)stream, *a);
     return check_launch(who);
 }
